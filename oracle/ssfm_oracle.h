@@ -1,0 +1,93 @@
+/* ORACLE (test infrastructure only) -- C API of the CPU restatement.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (spherical_sfm_amd/) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for any function on
+ * this path (finding F7) and its un-vendored dependencies (Ceres 2.2.0, Eigen 3.4)
+ * are absent here, so the reference cannot be run.  The oracle is anchored on the reference's
+ * call sites (cited per function) and on oracle-free known-answer tests (tests/test_oracle_*.py).
+ */
+#ifndef SSFM_ORACLE_H
+#define SSFM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t num_cameras;
+    int32_t num_points;
+    int64_t num_observations;
+    double* cameras;           /* [num_cameras*6] = [t;r] per camera (sfm.cpp:104-105), in/out */
+    double* points;            /* [num_points*3], in/out */
+    double* focal;             /* shared focal (sfm.cpp:220), in/out */
+    const double* obs_xy;      /* [M*2] principal-point-centred pixels */
+    const int32_t* obs_cam;    /* [M] */
+    const int32_t* obs_pt;     /* [M] */
+    const uint8_t* rot_fixed;  /* [num_cameras] or NULL */
+    const uint8_t* trans_fixed;/* [num_cameras] or NULL */
+    const uint8_t* pt_fixed;   /* [num_points] or NULL */
+    int32_t focal_fixed;
+} oracle_ba_problem;
+
+typedef struct {
+    int32_t max_num_iterations;                 /* sfm.cpp:205 -> 2000 */
+    int32_t max_num_consecutive_invalid_steps;  /* sfm.cpp:206 -> 100 */
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+    double min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
+    int32_t loss_type;        /* 0 trivial, 1 Cauchy, 2 SoftLOne */
+    double loss_scale;        /* 'a' of the loss */
+    int32_t jacobi_scaling;
+    int32_t num_threads;      /* sfm.cpp:209 -> 16; clamped to hardware */
+    int32_t verbose;
+} oracle_lm_options;
+
+typedef struct {
+    int32_t termination;      /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE, 3 nothing to do */
+    int32_t iterations;
+    int32_t num_successful_steps, num_unsuccessful_steps, num_linear_solves;
+    double initial_cost, final_cost;
+    int64_t num_residual_blocks;   /* observations that entered the problem */
+    int32_t num_points_used;
+    int32_t threads_used;
+    double t_total_s, t_flatten_s, t_linearize_s, t_schur_s, t_cholesky_s, t_cost_s;
+} oracle_summary;
+
+void oracle_ba_default_options(oracle_lm_options* o);   /* values of sfm.cpp:194-212 + Ceres 2.2.0 defaults */
+int oracle_ba_solve(oracle_ba_problem* p, const oracle_lm_options* o, oracle_summary* s);
+
+/* one evaluation at the given state: cost, per-observation residuals [M*2] (robustified),
+ * and Jacobian blocks per observation [M*2*10] (columns: focal, t(3), r(3), X(3); unrobustified
+ * raw autodiff Jacobian when raw!=0).  Observations of unused points get zeros.  Outputs may be NULL. */
+int oracle_ba_evaluate(const oracle_ba_problem* p, const oracle_lm_options* o, int32_t raw,
+                       double* cost, double* residuals, double* jacobians, uint8_t* obs_used);
+
+/* SO(3) helpers (reference src/so3.cpp); matrices column-major */
+void oracle_so3exp(const double r[3], double R[9]);
+void oracle_so3ln(const double R[9], double r[3]);
+/* Ceres rotation.h restatements */
+void oracle_angle_axis_rotate_point(const double aa[3], const double pt[3], double out[3]);
+void oracle_angle_axis_to_rotation_matrix(const double aa[3], double R[9]);
+void oracle_rotation_matrix_to_angle_axis(const double R[9], double aa[3]);
+
+/* rotation averaging / pose graph (reference src/rotation_averaging.cpp:44-91,
+ * src/uncalibrated_pose_graph.cpp:116-203).  rotations: [n*9] column-major in/out. */
+double oracle_optimize_rotations(int32_t n, double* rotations, int32_t num_edges, const int32_t* index0,
+                                 const int32_t* index1, const double* rel_rotations, oracle_summary* s);
+double oracle_get_cost(int32_t n, const double* rotations, int32_t num_edges, const int32_t* index0,
+                       const int32_t* index1, const double* rel_rotations);
+double oracle_optimize_rotations_and_focal_length(int32_t n, double* rotations, int32_t num_edges,
+                                                  const int32_t* index0, const int32_t* index1,
+                                                  const double* rel_rotations, double* focal_length,
+                                                  double min_focal, double max_focal, oracle_summary* s);
+/* residual + 3x6 (or 3x7 with focal) Jacobian of one edge, for kernel parity tests.
+ * kind: 0 RotationError (meas = R), 1 PoseGraphError, 2 UncalibratedPoseGraphError */
+void oracle_rotation_edge(int32_t kind, const double r0[3], const double r1[3], double f,
+                          const double Rmeas[9], double scale, double res[3], double jac[21]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

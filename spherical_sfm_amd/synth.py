@@ -1,0 +1,135 @@
+"""Synthetic "circle" problems.
+
+The reference has no problem generator for the BA path (`examples/make_circle_views.cpp` is an
+image-based view synthesiser), so the workload is defined here.  Geometry follows the
+reference's own conventions:
+
+* cameras on the unit sphere looking outward, `t = (0,0,-1)`, `R_i = so3exp((0, 2*pi*i/Nc, 0))`
+  (`examples/spherical_sfm_tools.cpp:879-881`, `evaluation/problem_generator/problem_generator.cpp:27`);
+* observations are principal-point-centred pixels (`examples/spherical_sfm_tools.cpp:907-908`);
+* depth range as `problem_generator.cpp:45-46` (outward: 4..8).
+
+Everything is float64 / int32 numpy; deterministic for a given seed (numpy PCG64).
+"""
+from dataclasses import dataclass
+import numpy as np
+
+
+def so3exp(r):
+    """Rodrigues, reference src/so3.cpp:16-23.  r: (...,3) -> (...,3,3)."""
+    r = np.asarray(r, dtype=np.float64)
+    th = np.linalg.norm(r, axis=-1)[..., None, None]
+    safe = np.where(th < 1e-10, 1.0, th)
+    k = r[..., None, :] / safe  # (...,1,3)
+    K = np.zeros(r.shape[:-1] + (3, 3))
+    K[..., 0, 1] = -k[..., 0, 2]; K[..., 0, 2] = k[..., 0, 1]
+    K[..., 1, 0] = k[..., 0, 2]; K[..., 1, 2] = -k[..., 0, 0]
+    K[..., 2, 0] = -k[..., 0, 1]; K[..., 2, 1] = k[..., 0, 0]
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+    return np.where(th < 1e-10, np.eye(3), R)
+
+
+@dataclass
+class BAProblem:
+    cameras: np.ndarray      # (Nc,6) [t;r]  initial state
+    points: np.ndarray       # (Np,3)        initial state
+    focal: float             # initial focal
+    obs_xy: np.ndarray       # (M,2)
+    obs_cam: np.ndarray      # (M,) int32
+    obs_pt: np.ndarray       # (M,) int32
+    rot_fixed: np.ndarray    # (Nc,) uint8
+    trans_fixed: np.ndarray  # (Nc,) uint8
+    pt_fixed: np.ndarray     # (Np,) uint8
+    focal_fixed: bool
+    gt_cameras: np.ndarray
+    gt_points: np.ndarray
+    gt_focal: float
+
+    def copy(self):
+        return BAProblem(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self.__dict__.items()})
+
+
+def make_circle(num_cameras=60, num_points=20000, obs_per_point=6, *, spherical=True, focal_fixed=True,
+                seed=1234, focal=1000.0, pixel_noise=0.5, rot_noise_deg=0.5, point_noise=0.01,
+                focal_init_factor=1.1, trans_noise=0.0, check_in_frame=True, xy_range=None):
+    """Outward-facing circle.  M = obs_per_point * num_points exactly.
+
+    spherical=True  -> every translation fixed (examples/spherical_sfm_tools.cpp:883), camera 0 rotation fixed.
+    spherical=False -> only camera 0 fixed (general BA, run_spherical_sfm_uncalib.cpp:197-201).
+    """
+    Nc, Np, K = int(num_cameras), int(num_points), int(obs_per_point)
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * np.arange(Nc) / Nc
+    r_gt = np.stack([np.zeros(Nc), ang, np.zeros(Nc)], axis=1)
+    # keep angle-axis in (-pi, pi] so that so3ln round trips are unambiguous
+    r_gt[:, 1] = np.where(r_gt[:, 1] > np.pi, r_gt[:, 1] - 2 * np.pi, r_gt[:, 1])
+    t_gt = np.tile(np.array([0.0, 0.0, -1.0]), (Nc, 1))
+    R = so3exp(r_gt)                                      # (Nc,3,3)
+    anchor = (np.arange(Np, dtype=np.int64) * Nc // Np).astype(np.int64)
+    stride = max(1, int(round(Nc / (15.0 * (K - 1))))) if K > 1 else 1
+    span_deg = (K - 1) * stride * 360.0 / Nc
+    if xy_range is None:                                   # SURVEY 8d quotes 0.45 for the ~24 degree span of Nc >= 75
+        xy_range = 0.45 if span_deg <= 24.5 else 0.30      # small rings (config 1: 30 degrees) need a narrower anchor window
+    xy = rng.uniform(-xy_range, xy_range, size=(Np, 2))
+    depth = rng.uniform(4.0, 8.0, size=Np)
+    pc = np.concatenate([xy, np.ones((Np, 1))], axis=1) * depth[:, None]
+    X = np.einsum('nji,nj->ni', R[anchor], pc - t_gt[anchor])   # R_a^T (p - t)
+    offs = stride * (np.arange(K) - K // 2)
+    cam = (anchor[:, None] + offs[None, :]) % Nc                # (Np,K)
+    cam = np.sort(cam, axis=1)                                  # point-major, camera ascending (std::map order)
+    Xc = np.einsum('nkij,nj->nki', R[cam], X) + t_gt[cam]
+    assert (Xc[..., 2] > 0.5).all(), "generator: a point fell behind a camera"
+    proj = focal * Xc[..., :2] / Xc[..., 2:3]
+    if check_in_frame:
+        assert (np.abs(proj[..., 0]) < 960).all() and (np.abs(proj[..., 1]) < 540).all(), "projection outside 1920x1080"
+    obs = proj + rng.normal(0.0, pixel_noise, size=proj.shape)
+    cams0 = np.concatenate([t_gt, r_gt], axis=1).copy()
+    noise_r = rng.normal(0.0, np.deg2rad(rot_noise_deg), size=(Nc, 3)); noise_r[0] = 0
+    cams0[:, 3:] += noise_r
+    if not spherical and trans_noise > 0:
+        nt = rng.normal(0.0, trans_noise, size=(Nc, 3)); nt[0] = 0
+        cams0[:, :3] += nt
+    pts0 = X * (1.0 + rng.normal(0.0, point_noise, size=(Np, 1)))
+    rot_fixed = np.zeros(Nc, np.uint8); rot_fixed[0] = 1
+    trans_fixed = np.ones(Nc, np.uint8) if spherical else np.zeros(Nc, np.uint8)
+    trans_fixed[0] = 1
+    return BAProblem(cameras=cams0, points=pts0, focal=float(focal if focal_fixed else focal * focal_init_factor),
+                     obs_xy=np.ascontiguousarray(obs.reshape(-1, 2)),
+                     obs_cam=np.ascontiguousarray(cam.reshape(-1).astype(np.int32)),
+                     obs_pt=np.repeat(np.arange(Np, dtype=np.int32), K),
+                     rot_fixed=rot_fixed, trans_fixed=trans_fixed, pt_fixed=np.zeros(Np, np.uint8),
+                     focal_fixed=bool(focal_fixed), gt_cameras=np.concatenate([t_gt, r_gt], axis=1), gt_points=X,
+                     gt_focal=float(focal))
+
+
+def make_rotation_graph(num_cameras=300, max_offset=8, *, seed=1234, noise_deg=0.2, outlier_frac=0.02):
+    """Pose graph of SURVEY.md 8d: edges (i, i+d mod Nc), d=1..max_offset, R_rel = R_j R_i^T with noise,
+    a fraction of gross outliers.  Returns (R_init (Nc,3,3), index0, index1, R_rel (E,3,3), R_gt)."""
+    Nc = int(num_cameras)
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * np.arange(Nc) / Nc
+    r_gt = np.stack([np.zeros(Nc), ang, np.zeros(Nc)], axis=1)
+    r_gt[:, 1] = np.where(r_gt[:, 1] > np.pi, r_gt[:, 1] - 2 * np.pi, r_gt[:, 1])
+    R_gt = so3exp(r_gt)
+    i0 = np.repeat(np.arange(Nc), max_offset)
+    i1 = (i0 + np.tile(np.arange(1, max_offset + 1), Nc)) % Nc
+    keep = i0 != i1
+    i0, i1 = i0[keep], i1[keep]
+    E = len(i0)
+    noise = so3exp(rng.normal(0.0, np.deg2rad(noise_deg), size=(E, 3)))
+    R_rel = noise @ R_gt[i1] @ np.transpose(R_gt[i0], (0, 2, 1))
+    n_out = int(round(outlier_frac * E))
+    if n_out:
+        which = rng.choice(E, n_out, replace=False)
+        axis = rng.normal(size=(n_out, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        R_rel[which] = so3exp(axis * rng.uniform(0.5, 2.5, size=(n_out, 1)))
+    # sequential initialisation as initialize_rotations_sequential (examples/spherical_sfm_tools.cpp:794-813)
+    R_init = np.tile(np.eye(3), (Nc, 1, 1))
+    first = {(int(a), int(b)): k for k, (a, b) in reversed(list(enumerate(zip(i0, i1))))}
+    Rc = np.eye(3)
+    for idx in range(1, Nc):
+        k = first.get((idx - 1, idx))
+        if k is not None:
+            Rc = R_rel[k] @ Rc
+            R_init[idx] = Rc
+    return R_init, i0.astype(np.int32), i1.astype(np.int32), R_rel, R_gt
