@@ -1,0 +1,122 @@
+/* ssfm.h -- C ABI of the MI355X-native spherical-sfm optimisation core (libssfm_hip.so).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every entry point names the reference
+ * interface (file:line under jonathanventura/spherical-sfm) that it replaces.  Matrices crossing this
+ * boundary are COLUMN-MAJOR 3x3 (Eigen's default; the reference hands `Matrix3d::data()` to Ceres at
+ * src/rotation_averaging.cpp:28-29), cameras are 6 doubles [t;r] (include/sphericalsfm/sfm_types.h:9,
+ * src/sfm.cpp:104-105), points 3 doubles, observations principal-point-centred pixels
+ * (examples/spherical_sfm_tools.cpp:907-908).
+ *
+ * Return value: 0 = ok, <0 = error (ssfm_last_error gives the text).  No exceptions cross the ABI.
+ * A context is bound to one GPU and one HIP stream and is not thread-safe (one per host thread / rank).
+ */
+#ifndef SSFM_H
+#define SSFM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSFM_OK 0
+#define SSFM_ERR_INVALID -1
+#define SSFM_ERR_HIP -2
+#define SSFM_ERR_NO_DEVICE -3
+#define SSFM_ERR_COMM -4
+
+/* termination_type of ceres::Solver::Summary as the reference reads it (src/sfm.cpp:278-289) */
+#define SSFM_CONVERGENCE 0
+#define SSFM_NO_CONVERGENCE 1
+#define SSFM_FAILURE 2
+#define SSFM_NOTHING_TO_DO 3 /* src/sfm.cpp:230,265-268: Optimize() returns false before solving */
+
+typedef struct ssfm_ctx ssfm_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* device < 0: current device.  stream: a hipStream_t passed as void*, NULL = context-owned stream. */
+int ssfm_ctx_create(int32_t device, void* stream, ssfm_ctx** out);
+void ssfm_ctx_destroy(ssfm_ctx* ctx);
+const char* ssfm_last_error(const ssfm_ctx* ctx); /* ctx may be NULL: last creation error */
+int ssfm_version(void);
+
+/* Multi-GPU (one process per GPU; RCCL over xGMI).  Rank 0 obtains an id, the host side broadcasts the
+ * 128 bytes with whatever it has (torch.distributed in bench.py), every rank calls ssfm_comm_init. */
+int ssfm_comm_unique_id(uint8_t id[128]);
+int ssfm_comm_init(ssfm_ctx* ctx, const uint8_t id[128], int32_t nranks, int32_t rank);
+
+/* ---- bundle adjustment: replaces the body of sphericalsfm::SfM::Optimize (src/sfm.cpp:228-290) --- */
+typedef struct {
+    int32_t num_cameras;
+    int32_t num_points;
+    int64_t num_observations;
+    double* cameras;            /* [num_cameras*6] [t;r], in/out  (GetCameraPtr, src/sfm.cpp:89-92) */
+    double* points;             /* [num_points*3], in/out         (GetPointPtr,  src/sfm.cpp:94-97) */
+    double* focal;              /* &intrinsics.focal, in/out      (src/sfm.cpp:220) */
+    const double* obs_xy;       /* [M*2] */
+    const int32_t* obs_cam;     /* [M] */
+    const int32_t* obs_pt;      /* [M] */
+    const uint8_t* rot_fixed;   /* [num_cameras] rotationFixed, NULL = all free     (src/sfm.cpp:224) */
+    const uint8_t* trans_fixed; /* [num_cameras] translationFixed, NULL = all free  (src/sfm.cpp:223) */
+    const uint8_t* pt_fixed;    /* [num_points] pointFixed, NULL = all free         (src/sfm.cpp:225) */
+    int32_t focal_fixed;        /* focalFixed                                        (src/sfm.cpp:222) */
+} ssfm_ba_problem;
+
+typedef struct {
+    /* ConfigureSolverOptions / PreOptimize values (src/sfm.cpp:194-212), rest Ceres 2.2.0 defaults */
+    int32_t max_num_iterations;                /* 2000 */
+    int32_t max_num_consecutive_invalid_steps; /* 100 */
+    double function_tolerance;                 /* 1e-6 */
+    double gradient_tolerance;                 /* 1e-10 */
+    double parameter_tolerance;                /* 1e-8 */
+    double initial_trust_region_radius;        /* 1e4 */
+    double max_trust_region_radius;            /* 1e16 */
+    double min_trust_region_radius;            /* 1e-32 */
+    double min_lm_diagonal, max_lm_diagonal;   /* 1e-6, 1e32 */
+    double min_relative_decrease;              /* 1e-3 */
+    int32_t loss_type;                         /* 0 trivial, 1 Cauchy, 2 SoftLOne; default 1 */
+    double loss_scale;                         /* 1.0 */
+    int32_t jacobi_scaling;                    /* 1 */
+    /* reduced-camera-system solver (the reference uses a direct sparse Cholesky; this build uses PCG) */
+    int32_t pcg_max_iterations;                /* 1000 */
+    double pcg_tolerance;                      /* |r| <= tol |b|, default 1e-12 (parity with a direct solve) */
+    int32_t verbose;                           /* 1: one line per LM iteration (minimizer_progress_to_stdout) */
+} ssfm_ba_options;
+
+typedef struct {
+    int32_t termination;          /* SSFM_CONVERGENCE ... */
+    int32_t iterations;
+    int32_t num_successful_steps, num_unsuccessful_steps;
+    int32_t num_linearizations;   /* n_LM of SURVEY 8d: every assemble+solve, accepted or rejected */
+    int32_t pcg_iterations_total;
+    double initial_cost, final_cost;
+    int64_t num_residual_blocks;  /* observations that entered the problem (this rank) */
+    int64_t num_residual_blocks_global;
+    int32_t num_points_used;
+    int32_t camera_dof;           /* 3 = spherical (all translations fixed), 6 = general */
+    double t_flatten_s, t_upload_s, t_solve_s, t_download_s;   /* host wall-clock */
+    double t_kernel_linearize_ms, t_kernel_schur_ms, t_kernel_pcg_ms, t_kernel_update_ms; /* hipEvent sums */
+} ssfm_ba_summary;
+
+void ssfm_ba_default_options(ssfm_ba_options* o);
+
+/* One call = flatten (src/sfm.cpp:240-263 rules) + upload + device LM loop + scatter back. */
+int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s);
+
+/* Staged form: problem stays resident in HBM between runs (bench.py, multi-GPU sharding). */
+typedef struct ssfm_ba_handle ssfm_ba_handle;
+int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_handle** out);
+int ssfm_ba_reset(ssfm_ba_handle* h);                          /* restore the uploaded initial parameters */
+int ssfm_ba_run(ssfm_ba_handle* h, ssfm_ba_summary* s);        /* device LM loop only */
+int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p);   /* scatter parameters back */
+void ssfm_ba_destroy(ssfm_ba_handle* h);
+/* one evaluation at the uploaded state, for kernel parity tests: cost, residuals [M*2] (robustified),
+ * jacobians [M*2*10] (focal | t | r | X, robustified, unscaled); entries of unused observations are 0. */
+int ssfm_ba_evaluate(ssfm_ba_handle* h, double* cost, double* residuals, double* jacobians);
+/* on != 0: bracket every kernel launch of ssfm_ba_run with hipEvents (slower; for bench.py's profile leg) */
+int ssfm_ba_set_profiling(ssfm_ba_handle* h, int32_t on);
+/* per-kernel timing of the last run: name -> (launches, total ms); returns number of entries written */
+int ssfm_ba_kernel_times(ssfm_ba_handle* h, int32_t max_entries, char names[][32], int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

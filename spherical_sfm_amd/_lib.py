@@ -1,0 +1,95 @@
+"""ctypes binding of libssfm_hip.so (the C ABI declared in include/ssfm.h).
+
+There is no CPU fallback: if the HIP library is missing, or no GPU is visible when a context is created,
+this raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssfm_hip.so")
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class BAProblemC(C.Structure):
+    _fields_ = [("num_cameras", C.c_int32), ("num_points", C.c_int32), ("num_observations", C.c_int64),
+                ("cameras", c_double_p), ("points", c_double_p), ("focal", c_double_p),
+                ("obs_xy", c_double_p), ("obs_cam", c_i32_p), ("obs_pt", c_i32_p),
+                ("rot_fixed", c_u8_p), ("trans_fixed", c_u8_p), ("pt_fixed", c_u8_p), ("focal_fixed", C.c_int32)]
+
+
+class BAOptionsC(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("max_num_consecutive_invalid_steps", C.c_int32),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("min_relative_decrease", C.c_double), ("loss_type", C.c_int32), ("loss_scale", C.c_double),
+                ("jacobi_scaling", C.c_int32), ("pcg_max_iterations", C.c_int32), ("pcg_tolerance", C.c_double),
+                ("verbose", C.c_int32)]
+
+
+class BASummaryC(C.Structure):
+    _fields_ = [("termination", C.c_int32), ("iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("num_unsuccessful_steps", C.c_int32), ("num_linearizations", C.c_int32), ("pcg_iterations_total", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_residual_blocks", C.c_int64),
+                ("num_residual_blocks_global", C.c_int64), ("num_points_used", C.c_int32), ("camera_dof", C.c_int32),
+                ("t_flatten_s", C.c_double), ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double),
+                ("t_kernel_linearize_ms", C.c_double), ("t_kernel_schur_ms", C.c_double), ("t_kernel_pcg_ms", C.c_double),
+                ("t_kernel_update_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/ssfm.h declares (tests check that the library exports all of them)
+DECLARED_SYMBOLS = [
+    "ssfm_ctx_create", "ssfm_ctx_destroy", "ssfm_last_error", "ssfm_version", "ssfm_comm_unique_id", "ssfm_comm_init",
+    "ssfm_ba_default_options", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
+    "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
+]
+
+
+class SsfmError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libssfm_hip.so.  Importing torch first makes the process share torch's HIP runtime
+    (same SONAME libamdhip64.so.7), which is what bench.py relies on for streams / torch.distributed."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SsfmError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(make -C spherical_sfm_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    L.ssfm_ctx_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]; L.ssfm_ctx_create.restype = C.c_int
+    L.ssfm_ctx_destroy.argtypes = [vp]; L.ssfm_ctx_destroy.restype = None
+    L.ssfm_last_error.argtypes = [vp]; L.ssfm_last_error.restype = C.c_char_p
+    L.ssfm_version.restype = C.c_int
+    L.ssfm_comm_unique_id.argtypes = [c_u8_p]; L.ssfm_comm_unique_id.restype = C.c_int
+    L.ssfm_comm_init.argtypes = [vp, c_u8_p, C.c_int32, C.c_int32]; L.ssfm_comm_init.restype = C.c_int
+    L.ssfm_ba_default_options.argtypes = [C.POINTER(BAOptionsC)]; L.ssfm_ba_default_options.restype = None
+    L.ssfm_ba_solve.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]; L.ssfm_ba_solve.restype = C.c_int
+    L.ssfm_ba_create.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAOptionsC), C.POINTER(vp)]; L.ssfm_ba_create.restype = C.c_int
+    L.ssfm_ba_reset.argtypes = [vp]; L.ssfm_ba_reset.restype = C.c_int
+    L.ssfm_ba_run.argtypes = [vp, C.POINTER(BASummaryC)]; L.ssfm_ba_run.restype = C.c_int
+    L.ssfm_ba_download.argtypes = [vp, C.POINTER(BAProblemC)]; L.ssfm_ba_download.restype = C.c_int
+    L.ssfm_ba_destroy.argtypes = [vp]; L.ssfm_ba_destroy.restype = None
+    L.ssfm_ba_evaluate.argtypes = [vp, c_double_p, c_double_p, c_double_p]; L.ssfm_ba_evaluate.restype = C.c_int
+    L.ssfm_ba_set_profiling.argtypes = [vp, C.c_int32]; L.ssfm_ba_set_profiling.restype = C.c_int
+    L.ssfm_ba_kernel_times.argtypes = [vp, C.c_int32, C.c_void_p, c_i64_p, c_double_p]; L.ssfm_ba_kernel_times.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().ssfm_last_error(ctx)
+        raise SsfmError(f"ssfm error {rc}: {msg.decode() if msg else '?'}")

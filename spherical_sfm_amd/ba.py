@@ -1,0 +1,128 @@
+"""Python host side of the bundle-adjustment path: thin objects over the C ABI (include/ssfm.h).
+
+`Context` = one GPU + one HIP stream (+ optional RCCL communicator); `BundleAdjuster` keeps a flattened
+problem resident in HBM (ssfm_ba_create / reset / run / download).  `optimize()` is the one-call form that
+the C++ `sphericalsfm::SfM::Optimize` shim uses (ssfm_ba_solve).
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import BAProblemC, BAOptionsC, BASummaryC, c_double_p, c_i32_p, c_u8_p, c_i64_p
+
+TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "NOTHING_TO_DO"}
+
+
+def default_options(**kw):
+    o = BAOptionsC()
+    _lib.lib().ssfm_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    def __init__(self, device=-1, stream=None):
+        self._p = C.c_void_p()
+        L = _lib.lib()
+        rc = L.ssfm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._p))
+        if rc != 0:
+            raise _lib.SsfmError(f"ssfm_ctx_create failed ({rc}): {L.ssfm_last_error(None).decode()}")
+        self.nranks, self.rank = 1, 0
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().ssfm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, nranks: int, rank: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _lib.check(_lib.lib().ssfm_comm_init(self._p, buf, nranks, rank), self._p)
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if self._p:
+            _lib.lib().ssfm_ctx_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _ProblemBuffers:
+    """Owns contiguous numpy copies of a BAProblem-like object and the C struct pointing at them."""
+    def __init__(self, prob):
+        self.cams = np.ascontiguousarray(prob.cameras, np.float64).copy()
+        self.pts = np.ascontiguousarray(prob.points, np.float64).copy()
+        self.focal = np.array([prob.focal], np.float64)
+        self.xy = np.ascontiguousarray(prob.obs_xy, np.float64)
+        self.oc = np.ascontiguousarray(prob.obs_cam, np.int32)
+        self.op = np.ascontiguousarray(prob.obs_pt, np.int32)
+        self.rf = np.ascontiguousarray(prob.rot_fixed, np.uint8)
+        self.tf = np.ascontiguousarray(prob.trans_fixed, np.uint8)
+        self.pf = np.ascontiguousarray(prob.pt_fixed, np.uint8)
+        p = lambda a, t: a.ctypes.data_as(t)
+        self.c = BAProblemC(len(self.cams), len(self.pts), len(self.oc), p(self.cams, c_double_p), p(self.pts, c_double_p),
+                            p(self.focal, c_double_p), p(self.xy, c_double_p), p(self.oc, c_i32_p), p(self.op, c_i32_p),
+                            p(self.rf, c_u8_p), p(self.tf, c_u8_p), p(self.pf, c_u8_p), 1 if prob.focal_fixed else 0)
+
+
+def optimize(ctx, prob, options=None, **kw):
+    """One call: flatten + upload + device LM + scatter back.  Returns (cameras, points, focal, summary)."""
+    b = _ProblemBuffers(prob)
+    o = options or default_options(**kw)
+    s = BASummaryC()
+    _lib.check(_lib.lib().ssfm_ba_solve(ctx._p, C.byref(b.c), C.byref(o), C.byref(s)), ctx._p)
+    return b.cams, b.pts, float(b.focal[0]), s.as_dict()
+
+
+class BundleAdjuster:
+    def __init__(self, ctx, prob, options=None, **kw):
+        self.ctx = ctx
+        self.buf = _ProblemBuffers(prob)
+        self.opt = options or default_options(**kw)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ssfm_ba_create(ctx._p, C.byref(self.buf.c), C.byref(self.opt), C.byref(self._h)), ctx._p)
+
+    def reset(self):
+        _lib.check(_lib.lib().ssfm_ba_reset(self._h), self.ctx._p)
+
+    def run(self):
+        s = BASummaryC()
+        _lib.check(_lib.lib().ssfm_ba_run(self._h, C.byref(s)), self.ctx._p)
+        return s.as_dict()
+
+    def download(self):
+        _lib.check(_lib.lib().ssfm_ba_download(self._h, C.byref(self.buf.c)), self.ctx._p)
+        return self.buf.cams, self.buf.pts, float(self.buf.focal[0])
+
+    def evaluate(self):
+        M = len(self.buf.oc)
+        cost = C.c_double(0); res = np.zeros((M, 2)); jac = np.zeros((M, 2, 10))
+        _lib.check(_lib.lib().ssfm_ba_evaluate(self._h, C.byref(cost), res.ctypes.data_as(c_double_p), jac.ctypes.data_as(c_double_p)), self.ctx._p)
+        return cost.value, res, jac
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.lib().ssfm_ba_set_profiling(self._h, 1 if on else 0), self.ctx._p)
+
+    def kernel_times(self):
+        n = 32
+        names = ((C.c_char * 32) * n)(); launches = (C.c_int64 * n)(); ms = (C.c_double * n)()
+        k = _lib.lib().ssfm_ba_kernel_times(self._h, n, C.cast(names, C.c_void_p), C.cast(launches, c_i64_p), C.cast(ms, c_double_p))
+        return {names[i].value.decode(): {"launches": int(launches[i]), "total_ms": float(ms[i])} for i in range(k)}
+
+    def close(self):
+        if self._h:
+            _lib.lib().ssfm_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,149 @@
+// spherical_sfm_amd -- host-side flattening of a bundle-adjustment problem.
+//
+// Reproduces what the build loop of SfM::Optimize (reference src/sfm.cpp:240-263) decides:
+//   * a point enters iff it exists, |X| != 0 and it has >= 3 observations over existing cameras;
+//   * then ALL its observations enter, point-major, cameras ascending (std::map iteration order);
+//   * a repeated (camera, point) key keeps the last value (map assignment, src/sfm.cpp:140);
+//   * constant blocks (src/sfm.cpp:222-225) leave the program; cameras without observations are not in it.
+// The reference does this with O(Np*Nc) nested std::map lookups per Optimize() call; here it is one sort
+// (skipped when the input is already point-major) plus linear passes.
+//
+// It also builds what the device kernels need once per problem: camera-major observation lists, the block
+// structure of the reduced camera system S (cameras sharing a point), and the point range owned by this
+// rank when the problem is sharded over GPUs (contiguous ranges of used points balanced by observations;
+// every rank keeps all cameras -- SURVEY.md 8e).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+#include "../../include/ssfm.h"
+
+namespace ssfm {
+
+struct BAFlat {
+    int Nc = 0;
+    int nP = 0;               // used points owned by this rank
+    int nP_global = 0;
+    int64_t M = 0, M_global = 0;
+    int DC = 6;               // 3: every translation fixed (spherical BA) -> only rotations vary
+    bool focal_free = false;
+    std::vector<int> pt_ids;            // [nP] original point id
+    std::vector<int> pt_start;          // [nP+1]
+    std::vector<int> obs_cam;           // [M]
+    std::vector<int> obs_pt;            // [M] compact local point
+    std::vector<int64_t> obs_orig;      // [M] index into the caller's arrays
+    std::vector<double> obs_xy;         // [2M]
+    std::vector<int> cam_start, cam_obs;   // camera-major lists over local observations
+    std::vector<int> row_ptr, col_idx, diag_slot;   // block-CSR structure of S (global), sorted columns
+    std::vector<double> mask_cam;       // [Nc*6] 1 = free parameter that is in the problem
+    std::vector<double> mask_pt;        // [nP*3]
+    std::vector<double> pts0;           // [nP*3]
+    int max_row_blocks = 0;
+    bool nothing_to_do = false;
+};
+
+inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
+    const int Nc = P.num_cameras, Np = P.num_points;
+    const int64_t M = P.num_observations;
+    F = BAFlat();
+    F.Nc = Nc; F.focal_free = !P.focal_fixed;
+    if (Nc == 0 || Np == 0 || M == 0) { F.nothing_to_do = true; return; }
+    // ---- order observations point-major / camera-ascending (skip the sort if they already are)
+    bool sorted = true;
+    for (int64_t i = 1; i < M && sorted; i++)
+        if (P.obs_pt[i] < P.obs_pt[i - 1] || (P.obs_pt[i] == P.obs_pt[i - 1] && P.obs_cam[i] <= P.obs_cam[i - 1])) sorted = false;
+    std::vector<int64_t> order;
+    if (!sorted) {
+        order.resize(M); std::iota(order.begin(), order.end(), (int64_t)0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            if (P.obs_pt[a] != P.obs_pt[b]) return P.obs_pt[a] < P.obs_pt[b];
+            return P.obs_cam[a] < P.obs_cam[b]; });
+    }
+    auto at = [&](int64_t i) { return sorted ? i : order[i]; };
+    // ---- pass 1: which points are used (global), with their observation counts
+    struct Seg { int pt; int64_t begin, end; int nobs; };
+    std::vector<Seg> segs; segs.reserve(Np);
+    for (int64_t i = 0; i < M;) {
+        const int p = P.obs_pt[at(i)];
+        int64_t e = i; int nobs = 0; int last_cam = -1;
+        while (e < M && P.obs_pt[at(e)] == p) { const int c = P.obs_cam[at(e)]; if (c != last_cam && c >= 0 && c < Nc) { nobs++; last_cam = c; } e++; }
+        bool valid = p >= 0 && p < Np && nobs >= 3;
+        if (valid) { const double* X = &P.points[(size_t)p * 3]; valid = (X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) != 0.0; }
+        if (valid) segs.push_back({p, i, e, nobs});
+        i = e;
+    }
+    F.nP_global = (int)segs.size();
+    for (const Seg& s : segs) F.M_global += s.nobs;
+    if (segs.empty()) { F.nothing_to_do = true; return; }
+    // ---- structure of S and camera activity come from ALL used points (identical on every rank)
+    std::vector<char> cam_in(Nc, 0);
+    {
+        std::vector<std::vector<int>> nb(Nc);
+        std::vector<int> cams;
+        for (const Seg& s : segs) {
+            cams.clear(); int last = -1;
+            for (int64_t i = s.begin; i < s.end; i++) { const int c = P.obs_cam[at(i)]; if (c != last && c >= 0 && c < Nc) { cams.push_back(c); last = c; } }
+            for (int a : cams) { cam_in[a] = 1; for (int b : cams) if (nb[a].empty() || nb[a].back() != b) nb[a].push_back(b); }
+        }
+        F.row_ptr.assign(Nc + 1, 0); F.diag_slot.assign(Nc, -1);
+        for (int c = 0; c < Nc; c++) {
+            auto& v = nb[c]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+            if (v.empty()) v.push_back(c);          // isolated camera: identity row
+            F.row_ptr[c + 1] = F.row_ptr[c] + (int)v.size();
+            F.max_row_blocks = std::max(F.max_row_blocks, (int)v.size());
+        }
+        F.col_idx.resize(F.row_ptr[Nc]);
+        for (int c = 0; c < Nc; c++) {
+            std::copy(nb[c].begin(), nb[c].end(), F.col_idx.begin() + F.row_ptr[c]);
+            F.diag_slot[c] = (int)(std::lower_bound(nb[c].begin(), nb[c].end(), c) - nb[c].begin());
+        }
+    }
+    F.mask_cam.assign((size_t)Nc * 6, 0.0);
+    bool all_t_fixed = true;
+    for (int c = 0; c < Nc; c++) {
+        if (!cam_in[c]) continue;
+        const bool tf = P.trans_fixed && P.trans_fixed[c], rf = P.rot_fixed && P.rot_fixed[c];
+        if (!tf) { all_t_fixed = false; for (int k = 0; k < 3; k++) F.mask_cam[c * 6 + k] = 1.0; }
+        if (!rf) for (int k = 0; k < 3; k++) F.mask_cam[c * 6 + 3 + k] = 1.0;
+    }
+    F.DC = all_t_fixed ? 3 : 6;
+    // ---- this rank's contiguous share of the used points, balanced by observation count
+    size_t s0 = 0, s1 = segs.size();
+    if (nranks > 1) {
+        const int64_t lo = F.M_global * rank / nranks, hi = F.M_global * (rank + 1) / nranks;
+        int64_t acc = 0; s0 = s1 = segs.size(); bool have0 = false;
+        for (size_t k = 0; k < segs.size(); k++) {
+            if (!have0 && acc >= lo) { s0 = k; have0 = true; }
+            if (acc >= hi) { s1 = k; break; }
+            acc += segs[k].nobs;
+        }
+        if (!have0) s0 = segs.size();
+        if (rank == nranks - 1) s1 = segs.size();
+    }
+    // ---- pass 2: emit local observations
+    F.nP = (int)(s1 - s0);
+    F.pt_ids.reserve(F.nP); F.pt_start.assign(1, 0); F.pts0.reserve((size_t)F.nP * 3); F.mask_pt.reserve((size_t)F.nP * 3);
+    for (size_t k = s0; k < s1; k++) {
+        const Seg& s = segs[k];
+        for (int64_t i = s.begin; i < s.end; i++) {
+            const int64_t o = at(i); const int c = P.obs_cam[o];
+            if (c < 0 || c >= Nc) continue;
+            if (i + 1 < s.end && P.obs_cam[at(i + 1)] == c) continue;     // keep the last duplicate
+            F.obs_cam.push_back(c); F.obs_pt.push_back((int)F.pt_ids.size()); F.obs_orig.push_back(o);
+            F.obs_xy.push_back(P.obs_xy[2 * o]); F.obs_xy.push_back(P.obs_xy[2 * o + 1]);
+        }
+        const double m = (P.pt_fixed && P.pt_fixed[s.pt]) ? 0.0 : 1.0;
+        for (int d = 0; d < 3; d++) { F.pts0.push_back(P.points[(size_t)s.pt * 3 + d]); F.mask_pt.push_back(m); }
+        F.pt_ids.push_back(s.pt); F.pt_start.push_back((int)F.obs_cam.size());
+    }
+    F.M = (int64_t)F.obs_cam.size();
+    F.cam_start.assign(Nc + 1, 0);
+    for (int64_t j = 0; j < F.M; j++) F.cam_start[F.obs_cam[j] + 1]++;
+    for (int c = 0; c < Nc; c++) F.cam_start[c + 1] += F.cam_start[c];
+    F.cam_obs.resize(F.M);
+    { std::vector<int> fill(F.cam_start.begin(), F.cam_start.end() - 1);
+      for (int64_t j = 0; j < F.M; j++) F.cam_obs[fill[F.obs_cam[j]]++] = (int)j; }
+}
+
+}  // namespace ssfm

@@ -1,0 +1,688 @@
+// spherical_sfm_amd -- HIP kernels of the bundle-adjustment hot path (gfx950 / CDNA4, wave64, fp64).
+//
+// What the reference does inside ceres::Solve for SfM::Optimize (src/sfm.cpp:273-276) per LM iteration
+//   evaluate residuals + Jacobians (Jets)  ->  loss corrector  ->  Jacobi scaling  ->
+//   Schur-eliminate point blocks  ->  solve reduced camera system  ->  back-substitute  ->  candidate cost
+// is laid out here as a handful of streaming passes.  Nothing stores a per-observation Jacobian: every pass
+// re-linearises the observation it touches from the (L2-resident) camera table and its point, which costs
+// ~150 fp64 flops and saves 176 B/observation of HBM traffic per pass.
+//
+// Data layout in HBM (all fp64 / int32):
+//   cam[Nc*6]  [t;r]               rot[Nc*27] per-camera R, Rd, M (ssfm_math.h angle_axis_derivative_aid)
+//   pts[nP*3]                      obs_xy[M] double2, obs_cam[M], obs_pt[M]  point-major, pt_start[nP+1]
+//   cam_start[Nc+1], cam_obs[M]    camera-major view of the same observations
+//   scale_cam[Nc*6], scale_pt[nP*3], scale_f   Jacobi column scales, 0 for parameters that are constant
+//   Vinv[nP*6], gp[nP*3], Wf[nP*3]             per-point (V + D^2)^-1 (sym), J_p^T r, focal coupling
+//   S_val[nnzb*DC*DC]              block-CSR reduced camera system (row_ptr/col_idx), rhs[Nc*DC+1]
+// DC = 3 when every translation is fixed (spherical BA: only r varies), 6 otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ssfm_math.h"
+
+namespace ssfm {
+
+// slots of the per-iteration scalar block (device doubles)
+enum {
+    SC_COST = 0,      // 1/2 sum rho at x                       (sharded by point)
+    SC_FJJ = 1,       // sum (s_f J_f)^2                        (sharded)
+    SC_FJR = 2,       // sum s_f J_f r                          (sharded)
+    SC_FWW = 3,       // sum_p Wf V^-1 Wf^T                     (sharded)
+    SC_FWG = 4,       // sum_p Wf V^-1 g_p                      (sharded)
+    SC_MODEL = 5,     // sum m (r + m/2)                        (sharded)
+    SC_STEP2_PT = 6,  // |delta|^2 over points                  (sharded)
+    SC_XN2_PT = 7,    // |candidate|^2 over points              (sharded)
+    SC_CAND_COST = 8, // 1/2 sum rho at candidate               (sharded)
+    SC_X0N2_PT = 9,   // |x|^2 over points (iteration 0)        (sharded)
+    SC_NSUM = 10,
+    SC_GMAX = 10,     // max |gradient| (uint64 bit pattern)    (max-reduced)
+    SC_STEP2_CAM = 11, SC_XN2_CAM = 12, SC_X0N2_CAM = 13,   // replicated camera/focal parts
+    SC_TOTAL = 16
+};
+enum { PCG_RZ = 0, PCG_BN2 = 1, PCG_RR = 2, PCG_DONE = 3, PCG_ITERS = 4, PCG_BREAKDOWN = 5, PCG_TOTAL = 8 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum of N values per thread; result valid in thread 0.  red: LDS scratch [N * (blockDim/64)]
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; i++) { v[i] = wave_sum(v[i]); if (lane == 0) red[i * nw + w] = v[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) { double s = 0; for (int k = 0; k < nw; k++) s += red[i * nw + k]; v[i] = s; }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// ---- one observation: robustified residual + Jacobian blocks (unscaled) ---------------------------
+// reference ReprojectionError (src/sfm.cpp:38-63) + Ceres corrector (rho'' <= 0 => sqrt(rho') scaling)
+struct ObsLin {
+    double r[2], Jf[2], Jt[2][3], Jr[2][3], Jp[2][3], half_rho;
+};
+__device__ __forceinline__ bool project(double f, const double* t, const double* R, const double* X, double ox, double oy,
+                                        double& xp, double& yp, double& iz, double& r0, double& r1) {
+    const double p0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+    const double p1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+    const double p2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+    iz = 1.0 / p2; xp = p0 * iz; yp = p1 * iz;
+    r0 = f * xp - ox; r1 = f * yp - oy;
+    return true;
+}
+__device__ __forceinline__ double obs_cost(double f, const double* t, const double* R, const double* X, double ox, double oy, int loss, double la) {
+    double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
+    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);
+    return 0.5 * rho0;
+}
+template <bool NEED_T>
+__device__ __forceinline__ void lin_obs(double f, const double* t, const double* rot, const double* X, double ox, double oy,
+                                        int loss, double la, ObsLin& L) {
+    const double* R = rot; const double* Rd = rot + 9; const double* Mm = rot + 18;
+    double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
+    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);
+    const double sr = sqrt(rho1);
+    L.half_rho = 0.5 * rho0;
+    L.r[0] = sr * r0; L.r[1] = sr * r1;
+    L.Jf[0] = sr * xp; L.Jf[1] = sr * yp;
+    const double a = sr * f * iz;
+    const double A0[3] = {a, 0.0, -a * xp}, A1[3] = {0.0, a, -a * yp};
+    if (NEED_T) { for (int k = 0; k < 3; k++) { L.Jt[0][k] = A0[k]; L.Jt[1][k] = A1[k]; } }
+    double B0[3], B1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        L.Jp[0][k] = A0[0] * R[k] + A0[2] * R[6 + k];
+        L.Jp[1][k] = A1[1] * R[3 + k] + A1[2] * R[6 + k];
+        B0[k] = A0[0] * Rd[k] + A0[2] * Rd[6 + k];
+        B1[k] = A1[1] * Rd[3 + k] + A1[2] * Rd[6 + k];
+    }
+    // Y = [X]x M  (column k = X x M[:,k]);  Jr = -(A Rd) Y
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double m0 = Mm[k], m1 = Mm[3 + k], m2 = Mm[6 + k];
+        const double y0 = X[1] * m2 - X[2] * m1, y1 = X[2] * m0 - X[0] * m2, y2 = X[0] * m1 - X[1] * m0;
+        L.Jr[0][k] = -(B0[0] * y0 + B0[1] * y1 + B0[2] * y2);
+        L.Jr[1][k] = -(B1[0] * y0 + B1[1] * y1 + B1[2] * y2);
+    }
+}
+// scaled camera block Jc[2][DC] of an observation (DC=6: [t r], DC=3: r only)
+template <int DC>
+__device__ __forceinline__ void cam_block(const ObsLin& L, const double* sc6, double (&Jc)[2][DC]) {
+    if (DC == 6) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Jc[0][k] = L.Jt[0][k] * sc6[k]; Jc[1][k] = L.Jt[1][k] * sc6[k];
+                                      Jc[0][3 + k] = L.Jr[0][k] * sc6[3 + k]; Jc[1][3 + k] = L.Jr[1][k] * sc6[3 + k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Jc[0][k] = L.Jr[0][k] * sc6[3 + k]; Jc[1][k] = L.Jr[1][k] * sc6[3 + k]; }
+    }
+}
+
+// ---- K0: per-camera rotation tables ----------------------------------------------------------------
+__global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ rot, int Nc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nc) return;
+    double aa[3] = {cam[c * 6 + 3], cam[c * 6 + 4], cam[c * 6 + 5]};
+    double R[9], Rd[9], M[9];
+    angle_axis_derivative_aid(aa, R, Rd, M);
+    for (int i = 0; i < 9; i++) { rot[c * 27 + i] = R[i]; rot[c * 27 + 9 + i] = Rd[i]; rot[c * 27 + 18 + i] = M[i]; }
+}
+
+// ---- one-time: squared column norms of the unscaled robustified Jacobian (Jacobi scaling, iteration 0)
+__global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+                          const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+                          const int* __restrict__ pt_start, int nP, int loss, double la,
+                          double* __restrict__ diag_cam, double* __restrict__ diag_pt, double* __restrict__ diag_f) {
+    __shared__ double red[8];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double df[1] = {0.0};
+    if (p < nP) {
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double f = focal[0];
+        double dp[3] = {0, 0, 0};
+        for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            ObsLin L; lin_obs<true>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+            for (int k = 0; k < 3; k++) {
+                dp[k] += L.Jp[0][k] * L.Jp[0][k] + L.Jp[1][k] * L.Jp[1][k];
+                unsafeAtomicAdd(&diag_cam[c * 6 + k], L.Jt[0][k] * L.Jt[0][k] + L.Jt[1][k] * L.Jt[1][k]);
+                unsafeAtomicAdd(&diag_cam[c * 6 + 3 + k], L.Jr[0][k] * L.Jr[0][k] + L.Jr[1][k] * L.Jr[1][k]);
+            }
+            df[0] += L.Jf[0] * L.Jf[0] + L.Jf[1] * L.Jf[1];
+        }
+        for (int k = 0; k < 3; k++) diag_pt[3 * p + k] = dp[k];
+    }
+    block_sum<1>(df, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(diag_f, df[0]);
+}
+__global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) scale[i] = mask[i] * (jacobi ? 1.0 / (1.0 + sqrt(diag[i])) : 1.0);
+}
+
+// ---- K1: point pass.  One lane per point: V = sum Jp^T Jp (+D^2), V^-1, g_p, focal coupling ----------
+// Ceres SchurEliminator "chunk" work for the e-block, with the LM diagonal D_p^2 = clamp(diag V)/radius.
+__global__ void __launch_bounds__(256)
+k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+            const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+            const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
+            int loss, double la, double radius, double min_diag, double max_diag,
+            double* __restrict__ Vinv, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal) {
+    __shared__ double red[5 * 4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};   // cost, FJJ, FJR, FWW, FWG
+    double gmax = 0.0;
+    if (p < nP) {
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+        const double f = focal[0], sf = scale_f[0];
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, wf[3] = {0, 0, 0};
+        for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            ObsLin L; lin_obs<false>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+            acc[0] += L.half_rho;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const double j0 = L.Jp[a][0] * sp[0], j1 = L.Jp[a][1] * sp[1], j2 = L.Jp[a][2] * sp[2], jf = L.Jf[a] * sf;
+                V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
+                g[0] += j0 * L.r[a]; g[1] += j1 * L.r[a]; g[2] += j2 * L.r[a];
+                wf[0] += jf * j0; wf[1] += jf * j1; wf[2] += jf * j2;
+                acc[1] += jf * jf; acc[2] += jf * L.r[a];
+            }
+        }
+        if (sp[0] > 0.0) {
+            gmax = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
+            V[0] += fmin(fmax(V[0], min_diag), max_diag) / radius;
+            V[3] += fmin(fmax(V[3], min_diag), max_diag) / radius;
+            V[5] += fmin(fmax(V[5], min_diag), max_diag) / radius;
+        } else { V[0] = V[3] = V[5] = 1.0; }   // constant point: identity block, zero coupling
+        double Vi[6]; sym3_inverse(V, Vi);
+        const double u0 = wf[0] * Vi[0] + wf[1] * Vi[1] + wf[2] * Vi[2];
+        const double u1 = wf[0] * Vi[1] + wf[1] * Vi[3] + wf[2] * Vi[4];
+        const double u2 = wf[0] * Vi[2] + wf[1] * Vi[4] + wf[2] * Vi[5];
+        acc[3] = u0 * wf[0] + u1 * wf[1] + u2 * wf[2];
+        acc[4] = u0 * g[0] + u1 * g[1] + u2 * g[2];
+        for (int k = 0; k < 6; k++) Vinv[6 * p + k] = Vi[k];
+        for (int k = 0; k < 3; k++) { gp[3 * p + k] = g[k]; Wf[3 * p + k] = wf[k]; }
+    }
+    block_sum<5>(acc, red);
+    gmax = wave_max(gmax);
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&scal[SC_COST], acc[0]); unsafeAtomicAdd(&scal[SC_FJJ], acc[1]); unsafeAtomicAdd(&scal[SC_FJR], acc[2]);
+        unsafeAtomicAdd(&scal[SC_FWW], acc[3]); unsafeAtomicAdd(&scal[SC_FWG], acc[4]);
+    }
+}
+
+// ---- K2: Schur rows.  One workgroup per camera, its block row of S accumulated in LDS ----------------
+//   S[c,c'] = delta(c,c') U_c - sum_{p seen by c and c'} (W_cp V_p^-1) W_c'p^T,   W = Jc^T Jp
+//   rhs_c   = Jc^T r - sum_p (W_cp V_p^-1) g_p ;  focal border row S_fc likewise.
+// Lanes walk the camera's observations (sorted by point); each lane re-linearises the point's other
+// observations and adds the DCxDC products into the LDS row with ds_add_f64.  The neighbour loop starts at
+// a lane-dependent offset so that the lanes of a wave hit different blocks of the row at the same time.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+             const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ cam_start,
+             const int* __restrict__ cam_obs, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
+             const int* __restrict__ diag_slot, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
+             const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
+             const double* __restrict__ Wf, int loss, double la,
+             double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
+             double* __restrict__ gcraw) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int BB = DC * DC;
+    constexpr int NU = DC * (DC + 1) / 2;
+    constexpr int NSM = NU + 3 * DC;            // U (upper), gc, rs, sfc
+    const int c = blockIdx.x;
+    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    double* acc = lds;                          // [nnb*BB]
+    double* small = lds + nnb * BB;             // [NSM]
+    double* camc = small + NSM;                 // [6 + 27 + 6] camera c: t,r | rot | scale
+    for (int i = threadIdx.x; i < nnb * BB + NSM; i += blockDim.x) lds[i] = 0.0;
+    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
+    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
+    __syncthreads();
+    const int* cols = col_idx + rb;
+    const double f = focal[0], sf = scale_f[0];
+    double U[NU], gc[DC], rs[DC], sfc[DC];
+#pragma unroll
+    for (int i = 0; i < NU; i++) U[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DC; i++) gc[i] = rs[i] = sfc[i] = 0.0;
+
+    for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
+        const int j = cam_obs[q], p = obs_pt[j];
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+        const double2 o = obs_xy[j];
+        ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
+        double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
+        double Jp[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Jp[0][k] = L.Jp[0][k] * sp[k]; Jp[1][k] = L.Jp[1][k] * sp[k]; }
+        const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
+        {
+            int u = 0;
+#pragma unroll
+            for (int a = 0; a < DC; a++) {
+                gc[a] += Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1];
+                sfc[a] += jf0 * Jc[0][a] + jf1 * Jc[1][a];
+#pragma unroll
+                for (int b = a; b < DC; b++) U[u++] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+            }
+        }
+        // T = (Jc^T Jp) V^-1
+        const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
+        const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+        const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
+        double T[DC][3];
+#pragma unroll
+        for (int a = 0; a < DC; a++) {
+            const double w0 = Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0];
+            const double w1 = Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1];
+            const double w2 = Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2];
+            T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+            T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+            T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+            rs[a] -= T[a][0] * g[0] + T[a][1] * g[1] + T[a][2] * g[2];
+            sfc[a] -= T[a][0] * wf[0] + T[a][1] * wf[1] + T[a][2] * wf[2];
+        }
+        const int j0 = pt_start[p], K = pt_start[p + 1] - j0;
+        int kk = threadIdx.x % K;                 // stagger: lanes start on different neighbours
+        for (int it = 0; it < K; it++) {
+            const int j2 = j0 + kk; kk = (kk + 1 == K) ? 0 : kk + 1;
+            const int c2 = obs_cam[j2]; const double2 o2 = obs_xy[j2];
+            ObsLin L2; lin_obs<DC == 6>(f, cam + 6 * c2, rot + 27 * c2, X, o2.x, o2.y, loss, la, L2);
+            double Jc2[2][DC]; cam_block<DC>(L2, scale_cam + 6 * c2, Jc2);
+            int lo = 0, hi = nnb - 1;             // slot of c2 in this row (c2 is always present)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cols[mid] < c2) lo = mid + 1; else hi = mid; }
+            double* blk = acc + lo * BB;
+#pragma unroll
+            for (int b = 0; b < DC; b++) {
+                const double w0 = (Jc2[0][b] * L2.Jp[0][0] + Jc2[1][b] * L2.Jp[1][0]) * sp[0];
+                const double w1 = (Jc2[0][b] * L2.Jp[0][1] + Jc2[1][b] * L2.Jp[1][1]) * sp[1];
+                const double w2 = (Jc2[0][b] * L2.Jp[0][2] + Jc2[1][b] * L2.Jp[1][2]) * sp[2];
+#pragma unroll
+                for (int a = 0; a < DC; a++) unsafeAtomicAdd(&blk[a * DC + b], -(T[a][0] * w0 + T[a][1] * w1 + T[a][2] * w2));
+            }
+        }
+    }
+    // fold the per-lane camera-side sums: wave shuffle, then one LDS add per wave
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < NU; i++) { const double v = wave_sum(U[i]); if (lane == 0) unsafeAtomicAdd(&small[i], v); }
+#pragma unroll
+        for (int i = 0; i < DC; i++) {
+            double v = wave_sum(gc[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + i], v);
+            v = wave_sum(rs[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + DC + i], v);
+            v = wave_sum(sfc[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + 2 * DC + i], v);
+        }
+    }
+    __syncthreads();
+    // write the row: coalesced, U_c folded into the diagonal block
+    const int ds = diag_slot[c];
+    for (int i = threadIdx.x; i < nnb * BB; i += blockDim.x) {
+        double v = acc[i];
+        const int s = i / BB, e = i - s * BB;
+        if (s == ds) { int a = e / DC, b = e - a * DC; if (a > b) { const int t = a; a = b; b = t; } v += small[a * DC - a * (a - 1) / 2 + (b - a)]; }
+        S_val[(size_t)rb * BB + i] = v;
+    }
+    if (threadIdx.x < DC) {
+        const int a = threadIdx.x;
+        rhs[c * DC + a] = small[NU + a] + small[NU + DC + a];
+        gcraw[c * DC + a] = small[NU + a];
+        Sfc[c * DC + a] = small[NU + 2 * DC + a];
+        Udiag[c * DC + a] = small[a * DC - a * (a - 1) / 2];
+    }
+}
+
+// ---- K2b: after the (optional) all-reduce: LM diagonal on the camera blocks, block-Jacobi inverse, focal row
+template <int DC>
+__global__ void k_finalize_S(const int* __restrict__ row_ptr, const int* __restrict__ diag_slot, const double* __restrict__ scale_cam,
+                             const double* __restrict__ scale_f, const double* __restrict__ Udiag, const double* __restrict__ gcraw,
+                             double radius, double min_diag, double max_diag, int Nc,
+                             double* __restrict__ S_val, double* __restrict__ Minv, double* __restrict__ rhs,
+                             double* __restrict__ Sff, double* __restrict__ scal) {
+    constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double gmax = 0.0;
+    if (c < Nc) {
+        double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;
+        double A[DC][DC];
+#pragma unroll
+        for (int a = 0; a < DC; a++) {
+            const double s = scale_cam[c * 6 + off + a];
+            const double d2 = (s > 0.0) ? fmin(fmax(Udiag[c * DC + a], min_diag), max_diag) / radius : 1.0;
+            blk[a * DC + a] += d2;
+            if (s > 0.0) gmax = fmax(gmax, fabs(gcraw[c * DC + a] / s));
+        }
+#pragma unroll
+        for (int a = 0; a < DC; a++)
+#pragma unroll
+            for (int b = 0; b < DC; b++) A[a][b] = blk[a * DC + b];
+        // in-register Cholesky A = L L^T, then inverse = L^-T L^-1
+        double Lm[DC][DC];
+#pragma unroll
+        for (int i = 0; i < DC; i++)
+#pragma unroll
+            for (int j = 0; j < DC; j++) Lm[i][j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < DC; j++) {
+            double d = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
+            d = sqrt(d); Lm[j][j] = d;
+#pragma unroll
+            for (int i = j + 1; i < DC; i++) {
+                double s = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= Lm[i][k] * Lm[j][k];
+                Lm[i][j] = s / d;
+            }
+        }
+        double Li[DC][DC];   // L^-1 (lower)
+#pragma unroll
+        for (int i = 0; i < DC; i++)
+#pragma unroll
+            for (int j = 0; j < DC; j++) Li[i][j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < DC; j++) {
+            Li[j][j] = 1.0 / Lm[j][j];
+#pragma unroll
+            for (int i = j + 1; i < DC; i++) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = j; k < i; k++) s -= Lm[i][k] * Li[k][j];
+                Li[i][j] = s / Lm[i][i];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < DC; a++)
+#pragma unroll
+            for (int b = 0; b < DC; b++) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < DC; k++) s += Li[k][a] * Li[k][b];   // (L^-T L^-1)[a][b]; terms with k < max(a,b) are zero
+                Minv[(size_t)c * BB + a * DC + b] = s;
+            }
+    }
+    gmax = wave_max(gmax);
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double sf = scale_f[0];
+        if (sf > 0.0) {
+            const double fjj = scal[SC_FJJ];
+            Sff[0] = fjj + fmin(fmax(fjj, min_diag), max_diag) / radius - scal[SC_FWW];
+            rhs[Nc * DC] = scal[SC_FJR] - scal[SC_FWG];
+            atomic_max_nonneg(&scal[SC_GMAX], fabs(scal[SC_FJR] / sf));
+        } else { Sff[0] = 1.0; rhs[Nc * DC] = 0.0; }
+    }
+}
+
+// ---- PCG on the reduced system (block-CSR S + dense focal border), block-Jacobi preconditioner -------
+// One wave per block row for the mat-vec; all vector work + both dot products in ONE single-workgroup
+// kernel, so an iteration is two launches and no host round trip; a device flag ends the loop.
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_pcg_init(const double* __restrict__ rhs, const double* __restrict__ Minv, const double* __restrict__ Sff, int Nc,
+           double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ p, double* __restrict__ pcg) {
+    __shared__ double red[2 * 16];
+    const int n = Nc * DC;
+    double acc[2] = {0, 0};
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        double zi;
+        if (i < n) {
+            const int c = i / DC, a = i - c * DC; zi = 0.0;
+#pragma unroll
+            for (int b = 0; b < DC; b++) zi += Minv[(size_t)c * DC * DC + a * DC + b] * rhs[c * DC + b];
+        } else zi = rhs[n] / Sff[0];
+        const double ri = rhs[i];
+        x[i] = 0.0; r[i] = ri; z[i] = zi; p[i] = zi;
+        acc[0] += ri * zi; acc[1] += ri * ri;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        pcg[PCG_RZ] = acc[0]; pcg[PCG_BN2] = acc[1]; pcg[PCG_RR] = acc[1]; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0;
+        pcg[PCG_DONE] = (acc[1] == 0.0) ? 1.0 : 0.0;
+    }
+}
+
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_pcg_matvec(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+             const double* __restrict__ Sfc, const double* __restrict__ p, int Nc, const double* __restrict__ pcg,
+             double* __restrict__ q, double* __restrict__ pqpart) {
+    if (pcg[PCG_DONE] != 0.0) return;
+    __shared__ double part[4][64];
+    constexpr int BB = DC * DC;
+    constexpr int LW = (64 / DC) * DC;          // lanes used: a multiple of DC so that a lane keeps its row index
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + w;
+    if (c < Nc) {
+        const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+        double s = 0.0;
+        if (lane < LW) {
+            const int a = lane % DC;
+            for (int idx = lane; idx < nnb * DC; idx += LW) {
+                const int b = idx / DC;
+                const double* row = S_val + ((size_t)(rb + b)) * BB + a * DC;
+                const double* pv = p + col_idx[rb + b] * DC;
+#pragma unroll
+                for (int k = 0; k < DC; k++) s += row[k] * pv[k];
+            }
+        }
+        part[w][lane] = s;
+    }
+    __syncthreads();
+    if (c < Nc && lane < DC) {
+        double s = 0.0;
+        for (int l = lane; l < LW; l += DC) s += part[w][l];
+        const double pf = p[Nc * DC];
+        s += Sfc[c * DC + lane] * pf;
+        q[c * DC + lane] = s;
+        part[w][lane] = s * p[c * DC + lane];
+    }
+    __syncthreads();
+    if (c < Nc && lane == 0) { double s = 0.0; for (int a = 0; a < DC; a++) s += part[w][a]; pqpart[c] = s; }
+}
+
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_pcg_vecops(const double* __restrict__ Minv, const double* __restrict__ Sfc, const double* __restrict__ Sff, int Nc, double tol2,
+             double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ p,
+             const double* __restrict__ q, const double* __restrict__ pqpart, double* __restrict__ pcg) {
+    if (pcg[PCG_DONE] != 0.0) return;
+    __shared__ double red[2 * 16];
+    __shared__ double sh[2];
+    const int n = Nc * DC;
+    const double pf = p[n];
+    // q_f = Sff p_f + Sfc . p_c ;  pq = sum_c pqpart + p_f q_f
+    double acc[2] = {0, 0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc[0] += Sfc[i] * p[i];
+    for (int c = threadIdx.x; c < Nc; c += blockDim.x) acc[1] += pqpart[c];
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        const double qf = Sff[0] * pf + acc[0];
+        const double pq = acc[1] + pf * qf;
+        sh[0] = qf; sh[1] = pq;
+    }
+    __syncthreads();
+    const double qf = sh[0], pq = sh[1];
+    const double rz = pcg[PCG_RZ];
+    if (!(pq > 0.0)) { if (threadIdx.x == 0) { pcg[PCG_DONE] = 1.0; pcg[PCG_BREAKDOWN] = 1.0; } return; }
+    const double alpha = rz / pq;
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        const double qi = (i < n) ? q[i] : qf;
+        x[i] += alpha * p[i];
+        r[i] -= alpha * qi;
+    }
+    __syncthreads();
+    double acc2[2] = {0, 0};
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        double zi;
+        if (i < n) {
+            const int c = i / DC, a = i - c * DC; zi = 0.0;
+#pragma unroll
+            for (int b = 0; b < DC; b++) zi += Minv[(size_t)c * DC * DC + a * DC + b] * r[c * DC + b];
+        } else zi = r[n] / Sff[0];
+        z[i] = zi;
+        acc2[0] += r[i] * zi; acc2[1] += r[i] * r[i];
+    }
+    block_sum<2>(acc2, red);
+    if (threadIdx.x == 0) { sh[0] = acc2[0]; sh[1] = acc2[1]; }
+    __syncthreads();
+    const double rz_new = sh[0], rr = sh[1];
+    const double beta = rz_new / rz;
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) p[i] = z[i] + beta * p[i];
+    if (threadIdx.x == 0) {
+        pcg[PCG_RZ] = rz_new; pcg[PCG_RR] = rr; pcg[PCG_ITERS] += 1.0;
+        if (rr <= tol2 * pcg[PCG_BN2]) pcg[PCG_DONE] = 1.0;
+    }
+}
+
+// ---- K3a: candidate cameras/focal from the PCG solution (replicated on every rank) --------------------
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
+             const double* __restrict__ scale_f, const double* __restrict__ y, int Nc,
+             double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ scal) {
+    __shared__ double red[2 * 16];
+    constexpr int off = (DC == 6) ? 0 : 3;
+    double acc[2] = {0, 0};
+    for (int i = threadIdx.x; i < Nc * 6; i += blockDim.x) {
+        const int c = i / 6, k = i - c * 6;
+        double v = cam[i];
+        const double s = scale_cam[i];
+        if (s > 0.0 && k >= off) { const double d = -y[c * DC + (k - off)] * s; v += d; acc[0] += d * d; acc[1] += v * v; }
+        cam_c[i] = v;
+    }
+    if (threadIdx.x == 0) {
+        double v = focal[0]; const double s = scale_f[0];
+        if (s > 0.0) { const double d = -y[Nc * DC] * s; v += d; acc[0] += d * d; acc[1] += v * v; }
+        focal_c[0] = v;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; }
+}
+
+// ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
+//   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
+//   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+                const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+                const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
+                const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
+                const double* __restrict__ y, int Nc, int loss, double la, double* __restrict__ pts_c, double* __restrict__ scal) {
+    __shared__ double red[3 * 4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[3] = {0, 0, 0};   // model, step2, xn2
+    if (p < nP) {
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+        const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC];
+        double b[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+        const int j0 = pt_start[p], j1 = pt_start[p + 1];
+        for (int j = j0; j < j1; j++) {
+            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+            double Jc[2][DC]; cam_block<DC>(L, scale_cam + 6 * c, Jc);
+            double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
+#pragma unroll
+            for (int a = 0; a < DC; a++) { const double ya = y[c * DC + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) b[k] -= (L.Jp[0][k] * m0 + L.Jp[1][k] * m1) * sp[k];
+        }
+        const double* Vi = Vinv + 6 * p;
+        double yp[3];
+        yp[0] = Vi[0] * b[0] + Vi[1] * b[1] + Vi[2] * b[2];
+        yp[1] = Vi[1] * b[0] + Vi[3] * b[1] + Vi[4] * b[2];
+        yp[2] = Vi[2] * b[0] + Vi[4] * b[1] + Vi[5] * b[2];
+        if (!(sp[0] > 0.0)) yp[0] = yp[1] = yp[2] = 0.0;
+        // second sweep: model residual with the full step (= -y)
+        for (int j = j0; j < j1; j++) {
+            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+            double Jc[2][DC]; cam_block<DC>(L, scale_cam + 6 * c, Jc);
+            double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
+#pragma unroll
+            for (int a = 0; a < DC; a++) { const double ya = y[c * DC + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { m0 += L.Jp[0][k] * sp[k] * yp[k]; m1 += L.Jp[1][k] * sp[k] * yp[k]; }
+            m0 = -m0; m1 = -m1;
+            acc[0] += m0 * (L.r[0] + 0.5 * m0) + m1 * (L.r[1] + 0.5 * m1);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double d = -yp[k] * sp[k]; const double v = X[k] + d;
+            pts_c[3 * p + k] = v;
+            if (sp[k] > 0.0) { acc[1] += d * d; acc[2] += v * v; }
+        }
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[SC_MODEL], acc[0]); unsafeAtomicAdd(&scal[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&scal[SC_XN2_PT], acc[2]); }
+}
+
+// ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------
+__global__ void __launch_bounds__(256)
+k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+             const int* __restrict__ pt_start, int nP, int loss, double la, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[1] = {0.0};
+    if (p < nP) {
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double f = focal[0];
+        for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            acc[0] += obs_cost(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la);
+        }
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc[0]);
+}
+
+// |x|^2 over free parameters (iteration 0)
+__global__ void k_sqnorm_masked(const double* __restrict__ v, const double* __restrict__ mask, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[1] = {(i < n && mask[i] > 0.0) ? v[i] * v[i] : 0.0};
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0 && acc[0] != 0.0) unsafeAtomicAdd(out, acc[0]);
+}
+
+// ---- parity probe: per-observation residual + 2x10 Jacobian (focal | t | r | X), robustified, unscaled
+__global__ void k_eval_dump(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+                            const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+                            const int* __restrict__ obs_pt, int M, int loss, double la, double* __restrict__ res, double* __restrict__ jac) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const int c = obs_cam[j], p = obs_pt[j];
+    const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+    const double2 o = obs_xy[j];
+    ObsLin L; lin_obs<true>(focal[0], cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+    for (int a = 0; a < 2; a++) {
+        res[2 * j + a] = L.r[a];
+        double* J = jac + 20 * (size_t)j + 10 * a;
+        J[0] = L.Jf[a];
+        for (int k = 0; k < 3; k++) { J[1 + k] = L.Jt[a][k]; J[4 + k] = L.Jr[a][k]; J[7 + k] = L.Jp[a][k]; }
+    }
+}
+
+}  // namespace ssfm

@@ -1,0 +1,61 @@
+// spherical_sfm_amd -- context + communicator entry points of the C ABI (include/ssfm.h).
+#include <cstring>
+#include "ssfm_ctx.h"
+
+namespace ssfm { std::string g_last_error; }
+using namespace ssfm;
+
+extern "C" int ssfm_version(void) { return 100; }
+
+extern "C" int ssfm_ctx_create(int32_t device, void* stream, ssfm_ctx** out) {
+    if (!out) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, SSFM_ERR_NO_DEVICE, "ssfm_ctx_create: no HIP device (the MI355X path has no CPU fallback)");
+    if (device < 0) { e = hipGetDevice(&device); if (e != hipSuccess) return fail(nullptr, SSFM_ERR_HIP, hipGetErrorString(e)); }
+    if (device >= count) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ctx_create: device index out of range");
+    e = hipSetDevice(device); if (e != hipSuccess) return fail(nullptr, SSFM_ERR_HIP, hipGetErrorString(e));
+    ssfm_ctx* c = new ssfm_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(nullptr, SSFM_ERR_HIP, hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return SSFM_OK;
+}
+
+extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* ssfm_last_error(const ssfm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int ssfm_comm_unique_id(uint8_t id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId u;
+    ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, SSFM_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memcpy(id, &u, 128);
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_comm_init(ssfm_ctx* ctx, const uint8_t id[128], int32_t nranks, int32_t rank) {
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, SSFM_ERR_INVALID, "ssfm_comm_init: bad arguments");
+    if (nranks == 1) { ctx->nranks = 1; ctx->rank = 0; return SSFM_OK; }
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u; std::memcpy(&u, id, 128);
+    SSFM_NCCL_CHECK(ctx, ncclCommInitRank(&ctx->comm, nranks, u, rank));
+    ctx->nranks = nranks; ctx->rank = rank;
+    return SSFM_OK;
+}

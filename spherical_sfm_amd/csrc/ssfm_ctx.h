@@ -1,0 +1,42 @@
+// spherical_sfm_amd -- context shared by the C-ABI entry points (include/ssfm.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstdio>
+#include <string>
+#include "../../include/ssfm.h"
+
+struct ssfm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    ncclComm_t comm = nullptr;   // RCCL communicator (one rank per GPU), null for single-GPU
+    int nranks = 1, rank = 0;
+    int num_cus = 256;
+};
+
+namespace ssfm {
+
+extern std::string g_last_error;   // for failures before a context exists
+
+inline int fail(ssfm_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_last_error = msg;
+    return code;
+}
+
+#define SSFM_HIP_CHECK(ctx, expr)                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return ssfm::fail(ctx, SSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define SSFM_NCCL_CHECK(ctx, expr)                                                                     \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return ssfm::fail(ctx, SSFM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+}  // namespace ssfm

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (test infrastructure).  Built on demand from oracle/*.cpp."""
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import torch  # noqa: F401  (share torch's HIP runtime; also gives device queries)
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from spherical_sfm_amd import ba
+    ctx = ba.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,128 @@
+"""GPU parity tests of the bundle-adjustment path: HIP (through the C ABI) vs the CPU oracle.
+
+Tolerances: residuals/Jacobians 1e-9 relative (analytic vs dual-number derivatives of the same function);
+converged cameras / points / focal <= 1e-5 relative, the tolerance BASELINE.json's north_star states.
+"""
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(True, True), (True, False), (False, True), (False, False)]   # (spherical, focal_fixed)
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def point_rel_err(a, b):
+    return (np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-300)).max()
+
+
+@pytest.mark.parametrize("spherical,focal_fixed", MODES)
+def test_residual_and_jacobian_match_oracle(gpu_ctx, oracle, spherical, focal_fixed):
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 600, 6, spherical=spherical, focal_fixed=focal_fixed, trans_noise=0.01)
+    p.cameras[0, 3:] = 0.0            # exercises the theta^2 <= eps Taylor branch of the angle-axis code
+    p.cameras[1, 3:] = [1e-9, -2e-9, 1e-9]
+    adj = ba.BundleAdjuster(gpu_ctx, p)
+    cost, res, jac = adj.evaluate()
+    ocost, ores, ojac, used = oracle.ba_evaluate(p)
+    assert used.all()
+    assert abs(cost - ocost) <= 1e-11 * abs(ocost)
+    assert np.abs(res - ores).max() <= 1e-9 * np.abs(ores).max()
+    # compare column groups separately: they differ by orders of magnitude (pixels/rad vs pixels/unit)
+    for sl in (slice(0, 1), slice(1, 4), slice(4, 7), slice(7, 10)):
+        assert np.abs(jac[:, :, sl] - ojac[:, :, sl]).max() <= 1e-9 * np.abs(ojac[:, :, sl]).max()
+    adj.close()
+
+
+@pytest.mark.parametrize("spherical,focal_fixed", MODES)
+def test_solve_matches_oracle_small(gpu_ctx, oracle, spherical, focal_fixed):
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 1200, 6, spherical=spherical, focal_fixed=focal_fixed)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0
+    assert s["iterations"] == os_["iterations"]
+    assert s["num_residual_blocks"] == os_["num_residual_blocks"] == 7200
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-9 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5
+    assert point_rel_err(pts, opts) <= 1e-5
+    assert abs(f - of) <= 1e-5 * of
+    assert s["camera_dof"] == (3 if spherical else 6)
+
+
+def test_flatten_rules_match_reference(gpu_ctx, oracle):
+    """src/sfm.cpp:240-263: zero points and points with < 3 observations stay out, untouched; duplicates keep the
+    last value; unsorted input is accepted."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 800, 6, spherical=True, focal_fixed=True)
+    rng = np.random.default_rng(7)
+    p.points[5] = 0.0                                  # |X| == 0 -> skipped
+    keep = np.ones(len(p.obs_pt), bool)
+    drop = np.where(p.obs_pt == 9)[0][:4]              # point 9 keeps 2 observations -> skipped
+    keep[drop] = False
+    p.obs_xy, p.obs_cam, p.obs_pt = p.obs_xy[keep], p.obs_cam[keep], p.obs_pt[keep]
+    j = np.where(p.obs_pt == 20)[0][0]                 # duplicate key: the later entry wins
+    p.obs_xy = np.vstack([p.obs_xy, p.obs_xy[j] + 0.25]); p.obs_cam = np.append(p.obs_cam, p.obs_cam[j]); p.obs_pt = np.append(p.obs_pt, 20)
+    perm = rng.permutation(len(p.obs_pt))
+    # a stable shuffle that keeps the duplicate after the original
+    perm = np.concatenate([perm[perm != len(perm) - 1], [len(perm) - 1]])
+    p.obs_xy, p.obs_cam, p.obs_pt = p.obs_xy[perm], p.obs_cam[perm].astype(np.int32), p.obs_pt[perm].astype(np.int32)
+    before = p.points.copy()
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["num_residual_blocks"] == os_["num_residual_blocks"] == 6 * 798
+    assert s["num_points_used"] == 798
+    assert (pts[5] == 0).all() and (pts[9] == before[9]).all()
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(np.delete(pts, 5, 0), np.delete(opts, 5, 0)) <= 1e-5
+
+
+def test_nothing_to_do(gpu_ctx):
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 100, 6)
+    p.points[:] = 0.0
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["termination"] == 3 and (cams == p.cameras).all()
+
+
+def test_noise_free_recovers_ground_truth(gpu_ctx):
+    """Oracle-free known answer: without pixel noise the minimiser must return the generating scene."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 1500, 6, spherical=True, focal_fixed=False, pixel_noise=0.0)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, function_tolerance=1e-14, max_num_iterations=100)
+    assert np.abs(cams[:, 3:] - p.gt_cameras[:, 3:]).max() < 1e-7
+    assert point_rel_err(pts, p.gt_points) < 1e-6
+    assert abs(f - p.gt_focal) < 1e-4
+
+
+def test_fixed_point_and_resident_handle(gpu_ctx, oracle):
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 900, 6, spherical=False, focal_fixed=True)
+    p.pt_fixed[::7] = 1
+    adj = ba.BundleAdjuster(gpu_ctx, p)
+    s1 = adj.run(); c1, x1, f1 = [np.copy(a) for a in adj.download()]
+    adj.reset(); s2 = adj.run(); c2, x2, f2 = adj.download()
+    assert s1["iterations"] == s2["iterations"]
+    assert rel_err(c2, c1) <= 1e-9                       # run-to-run: atomics reorder sums, nothing more
+    assert (x1[::7] == p.points[::7]).all()
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert rel_err(c1, ocams) <= 1e-5 and point_rel_err(x1, opts) <= 1e-5
+    adj.close()
+
+
+@pytest.mark.parametrize("spherical,focal_fixed", [(True, True), (False, False)])
+def test_config2_full_size_parity(gpu_ctx, oracle, spherical, focal_fixed):
+    """BASELINE.json configs[1]: 300 cameras / 100k points / 600k observations."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(300, 100000, 6, spherical=spherical, focal_fixed=focal_fixed)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0
+    assert s["iterations"] == os_["iterations"]
+    assert rel_err(cams, ocams) <= 1e-5
+    assert point_rel_err(pts, opts) <= 1e-5
+    assert abs(f - of) <= 1e-5 * of
