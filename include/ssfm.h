@@ -77,7 +77,9 @@ typedef struct {
     int32_t jacobi_scaling;                    /* 1 */
     /* reduced-camera-system solver (the reference uses a direct sparse Cholesky; this build uses PCG) */
     int32_t pcg_max_iterations;                /* 1000 */
-    double pcg_tolerance;                      /* |r| <= tol |b|, default 1e-12 (parity with a direct solve) */
+    double pcg_tolerance;                      /* |r| <= tol |b|, default 1e-10 (tracks a direct solve) */
+    int32_t preconditioner;                    /* 0: block-banded Cholesky (exact on the Cuthill-McKee band) + PCG
+                                                  refinement; 1: block-Jacobi PCG */
     int32_t verbose;                           /* 1: one line per LM iteration (minimizer_progress_to_stdout) */
 } ssfm_ba_options;
 

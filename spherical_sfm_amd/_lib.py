@@ -30,7 +30,7 @@ class BAOptionsC(C.Structure):
                 ("min_trust_region_radius", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("min_relative_decrease", C.c_double), ("loss_type", C.c_int32), ("loss_scale", C.c_double),
                 ("jacobi_scaling", C.c_int32), ("pcg_max_iterations", C.c_int32), ("pcg_tolerance", C.c_double),
-                ("verbose", C.c_int32)]
+                ("preconditioner", C.c_int32), ("verbose", C.c_int32)]
 
 
 class BASummaryC(C.Structure):

@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 #include "../../include/ssfm.h"
@@ -41,7 +42,41 @@ struct BAFlat {
     std::vector<double> pts0;           // [nP*3]
     int max_row_blocks = 0;
     bool nothing_to_do = false;
+    // elimination order of the camera blocks for the banded Cholesky preconditioner
+    std::vector<int> cam_pos;           // [Nc] camera -> position
+    int band = 0;                       // block half-bandwidth in that order
+    std::vector<int> band_pairs;        // (i_rel | k_rel << 16), i_rel-major, 1 <= k_rel <= i_rel <= band
 };
+
+// Cuthill-McKee order of the camera graph given as block-CSR structure (folds a ring into a band of twice
+// its reach; any connected "video-like" graph becomes a narrow band).  Returns the half-bandwidth.
+inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos) {
+    pos.assign(n, -1);
+    std::vector<int> order; order.reserve(n);
+    std::vector<int> queue, nb;
+    auto degree = [&](int v) { return row_ptr[v + 1] - row_ptr[v]; };
+    auto far_node = [&](int start) {            // last node of a BFS restricted to unplaced nodes
+        std::vector<char> seen(n, 0); std::vector<int> q{start}; seen[start] = 1; size_t h = 0;
+        while (h < q.size()) { int u = q[h++]; for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) { int v = col_idx[e]; if (!seen[v] && pos[v] < 0) { seen[v] = 1; q.push_back(v); } } }
+        return q.back();
+    };
+    for (int s0 = 0; s0 < n; s0++) {
+        if (pos[s0] >= 0) continue;
+        int start = far_node(far_node(s0));
+        queue.assign(1, start); pos[start] = (int)order.size(); order.push_back(start);
+        size_t head = 0;
+        while (head < queue.size()) {
+            const int u = queue[head++];
+            nb.clear();
+            for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) { const int v = col_idx[e]; if (pos[v] < 0) { pos[v] = -2; nb.push_back(v); } }
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
+            for (int v : nb) { pos[v] = (int)order.size(); order.push_back(v); queue.push_back(v); }
+        }
+    }
+    int band = 0;
+    for (int u = 0; u < n; u++) for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) band = std::max(band, std::abs(pos[u] - pos[col_idx[e]]));
+    return band;
+}
 
 inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
     const int Nc = P.num_cameras, Np = P.num_points;
@@ -99,6 +134,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             F.diag_slot[c] = (int)(std::lower_bound(nb[c].begin(), nb[c].end(), c) - nb[c].begin());
         }
     }
+    F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos);
+    for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     F.mask_cam.assign((size_t)Nc * 6, 0.0);
     bool all_t_fixed = true;
     for (int c = 0; c < Nc; c++) {

@@ -17,6 +17,7 @@
 #include <vector>
 #include "ba_flatten.h"
 #include "ba_kernels.h"
+#include "band_kernels.h"
 #include "ssfm_ctx.h"
 
 namespace ssfm {
@@ -24,10 +25,12 @@ namespace ssfm {
 static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
-                KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_COUNT };
+                KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
+                KID_BAND_COMBINE, KID_REF_VEC, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_rows", "k_finalize_S", "k_pcg_init",
                                               "k_pcg_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
-                                              "k_point_cost", "rccl_allreduce"};
+                                              "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol", "k_band_fwd",
+                                              "k_band_back", "k_band_combine", "k_ref_vecops"};
 
 template <typename T>
 struct DevBuf {
@@ -50,6 +53,7 @@ struct ssfm_ba_handle {
     DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
     DevBuf<double> Vinv, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
+    DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0;
     bool scale_ready = false;
@@ -77,6 +81,7 @@ struct ssfm_ba_handle {
         rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); gp.free(); Wf.free();
+        band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free();
         redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
@@ -106,6 +111,74 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, op, h->ctx->comm, h->ctx->stream);
     h->span_end();
     if (r != ncclSuccess) return fail(h->ctx, SSFM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return SSFM_OK;
+}
+
+// Solve S y = rhs (block-CSR S with dense focal border) into h->px.
+//   preconditioner 0: exact block-banded Cholesky in Cuthill-McKee order, then PCG refinement on the residual
+//   preconditioner 1: block-Jacobi PCG (kept for comparison; needs ~10^3 iterations on a camera ring)
+template <int DC>
+static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bool* ok_out) {
+    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
+    const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
+    const int Nc = F.Nc, n = Nc * DC, b = F.band;
+    constexpr int BB = DC * DC;
+    const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
+    if (O.preconditioner == 1) {
+        LAUNCH(h, KID_PCG_INIT, k_pcg_init<DC>, 1, 1024, 0, h->rhs, h->Minv.p, h->Sff.p, Nc, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pcg.p);
+        int launched = 0; bool done = false;
+        int chunk = std::max(8, h->pcg_prev_iters + 2);
+        while (!done && launched < O.pcg_max_iterations) {
+            const int todo = std::min(chunk, O.pcg_max_iterations - launched);
+            for (int k = 0; k < todo; k++) {
+                LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+                LAUNCH(h, KID_PCG_VECOPS, k_pcg_vecops<DC>, 1, 1024, 0, h->Minv.p, h->Sfc, h->Sff.p, Nc, tol2, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pq.p, h->pqpart.p, h->pcg.p);
+            }
+            launched += todo;
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            done = host_pcg[PCG_DONE] != 0.0;
+            chunk = 8;
+        }
+        *iters_out = (int)host_pcg[PCG_ITERS];
+        *ok_out = done && host_pcg[PCG_BREAKDOWN] == 0.0;
+        return SSFM_OK;
+    }
+    // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
+    const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
+    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
+    const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band.p, 0, h->band.n * sizeof(double), st));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band_fail.p, 0, sizeof(int), st));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, PCG_TOTAL * sizeof(double), st));
+    LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
+    hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
+    LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, h->band_fail.p);
+    LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
+    LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
+    // ---- residual check r = rhs - S x, PCG refinement with the factor as preconditioner while it is too large
+    LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->px.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+    LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
+    int fail_flag = 0;
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&fail_flag, h->band_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    int it = 0;
+    if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; }     // S not positive definite: invalid step
+    while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
+        LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
+        LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);
+        LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+        LAUNCH(h, KID_REF_VEC, k_ref_step<DC>, 1, 1024, 0, h->Sfc, h->Sff.p, Nc, tol2, h->pp.p, h->pq.p, h->pqpart.p, h->px.p, h->pr.p, h->pcg.p);
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        it++;
+    }
+    *iters_out = it;
+    *ok_out = host_pcg[PCG_DONE] != 0.0 && host_pcg[PCG_BREAKDOWN] == 0.0;
     return SSFM_OK;
 }
 
@@ -185,26 +258,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
                radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[2], st));
-        // ================= PCG on the reduced system =================
-        LAUNCH(h, KID_PCG_INIT, k_pcg_init<DC>, 1, 1024, 0, h->rhs, h->Minv.p, h->Sff.p, Nc, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pcg.p);
-        const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
-        int launched = 0; bool pcg_done = false;
-        int chunk = std::max(8, h->pcg_prev_iters + 2);
-        while (!pcg_done && launched < O.pcg_max_iterations) {
-            const int todo = std::min(chunk, O.pcg_max_iterations - launched);
-            for (int k = 0; k < todo; k++) {
-                LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
-                LAUNCH(h, KID_PCG_VECOPS, k_pcg_vecops<DC>, 1, 1024, 0, h->Minv.p, h->Sfc, h->Sff.p, Nc, tol2, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pq.p, h->pqpart.p, h->pcg.p);
-            }
-            launched += todo;
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            pcg_done = host_pcg[PCG_DONE] != 0.0;
-            chunk = 8;
-        }
-        const int pcg_iters = (int)host_pcg[PCG_ITERS];
+        // ================= solve the reduced system =================
+        int pcg_iters = 0; bool pcg_ok = false;
+        { int rc = solve_reduced<DC>(h, host_pcg, &pcg_iters, &pcg_ok); if (rc) return rc; }
         h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
-        const bool pcg_ok = pcg_done && host_pcg[PCG_BREAKDOWN] == 0.0;
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         // ================= step, candidate, model cost, candidate cost =================
         LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, h->scal.p);
@@ -285,7 +342,7 @@ extern "C" void ssfm_ba_default_options(ssfm_ba_options* o) {
     o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->min_relative_decrease = 1e-3;
     o->loss_type = 1; o->loss_scale = 1.0;           // CauchyLoss(1.0), src/sfm.cpp:196
     o->jacobi_scaling = 1;
-    o->pcg_max_iterations = 1000; o->pcg_tolerance = 1e-12;
+    o->pcg_max_iterations = 1000; o->pcg_tolerance = 1e-10; o->preconditioner = 0;
     o->verbose = 0;
 }
 
@@ -326,7 +383,9 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
     AL(scal, SC_TOTAL); AL(pcg, PCG_TOTAL);
+    AL(band, (size_t)Nc * (F.band + 1) * DC * DC); AL(Linv, (size_t)Nc * DC * DC); AL(Yb, 2 * n); AL(Yr, 2 * n); AL(band_fail, 1);
 #undef AL
+    SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSFM_OK;

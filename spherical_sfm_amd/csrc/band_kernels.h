@@ -1,0 +1,329 @@
+// spherical_sfm_amd -- block-banded Cholesky preconditioner for the reduced camera system.
+//
+// The reference solves the reduced system with a direct sparse Cholesky (Ceres SPARSE_SCHUR,
+// src/sfm.cpp:273).  A camera ring has long-wavelength modes that block-Jacobi PCG needs ~10^3
+// iterations for (measured: profiles/r01_notes.md), so PCG is preconditioned with an exact Cholesky of S
+// restricted to a block band in Cuthill-McKee order.  When the band covers the whole structure (always the
+// case for the ordering built in ba_flatten.h) the preconditioner is S^-1 itself and PCG is a one-step
+// refinement that also checks the residual.
+//
+// Layout: band[(i*(b+1) + d)*DC*DC + ...] = block (i, i-d) of the permuted matrix, d = 0..b, row-major DCxDC.
+// One 1024-lane workgroup runs the right-looking factorisation; the DCxDC panel of the current block column
+// sits in LDS, the trailing window is updated in place (L2-resident).  Right-hand sides ride along as border
+// rows, so the forward substitution costs no extra pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ba_kernels.h"
+
+namespace ssfm {
+
+// S (block-CSR, camera order) -> band storage (permuted), right-hand sides permuted alongside
+template <int DC>
+__global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+                              const int* __restrict__ pos, int Nc, int b, double* __restrict__ band) {
+    constexpr int BB = DC * DC;
+    const int c = blockIdx.x;
+    const int i = pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    for (int idx = threadIdx.x; idx < nnb * BB; idx += blockDim.x) {
+        const int s = rb + idx / BB, e = idx % BB;
+        const int k = pos[col_idx[s]];
+        if (k <= i) band[((size_t)i * (b + 1) + (i - k)) * BB + e] = S_val[(size_t)s * BB + e];
+    }
+}
+template <int DC>
+__global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double* __restrict__ Sfc, const int* __restrict__ pos, int Nc,
+                                   double* __restrict__ Y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Nc * DC) return;
+    const int c = t / DC, a = t - c * DC;
+    Y[pos[c] * DC + a] = rhs[t];
+    Y[(size_t)Nc * DC + pos[c] * DC + a] = Sfc[t];
+}
+
+// Factorise in place (lower), store inverse diagonal factors, forward-substitute NR right-hand sides Y[r][N*DC].
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_band_chol(double* __restrict__ band, double* __restrict__ Linv_out, double* __restrict__ Y, const int* __restrict__ pairs,
+            int N, int b, int* __restrict__ fail_flag) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sLinv = lds;                // BB
+    double* sDiag = lds + BB;           // BB
+    double* sY = sDiag + BB;            // NR*DC
+    double* sPanel = sY + NR * DC;      // b*BB
+    const int W = b + 1, n = N * DC, tid = threadIdx.x;
+    for (int j = 0; j < N; j++) {
+        const int nb = min(b, N - 1 - j);
+        // ---- A: diagonal block
+        if (tid < BB) sDiag[tid] = band[((size_t)j * W) * BB + tid];
+        __syncthreads();
+        if (tid == 0) {
+            double L[DC][DC], Li[DC][DC];
+#pragma unroll
+            for (int r = 0; r < DC; r++)
+#pragma unroll
+                for (int c = 0; c < DC; c++) { L[r][c] = 0.0; Li[r][c] = 0.0; }
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < DC; c++) {
+                double d = sDiag[c * DC + c];
+#pragma unroll
+                for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
+                if (!(d > 0.0)) { bad = true; d = 1.0; }
+                d = sqrt(d); L[c][c] = d;
+#pragma unroll
+                for (int r = c + 1; r < DC; r++) {
+                    double s = sDiag[r * DC + c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) s -= L[r][k] * L[c][k];
+                    L[r][c] = s / d;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DC; c++) {
+                Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+                for (int r = c + 1; r < DC; r++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = c; k < r; k++) s -= L[r][k] * Li[k][c];
+                    Li[r][c] = s / L[r][r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < DC; r++)
+#pragma unroll
+                for (int c = 0; c < DC; c++) { sLinv[r * DC + c] = Li[r][c]; Linv_out[(size_t)j * BB + r * DC + c] = Li[r][c]; band[((size_t)j * W) * BB + r * DC + c] = L[r][c]; }
+            if (bad) *fail_flag = 1;
+        }
+        __syncthreads();
+        // ---- B: panel rows  L_ij = A_ij L_jj^-T  (one lane per block row), and y_j = L_jj^-1 r_j
+        for (int t = tid; t < nb * DC; t += 1024) {
+            const int blk = t / DC, a = t - blk * DC;
+            const size_t addr = (((size_t)(j + 1 + blk)) * W + (blk + 1)) * BB + a * DC;
+            double A[DC];
+#pragma unroll
+            for (int k = 0; k < DC; k++) A[k] = band[addr + k];
+#pragma unroll
+            for (int c = 0; c < DC; c++) { double s = 0.0;
+#pragma unroll
+                for (int k = 0; k <= c; k++) s += A[k] * sLinv[c * DC + k];
+                band[addr + c] = s; sPanel[blk * BB + a * DC + c] = s; }
+        }
+        if (tid >= 1024 - NR * 64 && (tid & 63) == 0) {
+            const int r = (tid - (1024 - NR * 64)) >> 6;
+            const size_t addr = (size_t)r * n + (size_t)j * DC;
+            double v[DC];
+#pragma unroll
+            for (int k = 0; k < DC; k++) v[k] = Y[addr + k];
+#pragma unroll
+            for (int a = 0; a < DC; a++) { double s = 0.0;
+#pragma unroll
+                for (int k = 0; k <= a; k++) s += sLinv[a * DC + k] * v[k];
+                Y[addr + a] = s; sY[r * DC + a] = s; }
+        }
+        __syncthreads();
+        // ---- C: trailing window  A_ik -= L_ij L_kj^T  (one lane per (pair, row)), r_k -= L_kj y_j
+        const int work = (nb * (nb + 1) / 2) * DC;
+        for (int t = tid; t < work; t += 1024) {
+            const int pr = t / DC, a = t - pr * DC;
+            const int pk = pairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;     // 1-based offsets from j
+            const double* Li_ = sPanel + (ir - 1) * BB + a * DC;
+            const double* Lk_ = sPanel + (kr - 1) * BB;
+            double la[DC];
+#pragma unroll
+            for (int m = 0; m < DC; m++) la[m] = Li_[m];
+            double* dst = band + (((size_t)(j + ir)) * W + (ir - kr)) * BB + a * DC;
+#pragma unroll
+            for (int c = 0; c < DC; c++) { double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) s += la[m] * Lk_[c * DC + m];
+                dst[c] -= s; }
+        }
+        for (int t = tid; t < nb * DC * NR; t += 1024) {
+            const int r = t / (nb * DC), q = t - r * nb * DC, kr = q / DC, a = q - kr * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) s += sPanel[kr * BB + a * DC + m] * sY[r * DC + m];
+            Y[(size_t)r * n + (size_t)(j + 1 + kr) * DC + a] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// forward substitution with an existing factor: Y <- L^-1 Y  (NR right-hand sides)
+template <int DC, int NR>
+__global__ void __launch_bounds__(256)
+k_band_fwd(const double* __restrict__ band, const double* __restrict__ Linv, double* __restrict__ Y, int N, int b) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;                       // ring of the last b solutions: [b][NR*DC]
+    double* sPart = sX + (size_t)b * NR * DC;   // [b][NR*DC] partial products
+    double* sAcc = sPart + (size_t)b * NR * DC; // NR*DC
+    const int W = b + 1, n = N * DC, tid = threadIdx.x;
+    for (int j = 0; j < N; j++) {
+        const int nb = min(b, j);
+        for (int t = tid; t < nb * DC * NR; t += blockDim.x) {
+            const int r = t / (nb * DC), q = t - r * nb * DC, d = q / DC + 1, a = q - (d - 1) * DC;
+            const double* blk = band + (((size_t)j) * W + d) * BB + a * DC;       // row a of block (j, j-d)
+            const double* x = sX + ((size_t)((j - d) % b) * NR + r) * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) s += blk[m] * x[m];
+            sPart[((size_t)(d - 1) * NR + r) * DC + a] = s;
+        }
+        __syncthreads();
+        if (tid < NR * DC) {
+            const int r = tid / DC, a = tid - r * DC;
+            double s = Y[(size_t)r * n + (size_t)j * DC + a];
+            for (int d = 0; d < nb; d++) s -= sPart[((size_t)d * NR + r) * DC + a];
+            sAcc[tid] = s;
+        }
+        __syncthreads();
+        if (tid < NR * DC) {
+            const int r = tid / DC, a = tid - r * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < DC; k++) if (k <= a) s += Linv[(size_t)j * BB + a * DC + k] * sAcc[r * DC + k];
+            Y[(size_t)r * n + (size_t)j * DC + a] = s;
+            if (b > 0) sX[((size_t)(j % b) * NR + r) * DC + a] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// backward substitution: Y <- L^-T Y
+template <int DC, int NR>
+__global__ void __launch_bounds__(256)
+k_band_back(const double* __restrict__ band, const double* __restrict__ Linv, double* __restrict__ Y, int N, int b) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;
+    double* sPart = sX + (size_t)b * NR * DC;
+    double* sAcc = sPart + (size_t)b * NR * DC;
+    const int W = b + 1, n = N * DC, tid = threadIdx.x;
+    for (int j = N - 1; j >= 0; j--) {
+        const int nb = min(b, N - 1 - j);
+        for (int t = tid; t < nb * DC * NR; t += blockDim.x) {
+            const int r = t / (nb * DC), q = t - r * nb * DC, d = q / DC + 1, a = q - (d - 1) * DC;
+            const double* blk = band + (((size_t)(j + d)) * W + d) * BB;          // block (j+d, j); need column a of it
+            const double* x = sX + ((size_t)((j + d) % b) * NR + r) * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) s += blk[m * DC + a] * x[m];
+            sPart[((size_t)(d - 1) * NR + r) * DC + a] = s;
+        }
+        __syncthreads();
+        if (tid < NR * DC) {
+            const int r = tid / DC, a = tid - r * DC;
+            double s = Y[(size_t)r * n + (size_t)j * DC + a];
+            for (int d = 0; d < nb; d++) s -= sPart[((size_t)d * NR + r) * DC + a];
+            sAcc[tid] = s;
+        }
+        __syncthreads();
+        if (tid < NR * DC) {
+            const int r = tid / DC, a = tid - r * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < DC; k++) if (k >= a) s += Linv[(size_t)j * BB + k * DC + a] * sAcc[r * DC + k];   // L_jj^-T
+            Y[(size_t)r * n + (size_t)j * DC + a] = s;
+            if (b > 0) sX[((size_t)(j % b) * NR + r) * DC + a] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// Arrow combine for the focal border:  [B s; s^T sigma] [y; phi] = [r; rho]
+//   v = B^-1 r (V, permuted), u = B^-1 s (U, permuted), phi = (rho - s.v)/(sigma - s.u), y = v - u phi
+// Writes the un-permuted result out[c*DC+a], out[n] = phi.
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_band_combine(const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
+               const double* __restrict__ rho_ptr, const int* __restrict__ pos, int Nc, double* __restrict__ out) {
+    __shared__ double red[2 * 16];
+    __shared__ double sphi;
+    const int n = Nc * DC;
+    double acc[2] = {0, 0};
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a;
+        acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi];
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) sphi = (rho_ptr[0] - acc[0]) / (Sff[0] - acc[1]);
+    __syncthreads();
+    const double phi = sphi;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a;
+        out[t] = V[pi] - U[pi] * phi;
+    }
+    if (threadIdx.x == 0) out[n] = phi;
+}
+
+// ---- refinement PCG around the banded preconditioner (single-workgroup vector kernels) -----------------
+// r = b - q ; flags
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_ref_residual(const double* __restrict__ bvec, const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ Sfc,
+               const double* __restrict__ Sff, int Nc, double tol2, double* __restrict__ r, double* __restrict__ pcg) {
+    __shared__ double red[2 * 16];
+    __shared__ double sqf;
+    const int n = Nc * DC;
+    double a0[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a0[0] += Sfc[i] * x[i];
+    block_sum<1>(a0, red);
+    if (threadIdx.x == 0) sqf = Sff[0] * x[n] + a0[0];
+    __syncthreads();
+    double a2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        const double qi = (i < n) ? q[i] : sqf;
+        const double ri = bvec[i] - qi; r[i] = ri;
+        a2[0] += ri * ri; a2[1] += bvec[i] * bvec[i];
+    }
+    block_sum<2>(a2, red);
+    if (threadIdx.x == 0) {
+        pcg[PCG_RR] = a2[0]; pcg[PCG_BN2] = a2[1]; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0;
+        pcg[PCG_DONE] = (a2[0] <= tol2 * a2[1]) ? 1.0 : 0.0;
+    }
+}
+// direction: rz = r.z ; p = z + (rz/rz_old) p  (first = 1: p = z)
+__global__ void __launch_bounds__(1024)
+k_ref_direction(const double* __restrict__ r, const double* __restrict__ z, int n1, int first, double* __restrict__ p, double* __restrict__ pcg) {
+    __shared__ double red[16];
+    __shared__ double sbeta;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) acc[0] += r[i] * z[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) { sbeta = first ? 0.0 : acc[0] / pcg[PCG_RZ]; pcg[PCG_RZ] = acc[0]; }
+    __syncthreads();
+    const double beta = sbeta;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) p[i] = z[i] + (first ? 0.0 : beta * p[i]);
+}
+// step: q_f, alpha = rz / p.q ; x += alpha p ; r -= alpha q ; rr ; done?
+template <int DC>
+__global__ void __launch_bounds__(1024)
+k_ref_step(const double* __restrict__ Sfc, const double* __restrict__ Sff, int Nc, double tol2, const double* __restrict__ p,
+           const double* __restrict__ q, const double* __restrict__ pqpart, double* __restrict__ x, double* __restrict__ r, double* __restrict__ pcg) {
+    __shared__ double red[2 * 16];
+    __shared__ double sh[2];
+    const int n = Nc * DC;
+    const double pf = p[n];
+    double acc[2] = {0, 0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc[0] += Sfc[i] * p[i];
+    for (int c = threadIdx.x; c < Nc; c += blockDim.x) acc[1] += pqpart[c];
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { const double qf = Sff[0] * pf + acc[0]; sh[0] = qf; sh[1] = acc[1] + pf * qf; }
+    __syncthreads();
+    const double qf = sh[0], pq = sh[1];
+    if (!(pq > 0.0)) { if (threadIdx.x == 0) { pcg[PCG_DONE] = 1.0; pcg[PCG_BREAKDOWN] = 1.0; } return; }
+    const double alpha = pcg[PCG_RZ] / pq;
+    double a1[1] = {0.0};
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        const double qi = (i < n) ? q[i] : qf;
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * qi; r[i] = ri; a1[0] += ri * ri;
+    }
+    block_sum<1>(a1, red);
+    if (threadIdx.x == 0) { pcg[PCG_RR] = a1[0]; pcg[PCG_ITERS] += 1.0; if (a1[0] <= tol2 * pcg[PCG_BN2]) pcg[PCG_DONE] = 1.0; }
+}
+
+}  // namespace ssfm
