@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- BA observations/second on the BASELINE.json configs[1] workload.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path: one `SfM::Optimize()`-equivalent solve (device LM loop: linearise +
+Schur assembly + reduced solve + back-substitution + candidate cost, every iteration until Ceres' termination
+tests fire) of the 300-camera / 100k-point / 600k-observation synthetic circle, general BA (6-dof cameras,
+camera 0 fixed, focal fixed -- the calibrated configuration of configs[1]).  The flattened problem is resident in
+HBM before the timed region (ssfm_ba_create); each step restores the initial parameters on the device
+(ssfm_ba_reset) and runs ssfm_ba_run.  value = M * n_LM / t  with n_LM = linearisations over the K steps
+(SURVEY.md 8d), whole job, max time over ranks.
+
+N > 1: points are sharded over ranks (cameras replicated), one RCCL all-reduce of the partial reduced system per
+LM iteration; the problem size is fixed, so scaling is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(M, nP, nnzb, dc, focal_free):
+    """per LM iteration 72 B/observation + 240 B/point (+ the S term, reported separately)."""
+    per_iter = 72.0 * M + 240.0 * nP
+    # pass A alone (k_schur_rows): obs 16 + ids 8 per observation; X 24 + V^-1 48 + g 24 (+ Wf 24) per point; S row blocks written
+    schur = 24.0 * M + (96.0 + (24.0 if focal_free else 0.0)) * nP + nnzb * dc * dc * 8.0
+    return per_iter, schur
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cameras", type=int, default=300)
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--obs-per-point", type=int, default=6)
+    ap.add_argument("--mode", choices=["general", "spherical"], default="general")
+    ap.add_argument("--focal-free", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from spherical_sfm_amd import ba, synth
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    stream = torch.cuda.Stream()
+    ctx = ba.Context(local_rank, stream=stream.cuda_stream)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(ba.Context.unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().tolist()), world, rank)
+
+    spherical = args.mode == "spherical"
+    prob = synth.make_circle(args.cameras, args.points, args.obs_per_point, spherical=spherical, focal_fixed=not args.focal_free)
+    adj = ba.BundleAdjuster(ctx, prob)
+
+    def one_step():
+        adj.reset()
+        return adj.run()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        s = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    n_lm = 0; phase = {"t_kernel_linearize_ms": 0.0, "t_kernel_schur_ms": 0.0, "t_kernel_pcg_ms": 0.0, "t_kernel_update_ms": 0.0}
+    for _ in range(args.steps):
+        s = one_step()
+        n_lm += s["num_linearizations"]
+        for k in phase:
+            phase[k] += s[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    M = int(s["num_residual_blocks_global"])
+    value = M * n_lm / elapsed
+
+    # ---- per-kernel durations: one extra step with every launch bracketed by hipEvents on the solver's stream
+    adj.set_profiling(True)
+    sp = one_step()
+    ktimes = adj.kernel_times()
+    adj.set_profiling(False)
+    cams_gpu, pts_gpu, f_gpu = [np.copy(a) if hasattr(a, "copy") else a for a in adj.download()]
+
+    out = None
+    if rank == 0:
+        dc = s["camera_dof"]
+        # structure sizes for the byte model
+        nnzb = s["reduced_blocks"]
+        per_iter_bytes, schur_bytes = algorithmic_bytes(M, args.points, nnzb, dc, args.focal_free)
+        kern = {k: {"launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / max(1, v["launches"])} for k, v in ktimes.items()}
+        dom = "k_schur_rows"
+        dom_us = kern.get(dom, {}).get("avg_us", float("nan"))
+        achieved = (schur_bytes / world) / (dom_us * 1e-6) / 1e9 if dom_us == dom_us else None
+        iter_ms = sum(phase.values()) / max(1, n_lm)
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "BA obs/sec (Jac+Schur+PCG)", "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.cameras} cams x {args.points} pts x {M} obs synthetic circle (BASELINE configs[1]), "
+                                   f"{args.mode} BA, focal {'free' if args.focal_free else 'fixed'}, CauchyLoss(1.0), Ceres-default LM",
+                       "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": schur_bytes / world, "avg_launch_us": dom_us},
+            "roofline_lm_iteration": {"bound": "hbm", "algorithmic_bytes": per_iter_bytes, "avg_device_ms": iter_ms,
+                                      "achieved": per_iter_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else None,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": per_iter_bytes / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else None},
+            "kernels": kern,
+            "phases_ms_per_lm_iteration": {k: v / max(1, n_lm) for k, v in phase.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O   # checker + timed CPU baseline ("port"): a proxy for the Ceres path
+            best = None
+            for _ in range(args.cpu_reps):
+                oc, op, of, os_ = O.ba_solve(prob)
+                if best is None or os_["t_total_s"] < best["t_total_s"]:
+                    best = os_
+            cpu_obs_s = best["num_residual_blocks"] * best["num_linear_solves"] / (best["t_total_s"] - best["t_flatten_s"])
+            err_c = float(np.abs(cams_gpu - oc).max() / np.abs(oc).max())
+            err_p = float((np.linalg.norm(pts_gpu - op, axis=1) / np.linalg.norm(op, axis=1)).max())
+            out["cpu_baseline"] = {"value": cpu_obs_s, "unit": "obs/s", "cores": best["threads_used"], "kind": "port",
+                                   "sample": f"the full step workload (one Optimize-equivalent solve, {best['num_linear_solves']} LM iterations), "
+                                             f"best of {args.cpu_reps}; LM loop only, flatten excluded on both sides",
+                                   "host_cpus": os.cpu_count(), "solve_s": best["t_total_s"] - best["t_flatten_s"],
+                                   "end_to_end_s": best["t_total_s"]}
+            out["parity_vs_oracle"] = {"max_rel_camera": err_c, "max_rel_point": err_p, "iterations_gpu": sp["iterations"],
+                                       "iterations_cpu": best["iterations"]}
+            out["speedup_vs_cpu_lm_loop"] = value / cpu_obs_s
+        print(json.dumps(out))
+    adj.close(); ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

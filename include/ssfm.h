@@ -96,9 +96,23 @@ typedef struct {
     int32_t camera_dof;           /* 3 = spherical (all translations fixed), 6 = general */
     double t_flatten_s, t_upload_s, t_solve_s, t_download_s;   /* host wall-clock */
     double t_kernel_linearize_ms, t_kernel_schur_ms, t_kernel_pcg_ms, t_kernel_update_ms; /* hipEvent sums */
+    int32_t reduced_blocks;       /* non-zero DCxDC blocks of the reduced camera system */
+    int32_t band_half_width;      /* block half-bandwidth of S in the Cuthill-McKee order */
 } ssfm_ba_summary;
 
 void ssfm_ba_default_options(ssfm_ba_options* o);
+
+/* Host-only planning (no GPU needed): what the flatten rules of src/sfm.cpp:240-263 keep, how the used points
+ * are sharded over ranks (contiguous ranges balanced by observations), and the camera elimination order. */
+typedef struct {
+    int32_t camera_dof, num_points_used, num_points_used_global, reduced_blocks, band_half_width, max_row_blocks;
+    int64_t num_observations_used, num_observations_used_global;
+} ssfm_ba_plan_info;
+/* point_ids: [num_points] capacity or NULL (receives the original ids of this rank's used points, in order);
+ * obs_used: [num_observations] or NULL (1 where the observation enters this rank's problem);
+ * cam_pos: [num_cameras] or NULL (camera -> position in the elimination order). */
+int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
+                 uint8_t* obs_used, int32_t* cam_pos);
 
 /* One call = flatten (src/sfm.cpp:240-263 rules) + upload + device LM loop + scatter back. */
 int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s);

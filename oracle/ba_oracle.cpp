@@ -545,6 +545,68 @@ extern "C" int oracle_ba_evaluate(const oracle_ba_problem* p, const oracle_lm_op
     return 0;
 }
 
+// Dense reduced camera system of the UNSCALED robustified Jacobian at the given state, in a fixed layout
+// (index 0 = focal, 1 + 6*c + k = camera c dof k; constant / absent parameters give zero rows):
+//   S = F^T F - F^T E (E^T E + mu I)^-1 E^T F,   rhs = F^T r - F^T E (E^T E + mu I)^-1 E^T r.
+// It is a plain sum over points, which is what the multi-GPU sharding relies on (tests/test_multirank_cpu.py).
+extern "C" int oracle_ba_reduced_system(const oracle_ba_problem* p, const oracle_lm_options* o, double mu, double* S_out, double* rhs_out) {
+    set_threads(1);
+    const int Nc = p->num_cameras, n = 6 * Nc + 1;
+    std::fill(S_out, S_out + (size_t)n * n, 0.0); std::fill(rhs_out, rhs_out + n, 0.0);
+    BAOracle B; B.loss_type = o->loss_type; B.loss_a = o->loss_scale;
+    if (!B.flatten(*p, nullptr)) return 1;
+    std::vector<double> x, g(B.nx); B.initial_x(x);
+    double c = 0; B.linearize(x.data(), &c, g.data());
+    const int nP = (int)B.used_pt.size();
+    for (int q = 0; q < nP; q++) {
+        const int j0 = B.pt_start[q], K = B.pt_start[q + 1] - j0;
+        const bool pfree = B.pt_idx[q] >= 0;
+        double V[9] = {mu, 0, 0, 0, mu, 0, 0, 0, mu}, gpv[3] = {0, 0, 0};
+        std::vector<double> F((size_t)K * 2 * 7), E((size_t)K * 2 * 3);   // per residual row: [Jf, Jc(6)] and Jp(3)
+        for (int k = 0; k < K; k++) {
+            const ObsLin& L = B.lin[j0 + k]; const int c6 = B.ob_cam[j0 + k] * 6;
+            for (int a = 0; a < 2; a++) {
+                double* f = &F[((size_t)k * 2 + a) * 7]; double* e = &E[((size_t)k * 2 + a) * 3];
+                f[0] = B.focal_free ? L.Jf[a] : 0.0;
+                for (int d = 0; d < 6; d++) f[1 + d] = B.cam_idx[c6 + d] >= 0 ? L.Jc[a][d] : 0.0;
+                for (int d = 0; d < 3; d++) e[d] = pfree ? L.Jp[a][d] : 0.0;
+                for (int u = 0; u < 3; u++) { gpv[u] += e[u] * L.r[a]; for (int v = 0; v < 3; v++) V[u * 3 + v] += e[u] * e[v]; }
+            }
+        }
+        const double Vs[6] = {V[0], V[1], V[2], V[4], V[5], V[8]};
+        double Vi6[6];
+        { const double c00 = Vs[3] * Vs[5] - Vs[4] * Vs[4], c01 = Vs[2] * Vs[4] - Vs[1] * Vs[5], c02 = Vs[1] * Vs[4] - Vs[2] * Vs[3];
+          const double id = 1.0 / (Vs[0] * c00 + Vs[1] * c01 + Vs[2] * c02);
+          Vi6[0] = c00 * id; Vi6[1] = c01 * id; Vi6[2] = c02 * id; Vi6[3] = (Vs[0] * Vs[5] - Vs[2] * Vs[2]) * id;
+          Vi6[4] = (Vs[1] * Vs[2] - Vs[0] * Vs[4]) * id; Vi6[5] = (Vs[0] * Vs[3] - Vs[1] * Vs[1]) * id; }
+        const double Vi[9] = {Vi6[0], Vi6[1], Vi6[2], Vi6[1], Vi6[3], Vi6[4], Vi6[2], Vi6[4], Vi6[5]};
+        // global column index of local f-column (k, d)
+        auto col = [&](int k, int d) { return d == 0 ? 0 : 1 + B.ob_cam[j0 + k] * 6 + (d - 1); };
+        // W_k = sum_a f_row^T e_row (7x3) per observation
+        std::vector<double> W((size_t)K * 21, 0.0);
+        for (int k = 0; k < K; k++)
+            for (int a = 0; a < 2; a++) {
+                const double* f = &F[((size_t)k * 2 + a) * 7]; const double* e = &E[((size_t)k * 2 + a) * 3];
+                const double r = B.lin[j0 + k].r[a];
+                for (int d = 0; d < 7; d++) {
+                    rhs_out[col(k, d)] += f[d] * r;
+                    for (int d2 = 0; d2 < 7; d2++) S_out[(size_t)col(k, d) * n + col(k, d2)] += f[d] * f[d2];
+                    for (int u = 0; u < 3; u++) W[(size_t)k * 21 + d * 3 + u] += f[d] * e[u];
+                }
+            }
+        for (int k = 0; k < K; k++)
+            for (int d = 0; d < 7; d++) {
+                double T[3];
+                for (int u = 0; u < 3; u++) T[u] = W[(size_t)k * 21 + d * 3] * Vi[u] + W[(size_t)k * 21 + d * 3 + 1] * Vi[3 + u] + W[(size_t)k * 21 + d * 3 + 2] * Vi[6 + u];
+                rhs_out[col(k, d)] -= T[0] * gpv[0] + T[1] * gpv[1] + T[2] * gpv[2];
+                for (int k2 = 0; k2 < K; k2++)
+                    for (int d2 = 0; d2 < 7; d2++)
+                        S_out[(size_t)col(k, d) * n + col(k2, d2)] -= T[0] * W[(size_t)k2 * 21 + d2 * 3] + T[1] * W[(size_t)k2 * 21 + d2 * 3 + 1] + T[2] * W[(size_t)k2 * 21 + d2 * 3 + 2];
+            }
+    }
+    return 0;
+}
+
 extern "C" void oracle_so3exp(const double r[3], double R[9]) { so3exp(r, R); }
 extern "C" void oracle_so3ln(const double R[9], double r[3]) { so3ln(R, r); }
 extern "C" void oracle_angle_axis_rotate_point(const double aa[3], const double pt[3], double out[3]) { AngleAxisRotatePoint<double>(aa, pt, out); }

@@ -64,6 +64,8 @@ def lib():
         L.oracle_ba_evaluate.argtypes = [C.POINTER(BAProblemC), C.POINTER(LMOptionsC), C.c_int32, c_double_p,
                                          c_double_p, c_double_p, c_u8_p]
         L.oracle_ba_evaluate.restype = C.c_int
+        L.oracle_ba_reduced_system.argtypes = [C.POINTER(BAProblemC), C.POINTER(LMOptionsC), C.c_double, c_double_p, c_double_p]
+        L.oracle_ba_reduced_system.restype = C.c_int
         for name in ("oracle_so3exp", "oracle_so3ln", "oracle_angle_axis_to_rotation_matrix",
                      "oracle_rotation_matrix_to_angle_axis"):
             getattr(L, name).argtypes = [c_double_p, c_double_p]
@@ -138,6 +140,16 @@ def ba_evaluate(prob, raw=False, options=None):
     res = np.zeros((M, 2)); jac = np.zeros((M, 2, 10)); used = np.zeros(M, np.uint8)
     lib().oracle_ba_evaluate(C.byref(h.c), C.byref(o), 1 if raw else 0, C.byref(cost), _dp(res), _dp(jac), _up(used))
     return cost.value, res, jac, used
+
+
+def ba_reduced_system(prob, mu=1.0, options=None):
+    """Dense S ((6Nc+1)^2) and rhs of the unscaled Schur complement at the problem's state (tests only)."""
+    h = _Held(prob)
+    o = options or default_options()
+    n = 6 * len(h.cams) + 1
+    S = np.zeros((n, n)); rhs = np.zeros(n)
+    lib().oracle_ba_reduced_system(C.byref(h.c), C.byref(o), mu, _dp(S), _dp(rhs))
+    return S, rhs
 
 
 def _vec3(fn, a, n_out):

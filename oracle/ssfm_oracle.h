@@ -64,6 +64,10 @@ int oracle_ba_solve(oracle_ba_problem* p, const oracle_lm_options* o, oracle_sum
 int oracle_ba_evaluate(const oracle_ba_problem* p, const oracle_lm_options* o, int32_t raw,
                        double* cost, double* residuals, double* jacobians, uint8_t* obs_used);
 
+/* dense reduced camera(+focal) system at the given state, fixed layout [focal | 6 per camera], size (6Nc+1)^2;
+ * unscaled robustified Jacobian, point blocks damped by mu.  Small problems only (tests). */
+int oracle_ba_reduced_system(const oracle_ba_problem* p, const oracle_lm_options* o, double mu, double* S_out, double* rhs_out);
+
 /* SO(3) helpers (reference src/so3.cpp); matrices column-major */
 void oracle_so3exp(const double r[3], double R[9]);
 void oracle_so3ln(const double R[9], double r[3]);

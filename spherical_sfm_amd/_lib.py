@@ -40,7 +40,16 @@ class BASummaryC(C.Structure):
                 ("num_residual_blocks_global", C.c_int64), ("num_points_used", C.c_int32), ("camera_dof", C.c_int32),
                 ("t_flatten_s", C.c_double), ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double),
                 ("t_kernel_linearize_ms", C.c_double), ("t_kernel_schur_ms", C.c_double), ("t_kernel_pcg_ms", C.c_double),
-                ("t_kernel_update_ms", C.c_double)]
+                ("t_kernel_update_ms", C.c_double), ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BAPlanInfoC(C.Structure):
+    _fields_ = [("camera_dof", C.c_int32), ("num_points_used", C.c_int32), ("num_points_used_global", C.c_int32),
+                ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32), ("max_row_blocks", C.c_int32),
+                ("num_observations_used", C.c_int64), ("num_observations_used_global", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -49,7 +58,7 @@ class BASummaryC(C.Structure):
 # every symbol include/ssfm.h declares (tests check that the library exports all of them)
 DECLARED_SYMBOLS = [
     "ssfm_ctx_create", "ssfm_ctx_destroy", "ssfm_last_error", "ssfm_version", "ssfm_comm_unique_id", "ssfm_comm_init",
-    "ssfm_ba_default_options", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
+    "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
 ]
 
@@ -76,6 +85,7 @@ def lib():
     L.ssfm_comm_unique_id.argtypes = [c_u8_p]; L.ssfm_comm_unique_id.restype = C.c_int
     L.ssfm_comm_init.argtypes = [vp, c_u8_p, C.c_int32, C.c_int32]; L.ssfm_comm_init.restype = C.c_int
     L.ssfm_ba_default_options.argtypes = [C.POINTER(BAOptionsC)]; L.ssfm_ba_default_options.restype = None
+    L.ssfm_ba_plan.argtypes = [C.POINTER(BAProblemC), C.c_int32, C.c_int32, C.POINTER(BAPlanInfoC), c_i32_p, c_u8_p, c_i32_p]; L.ssfm_ba_plan.restype = C.c_int
     L.ssfm_ba_solve.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]; L.ssfm_ba_solve.restype = C.c_int
     L.ssfm_ba_create.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAOptionsC), C.POINTER(vp)]; L.ssfm_ba_create.restype = C.c_int
     L.ssfm_ba_reset.argtypes = [vp]; L.ssfm_ba_reset.restype = C.c_int

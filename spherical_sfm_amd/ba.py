@@ -72,6 +72,17 @@ class _ProblemBuffers:
                             p(self.rf, c_u8_p), p(self.tf, c_u8_p), p(self.pf, c_u8_p), 1 if prob.focal_fixed else 0)
 
 
+def plan(prob, nranks=1, rank=0):
+    """Host-only (no GPU): flatten + shard.  Returns (info dict, point ids of this rank, obs_used mask, camera order)."""
+    b = _ProblemBuffers(prob)
+    info = _lib.BAPlanInfoC()
+    ids = np.zeros(len(b.pts), np.int32); used = np.zeros(len(b.oc), np.uint8); pos = np.zeros(len(b.cams), np.int32)
+    _lib.check(_lib.lib().ssfm_ba_plan(C.byref(b.c), nranks, rank, C.byref(info), ids.ctypes.data_as(c_i32_p),
+                                       used.ctypes.data_as(c_u8_p), pos.ctypes.data_as(c_i32_p)))
+    d = info.as_dict()
+    return d, ids[:d["num_points_used"]].copy(), used, pos
+
+
 def optimize(ctx, prob, options=None, **kw):
     """One call: flatten + upload + device LM + scatter back.  Returns (cameras, points, focal, summary)."""
     b = _ProblemBuffers(prob)

@@ -346,6 +346,22 @@ extern "C" void ssfm_ba_default_options(ssfm_ba_options* o) {
     o->verbose = 0;
 }
 
+extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
+                            uint8_t* obs_used, int32_t* cam_pos) {
+    if (!p || !info || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ba_plan: bad arguments");
+    BAFlat F; ba_flatten(*p, nranks, rank, F);
+    std::memset(info, 0, sizeof(*info));
+    if (obs_used) std::memset(obs_used, 0, (size_t)p->num_observations);
+    if (F.nothing_to_do) return SSFM_OK;
+    info->camera_dof = F.DC; info->num_points_used = F.nP; info->num_points_used_global = F.nP_global;
+    info->reduced_blocks = F.row_ptr[F.Nc]; info->band_half_width = F.band; info->max_row_blocks = F.max_row_blocks;
+    info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
+    if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];
+    if (obs_used) for (int64_t j = 0; j < F.M; j++) obs_used[F.obs_orig[j]] = 1;
+    if (cam_pos) for (int c = 0; c < F.Nc; c++) cam_pos[c] = F.cam_pos[c];
+    return SSFM_OK;
+}
+
 extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_handle** out) {
     if (!ctx || !p || !out) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_create: null argument");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -406,13 +422,15 @@ extern "C" int ssfm_ba_run(ssfm_ba_handle* h, ssfm_ba_summary* s) {
     if (!h || !s) return SSFM_ERR_INVALID;
     std::memset(s, 0, sizeof(*s));
     const BAFlat& F = h->F;
+    const int32_t nblk = F.nothing_to_do ? 0 : F.row_ptr[F.Nc];
     s->num_residual_blocks = F.M; s->num_residual_blocks_global = F.M_global; s->num_points_used = F.nP; s->camera_dof = F.DC;
+    s->reduced_blocks = F.nothing_to_do ? 0 : F.row_ptr[F.Nc]; s->band_half_width = F.band;
     if (F.nothing_to_do) { s->termination = SSFM_NOTHING_TO_DO; return SSFM_OK; }
     SSFM_HIP_CHECK(h->ctx, hipSetDevice(h->ctx->device));
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     const double t0 = wall_s();
     int rc = (F.DC == 3) ? lm_loop<3>(h, s) : lm_loop<6>(h, s);
-    s->t_solve_s = wall_s() - t0;
+    s->t_solve_s = wall_s() - t0; s->reduced_blocks = nblk; s->band_half_width = F.band;
     return rc;
 }
 

@@ -1,0 +1,67 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/), in this repository's container.
+
+The reference holds no golden vectors for this path and cannot be built here, so these fixtures pin
+the ORACLE's behaviour (regression + cross-machine determinism) and give the HIP path fixed targets; they do not
+pin the reference.  Re-run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O          # noqa: E402
+from spherical_sfm_amd import synth     # noqa: E402
+
+
+def so3_cases():
+    rng = np.random.default_rng(11)
+    angles = [0.0, 1e-12, 1e-9, 1e-4, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi - 1e-6, np.pi - 1e-3, 2.0]
+    rs = []
+    for a in angles:
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        rs.append(ax * a)
+    rs = np.array(rs)
+    R = np.array([O.so3exp(r) for r in rs])
+    ln = np.array([O.so3ln(Ri) for Ri in R])
+    Rc = np.array([O.angle_axis_to_rotation_matrix(r) for r in rs])
+    aac = np.array([O.rotation_matrix_to_angle_axis(Ri) for Ri in R])
+    pts = rng.normal(size=(len(rs), 3))
+    rot = np.array([O.angle_axis_rotate_point(r, p) for r, p in zip(rs, pts)])
+    return dict(r=rs, so3exp=R, so3ln=ln, ceres_R=Rc, ceres_aa=aac, pts=pts, rotated=rot)
+
+
+def ba_case(spherical, focal_fixed):
+    p = synth.make_circle(60, 240, 6, spherical=spherical, focal_fixed=focal_fixed, seed=99)
+    p.cameras[0, 3:] = 0.0
+    cost, res, jac, used = O.ba_evaluate(p)
+    cams, pts, f, s = O.ba_solve(p)
+    return dict(cameras0=p.cameras, points0=p.points, focal0=p.focal, obs_xy=p.obs_xy, obs_cam=p.obs_cam, obs_pt=p.obs_pt,
+                rot_fixed=p.rot_fixed, trans_fixed=p.trans_fixed, pt_fixed=p.pt_fixed, focal_fixed=int(p.focal_fixed),
+                cost0=cost, residuals0=res, jacobians0=jac, cameras=cams, points=pts, focal=f,
+                iterations=s["iterations"], final_cost=s["final_cost"], initial_cost=s["initial_cost"])
+
+
+def rot_case():
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(24, 4, seed=5, outlier_frac=0.05)
+    R, cost, s = O.optimize_rotations(R0, i0, i1, Rrel)
+    c0 = O.get_cost(R0, i0, i1, Rrel)
+    R2, f2, cost2, s2 = O.optimize_rotations_and_focal_length(R0, i0, i1, Rrel, 800.0, 400.0, 1600.0)
+    edges = []
+    rng = np.random.default_rng(3)
+    for kind in (0, 1, 2):
+        for _ in range(4):
+            r0 = rng.normal(size=3) * 0.5; r1 = rng.normal(size=3) * 0.5; Rm = O.so3exp(rng.normal(size=3) * 0.4)
+            res, jac = O.rotation_edge(kind, r0, r1, 1.1, Rm, 0.7)
+            edges.append(np.concatenate([[kind], r0, r1, Rm.reshape(-1), res, jac.reshape(-1)]))
+    return dict(R0=R0, i0=i0, i1=i1, Rrel=Rrel, R=R, cost=cost, cost0=c0, iterations=s["iterations"], R_focal=R2, focal=f2,
+                cost_focal=cost2, edges=np.array(edges))
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "so3.npz"), **so3_cases())
+    for sph in (True, False):
+        for ff in (True, False):
+            np.savez_compressed(os.path.join(HERE, f"ba_s{int(sph)}_f{int(ff)}.npz"), **ba_case(sph, ff))
+    np.savez_compressed(os.path.join(HERE, "rotavg.npz"), **rot_case())
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,116 @@
+"""CPU tests of the C-ABI library itself: it loads, exports every symbol include/ssfm.h declares, refuses to run
+without a GPU (no CPU fallback), and its host-side planning (flatten rules, sharding, elimination order) is right.
+No compute kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import _lib, ba, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "ssfm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssfm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = header_functions()
+    assert declared, "no functions parsed from include/ssfm.h"
+    for name in declared:
+        assert hasattr(L, name), f"libssfm_hip.so does not export {name}"
+    assert sorted(_lib.DECLARED_SYMBOLS) == declared
+    assert L.ssfm_version() >= 100
+
+
+def test_default_options_are_the_reference_values():
+    o = ba.default_options()
+    assert o.max_num_iterations == 2000 and o.max_num_consecutive_invalid_steps == 100      # src/sfm.cpp:205-206
+    assert o.loss_type == 1 and o.loss_scale == 1.0                                          # CauchyLoss(1.0), src/sfm.cpp:196
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)   # Ceres 2.2.0 defaults
+    assert (o.initial_trust_region_radius, o.min_relative_decrease, o.jacobi_scaling) == (1e4, 1e-3, 1)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.SsfmError, match="no HIP device"):
+        ba.Context(0)
+
+
+def test_struct_sizes_match_the_header():
+    # 4+4+8 + 9 pointers*8 + 4 (+4 pad)
+    assert C.sizeof(_lib.BAProblemC) == 96
+    assert C.sizeof(_lib.BAOptionsC) % 8 == 0 and C.sizeof(_lib.BASummaryC) % 8 == 0
+
+
+def test_plan_applies_the_reference_flatten_rules():
+    p = synth.make_circle(60, 400, 6)
+    p.points[11] = 0.0                                                   # |X| == 0 (src/sfm.cpp:243)
+    keep = ~((p.obs_pt == 20) & (np.arange(len(p.obs_pt)) % 6 >= 2))     # 2 observations left (src/sfm.cpp:254)
+    p.obs_xy, p.obs_cam, p.obs_pt = p.obs_xy[keep], p.obs_cam[keep], p.obs_pt[keep]
+    info, ids, used, pos = ba.plan(p)
+    assert info["num_points_used"] == 398 and info["num_observations_used"] == 6 * 398
+    assert 11 not in ids and 20 not in ids and (np.diff(ids) > 0).all()
+    assert not used[p.obs_pt == 11].any() and not used[p.obs_pt == 20].any() and used.sum() == 6 * 398
+    assert info["camera_dof"] == 3
+    p2 = synth.make_circle(60, 400, 6, spherical=False)
+    assert ba.plan(p2)[0]["camera_dof"] == 6
+
+
+def test_plan_accepts_unsorted_input_and_keeps_last_duplicate():
+    p = synth.make_circle(60, 100, 6)
+    rng = np.random.default_rng(3)
+    j = int(np.where(p.obs_pt == 5)[0][0])
+    p.obs_xy = np.vstack([p.obs_xy, p.obs_xy[j] + 1.0]); p.obs_cam = np.append(p.obs_cam, p.obs_cam[j]); p.obs_pt = np.append(p.obs_pt, 5)
+    n = len(p.obs_pt)
+    perm = np.concatenate([rng.permutation(n - 1), [n - 1]])
+    p.obs_xy, p.obs_cam, p.obs_pt = p.obs_xy[perm], p.obs_cam[perm].astype(np.int32), p.obs_pt[perm].astype(np.int32)
+    info, ids, used, pos = ba.plan(p)
+    assert info["num_observations_used"] == 600 and used.sum() == 600
+    assert used[-1] == 1 and used[np.where(perm == j)[0][0]] == 0       # the later duplicate wins (std::map assignment)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_sharding_partitions_the_used_points(nranks):
+    p = synth.make_circle(60, 1000, 6, spherical=False)
+    p.points[::97] = 0.0
+    all_ids, total_obs, sizes = [], 0, []
+    for r in range(nranks):
+        info, ids, used, pos = ba.plan(p, nranks, r)
+        assert info["num_points_used_global"] == len(p.points) - len(p.points[::97])
+        all_ids.append(ids); total_obs += info["num_observations_used"]; sizes.append(info["num_observations_used"])
+        assert used.sum() == info["num_observations_used"]
+        # every rank keeps whole points: all 6 observations of an owned point
+        assert (np.bincount(p.obs_pt[used.astype(bool)], minlength=len(p.points))[ids] == 6).all()
+    cat = np.concatenate(all_ids)
+    assert len(np.unique(cat)) == len(cat) == info["num_points_used_global"] and (np.diff(cat) > 0).all()   # disjoint, contiguous ranges
+    assert total_obs == info["num_observations_used_global"]
+    assert max(sizes) - min(sizes) <= 6 * 2                               # balanced by observation count
+
+
+def test_elimination_order_is_a_banded_permutation():
+    p = synth.make_circle(60, 600, 6)
+    info, ids, used, pos = ba.plan(p)
+    assert sorted(pos.tolist()) == list(range(60))
+    # cameras that share a point must sit within the reported half-bandwidth of each other
+    cams = p.obs_cam.reshape(-1, 6)
+    d = np.abs(pos[cams][:, :, None] - pos[cams][:, None, :]).max()
+    assert d == info["band_half_width"]
+    assert info["band_half_width"] <= 12          # a ring with reach 5 folds into a band of ~2*5
+    assert info["reduced_blocks"] == 60 * 11 and info["max_row_blocks"] == 11
+
+
+def test_config2_plan():
+    """BASELINE configs[1] sizes; the stride-4 recipe of SURVEY 8d gives four interleaved camera rings."""
+    p = synth.make_circle(300, 100000, 6, spherical=False)
+    info, ids, used, pos = ba.plan(p)
+    assert info["num_observations_used_global"] == 600000 and info["num_points_used_global"] == 100000
+    assert info["reduced_blocks"] == 300 * 11 and info["band_half_width"] <= 12
