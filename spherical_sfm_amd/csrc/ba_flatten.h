@@ -46,12 +46,15 @@ struct BAFlat {
     std::vector<int> cam_pos;           // [Nc] camera -> position
     int band = 0;                       // block half-bandwidth in that order
     std::vector<int> band_pairs;        // (i_rel | k_rel << 16), i_rel-major, 1 <= k_rel <= i_rel <= band
+    std::vector<int> comp_ptr;          // connected components of the camera graph = contiguous position ranges
 };
 
 // Cuthill-McKee order of the camera graph given as block-CSR structure (folds a ring into a band of twice
 // its reach; any connected "video-like" graph becomes a narrow band).  Returns the half-bandwidth.
-inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos) {
+inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos,
+                         std::vector<int>* comp_ptr = nullptr) {
     pos.assign(n, -1);
+    if (comp_ptr) comp_ptr->assign(1, 0);
     std::vector<int> order; order.reserve(n);
     std::vector<int> queue, nb;
     auto degree = [&](int v) { return row_ptr[v + 1] - row_ptr[v]; };
@@ -72,6 +75,7 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
             std::sort(nb.begin(), nb.end(), [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
             for (int v : nb) { pos[v] = (int)order.size(); order.push_back(v); queue.push_back(v); }
         }
+        if (comp_ptr) comp_ptr->push_back((int)order.size());
     }
     int band = 0;
     for (int u = 0; u < n; u++) for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) band = std::max(band, std::abs(pos[u] - pos[col_idx[e]]));
@@ -134,7 +138,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             F.diag_slot[c] = (int)(std::lower_bound(nb[c].begin(), nb[c].end(), c) - nb[c].begin());
         }
     }
-    F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos);
+    F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     F.mask_cam.assign((size_t)Nc * 6, 0.0);
     bool all_t_fixed = true;

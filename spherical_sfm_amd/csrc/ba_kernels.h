@@ -140,10 +140,11 @@ __global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ r
 }
 
 // ---- one-time: squared column norms of the unscaled robustified Jacobian (Jacobi scaling, iteration 0)
+// points + focal: one lane per point;  cameras: one workgroup per camera over its observation list (no atomics)
 __global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                           const int* __restrict__ pt_start, int nP, int loss, double la,
-                          double* __restrict__ diag_cam, double* __restrict__ diag_pt, double* __restrict__ diag_f) {
+                          double* __restrict__ diag_pt, double* __restrict__ diag_f) {
     __shared__ double red[8];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double df[1] = {0.0};
@@ -153,18 +154,32 @@ __global__ void k_colnorm(const double* __restrict__ cam, const double* __restri
         double dp[3] = {0, 0, 0};
         for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
             const int c = obs_cam[j]; const double2 o = obs_xy[j];
-            ObsLin L; lin_obs<true>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
-            for (int k = 0; k < 3; k++) {
-                dp[k] += L.Jp[0][k] * L.Jp[0][k] + L.Jp[1][k] * L.Jp[1][k];
-                unsafeAtomicAdd(&diag_cam[c * 6 + k], L.Jt[0][k] * L.Jt[0][k] + L.Jt[1][k] * L.Jt[1][k]);
-                unsafeAtomicAdd(&diag_cam[c * 6 + 3 + k], L.Jr[0][k] * L.Jr[0][k] + L.Jr[1][k] * L.Jr[1][k]);
-            }
+            ObsLin L; lin_obs<false>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+            for (int k = 0; k < 3; k++) dp[k] += L.Jp[0][k] * L.Jp[0][k] + L.Jp[1][k] * L.Jp[1][k];
             df[0] += L.Jf[0] * L.Jf[0] + L.Jf[1] * L.Jf[1];
         }
         for (int k = 0; k < 3; k++) diag_pt[3 * p + k] = dp[k];
     }
     block_sum<1>(df, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(diag_f, df[0]);
+}
+__global__ void __launch_bounds__(256)
+k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
+              const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam) {
+    __shared__ double red[6 * 4];
+    const int c = blockIdx.x;
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    const double f = focal[0];
+    for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
+        const int j = cam_obs[q], p = obs_pt[j];
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double2 o = obs_xy[j];
+        ObsLin L; lin_obs<true>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
+        for (int k = 0; k < 3; k++) { d[k] += L.Jt[0][k] * L.Jt[0][k] + L.Jt[1][k] * L.Jt[1][k]; d[3 + k] += L.Jr[0][k] * L.Jr[0][k] + L.Jr[1][k] * L.Jr[1][k]; }
+    }
+    block_sum<6>(d, red);
+    if (threadIdx.x == 0) for (int k = 0; k < 6; k++) diag_cam[c * 6 + k] = d[k];
 }
 __global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,7 +254,7 @@ k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, con
              const int* __restrict__ cam_obs, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
              const int* __restrict__ diag_slot, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
              const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
-             const double* __restrict__ Wf, int loss, double la,
+             const double* __restrict__ Wf, int loss, double la, int ncopy,
              double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
              double* __restrict__ gcraw) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -248,60 +263,53 @@ k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, con
     constexpr int NSM = NU + 3 * DC;            // U (upper), gc, rs, sfc
     const int c = blockIdx.x;
     const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    double* acc = lds;                          // [nnb*BB]
-    double* small = lds + nnb * BB;             // [NSM]
-    double* camc = small + NSM;                 // [6 + 27 + 6] camera c: t,r | rot | scale
-    for (int i = threadIdx.x; i < nnb * BB + NSM; i += blockDim.x) lds[i] = 0.0;
+    // ncopy private copies of [block row | camera-side sums]: lanes are spread over copies (and over the point's
+    // cameras) so that the lanes of a wave rarely add to the same LDS word in the same instruction
+    const int RS = nnb * BB + NSM + 1;          // doubles per copy (+1: odd stride de-phases the banks)
+    double* camc = lds + (size_t)ncopy * RS;    // [6 + 27 + 6] camera c: t,r | rot | scale
+    for (int i = threadIdx.x; i < ncopy * RS; i += blockDim.x) lds[i] = 0.0;
     if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
     if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
     __syncthreads();
+    double* acc = lds + (size_t)(threadIdx.x % ncopy) * RS;     // this lane's copy
+    double* small = acc + nnb * BB;
     const int* cols = col_idx + rb;
     const double f = focal[0], sf = scale_f[0];
-    double U[NU], gc[DC], rs[DC], sfc[DC];
-#pragma unroll
-    for (int i = 0; i < NU; i++) U[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < DC; i++) gc[i] = rs[i] = sfc[i] = 0.0;
 
     for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
         const int j = cam_obs[q], p = obs_pt[j];
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double2 o = obs_xy[j];
-        ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
-        double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
-        double Jp[2][3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { Jp[0][k] = L.Jp[0][k] * sp[k]; Jp[1][k] = L.Jp[1][k] * sp[k]; }
-        const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
+        double T[DC][3];
         {
+            ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
+            double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
+            double Jp[2][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { Jp[0][k] = L.Jp[0][k] * sp[k]; Jp[1][k] = L.Jp[1][k] * sp[k]; }
+            const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
+            const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
+            const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+            const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
             int u = 0;
 #pragma unroll
             for (int a = 0; a < DC; a++) {
-                gc[a] += Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1];
-                sfc[a] += jf0 * Jc[0][a] + jf1 * Jc[1][a];
+                const double w0 = Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0];
+                const double w1 = Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1];
+                const double w2 = Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2];
+                T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+                T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+                T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                unsafeAtomicAdd(&small[NU + a], Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1]);
+                unsafeAtomicAdd(&small[NU + DC + a], -(T[a][0] * g[0] + T[a][1] * g[1] + T[a][2] * g[2]));
+                unsafeAtomicAdd(&small[NU + 2 * DC + a], jf0 * Jc[0][a] + jf1 * Jc[1][a] - (T[a][0] * wf[0] + T[a][1] * wf[1] + T[a][2] * wf[2]));
 #pragma unroll
-                for (int b = a; b < DC; b++) U[u++] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+                for (int b = a; b < DC; b++) unsafeAtomicAdd(&small[u++], Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b]);
             }
         }
-        // T = (Jc^T Jp) V^-1
-        const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
-        const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
-        const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
-        double T[DC][3];
-#pragma unroll
-        for (int a = 0; a < DC; a++) {
-            const double w0 = Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0];
-            const double w1 = Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1];
-            const double w2 = Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2];
-            T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-            T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-            T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-            rs[a] -= T[a][0] * g[0] + T[a][1] * g[1] + T[a][2] * g[2];
-            sfc[a] -= T[a][0] * wf[0] + T[a][1] * wf[1] + T[a][2] * wf[2];
-        }
         const int j0 = pt_start[p], K = pt_start[p + 1] - j0;
-        int kk = threadIdx.x % K;                 // stagger: lanes start on different neighbours
+        int kk = (threadIdx.x / ncopy) % K;       // stagger: lanes sharing a copy start on different cameras of the point
         for (int it = 0; it < K; it++) {
             const int j2 = j0 + kk; kk = (kk + 1 == K) ? 0 : kk + 1;
             const int c2 = obs_cam[j2]; const double2 o2 = obs_xy[j2];
@@ -320,33 +328,28 @@ k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, con
             }
         }
     }
-    // fold the per-lane camera-side sums: wave shuffle, then one LDS add per wave
-    {
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int i = 0; i < NU; i++) { const double v = wave_sum(U[i]); if (lane == 0) unsafeAtomicAdd(&small[i], v); }
-#pragma unroll
-        for (int i = 0; i < DC; i++) {
-            double v = wave_sum(gc[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + i], v);
-            v = wave_sum(rs[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + DC + i], v);
-            v = wave_sum(sfc[i]); if (lane == 0) unsafeAtomicAdd(&small[NU + 2 * DC + i], v);
-        }
+    __syncthreads();
+    // fold the copies and write the row: coalesced, U_c folded into the diagonal block
+    const int ds = diag_slot[c];
+    for (int i = threadIdx.x; i < nnb * BB + NSM; i += blockDim.x) {
+        double v = 0.0;
+        for (int k = 0; k < ncopy; k++) v += lds[(size_t)k * RS + i];
+        lds[i] = v;
     }
     __syncthreads();
-    // write the row: coalesced, U_c folded into the diagonal block
-    const int ds = diag_slot[c];
+    const double* sm = lds + nnb * BB;
     for (int i = threadIdx.x; i < nnb * BB; i += blockDim.x) {
-        double v = acc[i];
+        double v = lds[i];
         const int s = i / BB, e = i - s * BB;
-        if (s == ds) { int a = e / DC, b = e - a * DC; if (a > b) { const int t = a; a = b; b = t; } v += small[a * DC - a * (a - 1) / 2 + (b - a)]; }
+        if (s == ds) { int a = e / DC, b = e - a * DC; if (a > b) { const int t = a; a = b; b = t; } v += sm[a * DC - a * (a - 1) / 2 + (b - a)]; }
         S_val[(size_t)rb * BB + i] = v;
     }
     if (threadIdx.x < DC) {
         const int a = threadIdx.x;
-        rhs[c * DC + a] = small[NU + a] + small[NU + DC + a];
-        gcraw[c * DC + a] = small[NU + a];
-        Sfc[c * DC + a] = small[NU + 2 * DC + a];
-        Udiag[c * DC + a] = small[a * DC - a * (a - 1) / 2];
+        rhs[c * DC + a] = sm[NU + a] + sm[NU + DC + a];
+        gcraw[c * DC + a] = sm[NU + a];
+        Sfc[c * DC + a] = sm[NU + 2 * DC + a];
+        Udiag[c * DC + a] = sm[a * DC - a * (a - 1) / 2];
     }
 }
 

@@ -53,7 +53,7 @@ struct ssfm_ba_handle {
     DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
     DevBuf<double> Vinv, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
-    DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail;
+    DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0;
     bool scale_ready = false;
@@ -81,7 +81,7 @@ struct ssfm_ba_handle {
         rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); gp.free(); Wf.free();
-        band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free();
+        band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
@@ -118,13 +118,17 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
 //   preconditioner 0: exact block-banded Cholesky in Cuthill-McKee order, then PCG refinement on the residual
 //   preconditioner 1: block-Jacobi PCG (kept for comparison; needs ~10^3 iterations on a camera ring)
 template <int DC>
-static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bool* ok_out) {
+static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bool* ok_out, int stage) {
+    // stage 0: enqueue the direct solve + residual check, no host sync (flags are read with the iteration scalars)
+    // stage 1: flags are in host_pcg; run PCG refinement if the residual test failed
+    // (block-Jacobi PCG, preconditioner 1, does everything in stage 0 with its own syncs)
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
     const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
     const int Nc = F.Nc, n = Nc * DC, b = F.band;
     constexpr int BB = DC * DC;
     const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
     if (O.preconditioner == 1) {
+        if (stage == 1) return SSFM_OK;
         LAUNCH(h, KID_PCG_INIT, k_pcg_init<DC>, 1, 1024, 0, h->rhs, h->Minv.p, h->Sff.p, Nc, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pcg.p);
         int launched = 0; bool done = false;
         int chunk = std::max(8, h->pcg_prev_iters + 2);
@@ -144,31 +148,49 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         *ok_out = done && host_pcg[PCG_BREAKDOWN] == 0.0;
         return SSFM_OK;
     }
+    const int ncomp = (int)F.comp_ptr.size() - 1;
+    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB) * sizeof(double);
+    const bool use_lds = lds_win <= 140 * 1024 && b * DC <= 256;
+    const int chol_threads = ((b * (b + 1) / 2) * DC <= 1024) ? 256 : 1024;
     // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
     const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
+    if (stage == 0) {
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band.p, 0, h->band.n * sizeof(double), st));
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band_fail.p, 0, sizeof(int), st));
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, PCG_TOTAL * sizeof(double), st));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
     LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
     hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
-    LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, h->band_fail.p);
-    LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
+    // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
+    if (use_lds) {
+        if (lds_win > 48 * 1024) {
+            SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_lds<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        }
+        LAUNCH(h, KID_BAND_CHOL, (k_band_chol_lds<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, h->comp_ptr.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+        LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
+    } else {
+        LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
+    }
     LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
     // ---- residual check r = rhs - S x, PCG refinement with the factor as preconditioner while it is too large
     LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->px.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
     LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
-    int fail_flag = 0;
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&fail_flag, h->band_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    *iters_out = 0; *ok_out = true;
+    return SSFM_OK;
+    }
     int it = 0;
-    if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; }     // S not positive definite: invalid step
+    { int fail_flag; std::memcpy(&fail_flag, &host_pcg[PCG_TOTAL], sizeof(int));
+      if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
     while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
-        LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
-        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+        if (use_lds) {
+            LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+        } else {
+            LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+        }
         LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
         LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);
         LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
@@ -194,20 +216,25 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
-    const size_t lds_bytes = ((size_t)F.max_row_blocks * BB + DC * (DC + 1) / 2 + 3 * DC + 39 + 1) * sizeof(double);
+    // k_schur_rows keeps `ncopy` private copies of a camera's block row in LDS (fewer same-address ds_add_f64 per wave)
+    const size_t row_doubles = (size_t)F.max_row_blocks * BB + DC * (DC + 1) / 2 + 3 * DC + 1;
+    int ncopy = 16;
+    while (ncopy > 1 && (row_doubles * ncopy + 40) * sizeof(double) > 64 * 1024) ncopy >>= 1;
+    const size_t lds_bytes = (row_doubles * ncopy + 40) * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(ctx, SSFM_ERR_INVALID, "reduced-system block row does not fit in LDS");
     if (lds_bytes > 48 * 1024)
         SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_rows<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
-    double host_scal[SC_TOTAL], host_pcg[PCG_TOTAL];
+    double host_scal[SC_TOTAL];
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
     if (!h->scale_ready) {
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->diag_cam.p, 0, (size_t)Nc * 6 * sizeof(double), st));
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->diag_f.p, 0, sizeof(double), st));
         if (nP > 0) hipLaunchKernelGGL(k_colnorm, dim3(gp_pts), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP,
-                                       loss, la, h->diag_cam.p, h->diag_pt.p, h->diag_f.p);
+                                       loss, la, h->diag_pt.p, h->diag_f.p);
+        hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
+                           loss, la, h->diag_cam.p);
         if (ctx->nranks > 1) {   // camera / focal column norms are sums over every rank's observations
             int rc = allreduce(h, h->diag_cam.p, (size_t)Nc * 6, ncclSum); if (rc) return rc;
             rc = allreduce(h, h->diag_f.p, 1, ncclSum); if (rc) return rc;
@@ -247,7 +274,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         LAUNCH(h, KID_SCHUR_ROWS, k_schur_rows<DC>, Nc, 256, lds_bytes, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->obs_pt.p, h->pt_start.p,
                h->cam_start.p, h->cam_obs.p, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_pt.p, h->scale_f.p,
-               h->Vinv.p, h->gp.p, h->Wf.p, loss, la, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw);
+               h->Vinv.p, h->gp.p, h->Wf.p, loss, la, ncopy, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw);
         if (ctx->nranks > 1) {
             // scalar sums ride at the tail of the same buffer
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -258,23 +285,42 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
                radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[2], st));
-        // ================= solve the reduced system =================
+        // ================= solve the reduced system, then step / candidate / model cost / candidate cost =================
+        // The direct solve and the tail are enqueued back to back; the solver's residual flags come back with the
+        // iteration scalars in ONE host synchronisation.  Only if the residual test failed (rare) does PCG refinement
+        // run and the tail get redone.
         int pcg_iters = 0; bool pcg_ok = false;
-        { int rc = solve_reduced<DC>(h, host_pcg, &pcg_iters, &pcg_ok); if (rc) return rc; }
-        h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
+        double host_pcg1[PCG_TOTAL + 1];
+        { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
-        // ================= step, candidate, model cost, candidate cost =================
-        LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, h->scal.p);
-        if (nP > 0)
-            LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
-                   h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, pts_c, h->scal.p);
-        LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
-        if (nP > 0)
-            LAUNCH(h, KID_COST, k_point_cost, gp_pts, 256, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST);
-        { int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc; }   // MODEL, STEP2_PT, XN2_PT, CAND_COST
+        auto enqueue_tail = [&]() -> int {
+            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, h->scal.p);
+            if (nP > 0)
+                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                       h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, pts_c, h->scal.p);
+            LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
+            if (nP > 0)
+                LAUNCH(h, KID_COST, k_point_cost, gp_pts, 256, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST);
+            int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
+            hipError_t e = hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && O.preconditioner == 0) e = hipMemcpyAsync(host_pcg1, h->pcg.p, (PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
+            return SSFM_OK;
+        };
+        { int rc = enqueue_tail(); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (O.preconditioner == 0) {
+            int fail_flag; std::memcpy(&fail_flag, &host_pcg1[PCG_TOTAL], sizeof(int));
+            if (fail_flag) pcg_ok = false;
+            else if (host_pcg1[PCG_DONE] == 0.0) {
+                int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 1); if (rc) return rc;
+                SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_MODEL, 0, 4 * sizeof(double), st));
+                rc = enqueue_tail(); if (rc) return rc;
+                SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            }
+        }
+        h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
         { float ms;
           if (hipEventElapsedTime(&ms, h->phase_ev[0], h->phase_ev[1]) == hipSuccess) ms_lin += ms;
           if (hipEventElapsedTime(&ms, h->phase_ev[1], h->phase_ev[2]) == hipSuccess) ms_schur += ms;
@@ -398,10 +444,11 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
-    AL(scal, SC_TOTAL); AL(pcg, PCG_TOTAL);
+    AL(scal, SC_TOTAL); AL(pcg, PCG_TOTAL + 1);
     AL(band, (size_t)Nc * (F.band + 1) * DC * DC); AL(Linv, (size_t)Nc * DC * DC); AL(Yb, 2 * n); AL(Yr, 2 * n); AL(band_fail, 1);
 #undef AL
     SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
+    SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSFM_OK;

@@ -17,6 +17,20 @@
 
 namespace ssfm {
 
+// 1/sqrt(d) from the hardware estimate (v_rsq_f64) plus two Newton steps: full double precision with a
+// dependent chain of ~10 instructions instead of the ~50 of an IEEE sqrt followed by an IEEE divide.
+// Barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would expose the
+// latency of the global prefetches / write-backs that the LDS-resident kernels deliberately leave in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
 // S (block-CSR, camera order) -> band storage (permuted), right-hand sides permuted alongside
 template <int DC>
 __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
@@ -324,6 +338,268 @@ k_ref_step(const double* __restrict__ Sfc, const double* __restrict__ Sff, int N
     }
     block_sum<1>(a1, red);
     if (threadIdx.x == 0) { pcg[PCG_RR] = a1[0]; pcg[PCG_ITERS] += 1.0; if (a1[0] <= tol2 * pcg[PCG_BN2]) pcg[PCG_DONE] = 1.0; }
+}
+
+}  // namespace ssfm
+
+// =====================================================================================================
+// LDS-resident variants.  The live part of a banded right-looking factorisation is rows j..j+b; with
+// (b+1)^2 DCxDC blocks <= ~140 KB it fits the CU's LDS, so a step never waits on L2.  One workgroup per
+// connected component of the camera graph (comp_ptr: contiguous position ranges from the Cuthill-McKee pass).
+// =====================================================================================================
+namespace ssfm {
+
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_band_chol_lds(double* __restrict__ band, double* __restrict__ Linv_out, double* __restrict__ Y, const int* __restrict__ pairs,
+                const int* __restrict__ comp_ptr, int N, int b, int* __restrict__ fail_flag) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int R = b + 1, W = b + 1, RW = W * BB;            // ring of R row slots, RW doubles each
+    double* sWin = lds;                                     // [R][W][BB]
+    double* sYr = sWin + (size_t)R * RW;                    // [R][NR][DC]
+    double* sLinv = sYr + (size_t)R * NR * DC;              // BB
+    const int n = N * DC, tid = threadIdx.x, nt = blockDim.x;
+    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    // preload rows r0 .. r0+b
+    for (int row = r0; row < min(r0 + R, r1); row++) {
+        for (int e = tid; e < RW; e += nt) sWin[(size_t)(row % R) * RW + e] = band[(size_t)row * RW + e];
+        for (int e = tid; e < NR * DC; e += nt) sYr[(size_t)(row % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
+    }
+    lds_barrier();
+    for (int j = r0; j < r1; j++) {
+        const int nb = min(b, r1 - 1 - j);
+        double* rowj = sWin + (size_t)(j % R) * RW;
+        double* yj = sYr + (size_t)(j % R) * NR * DC;
+        // prefetch the row that enters the window after this step (reuses row j's slot)
+        const int jn = j + R;
+        double pre[4]; double preY = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int e = tid + u * nt; pre[u] = (jn < r1 && e < RW) ? band[(size_t)jn * RW + e] : 0.0; }
+        if (jn < r1 && tid < NR * DC) preY = Y[(size_t)(tid / DC) * n + (size_t)jn * DC + (tid % DC)];
+        // ---- A: diagonal block (one lane; reciprocal square roots keep the dependent chain short)
+        if (tid == 0) {
+            double L[DC][DC], Li[DC][DC];
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < DC; c++) {
+                double d = rowj[c * DC + c];
+#pragma unroll
+                for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
+                if (!(d > 0.0)) { bad = true; d = 1.0; }
+                const double rs = fast_rsqrt(d);
+                L[c][c] = d * rs; Li[c][c] = rs;
+#pragma unroll
+                for (int r = c + 1; r < DC; r++) {
+                    double s = rowj[r * DC + c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) s -= L[r][k] * L[c][k];
+                    L[r][c] = s * rs;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DC; c++)
+#pragma unroll
+                for (int r = c + 1; r < DC; r++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = c; k < r; k++) s -= L[r][k] * Li[k][c];
+                    Li[r][c] = s * Li[r][r];
+                }
+#pragma unroll
+            for (int r = 0; r < DC; r++)
+#pragma unroll
+                for (int c = 0; c < DC; c++) { const double lv = (c <= r) ? L[r][c] : 0.0, iv = (c <= r) ? Li[r][c] : 0.0;
+                                               rowj[r * DC + c] = lv; sLinv[r * DC + c] = iv; }
+            if (bad) *fail_flag = 1;
+        }
+        lds_barrier();
+        // ---- B: panel (in place in the window), y_j, and write-back of the now final row j
+        for (int t = tid; t < nb * DC; t += nt) {
+            const int blk = t / DC, a = t - blk * DC;
+            double* A = sWin + (size_t)((j + 1 + blk) % R) * RW + (size_t)(blk + 1) * BB + a * DC;
+            double v[DC];
+#pragma unroll
+            for (int k = 0; k < DC; k++) v[k] = A[k];
+#pragma unroll
+            for (int c = 0; c < DC; c++) { double s = 0.0;
+#pragma unroll
+                for (int k = 0; k <= c; k++) s += v[k] * sLinv[c * DC + k];
+                A[c] = s; }
+        }
+        if (tid >= nt - NR * 64 && (tid & 63) == 0) {
+            const int r = (tid - (nt - NR * 64)) >> 6;
+            double v[DC];
+#pragma unroll
+            for (int k = 0; k < DC; k++) v[k] = yj[r * DC + k];
+#pragma unroll
+            for (int a = 0; a < DC; a++) { double s = 0.0;
+#pragma unroll
+                for (int k = 0; k <= a; k++) s += sLinv[a * DC + k] * v[k];
+                yj[r * DC + a] = s; Y[(size_t)r * n + (size_t)j * DC + a] = s; }
+        }
+        for (int e = tid; e < RW; e += nt) band[(size_t)j * RW + e] = rowj[e];          // row j is final (its own blocks are not touched below)
+        for (int e = tid; e < BB; e += nt) Linv_out[(size_t)j * BB + e] = sLinv[e];
+        lds_barrier();
+        // ---- C: trailing window and right-hand sides
+        const int work = (nb * (nb + 1) / 2) * DC;
+        for (int t = tid; t < work; t += nt) {
+            const int pr = t / DC, a = t - pr * DC;
+            const int pk = pairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
+            const double* Li_ = sWin + (size_t)((j + ir) % R) * RW + (size_t)ir * BB + a * DC;
+            const double* Lk_ = sWin + (size_t)((j + kr) % R) * RW + (size_t)kr * BB;
+            double la[DC];
+#pragma unroll
+            for (int m = 0; m < DC; m++) la[m] = Li_[m];
+            double* dst = sWin + (size_t)((j + ir) % R) * RW + (size_t)(ir - kr) * BB + a * DC;
+#pragma unroll
+            for (int c = 0; c < DC; c++) { double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) s += la[m] * Lk_[c * DC + m];
+                dst[c] -= s; }
+        }
+        for (int t = tid; t < nb * DC * NR; t += nt) {
+            const int r = t / (nb * DC), q = t - r * nb * DC, kr = q / DC + 1, a = q - (kr - 1) * DC;
+            const double* Lk_ = sWin + (size_t)((j + kr) % R) * RW + (size_t)kr * BB + a * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) s += Lk_[m] * yj[r * DC + m];
+            sYr[(size_t)((j + kr) % R) * NR * DC + r * DC + a] -= s;
+        }
+        lds_barrier();
+        // row j's slot now receives row j+b+1
+        if (jn < r1) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = tid + u * nt; if (e < RW) rowj[e] = pre[u]; }
+            for (int e = tid + 4 * nt; e < RW; e += nt) rowj[e] = band[(size_t)jn * RW + e];
+            if (tid < NR * DC) yj[tid] = preY;
+        }
+        // (the next use of this slot is behind the barrier after phase A of the next step)
+    }
+}
+
+// back substitution Y <- L^-T Y per component; next column of L prefetched into registers while the current step runs
+template <int DC, int NR>
+__global__ void __launch_bounds__(256)
+k_band_back_lds(const double* __restrict__ band, const double* __restrict__ Linv, double* __restrict__ Y, const int* __restrict__ comp_ptr,
+                int N, int b) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;                               // ring [b][NR*DC]
+    double* sPart = sX + (size_t)b * NR * DC;       // [b][NR*DC]
+    double* sAcc = sPart + (size_t)b * NR * DC;     // NR*DC
+    const int W = b + 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x;
+    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    const int d = tid / DC + 1, a = tid - (d - 1) * DC;     // this lane's (offset, column) of the L column, valid if tid < b*DC
+    const bool has = tid < b * DC;
+    double col[DC], li[DC], yv = 0.0;
+    auto fetch = [&](int j) {
+#pragma unroll
+        for (int m = 0; m < DC; m++) col[m] = (has && j >= r0 && j + d < r1) ? band[(((size_t)(j + d)) * W + d) * BB + m * DC + a] : 0.0;
+        if (tid < NR * DC && j >= r0) {
+            const int aa = tid % DC;
+#pragma unroll
+            for (int k = 0; k < DC; k++) li[k] = (k >= aa) ? Linv[(size_t)j * BB + k * DC + aa] : 0.0;      // column aa of L_jj^-1 = row of L^-T
+            yv = Y[(size_t)(tid / DC) * n + (size_t)j * DC + aa];
+        }
+    };
+    fetch(r1 - 1);
+    for (int j = r1 - 1; j >= r0; j--) {
+        const int nb = min(b, r1 - 1 - j);
+        double cur[DC], curli[DC]; const double cury = yv;
+#pragma unroll
+        for (int m = 0; m < DC; m++) { cur[m] = col[m]; curli[m] = li[m]; }
+        fetch(j - 1);                                   // in flight during this step
+        if (has && d <= nb) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double* x = sX + ((size_t)((j + d) % b) * NR + r) * DC;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) s += cur[m] * x[m];
+                sPart[((size_t)(d - 1) * NR + r) * DC + a] = s;
+            }
+        }
+        lds_barrier();
+        if (tid < NR * DC) {
+            const int r = tid / DC, aa = tid - r * DC;
+            double s = cury;
+            for (int dd = 0; dd < nb; dd++) s -= sPart[((size_t)dd * NR + r) * DC + aa];
+            sAcc[tid] = s;
+        }
+        lds_barrier();
+        if (tid < NR * DC) {
+            const int r = tid / DC, aa = tid - r * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < DC; k++) s += curli[k] * sAcc[r * DC + k];
+            Y[(size_t)r * n + (size_t)j * DC + aa] = s;
+            if (b > 0) sX[((size_t)(j % b) * NR + r) * DC + aa] = s;
+        }
+        lds_barrier();
+    }
+}
+
+// forward substitution Y <- L^-1 Y per component with the same prefetch scheme (PCG refinement applications)
+template <int DC, int NR>
+__global__ void __launch_bounds__(256)
+k_band_fwd_lds(const double* __restrict__ band, const double* __restrict__ Linv, double* __restrict__ Y, const int* __restrict__ comp_ptr,
+               int N, int b) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;
+    double* sPart = sX + (size_t)b * NR * DC;
+    double* sAcc = sPart + (size_t)b * NR * DC;
+    const int W = b + 1, n = N * DC, tid = threadIdx.x;
+    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    const int d = tid / DC + 1, a = tid - (d - 1) * DC;
+    const bool has = tid < b * DC;
+    double row[DC], li[DC], yv = 0.0;
+    auto fetch = [&](int j) {
+#pragma unroll
+        for (int m = 0; m < DC; m++) row[m] = (has && j < r1 && j - d >= r0) ? band[(((size_t)j) * W + d) * BB + a * DC + m] : 0.0;
+        if (tid < NR * DC && j < r1) {
+            const int aa = tid % DC;
+#pragma unroll
+            for (int k = 0; k < DC; k++) li[k] = (k <= aa) ? Linv[(size_t)j * BB + aa * DC + k] : 0.0;
+            yv = Y[(size_t)(tid / DC) * n + (size_t)j * DC + aa];
+        }
+    };
+    fetch(r0);
+    for (int j = r0; j < r1; j++) {
+        const int nb = min(b, j - r0);
+        double cur[DC], curli[DC]; const double cury = yv;
+#pragma unroll
+        for (int m = 0; m < DC; m++) { cur[m] = row[m]; curli[m] = li[m]; }
+        fetch(j + 1);
+        if (has && d <= nb) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double* x = sX + ((size_t)((j - d) % b) * NR + r) * DC;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) s += cur[m] * x[m];
+                sPart[((size_t)(d - 1) * NR + r) * DC + a] = s;
+            }
+        }
+        lds_barrier();
+        if (tid < NR * DC) {
+            const int r = tid / DC, aa = tid - r * DC;
+            double s = cury;
+            for (int dd = 0; dd < nb; dd++) s -= sPart[((size_t)dd * NR + r) * DC + aa];
+            sAcc[tid] = s;
+        }
+        lds_barrier();
+        if (tid < NR * DC) {
+            const int r = tid / DC, aa = tid - r * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < DC; k++) s += curli[k] * sAcc[r * DC + k];
+            Y[(size_t)r * n + (size_t)j * DC + aa] = s;
+            if (b > 0) sX[((size_t)(j % b) * NR + r) * DC + aa] = s;
+        }
+        lds_barrier();
+    }
 }
 
 }  // namespace ssfm

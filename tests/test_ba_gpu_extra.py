@@ -1,0 +1,67 @@
+"""More GPU parity cases: both reduced-system solver paths, wide bands, a hard start with rejected LM steps."""
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def point_rel_err(a, b):
+    return (np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-300)).max()
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+@pytest.mark.parametrize("spherical", [True, False])
+def test_both_preconditioners_reach_the_oracle_answer(gpu_ctx, oracle, precond, spherical):
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 1500, 6, spherical=spherical, focal_fixed=False)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, preconditioner=precond, pcg_max_iterations=4000, pcg_tolerance=1e-11)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == 0 and s["iterations"] == os_["iterations"]
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    if precond == 0:
+        assert s["pcg_iterations_total"] <= 2 * s["num_linearizations"]      # the banded factor is exact: refinement is rare
+
+
+@pytest.mark.parametrize("K,Nc", [(12, 90), (6, 45)])
+def test_wide_band_ring(gpu_ctx, oracle, K, Nc):
+    """One connected ring with long tracks: exercises the global-memory factorisation path (window > LDS) for K=12."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(Nc, 900, K, spherical=False, focal_fixed=True, check_in_frame=False, xy_range=0.2)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"]
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+
+
+def test_refinement_path_is_exercised(gpu_ctx, oracle):
+    """An impossible tolerance forces PCG refinement sweeps (forward/backward substitution with the stored factor);
+    the answer must not move."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 900, 6, spherical=False, focal_fixed=False)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, pcg_tolerance=1e-30, pcg_max_iterations=3)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["pcg_iterations_total"] >= s["num_linearizations"]
+    # the residual can never reach 1e-30, so every step is "invalid" for the LM loop -> FAILURE after the invalid-step budget,
+    # or convergence if the steps are still accepted; what matters here is that the kernels run and stay finite
+    assert np.isfinite(cams).all() and np.isfinite(pts).all()
+
+
+def test_hard_start_with_rejected_steps(gpu_ctx, oracle):
+    """A rough start with a huge initial trust region makes LM reject steps (radius /2, /4, ...); GPU and oracle must
+    agree on the whole accept/reject sequence, not only on the answer.  (Starts so bad that points run off to infinity
+    are chaotic for ANY two implementations and are not a parity target.)"""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 300, 6, spherical=False, rot_noise_deg=8.0, point_noise=0.25)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, initial_trust_region_radius=1e12)
+    ocams, opts, of, os_ = oracle.ba_solve(p, initial_trust_region_radius=1e12)
+    assert os_["num_unsuccessful_steps"] >= 3
+    assert s["termination"] == os_["termination"] == 0
+    assert s["num_unsuccessful_steps"] == os_["num_unsuccessful_steps"] and s["iterations"] == os_["iterations"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-8 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
