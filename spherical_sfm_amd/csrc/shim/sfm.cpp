@@ -1,0 +1,170 @@
+// C++ mirror of sphericalsfm::SfM over the C ABI (see sfm.h).  Host-only code; the solve runs in libssfm_hip.so.
+#include "sfm.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include "../ssfm_math.h"
+
+namespace sphericalsfm {
+
+double Vec3::norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+Pose::Pose() : R{1, 0, 0, 0, 1, 0, 0, 0, 1} {}
+Pose::Pose(const Vec3& _t, const Vec3& _r) : t(_t), r(_r) { ssfm::so3exp(r.v, R); }          // src/sfm_types.cpp:14-19
+Pose Pose::inverse() const {                                                                  // src/sfm_types.cpp:21-29
+    Pose q;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) q.R[3 * i + j] = R[3 * j + i];
+    double mt[3] = {-t.v[0], -t.v[1], -t.v[2]};
+    ssfm::mat3_vec(q.R, mt, q.t.v);
+    q.r = Vec3(-r.v[0], -r.v[1], -r.v[2]);
+    return q;
+}
+void Pose::postMultiply(const Pose& pose) {                                                   // src/sfm_types.cpp:31-36: P = P * pose.P
+    double Rn[9], tn[3];
+    ssfm::mat3_mul(R, pose.R, Rn);
+    ssfm::mat3_vec(R, pose.t.v, tn);
+    for (int i = 0; i < 3; i++) t.v[i] += tn[i];
+    for (int i = 0; i < 9; i++) R[i] = Rn[i];
+    ssfm::so3ln(R, r.v);
+}
+Point Pose::apply(const Point& p) const { Point q; ssfm::mat3_vec(R, p.v, q.v); for (int i = 0; i < 3; i++) q.v[i] += t.v[i]; return q; }
+Point Pose::applyInverse(const Point& p) const { double d[3] = {p.v[0] - t.v[0], p.v[1] - t.v[1], p.v[2] - t.v[2]}; Point q; ssfm::mat3_tvec(R, d, q.v); return q; }
+Vec3 Pose::getCenter() const { double mt[3] = {-t.v[0], -t.v[1], -t.v[2]}; Vec3 c; ssfm::mat3_tvec(R, mt, c.v); return c; }
+
+SfM::SfM(const Intrinsics& _intrinsics)
+    : intrinsics(_intrinsics), focalFixed(true), numCameras(0), numPoints(0), nextCamera(-1), nextPoint(0), ctx(nullptr), last_summary() {}
+SfM::~SfM() { if (ctx) ssfm_ctx_destroy(ctx); }
+
+int SfM::AddCamera(const Pose& pose, const std::string& path) {                               // src/sfm.cpp:99-111
+    nextCamera++; numCameras++;
+    cameras[nextCamera] = Camera{pose.t.v[0], pose.t.v[1], pose.t.v[2], pose.r.v[0], pose.r.v[1], pose.r.v[2]};
+    paths[nextCamera] = path; rotationFixed[nextCamera] = false; translationFixed[nextCamera] = false;
+    return nextCamera;
+}
+int SfM::AddPoint(const Point& X) { numPoints++; points[nextPoint] = X; pointFixed[nextPoint] = false; return nextPoint++; }   // src/sfm.cpp:113-127
+void SfM::AddObservation(int camera, int point, const Observation& o) { observations[camera][point] = o; }                 // src/sfm.cpp:143-146
+bool SfM::GetObservation(int camera, int point, Observation& o) {
+    auto r = observations.find(camera); if (r == observations.end()) return false;
+    auto c = r->second.find(point); if (c == r->second.end()) return false;
+    o = c->second; return true;
+}
+void SfM::MergePoint(int point1, int point2) {                                                // src/sfm.cpp:129-141
+    for (auto& row : observations) {
+        if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;
+        auto it = row.second.find(point2);
+        if (it != row.second.end()) row.second[point1] = it->second;
+    }
+    RemovePoint(point2);
+}
+void SfM::RemovePoint(int point) {                                                            // src/sfm.cpp:435-444
+    for (auto& row : observations) if (row.first >= 0 && row.first < numCameras) row.second.erase(point);
+    points.erase(point);
+}
+void SfM::RemoveCamera(int camera) {                                                          // src/sfm.cpp:446-461
+    cameras.erase(camera); observations.erase(camera);
+    for (int j = 0; j < numPoints; j++) {
+        bool seen = false;
+        for (auto& row : observations) if (row.first >= 0 && row.first < numCameras && row.second.count(j)) { seen = true; break; }
+        if (!seen) points.erase(j);
+    }
+}
+Pose SfM::GetPose(int camera) {
+    auto it = cameras.find(camera); if (it == cameras.end()) return Pose();
+    const Camera& c = it->second; return Pose(Vec3(c[0], c[1], c[2]), Vec3(c[3], c[4], c[5]));
+}
+void SfM::SetPose(int camera, const Pose& p) { cameras[camera] = Camera{p.t.v[0], p.t.v[1], p.t.v[2], p.r.v[0], p.r.v[1], p.r.v[2]}; }
+Point SfM::GetPoint(int point) { auto it = points.find(point); return it == points.end() ? Point(0, 0, 0) : it->second; }
+void SfM::SetPoint(int point, const Point& X) { points[point] = X; }
+
+bool SfM::Optimize() {
+    if (numCameras == 0 || numPoints == 0) return false;                                      // src/sfm.cpp:230
+    std::cout << "\tBuilding BA problem...\n";
+    // dense index spaces [0,numCameras) x [0,numPoints) as the reference's loops use them; absent entries stay absent
+    std::vector<double> cam((size_t)numCameras * 6, 0.0), pts((size_t)numPoints * 3, 0.0);
+    std::vector<uint8_t> rf(numCameras, 1), tf(numCameras, 1), pf(numPoints, 0);
+    for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) {
+        for (int k = 0; k < 6; k++) cam[(size_t)kv.first * 6 + k] = kv.second[k];
+        rf[kv.first] = rotationFixed[kv.first]; tf[kv.first] = translationFixed[kv.first];
+    }
+    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) {
+        for (int k = 0; k < 3; k++) pts[(size_t)kv.first * 3 + k] = kv.second.v[k];
+        pf[kv.first] = pointFixed[kv.first];
+    }
+    std::vector<double> xy; std::vector<int32_t> oc, op;
+    for (auto& row : observations) {
+        if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;   // src/sfm.cpp:249
+        for (auto& kv : row.second) {
+            if (kv.first < 0 || kv.first >= numPoints || !points.count(kv.first)) continue;     // src/sfm.cpp:242
+            xy.push_back(kv.second.x); xy.push_back(kv.second.y); oc.push_back(row.first); op.push_back(kv.first);
+        }
+    }
+    if (!ctx) {
+        int rc = ssfm_ctx_create(-1, nullptr, &ctx);
+        if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(nullptr) << "\n"; exit(1); }
+    }
+    ssfm_ba_problem P;
+    P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)oc.size();
+    P.cameras = cam.data(); P.points = pts.data(); P.focal = &intrinsics.focal;
+    P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data();
+    P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = focalFixed ? 1 : 0;
+    ssfm_ba_options O; ssfm_ba_default_options(&O);                                            // src/sfm.cpp:194-212
+    O.verbose = 1;                                                                            // minimizer_progress_to_stdout
+    int rc = ssfm_ba_solve(ctx, &P, &O, &last_summary);
+    if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(ctx) << "\n"; exit(1); }
+    if (last_summary.termination == SSFM_NOTHING_TO_DO) { std::cout << "didn't add any cameras\n"; return false; }   // src/sfm.cpp:265-268
+    std::cout << "Running optimizer...\n\t" << 2 * last_summary.num_residual_blocks << " residuals\n";
+    std::printf("iterations %d  initial cost %.6e  final cost %.6e  termination %d  solve %.3f s\n", last_summary.iterations,
+                last_summary.initial_cost, last_summary.final_cost, last_summary.termination, last_summary.t_solve_s);
+    if (last_summary.termination == SSFM_FAILURE) { std::cout << "error: ceres failed.\n"; exit(1); }             // src/sfm.cpp:278-282
+    for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) for (int k = 0; k < 6; k++) kv.second[k] = cam[(size_t)kv.first * 6 + k];
+    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = pts[(size_t)kv.first * 3 + k];
+    return last_summary.termination == SSFM_CONVERGENCE;                                      // src/sfm.cpp:289
+}
+
+void SfM::Apply(const Pose& pose) {                                                           // src/sfm.cpp:341-362
+    Pose inv = pose.inverse();
+    for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); c.postMultiply(inv); SetPose(i, c); }
+    for (int j = 0; j < numPoints; j++) {
+        if (!points.count(j)) continue;
+        Point X = GetPoint(j); if (X.norm() == 0) continue;
+        SetPoint(j, pose.apply(X));
+    }
+}
+void SfM::Apply(double scale) {                                                               // src/sfm.cpp:364-382
+    for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); for (int k = 0; k < 3; k++) c.t.v[k] *= scale; SetPose(i, c); }
+    for (int j = 0; j < numPoints; j++) {
+        if (!points.count(j)) continue;
+        Point X = GetPoint(j); if (X.norm() == 0) continue;
+        for (int k = 0; k < 3; k++) X.v[k] *= scale;
+        SetPoint(j, X);
+    }
+}
+void SfM::Unapply(const Pose& pose) {                                                         // src/sfm.cpp:384-402
+    for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); c.postMultiply(pose); SetPose(i, c); }
+    Pose inv = pose.inverse();
+    for (int j = 0; j < numPoints; j++) SetPoint(j, inv.apply(GetPoint(j)));
+}
+void SfM::Normalize(bool inward) {                                                            // src/sfm.cpp:535-571
+    Vec3 centroid;
+    for (int i = 0; i < numCameras; i++) { Vec3 c = GetPose(i).getCenter(); for (int k = 0; k < 3; k++) centroid.v[k] += c.v[k]; }
+    for (int k = 0; k < 3; k++) centroid.v[k] /= numCameras;
+    Apply(Pose(Vec3(-centroid.v[0], -centroid.v[1], -centroid.v[2]), Vec3(0, 0, 0)));
+    double avg = 0; for (int i = 0; i < numCameras; i++) avg += GetPose(i).getCenter().norm();
+    avg /= numCameras;
+    Apply(1.0 / avg);
+    const double tz = GetPose(0).t.v[2];
+    if ((inward && tz < 0) || (!inward && tz > 0)) { std::cout << "inverted! flipping to correct\n"; Apply(-1.0); }
+}
+void SfM::WritePoses(const std::string& path, const std::vector<int>& indices) {              // src/sfm.cpp:463-480
+    FILE* f = std::fopen(path.c_str(), "w"); if (!f) return;
+    for (int i = 0; i < numCameras; i++) {
+        std::fprintf(f, "%d ", indices[i]);
+        const Camera c = cameras[i];
+        for (int j = 0; j < 6; j++) std::fprintf(f, "%.15lf ", c[j]);
+        std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+}
+
+}  // namespace sphericalsfm

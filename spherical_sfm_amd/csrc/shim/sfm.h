@@ -1,0 +1,99 @@
+// spherical_sfm_amd -- C++ host-side mirror of the reference's BA container `sphericalsfm::SfM`
+// (reference include/sphericalsfm/sfm.h:15-105, src/sfm.cpp), written against the C ABI of include/ssfm.h.
+//
+// Same class name, method names, argument meaning and error behaviour for the hot path, so that a caller such as
+// build_sfm / run_spherical_sfm_uncalib (examples/spherical_sfm_tools.cpp:862-955, examples/run_spherical_sfm_uncalib.cpp:176-211)
+// compiles against it unchanged apart from the vector types: Eigen / OpenCV / Ceres are not available in this build,
+// so Vec3 / Pose below are small PODs with the member names the reference uses (t, r, getCenter, ...).
+// Storage is map-based like the reference's SparseVector / SparseMatrix (include/sphericalsfm/sparse.hpp), keyed
+// observations[camera][point]; Optimize() flattens by walking the sparse rows (not the O(Np*Nc) probe loop of
+// src/sfm.cpp:240-263) and hands caller-owned buffers to ssfm_ba_solve.
+#pragma once
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../../include/ssfm.h"
+
+namespace sphericalsfm {
+
+struct Vec3 {
+    double v[3];
+    Vec3() : v{0, 0, 0} {}
+    Vec3(double x, double y, double z) : v{x, y, z} {}
+    double& operator()(int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    double norm() const;
+};
+typedef Vec3 Point;                       // include/sphericalsfm/sfm_types.h:8
+typedef std::array<double, 6> Camera;     // [t;r], sfm_types.h:9
+struct Observation { double x, y; Observation() : x(0), y(0) {} Observation(double _x, double _y) : x(_x), y(_y) {} };
+
+struct Pose {                             // sfm_types.h:14-29 / src/sfm_types.cpp
+    Vec3 t, r;
+    double R[9];                          // row-major rotation so3exp(r) (the 3x3 block of the reference's P)
+    Pose();
+    Pose(const Vec3& _t, const Vec3& _r);
+    Pose inverse() const;
+    void postMultiply(const Pose& pose);
+    Point apply(const Point& point) const;
+    Point applyInverse(const Point& point) const;
+    Vec3 getCenter() const;
+};
+
+struct Intrinsics {                       // sfm_types.h:31-47
+    double focal, centerx, centery;
+    Intrinsics(double _focal, double _centerx, double _centery) : focal(_focal), centerx(_centerx), centery(_centery) {}
+};
+
+class SfM {
+protected:
+    Intrinsics intrinsics;
+    std::map<int, Camera> cameras;
+    std::map<int, Point> points;
+    std::map<int, std::map<int, Observation>> observations;   // [camera][point]
+    std::map<int, std::string> paths;
+    bool focalFixed;
+    std::map<int, bool> rotationFixed, translationFixed, pointFixed;
+    int numCameras, numPoints, nextCamera, nextPoint;
+    ssfm_ctx* ctx;                        // created on first Optimize()
+    ssfm_ba_summary last_summary;
+public:
+    explicit SfM(const Intrinsics& _intrinsics);
+    ~SfM();
+    SfM(const SfM&) = delete;
+    SfM& operator=(const SfM&) = delete;
+
+    Intrinsics GetIntrinsics() const { return intrinsics; }
+    int AddCamera(const Pose& initial_pose, const std::string& path = "");
+    int AddPoint(const Point& initial_position);
+    void AddObservation(int camera, int point, const Observation& observation);
+    void RemoveCamera(int camera);
+    void RemovePoint(int point);
+    void MergePoint(int point1, int point2);     // point2 will be removed
+    int GetNumCameras() { return numCameras; }
+    int GetNumPoints() { return numPoints; }
+    bool GetObservation(int camera, int point, Observation& observation);
+
+    bool Optimize();                              // src/sfm.cpp:228-290: true iff CONVERGENCE; exit(1) on FAILURE
+
+    void Apply(const Pose& pose);
+    void Apply(double scale);
+    void Unapply(const Pose& pose);
+    void Normalize(bool inward);
+    double GetFocal() { return intrinsics.focal; }
+    Pose GetPose(int camera);
+    void SetPose(int camera, const Pose& pose);
+    Point GetPoint(int point);
+    void SetPoint(int point, const Point& position);
+    void SetFocalFixed(bool fixed) { focalFixed = fixed; }
+    void SetRotationFixed(int camera, bool fixed) { rotationFixed[camera] = fixed; }
+    void SetTranslationFixed(int camera, bool fixed) { translationFixed[camera] = fixed; }
+    void SetPointFixed(int point, bool fixed) { pointFixed[point] = fixed; }
+    void WritePoses(const std::string& path, const std::vector<int>& indices);
+    const ssfm_ba_summary& LastSummary() const { return last_summary; }
+};
+
+}  // namespace sphericalsfm

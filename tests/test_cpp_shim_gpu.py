@@ -1,0 +1,51 @@
+"""The C++ mirror of sphericalsfm::SfM (spherical_sfm_amd/csrc/shim) driven like run_spherical_sfm_uncalib.cpp:177-211:
+AddCamera/AddPoint/AddObservation -> Optimize() (spherical) -> unfix translations -> Optimize() -> Normalize().
+The problem the C++ side built is dumped and replayed through the oracle: parity of the whole drop-in path."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "demo_circle")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.run([exe, "1200", dump], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHIM_RESULT")][0]
+    r = dict(kv.split("=") for kv in line.split()[1:])
+    assert r["ok1"] == "1" and r["ok2"] == "1" and r["dof2"] == "6"
+    assert abs(float(r["focal1"]) - 1000.0) < 2.0 and abs(float(r["focal2"]) - 1000.0) < 2.0
+    assert abs(float(r["mean_radius"]) - 1.0) < 1e-12                       # Normalize(), src/sfm.cpp:549-559
+    # ---- replay the first Optimize() through the oracle
+    b = open(dump, "rb").read()
+    Nc, Np, K = struct.unpack_from("3i", b, 0); off = 12
+    M = Np * K
+    rec = np.frombuffer(b, dtype=np.dtype([("c", "<i4"), ("p", "<i4"), ("x", "<f8"), ("y", "<f8")]), count=M, offset=off); off += M * 24
+    def state(o):
+        cams = np.frombuffer(b, "<f8", Nc * 6, o).reshape(Nc, 6); o += Nc * 48
+        pts = np.frombuffer(b, "<f8", Np * 3, o).reshape(Np, 3); o += Np * 24
+        f = np.frombuffer(b, "<f8", 1, o)[0]; o += 8
+        return cams.copy(), pts.copy(), float(f), o
+    c0, p0, f0, off = state(off)
+    c1, p1, f1, off = state(off)
+    tf = np.ones(Nc, np.uint8); rf = np.zeros(Nc, np.uint8); rf[0] = 1
+    prob = synth.BAProblem(cameras=c0, points=p0, focal=f0, obs_xy=np.stack([rec["x"], rec["y"]], 1), obs_cam=rec["c"].astype(np.int32),
+                           obs_pt=rec["p"].astype(np.int32), rot_fixed=rf, trans_fixed=tf, pt_fixed=np.zeros(Np, np.uint8), focal_fixed=False,
+                           gt_cameras=c0, gt_points=p0, gt_focal=0.0)
+    oc, op, of, os_ = oracle.ba_solve(prob)
+    assert os_["iterations"] == int(r["it1"])
+    assert np.abs(c1 - oc).max() / np.abs(oc).max() <= 1e-5
+    assert (np.linalg.norm(p1 - op, axis=1) / np.linalg.norm(op, axis=1)).max() <= 1e-5
+    assert abs(f1 - of) <= 1e-5 * of and abs(float(r["cost1"]) - os_["final_cost"]) <= 1e-8 * os_["final_cost"]
