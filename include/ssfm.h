@@ -132,6 +132,24 @@ int ssfm_ba_set_profiling(ssfm_ba_handle* h, int32_t on);
 /* per-kernel timing of the last run: name -> (launches, total ms); returns number of entries written */
 int ssfm_ba_kernel_times(ssfm_ba_handle* h, int32_t max_entries, char names[][32], int64_t* launches, double* total_ms);
 
+/* ---- SO(3) pose graphs ------------------------------------------------------------------------------
+ * rotations: [n*9] column-major 3x3 (std::vector<Eigen::Matrix3d>), in/out; index0/index1/rel_rotations: the fields of
+ * sphericalsfm::RelativeRotation (include/sphericalsfm/rotation_averaging.h:9-14), rel = R1 * R0^T, column-major.
+ * Options: ssfm_ba_options with the pose-graph defaults (Ceres defaults: 50 iterations, 5 invalid steps;
+ * SoftLOneLoss(0.03)).  summary->final_cost is the value the reference functions return. */
+void ssfm_rotavg_default_options(ssfm_ba_options* o);
+/* optimize_rotations (src/rotation_averaging.cpp:44-91) */
+int ssfm_rotavg_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int32_t num_edges, const int32_t* index0, const int32_t* index1,
+                      const double* rel_rotations, const ssfm_ba_options* o, ssfm_ba_summary* s);
+/* get_cost (src/uncalibrated_pose_graph.cpp:116-145) */
+int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotations, int32_t num_edges, const int32_t* index0, const int32_t* index1,
+                     const double* rel_rotations, double* cost);
+/* optimize_rotations_and_focal_length (src/uncalibrated_pose_graph.cpp:147-203); *focal_length is multiplied by the
+ * optimised multiplier, which is kept inside [min_focal, max_focal] / focal_length */
+int ssfm_posegraph_focal_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int32_t num_edges, const int32_t* index0,
+                               const int32_t* index1, const double* rel_rotations, double* focal_length, double min_focal,
+                               double max_focal, const ssfm_ba_options* o, ssfm_ba_summary* s);
+
 #ifdef __cplusplus
 }
 #endif

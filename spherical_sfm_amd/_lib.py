@@ -60,6 +60,7 @@ DECLARED_SYMBOLS = [
     "ssfm_ctx_create", "ssfm_ctx_destroy", "ssfm_last_error", "ssfm_version", "ssfm_comm_unique_id", "ssfm_comm_init",
     "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
+    "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
 ]
 
 
@@ -76,6 +77,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SsfmError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(make -C spherical_sfm_amd/csrc).  There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever is
+    # loaded first wins, and loading the second copy later corrupts the heap at exit -- so make sure torch's is first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     L.ssfm_ctx_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]; L.ssfm_ctx_create.restype = C.c_int
@@ -95,6 +102,13 @@ def lib():
     L.ssfm_ba_evaluate.argtypes = [vp, c_double_p, c_double_p, c_double_p]; L.ssfm_ba_evaluate.restype = C.c_int
     L.ssfm_ba_set_profiling.argtypes = [vp, C.c_int32]; L.ssfm_ba_set_profiling.restype = C.c_int
     L.ssfm_ba_kernel_times.argtypes = [vp, C.c_int32, C.c_void_p, c_i64_p, c_double_p]; L.ssfm_ba_kernel_times.restype = C.c_int
+    L.ssfm_rotavg_default_options.argtypes = [C.POINTER(BAOptionsC)]; L.ssfm_rotavg_default_options.restype = None
+    L.ssfm_rotavg_solve.argtypes = [vp, C.c_int32, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_double_p, C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]
+    L.ssfm_rotavg_solve.restype = C.c_int
+    L.ssfm_rotavg_cost.argtypes = [vp, C.c_int32, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_double_p, c_double_p]; L.ssfm_rotavg_cost.restype = C.c_int
+    L.ssfm_posegraph_focal_solve.argtypes = [vp, C.c_int32, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_double_p, c_double_p, C.c_double, C.c_double,
+                                             C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]
+    L.ssfm_posegraph_focal_solve.restype = C.c_int
     _LIB = L
     return L
 

@@ -130,7 +130,7 @@ __device__ __forceinline__ void cam_block(const ObsLin& L, const double* sc6, do
 }
 
 // ---- K0: per-camera rotation tables ----------------------------------------------------------------
-__global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ rot, int Nc) {
+static __global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ rot, int Nc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Nc) return;
     double aa[3] = {cam[c * 6 + 3], cam[c * 6 + 4], cam[c * 6 + 5]};
@@ -141,7 +141,7 @@ __global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ r
 
 // ---- one-time: squared column norms of the unscaled robustified Jacobian (Jacobi scaling, iteration 0)
 // points + focal: one lane per point;  cameras: one workgroup per camera over its observation list (no atomics)
-__global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+static __global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                           const int* __restrict__ pt_start, int nP, int loss, double la,
                           double* __restrict__ diag_pt, double* __restrict__ diag_f) {
@@ -163,7 +163,7 @@ __global__ void k_colnorm(const double* __restrict__ cam, const double* __restri
     block_sum<1>(df, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(diag_f, df[0]);
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
               const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
               const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam) {
@@ -181,14 +181,14 @@ k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, co
     block_sum<6>(d, red);
     if (threadIdx.x == 0) for (int k = 0; k < 6; k++) diag_cam[c * 6 + k] = d[k];
 }
-__global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
+static __global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) scale[i] = mask[i] * (jacobi ? 1.0 / (1.0 + sqrt(diag[i])) : 1.0);
 }
 
 // ---- K1: point pass.  One lane per point: V = sum Jp^T Jp (+D^2), V^-1, g_p, focal coupling ----------
 // Ceres SchurEliminator "chunk" work for the e-block, with the LM diagonal D_p^2 = clamp(diag V)/radius.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
             const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
@@ -642,7 +642,7 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
              const int* __restrict__ pt_start, int nP, int loss, double la, double* __restrict__ out) {
@@ -662,7 +662,7 @@ k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, con
 }
 
 // |x|^2 over free parameters (iteration 0)
-__global__ void k_sqnorm_masked(const double* __restrict__ v, const double* __restrict__ mask, int n, double* __restrict__ out) {
+static __global__ void k_sqnorm_masked(const double* __restrict__ v, const double* __restrict__ mask, int n, double* __restrict__ out) {
     __shared__ double red[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[1] = {(i < n && mask[i] > 0.0) ? v[i] * v[i] : 0.0};
@@ -671,7 +671,7 @@ __global__ void k_sqnorm_masked(const double* __restrict__ v, const double* __re
 }
 
 // ---- parity probe: per-observation residual + 2x10 Jacobian (focal | t | r | X), robustified, unscaled
-__global__ void k_eval_dump(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+static __global__ void k_eval_dump(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                             const int* __restrict__ obs_pt, int M, int loss, double la, double* __restrict__ res, double* __restrict__ jac) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;

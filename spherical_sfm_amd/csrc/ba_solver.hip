@@ -20,189 +20,9 @@
 #include "band_kernels.h"
 #include "ssfm_ctx.h"
 
-namespace ssfm {
-
-static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
-                KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_COUNT };
-static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_rows", "k_finalize_S", "k_pcg_init",
-                                              "k_pcg_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
-                                              "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol", "k_band_fwd",
-                                              "k_band_back", "k_band_combine", "k_ref_vecops"};
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
-    void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
-}  // namespace ssfm
-
-using namespace ssfm;
-
-struct ssfm_ba_handle {
-    ssfm_ctx* ctx = nullptr;
-    ssfm_ba_options opt;
-    BAFlat F;
-    int n_red = 0;                       // length of the all-reduced assembly buffer
-    // device state
-    DevBuf<double> cam_x, cam_c, cam_init, pts_x, pts_c, pts_init, focal3;   // focal3: [x, cand, init]
-    DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
-    DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
-    DevBuf<double> Vinv, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
-    DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
-    double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
-    double focal_host = 0;
-    bool scale_ready = false;
-    int pcg_prev_iters = 16;
-    // profiling
-    bool profile = false;
-    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
-    struct Span { int kid; hipEvent_t a, b; };
-    std::vector<Span> spans;
-    int64_t k_launches[KID_COUNT]; double k_ms[KID_COUNT];
-    hipEvent_t phase_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-
-    hipEvent_t get_event() {
-        if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
-        return ev_pool[ev_used++];
-    }
-    void span_begin(int kid) { if (!profile) return; Span s{kid, get_event(), get_event()}; (void)hipEventRecord(s.a, ctx->stream); spans.push_back(s); }
-    void span_end() { if (!profile) return; (void)hipEventRecord(spans.back().b, ctx->stream); }
-    void resolve_spans() {
-        for (auto& s : spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { k_ms[s.kid] += ms; k_launches[s.kid]++; } }
-        spans.clear(); ev_used = 0;
-    }
-    void free_all() {
-        cam_x.free(); cam_c.free(); cam_init.free(); pts_x.free(); pts_c.free(); pts_init.free(); focal3.free();
-        rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
-        diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
-        cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); gp.free(); Wf.free();
-        band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
-        for (auto e : ev_pool) (void)hipEventDestroy(e);
-        ev_pool.clear();
-        for (auto& e : phase_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    }
-};
+#include "ba_handle.h"
 
 namespace ssfm {
-
-#define LAUNCH(h, kid, kernel, grid, block, shmem, ...)                                   \
-    do {                                                                                  \
-        (h)->span_begin(kid);                                                             \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (h)->ctx->stream, __VA_ARGS__); \
-        (h)->span_end();                                                                  \
-    } while (0)
-
-template <typename T>
-static hipError_t upload(DevBuf<T>& b, const std::vector<T>& v, hipStream_t s) {
-    hipError_t e = b.alloc(v.size()); if (e != hipSuccess) return e;
-    if (v.empty()) return hipSuccess;
-    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-}
-
-static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
-    if (h->ctx->nranks <= 1) return SSFM_OK;
-    h->span_begin(KID_ALLREDUCE);
-    ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, op, h->ctx->comm, h->ctx->stream);
-    h->span_end();
-    if (r != ncclSuccess) return fail(h->ctx, SSFM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    return SSFM_OK;
-}
-
-// Solve S y = rhs (block-CSR S with dense focal border) into h->px.
-//   preconditioner 0: exact block-banded Cholesky in Cuthill-McKee order, then PCG refinement on the residual
-//   preconditioner 1: block-Jacobi PCG (kept for comparison; needs ~10^3 iterations on a camera ring)
-template <int DC>
-static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bool* ok_out, int stage) {
-    // stage 0: enqueue the direct solve + residual check, no host sync (flags are read with the iteration scalars)
-    // stage 1: flags are in host_pcg; run PCG refinement if the residual test failed
-    // (block-Jacobi PCG, preconditioner 1, does everything in stage 0 with its own syncs)
-    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
-    const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
-    const int Nc = F.Nc, n = Nc * DC, b = F.band;
-    constexpr int BB = DC * DC;
-    const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
-    if (O.preconditioner == 1) {
-        if (stage == 1) return SSFM_OK;
-        LAUNCH(h, KID_PCG_INIT, k_pcg_init<DC>, 1, 1024, 0, h->rhs, h->Minv.p, h->Sff.p, Nc, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pcg.p);
-        int launched = 0; bool done = false;
-        int chunk = std::max(8, h->pcg_prev_iters + 2);
-        while (!done && launched < O.pcg_max_iterations) {
-            const int todo = std::min(chunk, O.pcg_max_iterations - launched);
-            for (int k = 0; k < todo; k++) {
-                LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
-                LAUNCH(h, KID_PCG_VECOPS, k_pcg_vecops<DC>, 1, 1024, 0, h->Minv.p, h->Sfc, h->Sff.p, Nc, tol2, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pq.p, h->pqpart.p, h->pcg.p);
-            }
-            launched += todo;
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            done = host_pcg[PCG_DONE] != 0.0;
-            chunk = 8;
-        }
-        *iters_out = (int)host_pcg[PCG_ITERS];
-        *ok_out = done && host_pcg[PCG_BREAKDOWN] == 0.0;
-        return SSFM_OK;
-    }
-    const int ncomp = (int)F.comp_ptr.size() - 1;
-    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB) * sizeof(double);
-    const bool use_lds = lds_win <= 140 * 1024 && b * DC <= 256;
-    const int chol_threads = ((b * (b + 1) / 2) * DC <= 1024) ? 256 : 1024;
-    // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
-    const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
-    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
-    const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
-    if (stage == 0) {
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band.p, 0, h->band.n * sizeof(double), st));
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
-    LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
-    hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
-    // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
-    if (use_lds) {
-        if (lds_win > 48 * 1024) {
-            SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_lds<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        }
-        LAUNCH(h, KID_BAND_CHOL, (k_band_chol_lds<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, h->comp_ptr.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-        LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
-    } else {
-        LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
-    }
-    LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
-    // ---- residual check r = rhs - S x, PCG refinement with the factor as preconditioner while it is too large
-    LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->px.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
-    LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
-    *iters_out = 0; *ok_out = true;
-    return SSFM_OK;
-    }
-    int it = 0;
-    { int fail_flag; std::memcpy(&fail_flag, &host_pcg[PCG_TOTAL], sizeof(int));
-      if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
-    while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
-        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
-        if (use_lds) {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
-            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
-        } else {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
-            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
-        }
-        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
-        LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);
-        LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
-        LAUNCH(h, KID_REF_VEC, k_ref_step<DC>, 1, 1024, 0, h->Sfc, h->Sff.p, Nc, tol2, h->pp.p, h->pq.p, h->pqpart.p, h->px.p, h->pr.p, h->pcg.p);
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        it++;
-    }
-    *iters_out = it;
-    *ok_out = host_pcg[PCG_DONE] != 0.0 && host_pcg[PCG_BREAKDOWN] == 0.0;
-    return SSFM_OK;
-}
 
 template <int DC>
 static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {

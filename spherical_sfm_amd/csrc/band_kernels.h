@@ -300,7 +300,7 @@ k_ref_residual(const double* __restrict__ bvec, const double* __restrict__ q, co
     }
 }
 // direction: rz = r.z ; p = z + (rz/rz_old) p  (first = 1: p = z)
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_ref_direction(const double* __restrict__ r, const double* __restrict__ z, int n1, int first, double* __restrict__ p, double* __restrict__ pcg) {
     __shared__ double red[16];
     __shared__ double sbeta;

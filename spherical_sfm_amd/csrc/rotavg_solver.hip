@@ -1,0 +1,398 @@
+// spherical_sfm_amd -- SO(3) pose-graph solvers on the GPU.
+//
+// Replaces, behind the C ABI (include/ssfm.h):
+//   optimize_rotations                    reference src/rotation_averaging.cpp:44-91   (RotationError :15-42)
+//   get_cost                              reference src/uncalibrated_pose_graph.cpp:116-145 (PoseGraphError :81-114)
+//   optimize_rotations_and_focal_length   reference src/uncalibrated_pose_graph.cpp:147-203 (UncalibratedPoseGraphError :33-79,
+//                                         decompose_rotation :16-31, box bounds :181-182)
+// Ceres defaults apply there (50 iterations, 5 invalid steps, SoftLOneLoss(0.03), first rotation constant, residual scaled
+// by 1/max|log R_rel|).  One lane per edge evaluates the residual with dual numbers (dual.h) and scatters the 3x3 blocks
+// of J^T J into a block-CSR system over the nodes; the normal equations are then solved by the same banded-Cholesky /
+// PCG-refinement path as the BA reduced camera system (ba_handle.h, DC = 3, the shared focal multiplier as border row).
+#include <algorithm>
+#include <cstdio>
+#include "ba_handle.h"
+#include "dual.h"
+
+namespace ssfm {
+
+struct EdgeConst { double meas[9]; double r[3]; double rx, ry, thetaxy, thetaz; };   // meas row-major
+
+// reference decompose_rotation (src/uncalibrated_pose_graph.cpp:16-31), R row-major
+static void decompose_rotation_host(const double* R, double& rx, double& ry, double& thetaxy, double& thetaz) {
+    double Z[3] = {R[2], R[5], R[8]};
+    const double zn = norm3(Z); Z[0] /= zn; Z[1] /= zn; Z[2] /= zn;
+    const double axis[3] = {-Z[1], Z[0], 0.0};
+    const double an = norm3(axis);
+    const double rxy[3] = {axis[0] / an, axis[1] / an, axis[2] / an};
+    thetaxy = acos(Z[2]);
+    const double v[3] = {thetaxy * rxy[0], thetaxy * rxy[1], thetaxy * rxy[2]};
+    double Rxy[9]; so3exp(v, Rxy);
+    rx = rxy[0]; ry = rxy[1];
+    double Rz[9]; mat3_mul_at(Rxy, R, Rz);
+    double rz[3]; so3ln(Rz, rz);
+    thetaz = rz[2];
+}
+
+// res = scale * log(R1 R0^T R^T); kind 0: R = measured matrix; 1: R = exp(so3ln(meas)) (Ceres conversion); 2: tilt/roll model with f
+template <typename T>
+__device__ __forceinline__ void edge_residual(int kind, const EdgeConst& e, double scale, const T* r0, const T* r1, const T& f, T* res) {
+    T R[9];
+    if (kind == 0) { for (int i = 0; i < 9; i++) R[i] = T(e.meas[i]); }
+    else if (kind == 1) { const T myr[3] = {T(e.r[0]), T(e.r[1]), T(e.r[2])}; aa_to_matrix_t(myr, R); }
+    else {
+        const T fsq = f * f;
+        const T num = 2.0 * f * sin(e.thetaxy);
+        const T den = (1.0 + fsq) * cos(e.thetaxy) + (1.0 - fsq);
+        const T thp = datan2(num, den);
+        const T rxy[3] = {thp * e.rx, thp * e.ry, T(0.0)};
+        const T rz[3] = {T(0.0), T(0.0), T(e.thetaz)};
+        T Rxy[9], Rz[9]; aa_to_matrix_t(rxy, Rxy); aa_to_matrix_t(rz, Rz);
+        mat3_mul_t(Rxy, Rz, R);
+    }
+    T R0[9], R1[9], A[9], C[9];
+    aa_to_matrix_t(r0, R0); aa_to_matrix_t(r1, R1);
+    mat3_mul_bt_t(R1, R0, A); mat3_mul_bt_t(A, R, C);
+    matrix_to_aa_t(C, res);
+    res[0] = res[0] * scale; res[1] = res[1] * scale; res[2] = res[2] * scale;
+}
+
+__device__ __forceinline__ int find_slot(const int* cols, int n, int key) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cols[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// mode 0: assemble J^T J (block-CSR), J^T r, diag, focal border, cost.  mode 1: model cost change sum m (r + m/2) for step.
+__global__ void __launch_bounds__(64)
+k_rot_edges(int mode, int kind, int E, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec,
+            double scale, double loss_a, const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node,
+            const double* __restrict__ sc_f, const int* __restrict__ row_ptr, const int* __restrict__ col_idx, int n_nodes,
+            const double* __restrict__ step, double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag,
+            double* __restrict__ Sfc, double* __restrict__ scal) {
+    __shared__ double red[3];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[3] = {0, 0, 0};   // cost | FJJ or model | FJR
+    if (e < E) {
+        typedef Dual<7> D;
+        const int i0 = e0[e], i1 = e1[e];
+        D r0[3] = {D(x[3 * i0], 0), D(x[3 * i0 + 1], 1), D(x[3 * i0 + 2], 2)}, r1[3] = {D(x[3 * i1], 3), D(x[3 * i1 + 1], 4), D(x[3 * i1 + 2], 5)};
+        D f(fm[0], 6), res[3];
+        edge_residual<D>(kind, ec[e], scale, r0, r1, f, res);
+        double rho0, rho1; robust_loss(2, loss_a, res[0].a * res[0].a + res[1].a * res[1].a + res[2].a * res[2].a, rho0, rho1);
+        const double sr = sqrt(rho1);
+        acc[0] = 0.5 * rho0;
+        double J0[3][3], J1[3][3], Jf[3], r[3];
+        const double sf = sc_f[0];
+        for (int a = 0; a < 3; a++) {
+            r[a] = sr * res[a].a;
+            for (int k = 0; k < 3; k++) { J0[a][k] = sr * res[a].v[k] * sc_node[3 * i0 + k]; J1[a][k] = sr * res[a].v[3 + k] * sc_node[3 * i1 + k]; }
+            Jf[a] = sr * res[a].v[6] * sf;
+        }
+        if (mode == 1) {
+            const double sfv = step[3 * n_nodes];
+            for (int a = 0; a < 3; a++) {
+                double m = Jf[a] * sfv;
+                for (int k = 0; k < 3; k++) m += J0[a][k] * step[3 * i0 + k] + J1[a][k] * step[3 * i1 + k];
+                acc[1] += m * (r[a] + 0.5 * m);
+            }
+        } else {
+            const int* c0 = col_idx + row_ptr[i0]; const int n0 = row_ptr[i0 + 1] - row_ptr[i0];
+            const int* c1 = col_idx + row_ptr[i1]; const int n1 = row_ptr[i1 + 1] - row_ptr[i1];
+            double* b00 = S_val + (size_t)(row_ptr[i0] + find_slot(c0, n0, i0)) * 9;
+            double* b01 = S_val + (size_t)(row_ptr[i0] + find_slot(c0, n0, i1)) * 9;
+            double* b10 = S_val + (size_t)(row_ptr[i1] + find_slot(c1, n1, i0)) * 9;
+            double* b11 = S_val + (size_t)(row_ptr[i1] + find_slot(c1, n1, i1)) * 9;
+            for (int u = 0; u < 3; u++) {
+                double g0 = 0, g1 = 0, f0 = 0, f1 = 0, d0 = 0, d1 = 0;
+                for (int a = 0; a < 3; a++) { g0 += J0[a][u] * r[a]; g1 += J1[a][u] * r[a]; f0 += Jf[a] * J0[a][u]; f1 += Jf[a] * J1[a][u];
+                                              d0 += J0[a][u] * J0[a][u]; d1 += J1[a][u] * J1[a][u]; }
+                unsafeAtomicAdd(&rhs[3 * i0 + u], g0); unsafeAtomicAdd(&rhs[3 * i1 + u], g1);
+                unsafeAtomicAdd(&Sfc[3 * i0 + u], f0); unsafeAtomicAdd(&Sfc[3 * i1 + u], f1);
+                unsafeAtomicAdd(&Udiag[3 * i0 + u], d0); unsafeAtomicAdd(&Udiag[3 * i1 + u], d1);
+                for (int v = 0; v < 3; v++) {
+                    double s00 = 0, s01 = 0, s11 = 0;
+                    for (int a = 0; a < 3; a++) { s00 += J0[a][u] * J0[a][v]; s01 += J0[a][u] * J1[a][v]; s11 += J1[a][u] * J1[a][v]; }
+                    unsafeAtomicAdd(&b00[3 * u + v], s00); unsafeAtomicAdd(&b11[3 * u + v], s11);
+                    if (i0 != i1) { unsafeAtomicAdd(&b01[3 * u + v], s01); unsafeAtomicAdd(&b10[3 * v + u], s01); }
+                    else unsafeAtomicAdd(&b00[3 * u + v], s01 + (J1[0][u] * J0[0][v] + J1[1][u] * J0[1][v] + J1[2][u] * J0[2][v]));
+                }
+            }
+            for (int a = 0; a < 3; a++) { acc[1] += Jf[a] * Jf[a]; acc[2] += Jf[a] * r[a]; }
+        }
+    }
+    for (int i = 0; i < 3; i++) { acc[i] = wave_sum(acc[i]); }
+    (void)red;
+    if ((threadIdx.x & 63) == 0) {
+        if (mode == 1) unsafeAtomicAdd(&scal[SC_MODEL], acc[1]);
+        else { unsafeAtomicAdd(&scal[SC_COST], acc[0]); unsafeAtomicAdd(&scal[SC_FJJ], acc[1]); unsafeAtomicAdd(&scal[SC_FJR], acc[2]); }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_rot_cost(int kind, int E, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
+           const double* __restrict__ x, const double* __restrict__ fm, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0.0;
+    if (e < E) {
+        const int i0 = e0[e], i1 = e1[e];
+        const double r0[3] = {x[3 * i0], x[3 * i0 + 1], x[3 * i0 + 2]}, r1[3] = {x[3 * i1], x[3 * i1 + 1], x[3 * i1 + 2]};
+        double res[3]; edge_residual<double>(kind, ec[e], scale, r0, r1, fm[0], res);
+        double rho0, rho1; robust_loss(2, loss_a, res[0] * res[0] + res[1] * res[1] + res[2] * res[2], rho0, rho1);
+        c = 0.5 * rho0;
+    }
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, c);
+}
+
+// candidate = Plus(x, scale o step) with the box projection on the focal multiplier (Ceres ParameterBlock::Plus);
+// also |x - candidate|^2, |candidate|^2 and the projected-gradient max norm |x - Plus(x, -g)|_inf
+__global__ void __launch_bounds__(1024)
+k_rot_update(int n_nodes, const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node,
+             const double* __restrict__ sc_f, const double* __restrict__ y, const double* __restrict__ rhs_raw, double f_lo, double f_hi,
+             double* __restrict__ xc, double* __restrict__ fmc, double* __restrict__ step, double* __restrict__ scal) {
+    __shared__ double red[3 * 16];
+    double acc[2] = {0, 0}; double gmax = 0.0;
+    const int n = 3 * n_nodes;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double s = sc_node[i]; double v = x[i];
+        const double st = -y[i]; step[i] = st;
+        if (s > 0.0) { const double d = st * s; v += d; acc[0] += d * d; acc[1] += v * v; gmax = fmax(gmax, fabs(rhs_raw[i] / s)); }
+        xc[i] = v;
+    }
+    if (threadIdx.x == 0) {
+        const double s = sc_f[0]; double v = fm[0]; const double st = -y[n]; step[n] = st;
+        if (s > 0.0) {
+            const double nv = fmin(fmax(v + st * s, f_lo), f_hi);
+            acc[0] += (nv - v) * (nv - v); acc[1] += nv * nv;
+            const double g = rhs_raw[n] / s;                       // unscaled gradient of the focal multiplier
+            gmax = fmax(gmax, fabs(v - fmin(fmax(v - g, f_lo), f_hi)));
+            v = nv;
+        }
+        fmc[0] = v;
+    }
+    block_sum<2>(acc, red);
+    gmax = wave_max(gmax);
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
+    if (threadIdx.x == 0) { scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; }
+}
+
+struct RotGraph {
+    int n = 0, E = 0, kind = 0;
+    double scale = 1.0;
+    std::vector<int> e0, e1;
+    std::vector<EdgeConst> ec;
+    std::vector<double> x0;            // [3n] so3ln of the input rotations
+    std::vector<double> mask;          // [3n]
+};
+
+static void build_graph(int n, const double* rotations_cm, int E, const int32_t* i0, const int32_t* i1, const double* rel_cm, int kind,
+                        bool hold_first, RotGraph& G) {
+    G.n = n; G.E = E; G.kind = kind; G.e0.assign(i0, i0 + E); G.e1.assign(i1, i1 + E); G.ec.resize(E); G.x0.resize((size_t)3 * n);
+    for (int i = 0; i < n; i++) { double R[9]; for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) R[3 * a + b] = rotations_cm[9 * i + a + 3 * b]; so3ln(R, &G.x0[3 * i]); }
+    double maxn = 0;
+    for (int e = 0; e < E; e++) {
+        EdgeConst& c = G.ec[e];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c.meas[3 * a + b] = rel_cm[9 * e + a + 3 * b];
+        so3ln(c.meas, c.r);
+        maxn = std::max(maxn, norm3(c.r));
+        c.rx = c.ry = c.thetaxy = c.thetaz = 0;
+        if (kind == 2) { double Rr[9]; so3exp(c.r, Rr); decompose_rotation_host(Rr, c.rx, c.ry, c.thetaxy, c.thetaz); }
+    }
+    G.scale = 1.0 / maxn;                                  // src/rotation_averaging.cpp:50-55,63
+    G.mask.assign((size_t)3 * n, 0.0);
+    std::vector<char> in(n, 0);
+    for (int e = 0; e < E; e++) in[i0[e]] = in[i1[e]] = 1;
+    for (int i = 0; i < n; i++) if (in[i] && !(hold_first && i == 0)) G.mask[3 * i] = G.mask[3 * i + 1] = G.mask[3 * i + 2] = 1.0;   // :73
+}
+
+}  // namespace ssfm
+using namespace ssfm;
+
+extern "C" void ssfm_rotavg_default_options(ssfm_ba_options* o) {
+    ssfm_ba_default_options(o);
+    o->max_num_iterations = 50; o->max_num_consecutive_invalid_steps = 5;     // Ceres defaults (src/rotation_averaging.cpp:75-78)
+    o->loss_type = 2; o->loss_scale = 0.03;                                   // SoftLOneLoss(0.03), src/rotation_averaging.cpp:58
+}
+
+extern "C" int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
+                                const double* rel_rotations, double* cost) {
+    if (!ctx || !rotations || !cost || E <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg_cost: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    RotGraph G; build_graph(n, rotations, E, index0, index1, rel_rotations, 1, false, G);   // PoseGraphError, src/uncalibrated_pose_graph.cpp:131
+    DevBuf<double> x, fm, out; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    std::vector<double> one = {1.0}, zero = {0.0};
+    SSFM_HIP_CHECK(ctx, upload(x, G.x0, st)); SSFM_HIP_CHECK(ctx, upload(fm, one, st)); SSFM_HIP_CHECK(ctx, upload(out, zero, st));
+    SSFM_HIP_CHECK(ctx, upload(e0, G.e0, st)); SSFM_HIP_CHECK(ctx, upload(e1, G.e1, st)); SSFM_HIP_CHECK(ctx, upload(ec, G.ec, st));
+    hipLaunchKernelGGL(k_rot_cost, dim3((E + 63) / 64), dim3(64), 0, st, 1, E, e0.p, e1.p, ec.p, G.scale, 0.03, x.p, fm.p, out.p);
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(cost, out.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    x.free(); fm.free(); out.free(); e0.free(); e1.free(); ec.free();
+    return SSFM_OK;
+}
+
+static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
+                     const double* rel, double* focal_length, double min_focal, double max_focal, const ssfm_ba_options* opt_in,
+                     ssfm_ba_summary* S) {
+    if (!ctx || !rotations || !S || E <= 0 || n <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::memset(S, 0, sizeof(*S));
+    ssfm_ba_options O; if (opt_in) O = *opt_in; else ssfm_rotavg_default_options(&O);
+    const double t0 = wall_s();
+    RotGraph G; build_graph(n, rotations, E, index0, index1, rel, kind, true, G);
+    const bool with_f = kind == 2;
+    const double f_lo = with_f ? min_focal / *focal_length : 0.0, f_hi = with_f ? max_focal / *focal_length : 0.0;   // :181-182
+    // ---- reduced-system container (the BA handle's solver state with DC = 3)
+    ssfm_ba_handle H; ssfm_ba_handle* h = &H;
+    h->ctx = ctx; h->opt = O;
+    std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
+    BAFlat& F = h->F; F.Nc = n; F.DC = 3;
+    {
+        std::vector<std::vector<int>> nb(n);
+        for (int e = 0; e < E; e++) { nb[index0[e]].push_back(index1[e]); nb[index1[e]].push_back(index0[e]); }
+        F.row_ptr.assign(n + 1, 0); F.diag_slot.assign(n, 0);
+        for (int i = 0; i < n; i++) { auto& v = nb[i]; v.push_back(i); std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+                                      F.row_ptr[i + 1] = F.row_ptr[i] + (int)v.size(); F.max_row_blocks = std::max(F.max_row_blocks, (int)v.size()); }
+        F.col_idx.resize(F.row_ptr[n]);
+        for (int i = 0; i < n; i++) { std::copy(nb[i].begin(), nb[i].end(), F.col_idx.begin() + F.row_ptr[i]);
+                                      F.diag_slot[i] = (int)(std::lower_bound(nb[i].begin(), nb[i].end(), i) - nb[i].begin()); }
+        F.band = cuthill_mckee(n, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
+        for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
+    }
+    const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
+    // scale laid out 6 per node (slots 3..5) so that k_finalize_S<3> can be reused unchanged
+    std::vector<double> mask6((size_t)6 * n, 0.0); for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) mask6[6 * i + 3 + k] = G.mask[3 * i + k];
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, redz; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    std::vector<double> fmv = {1.0, 1.0};
+#define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
+    UPV(x, G.x0); UPV(fm2, fmv); UPV(e0, G.e0); UPV(e1, G.e1); UPV(ec, G.ec);
+    UPV(h->row_ptr, F.row_ptr); UPV(h->col_idx, F.col_idx); UPV(h->diag_slot, F.diag_slot); UPV(h->cam_pos, F.cam_pos);
+    UPV(h->band_pairs, F.band_pairs); UPV(h->comp_ptr, F.comp_ptr);
+#undef UPV
+#define ALV(buf, count) SSFM_HIP_CHECK(ctx, buf.alloc(count))
+    ALV(xc, nn); ALV(sc3, nn); ALV(sc6, 6 * (size_t)n); ALV(scf, 1); ALV(step, nn + 1);
+    const size_t n_red = nnzb * 9 + (nn + 1) + 3 * nn;
+    ALV(h->redbuf, n_red);
+    h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * 9; h->Udiag = h->rhs + (nn + 1); h->Sfc = h->Udiag + nn; h->gcraw = h->Sfc + nn;
+    ALV(h->Minv, (size_t)n * 9); ALV(h->Sff, 1); ALV(h->px, nn + 1); ALV(h->pr, nn + 1); ALV(h->pz, nn + 1); ALV(h->pp, nn + 1); ALV(h->pq, nn + 1);
+    ALV(h->pqpart, (size_t)n); ALV(h->scal, SC_TOTAL); ALV(h->pcg, PCG_TOTAL + 1);
+    ALV(h->band, (size_t)n * (F.band + 1) * 9); ALV(h->Linv, (size_t)n * 9); ALV(h->Yb, 2 * nn); ALV(h->Yr, 2 * nn);
+#undef ALV
+    double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
+    const int ge = (E + 63) / 64, gn = (n + 63) / 64;
+    const double la = O.loss_scale;
+    double host_scal[SC_TOTAL], host_pcg[PCG_TOTAL + 1];
+    auto assemble = [&](const double* s3, const double* sf) -> int {
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
+        hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
+                           (const double*)nullptr, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
+        return SSFM_OK;
+    };
+    // ---- Jacobi scaling from the initial Jacobian: s = mask / (1 + |J_col|)
+    {
+        DevBuf<double> m3, mf; std::vector<double> mfv = {with_f ? 1.0 : 0.0};
+        SSFM_HIP_CHECK(ctx, upload(m3, G.mask, st)); SSFM_HIP_CHECK(ctx, upload(mf, mfv, st));
+        int rc = assemble(m3.p, mf.p); if (rc) return rc;
+        hipLaunchKernelGGL(k_make_scale, dim3((3 * n + 255) / 256), dim3(256), 0, st, h->Udiag, m3.p, sc3.p, 3 * n, O.jacobi_scaling);
+        hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->scal.p + SC_FJJ, mf.p, scf.p, 1, O.jacobi_scaling);
+        std::vector<double> s3h(nn), s6h((size_t)6 * n, 0.0);
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s3h.data(), sc3.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) s6h[6 * i + 3 + k] = s3h[3 * i + k];
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(sc6.p, s6h.data(), s6h.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        m3.free(); mf.free();
+    }
+    double x_norm = 0; { double s2 = with_f ? 1.0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
+    double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
+    int iteration = 0, num_invalid = 0; bool last_successful = true;
+    S->num_successful_steps = 1; S->termination = SSFM_NO_CONVERGENCE; S->camera_dof = 3; S->num_residual_blocks = S->num_residual_blocks_global = E;
+    while (true) {
+        if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
+        if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
+        iteration++;
+        { int rc = assemble(sc3.p, scf.p); if (rc) return rc; }
+        LAUNCH(h, KID_FINALIZE, k_finalize_S<3>, gn, 64, 0, h->row_ptr.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal,
+               O.max_lm_diagonal, n, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
+        int pcg_iters = 0; bool pcg_ok = false;
+        { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
+        auto tail = [&]() -> int {
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_GMAX, 0, sizeof(double), st));
+            hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, xcand, fmc, step.p, h->scal.p);
+            hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
+                               step.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
+            hipLaunchKernelGGL(k_rot_cost, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xcand, fmc, h->scal.p + SC_CAND_COST);
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (O.preconditioner == 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, (PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            return SSFM_OK;
+        };
+        { int rc = tail(); if (rc) return rc; }
+        if (O.preconditioner == 0) {
+            int ff; std::memcpy(&ff, &host_pcg[PCG_TOTAL], sizeof(int));
+            if (ff) pcg_ok = false;
+            else if (host_pcg[PCG_DONE] == 0.0) {
+                int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 1); if (rc) return rc;
+                SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_MODEL, 0, 4 * sizeof(double), st));
+                rc = tail(); if (rc) return rc;
+            }
+        }
+        S->pcg_iterations_total += pcg_iters; S->num_linearizations++;
+        x_cost = host_scal[SC_COST];
+        double gmax; { unsigned long long bits; std::memcpy(&bits, &host_scal[SC_GMAX], 8); std::memcpy(&gmax, &bits, 8); }
+        if (iteration == 1) { S->initial_cost = x_cost; minimum_cost = x_cost; }
+        if (!std::isfinite(x_cost)) { S->termination = SSFM_FAILURE; break; }
+        if (last_successful && gmax <= O.gradient_tolerance) { S->termination = SSFM_CONVERGENCE; iteration--; break; }
+        const double model_cost_change = -host_scal[SC_MODEL];
+        const bool valid = pcg_ok && std::isfinite(model_cost_change) && model_cost_change > 0.0;
+        if (!valid) {
+            if (++num_invalid >= O.max_num_consecutive_invalid_steps) { S->termination = SSFM_FAILURE; break; }
+            radius /= decrease_factor; decrease_factor *= 2.0; last_successful = false; S->num_unsuccessful_steps++;
+            continue;
+        }
+        num_invalid = 0;
+        double cand_cost = host_scal[SC_CAND_COST]; if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+        const double step_norm = std::sqrt(host_scal[SC_STEP2_CAM]);
+        if (step_norm <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) { S->termination = SSFM_CONVERGENCE; break; }
+        const double cost_change = x_cost - cand_cost;
+        if (std::fabs(cost_change) <= O.function_tolerance * x_cost) { S->termination = SSFM_CONVERGENCE; break; }
+        const double rel = (cand_cost >= std::numeric_limits<double>::max()) ? std::numeric_limits<double>::lowest() : cost_change / model_cost_change;
+        if (rel > O.min_relative_decrease) {
+            std::swap(xx, xcand); std::swap(fmx, fmc);
+            x_norm = std::sqrt(host_scal[SC_XN2_CAM]);
+            radius = std::fmin(O.max_trust_region_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+            decrease_factor = 2.0; last_successful = true; S->num_successful_steps++;
+            x_cost = cand_cost; if (x_cost < minimum_cost) minimum_cost = x_cost;
+        } else { radius /= decrease_factor; decrease_factor *= 2.0; last_successful = false; S->num_unsuccessful_steps++; }
+        if (O.verbose) std::printf("[ssfm rot] iter %3d cost %.12e change %.3e |g| %.3e |step| %.3e rho %.3e radius %.3e %s\n", iteration, x_cost, cost_change,
+                                   gmax, step_norm, rel, radius, last_successful ? "" : "(rejected)");
+    }
+    S->iterations = iteration; S->final_cost = (minimum_cost == std::numeric_limits<double>::max()) ? x_cost : minimum_cost;
+    S->reduced_blocks = (int32_t)nnzb; S->band_half_width = F.band;
+    // ---- back to rotation matrices: every rotation is re-exponentiated (src/rotation_averaging.cpp:88)
+    std::vector<double> xf(nn); double fmult = 1.0;
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(xf.data(), xx, nn * sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&fmult, fmx, sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) { double R[9]; so3exp(&xf[3 * i], R); for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rotations[9 * i + a + 3 * b] = R[3 * a + b]; }
+    if (with_f) *focal_length *= fmult;                                         // src/uncalibrated_pose_graph.cpp:200
+    x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); e0.free(); e1.free(); ec.free();
+    h->free_all();
+    S->t_solve_s = wall_s() - t0;
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_rotavg_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
+                                 const double* rel_rotations, const ssfm_ba_options* o, ssfm_ba_summary* s) {
+    return rot_solve(ctx, 0, n, rotations, E, index0, index1, rel_rotations, nullptr, 0, 0, o, s);
+}
+
+extern "C" int ssfm_posegraph_focal_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
+                                          const double* rel_rotations, double* focal_length, double min_focal, double max_focal,
+                                          const ssfm_ba_options* o, ssfm_ba_summary* s) {
+    if (!focal_length) return fail(ctx, SSFM_ERR_INVALID, "ssfm_posegraph_focal_solve: focal_length is null");
+    return rot_solve(ctx, 2, n, rotations, E, index0, index1, rel_rotations, focal_length, min_focal, max_focal, o, s);
+}

@@ -1,0 +1,52 @@
+"""GPU parity of the SO(3) pose-graph solvers against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rot_angle(A, B):
+    return np.array([np.linalg.norm(Rotation.from_matrix(a @ b.T).as_rotvec()) for a, b in zip(A, B)])
+
+
+@pytest.mark.parametrize("n,d", [(24, 4), (60, 6), (300, 8)])
+def test_optimize_rotations_matches_oracle(gpu_ctx, oracle, n, d):
+    from spherical_sfm_amd import rotavg
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(n, d)
+    R, cost, s = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel)
+    Ro, co, so = oracle.optimize_rotations(R0.copy(), i0, i1, Rrel)
+    assert s["termination"] == so["termination"] and s["iterations"] == so["iterations"]
+    assert abs(cost - co) <= 1e-9 * co
+    assert rot_angle(R, Ro).max() <= 1e-5                         # <= 1e-5 rad between the two answers
+    assert np.allclose(R[0], R0[0], atol=1e-14)                    # first rotation held constant (src/rotation_averaging.cpp:73)
+
+
+def test_get_cost_matches_oracle(gpu_ctx, oracle):
+    from spherical_sfm_amd import rotavg
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(120, 8)
+    for R in (R0, Rgt):
+        c = rotavg.get_cost(gpu_ctx, R, i0, i1, Rrel)
+        assert abs(c - oracle.get_cost(R, i0, i1, Rrel)) <= 1e-11 * max(c, 1e-30)
+
+
+def test_consistent_graph_is_a_fixed_point(gpu_ctx):
+    from spherical_sfm_amd import rotavg
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(40, 4, noise_deg=0.0, outlier_frac=0.0)
+    assert rotavg.get_cost(gpu_ctx, Rgt, i0, i1, Rrel) < 1e-20
+    R, cost, s = rotavg.optimize_rotations(gpu_ctx, Rgt.copy(), i0, i1, Rrel)
+    assert cost < 1e-20 and rot_angle(R, Rgt).max() < 1e-9
+
+
+@pytest.mark.parametrize("bounds", [(400.0, 1600.0), (790.0, 810.0)])
+def test_focal_pose_graph_matches_oracle(gpu_ctx, oracle, bounds):
+    from spherical_sfm_amd import rotavg
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(60, 6, noise_deg=0.2, outlier_frac=0.02)
+    R, f, cost, s = rotavg.optimize_rotations_and_focal_length(gpu_ctx, R0, i0, i1, Rrel, 800.0, *bounds)
+    Ro, fo, co, so = oracle.optimize_rotations_and_focal_length(R0.copy(), i0, i1, Rrel, 800.0, *bounds)
+    assert bounds[0] - 1e-9 <= f <= bounds[1] + 1e-9
+    assert s["termination"] == so["termination"] and s["iterations"] == so["iterations"]
+    assert abs(cost - co) <= 1e-8 * co and abs(f - fo) <= 1e-5 * fo
+    assert rot_angle(R, Ro).max() <= 1e-5
