@@ -150,6 +150,31 @@ int ssfm_posegraph_focal_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int3
                                const int32_t* index1, const double* rel_rotations, double* focal_length, double min_focal,
                                double max_focal, const ssfm_ba_options* o, ssfm_ba_summary* s);
 
+/* ---- batched spherical relative-pose RANSAC ----------------------------------------------------------
+ * Replaces the OpenMP loop body of estimate_pairwise (examples/spherical_sfm_tools.cpp:332-420): per image pair
+ * LocallyOptimizedMSAC<..., SphericalEstimator>::EstimateModel (include/RansacLib/ransac.h:128) with the action-matrix
+ * minimal solver, final least squares, inlier mask and Decompose.  Pair p owns rays [pair_ptr[p], pair_ptr[p+1]) of
+ * u / v ([total*3]; u = first view, v = second view, as RayPair, include/sphericalsfm/ray.h:8-10).
+ * squared_inlier_threshold = (inlier_threshold_px * Kinv(0,0))^2 (spherical_sfm_tools.cpp:315).
+ * Outputs (any may be NULL): E, R [num_pairs*9] column-major; inlier_mask [total]; num_inliers, scores [num_pairs].
+ * R is the identity where num_inliers <= min_num_inliers (the reference skips such pairs, :410). */
+typedef struct {
+    int32_t num_hypotheses;      /* minimal samples per pair (fixed budget; default 1024) */
+    uint32_t seed;               /* RansacOptions::random_seed_ (default 0) */
+    int32_t min_num_inliers;     /* acceptance threshold of estimate_pairwise */
+    int32_t final_least_squares; /* LORansacOptions::final_least_squares_ (default 1, spherical_sfm_tools.cpp:318) */
+    int32_t inward;              /* SphericalEstimator(..., inward) */
+} ssfm_ransac_options;
+void ssfm_ransac_default_options(ssfm_ransac_options* o);
+int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
+                      double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
+                      int32_t* num_inliers, double* scores);
+/* parity probe: spherical_solver_action_matrix (src/spherical_solvers.cpp:102-311) on S given 3-point samples
+ * (samples: [S*3] indices into the n rays).  Es: [S*36] = up to 4 column-major 3x3 per sample (real solutions only),
+ * counts: [S]. */
+int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
+                                double* Es, int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

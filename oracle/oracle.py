@@ -80,6 +80,16 @@ def lib():
         L.oracle_optimize_rotations_and_focal_length.restype = C.c_double
         L.oracle_rotation_edge.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_double, c_double_p, C.c_double, c_double_p, c_double_p]
         L.oracle_rotation_edge.restype = None
+        L.oracle_sampson.argtypes = [c_double_p, c_double_p, c_double_p]; L.oracle_sampson.restype = C.c_double
+        L.oracle_spherical_solver.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p]; L.oracle_spherical_solver.restype = C.c_int
+        L.oracle_make_spherical_essential_matrix.argtypes = [c_double_p, C.c_int32, c_double_p]; L.oracle_make_spherical_essential_matrix.restype = None
+        L.oracle_decompose_spherical_essential_matrix.argtypes = [c_double_p, C.c_int32, c_double_p, c_double_p]
+        L.oracle_decompose_spherical_essential_matrix.restype = None
+        L.oracle_sampson_least_squares.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, C.c_int32, c_double_p]
+        L.oracle_sampson_least_squares.restype = None
+        L.oracle_ransac_pair.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
+                                         c_double_p, c_double_p, c_u8_p, C.POINTER(C.c_uint32), c_double_p]
+        L.oracle_ransac_pair.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -211,3 +221,50 @@ def rotation_edge(kind, r0, r1, f, Rmeas, scale):
     res = np.zeros(3); jac = np.zeros(21)
     lib().oracle_rotation_edge(kind, _dp(r0), _dp(r1), f, _dp(Rm), scale, _dp(res), _dp(jac))
     return res, jac.reshape(3, 7)
+
+
+# ---------------------------------------------------------------- spherical relative pose
+def _m(M):
+    """(3,3) indexed [i,j] -> column-major flat"""
+    return np.ascontiguousarray(np.asarray(M, np.float64).T).reshape(-1).copy()
+
+
+def _um(flat):
+    return np.asarray(flat, np.float64).reshape(3, 3).T.copy()
+
+
+def sampson(E, u, v):
+    Ec = _m(E); u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    return lib().oracle_sampson(_dp(Ec), _dp(u), _dp(v))
+
+
+def spherical_solver(u, v, sample):
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(sample, np.int32)
+    out = np.zeros(36)
+    k = lib().oracle_spherical_solver(len(u), _dp(u), _dp(v), len(s), _ip(s), _dp(out))
+    return [_um(out[9 * i:9 * i + 9]) for i in range(k)]
+
+
+def make_spherical_essential_matrix(R, inward=False):
+    out = np.zeros(9); Rc = _m(R)
+    lib().oracle_make_spherical_essential_matrix(_dp(Rc), int(inward), _dp(out)); return _um(out)
+
+
+def decompose_spherical_essential_matrix(E, inward=False):
+    r = np.zeros(3); t = np.zeros(3); Ec = _m(E)
+    lib().oracle_decompose_spherical_essential_matrix(_dp(Ec), int(inward), _dp(r), _dp(t)); return r, t
+
+
+def sampson_least_squares(u, v, sample, E, inward=False):
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(sample, np.int32)
+    Ec = _m(E)
+    lib().oracle_sampson_least_squares(len(u), _dp(u), _dp(v), len(s), _ip(s), int(inward), _dp(Ec)); return _um(Ec)
+
+
+def ransac_pair(u, v, sq_thresh, inward=False, min_iterations=100, max_iterations=10000, seed=0, min_num_inliers=0):
+    """estimate_pairwise's per-pair work.  -> dict(E, R, inliers mask, num_inliers, iterations, score)"""
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    E = np.zeros(9); R = np.zeros(9); mask = np.zeros(len(u), np.uint8); it = C.c_uint32(0); sc = C.c_double(0)
+    n = lib().oracle_ransac_pair(len(u), _dp(u), _dp(v), int(inward), sq_thresh, min_iterations, max_iterations, seed, min_num_inliers,
+                                 _dp(E), _dp(R), _up(mask), C.byref(it), C.byref(sc))
+    return dict(E=_um(E), R=_um(R), inliers=mask.astype(bool), num_inliers=n, iterations=it.value, score=sc.value)

@@ -1,0 +1,448 @@
+// ORACLE (test infrastructure only) -- CPU restatement of the spherical relative-pose RANSAC path.
+//
+//  * EvaluateModelOnPoint (Sampson)           src/spherical_estimator.cpp:67-78
+//  * spherical_solver_action_matrix           src/spherical_solvers.cpp:102-311
+//      rows of A (:119); nullspace basis B = last three columns of Q from a column-pivoted Householder QR of A^T
+//      (:124-125); the 6x10 matrix C (:127-277) holds the cubic forms  -T01, T20, T00, T21, T12, T22  of
+//      T = 2 E E^T E - tr(E E^T) E  with  E = [[p0,p1,p2],[p1,-p0,p3],[p4,p5,0]],  p = B (x,y,z)^T, over the monomials
+//      [x^3, x^2y, xy^2, y^3, x^2z, xyz, y^2z, xz^2, yz^2, z^3]  (identified symbolically; built here by polynomial
+//      arithmetic from that definition, not from the reference's generated expressions);  G = C[:, :6]^-1 C[:, 6:] (:279);
+//      4x4 action matrix for multiplication by x on the basis [y^2, x, y, 1] (:281-285); solutions = rows 1..3 of its
+//      eigenvectors (:296), E normalised to unit Frobenius norm (:305).  The reference keeps the REAL PART of complex
+//      eigenvectors as returned by Eigen::EigenSolver; such candidates are never valid models, and the oracle gives
+//      them the deterministic stand-in Re(v) with v scaled so that its last entry is 1.
+//  * NonMinimalSolver / LeastSquares / Decompose   src/spherical_estimator.cpp:86-164  (SampsonError :23-65)
+//  * make / decompose_spherical_essential_matrix   src/spherical_utils.cpp:9-66
+//  * LocallyOptimizedMSAC::EstimateModel, LocalOptimization, LeastSquaresFit, GetInliers   include/RansacLib/ransac.h:128-420
+//  * UniformSampling (std::mt19937 + std::uniform_int_distribution, libstdc++)          include/RansacLib/sampling.h:46-135
+//  * NumRequiredIterations, RandomShuffleAndResize                                      include/RansacLib/utils.h:48-140
+//  * estimate_pairwise per-pair logic                examples/spherical_sfm_tools.cpp:309-431
+// PARITY UNPINNED (ssfm_oracle.h).  3x3 matrices cross the C API column-major.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+#include "lm.hpp"
+#include "rotation.hpp"
+#include "ssfm_oracle.h"
+
+namespace oracle {
+
+struct Rays { int n; const double* u; const double* v; };   // [n*3] each
+
+// E row-major inside this file
+static inline double sampson(const double* E, const double* u, const double* v) {
+    const double Eu[3] = {E[0] * u[0] + E[1] * u[1] + E[2] * u[2], E[3] * u[0] + E[4] * u[1] + E[5] * u[2], E[6] * u[0] + E[7] * u[1] + E[8] * u[2]};
+    const double Etv[2] = {E[0] * v[0] + E[3] * v[1] + E[6] * v[2], E[1] * v[0] + E[4] * v[1] + E[7] * v[2]};
+    const double d = v[0] * Eu[0] + v[1] * Eu[1] + v[2] * Eu[2];
+    return (d * d) / (Eu[0] * Eu[0] + Eu[1] * Eu[1] + Etv[0] * Etv[0] + Etv[1] * Etv[1]);
+}
+
+// ---- small polynomial algebra in (x,y,z): linear (3), quadratic (6: xx xy xz yy yz zz), cubic (10, order above)
+struct Lin { double c[3]; };
+struct Quad { double c[6]; };
+struct Cub { double c[10]; };
+static inline Quad mul(const Lin& a, const Lin& b) {
+    Quad q; q.c[0] = a.c[0] * b.c[0]; q.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0]; q.c[2] = a.c[0] * b.c[2] + a.c[2] * b.c[0];
+    q.c[3] = a.c[1] * b.c[1]; q.c[4] = a.c[1] * b.c[2] + a.c[2] * b.c[1]; q.c[5] = a.c[2] * b.c[2]; return q; }
+static inline Quad add(const Quad& a, const Quad& b) { Quad q; for (int i = 0; i < 6; i++) q.c[i] = a.c[i] + b.c[i]; return q; }
+// cubic monomials: 0 x3, 1 x2y, 2 xy2, 3 y3, 4 x2z, 5 xyz, 6 y2z, 7 xz2, 8 yz2, 9 z3
+static inline void acc(Cub& r, const Quad& q, const Lin& l, double s) {
+    const double* a = q.c; const double* b = l.c;
+    r.c[0] += s * (a[0] * b[0]);
+    r.c[1] += s * (a[0] * b[1] + a[1] * b[0]);
+    r.c[2] += s * (a[1] * b[1] + a[3] * b[0]);
+    r.c[3] += s * (a[3] * b[1]);
+    r.c[4] += s * (a[0] * b[2] + a[2] * b[0]);
+    r.c[5] += s * (a[1] * b[2] + a[2] * b[1] + a[4] * b[0]);
+    r.c[6] += s * (a[3] * b[2] + a[4] * b[1]);
+    r.c[7] += s * (a[2] * b[2] + a[5] * b[0]);
+    r.c[8] += s * (a[4] * b[2] + a[5] * b[1]);
+    r.c[9] += s * (a[5] * b[2]);
+}
+
+// Householder QR with column pivoting of the 6 x N matrix A^T; returns Q (6x6, row-major)
+static void qr_colpiv_Q(std::vector<double> At, int N, double Q[36]) {      // At row-major 6 x N, modified
+    const int rows = 6, steps = std::min(rows, N);
+    std::vector<std::vector<double>> vs; std::vector<double> taus;
+    std::vector<double> colnorm(N);
+    for (int j = 0; j < N; j++) { double s = 0; for (int i = 0; i < rows; i++) s += At[i * N + j] * At[i * N + j]; colnorm[j] = s; }
+    for (int k = 0; k < steps; k++) {
+        int piv = k; double best = -1;
+        for (int j = k; j < N; j++) { double s = 0; for (int i = k; i < rows; i++) s += At[i * N + j] * At[i * N + j]; colnorm[j] = s; if (s > best) { best = s; piv = j; } }
+        if (piv != k) for (int i = 0; i < rows; i++) std::swap(At[i * N + k], At[i * N + piv]);
+        std::vector<double> v(rows, 0.0);
+        double alpha = 0; for (int i = k; i < rows; i++) alpha += At[i * N + k] * At[i * N + k];
+        alpha = std::sqrt(alpha);
+        if (alpha == 0.0) { vs.push_back(v); taus.push_back(0.0); continue; }
+        const double x0 = At[k * N + k];
+        const double beta = (x0 >= 0) ? -alpha : alpha;
+        for (int i = k; i < rows; i++) v[i] = At[i * N + k];
+        v[k] = x0 - beta;
+        double vn = 0; for (int i = k; i < rows; i++) vn += v[i] * v[i];
+        const double tau = (vn > 0) ? 2.0 / vn : 0.0;
+        for (int j = k; j < N; j++) { double d = 0; for (int i = k; i < rows; i++) d += v[i] * At[i * N + j]; d *= tau; for (int i = k; i < rows; i++) At[i * N + j] -= d * v[i]; }
+        vs.push_back(v); taus.push_back(tau);
+    }
+    for (int i = 0; i < 36; i++) Q[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    for (int k = (int)vs.size() - 1; k >= 0; k--) {       // Q = H0 H1 ... applied to I from the right-most
+        const auto& v = vs[k]; const double tau = taus[k];
+        for (int j = 0; j < 6; j++) { double d = 0; for (int i = 0; i < 6; i++) d += v[i] * Q[i * 6 + j]; d *= tau; for (int i = 0; i < 6; i++) Q[i * 6 + j] -= d * v[i]; }
+    }
+}
+
+static bool lu_solve6(double A[36], double Bm[24]) {      // A 6x6 row-major, B 6x4; partial pivoting (Eigen .lu())
+    for (int k = 0; k < 6; k++) {
+        int p = k; for (int i = k + 1; i < 6; i++) if (std::fabs(A[i * 6 + k]) > std::fabs(A[p * 6 + k])) p = i;
+        if (A[p * 6 + k] == 0.0) return false;
+        if (p != k) { for (int j = 0; j < 6; j++) std::swap(A[k * 6 + j], A[p * 6 + j]); for (int j = 0; j < 4; j++) std::swap(Bm[k * 4 + j], Bm[p * 4 + j]); }
+        for (int i = k + 1; i < 6; i++) {
+            const double f = A[i * 6 + k] / A[k * 6 + k];
+            for (int j = k; j < 6; j++) A[i * 6 + j] -= f * A[k * 6 + j];
+            for (int j = 0; j < 4; j++) Bm[i * 4 + j] -= f * Bm[k * 4 + j];
+        }
+    }
+    for (int k = 5; k >= 0; k--) for (int j = 0; j < 4; j++) {
+        double s = Bm[k * 4 + j]; for (int i = k + 1; i < 6; i++) s -= A[k * 6 + i] * Bm[i * 4 + j];
+        Bm[k * 4 + j] = s / A[k * 6 + k];
+    }
+    return true;
+}
+
+typedef std::complex<double> cd;
+// eigenvalues of a real 4x4: shifted QR on the Hessenberg form would be the textbook way; for a 4x4 the characteristic
+// polynomial (Faddeev-LeVerrier) + Durand-Kerner/Newton polishing is exact enough and short.
+static void eig4(const double M[16], cd lam[4]) {
+    double c[5]; // lambda^4 + c3 l^3 + c2 l^2 + c1 l + c0
+    double Mk[16], I[16]; for (int i = 0; i < 16; i++) { I[i] = (i % 5 == 0); Mk[i] = M[i]; }
+    double cc[4];
+    double Bk[16]; std::memcpy(Bk, I, sizeof(I));   // B1 = I
+    for (int k = 1; k <= 4; k++) {
+        double AB[16]; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int t = 0; t < 4; t++) s += M[i * 4 + t] * Bk[t * 4 + j]; AB[i * 4 + j] = s; }
+        double tr = AB[0] + AB[5] + AB[10] + AB[15];
+        cc[k - 1] = -tr / k;
+        for (int i = 0; i < 16; i++) Bk[i] = AB[i] + cc[k - 1] * I[i];
+    }
+    c[4] = 1; c[3] = cc[0]; c[2] = cc[1]; c[1] = cc[2]; c[0] = cc[3];
+    (void)Mk;
+    cd z[4] = {cd(0.4, 0.9), cd(-0.9, 0.4), cd(-0.4, -0.9), cd(0.9, -0.4)};
+    double scale = 1.0 + std::fabs(c[3]) + std::sqrt(std::fabs(c[2])) + std::cbrt(std::fabs(c[1])) + std::sqrt(std::sqrt(std::fabs(c[0])));
+    for (auto& r : z) r *= scale;
+    auto P = [&](cd x) { return (((x + c[3]) * x + c[2]) * x + c[1]) * x + c[0]; };
+    for (int it = 0; it < 200; it++) {
+        double change = 0;
+        for (int i = 0; i < 4; i++) {
+            cd den = 1; for (int j = 0; j < 4; j++) if (j != i) den *= (z[i] - z[j]);
+            if (std::abs(den) == 0) den = 1e-300;
+            const cd dz = P(z[i]) / den; z[i] -= dz; change = std::max(change, std::abs(dz));
+        }
+        if (change < 1e-15 * scale) break;
+    }
+    for (int i = 0; i < 4; i++) lam[i] = z[i];
+}
+
+// src/spherical_solvers.cpp:102-311.  sample: indices into rays.  Es: 4 x 9 row-major.  Returns number of models.
+static int solver_action_matrix(const Rays& R, const int* sample, int N, double Es[36]) {
+    if (N < 3) return 0;
+    std::vector<double> At((size_t)6 * N);
+    for (int i = 0; i < N; i++) {
+        const double* u = R.u + 3 * sample[i]; const double* v = R.v + 3 * sample[i];
+        const double row[6] = {u[0] * v[0] - u[1] * v[1], u[0] * v[1] + u[1] * v[0], u[2] * v[0], u[2] * v[1], u[0] * v[2], u[1] * v[2]};
+        for (int k = 0; k < 6; k++) At[(size_t)k * N + i] = row[k];
+    }
+    double Q[36]; qr_colpiv_Q(At, N, Q);
+    double B[6][3]; for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) B[i][j] = Q[i * 6 + 3 + j];
+    Lin p[6]; for (int k = 0; k < 6; k++) for (int j = 0; j < 3; j++) p[k].c[j] = B[k][j];
+    Lin zero = {{0, 0, 0}}, np0 = {{-p[0].c[0], -p[0].c[1], -p[0].c[2]}};
+    const Lin* Em[3][3] = {{&p[0], &p[1], &p[2]}, {&p[1], &np0, &p[3]}, {&p[4], &p[5], &zero}};
+    Quad EEt[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Quad q = mul(*Em[i][0], *Em[j][0]); q = add(q, mul(*Em[i][1], *Em[j][1])); q = add(q, mul(*Em[i][2], *Em[j][2])); EEt[i][j] = q; }
+    Quad tr = add(add(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    auto T = [&](int i, int j, double s) { Cub c; for (double& x : c.c) x = 0; for (int k = 0; k < 3; k++) acc(c, EEt[i][k], *Em[k][j], 2.0 * s); acc(c, tr, *Em[i][j], -s); return c; };
+    const Cub rows[6] = {T(0, 1, -1.0), T(2, 0, 1.0), T(0, 0, 1.0), T(2, 1, 1.0), T(1, 2, 1.0), T(2, 2, 1.0)};
+    double C1[36], C2[24];
+    for (int r = 0; r < 6; r++) { for (int k = 0; k < 6; k++) C1[r * 6 + k] = rows[r].c[k]; for (int k = 0; k < 4; k++) C2[r * 4 + k] = rows[r].c[6 + k]; }
+    if (!lu_solve6(C1, C2)) return 0;
+    double M[16] = {0};
+    for (int k = 0; k < 4; k++) { M[0 * 4 + k] = -C2[2 * 4 + k]; M[1 * 4 + k] = -C2[4 * 4 + k]; M[2 * 4 + k] = -C2[5 * 4 + k]; }
+    M[3 * 4 + 1] = 1.0;
+    cd lam[4]; eig4(M, lam);
+    for (int s = 0; s < 4; s++) {
+        // eigenvector with last entry 1: rows 1..3 of (M - lam I) v = 0 give v1 = lam (row 3) and a 2x2 system for v0, v2
+        const cd l = lam[s];
+        const cd v1 = l;                                   // row 3: v1 - l v3 = 0, v3 = 1
+        // rows 1 and 2: M10 v0 + (M11 - l) v1 + M12 v2 + M13 = 0 ; M20 v0 + M21 v1 + (M22 - l) v2 + M23 = 0
+        const cd a11 = M[4], a12 = M[6], b1 = -((M[5] - l) * v1 + M[7]);
+        const cd a21 = M[8], a22 = M[10] - l, b2 = -(M[9] * v1 + M[11]);
+        const cd det = a11 * a22 - a12 * a21;
+        cd v0, v2;
+        if (std::abs(det) > 0) { v0 = (b1 * a22 - a12 * b2) / det; v2 = (a11 * b2 - b1 * a21) / det; } else { v0 = 0; v2 = 0; }
+        (void)v0;
+        const double b[3] = {v1.real(), v2.real(), 1.0};
+        double ps[6]; for (int k = 0; k < 6; k++) ps[k] = B[k][0] * b[0] + B[k][1] * b[1] + B[k][2] * b[2];
+        double* E = Es + 9 * s;
+        E[0] = ps[0]; E[1] = ps[1]; E[2] = ps[2]; E[3] = ps[1]; E[4] = -ps[0]; E[5] = ps[3]; E[6] = ps[4]; E[7] = ps[5]; E[8] = 0.0;
+        double nrm = 0; for (int k = 0; k < 9; k++) nrm += E[k] * E[k]; nrm = std::sqrt(nrm);
+        for (int k = 0; k < 9; k++) E[k] /= nrm;
+    }
+    return 4;
+}
+
+// ---- src/spherical_utils.cpp:9-66 (row-major 3x3 here)
+static void make_E(const double* Rm, bool inward, double* E) {
+    double t[3] = {Rm[2], Rm[5], Rm[8] - 1.0};
+    if (inward) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+    const double S[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) E[3 * i + j] = S[3 * i] * Rm[j] + S[3 * i + 1] * Rm[3 + j] + S[3 * i + 2] * Rm[6 + j];
+}
+static void sym_eig3(const double A[9], double w[3], double V[9]) {       // Jacobi, eigenvalues descending
+    double a[9]; std::memcpy(a, A, 72); for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5]; if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+            if (a[3 * p + q] == 0.0) continue;
+            const double th = (a[3 * q + q] - a[3 * p + p]) / (2 * a[3 * p + q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), c = 1 / std::sqrt(t * t + 1), s = t * c;
+            for (int k = 0; k < 3; k++) { const double akp = a[3 * k + p], akq = a[3 * k + q]; a[3 * k + p] = c * akp - s * akq; a[3 * k + q] = s * akp + c * akq; }
+            for (int k = 0; k < 3; k++) { const double apk = a[3 * p + k], aqk = a[3 * q + k]; a[3 * p + k] = c * apk - s * aqk; a[3 * q + k] = s * apk + c * aqk; }
+            for (int k = 0; k < 3; k++) { const double vkp = V[3 * k + p], vkq = V[3 * k + q]; V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq; }
+        }
+    }
+    int idx[3] = {0, 1, 2}; double d[3] = {a[0], a[4], a[8]};
+    std::sort(idx, idx + 3, [&](int x, int y) { return d[x] > d[y]; });
+    double Vs[9]; for (int k = 0; k < 3; k++) { w[k] = d[idx[k]]; for (int i = 0; i < 3; i++) Vs[3 * i + k] = V[3 * i + idx[k]]; }
+    std::memcpy(V, Vs, 72);
+}
+static double det3(const double* M) { return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]); }
+static void svd3(const double* E, double U[9], double V[9]) {
+    double EtE[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) EtE[3 * i + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+    double w[3]; sym_eig3(EtE, w, V);
+    double u[3][3];
+    for (int k = 0; k < 2; k++) { for (int i = 0; i < 3; i++) u[k][i] = E[3 * i] * V[k] + E[3 * i + 1] * V[3 + k] + E[3 * i + 2] * V[6 + k];
+                                  const double n = std::sqrt(u[k][0] * u[k][0] + u[k][1] * u[k][1] + u[k][2] * u[k][2]); for (int i = 0; i < 3; i++) u[k][i] /= n; }
+    // re-orthogonalise u1 against u0, third = u0 x u1
+    double d = u[0][0] * u[1][0] + u[0][1] * u[1][1] + u[0][2] * u[1][2]; for (int i = 0; i < 3; i++) u[1][i] -= d * u[0][i];
+    double n = std::sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]); for (int i = 0; i < 3; i++) u[1][i] /= n;
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1]; u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2]; u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < 3; i++) U[3 * i + k] = u[k][i];
+}
+static void rm_so3ln(const double* Rm, double* r) { double cm[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cm[i + 3 * j] = Rm[3 * i + j]; so3ln(cm, r); }
+static void rm_so3exp(const double* r, double* Rm) { double cm[9]; so3exp(r, cm); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rm[3 * i + j] = cm[i + 3 * j]; }
+static void decompose_E(const double* E, bool inward, double r[3], double t[3]) {
+    double U[9], V[9]; svd3(E, U, V);
+    if (det3(U) < 0) for (double& x : U) x = -x;
+    if (det3(V) < 0) for (double& x : V) x = -x;
+    const double D[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, DT[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    auto mul3 = [](const double* A, const double* B, double* C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j]; };
+    double VT[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) VT[3 * i + j] = V[3 * j + i];
+    double UD[9], R1[9], R2[9]; mul3(U, D, UD); mul3(UD, VT, R1); mul3(U, DT, UD); mul3(UD, VT, R2);
+    const double tu[3] = {U[2], U[5], U[8]};
+    double t1[3] = {R1[2], R1[5], R1[8] - 1}, t2[3] = {R2[2], R2[5], R2[8] - 1};
+    if (inward) for (int k = 0; k < 3; k++) { t1[k] = -t1[k]; t2[k] = -t2[k]; }
+    const double n1 = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]), n2 = std::sqrt(t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2]);
+    const double s1 = std::fabs((t1[0] * tu[0] + t1[1] * tu[1] + t1[2] * tu[2]) / n1), s2 = std::fabs((t2[0] * tu[0] + t2[1] * tu[1] + t2[2] * tu[2]) / n2);
+    if (s1 > s2) { rm_so3ln(R1, r); std::memcpy(t, t1, 24); } else { rm_so3ln(R2, r); std::memcpy(t, t2, 24); }
+}
+
+// ---- LeastSquares (src/spherical_estimator.cpp:110-157): LM on r1 with SampsonError residuals
+template <typename T>
+static void sampson_residual(const T r1[3], bool inward, const double* u, const double* v, T* res) {
+    // ri = 0, ti = tj = (0,0,-1) (or +1): R = Rj, t = Rj (-ti) + tj
+    T Rj[9]; AngleAxisToRotationMatrix(r1, Rj);   // column-major
+    const double tz = inward ? 1.0 : -1.0;
+    T t[3] = {Rj[6] * (-tz), Rj[7] * (-tz), Rj[8] * (-tz) + tz};
+    // E = [t]x R, R(i,j) = Rj[i + 3j]
+    T E[9];
+    for (int j = 0; j < 3; j++) {
+        const T c0 = Rj[0 + 3 * j], c1 = Rj[1 + 3 * j], c2 = Rj[2 + 3 * j];
+        E[0 * 3 + j] = t[1] * c2 - t[2] * c1;      // row 0 of [t]x = (0, -t2, t1)
+        E[1 * 3 + j] = t[2] * c0 - t[0] * c2;      // row 1 = (t2, 0, -t0)
+        E[2 * 3 + j] = t[0] * c1 - t[1] * c0;      // row 2 = (-t1, t0, 0)
+    }
+    const T Eu[3] = {E[0] * u[0] + E[1] * u[1] + E[2] * u[2], E[3] * u[0] + E[4] * u[1] + E[5] * u[2], E[6] * u[0] + E[7] * u[1] + E[8] * u[2]};
+    const T Etv0 = E[0] * v[0] + E[3] * v[1] + E[6] * v[2], Etv1 = E[1] * v[0] + E[4] * v[1] + E[7] * v[2];
+    const T d = Eu[0] * v[0] + Eu[1] * v[1] + Eu[2] * v[2];
+    *res = (d * d) / (Eu[0] * Eu[0] + Eu[1] * Eu[1] + Etv0 * Etv0 + Etv1 * Etv1);
+}
+struct SampsonLSQ : LMProblem {
+    const Rays& R; const std::vector<int>& idx; bool inward;
+    std::vector<double> res, J;   // per residual: value, 3 partials
+    SampsonLSQ(const Rays& r, const std::vector<int>& i, bool in) : R(r), idx(i), inward(in), res(i.size()), J(3 * i.size()) {}
+    int num_parameters() const override { return 3; }
+    bool cost_only(const double* x, double* cost) override {
+        double c = 0; for (int k : idx) { double r; sampson_residual<double>(x, inward, R.u + 3 * k, R.v + 3 * k, &r); c += 0.5 * r * r; }
+        *cost = c; return std::isfinite(c);
+    }
+    bool linearize(const double* x, double* cost, double* g) override {
+        typedef Jet<3> J3; double c = 0; g[0] = g[1] = g[2] = 0;
+        for (size_t q = 0; q < idx.size(); q++) {
+            J3 r1[3] = {J3(x[0], 0), J3(x[1], 1), J3(x[2], 2)}, r;
+            sampson_residual<J3>(r1, inward, R.u + 3 * idx[q], R.v + 3 * idx[q], &r);
+            res[q] = r.a; for (int k = 0; k < 3; k++) { J[3 * q + k] = r.v[k]; g[k] += r.v[k] * r.a; }
+            c += 0.5 * r.a * r.a;
+        }
+        *cost = c; return std::isfinite(c);
+    }
+    void squared_column_norms(const double* s, double* out) override {
+        out[0] = out[1] = out[2] = 0; for (size_t q = 0; q < idx.size(); q++) for (int k = 0; k < 3; k++) out[k] += J[3 * q + k] * J[3 * q + k];
+        if (s) for (int k = 0; k < 3; k++) out[k] *= s[k] * s[k];
+    }
+    bool solve(const double* s, const double* D, double* y) override {
+        double A[9] = {0}, b[3] = {0};
+        for (size_t q = 0; q < idx.size(); q++) for (int a = 0; a < 3; a++) { const double ja = J[3 * q + a] * s[a]; b[a] += ja * res[q]; for (int c = 0; c < 3; c++) A[3 * a + c] += ja * J[3 * q + c] * s[c]; }
+        for (int a = 0; a < 3; a++) A[4 * a] += D[a] * D[a];
+        // Cholesky 3x3
+        double L[9] = {0};
+        for (int j = 0; j < 3; j++) { double d = A[4 * j]; for (int k = 0; k < j; k++) d -= L[3 * j + k] * L[3 * j + k]; if (!(d > 0)) return false; L[4 * j] = std::sqrt(d);
+            for (int i = j + 1; i < 3; i++) { double v = A[3 * i + j]; for (int k = 0; k < j; k++) v -= L[3 * i + k] * L[3 * j + k]; L[3 * i + j] = v / L[4 * j]; } }
+        double z[3]; for (int i = 0; i < 3; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[3 * i + k] * z[k]; z[i] = v / L[4 * i]; }
+        for (int i = 2; i >= 0; i--) { double v = z[i]; for (int k = i + 1; k < 3; k++) v -= L[3 * k + i] * y[k]; y[i] = v / L[4 * i]; }
+        return true;
+    }
+    double model_cost_change(const double* s, const double* step) override {
+        double a = 0; for (size_t q = 0; q < idx.size(); q++) { double m = 0; for (int k = 0; k < 3; k++) m += J[3 * q + k] * s[k] * step[k]; a += m * (res[q] + 0.5 * m); } return -a;
+    }
+    void plus(const double* x, const double* d, double* o) override { for (int k = 0; k < 3; k++) o[k] = x[k] + d[k]; }
+};
+static void least_squares(const Rays& R, bool inward, const std::vector<int>& sample, double* E) {
+    double r[3], t[3]; decompose_E(E, inward, r, t);
+    SampsonLSQ P(R, sample, inward);
+    LMOptions o; o.max_num_iterations = 200; o.max_num_consecutive_invalid_steps = 10;    // src/spherical_estimator.cpp:146-150
+    lm_minimize(P, o, r);
+    double Rm[9]; rm_so3exp(r, Rm); make_E(Rm, inward, E);
+}
+
+struct MSACOptions { uint32_t min_it = 100, max_it = 10000; double prob = 0.9999, sq_thresh = 1.0; unsigned seed = 0;
+                     int num_lo_steps = 10; double thresh_mult = std::sqrt(2.0); int num_lsq_it = 4, min_sample_mult = 7, non_min_mult = 3; uint32_t lo_start = 50; bool final_lsq = false; };
+
+static uint32_t num_required_iterations(double ratio, double pmiss, int ssize, uint32_t mn, uint32_t mx) {     // utils.h:110-140
+    if (ratio <= 0.0) return mx; if (ratio >= 1.0) return mn;
+    const double pn = 1.0 - std::pow(ratio, (double)ssize);
+    if (pn >= 0.99999999999999) return mx;
+    const double it = std::ceil(std::log(pmiss) / std::log(pn) + 0.5);
+    return std::max(mn, std::min((uint32_t)it, mx));
+}
+static void shuffle_resize(int target, std::mt19937* rng, std::vector<int>* s) {                                // utils.h:48-73
+    const int n = (int)s->size();
+    for (int i = 0; i < n - 1; i++) { std::uniform_int_distribution<int> dist(i, n - 1); std::swap((*s)[i], (*s)[dist(*rng)]); }
+    s->resize(target);
+}
+
+struct Msac {
+    const Rays& R; bool inward; MSACOptions o;
+    Msac(const Rays& r, bool in, const MSACOptions& op) : R(r), inward(in), o(op) {}
+    double score(const double* E) const { double s = 0; for (int i = 0; i < R.n; i++) s += std::min(sampson(E, R.u + 3 * i, R.v + 3 * i), o.sq_thresh); return s; }
+    int inliers(const double* E, double th, std::vector<int>* out) const { out->clear(); for (int i = 0; i < R.n; i++) if (sampson(E, R.u + 3 * i, R.v + 3 * i) < th) out->push_back(i); return (int)out->size(); }
+    static void update(double sc, const double* m, double* best_sc, double* best) { if (sc < *best_sc) { *best_sc = sc; std::memcpy(best, m, 72); } }
+    void lsq_fit(double thresh, std::mt19937* rng, double* model) const {                                       // ransac.h:409-420
+        std::vector<int> inl; const int n = inliers(model, thresh, &inl);
+        if (n < 3) return;
+        shuffle_resize(std::min(o.min_sample_mult * 3, n), rng, &inl);
+        least_squares(R, inward, inl, model);
+    }
+    void local_optimization(std::mt19937* rng, double* best_min, double* score_best) const {                    // ransac.h:341-407
+        if (4 > R.n) return;
+        double m_init[9]; std::memcpy(m_init, best_min, 72);
+        lsq_fit(o.sq_thresh * o.thresh_mult, rng, m_init);
+        update(score(m_init), m_init, score_best, best_min);
+        std::vector<int> base; inliers(m_init, o.sq_thresh * o.thresh_mult, &base);
+        const int nonmin = std::max(4, std::min(3 * o.non_min_mult, (int)base.size() / 2));
+        for (int r = 0; r < o.num_lo_steps; r++) {
+            std::vector<int> sample = base; shuffle_resize(nonmin, rng, &sample);
+            double Es[36]; if (solver_action_matrix(R, sample.data(), (int)sample.size(), Es) == 0) continue;      // NonMinimalSolver :86-108
+            double bs = INFINITY; int bi = 0;
+            for (int i = 0; i < 4; i++) { double sc = 0; for (int j : sample) sc += sampson(Es + 9 * i, R.u + 3 * j, R.v + 3 * j); if (sc < bs) { bs = sc; bi = i; } }
+            double m[9]; std::memcpy(m, Es + 9 * bi, 72);
+            update(score(m), m, score_best, best_min);
+            lsq_fit(o.sq_thresh, rng, m);
+            double th = o.thresh_mult * o.sq_thresh; const double upd = (o.thresh_mult - 1.0) * o.sq_thresh / (o.num_lsq_it - 1);
+            for (int i = 0; i < o.num_lsq_it; i++) { lsq_fit(th, rng, m); update(score(m), m, score_best, best_min); th -= upd; }
+        }
+    }
+    int estimate(double* best_model, uint32_t* iters_out, std::vector<int>* inl_out, double* best_score_out, int* lo_count) const {   // ransac.h:128-275
+        *iters_out = 0; *lo_count = 0; *best_score_out = std::numeric_limits<double>::max(); inl_out->clear();
+        if (3 > R.n) return 0;
+        std::mt19937 srng; srng.seed(o.seed); std::uniform_int_distribution<int> udist(0, R.n - 1);
+        const bool draw = ((double)R.n / (double)(R.n - 3)) < M_E;                                               // sampling.h:66-75
+        std::mt19937 rng; rng.seed(o.seed);
+        uint32_t max_it = std::max(o.max_it, o.min_it);
+        double best_min[9]; double best_min_score = std::numeric_limits<double>::max(), best_score = std::numeric_limits<double>::max();
+        int best_inl = 0; std::vector<int> sample(3);
+        uint32_t it = 0;
+        for (it = 0; it < max_it; ++it) {
+            if (it == o.lo_start && best_min_score < std::numeric_limits<double>::max()) {
+                ++*lo_count; local_optimization(&rng, best_model, &best_score);
+                best_inl = inliers(best_model, o.sq_thresh, inl_out);
+                max_it = num_required_iterations((double)best_inl / R.n, 1.0 - o.prob, 3, o.min_it, o.max_it);
+            }
+            if (draw) { sample.resize(3); for (int i = 0; i < 3; i++) { bool found = true; while (found) { found = false; sample[i] = udist(srng); for (int j = 0; j < i; j++) if (sample[j] == sample[i]) { found = true; break; } } } }
+            else { sample.resize(R.n); std::iota(sample.begin(), sample.end(), 0); if (R.n != 3) { for (int i = 0; i < R.n - 1; i++) { std::uniform_int_distribution<int> d(i, R.n - 1); std::swap(sample[i], sample[d(srng)]); } sample.resize(3); } }
+            double Es[36]; const int nm = solver_action_matrix(R, sample.data(), 3, Es);
+            if (nm <= 0) continue;
+            double bl = std::numeric_limits<double>::max(); int bid = 0;
+            for (int m = 0; m < nm; m++) { const double sc = score(Es + 9 * m); if (sc < bl) { bl = sc; bid = m; } }
+            if (bl < best_min_score || it == o.lo_start) {
+                const bool best_min_model = bl < best_min_score;
+                if (best_min_model) { best_min_score = bl; std::memcpy(best_min, Es + 9 * bid, 72); update(best_min_score, best_min, &best_score, best_model); }
+                const bool run_lo = (it >= o.lo_start && best_min_score < std::numeric_limits<double>::max());
+                if (!best_min_model && !run_lo) continue;
+                if (run_lo) { ++*lo_count; double sc = best_min_score; local_optimization(&rng, best_min, &sc); update(sc, best_min, &best_score, best_model); }
+                best_inl = inliers(best_model, o.sq_thresh, inl_out);
+                max_it = num_required_iterations((double)best_inl / R.n, 1.0 - o.prob, 3, o.min_it, o.max_it);
+            }
+        }
+        if (it <= o.lo_start && best_score < std::numeric_limits<double>::max()) {
+            ++*lo_count; local_optimization(&rng, best_model, &best_score);
+            best_inl = inliers(best_model, o.sq_thresh, inl_out);
+        }
+        if (o.final_lsq) {
+            double refined[9]; std::memcpy(refined, best_model, 72);
+            least_squares(R, inward, *inl_out, refined);
+            const double sc = score(refined);
+            if (sc < best_score) { best_score = sc; std::memcpy(best_model, refined, 72); best_inl = inliers(best_model, o.sq_thresh, inl_out); }
+        }
+        *iters_out = it; *best_score_out = best_score;
+        return best_inl;
+    }
+};
+
+static void cm_to_rm(const double* cm, double* rm) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rm[3 * i + j] = cm[i + 3 * j]; }
+static void rm_to_cm(const double* rm, double* cm) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cm[i + 3 * j] = rm[3 * i + j]; }
+
+}  // namespace oracle
+using namespace oracle;
+
+extern "C" double oracle_sampson(const double E_cm[9], const double u[3], const double v[3]) { double E[9]; cm_to_rm(E_cm, E); return sampson(E, u, v); }
+
+extern "C" int oracle_spherical_solver(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, double Es_cm[36]) {
+    Rays R{n, u, v}; double Es[36];
+    const int k = solver_action_matrix(R, sample, ns, Es);
+    for (int i = 0; i < k; i++) rm_to_cm(Es + 9 * i, Es_cm + 9 * i);
+    return k;
+}
+extern "C" void oracle_make_spherical_essential_matrix(const double R_cm[9], int32_t inward, double E_cm[9]) { double Rm[9], E[9]; cm_to_rm(R_cm, Rm); make_E(Rm, inward != 0, E); rm_to_cm(E, E_cm); }
+extern "C" void oracle_decompose_spherical_essential_matrix(const double E_cm[9], int32_t inward, double r[3], double t[3]) { double E[9]; cm_to_rm(E_cm, E); decompose_E(E, inward != 0, r, t); }
+extern "C" void oracle_sampson_least_squares(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, int32_t inward, double E_cm[9]) {
+    Rays R{n, u, v}; std::vector<int> s(sample, sample + ns); double E[9]; cm_to_rm(E_cm, E); least_squares(R, inward != 0, s, E); rm_to_cm(E, E_cm);
+}
+// per-pair logic of estimate_pairwise (examples/spherical_sfm_tools.cpp:314-318,378-419): options, EstimateModel, inlier mask, R
+extern "C" int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inward, double sq_thresh, uint32_t min_it, uint32_t max_it,
+                                  uint32_t seed, int32_t min_num_inliers, double E_cm[9], double R_cm[9], uint8_t* inlier_mask, uint32_t* iterations,
+                                  double* best_score) {
+    Rays R{n, u, v};
+    MSACOptions o; o.sq_thresh = sq_thresh; o.num_lo_steps = 0; o.num_lsq_it = 0; o.final_lsq = true; o.min_it = min_it; o.max_it = max_it; o.seed = seed;
+    Msac M(R, inward != 0, o);
+    double E[9] = {0}; std::vector<int> inl; uint32_t it; double bs; int lo;
+    M.estimate(E, &it, &inl, &bs, &lo);
+    int nin = 0;
+    for (int i = 0; i < n; i++) { const bool in = sampson(E, u + 3 * i, v + 3 * i) < sq_thresh; if (inlier_mask) inlier_mask[i] = in; nin += in; }
+    if (iterations) *iterations = it; if (best_score) *best_score = bs;
+    rm_to_cm(E, E_cm);
+    double Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (nin > min_num_inliers) { double r[3], t[3]; decompose_E(E, inward != 0, r, t); rm_so3exp(r, Rm); }
+    rm_to_cm(Rm, R_cm);
+    return nin;
+}

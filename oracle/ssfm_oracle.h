@@ -91,6 +91,17 @@ double oracle_optimize_rotations_and_focal_length(int32_t n, double* rotations, 
 void oracle_rotation_edge(int32_t kind, const double r0[3], const double r1[3], double f,
                           const double Rmeas[9], double scale, double res[3], double jac[21]);
 
+/* spherical relative pose (reference src/spherical_estimator.cpp, src/spherical_solvers.cpp, src/spherical_utils.cpp,
+ * include/RansacLib); rays u,v: [n*3]; all 3x3 matrices column-major */
+double oracle_sampson(const double E[9], const double u[3], const double v[3]);
+int oracle_spherical_solver(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, double Es[36]);
+void oracle_make_spherical_essential_matrix(const double R[9], int32_t inward, double E[9]);
+void oracle_decompose_spherical_essential_matrix(const double E[9], int32_t inward, double r[3], double t[3]);
+void oracle_sampson_least_squares(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, int32_t inward, double E[9]);
+int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inward, double squared_inlier_threshold, uint32_t min_iterations,
+                       uint32_t max_iterations, uint32_t seed, int32_t min_num_inliers, double E[9], double R[9], uint8_t* inlier_mask,
+                       uint32_t* iterations, double* best_score);
+
 #ifdef __cplusplus
 }
 #endif

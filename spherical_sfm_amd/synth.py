@@ -133,3 +133,34 @@ def make_rotation_graph(num_cameras=300, max_offset=8, *, seed=1234, noise_deg=0
             Rc = R_rel[k] @ Rc
             R_init[idx] = Rc
     return R_init, i0.astype(np.int32), i1.astype(np.int32), R_rel, R_gt
+
+
+def make_relative_pose_problem(num_corr=100, *, inward=False, rotation_deg=None, noise=0.0, outlier_frac=0.0, seed=0):
+    """Synthetic spherical pair with the geometry of the reference's generator
+    (evaluation/problem_generator/problem_generator.cpp:14-65): t = R e_z - e_z (negated if inward), points at
+    depth U(4,8) outward / U(0.25,0.75) inward in front of camera 1, image-plane noise `noise` (= sigma_px / focal);
+    a fraction of correspondences replaced by uniform outliers.  Returns u (n,3), v (n,3), R_gt, E_gt, inlier mask."""
+    rng = np.random.default_rng(seed)
+    while True:
+        angle = rng.uniform(0, np.pi) if rotation_deg is None else np.deg2rad(rotation_deg)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        R = so3exp(ax * angle)
+        t = R[:, 2] - np.array([0.0, 0.0, 1.0])
+        if inward:
+            t = -t
+        u = np.concatenate([rng.normal(size=(num_corr, 2)), np.ones((num_corr, 1))], axis=1)
+        depth = rng.uniform(0.25, 0.75, num_corr) if inward else rng.uniform(4.0, 8.0, num_corr)
+        X = u * depth[:, None]
+        P2 = X @ R.T + t
+        if (P2[:, 2] <= 0).any():
+            continue
+        v = np.concatenate([P2[:, :2] / P2[:, 2:3], np.ones((num_corr, 1))], axis=1)
+        break
+    u[:, :2] += noise * rng.normal(size=(num_corr, 2)); v[:, :2] += noise * rng.normal(size=(num_corr, 2))
+    inl = np.ones(num_corr, bool)
+    n_out = int(round(outlier_frac * num_corr))
+    if n_out:
+        idx = rng.choice(num_corr, n_out, replace=False)
+        v[idx, :2] = rng.uniform(-1.5, 1.5, size=(n_out, 2)); inl[idx] = False
+    S = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    return np.ascontiguousarray(u), np.ascontiguousarray(v), R, S @ R, inl

@@ -1,0 +1,89 @@
+"""CPU tests of the RANSAC oracle (oracle/ransac_oracle.cpp): oracle-free known answers for the 3-point solver, the
+Sampson score, the essential-matrix (de)composition, the Sampson least squares and the LO-MSAC loop.
+Error metrics follow evaluation/problem_generator/problem_generator.h:17-38 (calc_frob_error, calc_rot_error)."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from spherical_sfm_amd import synth
+
+
+def frob_err(E, Es):
+    a = E / np.linalg.norm(E); b = Es / np.linalg.norm(Es)
+    return min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+
+
+def rot_err(R, Rs):
+    return np.linalg.norm(Rotation.from_matrix(Rs @ R.T).as_rotvec())
+
+
+@pytest.mark.parametrize("inward", [False, True])
+def test_minimal_solver_recovers_ground_truth_without_noise(oracle, inward):
+    worst = 0.0
+    for seed in range(40):
+        u, v, R, E, _ = synth.make_relative_pose_problem(6, inward=inward, seed=seed)
+        Es = oracle.spherical_solver(u, v, [0, 1, 2])
+        assert len(Es) == 4 and all(abs(np.linalg.norm(e) - 1) < 1e-12 for e in Es)
+        worst = max(worst, min(frob_err(E, e) for e in Es))
+    assert worst < 1e-8          # "one of 4 E's has calc_frob_error < 1e-8"
+
+
+def test_solutions_have_the_spherical_structure_and_satisfy_the_constraints(oracle):
+    u, v, R, E, _ = synth.make_relative_pose_problem(3, seed=5)
+    for e in oracle.spherical_solver(u, v, [0, 1, 2]):
+        assert abs(e[1, 0] - e[0, 1]) < 1e-14 and abs(e[1, 1] + e[0, 0]) < 1e-14 and e[2, 2] == 0    # src/spherical_solvers.cpp:299-303
+    best = min(oracle.spherical_solver(u, v, [0, 1, 2]), key=lambda e: frob_err(E, e))
+    assert max(abs(v[i] @ best @ u[i]) for i in range(3)) < 1e-10                                   # epipolar constraint on the sample
+    T = 2 * best @ best.T @ best - np.trace(best @ best.T) * best
+    assert np.abs(T).max() < 1e-9 and abs(np.linalg.det(best)) < 1e-10                             # essential-matrix constraints
+
+
+def test_sampson_matches_numpy(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        E = rng.normal(size=(3, 3)); u = rng.normal(size=3); v = rng.normal(size=3)
+        Eu = E @ u; Etv = E.T @ v; d = v @ Eu
+        ref = d * d / (Eu[0] ** 2 + Eu[1] ** 2 + Etv[0] ** 2 + Etv[1] ** 2)                         # src/spherical_estimator.cpp:72-77
+        assert abs(oracle.sampson(E, u, v) - ref) <= 1e-13 * ref
+
+
+@pytest.mark.parametrize("inward", [False, True])
+def test_decompose_inverts_make(oracle, inward):
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        R = Rotation.from_rotvec(rng.normal(size=3) * 0.6).as_matrix()
+        E = oracle.make_spherical_essential_matrix(R, inward)
+        t = R[:, 2] - np.array([0, 0, 1.0]); t = -t if inward else t
+        S = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        assert np.allclose(E, S @ R, atol=1e-15)                                                   # src/spherical_utils.cpp:9-14
+        for Ein in (E, -E, 3.7 * E):
+            r, tt = oracle.decompose_spherical_essential_matrix(Ein, inward)
+            assert rot_err(R, Rotation.from_rotvec(r).as_matrix()) < 1e-9
+
+
+def test_least_squares_pulls_a_perturbed_model_back(oracle):
+    u, v, R, E, _ = synth.make_relative_pose_problem(60, seed=7, rotation_deg=25)
+    Rp = Rotation.from_rotvec(np.array([0.01, -0.02, 0.015])).as_matrix() @ R
+    Ep = oracle.make_spherical_essential_matrix(Rp)
+    Er = oracle.sampson_least_squares(u, v, np.arange(60), Ep)
+    assert frob_err(E, Er) < frob_err(E, Ep) * 1e-3
+    r, _ = oracle.decompose_spherical_essential_matrix(Er)
+    assert rot_err(R, Rotation.from_rotvec(r).as_matrix()) < 1e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_lo_msac_on_a_pair_with_outliers(oracle, seed):
+    """LO-MSAC on a 100-correspondence pair with 30 % outliers, 1 px noise at f = 600, 2 px threshold."""
+    u, v, R, E, inl = synth.make_relative_pose_problem(100, seed=seed, noise=1 / 600, outlier_frac=0.3, rotation_deg=20)
+    r = oracle.ransac_pair(u, v, (2 / 600) ** 2, seed=seed)
+    assert r["iterations"] >= 100                       # min_num_iterations_, ransac.h:49
+    assert (r["inliers"] == inl).mean() >= 0.95 and r["num_inliers"] == r["inliers"].sum()
+    assert rot_err(R, r["R"]) < 5e-3 and frob_err(E, r["E"]) < 5e-3
+    r2 = oracle.ransac_pair(u, v, (2 / 600) ** 2, seed=seed)
+    assert (r2["E"] == r["E"]).all()                    # std::mt19937 seeded -> reproducible (sampling.h:49-55)
+
+
+def test_too_few_correspondences(oracle):
+    u, v, R, E, _ = synth.make_relative_pose_problem(2, seed=0)
+    r = oracle.ransac_pair(u, v, 1e-4)
+    assert r["num_inliers"] == 0 and np.allclose(r["R"], np.eye(3))      # ransac.h:137-141
