@@ -175,6 +175,18 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
 int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
                                 double* Es, int32_t* counts);
 
+/* ---- feature tracks: the integer part of build_sfm (examples/spherical_sfm_tools.cpp:862-950), host only ------
+ * Keyframe k owns features [feat_ptr[k], feat_ptr[k+1]) of feat_xy ([total*2] pixels).  Match set s links keyframes
+ * (ms_index0[s], ms_index1[s]) with pairs (m_f0[m], m_f1[m]), m in [ms_ptr[s], ms_ptr[s+1]), feature indices local to their
+ * keyframe, first index ascending (std::map order).  Outputs: tracks [total] (-1 = unmatched; ids bit-exact with the
+ * reference's AddPoint sequence), num_points (ids issued, merged ones included), point_alive [>= num match pairs] (0 =
+ * removed by MergePoint), observations camera-major / point-ascending (the iteration order of SfM's maps), centred by
+ * (centerx, centery); obs_* need capacity 2 * (number of match pairs) and may be NULL to only count. */
+int ssfm_build_tracks(int32_t num_keyframes, const int32_t* feat_ptr, const double* feat_xy, int32_t num_match_sets,
+                      const int32_t* ms_index0, const int32_t* ms_index1, const int32_t* ms_ptr, const int32_t* m_f0, const int32_t* m_f1,
+                      double centerx, double centery, int32_t merge, int32_t* tracks, int32_t* num_points, uint8_t* point_alive,
+                      int64_t* num_observations, int32_t* obs_cam, int32_t* obs_pt, double* obs_xy);
+
 #ifdef __cplusplus
 }
 #endif
