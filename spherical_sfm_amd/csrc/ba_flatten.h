@@ -47,6 +47,16 @@ struct BAFlat {
     int band = 0;                       // block half-bandwidth in that order
     std::vector<int> band_pairs;        // (i_rel | k_rel << 16), i_rel-major, 1 <= k_rel <= i_rel <= band
     std::vector<int> comp_ptr;          // connected components of the camera graph = contiguous position ranges
+    // The stored structure (row_ptr/col_idx) is the LOWER triangle in elimination order: row c holds block (c, c2) iff
+    // cam_pos[c2] <= cam_pos[c].  trans_* lists, for every camera c, the stored blocks of OTHER rows whose column is c
+    // (the upper triangle by symmetry) for the symmetric mat-vec.
+    bool sym_lower = false;
+    std::vector<int> trans_ptr, trans_blk, trans_row;
+    // Schur pair lists (this rank's observations): for row c the entries (j, j2) = (observation of c, observation of the
+    // same point by a camera c2 of row c), grouped by slot and padded with -1 to whole 64-lane batches.
+    std::vector<int> pair_j, pair_j2, batch_slot, cam_batch_ptr;
+    // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
+    std::vector<int> chunk_cam, chunk_b0, chunk_b1;
 };
 
 // Cuthill-McKee order of the camera graph given as block-CSR structure (folds a ring into a band of twice
@@ -140,6 +150,23 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     }
     F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
+    {   // keep the lower triangle (in elimination order) only
+        std::vector<int> rp(Nc + 1, 0), ci; ci.reserve(F.col_idx.size() / 2 + Nc);
+        F.max_row_blocks = 0;
+        for (int c = 0; c < Nc; c++) {
+            for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) { const int c2 = F.col_idx[e]; if (F.cam_pos[c2] <= F.cam_pos[c]) ci.push_back(c2); }
+            rp[c + 1] = (int)ci.size();
+            F.max_row_blocks = std::max(F.max_row_blocks, rp[c + 1] - rp[c]);
+            F.diag_slot[c] = (int)(std::lower_bound(ci.begin() + rp[c], ci.end(), c) - (ci.begin() + rp[c]));
+        }
+        F.row_ptr.swap(rp); F.col_idx.swap(ci); F.sym_lower = true;
+        std::vector<int> cnt(Nc + 1, 0);
+        for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] != c) cnt[F.col_idx[e] + 1]++;
+        for (int c = 0; c < Nc; c++) cnt[c + 1] += cnt[c];
+        F.trans_ptr = cnt; F.trans_blk.resize(cnt[Nc]); F.trans_row.resize(cnt[Nc]);
+        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+        for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] != c) { const int k = fill[F.col_idx[e]]++; F.trans_blk[k] = e; F.trans_row[k] = c; }
+    }
     F.mask_cam.assign((size_t)Nc * 6, 0.0);
     bool all_t_fixed = true;
     for (int c = 0; c < Nc; c++) {
@@ -185,6 +212,34 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     F.cam_obs.resize(F.M);
     { std::vector<int> fill(F.cam_start.begin(), F.cam_start.end() - 1);
       for (int64_t j = 0; j < F.M; j++) F.cam_obs[fill[F.obs_cam[j]]++] = (int)j; }
+    // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
+    F.cam_batch_ptr.assign(Nc + 1, 0);
+    std::vector<std::vector<int>> by_slot;      // reused per camera: entries (j, j2) interleaved
+    for (int c = 0; c < Nc; c++) {
+        const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb;
+        by_slot.assign(nnb, std::vector<int>());
+        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
+            const int j = F.cam_obs[q], p = F.obs_pt[j];
+            for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
+                const int c2 = F.obs_cam[j2];
+                if (F.cam_pos[c2] > F.cam_pos[c]) continue;
+                const int slot = (int)(std::lower_bound(F.col_idx.begin() + rb, F.col_idx.begin() + rb + nnb, c2) - (F.col_idx.begin() + rb));
+                by_slot[slot].push_back(j); by_slot[slot].push_back(j2);
+            }
+        }
+        int nbatch = 0;
+        for (int s2 = 0; s2 < nnb; s2++) {
+            const int ne = (int)by_slot[s2].size() / 2; if (ne == 0) continue;
+            const int nb = (ne + 63) / 64;
+            for (int b = 0; b < nb; b++) F.batch_slot.push_back(s2);
+            for (int e = 0; e < nb * 64; e++) { F.pair_j.push_back(e < ne ? by_slot[s2][2 * e] : -1); F.pair_j2.push_back(e < ne ? by_slot[s2][2 * e + 1] : -1); }
+            nbatch += nb;
+        }
+        F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch;
+        for (int b = F.cam_batch_ptr[c]; b < F.cam_batch_ptr[c + 1]; b += 16) {
+            F.chunk_cam.push_back(c); F.chunk_b0.push_back(b); F.chunk_b1.push_back(std::min(b + 16, F.cam_batch_ptr[c + 1]));
+        }
+    }
 }
 
 }  // namespace ssfm

@@ -19,11 +19,11 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_rows", "k_finalize_S", "k_pcg_init",
                                               "k_pcg_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol", "k_band_fwd",
-                                              "k_band_back", "k_band_combine", "k_ref_vecops"};
+                                              "k_band_back", "k_band_combine", "k_ref_vecops", "k_cam_sums"};
 
 template <typename T>
 struct DevBuf {
@@ -47,6 +47,7 @@ struct ssfm_ba_handle {
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
     DevBuf<double> Vinv, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
+    DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0;
     bool scale_ready = false;
@@ -75,6 +76,7 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
+        trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free();
         redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
@@ -83,6 +85,16 @@ struct ssfm_ba_handle {
 };
 
 namespace ssfm {
+
+#define MATVEC(h, DCV, vec)                                                                                                   \
+    do {                                                                                                                   \
+        if ((h)->F.sym_lower)                                                                                              \
+            LAUNCH(h, KID_PCG_MATVEC, k_sym_matvec<DCV>, ((h)->F.Nc + 3) / 4, 256, 0, (h)->row_ptr.p, (h)->col_idx.p, (h)->trans_ptr.p, \
+                   (h)->trans_blk.p, (h)->trans_row.p, (h)->S_val, (h)->Sfc, vec, (h)->F.Nc, (h)->pcg.p, (h)->pq.p, (h)->pqpart.p);       \
+        else                                                                                                               \
+            LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DCV>, ((h)->F.Nc + 3) / 4, 256, 0, (h)->row_ptr.p, (h)->col_idx.p, (h)->S_val,       \
+                   (h)->Sfc, vec, (h)->F.Nc, (h)->pcg.p, (h)->pq.p, (h)->pqpart.p);                                         \
+    } while (0)
 
 #define LAUNCH(h, kid, kernel, grid, block, shmem, ...)                                   \
     do {                                                                                  \
@@ -128,7 +140,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         while (!done && launched < O.pcg_max_iterations) {
             const int todo = std::min(chunk, O.pcg_max_iterations - launched);
             for (int k = 0; k < todo; k++) {
-                LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+                MATVEC(h, DC, h->pp.p);
                 LAUNCH(h, KID_PCG_VECOPS, k_pcg_vecops<DC>, 1, 1024, 0, h->Minv.p, h->Sfc, h->Sff.p, Nc, tol2, h->px.p, h->pr.p, h->pz.p, h->pp.p, h->pq.p, h->pqpart.p, h->pcg.p);
             }
             launched += todo;
@@ -167,7 +179,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     }
     LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
     // ---- residual check r = rhs - S x, PCG refinement with the factor as preconditioner while it is too large
-    LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->px.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+    MATVEC(h, DC, h->px.p);
     LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
     *iters_out = 0; *ok_out = true;
     return SSFM_OK;
@@ -186,7 +198,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         }
         LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
         LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);
-        LAUNCH(h, KID_PCG_MATVEC, k_pcg_matvec<DC>, (Nc + 3) / 4, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->Sfc, h->pp.p, Nc, h->pcg.p, h->pq.p, h->pqpart.p);
+        MATVEC(h, DC, h->pp.p);
         LAUNCH(h, KID_REF_VEC, k_ref_step<DC>, 1, 1024, 0, h->Sfc, h->Sff.p, Nc, tol2, h->pp.p, h->pq.p, h->pqpart.p, h->px.p, h->pr.p, h->pcg.p);
         SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, PCG_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));

@@ -353,6 +353,209 @@ k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, con
     }
 }
 
+// ---- K2 (pair-list form): Schur complement without contended atomics -------------------------------------------
+// The host groups, for every row camera c, the (observation of c, observation of the same point by a row camera c2) pairs
+// by slot, pads each slot to whole 64-lane batches and cuts every camera's batch list into chunks of <= 16 batches
+// (ba_flatten.h) -- one workgroup per chunk, so that rows with 1 and with 11 neighbours load the chip evenly.  A wave
+// walks consecutive batches; a lane re-linearises its two observations and accumulates T_cp W_c2p^T into a private DCxDC
+// block; when the slot changes the wave folds its 64 private blocks with shuffles and adds the result to the chunk's
+// LDS row once; at the end the touched slots are added to S in global memory (a few hundred atomics per workgroup).
+// Only the lower triangle (in elimination order) is built.  k_cam_sums runs first and stores U_c into the diagonal blocks.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_cam_sums(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
+           const int* __restrict__ cam_start, const int* __restrict__ cam_obs, const int* __restrict__ row_ptr,
+           const int* __restrict__ diag_slot, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
+           const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
+           const double* __restrict__ Wf, int loss, double la, double* __restrict__ S_val, double* __restrict__ rhs,
+           double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw) {
+    constexpr int BB = DC * DC;
+    constexpr int NU = DC * (DC + 1) / 2;
+    constexpr int NSM = NU + 3 * DC;
+    __shared__ double red[NSM * 4];
+    __shared__ double camc[40];
+    const int c = blockIdx.x;
+    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
+    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
+    __syncthreads();
+    const double f = focal[0], sf = scale_f[0];
+    double sm[NSM];
+#pragma unroll
+    for (int i = 0; i < NSM; i++) sm[i] = 0.0;
+    for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
+        const int j = cam_obs[q], p = obs_pt[j];
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+        const double2 o = obs_xy[j];
+        ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
+        double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
+        const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
+        const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
+        const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+        const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
+        int u = 0;
+#pragma unroll
+        for (int a = 0; a < DC; a++) {
+            const double w0 = (Jc[0][a] * L.Jp[0][0] + Jc[1][a] * L.Jp[1][0]) * sp[0];
+            const double w1 = (Jc[0][a] * L.Jp[0][1] + Jc[1][a] * L.Jp[1][1]) * sp[1];
+            const double w2 = (Jc[0][a] * L.Jp[0][2] + Jc[1][a] * L.Jp[1][2]) * sp[2];
+            const double t0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2], t1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4], t2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+            sm[NU + a] += Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1];
+            sm[NU + DC + a] -= t0 * g[0] + t1 * g[1] + t2 * g[2];
+            sm[NU + 2 * DC + a] += jf0 * Jc[0][a] + jf1 * Jc[1][a] - (t0 * wf[0] + t1 * wf[1] + t2 * wf[2]);
+#pragma unroll
+            for (int b = a; b < DC; b++) sm[u++] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+        }
+    }
+    block_sum<NSM>(sm, red);
+    if (threadIdx.x == 0) {
+        double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;       // S was zeroed: store U_c (both triangles)
+        int u = 0;
+        for (int a = 0; a < DC; a++) for (int b = a; b < DC; b++) { blk[a * DC + b] = sm[u]; blk[b * DC + a] = sm[u]; u++; }
+        for (int a = 0; a < DC; a++) {
+            rhs[c * DC + a] = sm[NU + a] + sm[NU + DC + a]; gcraw[c * DC + a] = sm[NU + a]; Sfc[c * DC + a] = sm[NU + 2 * DC + a];
+            Udiag[c * DC + a] = sm[a * DC - a * (a - 1) / 2];
+        }
+    }
+}
+
+template <int DC>
+__global__ void __launch_bounds__(256, (DC == 3) ? 3 : 2)     // DC = 6 spills at 3 waves/SIMD (measured slower)
+k_schur_pairs(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+              const int* __restrict__ obs_pt, const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ chunk_cam,
+              const int* __restrict__ chunk_b0, const int* __restrict__ chunk_b1, const int* __restrict__ batch_slot,
+              const int* __restrict__ pair_j, const int* __restrict__ pair_j2, const double* __restrict__ scale_cam,
+              const double* __restrict__ scale_pt, const double* __restrict__ Vinv, int loss, double la, double* __restrict__ S_val) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int BB = DC * DC;
+    const int c = chunk_cam[blockIdx.x];
+    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    const int b0 = chunk_b0[blockIdx.x], b1 = chunk_b1[blockIdx.x];
+    const int s_lo = batch_slot[b0], s_hi = batch_slot[b1 - 1];     // slots of a chunk are a contiguous, ascending range
+    double* acc = lds;                         // [(s_hi - s_lo + 1) * BB] -- at most nnb blocks
+    double* camc = lds + nnb * BB;             // [6 + 27 + 6]
+    for (int i = threadIdx.x; i < (s_hi - s_lo + 1) * BB; i += blockDim.x) acc[i] = 0.0;
+    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
+    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
+    __syncthreads();
+    const double f = focal[0];
+    // wave index as a scalar: everything derived from it (batch range, slot, neighbour camera c2) is then wave-uniform for the
+    // compiler, and camera c2's 39 constants come in through scalar loads instead of 39 vector gathers per lane
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    {
+        const int nbt = b1 - b0, per = (nbt + nw - 1) / nw;
+        const int bs = b0 + w * per, be = min(b1, bs + per);
+        double blk[DC][DC];
+#pragma unroll
+        for (int a = 0; a < DC; a++)
+#pragma unroll
+            for (int b = 0; b < DC; b++) blk[a][b] = 0.0;
+        int cur = -1;
+        for (int bt = bs; bt <= be; bt++) {
+            const int slot = (bt < be) ? batch_slot[bt] : -2;
+            if (slot != cur) {
+                if (cur >= 0) {
+                    double* dst = acc + (cur - s_lo) * BB;
+#pragma unroll
+                    for (int a = 0; a < DC; a++)
+#pragma unroll
+                        for (int b = 0; b < DC; b++) { const double v = wave_sum(blk[a][b]); if (lane == 0) unsafeAtomicAdd(&dst[a * DC + b], v); blk[a][b] = 0.0; }
+                }
+                cur = slot;
+            }
+            if (bt >= be) break;
+            const int j = pair_j[(size_t)bt * 64 + lane];
+            if (j < 0) continue;
+            const int j2 = pair_j2[(size_t)bt * 64 + lane];
+            const int p = obs_pt[j];
+            const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+            const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+            double T[DC][3];
+            {
+                const double2 o = obs_xy[j];
+                ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
+                double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
+                const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
+#pragma unroll
+                for (int a = 0; a < DC; a++) {
+                    const double w0 = (Jc[0][a] * L.Jp[0][0] + Jc[1][a] * L.Jp[1][0]) * sp[0];
+                    const double w1 = (Jc[0][a] * L.Jp[0][1] + Jc[1][a] * L.Jp[1][1]) * sp[1];
+                    const double w2 = (Jc[0][a] * L.Jp[0][2] + Jc[1][a] * L.Jp[1][2]) * sp[2];
+                    T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+                    T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+                    T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                }
+            }
+            const int c2 = col_idx[rb + slot]; const double2 o2 = obs_xy[j2];
+            ObsLin L2; lin_obs<DC == 6>(f, cam + 6 * c2, rot + 27 * c2, X, o2.x, o2.y, loss, la, L2);
+            double Jc2[2][DC]; cam_block<DC>(L2, scale_cam + 6 * c2, Jc2);
+#pragma unroll
+            for (int b = 0; b < DC; b++) {
+                const double w0 = (Jc2[0][b] * L2.Jp[0][0] + Jc2[1][b] * L2.Jp[1][0]) * sp[0];
+                const double w1 = (Jc2[0][b] * L2.Jp[0][1] + Jc2[1][b] * L2.Jp[1][1]) * sp[1];
+                const double w2 = (Jc2[0][b] * L2.Jp[0][2] + Jc2[1][b] * L2.Jp[1][2]) * sp[2];
+#pragma unroll
+                for (int a = 0; a < DC; a++) blk[a][b] -= T[a][0] * w0 + T[a][1] * w1 + T[a][2] * w2;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (s_hi - s_lo + 1) * BB; i += blockDim.x) {
+        const double v = acc[i];
+        if (v != 0.0) unsafeAtomicAdd(&S_val[((size_t)rb + s_lo) * BB + i], v);
+    }
+}
+
+// symmetric mat-vec with only the lower triangle stored: q_c = sum_{s in row c} S_s p_col(s) + sum_{t in trans(c)} S_t^T p_row(t)
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_sym_matvec(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ trans_ptr,
+             const int* __restrict__ trans_blk, const int* __restrict__ trans_row, const double* __restrict__ S_val,
+             const double* __restrict__ Sfc, const double* __restrict__ p, int Nc, const double* __restrict__ pcg,
+             double* __restrict__ q, double* __restrict__ pqpart) {
+    if (pcg[PCG_DONE] != 0.0) return;
+    __shared__ double part[4][64];
+    constexpr int BB = DC * DC;
+    constexpr int LW = (64 / DC) * DC;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + w;
+    if (c < Nc) {
+        const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tb = trans_ptr[c], nt = trans_ptr[c + 1] - tb;
+        double s = 0.0;
+        if (lane < LW) {
+            const int a = lane % DC;
+            for (int idx = lane; idx < (nnb + nt) * DC; idx += LW) {
+                const int b = idx / DC;
+                if (b < nnb) {
+                    const double* row = S_val + ((size_t)(rb + b)) * BB + a * DC;
+                    const double* pv = p + col_idx[rb + b] * DC;
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += row[k] * pv[k];
+                } else {
+                    const int t = tb + (b - nnb);
+                    const double* blk = S_val + (size_t)trans_blk[t] * BB;      // block (row r, col c): use its transpose
+                    const double* pv = p + trans_row[t] * DC;
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += blk[k * DC + a] * pv[k];
+                }
+            }
+        }
+        part[w][lane] = s;
+    }
+    __syncthreads();
+    if (c < Nc && lane < DC) {
+        double s = 0.0;
+        for (int l = lane; l < LW; l += DC) s += part[w][l];
+        s += Sfc[c * DC + lane] * p[Nc * DC];
+        q[c * DC + lane] = s;
+        part[w][lane] = s * p[c * DC + lane];
+    }
+    __syncthreads();
+    if (c < Nc && lane == 0) { double s = 0.0; for (int a = 0; a < DC; a++) s += part[w][a]; pqpart[c] = s; }
+}
+
 // ---- K2b: after the (optional) all-reduce: LM diagonal on the camera blocks, block-Jacobi inverse, focal row
 template <int DC>
 __global__ void k_finalize_S(const int* __restrict__ row_ptr, const int* __restrict__ diag_slot, const double* __restrict__ scale_cam,

@@ -36,14 +36,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
-    // k_schur_rows keeps `ncopy` private copies of a camera's block row in LDS (fewer same-address ds_add_f64 per wave)
-    const size_t row_doubles = (size_t)F.max_row_blocks * BB + DC * (DC + 1) / 2 + 3 * DC + 1;
-    int ncopy = 16;
-    while (ncopy > 1 && (row_doubles * ncopy + 40) * sizeof(double) > 64 * 1024) ncopy >>= 1;
-    const size_t lds_bytes = (row_doubles * ncopy + 40) * sizeof(double);
+    // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
+    const size_t lds_bytes = ((size_t)F.max_row_blocks * BB + 48) * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(ctx, SSFM_ERR_INVALID, "reduced-system block row does not fit in LDS");
     if (lds_bytes > 48 * 1024)
-        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_rows<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_pairs<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
     double host_scal[SC_TOTAL];
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
@@ -92,9 +89,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->gp.p, h->Wf.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
-        LAUNCH(h, KID_SCHUR_ROWS, k_schur_rows<DC>, Nc, 256, lds_bytes, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->obs_pt.p, h->pt_start.p,
-               h->cam_start.p, h->cam_obs.p, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_pt.p, h->scale_f.p,
-               h->Vinv.p, h->gp.p, h->Wf.p, loss, la, ncopy, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw);
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->S_val, 0, (size_t)F.row_ptr[Nc] * BB * sizeof(double), st));
+        LAUNCH(h, KID_CAM_SUMS, k_cam_sums<DC>, Nc, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p, h->row_ptr.p,
+               h->diag_slot.p, h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->Wf.p, loss, la, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw);
+        if (!F.chunk_cam.empty())
+            LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs<DC>, (int)F.chunk_cam.size(), 256, lds_bytes, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->obs_pt.p,
+                   h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, h->scale_pt.p,
+                   h->Vinv.p, loss, la, h->S_val);
         if (ctx->nranks > 1) {
             // scalar sums ride at the tail of the same buffer
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -269,6 +270,11 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
 #undef AL
     SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
+    SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
+    SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st));
+    SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
+    SSFM_HIP_CHECK(ctx, upload(h->cam_batch_ptr, F.cam_batch_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_cam, F.chunk_cam, st));
+    SSFM_HIP_CHECK(ctx, upload(h->chunk_b0, F.chunk_b0, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_b1, F.chunk_b1, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSFM_OK;
