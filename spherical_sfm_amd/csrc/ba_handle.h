@@ -154,9 +154,9 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         return SSFM_OK;
     }
     const int ncomp = (int)F.comp_ptr.size() - 1;
-    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB) * sizeof(double);
+    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB + DC + 2) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
     const bool use_lds = lds_win <= 140 * 1024 && b * DC <= 256;
-    const int chol_threads = ((b * (b + 1) / 2) * DC <= 1024) ? 256 : 1024;
+    const int chol_threads = 256;
     // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
