@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 def algorithmic_bytes(M, nP, nnzb, dc, focal_free):
     """per LM iteration 72 B/observation + 240 B/point (+ the S term, reported separately)."""
     per_iter = 72.0 * M + 240.0 * nP
-    # pass A alone (k_schur_rows): obs 16 + ids 8 per observation; X 24 + V^-1 48 + g 24 (+ Wf 24) per point; S row blocks written
+    # pass A alone (k_schur_pairs): obs 16 + ids 8 per observation; X 24 + V^-1 48 + g 24 (+ Wf 24) per point; S row blocks written
     schur = 24.0 * M + (96.0 + (24.0 if focal_free else 0.0)) * nP + nnzb * dc * dc * 8.0
     return per_iter, schur
 
@@ -122,7 +122,7 @@ def main():
         nnzb = s["reduced_blocks"]
         per_iter_bytes, schur_bytes = algorithmic_bytes(M, args.points, nnzb, dc, args.focal_free)
         kern = {k: {"launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / max(1, v["launches"])} for k, v in ktimes.items()}
-        dom = "k_schur_rows"
+        dom = "k_schur_pairs"
         dom_us = kern.get(dom, {}).get("avg_us", float("nan"))
         achieved = (schur_bytes / world) / (dom_us * 1e-6) / 1e9 if dom_us == dom_us else None
         iter_ms = sum(phase.values()) / max(1, n_lm)

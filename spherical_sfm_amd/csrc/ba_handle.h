@@ -20,7 +20,7 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
                 KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_COUNT };
-static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_rows", "k_finalize_S", "k_pcg_init",
+static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs", "k_finalize_S", "k_pcg_init",
                                               "k_pcg_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol", "k_band_fwd",
                                               "k_band_back", "k_band_combine", "k_ref_vecops", "k_cam_sums"};
@@ -156,7 +156,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     const int ncomp = (int)F.comp_ptr.size() - 1;
     const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB + DC + 2) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
     const bool use_lds = lds_win <= 140 * 1024 && b * DC <= 256;
-    const int chol_threads = 256;
+    const int chol_threads = 384;      // wave 0 factors the next diagonal block, 5 waves share the trailing update (measured optimum 384-512)
     // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);

@@ -385,7 +385,7 @@ __device__ __forceinline__ bool chol_block(const double* __restrict__ a, double*
 //            waves 1..3    the rest of the trailing window, right-hand sides, store of the prefetched row
 //   barrier
 template <int DC, int NR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_band_chol_lds(double* __restrict__ band, double* __restrict__ Linv_out, double* __restrict__ Y, const int* __restrict__ pairs,
                 const int* __restrict__ comp_ptr, int N, int b, int* __restrict__ fail_flag) {
     constexpr int BB = DC * DC;
