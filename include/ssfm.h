@@ -175,6 +175,14 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
 int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
                                 double* Es, int32_t* counts);
 
+/* ---- SfM::Retriangulate (src/sfm.cpp:156-192) ------------------------------------------------------------------
+ * Re-estimates EVERY point of the problem from its observations and the current cameras/focal: LO-MSAC over 2-view DLT
+ * hypotheses (TriangulationEstimator, src/triangulation_estimator.cpp:46-127; squared inlier threshold 4 px^2, final
+ * least squares on), one GPU lane per point.  p->points is overwritten; points with < 3 observations or < 3 inliers
+ * become (0,0,0) exactly as in the reference (which removes them from later Optimize calls).  num_inliers_out: [num_points]
+ * or NULL.  The *_fixed masks are ignored, like the reference does. */
+int ssfm_retriangulate(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out);
+
 /* ---- feature tracks: the integer part of build_sfm (examples/spherical_sfm_tools.cpp:862-950), host only ------
  * Keyframe k owns features [feat_ptr[k], feat_ptr[k+1]) of feat_xy ([total*2] pixels).  Match set s links keyframes
  * (ms_index0[s], ms_index1[s]) with pairs (m_f0[m], m_f1[m]), m in [ms_ptr[s], ms_ptr[s+1]), feature indices local to their

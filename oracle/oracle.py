@@ -90,6 +90,7 @@ def lib():
         L.oracle_ransac_pair.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                          c_double_p, c_double_p, c_u8_p, C.POINTER(C.c_uint32), c_double_p]
         L.oracle_ransac_pair.restype = C.c_int
+        L.oracle_retriangulate.argtypes = [C.POINTER(BAProblemC), C.c_int32, c_i32_p]; L.oracle_retriangulate.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -268,3 +269,11 @@ def ransac_pair(u, v, sq_thresh, inward=False, min_iterations=100, max_iteration
     n = lib().oracle_ransac_pair(len(u), _dp(u), _dp(v), int(inward), sq_thresh, min_iterations, max_iterations, seed, min_num_inliers,
                                  _dp(E), _dp(R), _up(mask), C.byref(it), C.byref(sc))
     return dict(E=_um(E), R=_um(R), inliers=mask.astype(bool), num_inliers=n, iterations=it.value, score=sc.value)
+
+
+def retriangulate(prob, num_threads=16):
+    """SfM::Retriangulate on a BAProblem-like object -> (points (Np,3), num_inliers (Np,))"""
+    h = _Held(prob)
+    nin = np.zeros(len(h.pts), np.int32)
+    lib().oracle_retriangulate(C.byref(h.c), num_threads, _ip(nin))
+    return h.pts, nin

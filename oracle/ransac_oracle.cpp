@@ -25,7 +25,9 @@
 #include <numeric>
 #include <random>
 #include <vector>
+#include <array>
 #include "lm.hpp"
+#include "lomsac.hpp"
 #include "rotation.hpp"
 #include "ssfm_oracle.h"
 
@@ -315,98 +317,25 @@ static void least_squares(const Rays& R, bool inward, const std::vector<int>& sa
     double Rm[9]; rm_so3exp(r, Rm); make_E(Rm, inward, E);
 }
 
-struct MSACOptions { uint32_t min_it = 100, max_it = 10000; double prob = 0.9999, sq_thresh = 1.0; unsigned seed = 0;
-                     int num_lo_steps = 10; double thresh_mult = std::sqrt(2.0); int num_lsq_it = 4, min_sample_mult = 7, non_min_mult = 3; uint32_t lo_start = 50; bool final_lsq = false; };
-
-static uint32_t num_required_iterations(double ratio, double pmiss, int ssize, uint32_t mn, uint32_t mx) {     // utils.h:110-140
-    if (ratio <= 0.0) return mx; if (ratio >= 1.0) return mn;
-    const double pn = 1.0 - std::pow(ratio, (double)ssize);
-    if (pn >= 0.99999999999999) return mx;
-    const double it = std::ceil(std::log(pmiss) / std::log(pn) + 0.5);
-    return std::max(mn, std::min((uint32_t)it, mx));
-}
-static void shuffle_resize(int target, std::mt19937* rng, std::vector<int>* s) {                                // utils.h:48-73
-    const int n = (int)s->size();
-    for (int i = 0; i < n - 1; i++) { std::uniform_int_distribution<int> dist(i, n - 1); std::swap((*s)[i], (*s)[dist(*rng)]); }
-    s->resize(target);
-}
-
-struct Msac {
-    const Rays& R; bool inward; MSACOptions o;
-    Msac(const Rays& r, bool in, const MSACOptions& op) : R(r), inward(in), o(op) {}
-    double score(const double* E) const { double s = 0; for (int i = 0; i < R.n; i++) s += std::min(sampson(E, R.u + 3 * i, R.v + 3 * i), o.sq_thresh); return s; }
-    int inliers(const double* E, double th, std::vector<int>* out) const { out->clear(); for (int i = 0; i < R.n; i++) if (sampson(E, R.u + 3 * i, R.v + 3 * i) < th) out->push_back(i); return (int)out->size(); }
-    static void update(double sc, const double* m, double* best_sc, double* best) { if (sc < *best_sc) { *best_sc = sc; std::memcpy(best, m, 72); } }
-    void lsq_fit(double thresh, std::mt19937* rng, double* model) const {                                       // ransac.h:409-420
-        std::vector<int> inl; const int n = inliers(model, thresh, &inl);
-        if (n < 3) return;
-        shuffle_resize(std::min(o.min_sample_mult * 3, n), rng, &inl);
-        least_squares(R, inward, inl, model);
+typedef std::array<double, 9> EMat;      // row-major
+struct SphericalSolver {                 // SphericalEstimator, include/sphericalsfm/spherical_estimator.h:8-35
+    const Rays& R; bool inward;
+    int min_sample_size() const { return 3; }
+    int non_minimal_sample_size() const { return 4; }
+    int num_data() const { return R.n; }
+    int MinimalSolver(const std::vector<int>& sample, std::vector<EMat>* Es) const {
+        double buf[36]; const int k = solver_action_matrix(R, sample.data(), (int)sample.size(), buf);
+        Es->resize(k); for (int i = 0; i < k; i++) std::memcpy((*Es)[i].data(), buf + 9 * i, 72);
+        return k;
     }
-    void local_optimization(std::mt19937* rng, double* best_min, double* score_best) const {                    // ransac.h:341-407
-        if (4 > R.n) return;
-        double m_init[9]; std::memcpy(m_init, best_min, 72);
-        lsq_fit(o.sq_thresh * o.thresh_mult, rng, m_init);
-        update(score(m_init), m_init, score_best, best_min);
-        std::vector<int> base; inliers(m_init, o.sq_thresh * o.thresh_mult, &base);
-        const int nonmin = std::max(4, std::min(3 * o.non_min_mult, (int)base.size() / 2));
-        for (int r = 0; r < o.num_lo_steps; r++) {
-            std::vector<int> sample = base; shuffle_resize(nonmin, rng, &sample);
-            double Es[36]; if (solver_action_matrix(R, sample.data(), (int)sample.size(), Es) == 0) continue;      // NonMinimalSolver :86-108
-            double bs = INFINITY; int bi = 0;
-            for (int i = 0; i < 4; i++) { double sc = 0; for (int j : sample) sc += sampson(Es + 9 * i, R.u + 3 * j, R.v + 3 * j); if (sc < bs) { bs = sc; bi = i; } }
-            double m[9]; std::memcpy(m, Es + 9 * bi, 72);
-            update(score(m), m, score_best, best_min);
-            lsq_fit(o.sq_thresh, rng, m);
-            double th = o.thresh_mult * o.sq_thresh; const double upd = (o.thresh_mult - 1.0) * o.sq_thresh / (o.num_lsq_it - 1);
-            for (int i = 0; i < o.num_lsq_it; i++) { lsq_fit(th, rng, m); update(score(m), m, score_best, best_min); th -= upd; }
-        }
+    int NonMinimalSolver(const std::vector<int>& sample, EMat* E) const {            // src/spherical_estimator.cpp:86-108
+        double buf[36]; if (solver_action_matrix(R, sample.data(), (int)sample.size(), buf) == 0) return 0;
+        double bs = INFINITY; int bi = 0;
+        for (int i = 0; i < 4; i++) { double sc = 0; for (int j : sample) sc += sampson(buf + 9 * i, R.u + 3 * j, R.v + 3 * j); if (sc < bs) { bs = sc; bi = i; } }
+        std::memcpy(E->data(), buf + 9 * bi, 72); return 1;
     }
-    int estimate(double* best_model, uint32_t* iters_out, std::vector<int>* inl_out, double* best_score_out, int* lo_count) const {   // ransac.h:128-275
-        *iters_out = 0; *lo_count = 0; *best_score_out = std::numeric_limits<double>::max(); inl_out->clear();
-        if (3 > R.n) return 0;
-        std::mt19937 srng; srng.seed(o.seed); std::uniform_int_distribution<int> udist(0, R.n - 1);
-        const bool draw = ((double)R.n / (double)(R.n - 3)) < M_E;                                               // sampling.h:66-75
-        std::mt19937 rng; rng.seed(o.seed);
-        uint32_t max_it = std::max(o.max_it, o.min_it);
-        double best_min[9]; double best_min_score = std::numeric_limits<double>::max(), best_score = std::numeric_limits<double>::max();
-        int best_inl = 0; std::vector<int> sample(3);
-        uint32_t it = 0;
-        for (it = 0; it < max_it; ++it) {
-            if (it == o.lo_start && best_min_score < std::numeric_limits<double>::max()) {
-                ++*lo_count; local_optimization(&rng, best_model, &best_score);
-                best_inl = inliers(best_model, o.sq_thresh, inl_out);
-                max_it = num_required_iterations((double)best_inl / R.n, 1.0 - o.prob, 3, o.min_it, o.max_it);
-            }
-            if (draw) { sample.resize(3); for (int i = 0; i < 3; i++) { bool found = true; while (found) { found = false; sample[i] = udist(srng); for (int j = 0; j < i; j++) if (sample[j] == sample[i]) { found = true; break; } } } }
-            else { sample.resize(R.n); std::iota(sample.begin(), sample.end(), 0); if (R.n != 3) { for (int i = 0; i < R.n - 1; i++) { std::uniform_int_distribution<int> d(i, R.n - 1); std::swap(sample[i], sample[d(srng)]); } sample.resize(3); } }
-            double Es[36]; const int nm = solver_action_matrix(R, sample.data(), 3, Es);
-            if (nm <= 0) continue;
-            double bl = std::numeric_limits<double>::max(); int bid = 0;
-            for (int m = 0; m < nm; m++) { const double sc = score(Es + 9 * m); if (sc < bl) { bl = sc; bid = m; } }
-            if (bl < best_min_score || it == o.lo_start) {
-                const bool best_min_model = bl < best_min_score;
-                if (best_min_model) { best_min_score = bl; std::memcpy(best_min, Es + 9 * bid, 72); update(best_min_score, best_min, &best_score, best_model); }
-                const bool run_lo = (it >= o.lo_start && best_min_score < std::numeric_limits<double>::max());
-                if (!best_min_model && !run_lo) continue;
-                if (run_lo) { ++*lo_count; double sc = best_min_score; local_optimization(&rng, best_min, &sc); update(sc, best_min, &best_score, best_model); }
-                best_inl = inliers(best_model, o.sq_thresh, inl_out);
-                max_it = num_required_iterations((double)best_inl / R.n, 1.0 - o.prob, 3, o.min_it, o.max_it);
-            }
-        }
-        if (it <= o.lo_start && best_score < std::numeric_limits<double>::max()) {
-            ++*lo_count; local_optimization(&rng, best_model, &best_score);
-            best_inl = inliers(best_model, o.sq_thresh, inl_out);
-        }
-        if (o.final_lsq) {
-            double refined[9]; std::memcpy(refined, best_model, 72);
-            least_squares(R, inward, *inl_out, refined);
-            const double sc = score(refined);
-            if (sc < best_score) { best_score = sc; std::memcpy(best_model, refined, 72); best_inl = inliers(best_model, o.sq_thresh, inl_out); }
-        }
-        *iters_out = it; *best_score_out = best_score;
-        return best_inl;
-    }
+    double EvaluateModelOnPoint(const EMat& E, int i) const { return sampson(E.data(), R.u + 3 * i, R.v + 3 * i); }
+    void LeastSquares(const std::vector<int>& sample, EMat* E) const { least_squares(R, inward, sample, E->data()); }
 };
 
 static void cm_to_rm(const double* cm, double* rm) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rm[3 * i + j] = cm[i + 3 * j]; }
@@ -434,9 +363,12 @@ extern "C" int oracle_ransac_pair(int32_t n, const double* u, const double* v, i
                                   double* best_score) {
     Rays R{n, u, v};
     MSACOptions o; o.sq_thresh = sq_thresh; o.num_lo_steps = 0; o.num_lsq_it = 0; o.final_lsq = true; o.min_it = min_it; o.max_it = max_it; o.seed = seed;
-    Msac M(R, inward != 0, o);
-    double E[9] = {0}; std::vector<int> inl; uint32_t it; double bs; int lo;
-    M.estimate(E, &it, &inl, &bs, &lo);
+    SphericalSolver solver{R, inward != 0};
+    LoMsac<SphericalSolver, EMat> M(solver, o);
+    EMat Em{}; MSACStats st;
+    M.estimate(&Em, &st);
+    double E[9]; std::memcpy(E, Em.data(), 72);
+    const uint32_t it = st.iterations; const double bs = st.best_score;
     int nin = 0;
     for (int i = 0; i < n; i++) { const bool in = sampson(E, u + 3 * i, v + 3 * i) < sq_thresh; if (inlier_mask) inlier_mask[i] = in; nin += in; }
     if (iterations) *iterations = it; if (best_score) *best_score = bs;

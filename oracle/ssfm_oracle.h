@@ -102,6 +102,10 @@ int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inwa
                        uint32_t max_iterations, uint32_t seed, int32_t min_num_inliers, double E[9], double R[9], uint8_t* inlier_mask,
                        uint32_t* iterations, double* best_score);
 
+/* SfM::Retriangulate (src/sfm.cpp:156-192): every point is re-estimated from its observations with the per-point LO-MSAC
+ * of TriangulationEstimator; points with < 3 observations or < 3 inliers become (0,0,0).  num_inliers_out: [num_points] or NULL */
+int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out);
+
 #ifdef __cplusplus
 }
 #endif

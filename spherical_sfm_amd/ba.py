@@ -92,6 +92,14 @@ def optimize(ctx, prob, options=None, **kw):
     return b.cams, b.pts, float(b.focal[0]), s.as_dict()
 
 
+def retriangulate(ctx, prob):
+    """SfM::Retriangulate (reference src/sfm.cpp:156-192) on the GPU -> (points (Np,3), num_inliers (Np,))."""
+    b = _ProblemBuffers(prob)
+    nin = np.zeros(len(b.pts), np.int32)
+    _lib.check(_lib.lib().ssfm_retriangulate(ctx._p, C.byref(b.c), nin.ctypes.data_as(c_i32_p)), ctx._p)
+    return b.pts, nin
+
+
 class BundleAdjuster:
     def __init__(self, ctx, prob, options=None, **kw):
         self.ctx = ctx

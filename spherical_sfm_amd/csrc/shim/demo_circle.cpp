@@ -1,5 +1,5 @@
-// Drop-in demonstration: the call sequence of examples/run_spherical_sfm_uncalib.cpp:177-211 (spherical BA,
-// then general BA + Normalize) on a small synthetic circle, through the sphericalsfm::SfM mirror.
+// Drop-in demonstration: the call sequence of examples/run_spherical_sfm_uncalib.cpp:177-211 / run_spherical_sfm.cpp:93-112
+// (spherical BA, Retriangulate, BA; then general BA + Normalize + Retriangulate + BA + Normalize) on a small synthetic circle, through the sphericalsfm::SfM mirror.
 // Prints a machine-readable summary line consumed by tests/test_cpp_shim_gpu.py.
 #include <cmath>
 #include <cstdio>
@@ -51,13 +51,25 @@ int main(int argc, char** argv) {
     dump_state();
     const bool ok1 = sfm.Optimize();                                                          // spherical BA
     dump_state();
-    if (dump) std::fclose(dump);
     const double f1 = sfm.GetFocal(), c1 = sfm.LastSummary().final_cost; const int it1 = sfm.LastSummary().iterations;
-    for (int i = 1; i < sfm.GetNumCameras(); i++) sfm.SetTranslationFixed(i, false);          // general BA
+    auto count_zero = [&]() { int z = 0; for (int j = 0; j < Np; j++) { Point X = sfm.GetPoint(j); if (X.v[0] == 0 && X.v[1] == 0 && X.v[2] == 0) z++; } return z; };
+    sfm.Retriangulate();                                                                      // run_spherical_sfm.cpp:93-95
+    dump_state();
+    if (dump) std::fclose(dump);
+    const int zero1 = count_zero();
+    const bool ok1b = sfm.Optimize();
+    const double c1b = sfm.LastSummary().final_cost;
+    for (int i = 1; i < sfm.GetNumCameras(); i++) sfm.SetTranslationFixed(i, false);          // general BA (run_spherical_sfm.cpp:101-112)
     const bool ok2 = sfm.Optimize();
+    const int it2 = sfm.LastSummary().iterations; const double c2 = sfm.LastSummary().final_cost, f2 = sfm.GetFocal();
+    sfm.Normalize(false);
+    sfm.Retriangulate();
+    const int zero2 = count_zero();
+    const bool ok3 = sfm.Optimize();
     sfm.Normalize(false);
     double mean_radius = 0; for (int i = 0; i < Nc; i++) mean_radius += sfm.GetPose(i).getCenter().norm();
-    std::printf("SHIM_RESULT ok1=%d ok2=%d it1=%d it2=%d focal1=%.9f focal2=%.9f cost1=%.9e cost2=%.9e dof2=%d mean_radius=%.12f\n", ok1, ok2, it1,
-                sfm.LastSummary().iterations, f1, sfm.GetFocal(), c1, sfm.LastSummary().final_cost, sfm.LastSummary().camera_dof, mean_radius / Nc);
-    return (ok1 && ok2) ? 0 : 1;
+    std::printf("SHIM_RESULT ok1=%d ok1b=%d ok2=%d ok3=%d it1=%d it2=%d focal1=%.9f focal2=%.9f focal3=%.9f cost1=%.9e cost1b=%.9e cost2=%.9e cost3=%.9e dof2=%d "
+                "zero1=%d zero2=%d mean_radius=%.12f\n", ok1, ok1b, ok2, ok3, it1, it2, f1, f2, sfm.GetFocal(), c1, c1b, c2, sfm.LastSummary().final_cost,
+                sfm.LastSummary().camera_dof, zero1, zero2, mean_radius / Nc);
+    return (ok1 && ok1b && ok2 && ok3) ? 0 : 1;
 }

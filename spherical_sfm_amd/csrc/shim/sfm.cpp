@@ -77,37 +77,52 @@ void SfM::SetPose(int camera, const Pose& p) { cameras[camera] = Camera{p.t.v[0]
 Point SfM::GetPoint(int point) { auto it = points.find(point); return it == points.end() ? Point(0, 0, 0) : it->second; }
 void SfM::SetPoint(int point, const Point& X) { points[point] = X; }
 
-bool SfM::Optimize() {
-    if (numCameras == 0 || numPoints == 0) return false;                                      // src/sfm.cpp:230
-    std::cout << "\tBuilding BA problem...\n";
-    // dense index spaces [0,numCameras) x [0,numPoints) as the reference's loops use them; absent entries stay absent
-    std::vector<double> cam((size_t)numCameras * 6, 0.0), pts((size_t)numPoints * 3, 0.0);
-    std::vector<uint8_t> rf(numCameras, 1), tf(numCameras, 1), pf(numPoints, 0);
+// dense index spaces [0,numCameras) x [0,numPoints) as the reference's loops use them; absent entries stay absent
+void SfM::Flatten(FlatProblem& F) {
+    F.cam.assign((size_t)numCameras * 6, 0.0); F.pts.assign((size_t)numPoints * 3, 0.0);
+    F.rf.assign(numCameras, 1); F.tf.assign(numCameras, 1); F.pf.assign(numPoints, 0);
+    F.xy.clear(); F.oc.clear(); F.op.clear();
     for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) {
-        for (int k = 0; k < 6; k++) cam[(size_t)kv.first * 6 + k] = kv.second[k];
-        rf[kv.first] = rotationFixed[kv.first]; tf[kv.first] = translationFixed[kv.first];
+        for (int k = 0; k < 6; k++) F.cam[(size_t)kv.first * 6 + k] = kv.second[k];
+        F.rf[kv.first] = rotationFixed[kv.first]; F.tf[kv.first] = translationFixed[kv.first];
     }
     for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) {
-        for (int k = 0; k < 3; k++) pts[(size_t)kv.first * 3 + k] = kv.second.v[k];
-        pf[kv.first] = pointFixed[kv.first];
+        for (int k = 0; k < 3; k++) F.pts[(size_t)kv.first * 3 + k] = kv.second.v[k];
+        F.pf[kv.first] = pointFixed[kv.first];
     }
-    std::vector<double> xy; std::vector<int32_t> oc, op;
     for (auto& row : observations) {
-        if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;   // src/sfm.cpp:249
+        if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;   // src/sfm.cpp:249 / :167
         for (auto& kv : row.second) {
-            if (kv.first < 0 || kv.first >= numPoints || !points.count(kv.first)) continue;     // src/sfm.cpp:242
-            xy.push_back(kv.second.x); xy.push_back(kv.second.y); oc.push_back(row.first); op.push_back(kv.first);
+            if (kv.first < 0 || kv.first >= numPoints || !points.count(kv.first)) continue;     // src/sfm.cpp:242 / :161
+            F.xy.push_back(kv.second.x); F.xy.push_back(kv.second.y); F.oc.push_back(row.first); F.op.push_back(kv.first);
         }
     }
     if (!ctx) {
         int rc = ssfm_ctx_create(-1, nullptr, &ctx);
         if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(nullptr) << "\n"; exit(1); }
     }
-    ssfm_ba_problem P;
-    P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)oc.size();
-    P.cameras = cam.data(); P.points = pts.data(); P.focal = &intrinsics.focal;
-    P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data();
-    P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = focalFixed ? 1 : 0;
+    ssfm_ba_problem& P = F.P;
+    P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)F.oc.size();
+    P.cameras = F.cam.data(); P.points = F.pts.data(); P.focal = &intrinsics.focal;
+    P.obs_xy = F.xy.data(); P.obs_cam = F.oc.data(); P.obs_pt = F.op.data();
+    P.rot_fixed = F.rf.data(); P.trans_fixed = F.tf.data(); P.pt_fixed = F.pf.data(); P.focal_fixed = focalFixed ? 1 : 0;
+}
+
+// src/sfm.cpp:156-192: every existing point is re-estimated from its observations (one GPU lane per point instead of the
+// cv::parallel_for_ over LO-MSAC objects); < 3 observations or < 3 inliers -> (0,0,0)
+void SfM::Retriangulate() {
+    if (numCameras == 0 || numPoints == 0) return;
+    FlatProblem F; Flatten(F);
+    int rc = ssfm_retriangulate(ctx, &F.P, nullptr);
+    if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(ctx) << "\n"; exit(1); }
+    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = F.pts[(size_t)kv.first * 3 + k];
+}
+
+bool SfM::Optimize() {
+    if (numCameras == 0 || numPoints == 0) return false;                                      // src/sfm.cpp:230
+    std::cout << "\tBuilding BA problem...\n";
+    FlatProblem F; Flatten(F);
+    ssfm_ba_problem& P = F.P; std::vector<double>&cam = F.cam, &pts = F.pts;
     ssfm_ba_options O; ssfm_ba_default_options(&O);                                            // src/sfm.cpp:194-212
     O.verbose = 1;                                                                            // minimizer_progress_to_stdout
     int rc = ssfm_ba_solve(ctx, &P, &O, &last_summary);

@@ -60,6 +60,10 @@ protected:
     int numCameras, numPoints, nextCamera, nextPoint;
     ssfm_ctx* ctx;                        // created on first Optimize()
     ssfm_ba_summary last_summary;
+    struct FlatProblem {                  // the flat arrays the C ABI takes + the struct pointing at them
+        std::vector<double> cam, pts, xy; std::vector<int32_t> oc, op; std::vector<uint8_t> rf, tf, pf; ssfm_ba_problem P;
+    };
+    void Flatten(FlatProblem& F);
 public:
     explicit SfM(const Intrinsics& _intrinsics);
     ~SfM();
@@ -77,6 +81,7 @@ public:
     int GetNumPoints() { return numPoints; }
     bool GetObservation(int camera, int point, Observation& observation);
 
+    void Retriangulate();                         // src/sfm.cpp:156-192
     bool Optimize();                              // src/sfm.cpp:228-290: true iff CONVERGENCE; exit(1) on FAILURE
 
     void Apply(const Pose& pose);

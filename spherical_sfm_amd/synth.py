@@ -164,3 +164,19 @@ def make_relative_pose_problem(num_corr=100, *, inward=False, rotation_deg=None,
         v[idx, :2] = rng.uniform(-1.5, 1.5, size=(n_out, 2)); inl[idx] = False
     S = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     return np.ascontiguousarray(u), np.ascontiguousarray(v), R, S @ R, inl
+
+
+def corrupt_observations(prob, frac=0.1, seed=5, lo=30.0, hi=80.0):
+    """Gross outliers for Retriangulate tests: one observation of `frac` of the points is displaced by lo..hi px.
+    Returns the ids of the touched points; prob.obs_xy is replaced."""
+    rng = np.random.default_rng(seed)
+    xy = np.array(prob.obs_xy, np.float64, copy=True)
+    pts = rng.choice(len(prob.points), int(frac * len(prob.points)), replace=False)
+    order = np.argsort(prob.obs_pt, kind="stable")
+    start = np.searchsorted(prob.obs_pt[order], np.arange(len(prob.points) + 1))
+    for p in pts:
+        i = order[rng.integers(start[p], start[p + 1])]
+        ang = rng.uniform(0, 2 * np.pi); r = rng.uniform(lo, hi)
+        xy[i] += r * np.array([np.cos(ang), np.sin(ang)])
+    prob.obs_xy = xy
+    return pts

@@ -1,5 +1,6 @@
 """The C++ mirror of sphericalsfm::SfM (spherical_sfm_amd/csrc/shim) driven like run_spherical_sfm_uncalib.cpp:177-211:
-AddCamera/AddPoint/AddObservation -> Optimize() (spherical) -> unfix translations -> Optimize() -> Normalize().
+AddCamera/AddPoint/AddObservation -> Optimize() (spherical) -> Retriangulate() -> Optimize() -> unfix translations ->
+Optimize() -> Normalize() -> Retriangulate() -> Optimize() -> Normalize().
 The problem the C++ side built is dumped and replayed through the oracle: parity of the whole drop-in path."""
 import os
 import struct
@@ -25,7 +26,9 @@ def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("SHIM_RESULT")][0]
     r = dict(kv.split("=") for kv in line.split()[1:])
-    assert r["ok1"] == "1" and r["ok2"] == "1" and r["dof2"] == "6"
+    assert r["ok1"] == "1" and r["ok1b"] == "1" and r["ok2"] == "1" and r["ok3"] == "1" and r["dof2"] == "6"
+    assert r["zero1"] == "0" and r["zero2"] == "0"                          # clean tracks: Retriangulate keeps every point
+    assert float(r["cost1b"]) <= float(r["cost1"]) * (1 + 1e-6) and float(r["cost3"]) <= float(r["cost2"]) * (1 + 1e-6)
     assert abs(float(r["focal1"]) - 1000.0) < 2.0 and abs(float(r["focal2"]) - 1000.0) < 2.0
     assert abs(float(r["mean_radius"]) - 1.0) < 1e-12                       # Normalize(), src/sfm.cpp:549-559
     # ---- replay the first Optimize() through the oracle
@@ -40,6 +43,7 @@ def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
         return cams.copy(), pts.copy(), float(f), o
     c0, p0, f0, off = state(off)
     c1, p1, f1, off = state(off)
+    c2, p2, f2, off = state(off)                                            # after the first Retriangulate()
     tf = np.ones(Nc, np.uint8); rf = np.zeros(Nc, np.uint8); rf[0] = 1
     prob = synth.BAProblem(cameras=c0, points=p0, focal=f0, obs_xy=np.stack([rec["x"], rec["y"]], 1), obs_cam=rec["c"].astype(np.int32),
                            obs_pt=rec["p"].astype(np.int32), rot_fixed=rf, trans_fixed=tf, pt_fixed=np.zeros(Np, np.uint8), focal_fixed=False,
@@ -49,3 +53,10 @@ def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
     assert np.abs(c1 - oc).max() / np.abs(oc).max() <= 1e-5
     assert (np.linalg.norm(p1 - op, axis=1) / np.linalg.norm(op, axis=1)).max() <= 1e-5
     assert abs(f1 - of) <= 1e-5 * of and abs(float(r["cost1"]) - os_["final_cost"]) <= 1e-8 * os_["final_cost"]
+    # ---- and the Retriangulate() that followed (src/sfm.cpp:156-192): same cameras, points re-estimated
+    assert np.array_equal(c2, c1) and f2 == f1
+    prob1 = synth.BAProblem(cameras=c1, points=p1, focal=f1, obs_xy=prob.obs_xy, obs_cam=prob.obs_cam, obs_pt=prob.obs_pt, rot_fixed=rf, trans_fixed=tf,
+                            pt_fixed=prob.pt_fixed, focal_fixed=False, gt_cameras=c1, gt_points=p1, gt_focal=0.0)
+    Xo, nin = oracle.retriangulate(prob1)
+    rel = np.linalg.norm(p2 - Xo, axis=1) / np.linalg.norm(Xo, axis=1)
+    assert np.quantile(rel, 0.99) <= 1e-4 and np.median(rel) <= 1e-5
