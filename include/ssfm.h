@@ -42,6 +42,12 @@ int ssfm_version(void);
  * 128 bytes with whatever it has (torch.distributed in bench.py), every rank calls ssfm_comm_init. */
 int ssfm_comm_unique_id(uint8_t id[128]);
 int ssfm_comm_init(ssfm_ctx* ctx, const uint8_t id[128], int32_t nranks, int32_t rank);
+/* Alternative to RCCL: the caller supplies the collective (MPI, gloo, a test harness).  The library stages each reduction
+ * through pinned host memory and calls fn(user, buf, n, op) with op = SSFM_REDUCE_SUM / SSFM_REDUCE_MAX; fn must leave the
+ * element-wise reduction over all ranks in buf and return 0.  Same sharding and the same reductions as the RCCL path. */
+enum { SSFM_REDUCE_SUM = 0, SSFM_REDUCE_MAX = 1 };
+typedef int (*ssfm_host_allreduce_fn)(void* user, double* buf, uint64_t n, int32_t op);
+int ssfm_comm_init_host(ssfm_ctx* ctx, int32_t nranks, int32_t rank, ssfm_host_allreduce_fn fn, void* user);
 
 /* ---- bundle adjustment: replaces the body of sphericalsfm::SfM::Optimize (src/sfm.cpp:228-290) --- */
 typedef struct {

@@ -61,8 +61,10 @@ class RansacOptionsC(C.Structure):
 
 
 # every symbol include/ssfm.h declares (tests check that the library exports all of them)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_int32)
+
 DECLARED_SYMBOLS = [
-    "ssfm_ctx_create", "ssfm_ctx_destroy", "ssfm_last_error", "ssfm_version", "ssfm_comm_unique_id", "ssfm_comm_init",
+    "ssfm_ctx_create", "ssfm_ctx_destroy", "ssfm_last_error", "ssfm_version", "ssfm_comm_unique_id", "ssfm_comm_init", "ssfm_comm_init_host",
     "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
@@ -97,6 +99,7 @@ def lib():
     L.ssfm_version.restype = C.c_int
     L.ssfm_comm_unique_id.argtypes = [c_u8_p]; L.ssfm_comm_unique_id.restype = C.c_int
     L.ssfm_comm_init.argtypes = [vp, c_u8_p, C.c_int32, C.c_int32]; L.ssfm_comm_init.restype = C.c_int
+    L.ssfm_comm_init_host.argtypes = [vp, C.c_int32, C.c_int32, HOST_ALLREDUCE_FN, vp]; L.ssfm_comm_init_host.restype = C.c_int
     L.ssfm_ba_default_options.argtypes = [C.POINTER(BAOptionsC)]; L.ssfm_ba_default_options.restype = None
     L.ssfm_ba_plan.argtypes = [C.POINTER(BAProblemC), C.c_int32, C.c_int32, C.POINTER(BAPlanInfoC), c_i32_p, c_u8_p, c_i32_p]; L.ssfm_ba_plan.restype = C.c_int
     L.ssfm_ba_solve.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]; L.ssfm_ba_solve.restype = C.c_int

@@ -42,6 +42,19 @@ class Context:
         _lib.check(_lib.lib().ssfm_comm_init(self._p, buf, nranks, rank), self._p)
         self.nranks, self.rank = nranks, rank
 
+    def comm_init_host(self, nranks: int, rank: int, allreduce):
+        """Bring-your-own collective: allreduce(array (n,) float64 view, op) must reduce IN PLACE over all ranks
+        (op 0 = sum, 1 = max).  Used with gloo/MPI, and by the tests to run two ranks on one GPU."""
+        def _hook(user, buf, n, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(n),)), int(op))
+                return 0
+            except Exception:            # noqa: BLE001 - reported through the C status
+                import traceback; traceback.print_exc()
+                return 1
+        self._hook = _lib.HOST_ALLREDUCE_FN(_hook)            # keep alive
+        _lib.check(_lib.lib().ssfm_comm_init_host(self._p, nranks, rank, self._hook, None), self._p)
+
     def close(self):
         if self._p:
             _lib.lib().ssfm_ctx_destroy(self._p)

@@ -52,7 +52,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                        loss, la, h->diag_pt.p, h->diag_f.p);
         hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
                            loss, la, h->diag_cam.p);
-        if (ctx->nranks > 1) {   // camera / focal column norms are sums over every rank's observations
+        if (ctx->collective) {   // camera / focal column norms are sums over every rank's observations
             int rc = allreduce(h, h->diag_cam.p, (size_t)Nc * 6, ncclSum); if (rc) return rc;
             rc = allreduce(h, h->diag_f.p, 1, ncclSum); if (rc) return rc;
         }
@@ -96,7 +96,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs<DC>, (int)F.chunk_cam.size(), 256, lds_bytes, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->obs_pt.p,
                    h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, h->scale_pt.p,
                    h->Vinv.p, loss, la, h->S_val);
-        if (ctx->nranks > 1) {
+        if (ctx->collective) {
             // scalar sums ride at the tail of the same buffer
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
             int rc = allreduce(h, h->redbuf.p, (size_t)h->n_red, ncclSum); if (rc) return rc;
@@ -321,6 +321,25 @@ extern "C" int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p) {
     for (size_t i = 0; i < cams.size(); i++) if (F.mask_cam[i] > 0.0) p->cameras[i] = cams[i];
     for (int q = 0; q < F.nP; q++) if (F.mask_pt[(size_t)q * 3] > 0.0) for (int d = 0; d < 3; d++) p->points[(size_t)F.pt_ids[q] * 3 + d] = pts[(size_t)q * 3 + d];
     if (F.focal_free) *p->focal = f;
+    if (ctx->collective && ctx->nranks > 1) {
+        // every rank leaves with every point: [x y z owned] per global point id, summed over ranks (each point has one owner)
+        const size_t Np = (size_t)p->num_points;
+        std::vector<double> all(Np * 4, 0.0);
+        for (int q = 0; q < F.nP; q++) if (F.mask_pt[(size_t)q * 3] > 0.0) {
+            const size_t g = (size_t)F.pt_ids[q];
+            for (int d = 0; d < 3; d++) all[g * 4 + d] = pts[(size_t)q * 3 + d];
+            all[g * 4 + 3] = 1.0;
+        }
+        DevBuf<double> dall; SSFM_HIP_CHECK(ctx, upload(dall, all, st));
+        int rc = allreduce(h, dall.p, all.size(), ncclSum);
+        if (rc == SSFM_OK) {
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(all.data(), dall.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            for (size_t g = 0; g < Np; g++) if (all[g * 4 + 3] > 0.5) for (int d = 0; d < 3; d++) p->points[g * 3 + d] = all[g * 4 + d];
+        }
+        dall.free();
+        return rc;
+    }
     return SSFM_OK;
 }
 
@@ -367,7 +386,7 @@ extern "C" int ssfm_ba_evaluate(ssfm_ba_handle* h, double* cost, double* residua
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&c, dcost.p, sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     dres.free(); djac.free(); dcost.free();
-    if (ctx->nranks > 1) { /* cost of this rank's shard only; callers sum */ }
+    if (ctx->collective) { /* cost of this rank's shard only; callers sum */ }
     if (cost) *cost = c;
     for (int64_t j = 0; j < M; j++) {
         const int64_t o = F.obs_orig[j];

@@ -1,4 +1,5 @@
 // spherical_sfm_amd -- context + communicator entry points of the C ABI (include/ssfm.h).
+#include <cstdlib>
 #include <cstring>
 #include "ssfm_ctx.h"
 
@@ -35,6 +36,7 @@ extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -52,10 +54,21 @@ extern "C" int ssfm_comm_unique_id(uint8_t id[128]) {
 
 extern "C" int ssfm_comm_init(ssfm_ctx* ctx, const uint8_t id[128], int32_t nranks, int32_t rank) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, SSFM_ERR_INVALID, "ssfm_comm_init: bad arguments");
-    if (nranks == 1) { ctx->nranks = 1; ctx->rank = 0; return SSFM_OK; }
+    // a 1-rank job needs no communicator; SSFM_COMM_SINGLE_RANK=1 creates one anyway so that the RCCL code path can be
+    // exercised on a single GPU (tests)
+    const char* force = std::getenv("SSFM_COMM_SINGLE_RANK");
+    if (nranks == 1 && !(force && force[0] == '1')) { ctx->nranks = 1; ctx->rank = 0; ctx->collective = false; return SSFM_OK; }
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ncclUniqueId u; std::memcpy(&u, id, 128);
     SSFM_NCCL_CHECK(ctx, ncclCommInitRank(&ctx->comm, nranks, u, rank));
-    ctx->nranks = nranks; ctx->rank = rank;
+    ctx->nranks = nranks; ctx->rank = rank; ctx->collective = true;
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_comm_init_host(ssfm_ctx* ctx, int32_t nranks, int32_t rank, ssfm_host_allreduce_fn fn, void* user) {
+    if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, SSFM_ERR_INVALID, "ssfm_comm_init_host: bad arguments");
+    if (ctx->comm) return fail(ctx, SSFM_ERR_INVALID, "ssfm_comm_init_host: an RCCL communicator is already attached");
+    ctx->host_allreduce = fn; ctx->host_allreduce_user = user;
+    ctx->nranks = nranks; ctx->rank = rank; ctx->collective = true;
     return SSFM_OK;
 }

@@ -1,0 +1,37 @@
+"""Worker for tests/test_multirank_gpu.py: one rank of a point-sharded bundle adjustment.
+mode 'host': N ranks share GPU 0, reductions go through the host all-reduce hook (gloo).
+mode 'rccl1': one rank with a forced 1-rank RCCL communicator (SSFM_COMM_SINGLE_RANK=1) - exercises ncclAllReduce on the solver stream."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, out, spherical, focal_fixed = sys.argv[1], sys.argv[2], sys.argv[3] == "1", sys.argv[4] == "1"
+    import torch
+    from spherical_sfm_amd import ba, synth
+    prob = synth.make_circle(60, 6000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
+    ctx = ba.Context(0)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if mode == "host":
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        def hook(arr, op):
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        ctx.comm_init_host(world, rank, hook)
+    elif mode == "rccl1":
+        ctx.comm_init(ba.Context.unique_id(), 1, 0)
+    cams, pts, focal, summ = ba.optimize(ctx, prob)
+    np.savez(out + f".{rank}.npz", cams=cams, pts=pts, focal=focal, iterations=summ["iterations"], final_cost=summ["final_cost"],
+             initial_cost=summ["initial_cost"], termination=summ["termination"])
+    if mode == "host":
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
