@@ -10,7 +10,7 @@
 #include <vector>
 #include "ba_flatten.h"
 #include "ba_kernels.h"
-#include "band_kernels.h"
+#include "band_kernels2.h"
 #include "ssfm_ctx.h"
 
 namespace ssfm {
@@ -171,9 +171,13 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         return SSFM_OK;
     }
     const int ncomp = (int)F.comp_ptr.size() - 1;
-    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB + DC + 2) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
-    const bool use_lds = lds_win <= 140 * 1024 && b * DC <= 256;
-    const int chol_threads = 384;      // wave 0 factors the next diagonal block, 5 waves share the trailing update (measured optimum 384-512)
+    // LDS-resident factorisation (band_kernels2.h): window ring + panel + right-hand-side rows + scratch + pair table
+    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
+    const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
+    const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
+    // wave roles of k_band_chol_v2: 1 look-ahead + trailing-update waves (one block task per lane) + loaders + 1 writer
+    const int tr_tasks = (b * (b + 1) / 2) * ((DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC) + b * DC;
+    const int chol_threads = 64 * (2 + CHOL2_LOADERS + std::min(std::max((tr_tasks + 63) / 64, 1), 7));
     // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
@@ -186,10 +190,16 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
     if (use_lds) {
         if (lds_win > 48 * 1024) {
-            SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_lds<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+            SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         }
-        LAUNCH(h, KID_BAND_CHOL, (k_band_chol_lds<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, h->comp_ptr.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-        LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
+        LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, h->comp_ptr.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+        if (back_v2) {
+            h->span_begin(KID_BAND_BACK);
+            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
+            h->span_end();
+        } else {
+            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
+        }
     } else {
         LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
         LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
@@ -208,7 +218,13 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
         if (use_lds) {
             LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
-            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+            if (back_v2) {
+                h->span_begin(KID_BAND_BACK);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+                h->span_end();
+            } else {
+                LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+            }
         } else {
             LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
             LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);

@@ -1,0 +1,318 @@
+// spherical_sfm_amd -- second-generation block-banded Cholesky kernels (the reduced camera system).
+//
+// The factorisation of a camera ring is a chain of N dependent steps with a few kflop each, so what matters is the number
+// of instructions (and barriers) on the dependent path of one step, not flops:
+//   * the diagonal block is factored by wave 0 with one lane per ROW and v_readlane broadcasts (no LDS round trips, ~125
+//     instructions instead of ~250 on a single lane), and its inverse G = L^-1 follows with one lane per column;
+//   * the panel is a multiplication by G^T (independent 6-term dot products) instead of a forward substitution (a chain);
+//   * the panel lands in its own LDS buffer, which frees the slot of the leaving row at once: the prefetched row is stored
+//     during the same step and a step has TWO barriers (panel | trailing update + look-ahead factorisation);
+//   * only G and the off-diagonal blocks of L are ever stored; nothing downstream needs L_jj itself.
+// The back substitution runs on ONE wave per (component, right-hand side), right-looking: once x_j is known every pending
+// row sum takes its L(j,i)^T x_j term at once, the sums shift by one block row per step through ds_bpermute, and no barrier
+// is needed at all.
+#pragma once
+#include "band_kernels.h"
+
+namespace ssfm {
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {            // src_lane: compile-time constant after unrolling
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_shift_down(double v, int delta) {          // value of lane (l + delta); garbage when out of range
+    const int idx = (int)(((threadIdx.x & 63) + delta) & 63) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(idx, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(idx, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-level factorisation of one DCxDC block.  Lane r (< DC) enters with row r of the SPD block in row[]; on exit lane c
+// holds column c of G = L^-1 in g[] (g[r] = G[r][c], zero above the diagonal).  Returns false if a pivot is not positive.
+template <int DC>
+__device__ __forceinline__ bool wave_chol_inverse(double (&row)[DC], double (&g)[DC]) {
+    const int lane = threadIdx.x & 63;
+    double L[DC], rs[DC]; bool ok = true;
+#pragma unroll
+    for (int c = 0; c < DC; c++) {
+        double d = lane_bcast(row[c], c);
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        rs[c] = fast_rsqrt(d);
+        const double l = row[c] * rs[c];                 // L[r][c] on lane r (meaningful for r >= c)
+        L[c] = l;
+#pragma unroll
+        for (int c2 = c + 1; c2 < DC; c2++) row[c2] -= l * lane_bcast(l, c2);      // a[r][c2] -= L[r][c] L[c2][c]
+    }
+#pragma unroll
+    for (int r = 0; r < DC; r++) {                       // G[r][c] = rs_r ( [r == c] - sum_{k<r} L[r][k] G[k][c] ) on lane c
+        double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++) acc -= lane_bcast(L[k], r) * g[k];
+        g[r] = acc * rs[r];
+    }
+    return ok;
+}
+
+// Right-looking block-band Cholesky with look-ahead, LDS-resident window, one workgroup per connected component.
+//   band  [N][b+1][DC*DC]  in/out: block d of row i = (i, i-d); off-diagonal blocks leave as L, diagonal blocks are left alone
+//   Ginv  [N][DC*DC]       out: L_jj^-1 (row-major, lower)
+//   Y     [NR][N*DC]       in/out: right-hand sides -> L^-1 Y (forward substitution rides along)
+// Wave roles (blockDim.x = 64 * (1 + ntw + CHOL2_LOADERS + 1)):
+//   wave 0                      look-ahead: next diagonal block, its factor and inverse.  No global memory traffic at all.
+//   waves 1..ntw                trailing update of the window + right-hand sides (LDS only)
+//   next CHOL2_LOADERS waves    loaders: together they bring in the row that enters the window, one step ahead; they are the
+//                               only waves that ever wait on vmcnt
+//   last wave                   writer: panel, y_j and G to global memory (stores only, never waited on)
+// Every wave takes its share of the panel product in phase B.
+constexpr int CHOL2_LOADERS = 2;
+template <int DC, int NR>
+__global__ void __launch_bounds__(768)
+k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
+               const int* __restrict__ comp_ptr, int N, int b, int* __restrict__ fail_flag) {
+    constexpr int BB = DC * DC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int R = b + 1, W = b + 1, RW = W * BB;
+    double* sWin = lds;                                     // [R][W][BB] ring of window rows
+    double* sP = sWin + (size_t)R * RW;                     // [b][BB]    panel of the current step = L(j+k, j)
+    double* sYr = sP + (size_t)b * BB;                      // [R][NR][DC] right-hand-side rows of the window
+    double* sYj = sYr + (size_t)R * NR * DC;                // [NR][DC]   final y_j
+    double* sG = sYj + NR * DC;                             // [BB]       inverse factor of the current diagonal block
+    double* sD = sG + BB;                                   // [BB]       scratch: updated next diagonal block
+    int* sPairs = reinterpret_cast<int*>(sD + BB);
+    const int n = N * DC, tid = threadIdx.x, nt = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int ntw = nw - 2 - CHOL2_LOADERS;                 // trailing-update waves
+    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    if (r0 >= r1) return;
+    for (int e = tid; e < b * (b + 1) / 2; e += nt) sPairs[e] = pairs[e];
+    for (int row = r0; row < min(r0 + R, r1); row++) {
+        for (int e = tid; e < RW; e += nt) sWin[(size_t)(row % R) * RW + e] = band[(size_t)row * RW + e];
+        for (int e = tid; e < NR * DC; e += nt) sYr[(size_t)(row % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // factor the first diagonal block
+        double row[DC], g[DC];
+        const double* D0 = sWin + (size_t)(r0 % R) * RW;
+#pragma unroll
+        for (int c = 0; c < DC; c++) row[c] = (lane < DC) ? D0[lane * DC + c] : ((lane == c) ? 1.0 : 0.0);
+        if (!wave_chol_inverse<DC>(row, g) && lane == 0) *fail_flag = 1;
+        if (lane < DC) {
+#pragma unroll
+            for (int r = 0; r < DC; r++) sG[r * DC + lane] = g[r];
+        }
+    }
+    __syncthreads();
+    const int jm0 = r0 % R;
+    const bool is_writer = wave == nw - 1;
+    const int lw = wave - 1 - ntw;                          // loader index, valid when 0 <= lw < CHOL2_LOADERS
+    // ---- phase B, shared by every role: panel X_k = A_k G^T and y_j = G y_j into LDS
+    auto phaseB = [&](int j, int jm, int nb) {
+        for (int e = tid; e < nb * BB; e += nt) {
+            const int k = e / BB, rc = e - k * BB, a = rc / DC, c = rc - a * DC;
+            int sl = jm + 1 + k; if (sl >= R) sl -= R;
+            const double* A = sWin + (size_t)sl * RW + (size_t)(k + 1) * BB + a * DC;
+            const double* Gc = sG + c * DC;
+            double x = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) x += A[m] * Gc[m];
+            sP[e] = x;
+        }
+        if (tid >= nt - 128 && tid < nt - 128 + NR * DC) {
+            const int q = tid - (nt - 128), r = q / DC, c = q - r * DC;
+            const double* yr = sYr + (size_t)jm * NR * DC + r * DC;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) s += sG[c * DC + m] * yr[m];
+            sYj[q] = s;
+        }
+    };
+    // Each role runs its own copy of the step loop (a barrier only counts arrivals), so that no role carries another role's
+    // registers around the back edge: a loop-carried register set that is refreshed by global loads in one branch only
+    // becomes copies at the back edge, and the copies wait for the loads.
+    if (wave == 0) {
+        // ---- look-ahead: next diagonal block, its factor and inverse.  No global memory traffic.
+        int jm = jm0;
+        for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+            const int nb = min(b, r1 - 1 - j);
+            phaseB(j, jm, nb);
+            lds_barrier();
+            if (nb >= 1) {
+                int s1 = jm + 1; if (s1 >= R) s1 -= R;
+                const double* dblk = sWin + (size_t)s1 * RW;                        // block (j+1, j+1)
+                if (lane < BB) {
+                    const int a = lane / DC, c = lane - a * DC;
+                    double v = dblk[lane];
+#pragma unroll
+                    for (int m = 0; m < DC; m++) v -= sP[a * DC + m] * sP[c * DC + m];
+                    sD[lane] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // wave-local LDS round trip
+                double row[DC], g[DC];
+#pragma unroll
+                for (int c = 0; c < DC; c++) row[c] = (lane < DC) ? sD[lane * DC + c] : ((lane == c) ? 1.0 : 0.0);
+                if (!wave_chol_inverse<DC>(row, g) && lane == 0) *fail_flag = 1;
+                if (lane < DC) {
+#pragma unroll
+                    for (int r = 0; r < DC; r++) sG[r * DC + lane] = g[r];
+                }
+            }
+            lds_barrier();
+        }
+    } else if (wave <= ntw) {
+        // ---- trailing update of the window + right-hand sides (LDS only)
+        // block tasks: (pair, row part, column part) -> TR x TR outputs in registers; pair 0 = (1,1) belongs to wave 0
+        constexpr int TR = (DC % 3 == 0) ? 3 : 1, TP = DC / TR, TPB = TP * TP;
+        const int cw = ntw * 64, ct = tid - 64;
+        int jm = jm0;
+        for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+            const int nb = min(b, r1 - 1 - j);
+            phaseB(j, jm, nb);
+            lds_barrier();
+            const int work = (nb * (nb + 1) / 2) * TPB;
+            for (int t = ct + TPB; t < work + nb * DC; t += cw) {
+                if (t < work) {
+                    const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
+                    const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
+                    const double* Li_ = sP + (size_t)(ir - 1) * BB + a0 * DC;
+                    const double* Lk_ = sP + (size_t)(kr - 1) * BB + c0 * DC;
+                    double la[TR][DC], lk[TR][DC];
+#pragma unroll
+                    for (int u = 0; u < TR; u++)
+#pragma unroll
+                        for (int m = 0; m < DC; m++) { la[u][m] = Li_[u * DC + m]; lk[u][m] = Lk_[u * DC + m]; }
+                    int si = jm + ir; if (si >= R) si -= R;
+                    double* dst = sWin + (size_t)si * RW + (size_t)(ir - kr) * BB + a0 * DC + c0;
+#pragma unroll
+                    for (int u = 0; u < TR; u++)
+#pragma unroll
+                        for (int w = 0; w < TR; w++) { double v = 0.0;
+#pragma unroll
+                            for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
+                            dst[u * DC + w] -= v; }
+                } else {                                                          // right-hand sides: y_{j+kr} -= X_kr y_j
+                    const int qq = t - work;
+                    const int kr = qq / DC + 1, a = qq - (kr - 1) * DC;
+                    int sk = jm + kr; if (sk >= R) sk -= R;
+                    const double* Lk_ = sP + (size_t)(kr - 1) * BB + a * DC;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) { double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < DC; m++) v += Lk_[m] * sYj[r * DC + m];
+                        sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
+                }
+            }
+            lds_barrier();
+        }
+    } else if (!is_writer) {
+        // ---- loaders: together they bring in the row that enters the window (RW + NR*DC doubles), one step ahead, in
+        // registers; loads are unconditional from clamped addresses (a select on a loaded value would wait for it at once)
+        constexpr int PRE = 5;                              // covers RW + NR*DC <= 64 * CHOL2_LOADERS * PRE; longer rows take the slow tail
+        const int le0 = lw * 64 + lane;
+        double pre[PRE];
+        auto issue_prefetch = [&](int jn) {
+            const int jc = min(jn, r1 - 1);
+#pragma unroll
+            for (int u = 0; u < PRE; u++) {
+                const int e = le0 + u * 64 * CHOL2_LOADERS;
+                const int q = max(min(e - RW, NR * DC - 1), 0);
+                const double* src = (e < RW) ? band + (size_t)jc * RW + e : Y + (size_t)(q / DC) * n + (size_t)jc * DC + (q % DC);
+                pre[u] = *src;
+            }
+        };
+        issue_prefetch(r0 + R);
+        int jm = jm0;
+        for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+            const int nb = min(b, r1 - 1 - j), jn = j + R;
+            phaseB(j, jm, nb);
+            lds_barrier();
+            // row j's slot is dead (its blocks left as panels of earlier steps): it takes row j + R, loaded during the last step
+            double* rowj = sWin + (size_t)jm * RW;
+            double* yrow = sYr + (size_t)jm * NR * DC;
+#pragma unroll
+            for (int u = 0; u < PRE; u++) { const int e = le0 + u * 64 * CHOL2_LOADERS; if (e < RW) rowj[e] = pre[u]; else if (e < RW + NR * DC) yrow[e - RW] = pre[u]; }
+            if (jn < r1) for (int e = le0 + PRE * 64 * CHOL2_LOADERS; e < RW + NR * DC; e += 64 * CHOL2_LOADERS) {   // rows longer than the register budget
+                if (e < RW) rowj[e] = band[(size_t)jn * RW + e];
+                else { const int q = e - RW; yrow[q] = Y[(size_t)(q / DC) * n + (size_t)jn * DC + (q % DC)]; }
+            }
+            issue_prefetch(jn + 1);
+            lds_barrier();
+        }
+    } else {
+        // ---- writer: panel, y_j and G to global memory (stores only, never waited on)
+        int jm = jm0;
+        for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+            const int nb = min(b, r1 - 1 - j);
+            phaseB(j, jm, nb);
+            if (lane < BB) Ginv[(size_t)j * BB + lane] = sG[lane];                   // before wave 0 replaces it
+            lds_barrier();
+            for (int e = lane; e < nb * BB; e += 64) { const int k = e / BB; band[((size_t)(j + 1 + k) * W + (k + 1)) * BB + (e - k * BB)] = sP[e]; }
+            if (lane < NR * DC) Y[(size_t)(lane / DC) * n + (size_t)j * DC + (lane % DC)] = sYj[lane];
+            lds_barrier();
+        }
+    }
+}
+
+// Back substitution Y <- L^-T Y.  grid (components, NR), ONE wave per block.  Task t = (d-1)*DC + a (d = 1..b) owns the pending
+// sum of row j-(d-1), component a; lanes carry tasks t = lane and t = lane + 64 (b*DC <= 128).  The factor streams from
+// global memory BACK_PD steps ahead (a step is shorter than one memory latency), loads unconditional from clamped addresses.
+constexpr int BACK_PD = 4;
+template <int DC>
+__global__ void __launch_bounds__(64)
+k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ comp_ptr,
+               int N, int b) {
+    constexpr int BB = DC * DC;
+    const int W = b + 1, n = N * DC, lane = threadIdx.x;
+    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    if (r0 >= r1) return;
+    double* y = Y + (size_t)blockIdx.y * n;
+    const int T = b * DC;
+    const int t0 = min(lane, T - 1), t1 = min(lane + 64, T - 1);            // clamped: lanes without a task recompute a valid one and are masked
+    const int d0 = t0 / DC + 1, a0 = t0 - (d0 - 1) * DC, d1 = t1 / DC + 1, a1 = t1 - (d1 - 1) * DC;
+    const bool has0 = lane < T, has1 = lane + 64 < T;
+    const int lc = min(lane, DC - 1);
+    struct Stage { double col0[DC], col1[DC], li[DC], yv; };
+    Stage st[BACK_PD];
+    auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
+        const int jc = max(j, r0);
+#pragma unroll
+        for (int m = 0; m < DC; m++) {
+            s.col0[m] = band[(((size_t)jc) * W + d0) * BB + m * DC + a0];
+            s.col1[m] = band[(((size_t)jc) * W + d1) * BB + m * DC + a1];
+            s.li[m] = Ginv[(size_t)jc * BB + m * DC + lc];                // G[m][lane], zero for m < lane
+        }
+        s.yv = y[(size_t)jc * DC + lc];
+    };
+#pragma unroll
+    for (int u = 0; u < BACK_PD; u++) fetch(r1 - 1 - u, st[u]);
+    double acc0 = 0.0, acc1 = 0.0;         // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
+    for (int jb = r1 - 1; jb >= r0; jb -= BACK_PD) {
+#pragma unroll
+        for (int u = 0; u < BACK_PD; u++) {
+            const int j = jb - u;
+            if (j < r0) break;
+            double c0[DC], c1[DC], cl[DC]; const double cy = st[u].yv;
+            const bool v0 = has0 && j - d0 >= r0, v1 = has1 && j - d1 >= r0;       // rows above the component do not exist
+#pragma unroll
+            for (int m = 0; m < DC; m++) { c0[m] = v0 ? st[u].col0[m] : 0.0; c1[m] = v1 ? st[u].col1[m] : 0.0; cl[m] = st[u].li[m]; }
+            fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
+            // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc0
+            const double z = cy - acc0;                             // lanes 0..DC-1
+            // the shift does not depend on x_j: issue it before the dependent chain
+            const double sh0 = lane_shift_down(acc0, DC), sh1 = lane_shift_down(acc1, DC);
+            double sft0 = (lane + DC < 64) ? sh0 : sh1;             // lanes near the top of set 0 take from the bottom of set 1
+            if (!(lane + DC < T)) sft0 = 0.0;
+            double sft1 = (lane + DC < 64) ? sh1 : 0.0;
+            if (!(lane + 64 + DC < T)) sft1 = 0.0;
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
+            if (lane < DC) y[(size_t)j * DC + lane] = x;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; s1 += c1[m] * xm; }
+            // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
+            acc0 = sft0 + s0; acc1 = sft1 + s1;
+        }
+    }
+}
+
+}  // namespace ssfm
