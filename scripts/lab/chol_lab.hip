@@ -1,5 +1,5 @@
 // Lab bench for the block-banded Cholesky kernels: random SPD block-banded systems shaped like the reduced camera system of
-// BASELINE config 2 (4 rings x 75 cameras, band 12, 6x6 blocks), old vs second-generation kernels, checked against a dense
+// BASELINE config 2 (4 rings x 75 cameras, band 12, 6x6 blocks), second-generation kernels over wave counts, checked against a dense
 // CPU Cholesky.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../spherical_sfm_amd/csrc chol_lab.hip -o chol_lab
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -7,7 +7,6 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-//#define SSFM_CHOL_TIMING 1
 #include "band_kernels2.h"
 using namespace ssfm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -63,12 +62,9 @@ int run(int ncomp, int ncam, int b, int reps) {
         printf("  %-28s max rel err %.3e  fail=%d\n", tag, num / den, fl);
         return num / den;
     };
-    const size_t lds_old = ((size_t)(b + 1) * (b + 1) * BB + (size_t)(b + 1) * 2 * DC + BB + DC + 2) * 8 + ((size_t)b * (b + 1) / 2 + 2) * 4;
-    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * 8;
     const size_t lds_new = ((size_t)(b + 1) * W * BB + (size_t)b * BB + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * 8 + ((size_t)b * (b + 1) / 2 + 2) * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_lds<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
-    printf("DC=%d ncomp=%d ncam=%d b=%d  lds old %zu new %zu\n", DC, ncomp, ncam, b, lds_old, lds_new);
+    printf("DC=%d ncomp=%d ncam=%d b=%d  lds %zu\n", DC, ncomp, ncam, b, lds_new);
     auto bench = [&](const char* tag, auto chol, auto back) {
         float tc = 0, tb = 0;
         for (int it = 0; it < reps + 3; it++) {
@@ -81,29 +77,11 @@ int run(int ncomp, int ncam, int b, int reps) {
         printf("%-24s chol %.1f us   back %.1f us   (per step %.2f / %.2f us)\n", tag, tc / reps * 1e3, tb / reps * 1e3, tc / reps * 1e3 / ncam, tb / reps * 1e3 / ncam);
         check(tag);
     };
-    bench("old (384 thr)", [&] { hipLaunchKernelGGL((k_band_chol_lds<DC, 2>), dim3(ncomp), dim3(384), lds_old, st, dband, dG, dY, dpairs, dcomp, N, b, dfail); },
-          [&] { hipLaunchKernelGGL((k_band_back_lds<DC, 2>), dim3(ncomp), dim3(256), lds_sub2, st, dband, dG, dY, dcomp, N, b); });
-    long long* ddbg; CK(hipMalloc(&ddbg, (size_t)ncam * 16 * 5 * 8)); CK(hipMemset(ddbg, 0, (size_t)ncam * 16 * 5 * 8));
     for (int nw : {6, 8, 9, 10, 12}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
-        bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, N, b, dfail
-#ifdef SSFM_CHOL_TIMING
-            , ddbg
-#endif
-            ); },
+        bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, N, b, dfail); },
               [&] { hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, N, b); });
     }
-#ifdef SSFM_CHOL_TIMING
-    {   // phase stamps of the last configuration (12 waves): steps 30..33 of block 0
-        const int nw = 12; std::vector<long long> dbg((size_t)ncam * nw * 5); CK(hipMemcpy(dbg.data(), ddbg, dbg.size() * 8, hipMemcpyDeviceToHost));
-        const long long t0 = dbg[((size_t)30 * nw + 0) * 5];
-        for (int j = 30; j < 33 && j < ncam; j++) for (int w = 0; w < nw; w++) {
-            printf("   step %d wave %2d:", j, w);
-            for (int k = 0; k < 5; k++) printf(" %7lld", dbg[((size_t)j * nw + w) * 5 + k] - t0);
-            printf("\n");
-        }
-    }
-#endif
     return 0;
 }
 

@@ -36,6 +36,7 @@ struct BAFlat {
     std::vector<int64_t> obs_orig;      // [M] index into the caller's arrays
     std::vector<double> obs_xy;         // [2M]
     std::vector<int> cam_start, cam_obs;   // camera-major lists over local observations
+    std::vector<int> cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;   // point of each camera-major entry; k_cam_sums2 wave tasks (<= 256 entries)
     std::vector<int> row_ptr, col_idx, diag_slot;   // block-CSR structure of S (global), sorted columns
     std::vector<double> mask_cam;       // [Nc*6] 1 = free parameter that is in the problem
     std::vector<double> mask_pt;        // [nP*3]
@@ -54,7 +55,7 @@ struct BAFlat {
     std::vector<int> trans_ptr, trans_blk, trans_row;
     // Schur pair lists (this rank's observations): for row c the entries (j, j2) = (observation of c, observation of the
     // same point by a camera c2 of row c), grouped by slot and padded with -1 to whole 64-lane batches.
-    std::vector<int> pair_j, pair_j2, batch_slot, cam_batch_ptr;
+    std::vector<int> pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr;
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
 };
@@ -212,6 +213,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     F.cam_obs.resize(F.M);
     { std::vector<int> fill(F.cam_start.begin(), F.cam_start.end() - 1);
       for (int64_t j = 0; j < F.M; j++) F.cam_obs[fill[F.obs_cam[j]]++] = (int)j; }
+    F.cam_obs_pt.resize(F.M);
+    for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
+    for (int c = 0; c < Nc; c++)
+        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     F.cam_batch_ptr.assign(Nc + 1, 0);
     std::vector<std::vector<int>> by_slot;      // reused per camera: entries (j, j2) interleaved
@@ -222,7 +227,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             const int j = F.cam_obs[q], p = F.obs_pt[j];
             for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
                 const int c2 = F.obs_cam[j2];
-                if (F.cam_pos[c2] > F.cam_pos[c]) continue;
+                if (F.cam_pos[c2] >= F.cam_pos[c]) continue;          // diagonal blocks are built by k_cam_sums
                 const int slot = (int)(std::lower_bound(F.col_idx.begin() + rb, F.col_idx.begin() + rb + nnb, c2) - (F.col_idx.begin() + rb));
                 by_slot[slot].push_back(j); by_slot[slot].push_back(j2);
             }
@@ -232,7 +237,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             const int ne = (int)by_slot[s2].size() / 2; if (ne == 0) continue;
             const int nb = (ne + 63) / 64;
             for (int b = 0; b < nb; b++) F.batch_slot.push_back(s2);
-            for (int e = 0; e < nb * 64; e++) { F.pair_j.push_back(e < ne ? by_slot[s2][2 * e] : -1); F.pair_j2.push_back(e < ne ? by_slot[s2][2 * e + 1] : -1); }
+            for (int e = 0; e < nb * 64; e++) {
+                F.pair_j.push_back(e < ne ? by_slot[s2][2 * e] : -1); F.pair_j2.push_back(e < ne ? by_slot[s2][2 * e + 1] : -1);
+                F.pair_p.push_back(e < ne ? F.obs_pt[by_slot[s2][2 * e]] : -1);
+            }
             nbatch += nb;
         }
         F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch;

@@ -45,9 +45,9 @@ struct ssfm_ba_handle {
     DevBuf<double> cam_x, cam_c, cam_init, pts_x, pts_c, pts_init, focal3;   // focal3: [x, cand, init]
     DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
-    DevBuf<double> Vinv, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
+    DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
-    DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1;
+    DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0;
     bool scale_ready = false;
@@ -74,9 +74,9 @@ struct ssfm_ba_handle {
         cam_x.free(); cam_c.free(); cam_init.free(); pts_x.free(); pts_c.free(); pts_init.free(); focal3.free();
         rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
-        cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); gp.free(); Wf.free();
+        cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free();
+        trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();

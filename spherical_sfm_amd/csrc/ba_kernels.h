@@ -193,7 +193,7 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
             const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
             int loss, double la, double radius, double min_diag, double max_diag,
-            double* __restrict__ Vinv, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal) {
+            double* __restrict__ Vinv, double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal) {
     __shared__ double red[5 * 4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[5] = {0, 0, 0, 0, 0};   // cost, FJJ, FJR, FWW, FWG
@@ -229,6 +229,14 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
         acc[3] = u0 * wf[0] + u1 * wf[1] + u2 * wf[2];
         acc[4] = u0 * g[0] + u1 * g[1] + u2 * g[2];
         for (int k = 0; k < 6; k++) Vinv[6 * p + k] = Vi[k];
+        // per-point record of the Schur kernels, Jacobi point scales folded in so that they need no scale loads:
+        //   [ diag(s) V^-1 diag(s) (6) | s o (V^-1 g) (3) | s o (V^-1 w_f) (3) ]
+        double* ps = Vs + 12 * (size_t)p;
+        ps[0] = Vi[0] * sp[0] * sp[0]; ps[1] = Vi[1] * sp[0] * sp[1]; ps[2] = Vi[2] * sp[0] * sp[2];
+        ps[3] = Vi[3] * sp[1] * sp[1]; ps[4] = Vi[4] * sp[1] * sp[2]; ps[5] = Vi[5] * sp[2] * sp[2];
+        ps[6] = sp[0] * (Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2]); ps[7] = sp[1] * (Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2]);
+        ps[8] = sp[2] * (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
+        ps[9] = sp[0] * u0; ps[10] = sp[1] * u1; ps[11] = sp[2] * u2;
         for (int k = 0; k < 3; k++) { gp[3 * p + k] = g[k]; Wf[3 * p + k] = wf[k]; }
     }
     block_sum<5>(acc, red);
@@ -240,272 +248,179 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
     }
 }
 
-// ---- K2: Schur rows.  One workgroup per camera, its block row of S accumulated in LDS ----------------
-//   S[c,c'] = delta(c,c') U_c - sum_{p seen by c and c'} (W_cp V_p^-1) W_c'p^T,   W = Jc^T Jp
-//   rhs_c   = Jc^T r - sum_p (W_cp V_p^-1) g_p ;  focal border row S_fc likewise.
-// Lanes walk the camera's observations (sorted by point); each lane re-linearises the point's other
-// observations and adds the DCxDC products into the LDS row with ds_add_f64.  The neighbour loop starts at
-// a lane-dependent offset so that the lanes of a wave hit different blocks of the row at the same time.
+// ---- camera-side sums, second generation: diagonal blocks of the reduced system, right-hand side, focal border ---------
+// One WAVE per task = a run of <= 4 batches (64 observations each) of one camera's observation list; no LDS, no barriers,
+// gathers of batch i+1 in flight during batch i, per-point record PS = [diag(s) V^-1 diag(s) | s o V^-1 g | s o V^-1 w_f].
+//   S[c,c]  += sum_j Jc^T Jc - W PS_V W^T        (W = Jc^T Jp, unscaled on the point side)
+//   rhs_c   += sum_j Jc^T r - W PS_g ;  S_fc += sum_j Jc^T J_f - W PS_w ;  diag U (for the LM diagonal) and Jc^T r on their own
+// Everything is accumulated with atomics into buffers zeroed once per pass.
 template <int DC>
-__global__ void __launch_bounds__(256)
-k_schur_rows(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
-             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
-             const int* __restrict__ obs_pt, const int* __restrict__ pt_start, const int* __restrict__ cam_start,
-             const int* __restrict__ cam_obs, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
-             const int* __restrict__ diag_slot, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
-             const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
-             const double* __restrict__ Wf, int loss, double la, int ncopy,
-             double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
-             double* __restrict__ gcraw) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__global__ void __launch_bounds__(256, 2)
+k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+            const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ cam_obs,
+            const int* __restrict__ cam_obs_pt, const int* __restrict__ task_cam, const int* __restrict__ task_q0,
+            const int* __restrict__ task_q1, int ntasks, const int* __restrict__ row_ptr, const int* __restrict__ diag_slot,
+            const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ PS, int loss, double la,
+            double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
+            double* __restrict__ gcraw) {
     constexpr int BB = DC * DC;
     constexpr int NU = DC * (DC + 1) / 2;
-    constexpr int NSM = NU + 3 * DC;            // U (upper), gc, rs, sfc
-    const int c = blockIdx.x;
-    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    // ncopy private copies of [block row | camera-side sums]: lanes are spread over copies (and over the point's
-    // cameras) so that the lanes of a wave rarely add to the same LDS word in the same instruction
-    const int RS = nnb * BB + NSM + 1;          // doubles per copy (+1: odd stride de-phases the banks)
-    double* camc = lds + (size_t)ncopy * RS;    // [6 + 27 + 6] camera c: t,r | rot | scale
-    for (int i = threadIdx.x; i < ncopy * RS; i += blockDim.x) lds[i] = 0.0;
-    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
-    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
-    __syncthreads();
-    double* acc = lds + (size_t)(threadIdx.x % ncopy) * RS;     // this lane's copy
-    double* small = acc + nnb * BB;
-    const int* cols = col_idx + rb;
-    const double f = focal[0], sf = scale_f[0];
-
-    for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
-        const int j = cam_obs[q], p = obs_pt[j];
-        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
-        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
-        const double2 o = obs_xy[j];
-        double T[DC][3];
-        {
-            ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
-            double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
-            double Jp[2][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { Jp[0][k] = L.Jp[0][k] * sp[k]; Jp[1][k] = L.Jp[1][k] * sp[k]; }
-            const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
-            const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
-            const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
-            const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
-            int u = 0;
-#pragma unroll
-            for (int a = 0; a < DC; a++) {
-                const double w0 = Jc[0][a] * Jp[0][0] + Jc[1][a] * Jp[1][0];
-                const double w1 = Jc[0][a] * Jp[0][1] + Jc[1][a] * Jp[1][1];
-                const double w2 = Jc[0][a] * Jp[0][2] + Jc[1][a] * Jp[1][2];
-                T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-                T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-                T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-                unsafeAtomicAdd(&small[NU + a], Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1]);
-                unsafeAtomicAdd(&small[NU + DC + a], -(T[a][0] * g[0] + T[a][1] * g[1] + T[a][2] * g[2]));
-                unsafeAtomicAdd(&small[NU + 2 * DC + a], jf0 * Jc[0][a] + jf1 * Jc[1][a] - (T[a][0] * wf[0] + T[a][1] * wf[1] + T[a][2] * wf[2]));
-#pragma unroll
-                for (int b = a; b < DC; b++) unsafeAtomicAdd(&small[u++], Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b]);
-            }
-        }
-        const int j0 = pt_start[p], K = pt_start[p + 1] - j0;
-        int kk = (threadIdx.x / ncopy) % K;       // stagger: lanes sharing a copy start on different cameras of the point
-        for (int it = 0; it < K; it++) {
-            const int j2 = j0 + kk; kk = (kk + 1 == K) ? 0 : kk + 1;
-            const int c2 = obs_cam[j2]; const double2 o2 = obs_xy[j2];
-            ObsLin L2; lin_obs<DC == 6>(f, cam + 6 * c2, rot + 27 * c2, X, o2.x, o2.y, loss, la, L2);
-            double Jc2[2][DC]; cam_block<DC>(L2, scale_cam + 6 * c2, Jc2);
-            int lo = 0, hi = nnb - 1;             // slot of c2 in this row (c2 is always present)
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cols[mid] < c2) lo = mid + 1; else hi = mid; }
-            double* blk = acc + lo * BB;
-#pragma unroll
-            for (int b = 0; b < DC; b++) {
-                const double w0 = (Jc2[0][b] * L2.Jp[0][0] + Jc2[1][b] * L2.Jp[1][0]) * sp[0];
-                const double w1 = (Jc2[0][b] * L2.Jp[0][1] + Jc2[1][b] * L2.Jp[1][1]) * sp[1];
-                const double w2 = (Jc2[0][b] * L2.Jp[0][2] + Jc2[1][b] * L2.Jp[1][2]) * sp[2];
-#pragma unroll
-                for (int a = 0; a < DC; a++) unsafeAtomicAdd(&blk[a * DC + b], -(T[a][0] * w0 + T[a][1] * w1 + T[a][2] * w2));
-            }
-        }
-    }
-    __syncthreads();
-    // fold the copies and write the row: coalesced, U_c folded into the diagonal block
-    const int ds = diag_slot[c];
-    for (int i = threadIdx.x; i < nnb * BB + NSM; i += blockDim.x) {
-        double v = 0.0;
-        for (int k = 0; k < ncopy; k++) v += lds[(size_t)k * RS + i];
-        lds[i] = v;
-    }
-    __syncthreads();
-    const double* sm = lds + nnb * BB;
-    for (int i = threadIdx.x; i < nnb * BB; i += blockDim.x) {
-        double v = lds[i];
-        const int s = i / BB, e = i - s * BB;
-        if (s == ds) { int a = e / DC, b = e - a * DC; if (a > b) { const int t = a; a = b; b = t; } v += sm[a * DC - a * (a - 1) / 2 + (b - a)]; }
-        S_val[(size_t)rb * BB + i] = v;
-    }
-    if (threadIdx.x < DC) {
-        const int a = threadIdx.x;
-        rhs[c * DC + a] = sm[NU + a] + sm[NU + DC + a];
-        gcraw[c * DC + a] = sm[NU + a];
-        Sfc[c * DC + a] = sm[NU + 2 * DC + a];
-        Udiag[c * DC + a] = sm[a * DC - a * (a - 1) / 2];
-    }
-}
-
-// ---- K2 (pair-list form): Schur complement without contended atomics -------------------------------------------
-// The host groups, for every row camera c, the (observation of c, observation of the same point by a row camera c2) pairs
-// by slot, pads each slot to whole 64-lane batches and cuts every camera's batch list into chunks of <= 16 batches
-// (ba_flatten.h) -- one workgroup per chunk, so that rows with 1 and with 11 neighbours load the chip evenly.  A wave
-// walks consecutive batches; a lane re-linearises its two observations and accumulates T_cp W_c2p^T into a private DCxDC
-// block; when the slot changes the wave folds its 64 private blocks with shuffles and adds the result to the chunk's
-// LDS row once; at the end the touched slots are added to S in global memory (a few hundred atomics per workgroup).
-// Only the lower triangle (in elimination order) is built.  k_cam_sums runs first and stores U_c into the diagonal blocks.
-template <int DC>
-__global__ void __launch_bounds__(256)
-k_cam_sums(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
-           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
-           const int* __restrict__ cam_start, const int* __restrict__ cam_obs, const int* __restrict__ row_ptr,
-           const int* __restrict__ diag_slot, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
-           const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
-           const double* __restrict__ Wf, int loss, double la, double* __restrict__ S_val, double* __restrict__ rhs,
-           double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw) {
-    constexpr int BB = DC * DC;
-    constexpr int NU = DC * (DC + 1) / 2;
-    constexpr int NSM = NU + 3 * DC;
-    __shared__ double red[NSM * 4];
-    __shared__ double camc[40];
-    const int c = blockIdx.x;
-    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
-    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
-    __syncthreads();
+    constexpr int NSM = NU + 4 * DC;           // [S_cc (upper) | Jc^T r | -W g' | focal coupling | diag U]   (<= 64 for DC <= 6)
+    const int lane = threadIdx.x & 63;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (task >= ntasks) return;
+    const int c = __builtin_amdgcn_readfirstlane(task_cam[task]);
+    const int q0 = __builtin_amdgcn_readfirstlane(task_q0[task]), q1 = __builtin_amdgcn_readfirstlane(task_q1[task]);
     const double f = focal[0], sf = scale_f[0];
     double sm[NSM];
 #pragma unroll
     for (int i = 0; i < NSM; i++) sm[i] = 0.0;
-    for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
-        const int j = cam_obs[q], p = obs_pt[j];
-        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
-        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
-        const double2 o = obs_xy[j];
-        ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
-        double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
-        const double jf0 = L.Jf[0] * sf, jf1 = L.Jf[1] * sf;
-        const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
-        const double g[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
-        const double wf[3] = {Wf[3 * p], Wf[3 * p + 1], Wf[3 * p + 2]};
-        int u = 0;
-#pragma unroll
-        for (int a = 0; a < DC; a++) {
-            const double w0 = (Jc[0][a] * L.Jp[0][0] + Jc[1][a] * L.Jp[1][0]) * sp[0];
-            const double w1 = (Jc[0][a] * L.Jp[0][1] + Jc[1][a] * L.Jp[1][1]) * sp[1];
-            const double w2 = (Jc[0][a] * L.Jp[0][2] + Jc[1][a] * L.Jp[1][2]) * sp[2];
-            const double t0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2], t1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4], t2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-            sm[NU + a] += Jc[0][a] * L.r[0] + Jc[1][a] * L.r[1];
-            sm[NU + DC + a] -= t0 * g[0] + t1 * g[1] + t2 * g[2];
-            sm[NU + 2 * DC + a] += jf0 * Jc[0][a] + jf1 * Jc[1][a] - (t0 * wf[0] + t1 * wf[1] + t2 * wf[2]);
-#pragma unroll
-            for (int b = a; b < DC; b++) sm[u++] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
-        }
+#define CS2_LOAD(qb_, X_, P_, o_, wgt_)                                                                               \
+    do {                                                                                                              \
+        const int q_ = (qb_) + lane;                                                                                  \
+        wgt_ = (q_ < q1) ? 1.0 : 0.0;                                                                                 \
+        const int qc_ = min(q_, q1 - 1);                                                                              \
+        const int j_ = cam_obs[qc_], p_ = cam_obs_pt[qc_];                                                            \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) X_[k] = pts[3 * (size_t)p_ + k];                                \
+        _Pragma("unroll") for (int k = 0; k < 12; k++) P_[k] = PS[12 * (size_t)p_ + k];                               \
+        o_ = obs_xy[j_];                                                                                              \
+    } while (0)
+#define CS2_COMPUTE(X_, P_, o_, wgt_)                                                                                 \
+    do {                                                                                                              \
+        ObsLin L_; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X_, o_.x, o_.y, loss, la, L_);                      \
+        double Jc_[2][DC]; cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                                 \
+        const double jf0 = L_.Jf[0] * sf, jf1 = L_.Jf[1] * sf;                                                        \
+        double Wm[DC][3];                                                                                             \
+        _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                              \
+            Jc_[0][a] *= wgt_; Jc_[1][a] *= wgt_;                                                                     \
+            Wm[a][0] = Jc_[0][a] * L_.Jp[0][0] + Jc_[1][a] * L_.Jp[1][0];                                             \
+            Wm[a][1] = Jc_[0][a] * L_.Jp[0][1] + Jc_[1][a] * L_.Jp[1][1];                                             \
+            Wm[a][2] = Jc_[0][a] * L_.Jp[0][2] + Jc_[1][a] * L_.Jp[1][2];                                             \
+        }                                                                                                             \
+        int u = 0;                                                                                                    \
+        _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                              \
+            const double w0 = Wm[a][0], w1 = Wm[a][1], w2 = Wm[a][2];                                                 \
+            const double t0 = w0 * P_[0] + w1 * P_[1] + w2 * P_[2], t1 = w0 * P_[1] + w1 * P_[3] + w2 * P_[4],        \
+                         t2 = w0 * P_[2] + w1 * P_[4] + w2 * P_[5];                                                   \
+            sm[NU + a] += Jc_[0][a] * L_.r[0] + Jc_[1][a] * L_.r[1];                                                  \
+            sm[NU + DC + a] -= w0 * P_[6] + w1 * P_[7] + w2 * P_[8];                                                  \
+            sm[NU + 2 * DC + a] += jf0 * Jc_[0][a] + jf1 * Jc_[1][a] - (w0 * P_[9] + w1 * P_[10] + w2 * P_[11]);      \
+            sm[NU + 3 * DC + a] += Jc_[0][a] * Jc_[0][a] + Jc_[1][a] * Jc_[1][a];                                     \
+            _Pragma("unroll") for (int b = a; b < DC; b++)                                                            \
+                sm[u++] += Jc_[0][a] * Jc_[0][b] + Jc_[1][a] * Jc_[1][b] - (t0 * Wm[b][0] + t1 * Wm[b][1] + t2 * Wm[b][2]); \
+        }                                                                                                             \
+    } while (0)
+    double Xa[3], Pa[12], wa; double2 oa;
+    double Xb[3], Pb[12], wb; double2 ob;
+    CS2_LOAD(q0, Xa, Pa, oa, wa);
+    for (int qb = q0; qb < q1; qb += 128) {
+        CS2_LOAD(qb + 64, Xb, Pb, ob, wb);
+        CS2_COMPUTE(Xa, Pa, oa, wa);
+        CS2_LOAD(qb + 128, Xa, Pa, oa, wa);
+        if (qb + 64 < q1) CS2_COMPUTE(Xb, Pb, ob, wb);
     }
-    block_sum<NSM>(sm, red);
-    if (threadIdx.x == 0) {
-        double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;       // S was zeroed: store U_c (both triangles)
-        int u = 0;
-        for (int a = 0; a < DC; a++) for (int b = a; b < DC; b++) { blk[a * DC + b] = sm[u]; blk[b * DC + a] = sm[u]; u++; }
-        for (int a = 0; a < DC; a++) {
-            rhs[c * DC + a] = sm[NU + a] + sm[NU + DC + a]; gcraw[c * DC + a] = sm[NU + a]; Sfc[c * DC + a] = sm[NU + 2 * DC + a];
-            Udiag[c * DC + a] = sm[a * DC - a * (a - 1) / 2];
-        }
-    }
+#undef CS2_LOAD
+#undef CS2_COMPUTE
+    // fold: value i ends up in lane i, which owns its destination(s)
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSM; i++) { const double v = wave_sum(sm[i]); if (lane == i) mine = v; }
+    if (lane < NU) {
+        int a = 0, rem = lane; while (rem >= DC - a) { rem -= DC - a; a++; }
+        const int b = a + rem;
+        double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;
+        unsafeAtomicAdd(&blk[a * DC + b], mine); if (b != a) unsafeAtomicAdd(&blk[b * DC + a], mine);
+    } else if (lane < NU + DC) { const int a = lane - NU; unsafeAtomicAdd(&rhs[c * DC + a], mine); unsafeAtomicAdd(&gcraw[c * DC + a], mine); }
+    else if (lane < NU + 2 * DC) unsafeAtomicAdd(&rhs[c * DC + lane - NU - DC], mine);
+    else if (lane < NU + 3 * DC) unsafeAtomicAdd(&Sfc[c * DC + lane - NU - 2 * DC], mine);
+    else if (lane < NSM) unsafeAtomicAdd(&Udiag[c * DC + lane - NU - 3 * DC], mine);
 }
 
+// ---- Schur complement from the slot-sorted pair lists, second generation ------------------------------------------
+// One WAVE per task = a run of <= 16 batches (64 pairs each) of one camera row; no LDS, no barriers.  The gathers of batch
+// bt+1 are issued before the arithmetic of batch bt (two register sets, loop unrolled by two so that neither set is copied at
+// the back edge), loads are unconditional from clamped indices (padding lanes carry a zero weight), the point index rides in
+// the pair list (one dependent load less) and the Jacobi point scales are pre-folded into Vs.  Blocks are folded across the
+// wave at every slot change and added to S with global atomics (a few dozen per task).
 template <int DC>
-__global__ void __launch_bounds__(256, (DC == 3) ? 3 : 2)     // DC = 6 spills at 3 waves/SIMD (measured slower)
-k_schur_pairs(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
-              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
-              const int* __restrict__ obs_pt, const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ chunk_cam,
-              const int* __restrict__ chunk_b0, const int* __restrict__ chunk_b1, const int* __restrict__ batch_slot,
-              const int* __restrict__ pair_j, const int* __restrict__ pair_j2, const double* __restrict__ scale_cam,
-              const double* __restrict__ scale_pt, const double* __restrict__ Vinv, int loss, double la, double* __restrict__ S_val) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__global__ void __launch_bounds__(256, 2)
+k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+               const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ row_ptr,
+               const int* __restrict__ col_idx, const int* __restrict__ task_cam, const int* __restrict__ task_b0,
+               const int* __restrict__ task_b1, int ntasks, const int* __restrict__ batch_slot, const int* __restrict__ pair_j,
+               const int* __restrict__ pair_j2, const int* __restrict__ pair_p, const double* __restrict__ scale_cam,
+               const double* __restrict__ Vs, int loss, double la, double* __restrict__ S_val) {
     constexpr int BB = DC * DC;
-    const int c = chunk_cam[blockIdx.x];
-    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    const int b0 = chunk_b0[blockIdx.x], b1 = chunk_b1[blockIdx.x];
-    const int s_lo = batch_slot[b0], s_hi = batch_slot[b1 - 1];     // slots of a chunk are a contiguous, ascending range
-    double* acc = lds;                         // [(s_hi - s_lo + 1) * BB] -- at most nnb blocks
-    double* camc = lds + nnb * BB;             // [6 + 27 + 6]
-    for (int i = threadIdx.x; i < (s_hi - s_lo + 1) * BB; i += blockDim.x) acc[i] = 0.0;
-    if (threadIdx.x < 6) { camc[threadIdx.x] = cam[c * 6 + threadIdx.x]; camc[33 + threadIdx.x] = scale_cam[c * 6 + threadIdx.x]; }
-    if (threadIdx.x < 27) camc[6 + threadIdx.x] = rot[c * 27 + threadIdx.x];
-    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (task >= ntasks) return;
+    const int c = __builtin_amdgcn_readfirstlane(task_cam[task]);
+    const int b0 = __builtin_amdgcn_readfirstlane(task_b0[task]), b1 = __builtin_amdgcn_readfirstlane(task_b1[task]);
+    const int rb = __builtin_amdgcn_readfirstlane(row_ptr[c]);
     const double f = focal[0];
-    // wave index as a scalar: everything derived from it (batch range, slot, neighbour camera c2) is then wave-uniform for the
-    // compiler, and camera c2's 39 constants come in through scalar loads instead of 39 vector gathers per lane
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    {
-        const int nbt = b1 - b0, per = (nbt + nw - 1) / nw;
-        const int bs = b0 + w * per, be = min(b1, bs + per);
-        double blk[DC][DC];
+    // two register sets, spelled out as plain locals (a struct handed to lambdas by reference ends up in scratch memory)
+#define SP2_LOAD(bt_, X_, V_, o_, o2_, wgt_)                                                                         \
+    do {                                                                                                              \
+        const size_t e_ = (size_t)(bt_) * 64 + lane;                                                                  \
+        const int j_ = pair_j[e_], j2_ = pair_j2[e_], p_ = pair_p[e_];                                                \
+        const int jc_ = max(j_, 0), j2c_ = max(j2_, 0), pc_ = max(p_, 0);                                             \
+        wgt_ = (j_ >= 0) ? 1.0 : 0.0;                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) X_[k] = pts[3 * (size_t)pc_ + k];                               \
+        _Pragma("unroll") for (int k = 0; k < 6; k++) V_[k] = Vs[12 * (size_t)pc_ + k];                               \
+        o_ = obs_xy[jc_]; o2_ = obs_xy[j2c_];                                                                         \
+    } while (0)
+    double blk[DC][DC];
+#pragma unroll
+    for (int a = 0; a < DC; a++)
+#pragma unroll
+        for (int b = 0; b < DC; b++) blk[a][b] = 0.0;
+    int cur = -1;
+    auto fold = [&]() {                                    // wave-uniform: add the finished block to S
+        double* dst = S_val + ((size_t)rb + cur) * BB;
 #pragma unroll
         for (int a = 0; a < DC; a++)
 #pragma unroll
-            for (int b = 0; b < DC; b++) blk[a][b] = 0.0;
-        int cur = -1;
-        for (int bt = bs; bt <= be; bt++) {
-            const int slot = (bt < be) ? batch_slot[bt] : -2;
-            if (slot != cur) {
-                if (cur >= 0) {
-                    double* dst = acc + (cur - s_lo) * BB;
-#pragma unroll
-                    for (int a = 0; a < DC; a++)
-#pragma unroll
-                        for (int b = 0; b < DC; b++) { const double v = wave_sum(blk[a][b]); if (lane == 0) unsafeAtomicAdd(&dst[a * DC + b], v); blk[a][b] = 0.0; }
-                }
-                cur = slot;
-            }
-            if (bt >= be) break;
-            const int j = pair_j[(size_t)bt * 64 + lane];
-            if (j < 0) continue;
-            const int j2 = pair_j2[(size_t)bt * 64 + lane];
-            const int p = obs_pt[j];
-            const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
-            const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
-            double T[DC][3];
-            {
-                const double2 o = obs_xy[j];
-                ObsLin L; lin_obs<DC == 6>(f, camc, camc + 6, X, o.x, o.y, loss, la, L);
-                double Jc[2][DC]; cam_block<DC>(L, camc + 33, Jc);
-                const double Vi[6] = {Vinv[6 * p], Vinv[6 * p + 1], Vinv[6 * p + 2], Vinv[6 * p + 3], Vinv[6 * p + 4], Vinv[6 * p + 5]};
-#pragma unroll
-                for (int a = 0; a < DC; a++) {
-                    const double w0 = (Jc[0][a] * L.Jp[0][0] + Jc[1][a] * L.Jp[1][0]) * sp[0];
-                    const double w1 = (Jc[0][a] * L.Jp[0][1] + Jc[1][a] * L.Jp[1][1]) * sp[1];
-                    const double w2 = (Jc[0][a] * L.Jp[0][2] + Jc[1][a] * L.Jp[1][2]) * sp[2];
-                    T[a][0] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-                    T[a][1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-                    T[a][2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-                }
-            }
-            const int c2 = col_idx[rb + slot]; const double2 o2 = obs_xy[j2];
-            ObsLin L2; lin_obs<DC == 6>(f, cam + 6 * c2, rot + 27 * c2, X, o2.x, o2.y, loss, la, L2);
-            double Jc2[2][DC]; cam_block<DC>(L2, scale_cam + 6 * c2, Jc2);
-#pragma unroll
-            for (int b = 0; b < DC; b++) {
-                const double w0 = (Jc2[0][b] * L2.Jp[0][0] + Jc2[1][b] * L2.Jp[1][0]) * sp[0];
-                const double w1 = (Jc2[0][b] * L2.Jp[0][1] + Jc2[1][b] * L2.Jp[1][1]) * sp[1];
-                const double w2 = (Jc2[0][b] * L2.Jp[0][2] + Jc2[1][b] * L2.Jp[1][2]) * sp[2];
-#pragma unroll
-                for (int a = 0; a < DC; a++) blk[a][b] -= T[a][0] * w0 + T[a][1] * w1 + T[a][2] * w2;
-            }
-        }
+            for (int b = 0; b < DC; b++) { const double v = wave_sum(blk[a][b]); if (lane == a * DC + b) unsafeAtomicAdd(&dst[a * DC + b], v); blk[a][b] = 0.0; }
+    };
+#define SP2_COMPUTE(bt_, X_, V_, o_, o2_, wgt_)                                                                       \
+    do {                                                                                                              \
+        const int slot_ = __builtin_amdgcn_readfirstlane(batch_slot[bt_]);                                            \
+        if (slot_ != cur) { if (cur >= 0) fold(); cur = slot_; }                                                      \
+        const int c2_ = __builtin_amdgcn_readfirstlane(col_idx[rb + slot_]);                                          \
+        double T_[DC][3];                                                                                             \
+        {                                                                                                             \
+            ObsLin L_; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X_, o_.x, o_.y, loss, la, L_);                  \
+            double Jc_[2][DC]; cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                             \
+            _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                          \
+                const double w0 = (Jc_[0][a] * L_.Jp[0][0] + Jc_[1][a] * L_.Jp[1][0]) * wgt_;                         \
+                const double w1 = (Jc_[0][a] * L_.Jp[0][1] + Jc_[1][a] * L_.Jp[1][1]) * wgt_;                         \
+                const double w2 = (Jc_[0][a] * L_.Jp[0][2] + Jc_[1][a] * L_.Jp[1][2]) * wgt_;                         \
+                T_[a][0] = w0 * V_[0] + w1 * V_[1] + w2 * V_[2];                                                      \
+                T_[a][1] = w0 * V_[1] + w1 * V_[3] + w2 * V_[4];                                                      \
+                T_[a][2] = w0 * V_[2] + w1 * V_[4] + w2 * V_[5];                                                      \
+            }                                                                                                         \
+        }                                                                                                             \
+        ObsLin L2_; lin_obs<DC == 6>(f, cam + 6 * c2_, rot + 27 * c2_, X_, o2_.x, o2_.y, loss, la, L2_);              \
+        double Jc2_[2][DC]; cam_block<DC>(L2_, scale_cam + 6 * c2_, Jc2_);                                            \
+        _Pragma("unroll") for (int b = 0; b < DC; b++) {                                                              \
+            const double w0 = Jc2_[0][b] * L2_.Jp[0][0] + Jc2_[1][b] * L2_.Jp[1][0];                                  \
+            const double w1 = Jc2_[0][b] * L2_.Jp[0][1] + Jc2_[1][b] * L2_.Jp[1][1];                                  \
+            const double w2 = Jc2_[0][b] * L2_.Jp[0][2] + Jc2_[1][b] * L2_.Jp[1][2];                                  \
+            _Pragma("unroll") for (int a = 0; a < DC; a++) blk[a][b] -= T_[a][0] * w0 + T_[a][1] * w1 + T_[a][2] * w2; \
+        }                                                                                                             \
+    } while (0)
+    double Xa[3], Va[6], wa; double2 oa, o2a;
+    double Xb[3], Vb[6], wb; double2 ob, o2b;
+    SP2_LOAD(b0, Xa, Va, oa, o2a, wa);
+    for (int bt = b0; bt < b1; bt += 2) {
+        SP2_LOAD(min(bt + 1, b1 - 1), Xb, Vb, ob, o2b, wb);
+        SP2_COMPUTE(bt, Xa, Va, oa, o2a, wa);
+        SP2_LOAD(min(bt + 2, b1 - 1), Xa, Va, oa, o2a, wa);
+        if (bt + 1 < b1) SP2_COMPUTE(bt + 1, Xb, Vb, ob, o2b, wb);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (s_hi - s_lo + 1) * BB; i += blockDim.x) {
-        const double v = acc[i];
-        if (v != 0.0) unsafeAtomicAdd(&S_val[((size_t)rb + s_lo) * BB + i], v);
-    }
+#undef SP2_LOAD
+#undef SP2_COMPUTE
+    if (cur >= 0) fold();
 }
 
 // symmetric mat-vec with only the lower triangle stored: q_c = sum_{s in row c} S_s p_col(s) + sum_{t in trans(c)} S_t^T p_row(t)

@@ -37,11 +37,6 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
     // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
-    const size_t lds_bytes = ((size_t)F.max_row_blocks * BB + 48) * sizeof(double);
-    if (lds_bytes > 160 * 1024) return fail(ctx, SSFM_ERR_INVALID, "reduced-system block row does not fit in LDS");
-    if (lds_bytes > 48 * 1024)
-        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_pairs<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-
     double host_scal[SC_TOTAL];
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
@@ -87,15 +82,20 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0)
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
-                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->gp.p, h->Wf.p, h->scal.p);
+                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->S_val, 0, (size_t)F.row_ptr[Nc] * BB * sizeof(double), st));
-        LAUNCH(h, KID_CAM_SUMS, k_cam_sums<DC>, Nc, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p, h->row_ptr.p,
-               h->diag_slot.p, h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->Wf.p, loss, la, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw);
-        if (!F.chunk_cam.empty())
-            LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs<DC>, (int)F.chunk_cam.size(), 256, lds_bytes, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->obs_pt.p,
-                   h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, h->scale_pt.p,
-                   h->Vinv.p, loss, la, h->S_val);
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, (size_t)h->n_red * sizeof(double), st));      // [S | rhs | diag U | S_fc | Jc^T r | sums]: all accumulated
+        if (!F.cs_task_cam.empty()) {
+            const int ntasks = (int)F.cs_task_cam.size();
+            LAUNCH(h, KID_CAM_SUMS, k_cam_sums2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->cam_obs.p, h->cam_obs_pt.p, h->cs_task_cam.p,
+                   h->cs_task_q0.p, h->cs_task_q1.p, ntasks, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, h->S_val, h->rhs,
+                   h->Udiag, h->Sfc, h->gcraw);
+        }
+        if (!F.chunk_cam.empty()) {
+            const int ntasks = (int)F.chunk_cam.size();
+            LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
+                   h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
+        }
         if (ctx->collective) {
             // scalar sums ride at the tail of the same buffer
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -250,13 +250,13 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     UP(cam_x, cams); UP(cam_init, cams); UP(pts_x, F.pts0); UP(pts_init, F.pts0); UP(focal3, f3);
     UP(mask_cam, F.mask_cam); UP(mask_pt, F.mask_pt); UP(mask_f, maskf);
     UP(obs_xy, F.obs_xy); UP(obs_cam, F.obs_cam); UP(obs_pt, F.obs_pt); UP(pt_start, F.pt_start);
-    UP(cam_start, F.cam_start); UP(cam_obs, F.cam_obs); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
+    UP(cam_start, F.cam_start); UP(cam_obs, F.cam_obs); UP(cam_obs_pt, F.cam_obs_pt); UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
 #undef UP
 #define AL(buf, count) SSFM_HIP_CHECK(ctx, h->buf.alloc(count))
     AL(cam_c, (size_t)Nc * 6); AL(pts_c, (size_t)nP * 3); AL(rot_x, (size_t)Nc * 27); AL(rot_c, (size_t)Nc * 27);
     AL(scale_cam, (size_t)Nc * 6); AL(scale_pt, (size_t)nP * 3); AL(scale_f, 1);
     AL(diag_cam, (size_t)Nc * 6); AL(diag_pt, (size_t)nP * 3); AL(diag_f, 1);
-    AL(Vinv, (size_t)nP * 6); AL(gp, (size_t)nP * 3); AL(Wf, (size_t)nP * 3);
+    AL(Vinv, (size_t)nP * 6); AL(Vs, (size_t)nP * 12); AL(gp, (size_t)nP * 3); AL(Wf, (size_t)nP * 3);
     const size_t nnzb = (size_t)F.row_ptr[Nc], n = (size_t)Nc * DC;
     const size_t n_red = nnzb * DC * DC + (n + 1) + 3 * n + SC_NSUM;
     h->n_red = (int)n_red;
@@ -272,7 +272,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
     SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st));
-    SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
+    SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
     SSFM_HIP_CHECK(ctx, upload(h->cam_batch_ptr, F.cam_batch_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_cam, F.chunk_cam, st));
     SSFM_HIP_CHECK(ctx, upload(h->chunk_b0, F.chunk_b0, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_b1, F.chunk_b1, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));

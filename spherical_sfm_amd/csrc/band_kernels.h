@@ -343,185 +343,11 @@ k_ref_step(const double* __restrict__ Sfc, const double* __restrict__ Sff, int N
 }  // namespace ssfm
 
 // =====================================================================================================
-// LDS-resident variants.  The live part of a banded right-looking factorisation is rows j..j+b; with
-// (b+1)^2 DCxDC blocks <= ~140 KB it fits the CU's LDS, so a step never waits on L2.  One workgroup per
-// connected component of the camera graph (comp_ptr: contiguous position ranges from the Cuthill-McKee pass).
+// Substitution kernels for factors produced by k_band_chol_v2 (band_kernels2.h): one workgroup per connected component of
+// the camera graph (comp_ptr: contiguous position ranges from the Cuthill-McKee pass).  The forward kernel serves the PCG
+// refinement path; the back kernel is the fallback for bands too wide for the single-wave k_band_back_v2.
 // =====================================================================================================
 namespace ssfm {
-
-// Cholesky of one DCxDC block by a single lane: L (lower, row-major into sL) and the reciprocals of its diagonal (sRs).
-// Reciprocal square roots keep the dependent chain short; the explicit inverse is NOT formed here (off the critical path).
-template <int DC>
-__device__ __forceinline__ bool chol_block(const double* __restrict__ a, double* __restrict__ sL, double* __restrict__ sRs) {
-    double L[DC][DC]; bool bad = false;
-#pragma unroll
-    for (int c = 0; c < DC; c++) {
-        double d = a[c * DC + c];
-#pragma unroll
-        for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double rs = fast_rsqrt(d);
-        L[c][c] = d * rs; sRs[c] = rs;
-#pragma unroll
-        for (int r = c + 1; r < DC; r++) {
-            double t = a[r * DC + c];
-#pragma unroll
-            for (int k = 0; k < c; k++) t -= L[r][k] * L[c][k];
-            L[r][c] = t * rs;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < DC; r++)
-#pragma unroll
-        for (int c = 0; c < DC; c++) sL[r * DC + c] = (c <= r) ? L[r][c] : 0.0;
-    return !bad;
-}
-
-// Look-ahead schedule, 4 waves:  per block column j
-//   phase B  (all waves)   panel rows by forward substitution with L_jj, y_j, the inverse of L_jj (for the substitution
-//                          kernels), write-back of the final row j, issue of the prefetch for the row entering the window
-//   barrier
-//   phase C  wave 0        update the NEXT diagonal block with its panel row, factor it (one lane)
-//            waves 1..3    the rest of the trailing window, right-hand sides, store of the prefetched row
-//   barrier
-template <int DC, int NR>
-__global__ void __launch_bounds__(1024)
-k_band_chol_lds(double* __restrict__ band, double* __restrict__ Linv_out, double* __restrict__ Y, const int* __restrict__ pairs,
-                const int* __restrict__ comp_ptr, int N, int b, int* __restrict__ fail_flag) {
-    constexpr int BB = DC * DC;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int R = b + 1, W = b + 1, RW = W * BB;
-    double* sWin = lds;                                     // [R][W][BB]
-    double* sYr = sWin + (size_t)R * RW;                    // [R][NR][DC]
-    double* sL = sYr + (size_t)R * NR * DC;                 // BB   factor of the current diagonal block
-    double* sRs = sL + BB;                                  // DC   reciprocals of its diagonal
-    int* sPairs = reinterpret_cast<int*>(sRs + DC + 1);     // pair table in LDS: a global load inside the step loop would sit
-                                                            // behind the write-back stores in vmcnt order and stall every step
-    for (int e = threadIdx.x; e < b * (b + 1) / 2; e += blockDim.x) sPairs[e] = pairs[e];
-    const int n = N * DC, tid = threadIdx.x, nt = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
-    for (int row = r0; row < min(r0 + R, r1); row++) {
-        for (int e = tid; e < RW; e += nt) sWin[(size_t)(row % R) * RW + e] = band[(size_t)row * RW + e];
-        for (int e = tid; e < NR * DC; e += nt) sYr[(size_t)(row % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
-    }
-    __syncthreads();
-    if (tid == 0 && r0 < r1) { if (!chol_block<DC>(sWin + (size_t)(r0 % R) * RW, sL, sRs)) *fail_flag = 1; }
-    __syncthreads();
-    int jm = r0 % R;                                         // ring slot of row j, kept incrementally (runtime % costs ~40 VALU ops)
-    auto slot = [&](int off) { int q = jm + off; return q >= R ? q - R : q; };      // 0 <= off <= b < R
-    for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
-        const int nb = min(b, r1 - 1 - j);
-        double* rowj = sWin + (size_t)jm * RW;
-        double* yj = sYr + (size_t)jm * NR * DC;
-        const int jn = j + R;
-        // prefetch of the entering row (lands in row j's slot during phase C)
-        double pre[4]; double preY = 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int e = tid + u * nt; pre[u] = (jn < r1 && e < RW) ? band[(size_t)jn * RW + e] : 0.0; }
-        if (jn < r1 && tid < NR * DC) preY = Y[(size_t)(tid / DC) * n + (size_t)jn * DC + (tid % DC)];
-        // ---- B
-        for (int t = tid; t < nb * DC; t += nt) {           // panel row: x L^T = a
-            const int blk = t / DC, a = t - blk * DC;
-            double* A = sWin + (size_t)slot(1 + blk) * RW + (size_t)(blk + 1) * BB + a * DC;
-            double x[DC];
-#pragma unroll
-            for (int c = 0; c < DC; c++) { double v = A[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) v -= x[k] * sL[c * DC + k];
-                x[c] = v * sRs[c]; }
-#pragma unroll
-            for (int c = 0; c < DC; c++) A[c] = x[c];
-        }
-        if (tid >= nt - NR * 64 && (tid & 63) == 0) {       // y_j = L^-1 y_j
-            const int r = (tid - (nt - NR * 64)) >> 6;
-            double x[DC];
-#pragma unroll
-            for (int c = 0; c < DC; c++) { double v = yj[r * DC + c];
-#pragma unroll
-                for (int k = 0; k < c; k++) v -= sL[c * DC + k] * x[k];
-                x[c] = v * sRs[c]; }
-#pragma unroll
-            for (int c = 0; c < DC; c++) { yj[r * DC + c] = x[c]; Y[(size_t)r * n + (size_t)j * DC + c] = x[c]; }
-        }
-        if (tid >= nt - NR * 64 - 64 && tid < nt - NR * 64 - 64 + DC) {   // column c of L^-1 for the substitution kernels
-            const int c = tid - (nt - NR * 64 - 64);
-            double li[DC];
-#pragma unroll
-            for (int r = 0; r < DC; r++) {
-                double v = 0.0;
-                if (r == c) v = sRs[c];
-                else if (r > c) {
-#pragma unroll
-                    for (int k = 0; k < DC; k++) if (k >= c && k < r) v -= sL[r * DC + k] * li[k];
-                    v *= sRs[r];
-                }
-                li[r] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < DC; r++) Linv_out[(size_t)j * BB + r * DC + c] = li[r];
-        }
-        for (int e = tid; e < RW; e += nt) band[(size_t)j * RW + e] = (e < BB) ? sL[e] : rowj[e];     // final row j (diagonal block = L_jj)
-        lds_barrier();
-        // ---- C  (wave 0: next diagonal block + its factor; waves 1..3: everything else)
-        if (wave == 0) {
-            if (nb >= 1) {
-                double* dblk = sWin + (size_t)slot(1) * RW;                  // block (j+1, j+1)
-                const double* Lp = dblk + BB;                                      // block (j+1, j) = panel row 1
-                if (lane < BB) {
-                    const int a = lane / DC, c = lane - a * DC;
-                    double v = 0.0;
-#pragma unroll
-                    for (int m = 0; m < DC; m++) v += Lp[a * DC + m] * Lp[c * DC + m];
-                    dblk[lane] -= v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // wave-local: LDS writes visible to lane 0
-                if (lane == 0) { if (!chol_block<DC>(dblk, sL, sRs)) *fail_flag = 1; }
-            }
-        } else {
-            const int cw = nt - 64, ct = tid - 64;
-            const int work = (nb * (nb + 1) / 2) * DC;
-            for (int t = ct + DC; t < work; t += cw) {                             // pair 0 = (1,1) belongs to wave 0
-                const int pr = t / DC, a = t - pr * DC;
-                const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
-                const int si = slot(ir);
-                const double* Li_ = sWin + (size_t)si * RW + (size_t)ir * BB + a * DC;
-                const double* Lk_ = sWin + (size_t)slot(kr) * RW + (size_t)kr * BB;
-                double la[DC];
-#pragma unroll
-                for (int m = 0; m < DC; m++) la[m] = Li_[m];
-                double* dst = sWin + (size_t)si * RW + (size_t)(ir - kr) * BB + a * DC;
-#pragma unroll
-                for (int c = 0; c < DC; c++) { double v = 0.0;
-#pragma unroll
-                    for (int m = 0; m < DC; m++) v += la[m] * Lk_[c * DC + m];
-                    dst[c] -= v; }
-            }
-            for (int q = ct; q < nb * DC; q += cw) {
-                const int kr = q / DC + 1, a = q - (kr - 1) * DC, sk = slot(kr);
-                const double* Lk_ = sWin + (size_t)sk * RW + (size_t)kr * BB + a * DC;
-                double lk[DC];
-#pragma unroll
-                for (int m = 0; m < DC; m++) lk[m] = Lk_[m];
-#pragma unroll
-                for (int r = 0; r < NR; r++) { double v = 0.0;
-#pragma unroll
-                    for (int m = 0; m < DC; m++) v += lk[m] * yj[r * DC + m];
-                    sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
-            }
-        }
-        lds_barrier();
-        // row j's slot receives the prefetched row j+b+1 (first read: panel of step j+1, behind the next barrier... the
-        // panel of step j+1 runs right away, so the store and a barrier come first)
-        if (jn < r1) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int e = tid + u * nt; if (e < RW) rowj[e] = pre[u]; }
-            for (int e = tid + 4 * nt; e < RW; e += nt) rowj[e] = band[(size_t)jn * RW + e];
-            if (tid < NR * DC) yj[tid] = preY;
-            lds_barrier();
-        }
-    }
-}
 
 // back substitution Y <- L^-T Y per component; next column of L prefetched into registers while the current step runs
 template <int DC, int NR>
