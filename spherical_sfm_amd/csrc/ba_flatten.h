@@ -218,6 +218,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     for (int c = 0; c < Nc; c++)
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
+    int task_batches = 16;                                   // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
+    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
     F.cam_batch_ptr.assign(Nc + 1, 0);
     std::vector<std::vector<int>> by_slot;      // reused per camera: entries (j, j2) interleaved
     for (int c = 0; c < Nc; c++) {
@@ -244,8 +246,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             nbatch += nb;
         }
         F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch;
-        for (int b = F.cam_batch_ptr[c]; b < F.cam_batch_ptr[c + 1]; b += 16) {
-            F.chunk_cam.push_back(c); F.chunk_b0.push_back(b); F.chunk_b1.push_back(std::min(b + 16, F.cam_batch_ptr[c + 1]));
+        for (int b = F.cam_batch_ptr[c]; b < F.cam_batch_ptr[c + 1]; b += task_batches) {
+            F.chunk_cam.push_back(c); F.chunk_b0.push_back(b); F.chunk_b1.push_back(std::min(b + task_batches, F.cam_batch_ptr[c + 1]));
         }
     }
 }

@@ -64,6 +64,7 @@ __device__ __forceinline__ bool wave_chol_inverse(double (&row)[DC], double (&g)
 //   last wave                   writer: panel, y_j and G to global memory (stores only, never waited on)
 // Every wave takes its share of the panel product in phase B.
 constexpr int CHOL2_LOADERS = 2;
+
 template <int DC, int NR>
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
@@ -203,39 +204,50 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             lds_barrier();
         }
     } else if (!is_writer) {
-        // ---- loaders: together they bring in the row that enters the window (RW + NR*DC doubles), one step ahead, in
+        // ---- loaders: together they bring in the row that enters the window (RW + NR*DC doubles), two steps ahead, in
         // registers; loads are unconditional from clamped addresses (a select on a loaded value would wait for it at once)
         constexpr int PRE = 5;                              // covers RW + NR*DC <= 64 * CHOL2_LOADERS * PRE; longer rows take the slow tail
         const int le0 = lw * 64 + lane;
-        double pre[PRE];
-        auto issue_prefetch = [&](int jn) {
-            const int jc = min(jn, r1 - 1);
-#pragma unroll
-            for (int u = 0; u < PRE; u++) {
-                const int e = le0 + u * 64 * CHOL2_LOADERS;
-                const int q = max(min(e - RW, NR * DC - 1), 0);
-                const double* src = (e < RW) ? band + (size_t)jc * RW + e : Y + (size_t)(q / DC) * n + (size_t)jc * DC + (q % DC);
-                pre[u] = *src;
-            }
-        };
-        issue_prefetch(r0 + R);
+        double preA[PRE], preB[PRE];                        // two rows in flight: the factor comes from another XCD's L2 / MALL, more than a step away
+#define CHOL2_ISSUE(pre_, jn_)                                                                                        \
+        do {                                                                                                          \
+            const int jc_ = min((jn_), r1 - 1);                                                                       \
+            _Pragma("unroll") for (int u = 0; u < PRE; u++) {                                                         \
+                const int e = le0 + u * 64 * CHOL2_LOADERS;                                                           \
+                const int q = max(min(e - RW, NR * DC - 1), 0);                                                       \
+                const double* src = (e < RW) ? band + (size_t)jc_ * RW + e : Y + (size_t)(q / DC) * n + (size_t)jc_ * DC + (q % DC); \
+                pre_[u] = *src;                                                                                       \
+            }                                                                                                         \
+        } while (0)
+#define CHOL2_STEP(pre_, j_)                                                                                          \
+        do {                                                                                                          \
+            const int nb = min(b, r1 - 1 - (j_)), jn = (j_) + R;                                                      \
+            phaseB((j_), jm, nb);                                                                                     \
+            lds_barrier();                                                                                            \
+            /* row j's slot is dead (its blocks left as panels of earlier steps): it takes row j + R */               \
+            double* rowj = sWin + (size_t)jm * RW;                                                                    \
+            double* yrow = sYr + (size_t)jm * NR * DC;                                                                \
+            _Pragma("unroll") for (int u = 0; u < PRE; u++) {                                                         \
+                const int e = le0 + u * 64 * CHOL2_LOADERS;                                                           \
+                if (e < RW) rowj[e] = pre_[u]; else if (e < RW + NR * DC) yrow[e - RW] = pre_[u];                     \
+            }                                                                                                         \
+            if (jn < r1) for (int e = le0 + PRE * 64 * CHOL2_LOADERS; e < RW + NR * DC; e += 64 * CHOL2_LOADERS) {    \
+                if (e < RW) rowj[e] = band[(size_t)jn * RW + e];                                                      \
+                else { const int q = e - RW; yrow[q] = Y[(size_t)(q / DC) * n + (size_t)jn * DC + (q % DC)]; }        \
+            }                                                                                                         \
+            CHOL2_ISSUE(pre_, jn + 2);                                                                                \
+            lds_barrier();                                                                                            \
+            jm = (jm + 1 == R) ? 0 : jm + 1;                                                                          \
+        } while (0)
+        CHOL2_ISSUE(preA, r0 + R);
+        CHOL2_ISSUE(preB, r0 + R + 1);
         int jm = jm0;
-        for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
-            const int nb = min(b, r1 - 1 - j), jn = j + R;
-            phaseB(j, jm, nb);
-            lds_barrier();
-            // row j's slot is dead (its blocks left as panels of earlier steps): it takes row j + R, loaded during the last step
-            double* rowj = sWin + (size_t)jm * RW;
-            double* yrow = sYr + (size_t)jm * NR * DC;
-#pragma unroll
-            for (int u = 0; u < PRE; u++) { const int e = le0 + u * 64 * CHOL2_LOADERS; if (e < RW) rowj[e] = pre[u]; else if (e < RW + NR * DC) yrow[e - RW] = pre[u]; }
-            if (jn < r1) for (int e = le0 + PRE * 64 * CHOL2_LOADERS; e < RW + NR * DC; e += 64 * CHOL2_LOADERS) {   // rows longer than the register budget
-                if (e < RW) rowj[e] = band[(size_t)jn * RW + e];
-                else { const int q = e - RW; yrow[q] = Y[(size_t)(q / DC) * n + (size_t)jn * DC + (q % DC)]; }
-            }
-            issue_prefetch(jn + 1);
-            lds_barrier();
+        for (int j = r0; j < r1; j += 2) {
+            CHOL2_STEP(preA, j);
+            if (j + 1 < r1) CHOL2_STEP(preB, j + 1);
         }
+#undef CHOL2_ISSUE
+#undef CHOL2_STEP
     } else {
         // ---- writer: panel, y_j and G to global memory (stores only, never waited on)
         int jm = jm0;
