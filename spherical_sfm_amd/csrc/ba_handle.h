@@ -20,10 +20,11 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
                 KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_COUNT };
-static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs", "k_finalize_S", "k_pcg_init",
-                                              "k_pcg_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
-                                              "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol", "k_band_fwd",
-                                              "k_band_back", "k_band_combine", "k_ref_vecops", "k_cam_sums"};
+// names as rocprofv3 prints them (template arguments dropped)
+static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_S", "k_pcg_init",
+                                              "k_sym_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
+                                              "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
+                                              "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2"};
 
 template <typename T>
 struct DevBuf {
@@ -45,6 +46,7 @@ struct ssfm_ba_handle {
     DevBuf<double> cam_x, cam_c, cam_init, pts_x, pts_c, pts_init, focal3;   // focal3: [x, cand, init]
     DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
+    DevBuf<double> zone; bool zone_views = false;      // BA: scal, pcg and redbuf are views into zone (zeroed by one memset per iteration)
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
@@ -77,7 +79,8 @@ struct ssfm_ba_handle {
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
-        redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
+        if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
+        zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         for (auto& e : phase_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -183,8 +186,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
     const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
     if (stage == 0) {
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->band.p, 0, h->band.n * sizeof(double), st));
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
+    if (!h->zone_views) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
     LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
     hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
     // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component

@@ -116,6 +116,21 @@ __device__ __forceinline__ void lin_obs(double f, const double* t, const double*
         L.Jr[1][k] = -(B1[0] * y0 + B1[1] * y1 + B1[2] * y2);
     }
 }
+// point-side view of the same linearisation (no camera blocks, R only): residual, focal column, point block
+struct ObsPoint { double r[2], Jf[2], Jp[2][3], half_rho; };
+constexpr int OBS_UNROLL = 3;
+__device__ __forceinline__ void lin_obs_point(double f, const double* t, const double* R, const double* X, double ox, double oy, int loss, double la,
+                                              ObsPoint& L) {
+    double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
+    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);
+    const double sr = sqrt(rho1);
+    L.half_rho = 0.5 * rho0;
+    L.r[0] = sr * r0; L.r[1] = sr * r1;
+    L.Jf[0] = sr * xp; L.Jf[1] = sr * yp;
+    const double a = sr * f * iz, a02 = -a * xp, a12 = -a * yp;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.Jp[0][k] = a * R[k] + a02 * R[6 + k]; L.Jp[1][k] = a * R[3 + k] + a12 * R[6 + k]; }
+}
 // scaled camera block Jc[2][DC] of an observation (DC=6: [t r], DC=3: r only)
 template <int DC>
 __device__ __forceinline__ void cam_block(const ObsLin& L, const double* sc6, double (&Jc)[2][DC]) {
@@ -203,17 +218,34 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double f = focal[0], sf = scale_f[0];
         double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, wf[3] = {0, 0, 0};
-        for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
-            const int c = obs_cam[j]; const double2 o = obs_xy[j];
-            ObsLin L; lin_obs<false>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
-            acc[0] += L.half_rho;
+        // observations in groups of OBS_UNROLL: indices first, then every camera's [t | R], then the arithmetic, so that the
+        // dependent gathers of a group are in flight together (a point has 3-10 observations; lanes beyond the list recompute
+        // the last one with zero weight)
+        const int js = pt_start[p], je = pt_start[p + 1];
+        for (int jb = js; jb < je; jb += OBS_UNROLL) {
+            int cc[OBS_UNROLL]; double2 oo[OBS_UNROLL]; double tR[OBS_UNROLL][12];
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const double j0 = L.Jp[a][0] * sp[0], j1 = L.Jp[a][1] * sp[1], j2 = L.Jp[a][2] * sp[2], jf = L.Jf[a] * sf;
-                V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
-                g[0] += j0 * L.r[a]; g[1] += j1 * L.r[a]; g[2] += j2 * L.r[a];
-                wf[0] += jf * j0; wf[1] += jf * j1; wf[2] += jf * j2;
-                acc[1] += jf * jf; acc[2] += jf * L.r[a];
+            for (int u = 0; u < OBS_UNROLL; u++) { const int jj = min(jb + u, je - 1); cc[u] = obs_cam[jj]; oo[u] = obs_xy[jj]; }
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) tR[u][k] = cam[6 * (size_t)cc[u] + k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) tR[u][3 + k] = rot[27 * (size_t)cc[u] + k];
+            }
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) {
+                const double wgt = (jb + u < je) ? 1.0 : 0.0;
+                ObsPoint L; lin_obs_point(f, tR[u], tR[u] + 3, X, oo[u].x, oo[u].y, loss, la, L);
+                acc[0] += wgt * L.half_rho;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const double j0 = L.Jp[a][0] * sp[0] * wgt, j1 = L.Jp[a][1] * sp[1] * wgt, j2 = L.Jp[a][2] * sp[2] * wgt, jf = L.Jf[a] * sf * wgt;
+                    V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
+                    g[0] += j0 * L.r[a]; g[1] += j1 * L.r[a]; g[2] += j2 * L.r[a];
+                    wf[0] += jf * j0; wf[1] += jf * j1; wf[2] += jf * j2;
+                    acc[1] += jf * jf; acc[2] += jf * L.r[a];
+                }
             }
         }
         if (sp[0] > 0.0) {
@@ -248,6 +280,18 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
     }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and every XCD has its own L2.  Wave-task lists
+// are ordered by camera, and neighbouring cameras share points: this maps the workgroups of one XCD onto one CONTIGUOUS eighth of
+// the list, so that the points a camera range re-reads are found in that XCD's L2 instead of being fetched once per XCD.
+__device__ __forceinline__ int xcd_contiguous_block(int w, int nwg) {
+    const int x = w & 7, idx = w >> 3;
+    // workgroups on XCD y: (nwg - y + 7) / 8;  base = how many sit on XCDs 0..x-1
+    int base = 0;
+#pragma unroll
+    for (int y = 0; y < 7; y++) if (y < x) base += (nwg - y + 7) >> 3;
+    return base + idx;
+}
+
 // ---- camera-side sums, second generation: diagonal blocks of the reduced system, right-hand side, focal border ---------
 // One WAVE per task = a run of <= 4 batches (64 observations each) of one camera's observation list; no LDS, no barriers,
 // gathers of batch i+1 in flight during batch i, per-point record PS = [diag(s) V^-1 diag(s) | s o V^-1 g | s o V^-1 w_f].
@@ -267,7 +311,7 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
     constexpr int NU = DC * (DC + 1) / 2;
     constexpr int NSM = NU + 4 * DC;           // [S_cc (upper) | Jc^T r | -W g' | focal coupling | diag U]   (<= 64 for DC <= 6)
     const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (task >= ntasks) return;
     const int c = __builtin_amdgcn_readfirstlane(task_cam[task]);
     const int q0 = __builtin_amdgcn_readfirstlane(task_q0[task]), q1 = __builtin_amdgcn_readfirstlane(task_q1[task]);
@@ -352,7 +396,7 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
                const double* __restrict__ Vs, int loss, double la, double* __restrict__ S_val) {
     constexpr int BB = DC * DC;
     const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (task >= ntasks) return;
     const int c = __builtin_amdgcn_readfirstlane(task_cam[task]);
     const int b0 = __builtin_amdgcn_readfirstlane(task_b0[task]), b1 = __builtin_amdgcn_readfirstlane(task_b1[task]);

@@ -37,7 +37,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
     // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
-    double host_scal[SC_TOTAL];
+    double host_sp[SC_TOTAL + PCG_TOTAL + 1];            // [scalars | solver flags], one copy per iteration
+    double* host_scal = host_sp; double* host_pcg1 = host_sp + SC_TOTAL;
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
@@ -78,13 +79,12 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
         iteration++;
         // ================= assemble at x with the current radius =================
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));   // scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0)
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, (size_t)h->n_red * sizeof(double), st));      // [S | rhs | diag U | S_fc | Jc^T r | sums]: all accumulated
         if (!F.cs_task_cam.empty()) {
             const int ntasks = (int)F.cs_task_cam.size();
             LAUNCH(h, KID_CAM_SUMS, k_cam_sums2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->cam_obs.p, h->cam_obs_pt.p, h->cs_task_cam.p,
@@ -111,7 +111,6 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         // iteration scalars in ONE host synchronisation.  Only if the residual test failed (rare) does PCG refinement
         // run and the tail get redone.
         int pcg_iters = 0; bool pcg_ok = false;
-        double host_pcg1[PCG_TOTAL + 1];
         { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         auto enqueue_tail = [&]() -> int {
@@ -123,8 +122,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             if (nP > 0)
                 LAUNCH(h, KID_COST, k_point_cost, gp_pts, 256, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
-            hipError_t e = hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && O.preconditioner == 0) e = hipMemcpyAsync(host_pcg1, h->pcg.p, (PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);
+            hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;
         };
@@ -260,12 +258,15 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     const size_t nnzb = (size_t)F.row_ptr[Nc], n = (size_t)Nc * DC;
     const size_t n_red = nnzb * DC * DC + (n + 1) + 3 * n + SC_NSUM;
     h->n_red = (int)n_red;
-    AL(redbuf, n_red);
+    // [scal | pcg flags + factorisation fail word | redbuf] share one allocation: one memset per LM iteration zeroes them all,
+    // and one copy brings both scalar groups back
+    AL(zone, SC_TOTAL + PCG_TOTAL + 1 + n_red);
+    h->scal.p = h->zone.p; h->scal.n = SC_TOTAL; h->pcg.p = h->zone.p + SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
+    h->redbuf.p = h->pcg.p + PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
     h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * DC * DC; h->Udiag = h->rhs + (n + 1); h->Sfc = h->Udiag + n;
     h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
-    AL(scal, SC_TOTAL); AL(pcg, PCG_TOTAL + 1);
     AL(band, (size_t)Nc * (F.band + 1) * DC * DC); AL(Linv, (size_t)Nc * DC * DC); AL(Yb, 2 * n); AL(Yr, 2 * n); AL(band_fail, 1);
 #undef AL
     SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
@@ -275,7 +276,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
     SSFM_HIP_CHECK(ctx, upload(h->cam_batch_ptr, F.cam_batch_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_cam, F.chunk_cam, st));
     SSFM_HIP_CHECK(ctx, upload(h->chunk_b0, F.chunk_b0, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_b1, F.chunk_b1, st));
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSFM_OK;
 }

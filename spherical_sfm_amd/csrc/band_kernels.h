@@ -38,10 +38,14 @@ __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __rest
     constexpr int BB = DC * DC;
     const int c = blockIdx.x;
     const int i = pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    // the workgroup owns band row i (its blocks all come from S row c): clear it, then scatter
+    double* row = band + (size_t)i * (b + 1) * BB;
+    for (int e = threadIdx.x; e < (b + 1) * BB; e += blockDim.x) row[e] = 0.0;
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nnb * BB; idx += blockDim.x) {
         const int s = rb + idx / BB, e = idx % BB;
         const int k = pos[col_idx[s]];
-        if (k <= i) band[((size_t)i * (b + 1) + (i - k)) * BB + e] = S_val[(size_t)s * BB + e];
+        if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e];
     }
 }
 template <int DC>
