@@ -170,6 +170,7 @@ typedef struct {
     int32_t min_num_inliers;     /* acceptance threshold of estimate_pairwise */
     int32_t final_least_squares; /* LORansacOptions::final_least_squares_ (default 1, spherical_sfm_tools.cpp:318) */
     int32_t inward;              /* SphericalEstimator(..., inward) */
+    int32_t use_poly_solver;     /* SphericalEstimator(..., use_poly_solver, ...): 0 = action matrix (estimate_pairwise's choice), 1 = quartic */
 } ssfm_ransac_options;
 void ssfm_ransac_default_options(ssfm_ransac_options* o);
 int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
@@ -180,6 +181,9 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
  * counts: [S]. */
 int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
                                 double* Es, int32_t* counts);
+/* same for spherical_solver_polynomial (src/spherical_solvers.cpp:313-660, SolveQuartic :15-69) */
+int ssfm_spherical_solver_poly_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
+                                     double* Es, int32_t* counts);
 
 /* ---- SfM::Retriangulate (src/sfm.cpp:156-192) ------------------------------------------------------------------
  * Re-estimates EVERY point of the problem from its observations and the current cameras/focal: LO-MSAC over 2-view DLT

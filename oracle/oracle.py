@@ -82,6 +82,7 @@ def lib():
         L.oracle_rotation_edge.restype = None
         L.oracle_sampson.argtypes = [c_double_p, c_double_p, c_double_p]; L.oracle_sampson.restype = C.c_double
         L.oracle_spherical_solver.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p]; L.oracle_spherical_solver.restype = C.c_int
+        L.oracle_spherical_solver_poly.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p, c_double_p]; L.oracle_spherical_solver_poly.restype = C.c_int
         L.oracle_make_spherical_essential_matrix.argtypes = [c_double_p, C.c_int32, c_double_p]; L.oracle_make_spherical_essential_matrix.restype = None
         L.oracle_decompose_spherical_essential_matrix.argtypes = [c_double_p, C.c_int32, c_double_p, c_double_p]
         L.oracle_decompose_spherical_essential_matrix.restype = None
@@ -244,6 +245,14 @@ def spherical_solver(u, v, sample):
     out = np.zeros(36)
     k = lib().oracle_spherical_solver(len(u), _dp(u), _dp(v), len(s), _ip(s), _dp(out))
     return [_um(out[9 * i:9 * i + 9]) for i in range(k)]
+
+
+def spherical_solver_poly(u, v, sample):
+    """spherical_solver_polynomial -> (list of E (3,3), imaginary parts of the quartic roots)"""
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(sample, np.int32)
+    out = np.zeros(36); im = np.zeros(4)
+    k = lib().oracle_spherical_solver_poly(len(u), _dp(u), _dp(v), len(s), _ip(s), _dp(out), _dp(im))
+    return [_um(out[9 * i:9 * i + 9]) for i in range(k)], im[:k]
 
 
 def make_spherical_essential_matrix(R, inward=False):

@@ -146,9 +146,12 @@ static void eig4(const double M[16], cd lam[4]) {
     for (int i = 0; i < 4; i++) lam[i] = z[i];
 }
 
-// src/spherical_solvers.cpp:102-311.  sample: indices into rays.  Es: 4 x 9 row-major.  Returns number of models.
-static int solver_action_matrix(const Rays& R, const int* sample, int N, double Es[36]) {
-    if (N < 3) return 0;
+// Common front end of both minimal solvers (src/spherical_solvers.cpp:113-125 / 324-337 and the generated constraint matrix):
+// nullspace basis B (6x3) and the six cubic constraints -T01, T20, T00, T21, T12, T22 of T = 2 E E^T E - tr(E E^T) E over the
+// monomials [x^3, x^2y, xy^2, y^3, x^2z, xyz, y^2z, xz^2, yz^2, z^3]  (identified symbolically from the generated code; the
+// polynomial variant holds the same rows times 1/2 in a different monomial order).
+static bool solver_front(const Rays& R, const int* sample, int N, double B[6][3], Cub rows[6]) {
+    if (N < 3) return false;
     std::vector<double> At((size_t)6 * N);
     for (int i = 0; i < N; i++) {
         const double* u = R.u + 3 * sample[i]; const double* v = R.v + 3 * sample[i];
@@ -156,7 +159,7 @@ static int solver_action_matrix(const Rays& R, const int* sample, int N, double 
         for (int k = 0; k < 6; k++) At[(size_t)k * N + i] = row[k];
     }
     double Q[36]; qr_colpiv_Q(At, N, Q);
-    double B[6][3]; for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) B[i][j] = Q[i * 6 + 3 + j];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) B[i][j] = Q[i * 6 + 3 + j];
     Lin p[6]; for (int k = 0; k < 6; k++) for (int j = 0; j < 3; j++) p[k].c[j] = B[k][j];
     Lin zero = {{0, 0, 0}}, np0 = {{-p[0].c[0], -p[0].c[1], -p[0].c[2]}};
     const Lin* Em[3][3] = {{&p[0], &p[1], &p[2]}, {&p[1], &np0, &p[3]}, {&p[4], &p[5], &zero}};
@@ -164,7 +167,20 @@ static int solver_action_matrix(const Rays& R, const int* sample, int N, double 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Quad q = mul(*Em[i][0], *Em[j][0]); q = add(q, mul(*Em[i][1], *Em[j][1])); q = add(q, mul(*Em[i][2], *Em[j][2])); EEt[i][j] = q; }
     Quad tr = add(add(EEt[0][0], EEt[1][1]), EEt[2][2]);
     auto T = [&](int i, int j, double s) { Cub c; for (double& x : c.c) x = 0; for (int k = 0; k < 3; k++) acc(c, EEt[i][k], *Em[k][j], 2.0 * s); acc(c, tr, *Em[i][j], -s); return c; };
-    const Cub rows[6] = {T(0, 1, -1.0), T(2, 0, 1.0), T(0, 0, 1.0), T(2, 1, 1.0), T(1, 2, 1.0), T(2, 2, 1.0)};
+    rows[0] = T(0, 1, -1.0); rows[1] = T(2, 0, 1.0); rows[2] = T(0, 0, 1.0); rows[3] = T(2, 1, 1.0); rows[4] = T(1, 2, 1.0); rows[5] = T(2, 2, 1.0);
+    return true;
+}
+static void essential_from_b(const double B[6][3], const double b[3], double* E) {      // src/spherical_solvers.cpp:296-305 / 645-654
+    double ps[6]; for (int k = 0; k < 6; k++) ps[k] = B[k][0] * b[0] + B[k][1] * b[1] + B[k][2] * b[2];
+    E[0] = ps[0]; E[1] = ps[1]; E[2] = ps[2]; E[3] = ps[1]; E[4] = -ps[0]; E[5] = ps[3]; E[6] = ps[4]; E[7] = ps[5]; E[8] = 0.0;
+    double nrm = 0; for (int k = 0; k < 9; k++) nrm += E[k] * E[k]; nrm = std::sqrt(nrm);
+    for (int k = 0; k < 9; k++) E[k] /= nrm;
+}
+
+// src/spherical_solvers.cpp:102-311.  sample: indices into rays.  Es: 4 x 9 row-major.  Returns number of models.
+static int solver_action_matrix(const Rays& R, const int* sample, int N, double Es[36]) {
+    double B[6][3]; Cub rows[6];
+    if (!solver_front(R, sample, N, B, rows)) return 0;
     double C1[36], C2[24];
     for (int r = 0; r < 6; r++) { for (int k = 0; k < 6; k++) C1[r * 6 + k] = rows[r].c[k]; for (int k = 0; k < 4; k++) C2[r * 4 + k] = rows[r].c[6 + k]; }
     if (!lu_solve6(C1, C2)) return 0;
@@ -184,11 +200,51 @@ static int solver_action_matrix(const Rays& R, const int* sample, int N, double 
         if (std::abs(det) > 0) { v0 = (b1 * a22 - a12 * b2) / det; v2 = (a11 * b2 - b1 * a21) / det; } else { v0 = 0; v2 = 0; }
         (void)v0;
         const double b[3] = {v1.real(), v2.real(), 1.0};
-        double ps[6]; for (int k = 0; k < 6; k++) ps[k] = B[k][0] * b[0] + B[k][1] * b[1] + B[k][2] * b[2];
-        double* E = Es + 9 * s;
-        E[0] = ps[0]; E[1] = ps[1]; E[2] = ps[2]; E[3] = ps[1]; E[4] = -ps[0]; E[5] = ps[3]; E[6] = ps[4]; E[7] = ps[5]; E[8] = 0.0;
-        double nrm = 0; for (int k = 0; k < 9; k++) nrm += E[k] * E[k]; nrm = std::sqrt(nrm);
-        for (int k = 0; k < 9; k++) E[k] /= nrm;
+        essential_from_b(B, b, Es + 9 * s);
+    }
+    return 4;
+}
+
+// SolveQuartic (Ferrari, "from Theia library"), src/spherical_solvers.cpp:15-69
+static void solve_quartic(double a, double b, double c, double d, double e, cd roots[4]) {
+    const double a2 = a * a, b2 = b * b, a3 = a2 * a, b3 = b2 * b, a4 = a3 * a, b4 = b3 * b;
+    const double alpha = -3.0 * b2 / (8.0 * a2) + c / a;
+    const double beta = b3 / (8.0 * a3) - b * c / (2.0 * a2) + d / a;
+    const double gamma = -3.0 * b4 / (256.0 * a4) + b2 * c / (16.0 * a3) - b * d / (4.0 * a2) + e / a;
+    const double alpha2 = alpha * alpha, alpha3 = alpha2 * alpha;
+    const cd P(-alpha2 / 12.0 - gamma, 0);
+    const cd Q(-alpha3 / 108.0 + alpha * gamma / 3.0 - std::pow(beta, 2.0) / 8.0, 0);
+    const cd Rr = -Q / 2.0 + std::sqrt(std::pow(Q, 2.0) / 4.0 + std::pow(P, 3.0) / 27.0);
+    const cd U = std::pow(Rr, (1.0 / 3.0));
+    cd y;
+    if (std::abs(U.real()) < 1e-8) y = -5.0 * alpha / 6.0 - std::pow(Q, (1.0 / 3.0));
+    else y = -5.0 * alpha / 6.0 - P / (3.0 * U) + U;
+    const cd w = std::sqrt(alpha + 2.0 * y);
+    roots[0] = -b / (4.0 * a) + 0.5 * (w + std::sqrt(-(3.0 * alpha + 2.0 * y + 2.0 * beta / w)));
+    roots[1] = -b / (4.0 * a) + 0.5 * (w - std::sqrt(-(3.0 * alpha + 2.0 * y + 2.0 * beta / w)));
+    roots[2] = -b / (4.0 * a) + 0.5 * (-w + std::sqrt(-(3.0 * alpha + 2.0 * y - 2.0 * beta / w)));
+    roots[3] = -b / (4.0 * a) + 0.5 * (-w - std::sqrt(-(3.0 * alpha + 2.0 * y - 2.0 * beta / w)));
+}
+
+// src/spherical_solvers.cpp:313-660: same constraints (times 1/2), monomials [x^3 x^2y xy^2 x^2z xyz xz^2 | y^3 y^2z yz^2 z^3];
+// rows 4, 5 of G = C[:, :6]^-1 C[:, 6:] give xy and x as cubics in y (z = 1) => quartic in y; the REAL PARTS of all four roots
+// are used (SolveQuarticReals without tolerance, :629-631).  imag_out (optional): imaginary parts, for the tests.
+static int solver_polynomial(const Rays& R, const int* sample, int N, double Es[36], double* imag_out = nullptr) {
+    double B[6][3]; Cub rows[6];
+    if (!solver_front(R, sample, N, B, rows)) return 0;
+    static const int perm[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};
+    double C1[36], C2[24];
+    for (int r = 0; r < 6; r++) { for (int k = 0; k < 6; k++) C1[r * 6 + k] = 0.5 * rows[r].c[perm[k]]; for (int k = 0; k < 4; k++) C2[r * 4 + k] = 0.5 * rows[r].c[perm[6 + k]]; }
+    if (!lu_solve6(C1, C2)) return 0;
+    const double* G4 = C2 + 16; const double* G5 = C2 + 20;
+    const double a = -G5[0], b = G4[0] - G5[1], c = G4[1] - G5[2], d = G4[2] - G5[3], e = G4[3];
+    cd roots[4]; solve_quartic(a, b, c, d, e, roots);
+    for (int s = 0; s < 4; s++) {
+        const double y = roots[s].real(), y2 = y * y, y3 = y2 * y;
+        const double x = -G5[0] * y3 - G5[1] * y2 - G5[2] * y - G5[3];
+        const double bs[3] = {x, y, 1.0};
+        essential_from_b(B, bs, Es + 9 * s);
+        if (imag_out) imag_out[s] = roots[s].imag();
     }
     return 4;
 }
@@ -349,6 +405,12 @@ extern "C" double oracle_sampson(const double E_cm[9], const double u[3], const 
 extern "C" int oracle_spherical_solver(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, double Es_cm[36]) {
     Rays R{n, u, v}; double Es[36];
     const int k = solver_action_matrix(R, sample, ns, Es);
+    for (int i = 0; i < k; i++) rm_to_cm(Es + 9 * i, Es_cm + 9 * i);
+    return k;
+}
+extern "C" int oracle_spherical_solver_poly(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, double Es_cm[36], double imag[4]) {
+    Rays R{n, u, v}; double Es[36];
+    const int k = solver_polynomial(R, sample, ns, Es, imag);
     for (int i = 0; i < k; i++) rm_to_cm(Es + 9 * i, Es_cm + 9 * i);
     return k;
 }

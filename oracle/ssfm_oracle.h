@@ -95,6 +95,8 @@ void oracle_rotation_edge(int32_t kind, const double r0[3], const double r1[3], 
  * include/RansacLib); rays u,v: [n*3]; all 3x3 matrices column-major */
 double oracle_sampson(const double E[9], const double u[3], const double v[3]);
 int oracle_spherical_solver(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, double Es[36]);
+/* spherical_solver_polynomial (src/spherical_solvers.cpp:313-660); imag: imaginary parts of the quartic roots whose real parts were used */
+int oracle_spherical_solver_poly(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, double Es[36], double imag[4]);
 void oracle_make_spherical_essential_matrix(const double R[9], int32_t inward, double E[9]);
 void oracle_decompose_spherical_essential_matrix(const double E[9], int32_t inward, double r[3], double t[3]);
 void oracle_sampson_least_squares(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, int32_t inward, double E[9]);

@@ -57,7 +57,7 @@ class BAPlanInfoC(C.Structure):
 
 class RansacOptionsC(C.Structure):
     _fields_ = [("num_hypotheses", C.c_int32), ("seed", C.c_uint32), ("min_num_inliers", C.c_int32), ("final_least_squares", C.c_int32),
-                ("inward", C.c_int32)]
+                ("inward", C.c_int32), ("use_poly_solver", C.c_int32)]
 
 
 # every symbol include/ssfm.h declares (tests check that the library exports all of them)
@@ -68,7 +68,7 @@ DECLARED_SYMBOLS = [
     "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
-    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_spherical_solver_probe", "ssfm_build_tracks", "ssfm_retriangulate",
+    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_retriangulate",
 ]
 
 
@@ -124,6 +124,8 @@ def lib():
     L.ssfm_ransac_batch.restype = C.c_int
     L.ssfm_spherical_solver_probe.argtypes = [vp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p, c_i32_p]
     L.ssfm_spherical_solver_probe.restype = C.c_int
+    L.ssfm_spherical_solver_poly_probe.argtypes = [vp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p, c_i32_p]
+    L.ssfm_spherical_solver_poly_probe.restype = C.c_int
     L.ssfm_build_tracks.argtypes = [C.c_int32, c_i32_p, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_i32_p, c_i32_p, c_i32_p, C.c_double, C.c_double,
                                     C.c_int32, c_i32_p, c_i32_p, c_u8_p, c_i64_p, c_i32_p, c_i32_p, c_double_p]
     L.ssfm_build_tracks.restype = C.c_int

@@ -43,7 +43,32 @@ __device__ __forceinline__ void cub_acc(double* r, const double* a, const double
     r[7] += s * (a[2] * b[2] + a[5] * b[0]); r[8] += s * (a[4] * b[2] + a[5] * b[1]); r[9] += s * (a[5] * b[2]);
 }
 
+// complex helpers for Ferrari's method (principal branches, as std::sqrt / std::pow(z, 1/3) of the reference's SolveQuartic)
+struct cplx { double r, i; };
+__device__ __forceinline__ cplx cmk(double r, double i = 0.0) { return cplx{r, i}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cplx{a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cplx{a.r - b.r, a.i - b.i}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return cplx{a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return cplx{a.r * s, a.i * s}; }
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b) { const double d = b.r * b.r + b.i * b.i; return cplx{(a.r * b.r + a.i * b.i) / d, (a.i * b.r - a.r * b.i) / d}; }
+__device__ __forceinline__ cplx csqrt_p(cplx a) {
+    const double m = hypot(a.r, a.i);
+    if (m == 0.0) return cplx{0.0, 0.0};
+    const double sr = sqrt(0.5 * (m + fabs(a.r)));
+    if (a.r >= 0.0) return cplx{sr, a.i / (2.0 * sr)};
+    return cplx{fabs(a.i) / (2.0 * sr), (a.i >= 0.0) ? sr : -sr};
+}
+__device__ __forceinline__ cplx ccbrt_p(cplx a) {                   // exp(log(a) / 3), arg in (-pi, pi]
+    const double m = hypot(a.r, a.i);
+    if (m == 0.0) return cplx{0.0, 0.0};
+    const double rho = cbrt(m), th = atan2(a.i, a.r) / 3.0;
+    return cplx{rho * cos(th), rho * sin(th)};
+}
+
 // Minimal solver for one 3-point sample.  Es: up to 4 real solutions (row-major 3x3, unit Frobenius norm); returns count.
+// POLY = false: action-matrix variant (src/spherical_solvers.cpp:102-311); POLY = true: quartic variant (:313-660), whose
+// constraint matrix is the same six rows (times 1/2) with the monomials ordered [x^3 x^2y xy^2 x^2z xyz xz^2 | y^3 y^2z yz^2 z^3].
+template <bool POLY>
 __device__ int spherical_minimal_solver(const double* u3, const double* v3, double* Es) {
     // A^T (6x3), Householder QR without pivoting; B = last three columns of Q  (src/spherical_solvers.cpp:119-125)
     double At[6][3];
@@ -124,6 +149,17 @@ __device__ int spherical_minimal_solver(const double* u3, const double* v3, doub
         for (int k = 0; k < 3; k++) cub_acc(C[r], EEt[ri[r]][k], Em[k][rj[r]], 2.0 * rs[r]);
         cub_acc(C[r], tr, Em[ri[r]][rj[r]], -rs[r]);
     }
+    if (POLY) {                                         // monomial order of the quartic variant; the factor 1/2 is exact
+        const int perm[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double t[10];
+#pragma unroll
+            for (int m = 0; m < 10; m++) t[m] = 0.5 * C[r][perm[m]];
+#pragma unroll
+            for (int m = 0; m < 10; m++) C[r][m] = t[m];
+        }
+    }
     // G = C[:, :6]^-1 C[:, 6:]  by Gaussian elimination with partial pivoting (static indices: predicated row swaps)
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -145,6 +181,58 @@ __device__ int spherical_minimal_solver(const double* u3, const double* v3, doub
         }
 #pragma unroll
         for (int m = 0; m < 10; m++) if (m >= k) C[k][m] *= inv;
+    }
+    if (POLY) {
+        // rows 4, 5: xy + G4.[y^3 y^2 y 1] = 0, x + G5.[y^3 y^2 y 1] = 0 (z = 1)  =>  quartic in y  (src/spherical_solvers.cpp:623-627)
+        const double* G4 = &C[4][6]; const double* G5 = &C[5][6];
+        const double qa = -G5[0], qb = G4[0] - G5[1], qc = G4[1] - G5[2], qd = G4[2] - G5[3], qe = G4[3];
+        if (qa == 0.0 || !isfinite(qa + qb + qc + qd + qe)) return 0;
+        // Ferrari (src/spherical_solvers.cpp:15-69)
+        const double a2 = qa * qa, b2 = qb * qb, a3 = a2 * qa, b3 = b2 * qb, a4 = a3 * qa, b4 = b3 * qb;
+        const double alpha = -3.0 * b2 / (8.0 * a2) + qc / qa;
+        const double beta = b3 / (8.0 * a3) - qb * qc / (2.0 * a2) + qd / qa;
+        const double gamma = -3.0 * b4 / (256.0 * a4) + b2 * qc / (16.0 * a3) - qb * qd / (4.0 * a2) + qe / qa;
+        const double P = -alpha * alpha / 12.0 - gamma;
+        const double Q = -alpha * alpha * alpha / 108.0 + alpha * gamma / 3.0 - beta * beta / 8.0;
+        const cplx Rr = cadd(cmk(-Q / 2.0), csqrt_p(cmk(Q * Q / 4.0 + P * P * P / 27.0)));
+        const cplx U = ccbrt_p(Rr);
+        cplx y;
+        if (fabs(U.r) < 1e-8) y = csub(cmk(-5.0 * alpha / 6.0), ccbrt_p(cmk(Q)));
+        else y = cadd(csub(cmk(-5.0 * alpha / 6.0), cdiv(cmk(P), cscale(U, 3.0))), U);
+        const cplx w = csqrt_p(cadd(cmk(alpha), cscale(y, 2.0)));
+        const cplx base = cadd(cmk(3.0 * alpha), cscale(y, 2.0));
+        const cplx bw = cdiv(cmk(2.0 * beta), w);
+        const cplx s1 = csqrt_p(cscale(cadd(base, bw), -1.0)), s2 = csqrt_p(cscale(csub(base, bw), -1.0));
+        const double sh = -qb / (4.0 * qa);
+        const cplx roots[4] = {cadd(cmk(sh), cscale(cadd(w, s1), 0.5)), cadd(cmk(sh), cscale(csub(w, s1), 0.5)),
+                               cadd(cmk(sh), cscale(cadd(cscale(w, -1.0), s2), 0.5)), cadd(cmk(sh), cscale(csub(cscale(w, -1.0), s2), 0.5))};
+        const double scale = 1.0 + fabs(qb / qa) + sqrt(fabs(qc / qa)) + cbrt(fabs(qd / qa)) + sqrt(sqrt(fabs(qe / qa)));
+        int count = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (!isfinite(roots[s].r) || !(fabs(roots[s].i) <= 1e-7 * scale)) continue;     // complex pair: not a model
+            double yv = roots[s].r;
+#pragma unroll
+            for (int it = 0; it < 2; it++) {                   // Newton polish on the real axis
+                const double pv = (((qa * yv + qb) * yv + qc) * yv + qd) * yv + qe, dp = ((4 * qa * yv + 3 * qb) * yv + 2 * qc) * yv + qd;
+                if (dp != 0.0) yv -= pv / dp;
+            }
+            const double xv = -(((G5[0] * yv + G5[1]) * yv + G5[2]) * yv + G5[3]);
+            double ps[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) ps[k] = B[k][0] * xv + B[k][1] * yv + B[k][2];
+            double* E = Es + 9 * count;
+            E[0] = ps[0]; E[1] = ps[1]; E[2] = ps[2]; E[3] = ps[1]; E[4] = -ps[0]; E[5] = ps[3]; E[6] = ps[4]; E[7] = ps[5]; E[8] = 0.0;
+            double n2 = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) n2 += E[k] * E[k];
+            if (!(n2 > 0.0) || !isfinite(n2)) continue;
+            const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+            for (int k = 0; k < 9; k++) E[k] *= inv;
+            count++;
+        }
+        return count;
     }
     // action matrix of multiplication by x on [y^2, x, y, 1]
     double M[4][4];
@@ -230,6 +318,7 @@ __device__ int spherical_minimal_solver(const double* u3, const double* v3, doub
 }
 
 // probe for parity tests: one lane per given sample
+template <bool POLY>
 __global__ void k_solver_probe(int S, const int* __restrict__ sample, const double* __restrict__ u, const double* __restrict__ v,
                                double* __restrict__ Es, int* __restrict__ counts) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,12 +326,13 @@ __global__ void k_solver_probe(int S, const int* __restrict__ sample, const doub
     double u3[9], v3[9];
     for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { u3[3 * i + k] = u[3 * sample[3 * s + i] + k]; v3[3 * i + k] = v[3 * sample[3 * s + i] + k]; }
     double E[36];
-    const int c = spherical_minimal_solver(u3, v3, E);
+    const int c = spherical_minimal_solver<POLY>(u3, v3, E);
     counts[s] = c;
     for (int k = 0; k < 36; k++) Es[36 * (size_t)s + k] = (k < 9 * c) ? E[k] : 0.0;
 }
 
 // ---- kernel 1: hypotheses + MSAC scores + per-pair arg-min ----------------------------------------------
+template <bool POLY>
 __global__ void __launch_bounds__(256)
 k_ransac_hypotheses(const int* __restrict__ pair_ptr, const double* __restrict__ u, const double* __restrict__ v, double sq_thresh,
                     int num_hyp, unsigned long long seed, double* __restrict__ bestE, double* __restrict__ bestScore) {
@@ -268,7 +358,7 @@ k_ransac_hypotheses(const int* __restrict__ pair_ptr, const double* __restrict__
 #pragma unroll
                 for (int k = 0; k < 3; k++) { u3[3 * i + k] = su[3 * idx[i] + k]; v3[3 * i + k] = sv[3 * idx[i] + k]; }
             double Es[36];
-            const int cnt = spherical_minimal_solver(u3, v3, Es);
+            const int cnt = spherical_minimal_solver<POLY>(u3, v3, Es);
             for (int m = 0; m < cnt; m++) {
                 const double* E = Es + 9 * m;
                 double sc = 0.0;
@@ -467,6 +557,7 @@ extern "C" void ssfm_ransac_default_options(ssfm_ransac_options* o) {
     o->min_num_inliers = 0;            // estimate_pairwise's acceptance test (spherical_sfm_tools.cpp:410)
     o->final_least_squares = 1;        // spherical_sfm_tools.cpp:318
     o->inward = 0;
+    o->use_poly_solver = 0;            // estimate_pairwise passes use_poly_solver = false (spherical_sfm_tools.cpp:378)
 }
 
 extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,
@@ -488,8 +579,13 @@ extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(dv.p, v, (size_t)3 * total * sizeof(double), hipMemcpyHostToDevice, st));
     SSFM_HIP_CHECK(ctx, dE.alloc((size_t)9 * num_pairs)); SSFM_HIP_CHECK(ctx, dS.alloc(num_pairs)); SSFM_HIP_CHECK(ctx, dR.alloc((size_t)9 * num_pairs));
     SSFM_HIP_CHECK(ctx, dmask.alloc(total)); SSFM_HIP_CHECK(ctx, dnin.alloc(num_pairs));
-    if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_hypotheses), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, dE.p, dS.p);
+    if (O.use_poly_solver) {
+        if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_hypotheses<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, dE.p, dS.p);
+    } else {
+        if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_hypotheses<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, dE.p, dS.p);
+    }
     hipLaunchKernelGGL(k_ransac_refine, dim3(num_pairs), dim3(256), 0, st, dptr.p, du.p, dv.p, sq_thresh, O.inward, O.min_num_inliers, O.final_least_squares,
                        dE.p, dS.p, dR.p, dmask.p, dnin.p);
     std::vector<double> hE((size_t)9 * num_pairs), hR((size_t)9 * num_pairs), hS(num_pairs);
@@ -505,8 +601,7 @@ extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t
 }
 
 // parity probe: the minimal solver on given 3-point samples.  Es: [S*36] (4 column-major 3x3 per sample), counts: [S]
-extern "C" int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
-                                           double* Es, int32_t* counts) {
+static int solver_probe(ssfm_ctx* ctx, bool poly, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples, double* Es, int32_t* counts) {
     if (!ctx || S <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_spherical_solver_probe: bad arguments");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -514,7 +609,8 @@ extern "C" int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const doubl
     std::vector<double> hu(u, u + (size_t)3 * n), hv(v, v + (size_t)3 * n); std::vector<int> hs(samples, samples + (size_t)3 * S);
     SSFM_HIP_CHECK(ctx, upload(du, hu, st)); SSFM_HIP_CHECK(ctx, upload(dv, hv, st)); SSFM_HIP_CHECK(ctx, upload(ds, hs, st));
     SSFM_HIP_CHECK(ctx, dE.alloc((size_t)36 * S)); SSFM_HIP_CHECK(ctx, dc.alloc(S));
-    hipLaunchKernelGGL(k_solver_probe, dim3((S + 63) / 64), dim3(64), 0, st, S, ds.p, du.p, dv.p, dE.p, dc.p);
+    if (poly) hipLaunchKernelGGL(k_solver_probe<true>, dim3((S + 63) / 64), dim3(64), 0, st, S, ds.p, du.p, dv.p, dE.p, dc.p);
+    else hipLaunchKernelGGL(k_solver_probe<false>, dim3((S + 63) / 64), dim3(64), 0, st, S, ds.p, du.p, dv.p, dE.p, dc.p);
     std::vector<double> hE((size_t)36 * S);
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hE.data(), dE.p, hE.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(counts, dc.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -523,3 +619,7 @@ extern "C" int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const doubl
     du.free(); dv.free(); dE.free(); ds.free(); dc.free();
     return SSFM_OK;
 }
+extern "C" int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
+                                           double* Es, int32_t* counts) { return solver_probe(ctx, false, n, u, v, S, samples, Es, counts); }
+extern "C" int ssfm_spherical_solver_poly_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
+                                                double* Es, int32_t* counts) { return solver_probe(ctx, true, n, u, v, S, samples, Es, counts); }

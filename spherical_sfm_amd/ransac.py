@@ -36,11 +36,13 @@ def estimate_pairs(ctx, pairs, squared_inlier_threshold, options=None, **kw):
     return dict(E=_unflat(E), R=_unflat(R), inliers=[mask[ptr[i]:ptr[i + 1]].astype(bool) for i in range(P)], num_inliers=nin, scores=sc)
 
 
-def solver_probe(ctx, u, v, samples):
-    """The minimal solver on given 3-point samples -> list (per sample) of lists of E (3,3)."""
+def solver_probe(ctx, u, v, samples, poly=False):
+    """The minimal solver (action matrix, or the quartic variant with poly=True) on given 3-point samples ->
+    list (per sample) of lists of E (3,3)."""
     u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(samples, np.int32).reshape(-1, 3)
     S = len(s); Es = np.zeros(36 * S); cnt = np.zeros(S, np.int32)
-    _lib.check(_lib.lib().ssfm_spherical_solver_probe(ctx._p, len(u), u.ctypes.data_as(c_double_p), v.ctypes.data_as(c_double_p), S,
+    fn = _lib.lib().ssfm_spherical_solver_poly_probe if poly else _lib.lib().ssfm_spherical_solver_probe
+    _lib.check(fn(ctx._p, len(u), u.ctypes.data_as(c_double_p), v.ctypes.data_as(c_double_p), S,
                                                       s.ctypes.data_as(c_i32_p), Es.ctypes.data_as(c_double_p), cnt.ctypes.data_as(c_i32_p)), ctx._p)
     out = []
     for i in range(S):

@@ -89,3 +89,41 @@ def test_too_few_correspondences(oracle):
     u, v, R, E, _ = synth.make_relative_pose_problem(2, seed=0)
     r = oracle.ransac_pair(u, v, 1e-4)
     assert r["num_inliers"] == 0 and np.allclose(r["R"], np.eye(3))      # ransac.h:137-141
+
+
+# ---- spherical_solver_polynomial (src/spherical_solvers.cpp:313-660) + SolveQuartic (:15-69) -------------------------
+@pytest.mark.parametrize("inward", [False, True])
+def test_polynomial_solver_recovers_ground_truth_without_noise(oracle, inward):
+    worst = 0.0
+    for seed in range(40):
+        u, v, R, E, _ = synth.make_relative_pose_problem(6, inward=inward, seed=seed)
+        Es, im = oracle.spherical_solver_poly(u, v, [0, 1, 2])
+        assert len(Es) == 4 and all(abs(np.linalg.norm(e) - 1) < 1e-12 for e in Es)
+        worst = max(worst, min(frob_err(E, e) for e in Es))
+    assert worst < 1e-7          # Ferrari's closed form is a little less accurate than the eigenvalue route
+
+
+def test_polynomial_and_action_matrix_variants_agree_on_the_real_solutions(oracle):
+    """Both variants eliminate the same six cubic constraints; where the quartic root is real the two E's coincide."""
+    checked = 0
+    for seed in range(60):
+        u, v, R, E, _ = synth.make_relative_pose_problem(3, seed=100 + seed)
+        Ea = oracle.spherical_solver(u, v, [0, 1, 2])
+        Eb, im = oracle.spherical_solver_poly(u, v, [0, 1, 2])
+        for e, i in zip(Eb, im):
+            if abs(i) > 1e-9:
+                continue
+            assert min(frob_err(e, a) for a in Ea) < 1e-6
+            T = 2 * e @ e.T @ e - np.trace(e @ e.T) * e
+            assert np.abs(T).max() < 1e-6 and max(abs(v[k] @ e @ u[k]) for k in range(3)) < 1e-9
+            checked += 1
+    assert checked >= 120        # at least two real roots per sample (the true pose and its twin)
+
+
+def test_quartic_roots_against_numpy(oracle):
+    """SolveQuartic through the solver: the y-values implied by the solutions are roots of the same quartic numpy finds."""
+    u, v, R, E, _ = synth.make_relative_pose_problem(3, seed=9)
+    Ea = oracle.spherical_solver(u, v, [0, 1, 2])
+    Eb, im = oracle.spherical_solver_poly(u, v, [0, 1, 2])
+    real_b = [e for e, i in zip(Eb, im) if abs(i) < 1e-9]
+    assert 2 <= len(real_b) <= 4 and all(min(frob_err(e, a) for a in Ea) < 1e-7 for e in real_b)

@@ -98,3 +98,40 @@ def test_noise_free_pair_is_solved_exactly(gpu_ctx):
     u, v, R, E, _ = synth.make_relative_pose_problem(80, seed=9, rotation_deg=17)
     out = ransac.estimate_pairs(gpu_ctx, [(u, v)], 1e-10)
     assert out["num_inliers"][0] == 80 and rot_err(R, out["R"][0]) < 1e-7 and frob_err(E, out["E"][0]) < 1e-7
+
+
+# ---- quartic variant of the minimal solver (spherical_solver_polynomial, src/spherical_solvers.cpp:313-660) ----------
+def test_polynomial_solver_matches_oracle(gpu_ctx, oracle):
+    from spherical_sfm_amd import ransac
+    u, v, R, E, _ = synth.make_relative_pose_problem(40, seed=3, noise=1e-3)
+    rng = np.random.default_rng(0)
+    samples = np.array([rng.choice(40, 3, replace=False) for _ in range(200)], np.int32)
+    got = ransac.solver_probe(gpu_ctx, u, v, samples, poly=True)
+    errs = []; n_real_ref = 0
+    for s, Es in zip(samples, got):
+        ref, im = oracle.spherical_solver_poly(u, v, s)
+        real_ref = [r for r, i in zip(ref, im) if abs(i) < 1e-9]
+        n_real_ref += len(real_ref)
+        for e in Es:                                           # every GPU solution is one of the oracle's real-root solutions
+            errs.append(min(frob_err(e, r) for r in real_ref) if real_ref else 1.0)
+    errs = np.array(errs)
+    assert len(errs) >= 0.95 * n_real_ref and len(errs) >= 400
+    # same tolerance rationale as the action-matrix variant; the GPU adds two Newton steps on the quartic, the oracle keeps
+    # Ferrari's raw roots, which limits the agreement to the closed form's own accuracy (~1e-9 typical)
+    assert np.median(errs) < 1e-9 and np.quantile(errs, 0.95) < 1e-6 and (errs > 1e-4).mean() < 0.01
+
+
+def test_polynomial_solver_recovers_ground_truth_and_batch_runs_with_it(gpu_ctx):
+    from spherical_sfm_amd import ransac
+    worst = 0.0
+    for seed in range(20):
+        u, v, R, E, _ = synth.make_relative_pose_problem(6, seed=seed)
+        Es = ransac.solver_probe(gpu_ctx, u, v, [[0, 1, 2]], poly=True)[0]
+        worst = max(worst, min(frob_err(E, e) for e in Es))
+    assert worst < 1e-8
+    probs = _pairs(16, 300, 0.3, 1 / 600)
+    thr = (2 / 600) ** 2
+    a = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=1)
+    b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=0)
+    for k, p in enumerate(probs):
+        assert rot_err(p[2], a["R"][k]) < 5e-3 and abs(int(a["num_inliers"][k]) - int(b["num_inliers"][k])) <= 0.02 * len(p[0])
