@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include "../ssfm_math.h"
 
 namespace sphericalsfm {
@@ -43,6 +45,8 @@ int SfM::AddCamera(const Pose& pose, const std::string& path) {                 
     return nextCamera;
 }
 int SfM::AddPoint(const Point& X) { numPoints++; points[nextPoint] = X; pointFixed[nextPoint] = false; return nextPoint++; }   // src/sfm.cpp:113-127
+int SfM::AddPoint(const Point& X, const std::array<unsigned char, 3>& color_bgr) { const int p = AddPoint(X); colors[p] = color_bgr; return p; }
+std::array<unsigned char, 3> SfM::GetColor(int point) { auto it = colors.find(point); return it == colors.end() ? std::array<unsigned char, 3>{0, 0, 0} : it->second; }
 void SfM::AddObservation(int camera, int point, const Observation& o) { observations[camera][point] = o; }                 // src/sfm.cpp:143-146
 bool SfM::GetObservation(int camera, int point, Observation& o) {
     auto r = observations.find(camera); if (r == observations.end()) return false;
@@ -59,7 +63,7 @@ void SfM::MergePoint(int point1, int point2) {                                  
 }
 void SfM::RemovePoint(int point) {                                                            // src/sfm.cpp:435-444
     for (auto& row : observations) if (row.first >= 0 && row.first < numCameras) row.second.erase(point);
-    points.erase(point);
+    points.erase(point); colors.erase(point);
 }
 void SfM::RemoveCamera(int camera) {                                                          // src/sfm.cpp:446-461
     cameras.erase(camera); observations.erase(camera);
@@ -180,6 +184,121 @@ void SfM::WritePoses(const std::string& path, const std::vector<int>& indices) {
         std::fprintf(f, "\n");
     }
     std::fclose(f);
+}
+
+void SfM::WritePointsOBJ(const std::string& path) {                                           // src/sfm.cpp:482-519
+    FILE* f = std::fopen(path.c_str(), "w"); if (!f) return;
+    std::vector<double> distances(numPoints, 0.0);             // distance to the LAST camera that observes the point, as the reference's loop leaves it
+    for (int i = 0; i < numCameras; i++) {
+        const Vec3 center = GetPose(i).getCenter();
+        auto row = observations.find(i); if (row == observations.end()) continue;
+        for (auto& kv : row->second) {
+            const int j = kv.first; if (j < 0 || j >= numPoints || !points.count(j)) continue;
+            const Point X = GetPoint(j);
+            distances[j] = Vec3(X.v[0] - center.v[0], X.v[1] - center.v[1], X.v[2] - center.v[2]).norm();
+        }
+    }
+    for (int i = 0; i < numPoints; i++) {
+        if (!points.count(i)) continue;
+        if (distances[i] > 2000.) continue;
+        const Point X = GetPoint(i);
+        if (X.norm() == 0) continue;
+        std::fprintf(f, "v %0.15lf %0.15lf %0.15lf\n", X.v[0], X.v[1], X.v[2]);
+    }
+    std::fclose(f);
+}
+void SfM::WriteCameraCentersOBJ(const std::string& path) {                                    // src/sfm.cpp:521-533
+    FILE* f = std::fopen(path.c_str(), "w"); if (!f) return;
+    for (int i = 0; i < numCameras; i++) { const Vec3 c = GetPose(i).getCenter(); std::fprintf(f, "v %0.15lf %0.15lf %0.15lf\n", c.v[0], c.v[1], c.v[2]); }
+    std::fclose(f);
+}
+void SfM::WriteCOLMAP(const std::string& sparse_dir, int width, int height) {                 // src/sfm.cpp:573-647
+    mkdir(sparse_dir.c_str(), 0777);
+    FILE* camerasf = std::fopen((sparse_dir + "/cameras.txt").c_str(), "w"); if (!camerasf) return;
+    std::fprintf(camerasf, "# Camera list with one line of data per camera:\n");
+    std::fprintf(camerasf, "#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n");
+    std::fprintf(camerasf, "# Number of cameras: 1\n");
+    std::fprintf(camerasf, "1 SIMPLE_PINHOLE %d %d %lf %lf %lf\n", width, height, intrinsics.focal, intrinsics.centerx, intrinsics.centery);
+    std::fclose(camerasf);
+    FILE* imagesf = std::fopen((sparse_dir + "/images.txt").c_str(), "w"); if (!imagesf) return;
+    std::fprintf(imagesf, "# Image list with two lines of data per image:\n");
+    std::fprintf(imagesf, "#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n");
+    std::fprintf(imagesf, "#   POINTS2D[] as (X, Y, POINT3D_ID)\n");
+    std::fprintf(imagesf, "# Number of images: %d, mean observations per image:\n", GetNumCameras());
+    std::vector<std::vector<std::pair<int, int>>> point_obs(GetNumPoints());
+    for (int i = 0; i < GetNumCameras(); i++) {
+        const Pose pose = GetPose(i);
+        std::fprintf(imagesf, "%d ", i + 1);
+        double qw = 1, qx = 0, qy = 0, qz = 0;                      // Eigen::Quaterniond(AngleAxisd(|r|, r/|r|))
+        const double th = pose.r.norm();
+        if (th != 0) { const double s = std::sin(0.5 * th) / th; qw = std::cos(0.5 * th); qx = pose.r.v[0] * s; qy = pose.r.v[1] * s; qz = pose.r.v[2] * s; }
+        std::fprintf(imagesf, "%lf %lf %lf %lf ", qw, qx, qy, qz);
+        std::fprintf(imagesf, "%lf %lf %lf ", pose.t.v[0], pose.t.v[1], pose.t.v[2]);
+        std::fprintf(imagesf, "1 ");
+        std::fprintf(imagesf, "%s\n", paths[i].c_str());
+        int k = 0;
+        auto row = observations.find(i);
+        if (row != observations.end() && cameras.count(i))
+            for (auto& kv : row->second) {                            // std::map order = ascending point id = the reference's j loop
+                const int j = kv.first; if (j < 0 || j >= GetNumPoints()) continue;
+                if (GetPoint(j).norm() == 0) continue;
+                std::fprintf(imagesf, "%lf %lf %d ", kv.second.x + intrinsics.centerx, kv.second.y + intrinsics.centery, j + 1);
+                point_obs[j].push_back(std::make_pair(i + 1, k));
+                k++;
+            }
+        std::fprintf(imagesf, "\n");
+    }
+    std::fclose(imagesf);
+    FILE* pointsf = std::fopen((sparse_dir + "/points3D.txt").c_str(), "w"); if (!pointsf) return;
+    std::fprintf(pointsf, "# 3D point list with one line of data per point:\n");
+    std::fprintf(pointsf, "#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[] as (IMAGE_ID, POINT2D_IDX)\n");
+    std::fprintf(pointsf, "# Number of points: %d, mean track length: \n", GetNumPoints());
+    for (int j = 0; j < GetNumPoints(); j++) {
+        const Point point = GetPoint(j);
+        const std::array<unsigned char, 3> color = GetColor(j);
+        if (point.norm() == 0) continue;
+        std::fprintf(pointsf, "%d ", j + 1);
+        std::fprintf(pointsf, "%lf %lf %lf ", point.v[0], point.v[1], point.v[2]);
+        std::fprintf(pointsf, "%d %d %d ", color[2], color[1], color[0]);   // RGB
+        std::fprintf(pointsf, "0 ");                                        // error
+        for (size_t k = 0; k < point_obs[j].size(); k++) std::fprintf(pointsf, "%d %d ", point_obs[j][k].first, point_obs[j][k].second);
+        std::fprintf(pointsf, "\n");
+    }
+    std::fclose(pointsf);
+}
+void SfM::WriteCalib(const std::string& path) {                                               // run_spherical_sfm_uncalib.cpp:225-228
+    FILE* f = std::fopen(path.c_str(), "w"); if (!f) return;
+    std::fprintf(f, "%0.15f %0.15f %0.15f\n", GetFocal(), intrinsics.centerx, intrinsics.centery);
+    std::fclose(f);
+}
+void SfM::FilterObservations(double thresh) {                                                 // src/sfm.cpp:297-339
+    int nremoved = 0;
+    for (int j = 0; j < numPoints; j++) {
+        if (!points.count(j)) continue;
+        if (GetPoint(j).norm() == 0) continue;
+        int nobs = 0;
+        for (auto& row : observations) if (row.first >= 0 && row.first < numCameras && cameras.count(row.first) && row.second.count(j)) nobs++;
+        if (nobs < 3) continue;
+        const Point X = GetPoint(j);
+        for (auto& row : observations) {
+            const int i = row.first;
+            if (i < 0 || i >= numCameras || !cameras.count(i)) continue;
+            auto it = row.second.find(j); if (it == row.second.end()) continue;
+            // ReprojectionError without loss (src/sfm.cpp:38-63): p = R(r) X + t with Ceres' AngleAxisRotatePoint
+            const Camera& c = cameras[i];
+            double R[9], p[3]; ssfm::angle_axis_to_matrix(&c[3], R);
+            ssfm::mat3_vec(R, GetPoint(j).v, p);
+            p[0] += c[0]; p[1] += c[1]; p[2] += c[2];
+            const double r0 = intrinsics.focal * (p[0] / p[2]) - it->second.x, r1 = intrinsics.focal * (p[1] / p[2]) - it->second.y;
+            const double err = std::sqrt(r0 * r0 + r1 * r1);
+            if (err > thresh) {
+                row.second.erase(it);
+                nobs--; nremoved++;
+                if (nobs == 0) SetPoint(j, Point(0, 0, 0));
+            }
+        }
+    }
+    std::cout << "removed " << nremoved << " observations\n";
 }
 
 }  // namespace sphericalsfm

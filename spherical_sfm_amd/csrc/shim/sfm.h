@@ -55,6 +55,7 @@ protected:
     std::map<int, Point> points;
     std::map<int, std::map<int, Observation>> observations;   // [camera][point]
     std::map<int, std::string> paths;
+    std::map<int, std::array<unsigned char, 3>> colors;        // BGR like cv::Vec3b (the reference's SparseVector<cv::Vec3b>)
     bool focalFixed;
     std::map<int, bool> rotationFixed, translationFixed, pointFixed;
     int numCameras, numPoints, nextCamera, nextPoint;
@@ -73,6 +74,8 @@ public:
     Intrinsics GetIntrinsics() const { return intrinsics; }
     int AddCamera(const Pose& initial_pose, const std::string& path = "");
     int AddPoint(const Point& initial_position);
+    int AddPoint(const Point& initial_position, const std::array<unsigned char, 3>& color_bgr);   // descriptors are opaque to this path and not kept
+    std::array<unsigned char, 3> GetColor(int point);
     void AddObservation(int camera, int point, const Observation& observation);
     void RemoveCamera(int camera);
     void RemovePoint(int point);
@@ -97,7 +100,12 @@ public:
     void SetRotationFixed(int camera, bool fixed) { rotationFixed[camera] = fixed; }
     void SetTranslationFixed(int camera, bool fixed) { translationFixed[camera] = fixed; }
     void SetPointFixed(int point, bool fixed) { pointFixed[point] = fixed; }
-    void WritePoses(const std::string& path, const std::vector<int>& indices);
+    void WritePoses(const std::string& path, const std::vector<int>& indices);        // src/sfm.cpp:463-480
+    void WritePointsOBJ(const std::string& path);                                    // src/sfm.cpp:482-519
+    void WriteCameraCentersOBJ(const std::string& path);                             // src/sfm.cpp:521-533
+    void WriteCOLMAP(const std::string& sparse_dir, int width, int height);          // src/sfm.cpp:573-647
+    void WriteCalib(const std::string& path);                                        // run_spherical_sfm_uncalib.cpp:225-228
+    void FilterObservations(double thresh);                                          // src/sfm.cpp:297-339
     const ssfm_ba_summary& LastSummary() const { return last_summary; }
 };
 
