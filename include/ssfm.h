@@ -185,6 +185,19 @@ int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const
 int ssfm_spherical_solver_poly_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
                                      double* Es, int32_t* counts);
 
+/* ---- focal-length search around the pose graph (examples/spherical_sfm_tools.cpp:1418-1496, find_best_focal_length_random)
+ * costs[t] = loop_constraint_cost_fn(focals[t]) (:1138-1157): every match's essential matrix (rebuilt from its rotation,
+ * :1429-1433) is rescaled by T = diag(f/f0, f/f0, 1) on both sides and decomposed again (transform_image_matches, :1118-1132),
+ * the rotations are chained over the matches (k-1, k) (initialize_rotations_sequential, :794-813; the -sequential mode, the
+ * GraphOptim initialisation is out of scope) and get_cost (src/uncalibrated_pose_graph.cpp:116-145) is evaluated -- one
+ * workgroup per trial.  The reference draws the trial focals from std::random_device; here the caller supplies them.
+ * best_trial: first minimum (strict <, :1467-1474); rotations_best [n*9]: the chained rotations at that focal, column-major,
+ * rel_rotations_best [num_edges*9]: the matches' rotations re-derived at that focal (what run_optimization, :1160-1188, feeds to
+ * optimize_rotations_and_focal_length = ssfm_posegraph_focal_solve).  Any output may be NULL. */
+int ssfm_focal_search(ssfm_ctx* ctx, int32_t n, int32_t num_edges, const int32_t* index0, const int32_t* index1,
+                      const double* rel_rotations, int32_t inward, double focal_guess, int32_t num_trials, const double* focals,
+                      double* costs, int32_t* best_trial, double* rotations_best, double* rel_rotations_best);
+
 /* ---- SfM::Retriangulate (src/sfm.cpp:156-192) ------------------------------------------------------------------
  * Re-estimates EVERY point of the problem from its observations and the current cameras/focal: LO-MSAC over 2-view DLT
  * hypotheses (TriangulationEstimator, src/triangulation_estimator.cpp:46-127; squared inlier threshold 4 px^2, final

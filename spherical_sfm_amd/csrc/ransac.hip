@@ -546,6 +546,69 @@ k_ransac_refine(const int* __restrict__ pair_ptr, const double* __restrict__ u, 
     (void)shi;
 }
 
+// ---- focal-length search around the pose graph ------------------------------------------------
+// One workgroup per trial focal: the loop_constraint_cost_fn of examples/spherical_sfm_tools.cpp:1138-1157 --
+//   transform_image_matches (:1118-1132): E_new = T E T, T = diag(f/f0, f/f0, 1); decompose -> r_new -> R = so3exp(r_new)
+//   initialize_rotations_sequential (:794-813): chain over the matches (k-1, k); a camera without such a match keeps the identity
+//   get_cost (src/uncalibrated_pose_graph.cpp:116-145): 1/2 sum SoftLOne_0.03(|s log(R1 R0^T R^T)|^2), s = 1 / max |log R_rel|
+// Lanes share the edges (decomposition, residuals), lane 0 walks the rotation chain.  Per-trial scratch in global memory.
+__global__ void __launch_bounds__(256)
+k_focal_trials(int n, int E, const int* __restrict__ e0, const int* __restrict__ e1, const int* __restrict__ chain_edge,
+               const double* __restrict__ Es /*[E*9] row-major*/, int inward, double focal_guess, const double* __restrict__ focals,
+               double* __restrict__ rnew_all /*[trials*E*3]*/, double* __restrict__ x_all /*[trials*n*3]*/,
+               double* __restrict__ rot_all /*[trials*n*9] row-major*/, double* __restrict__ costs) {
+    __shared__ double red[4]; __shared__ double s_scale;
+    const int trial = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const double f = focals[trial], tf = f / focal_guess;
+    double* rnew = rnew_all + (size_t)trial * E * 3; double* x = x_all + (size_t)trial * n * 3; double* rot = rot_all + (size_t)trial * n * 9;
+    double mx = 0.0;
+    for (int e = tid; e < E; e += nt) {
+        double En[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) En[3 * i + j] = Es[9 * (size_t)e + 3 * i + j] * ((i < 2) ? tf : 1.0) * ((j < 2) ? tf : 1.0);
+        double r[3]; decompose_E_dev(En, inward != 0, r);
+        // the reference stores so3exp(r_new) and get_cost takes so3ln of it again
+        double Rm[9], rr[3]; so3exp(r, Rm); so3ln(Rm, rr);
+        rnew[3 * e] = rr[0]; rnew[3 * e + 1] = rr[1]; rnew[3 * e + 2] = rr[2];
+        mx = fmax(mx, norm3(rr));
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) { double m = 0; for (int w = 0; w < (nt >> 6); w++) m = fmax(m, red[w]); s_scale = 1.0 / m; }
+    // chain (lane 0; global writes of this block are visible to it after the barrier above)
+    if (tid == 0) {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; k++) rot[k] = R[k];
+        for (int idx = 1; idx < n; idx++) {
+            const int e = chain_edge[idx];
+            double* dst = rot + 9 * (size_t)idx;
+            if (e >= 0) {
+                double Rm[9], Rn[9]; so3exp(rnew + 3 * e, Rm); mat3_mul(Rm, R, Rn);
+                for (int k = 0; k < 9; k++) { R[k] = Rn[k]; dst[k] = Rn[k]; }
+            } else { for (int k = 0; k < 9; k++) dst[k] = (k % 4 == 0) ? 1.0 : 0.0; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) so3ln(rot + 9 * (size_t)i, x + 3 * i);
+    __syncthreads();
+    const double scale = s_scale;
+    double c = 0.0;
+    for (int e = tid; e < E; e += nt) {
+        double Rm[9], R0[9], R1[9], A[9], C[9], res[3];
+        angle_axis_to_matrix(rnew + 3 * e, Rm); angle_axis_to_matrix(x + 3 * e0[e], R0); angle_axis_to_matrix(x + 3 * e1[e], R1);
+        mat3_mul_bt(R1, R0, A); mat3_mul_bt(A, Rm, C);
+        matrix_to_angle_axis(C, res);
+        const double s2 = scale * scale * (res[0] * res[0] + res[1] * res[1] + res[2] * res[2]);
+        double rho0, rho1; robust_loss(2, 0.03, s2, rho0, rho1);
+        c += 0.5 * rho0;
+    }
+    c = wave_sum(c);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int w = 0; w < (nt >> 6); w++) t += red[w]; costs[trial] = t; }
+}
+
 }  // namespace ssfm
 using namespace ssfm;
 
@@ -623,3 +686,51 @@ extern "C" int ssfm_spherical_solver_probe(ssfm_ctx* ctx, int32_t n, const doubl
                                            double* Es, int32_t* counts) { return solver_probe(ctx, false, n, u, v, S, samples, Es, counts); }
 extern "C" int ssfm_spherical_solver_poly_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples,
                                                 double* Es, int32_t* counts) { return solver_probe(ctx, true, n, u, v, S, samples, Es, counts); }
+
+// find_best_focal_length_random without its random draw (examples/spherical_sfm_tools.cpp:1418-1496): the caller supplies the
+// trial focals; costs[t] = loop_constraint_cost_fn(focals[t]); best_trial = first minimum; rotations_best = the sequential
+// initialisation at that focal (column-major 3x3 per camera), ready for ssfm_posegraph_focal_solve (run_optimization, :1160-1188).
+extern "C" int ssfm_focal_search(ssfm_ctx* ctx, int32_t n, int32_t E, const int32_t* index0, const int32_t* index1, const double* rel_rotations,
+                                 int32_t inward, double focal_guess, int32_t num_trials, const double* focals, double* costs,
+                                 int32_t* best_trial, double* rotations_best, double* rel_rotations_best) {
+    if (!ctx || n <= 0 || E <= 0 || num_trials <= 0 || !index0 || !index1 || !rel_rotations || !focals)
+        return fail(ctx, SSFM_ERR_INVALID, "ssfm_focal_search: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // Es[i] = make_spherical_essential_matrix(R_i, inward) (:1429-1433), row-major for the device
+    std::vector<double> Es((size_t)9 * E); std::vector<int> e0(index0, index0 + E), e1(index1, index1 + E), chain(n, -1);
+    for (int e = 0; e < E; e++) {
+        double Rm[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rm[3 * i + j] = rel_rotations[9 * (size_t)e + i + 3 * j];
+        double t[3] = {Rm[2], Rm[5], Rm[8] - 1.0}; if (inward) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+        double* Em = &Es[9 * (size_t)e];
+        for (int j = 0; j < 3; j++) { Em[j] = t[1] * Rm[6 + j] - t[2] * Rm[3 + j]; Em[3 + j] = t[2] * Rm[j] - t[0] * Rm[6 + j]; Em[6 + j] = t[0] * Rm[3 + j] - t[1] * Rm[j]; }
+        if (index1[e] >= 1 && index1[e] < n && index0[e] == index1[e] - 1 && chain[index1[e]] < 0) chain[index1[e]] = e;      // first match (k-1, k), :804-810
+    }
+    DevBuf<double> dEs, dF, dR, dX, dRot, dC; DevBuf<int> de0, de1, dch;
+    std::vector<double> fv(focals, focals + num_trials);
+    SSFM_HIP_CHECK(ctx, upload(dEs, Es, st)); SSFM_HIP_CHECK(ctx, upload(dF, fv, st)); SSFM_HIP_CHECK(ctx, upload(de0, e0, st));
+    SSFM_HIP_CHECK(ctx, upload(de1, e1, st)); SSFM_HIP_CHECK(ctx, upload(dch, chain, st));
+    SSFM_HIP_CHECK(ctx, dR.alloc((size_t)num_trials * E * 3)); SSFM_HIP_CHECK(ctx, dX.alloc((size_t)num_trials * n * 3));
+    SSFM_HIP_CHECK(ctx, dRot.alloc((size_t)num_trials * n * 9)); SSFM_HIP_CHECK(ctx, dC.alloc(num_trials));
+    hipLaunchKernelGGL(k_focal_trials, dim3(num_trials), dim3(256), 0, st, n, E, de0.p, de1.p, dch.p, dEs.p, inward, focal_guess, dF.p, dR.p, dX.p, dRot.p, dC.p);
+    std::vector<double> hc(num_trials);
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), dC.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    int best = 0; for (int t = 1; t < num_trials; t++) if (hc[t] < hc[best]) best = t;                 // :1467-1474 (strict <, first minimum)
+    if (costs) std::memcpy(costs, hc.data(), hc.size() * sizeof(double));
+    if (best_trial) *best_trial = best;
+    if (rotations_best) {
+        std::vector<double> hr((size_t)n * 9);
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), dRot.p + (size_t)best * n * 9, hr.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (int i = 0; i < n; i++) rm_to_cm(&hr[9 * (size_t)i], rotations_best + 9 * (size_t)i);
+    }
+    if (rel_rotations_best) {                              // the matches as transform_image_matches leaves them at the best focal
+        std::vector<double> hr((size_t)E * 3);
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), dR.p + (size_t)best * E * 3, hr.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (int e = 0; e < E; e++) { double Rm[9]; so3exp(&hr[3 * (size_t)e], Rm); rm_to_cm(Rm, rel_rotations_best + 9 * (size_t)e); }
+    }
+    dEs.free(); dF.free(); dR.free(); dX.free(); dRot.free(); dC.free(); de0.free(); de1.free(); dch.free();
+    return SSFM_OK;
+}

@@ -52,3 +52,18 @@ def optimize_rotations_and_focal_length(ctx, rotations, index0, index1, rel_rota
                                                      i1.ctypes.data_as(c_i32_p), rel.ctypes.data_as(c_double_p), C.byref(f), min_focal, max_focal,
                                                      C.byref(o), C.byref(s)), ctx._p)
     return np.transpose(buf.reshape(-1, 3, 3), (0, 2, 1)).copy(), f.value, s.final_cost, s.as_dict()
+
+
+def focal_search(ctx, num_cameras, index0, index1, rel_rotations, focal_guess, focals, inward=False, return_matches=False):
+    """find_best_focal_length_random (examples/spherical_sfm_tools.cpp:1418-1496) for caller-supplied trial focals ->
+    (costs (T,), best_trial, rotations at the best focal (n,3,3)); with return_matches=True also the matches' rotations
+    re-derived at the best focal (E,3,3)."""
+    i0, i1, rel = _edges(index0, index1, rel_rotations)
+    fv = np.ascontiguousarray(focals, np.float64); T = len(fv)
+    costs = np.zeros(T); best = C.c_int32(0); rot = np.zeros(9 * num_cameras); relb = np.zeros(9 * len(i0))
+    _lib.check(_lib.lib().ssfm_focal_search(ctx._p, num_cameras, len(i0), i0.ctypes.data_as(c_i32_p), i1.ctypes.data_as(c_i32_p),
+                                            rel.ctypes.data_as(c_double_p), int(bool(inward)), float(focal_guess), T, fv.ctypes.data_as(c_double_p),
+                                            costs.ctypes.data_as(c_double_p), C.byref(best), rot.ctypes.data_as(c_double_p),
+                                            relb.ctypes.data_as(c_double_p)), ctx._p)
+    out = (costs, best.value, np.transpose(rot.reshape(-1, 3, 3), (0, 2, 1)).copy())
+    return out + (np.transpose(relb.reshape(-1, 3, 3), (0, 2, 1)).copy(),) if return_matches else out

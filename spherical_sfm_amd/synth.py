@@ -180,3 +180,4 @@ def corrupt_observations(prob, frac=0.1, seed=5, lo=30.0, hi=80.0):
         xy[i] += r * np.array([np.cos(ang), np.sin(ang)])
     prob.obs_xy = xy
     return pts
+
