@@ -3,6 +3,7 @@
 // POD stand-ins for the Eigen types, as in sfm.h.  Host code only.
 #pragma once
 #include <array>
+#include <cstddef>
 #include <map>
 #include <vector>
 #include "../../../include/ssfm.h"
@@ -10,7 +11,7 @@
 namespace sphericalsfm {
 
 typedef std::array<double, 9> Mat3;                       // column-major like Eigen::Matrix3d::data()
-typedef std::map<size_t, size_t> Matches;                 // spherical_sfm_tools.h:20
+typedef std::map<std::size_t, std::size_t> Matches;                 // spherical_sfm_tools.h:20
 
 struct ImageMatch {                                       // spherical_sfm_tools.h:41-50
     int index0, index1;

@@ -60,3 +60,19 @@ def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
     Xo, nin = oracle.retriangulate(prob1)
     rel = np.linalg.norm(p2 - Xo, axis=1) / np.linalg.norm(Xo, axis=1)
     assert np.quantile(rel, 0.99) <= 1e-4 and np.median(rel) <= 1e-5
+
+
+def test_cpp_focal_search_wrapper(tmp_path):
+    """find_best_focal_length_random with the reference's signature (csrc/shim/tools.cpp) on a ring that is consistent with the
+    guessed focal: 256 trials on the GPU, first minimum, joint refinement -> the guess comes back, the ring closes."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "demo_focal")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("FOCAL_RESULT")][0]
+    r = dict(kv.split("=") for kv in line.split()[1:])
+    assert r["ok"] == "1" and r["n"] == "48"
+    assert abs(float(r["focal"]) - 1000.0) < 10.0 and float(r["max_rot_err"]) < 2e-3
