@@ -38,6 +38,11 @@ enum {
     SC_STEP2_CAM = 11, SC_XN2_CAM = 12, SC_X0N2_CAM = 13,   // replicated camera/focal parts
     SC_TOTAL = 16
 };
+// Same-address floating-point atomics serialise at ~12 ns each (measured: k_point_lin 41 us with 391 workgroups x 6 atomics,
+// 110 us with 1563 x 6), so the per-workgroup partial sums go to one of SC_NSLOT replicas of the scalar block (workgroup id
+// mod SC_NSLOT); readers fold the replicas (k_finalize_S on the device, the host after the copy, k_scal_fold before a collective).
+constexpr int SC_NSLOT = 64;
+__device__ __forceinline__ double* scal_slot(double* scal) { return scal + (size_t)(blockIdx.x & (SC_NSLOT - 1)) * SC_TOTAL; }
 enum { PCG_RZ = 0, PCG_BN2 = 1, PCG_RR = 2, PCG_DONE = 3, PCG_ITERS = 4, PCG_BREAKDOWN = 5, PCG_TOTAL = 8 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -273,10 +278,11 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
     }
     block_sum<5>(acc, red);
     gmax = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
+    double* sl = scal_slot(scal);
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(&scal[SC_COST], acc[0]); unsafeAtomicAdd(&scal[SC_FJJ], acc[1]); unsafeAtomicAdd(&scal[SC_FJR], acc[2]);
-        unsafeAtomicAdd(&scal[SC_FWW], acc[3]); unsafeAtomicAdd(&scal[SC_FWG], acc[4]);
+        unsafeAtomicAdd(&sl[SC_COST], acc[0]); unsafeAtomicAdd(&sl[SC_FJJ], acc[1]); unsafeAtomicAdd(&sl[SC_FJR], acc[2]);
+        unsafeAtomicAdd(&sl[SC_FWW], acc[3]); unsafeAtomicAdd(&sl[SC_FWG], acc[4]);
     }
 }
 
@@ -587,14 +593,17 @@ __global__ void k_finalize_S(const int* __restrict__ row_ptr, const int* __restr
     }
     gmax = wave_max(gmax);
     if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double sf = scale_f[0];
-        if (sf > 0.0) {
-            const double fjj = scal[SC_FJJ];
-            Sff[0] = fjj + fmin(fmax(fjj, min_diag), max_diag) / radius - scal[SC_FWW];
-            rhs[Nc * DC] = scal[SC_FJR] - scal[SC_FWG];
-            atomic_max_nonneg(&scal[SC_GMAX], fabs(scal[SC_FJR] / sf));
-        } else { Sff[0] = 1.0; rhs[Nc * DC] = 0.0; }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {             // wave 0 of workgroup 0 folds the replicas of the focal sums (blockDim = 64)
+        const double* sl = scal + (size_t)(threadIdx.x & (SC_NSLOT - 1)) * SC_TOTAL;
+        const double fjj = wave_sum(sl[SC_FJJ]), fww = wave_sum(sl[SC_FWW]), fjr = wave_sum(sl[SC_FJR]), fwg = wave_sum(sl[SC_FWG]);
+        if (threadIdx.x == 0) {
+            const double sf = scale_f[0];
+            if (sf > 0.0) {
+                Sff[0] = fjj + fmin(fmax(fjj, min_diag), max_diag) / radius - fww;
+                rhs[Nc * DC] = fjr - fwg;
+                atomic_max_nonneg(&scal[SC_GMAX], fabs(fjr / sf));
+            } else { Sff[0] = 1.0; rhs[Nc * DC] = 0.0; }
+        }
     }
 }
 
@@ -800,14 +809,14 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         }
     }
     block_sum<3>(acc, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[SC_MODEL], acc[0]); unsafeAtomicAdd(&scal[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&scal[SC_XN2_PT], acc[2]); }
+    if (threadIdx.x == 0) { double* sl = scal_slot(scal); unsafeAtomicAdd(&sl[SC_MODEL], acc[0]); unsafeAtomicAdd(&sl[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&sl[SC_XN2_PT], acc[2]); }
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------
 static __global__ void __launch_bounds__(256)
 k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
-             const int* __restrict__ pt_start, int nP, int loss, double la, double* __restrict__ out) {
+             const int* __restrict__ pt_start, int nP, int loss, double la, double* __restrict__ out, int slot_stride) {
     __shared__ double red[4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[1] = {0.0};
@@ -820,7 +829,19 @@ k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, con
         }
     }
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc[0]);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out + (size_t)(blockIdx.x & (SC_NSLOT - 1)) * slot_stride, acc[0]);   // slot_stride 0: a single scalar
+}
+
+// fold the SC_NSLOT replicas of the scalar block into replica 0 (sums; SC_GMAX by max) and clear the others: run before a
+// collective reduces the block, by ONE workgroup of SC_TOTAL * 64 lanes
+static __global__ void __launch_bounds__(SC_TOTAL * 64)
+k_scal_fold(double* __restrict__ scal) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* p = scal + (size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k;
+    const double v = *p;
+    const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);           // non-negative doubles order like their bit patterns
+    __syncthreads();
+    *p = (lane == 0) ? r : 0.0;
 }
 
 // |x|^2 over free parameters (iteration 0)

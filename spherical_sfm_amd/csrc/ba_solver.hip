@@ -31,14 +31,24 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const int Nc = F.Nc, nP = F.nP; const int n = Nc * DC;
     const int loss = O.loss_type; const double la = O.loss_scale;
     const int gp_pts = (nP + 255) / 256, gp_cam = (Nc + 63) / 64;
+    // lane-per-point kernels of the LM loop run as single-wave workgroups: 4x more workgroups spread evenly over the CUs
+    static const int PTB = std::getenv("SSFM_PT_BLOCK") ? std::atoi(std::getenv("SSFM_PT_BLOCK")) : 256;
+    const int gp_pts_lm = (nP + PTB - 1) / PTB;
     const double2* oxy = reinterpret_cast<const double2*>(h->obs_xy.p);
     double* fx = h->focal3.p; double* fc = h->focal3.p + 1;
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
     // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
-    double host_sp[SC_TOTAL + PCG_TOTAL + 1];            // [scalars | solver flags], one copy per iteration
-    double* host_scal = host_sp; double* host_pcg1 = host_sp + SC_TOTAL;
+    double host_sp[SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1];            // [scalar replicas | solver flags], one copy per iteration
+    double* host_scal = host_sp; double* host_pcg1 = host_sp + SC_NSLOT * SC_TOTAL;
+    auto fold_host_scal = [&]() {                                    // replicas -> replica 0 (sums; the gradient max by max)
+        for (int k = 0; k < SC_TOTAL; k++) {
+            double a = host_sp[k];
+            for (int s2 = 1; s2 < SC_NSLOT; s2++) { const double v = host_sp[(size_t)s2 * SC_TOTAL + k]; a = (k == SC_GMAX) ? std::max(a, v) : a + v; }
+            host_sp[k] = a;
+        }
+    };
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
@@ -82,7 +92,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));   // scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0)
-            LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
+            LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p);
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         if (!F.cs_task_cam.empty()) {
@@ -97,6 +107,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
         if (ctx->collective) {
+            hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p);
             // scalar sums ride at the tail of the same buffer
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
             int rc = allreduce(h, h->redbuf.p, (size_t)h->n_red, ncclSum); if (rc) return rc;
@@ -116,27 +127,30 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         auto enqueue_tail = [&]() -> int {
             LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, h->scal.p);
             if (nP > 0)
-                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                        h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, pts_c, h->scal.p);
             LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
             if (nP > 0)
-                LAUNCH(h, KID_COST, k_point_cost, gp_pts, 256, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST);
+                LAUNCH(h, KID_COST, k_point_cost, gp_pts_lm, PTB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST, (int)SC_TOTAL);
+            if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
-            hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
+            hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;
         };
         { int rc = enqueue_tail(); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        fold_host_scal();
         if (O.preconditioner == 0) {
             int fail_flag; std::memcpy(&fail_flag, &host_pcg1[PCG_TOTAL], sizeof(int));
             if (fail_flag) pcg_ok = false;
             else if (host_pcg1[PCG_DONE] == 0.0) {
                 int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 1); if (rc) return rc;
-                SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_MODEL, 0, 4 * sizeof(double), st));
+                SSFM_HIP_CHECK(ctx, hipMemset2DAsync(h->scal.p + SC_MODEL, SC_TOTAL * sizeof(double), 0, 4 * sizeof(double), SC_NSLOT, st));   // MODEL..CAND_COST of every replica
                 rc = enqueue_tail(); if (rc) return rc;
                 SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                fold_host_scal();
             }
         }
         h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
@@ -260,8 +274,8 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->n_red = (int)n_red;
     // [scal | pcg flags + factorisation fail word | redbuf] share one allocation: one memset per LM iteration zeroes them all,
     // and one copy brings both scalar groups back
-    AL(zone, SC_TOTAL + PCG_TOTAL + 1 + n_red);
-    h->scal.p = h->zone.p; h->scal.n = SC_TOTAL; h->pcg.p = h->zone.p + SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
+    AL(zone, SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red);
+    h->scal.p = h->zone.p; h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.p = h->zone.p + SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
     h->redbuf.p = h->pcg.p + PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
     h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * DC * DC; h->Udiag = h->rhs + (n + 1); h->Sfc = h->Udiag + n;
     h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
@@ -377,7 +391,7 @@ extern "C" int ssfm_ba_evaluate(ssfm_ba_handle* h, double* cost, double* residua
         hipLaunchKernelGGL(k_eval_dump, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, h->cam_x.p, h->rot_x.p, h->pts_x.p, h->focal3.p, oxy,
                            h->obs_cam.p, h->obs_pt.p, (int)M, h->opt.loss_type, h->opt.loss_scale, dres.p, djac.p);
         hipLaunchKernelGGL(k_point_cost, dim3((nP + 255) / 256), dim3(256), 0, st, h->cam_x.p, h->rot_x.p, h->pts_x.p, h->focal3.p, oxy, h->obs_cam.p,
-                           h->pt_start.p, nP, h->opt.loss_type, h->opt.loss_scale, dcost.p);
+                           h->pt_start.p, nP, h->opt.loss_type, h->opt.loss_scale, dcost.p, 0);
     }
     std::vector<double> res((size_t)M * 2), jac((size_t)M * 20); double c = 0;
     if (M > 0) {

@@ -277,7 +277,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     ALV(h->redbuf, n_red);
     h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * 9; h->Udiag = h->rhs + (nn + 1); h->Sfc = h->Udiag + nn; h->gcraw = h->Sfc + nn;
     ALV(h->Minv, (size_t)n * 9); ALV(h->Sff, 1); ALV(h->px, nn + 1); ALV(h->pr, nn + 1); ALV(h->pz, nn + 1); ALV(h->pp, nn + 1); ALV(h->pq, nn + 1);
-    ALV(h->pqpart, (size_t)n); ALV(h->scal, SC_TOTAL); ALV(h->pcg, PCG_TOTAL + 1);
+    ALV(h->pqpart, (size_t)n); ALV(h->scal, SC_NSLOT * SC_TOTAL); ALV(h->pcg, PCG_TOTAL + 1);
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_NSLOT * SC_TOTAL * sizeof(double), st));    // this solver only ever writes replica 0 (k_finalize_S folds all of them)
     ALV(h->band, (size_t)n * (F.band + 1) * 9); ALV(h->Linv, (size_t)n * 9); ALV(h->Yb, 2 * nn); ALV(h->Yr, 2 * nn);
 #undef ALV
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
