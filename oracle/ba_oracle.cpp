@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <array>
 #include <vector>
 #include "lm.hpp"
 #include "rotation.hpp"
@@ -605,6 +607,30 @@ extern "C" int oracle_ba_reduced_system(const oracle_ba_problem* p, const oracle
             }
     }
     return 0;
+}
+
+// The reference's own problem-building loop (src/sfm.cpp:240-263) on its own storage (std::map-based SparseVector / SparseMatrix,
+// include/sphericalsfm/sparse.hpp): for every point, every camera is probed twice.  Timed only -- it quantifies the host overhead
+// of SfM::Optimize() that the port's O(M) flatten does not have.  Returns the number of residual blocks it would add.
+extern "C" int64_t oracle_reference_style_flatten(const oracle_ba_problem* p, double* seconds) {
+    std::map<int, std::array<double, 6>> cameras; std::map<int, std::array<double, 3>> points;
+    std::map<int, std::map<int, std::array<double, 2>>> observations;                 // [camera][point]
+    for (int i = 0; i < p->num_cameras; i++) { std::array<double, 6> c; for (int k = 0; k < 6; k++) c[k] = p->cameras[6 * (size_t)i + k]; cameras[i] = c; }
+    for (int j = 0; j < p->num_points; j++) { std::array<double, 3> X; for (int k = 0; k < 3; k++) X[k] = p->points[3 * (size_t)j + k]; points[j] = X; }
+    for (int64_t o = 0; o < p->num_observations; o++) observations[p->obs_cam[o]][p->obs_pt[o]] = {p->obs_xy[2 * o], p->obs_xy[2 * o + 1]};
+    auto exists2 = [&](int r, int c) { auto it = observations.find(r); if (it == observations.end()) return false; return it->second.find(c) != it->second.end(); };
+    const double t0 = now_s();
+    int64_t added = 0;
+    for (int j = 0; j < p->num_points; j++) {
+        auto pit = points.find(j); if (pit == points.end()) continue;
+        const auto& X = pit->second; if (std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) == 0) continue;
+        int nobs = 0;
+        for (int i = 0; i < p->num_cameras; i++) { if (cameras.find(i) == cameras.end()) continue; if (!exists2(i, j)) continue; nobs++; }
+        if (nobs < 3) continue;
+        for (int i = 0; i < p->num_cameras; i++) { if (cameras.find(i) == cameras.end()) continue; if (!exists2(i, j)) continue; added++; }
+    }
+    if (seconds) *seconds = now_s() - t0;
+    return added;
 }
 
 extern "C" void oracle_so3exp(const double r[3], double R[9]) { so3exp(r, R); }

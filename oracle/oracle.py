@@ -280,6 +280,14 @@ def ransac_pair(u, v, sq_thresh, inward=False, min_iterations=100, max_iteration
     return dict(E=_um(E), R=_um(R), inliers=mask.astype(bool), num_inliers=n, iterations=it.value, score=sc.value)
 
 
+def reference_style_flatten(prob):
+    """(residual blocks, seconds) of the reference's own O(Np x Nc) build loop on std::map storage (src/sfm.cpp:240-263)."""
+    h = _Held(prob); sec = C.c_double(0)
+    lib().oracle_reference_style_flatten.restype = C.c_int64
+    n = lib().oracle_reference_style_flatten(C.byref(h.c), C.byref(sec))
+    return int(n), sec.value
+
+
 def retriangulate(prob, num_threads=16):
     """SfM::Retriangulate on a BAProblem-like object -> (points (Np,3), num_inliers (Np,))"""
     h = _Held(prob)

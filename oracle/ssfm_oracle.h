@@ -61,6 +61,8 @@ int oracle_ba_solve(oracle_ba_problem* p, const oracle_lm_options* o, oracle_sum
 /* one evaluation at the given state: cost, per-observation residuals [M*2] (robustified),
  * and Jacobian blocks per observation [M*2*10] (columns: focal, t(3), r(3), X(3); unrobustified
  * raw autodiff Jacobian when raw!=0).  Observations of unused points get zeros.  Outputs may be NULL. */
+/* the reference's O(Np x Nc) map-probing build loop (src/sfm.cpp:240-263), timed; returns the residual blocks it would add */
+int64_t oracle_reference_style_flatten(const oracle_ba_problem* p, double* seconds);
 int oracle_ba_evaluate(const oracle_ba_problem* p, const oracle_lm_options* o, int32_t raw,
                        double* cost, double* residuals, double* jacobians, uint8_t* obs_used);
 

@@ -15,8 +15,11 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 #include <vector>
 #include "../../include/ssfm.h"
 
@@ -60,6 +63,20 @@ struct BAFlat {
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
 };
 
+// fork-join over [0, n) in T contiguous chunks on std::thread (the planner's loops over cameras / points are independent once the
+// prefix sums are known); f(thread index, begin, end)
+template <class Fn>
+inline void parallel_chunks(int64_t n, int T, Fn f) {
+    if (T <= 1 || n < 4 * (int64_t)T) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th; th.reserve(T);
+    for (int t = 0; t < T; t++) th.emplace_back([=]() { f(t, n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+}
+inline int planner_threads() {
+    if (const char* e = std::getenv("SSFM_PLAN_THREADS")) return std::max(1, std::atoi(e));
+    return (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));        // measured on the MI355X host: 4 threads halve the plan, 16 add nothing
+}
+
 // Cuthill-McKee order of the camera graph given as block-CSR structure (folds a ring into a band of twice
 // its reach; any connected "video-like" graph becomes a narrow band).  Returns the half-bandwidth.
 inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos,
@@ -94,8 +111,13 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
 }
 
 inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
+    const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; const auto t = std::chrono::steady_clock::now();
+                                       std::fprintf(stderr, "[plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
     const int Nc = P.num_cameras, Np = P.num_points;
     const int64_t M = P.num_observations;
+    const int NT = planner_threads();
     F = BAFlat();
     F.Nc = Nc; F.focal_free = !P.focal_fixed;
     if (Nc == 0 || Np == 0 || M == 0) { F.nothing_to_do = true; return; }
@@ -123,32 +145,50 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         if (valid) segs.push_back({p, i, e, nobs});
         i = e;
     }
+    lap("sorted check + segments");
     F.nP_global = (int)segs.size();
     for (const Seg& s : segs) F.M_global += s.nobs;
     if (segs.empty()) { F.nothing_to_do = true; return; }
     // ---- structure of S and camera activity come from ALL used points (identical on every rank)
     std::vector<char> cam_in(Nc, 0);
     {
-        std::vector<std::vector<int>> nb(Nc);
-        std::vector<int> cams;
-        for (const Seg& s : segs) {
-            cams.clear(); int last = -1;
-            for (int64_t i = s.begin; i < s.end; i++) { const int c = P.obs_cam[at(i)]; if (c != last && c >= 0 && c < Nc) { cams.push_back(c); last = c; } }
-            for (int a : cams) { cam_in[a] = 1; for (int b : cams) if (nb[a].empty() || nb[a].back() != b) nb[a].push_back(b); }
+        // camera-major view of the used observations (global), then per camera one sweep over its points' camera lists with a
+        // "last row that saw this column" mark: O(M K) without sorting M K entries
+        std::vector<int> gstart(Nc + 1, 0);
+        std::vector<int64_t> seg_first(segs.size() + 1, 0);           // compacted (deduplicated) camera lists per used point
+        std::vector<int> seg_cams; seg_cams.reserve((size_t)F.M_global);
+        for (size_t k = 0; k < segs.size(); k++) {
+            const Seg& sg = segs[k]; int last = -1;
+            for (int64_t i = sg.begin; i < sg.end; i++) { const int c = P.obs_cam[at(i)]; if (c != last && c >= 0 && c < Nc) { seg_cams.push_back(c); gstart[c + 1]++; cam_in[c] = 1; last = c; } }
+            seg_first[k + 1] = (int64_t)seg_cams.size();
         }
-        F.row_ptr.assign(Nc + 1, 0); F.diag_slot.assign(Nc, -1);
+        for (int c = 0; c < Nc; c++) gstart[c + 1] += gstart[c];
+        std::vector<int> gseg(seg_cams.size());                       // for every camera: the used points (segment ids) it observes
+        { std::vector<int> fill(gstart.begin(), gstart.end() - 1);
+          for (size_t k = 0; k < segs.size(); k++) for (int64_t i = seg_first[k]; i < seg_first[k + 1]; i++) gseg[fill[seg_cams[i]]++] = (int)k; }
+        std::vector<std::vector<int>> rows(Nc);
+        parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+            std::vector<int> mark(Nc, -1);
+            for (int c = (int)c0; c < (int)c1; c++) {
+                std::vector<int>& row = rows[c];
+                for (int q = gstart[c]; q < gstart[c + 1]; q++) {
+                    const int k = gseg[q];
+                    for (int64_t i = seg_first[k]; i < seg_first[k + 1]; i++) { const int b2 = seg_cams[i]; if (mark[b2] != c) { mark[b2] = c; row.push_back(b2); } }
+                }
+                if (row.empty()) row.push_back(c);          // isolated camera: identity row
+                std::sort(row.begin(), row.end());
+            }
+        });
+        F.row_ptr.assign(Nc + 1, 0); F.diag_slot.assign(Nc, -1); F.col_idx.clear(); F.col_idx.reserve((size_t)Nc * 16);
         for (int c = 0; c < Nc; c++) {
-            auto& v = nb[c]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
-            if (v.empty()) v.push_back(c);          // isolated camera: identity row
-            F.row_ptr[c + 1] = F.row_ptr[c] + (int)v.size();
-            F.max_row_blocks = std::max(F.max_row_blocks, (int)v.size());
-        }
-        F.col_idx.resize(F.row_ptr[Nc]);
-        for (int c = 0; c < Nc; c++) {
-            std::copy(nb[c].begin(), nb[c].end(), F.col_idx.begin() + F.row_ptr[c]);
-            F.diag_slot[c] = (int)(std::lower_bound(nb[c].begin(), nb[c].end(), c) - nb[c].begin());
+            const std::vector<int>& row = rows[c];
+            F.diag_slot[c] = (int)(std::lower_bound(row.begin(), row.end(), c) - row.begin());
+            F.col_idx.insert(F.col_idx.end(), row.begin(), row.end());
+            F.row_ptr[c + 1] = (int)F.col_idx.size();
+            F.max_row_blocks = std::max(F.max_row_blocks, (int)row.size());
         }
     }
+    lap("S structure");
     F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     {   // keep the lower triangle (in elimination order) only
@@ -168,6 +208,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         std::vector<int> fill(cnt.begin(), cnt.end() - 1);
         for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] != c) { const int k = fill[F.col_idx[e]]++; F.trans_blk[k] = e; F.trans_row[k] = c; }
     }
+    lap("ordering + lower triangle");
     F.mask_cam.assign((size_t)Nc * 6, 0.0);
     bool all_t_fixed = true;
     for (int c = 0; c < Nc; c++) {
@@ -192,20 +233,29 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     }
     // ---- pass 2: emit local observations
     F.nP = (int)(s1 - s0);
-    F.pt_ids.reserve(F.nP); F.pt_start.assign(1, 0); F.pts0.reserve((size_t)F.nP * 3); F.mask_pt.reserve((size_t)F.nP * 3);
-    for (size_t k = s0; k < s1; k++) {
-        const Seg& s = segs[k];
-        for (int64_t i = s.begin; i < s.end; i++) {
-            const int64_t o = at(i); const int c = P.obs_cam[o];
-            if (c < 0 || c >= Nc) continue;
-            if (i + 1 < s.end && P.obs_cam[at(i + 1)] == c) continue;     // keep the last duplicate
-            F.obs_cam.push_back(c); F.obs_pt.push_back((int)F.pt_ids.size()); F.obs_orig.push_back(o);
-            F.obs_xy.push_back(P.obs_xy[2 * o]); F.obs_xy.push_back(P.obs_xy[2 * o + 1]);
-        }
-        const double m = (P.pt_fixed && P.pt_fixed[s.pt]) ? 0.0 : 1.0;
-        for (int d = 0; d < 3; d++) { F.pts0.push_back(P.points[(size_t)s.pt * 3 + d]); F.mask_pt.push_back(m); }
-        F.pt_ids.push_back(s.pt); F.pt_start.push_back((int)F.obs_cam.size());
+    {
+        int64_t mloc = 0; for (size_t k = s0; k < s1; k++) mloc += segs[k].nobs;
+        F.pt_ids.resize(F.nP); F.pt_start.resize((size_t)F.nP + 1); F.pts0.resize((size_t)F.nP * 3); F.mask_pt.resize((size_t)F.nP * 3);
+        F.obs_cam.resize(mloc); F.obs_pt.resize(mloc); F.obs_orig.resize(mloc); F.obs_xy.resize((size_t)mloc * 2);
+        F.pt_start[0] = 0;
+        for (size_t k = s0; k < s1; k++) F.pt_start[k - s0 + 1] = F.pt_start[k - s0] + segs[k].nobs;
+        parallel_chunks((int64_t)(s1 - s0), NT, [&](int, int64_t q0, int64_t q1) {
+            for (int64_t q = q0; q < q1; q++) {
+                const Seg& sg = segs[s0 + (size_t)q];
+                int64_t w = F.pt_start[q];
+                for (int64_t i = sg.begin; i < sg.end; i++) {
+                    const int64_t o = at(i); const int c = P.obs_cam[o];
+                    if (c < 0 || c >= Nc) continue;
+                    if (i + 1 < sg.end && P.obs_cam[at(i + 1)] == c) continue;     // keep the last duplicate
+                    F.obs_cam[w] = c; F.obs_pt[w] = (int)q; F.obs_orig[w] = o; F.obs_xy[2 * w] = P.obs_xy[2 * o]; F.obs_xy[2 * w + 1] = P.obs_xy[2 * o + 1]; w++;
+                }
+                const double m = (P.pt_fixed && P.pt_fixed[sg.pt]) ? 0.0 : 1.0;
+                for (int d = 0; d < 3; d++) { F.pts0[(size_t)q * 3 + d] = P.points[(size_t)sg.pt * 3 + d]; F.mask_pt[(size_t)q * 3 + d] = m; }
+                F.pt_ids[q] = sg.pt;
+            }
+        });
     }
+    lap("emit observations");
     F.M = (int64_t)F.obs_cam.size();
     F.cam_start.assign(Nc + 1, 0);
     for (int64_t j = 0; j < F.M; j++) F.cam_start[F.obs_cam[j] + 1]++;
@@ -217,39 +267,63 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
     for (int c = 0; c < Nc; c++)
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
+    lap("camera-major lists");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     int task_batches = 16;                                   // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
     if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
     F.cam_batch_ptr.assign(Nc + 1, 0);
-    std::vector<std::vector<int>> by_slot;      // reused per camera: entries (j, j2) interleaved
-    for (int c = 0; c < Nc; c++) {
-        const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb;
-        by_slot.assign(nnb, std::vector<int>());
-        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
-            const int j = F.cam_obs[q], p = F.obs_pt[j];
-            for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
-                const int c2 = F.obs_cam[j2];
-                if (F.cam_pos[c2] >= F.cam_pos[c]) continue;          // diagonal blocks are built by k_cam_sums
-                const int slot = (int)(std::lower_bound(F.col_idx.begin() + rb, F.col_idx.begin() + rb + nnb, c2) - (F.col_idx.begin() + rb));
-                by_slot[slot].push_back(j); by_slot[slot].push_back(j2);
+    {
+        // two sweeps per camera, both parallel over cameras: count the pairs of every slot; (serial) offsets of the 64-padded
+        // batches; fill in place
+        const size_t nnzb = F.col_idx.size();
+        std::vector<int> slot_cnt(nnzb, 0);
+        parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+            std::vector<int> slot_of(Nc, -1);
+            for (int c = (int)c0; c < (int)c1; c++) {
+                const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
+                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
+                for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
+                    const int p = F.cam_obs_pt[q];
+                    for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) { const int c2 = F.obs_cam[j2]; if (F.cam_pos[c2] < pc) slot_cnt[rb + slot_of[c2]]++; }   // diagonal blocks: k_cam_sums2
+                }
+                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
+            }
+        });
+        std::vector<int64_t> slot_off(nnzb, 0);                       // first pair entry of every slot
+        int64_t nbatch_total = 0;
+        for (int c = 0; c < Nc; c++) {
+            int nbatch = 0;
+            for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) {
+                if (slot_cnt[e] == 0) continue;
+                const int nb = (slot_cnt[e] + 63) / 64;
+                slot_off[e] = (nbatch_total + nbatch) * 64;
+                for (int b2 = 0; b2 < nb; b2++) F.batch_slot.push_back(e - F.row_ptr[c]);
+                nbatch += nb;
+            }
+            F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch; nbatch_total += nbatch;
+            for (int b2 = F.cam_batch_ptr[c]; b2 < F.cam_batch_ptr[c + 1]; b2 += task_batches) {
+                F.chunk_cam.push_back(c); F.chunk_b0.push_back(b2); F.chunk_b1.push_back(std::min(b2 + task_batches, F.cam_batch_ptr[c + 1]));
             }
         }
-        int nbatch = 0;
-        for (int s2 = 0; s2 < nnb; s2++) {
-            const int ne = (int)by_slot[s2].size() / 2; if (ne == 0) continue;
-            const int nb = (ne + 63) / 64;
-            for (int b = 0; b < nb; b++) F.batch_slot.push_back(s2);
-            for (int e = 0; e < nb * 64; e++) {
-                F.pair_j.push_back(e < ne ? by_slot[s2][2 * e] : -1); F.pair_j2.push_back(e < ne ? by_slot[s2][2 * e + 1] : -1);
-                F.pair_p.push_back(e < ne ? F.obs_pt[by_slot[s2][2 * e]] : -1);
+        F.pair_j.assign((size_t)nbatch_total * 64, -1); F.pair_j2.assign((size_t)nbatch_total * 64, -1); F.pair_p.assign((size_t)nbatch_total * 64, -1);
+        parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+            std::vector<int> slot_of(Nc, -1);
+            for (int c = (int)c0; c < (int)c1; c++) {
+                const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
+                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
+                for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
+                    const int j = F.cam_obs[q], p = F.cam_obs_pt[q];
+                    for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
+                        const int c2 = F.obs_cam[j2]; if (!(F.cam_pos[c2] < pc)) continue;
+                        const int64_t w = slot_off[rb + slot_of[c2]]++;
+                        F.pair_j[w] = j; F.pair_j2[w] = j2; F.pair_p[w] = p;
+                    }
+                }
+                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
             }
-            nbatch += nb;
-        }
-        F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch;
-        for (int b = F.cam_batch_ptr[c]; b < F.cam_batch_ptr[c + 1]; b += task_batches) {
-            F.chunk_cam.push_back(c); F.chunk_b0.push_back(b); F.chunk_b1.push_back(std::min(b + task_batches, F.cam_batch_ptr[c + 1]));
-        }
+        });
     }
+    lap("pair lists");
 }
 
 }  // namespace ssfm

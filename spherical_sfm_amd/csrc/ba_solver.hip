@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -248,7 +249,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->ctx = ctx;
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
-    ba_flatten(*p, ctx->nranks, ctx->rank, h->F);
+    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F); h->t_flatten_s = wall_s() - tf; }
     *out = h;
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
@@ -411,19 +412,92 @@ extern "C" int ssfm_ba_evaluate(ssfm_ba_handle* h, double* cost, double* residua
     return SSFM_OK;
 }
 
+// ---- plan cache of ssfm_ba_solve ---------------------------------------------------------------------------------
+// The drivers call Optimize() several times on the same structure (run_spherical_sfm.cpp:93-112: BA, Retriangulate, BA, ...).
+// Planning + allocation + index uploads cost more than the solve itself at config 2, so ssfm_ba_solve keeps the handle of the
+// last structure it saw: a 128-bit hash over everything the plan depends on (observation ids in order, the fixed masks, which
+// points are zero, the sizes, the rank layout) decides between "upload the new parameters and run" and a fresh plan.
+namespace {
+struct PlanCache { ssfm_ba_handle* h = nullptr; int Nc = 0, Np = 0; int64_t M = 0; int nranks = 0, rank = 0, focal_fixed = 0; uint64_t h1 = 0, h2 = 0; };
+void plan_cache_free(void* c) { PlanCache* pc = static_cast<PlanCache*>(c); if (pc->h) ssfm_ba_destroy(pc->h); delete pc; }
+inline void mix(uint64_t& a, uint64_t& b, uint64_t w) {
+    a = (a ^ w) * 0x9E3779B97F4A7C15ull; a ^= a >> 32;
+    b = (b + w + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull; b ^= b >> 29;
+}
+void hash_bytes(const void* data, size_t n, uint64_t& a, uint64_t& b) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); mix(a, b, w); }
+    uint64_t w = 0; if (i < n) std::memcpy(&w, p + i, n - i);
+    mix(a, b, w ^ ((uint64_t)n << 56));
+}
+void structure_hash(const ssfm_ba_problem* p, uint64_t& a, uint64_t& b) {
+    a = 0x243F6A8885A308D3ull; b = 0x13198A2E03707344ull;
+    hash_bytes(p->obs_cam, (size_t)p->num_observations * sizeof(int32_t), a, b);
+    hash_bytes(p->obs_pt, (size_t)p->num_observations * sizeof(int32_t), a, b);
+    if (p->rot_fixed) hash_bytes(p->rot_fixed, (size_t)p->num_cameras, a, b); else mix(a, b, 1);
+    if (p->trans_fixed) hash_bytes(p->trans_fixed, (size_t)p->num_cameras, a, b); else mix(a, b, 2);
+    if (p->pt_fixed) hash_bytes(p->pt_fixed, (size_t)p->num_points, a, b); else mix(a, b, 3);
+    uint64_t bits = 0; int nb = 0;                                   // which points are (0,0,0): they leave the problem (src/sfm.cpp:243)
+    for (int j = 0; j < p->num_points; j++) {
+        const double* X = p->points + 3 * (size_t)j;
+        bits = (bits << 1) | ((X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) == 0.0 ? 1u : 0u);
+        if (++nb == 64) { mix(a, b, bits); bits = 0; nb = 0; }
+    }
+    mix(a, b, bits ^ ((uint64_t)nb << 57));
+}
+// new parameter values into a resident handle whose structure matches p
+int upload_state(ssfm_ba_handle* h, const ssfm_ba_problem* p) {
+    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; BAFlat& F = h->F;
+    if (F.nothing_to_do) return SSFM_OK;
+    for (int q = 0; q < F.nP; q++) for (int d = 0; d < 3; d++) F.pts0[(size_t)q * 3 + d] = p->points[(size_t)F.pt_ids[q] * 3 + d];
+    for (int64_t j = 0; j < F.M; j++) { const int64_t o = F.obs_orig[j]; F.obs_xy[2 * j] = p->obs_xy[2 * o]; F.obs_xy[2 * j + 1] = p->obs_xy[2 * o + 1]; }
+    const double f3[3] = {*p->focal, *p->focal, *p->focal};
+    h->focal_host = *p->focal;
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->cam_init.p, p->cameras, (size_t)F.Nc * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->pts_init.p, F.pts0.data(), F.pts0.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (F.M > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->obs_xy.p, F.obs_xy.data(), F.obs_xy.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->focal3.p, f3, sizeof(f3), hipMemcpyHostToDevice, st));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));                   // the host sources above are reused by the caller
+    return ssfm_ba_reset(h);
+}
+}  // namespace
+
 extern "C" int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s) {
     if (!ctx || !p || !s) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_solve: null argument");
+    static const bool no_cache = std::getenv("SSFM_NO_PLAN_CACHE") != nullptr;
     const double t0 = wall_s();
-    ssfm_ba_handle* h = nullptr;
-    int rc = ssfm_ba_create(ctx, p, o, &h);
+    PlanCache key; key.Nc = p->num_cameras; key.Np = p->num_points; key.M = p->num_observations; key.nranks = ctx->nranks; key.rank = ctx->rank;
+    key.focal_fixed = p->focal_fixed ? 1 : 0;
+    PlanCache* pc = static_cast<PlanCache*>(ctx->plan_cache);
+    ssfm_ba_handle* h = nullptr; bool reused = false; int rc = SSFM_OK;
+    if (!no_cache) {
+        structure_hash(p, key.h1, key.h2);
+        if (pc && pc->h && pc->Nc == key.Nc && pc->Np == key.Np && pc->M == key.M && pc->nranks == key.nranks && pc->rank == key.rank &&
+            pc->focal_fixed == key.focal_fixed && pc->h1 == key.h1 && pc->h2 == key.h2) {
+            h = pc->h; reused = true;
+            if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
+            h->t_flatten_s = 0.0;
+            rc = upload_state(h, p);
+        }
+    }
+    if (!reused) {
+        if (pc) { if (pc->h) ssfm_ba_destroy(pc->h); pc->h = nullptr; }
+        rc = ssfm_ba_create(ctx, p, o, &h);
+        if (rc != SSFM_OK) { if (h) ssfm_ba_destroy(h); return rc; }
+    }
     const double t1 = wall_s();
-    if (rc != SSFM_OK) { if (h) ssfm_ba_destroy(h); return rc; }
-    rc = ssfm_ba_run(h, s);
+    if (rc == SSFM_OK) rc = ssfm_ba_run(h, s);
     const double t2 = wall_s();
     if (rc == SSFM_OK) rc = ssfm_ba_download(h, p);
     const double t3 = wall_s();
-    s->t_flatten_s = 0.0; s->t_upload_s = t1 - t0; s->t_download_s = t3 - t2;
-    (void)t2;
-    ssfm_ba_destroy(h);
+    s->t_flatten_s = h->t_flatten_s; s->t_upload_s = (t1 - t0) - h->t_flatten_s; s->t_download_s = t3 - t2;   // host planning | hash / allocation + H2D | D2H + scatter
+    if (no_cache || rc != SSFM_OK) {
+        if (reused && pc) pc->h = nullptr;
+        ssfm_ba_destroy(h);
+    } else {
+        if (!pc) { pc = new PlanCache(); ctx->plan_cache = pc; ctx->plan_cache_free = plan_cache_free; }
+        key.h = h; *pc = key;
+    }
     return rc;
 }

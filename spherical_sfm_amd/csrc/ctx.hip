@@ -35,6 +35,7 @@ extern "C" int ssfm_ctx_create(int32_t device, void* stream, ssfm_ctx** out) {
 extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->plan_cache && ctx->plan_cache_free) ctx->plan_cache_free(ctx->plan_cache);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -107,3 +107,32 @@ def test_full_size_noise_free_property(gpu_ctx):
     assert abs(f - p.gt_focal) < 1e-4
     own = (np.arange(300) % 4) == 0                              # the component of the fixed camera 0
     assert np.abs(cams[own, 3:] - p.gt_cameras[own, 3:]).max() < 1e-7
+
+
+def test_plan_cache_reuses_structure_and_detects_changes(gpu_ctx, oracle):
+    """ssfm_ba_solve keeps the handle of the last structure: same structure + new parameters -> same answer as a fresh plan;
+    a point set to zero (what Retriangulate does to a failed point, src/sfm.cpp:172,186) or a changed mask -> new plan."""
+    import dataclasses
+    from spherical_sfm_amd import ba
+    prob = synth.make_circle(60, 3000, 6, spherical=False, focal_fixed=False, seed=31)
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, prob)                       # plans
+    c2, p2, f2, s2 = ba.optimize(gpu_ctx, prob)                       # cache hit: no planning time
+    assert s2["t_flatten_s"] == 0.0 and s1["t_flatten_s"] > 0.0
+    assert s2["iterations"] == s1["iterations"] and np.abs(c2 - c1).max() <= 1e-10 * np.abs(c1).max() and abs(f2 - f1) <= 1e-10 * f1
+    # same structure, different parameter values and pixels: answer must match the oracle on THAT problem
+    prob_b = dataclasses.replace(prob, cameras=prob.cameras + 1e-4, obs_xy=prob.obs_xy + 0.25, focal=prob.focal * 0.97)
+    c3, p3, f3, s3 = ba.optimize(gpu_ctx, prob_b)
+    oc, op, of, os_ = oracle.ba_solve(prob_b)
+    assert s3["t_flatten_s"] == 0.0 and s3["iterations"] == os_["iterations"]
+    assert np.abs(c3 - oc).max() <= 1e-7 * np.abs(oc).max() and abs(f3 - of) <= 1e-7 * of
+    # structure change: point 5 zeroed -> it leaves the problem, the plan is rebuilt
+    pts = prob.points.copy(); pts[5] = 0.0
+    prob_c = dataclasses.replace(prob, points=pts)
+    c4, p4, f4, s4 = ba.optimize(gpu_ctx, prob_c)
+    oc, op, of, os_ = oracle.ba_solve(prob_c)
+    assert s4["t_flatten_s"] > 0.0 and s4["num_residual_blocks"] == s1["num_residual_blocks"] - 6
+    assert np.abs(c4 - oc).max() <= 1e-7 * np.abs(oc).max() and not p4[5].any()
+    # mask change
+    tf = prob.trans_fixed.copy(); tf[7] = 1
+    c5, p5, f5, s5 = ba.optimize(gpu_ctx, dataclasses.replace(prob, trans_fixed=tf))
+    assert s5["t_flatten_s"] > 0.0 and np.array_equal(c5[7, :3], prob.cameras[7, :3])
