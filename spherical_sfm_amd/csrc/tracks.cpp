@@ -58,7 +58,7 @@ extern "C" int ssfm_build_tracks(int32_t num_keyframes, const int32_t* feat_ptr,
         }
     }
     *num_points = (int32_t)members.size();
-    if (point_alive) std::memcpy(point_alive, alive.data(), alive.size());
+    if (point_alive && !alive.empty()) std::memcpy(point_alive, alive.data(), alive.size());
     int64_t n = 0;
     for (int c = 0; c < num_keyframes; c++)
         for (auto& kv : obs[c]) { if (obs_cam) { obs_cam[n] = c; obs_pt[n] = kv.first; obs_xy[2 * n] = kv.second.x; obs_xy[2 * n + 1] = kv.second.y; } n++; }

@@ -1,0 +1,78 @@
+// Sanitizer harness for the host planner (spherical_sfm_amd/csrc/ba_flatten.h) and the track builder (tracks.cpp): random and
+// degenerate problems under -fsanitize=address,undefined (and thread).  Built and run by tests/test_sanitizers_cpu.py.
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "../../spherical_sfm_amd/csrc/ba_flatten.h"
+
+extern "C" int ssfm_build_tracks(int32_t, const int32_t*, const double*, int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                                 double, double, int32_t, int32_t*, int32_t*, uint8_t*, int64_t*, int32_t*, int32_t*, double*);
+
+static long check(const ssfm::BAFlat& F, int Nc) {
+    long sum = 0;
+    if (F.nothing_to_do) return 0;
+    // every index the kernels will dereference stays in range
+    for (size_t j = 0; j < F.obs_cam.size(); j++) { if (F.obs_cam[j] < 0 || F.obs_cam[j] >= Nc || F.obs_pt[j] < 0 || F.obs_pt[j] >= F.nP) { std::printf("bad obs index\n"); std::abort(); } }
+    for (size_t e = 0; e < F.pair_j.size(); e++) {
+        const int j = F.pair_j[e], j2 = F.pair_j2[e], p = F.pair_p[e];
+        if (j < 0) { if (j2 >= 0 || p >= 0) { std::printf("bad padding\n"); std::abort(); } continue; }
+        if (j >= F.M || j2 < 0 || j2 >= F.M || p != F.obs_pt[j] || p != F.obs_pt[j2]) { std::printf("bad pair\n"); std::abort(); }
+        sum += j + j2;
+    }
+    for (size_t t = 0; t < F.chunk_cam.size(); t++) {
+        if (F.chunk_b0[t] >= F.chunk_b1[t] || F.chunk_b1[t] * 64 > (long)F.pair_j.size()) { std::printf("bad task\n"); std::abort(); }
+        for (int b = F.chunk_b0[t]; b < F.chunk_b1[t]; b++) { const int c = F.chunk_cam[t]; if (F.batch_slot[b] < 0 || F.batch_slot[b] >= F.row_ptr[c + 1] - F.row_ptr[c]) { std::printf("bad slot\n"); std::abort(); } }
+    }
+    for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] < 0 || F.col_idx[e] >= Nc) { std::printf("bad col\n"); std::abort(); }
+    return sum;
+}
+
+int main() {
+    std::mt19937 rng(42);
+    long acc = 0;
+    for (int trial = 0; trial < 60; trial++) {
+        const int Nc = 1 + rng() % 40, Np = rng() % 300, K = 1 + rng() % 7;
+        std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
+        std::vector<uint8_t> rf(Nc, 0), tf(Nc, trial % 3 == 0), pf(Np, 0);
+        for (auto& v : pts) v = (rng() % 100) / 10.0 + 0.5;
+        for (int j = 0; j < Np; j++) {
+            if (rng() % 11 == 0) { pts[3 * j] = pts[3 * j + 1] = pts[3 * j + 2] = 0.0; }          // zero point: leaves the problem
+            const int k = rng() % (K + 1);
+            for (int q = 0; q < k; q++) {
+                int c = (int)(rng() % (Nc + 2)) - 1;                                               // includes -1 and Nc (out of range ids)
+                int pid = (rng() % 37 == 0) ? Np + 3 : j;                                          // and out-of-range point ids
+                oc.push_back(c); op.push_back(pid); xy.push_back(1.0); xy.push_back(2.0);
+                if (rng() % 13 == 0) { oc.push_back(c); op.push_back(pid); xy.push_back(3.0); xy.push_back(4.0); }   // duplicate key
+            }
+        }
+        if (trial % 2) {                                                                           // unsorted input
+            for (size_t i = oc.size(); i > 1; i--) { const size_t k = rng() % i; std::swap(oc[i - 1], oc[k]); std::swap(op[i - 1], op[k]); std::swap(xy[2 * i - 2], xy[2 * k]); std::swap(xy[2 * i - 1], xy[2 * k + 1]); }
+        }
+        double focal = 800.0;
+        ssfm_ba_problem P;
+        P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
+        P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = 1;
+        for (int nr = 1; nr <= 3; nr++) for (int r = 0; r < nr; r++) { ssfm::BAFlat F; ssfm::ba_flatten(P, nr, r, F); acc += check(F, Nc); }
+    }
+    // tracks: random match sets incl. merges
+    for (int trial = 0; trial < 20; trial++) {
+        const int nk = 2 + rng() % 6; std::vector<int32_t> fp(nk + 1, 0); for (int k = 0; k < nk; k++) fp[k + 1] = fp[k] + 5 + rng() % 20;
+        std::vector<double> fxy((size_t)fp[nk] * 2, 1.0);
+        std::vector<int32_t> i0, i1, mp(1, 0), f0, f1;
+        for (int a = 0; a < nk; a++) for (int b = a + 1; b < nk; b++) {
+            if (rng() % 3 == 0) continue;
+            i0.push_back(a); i1.push_back(b);
+            const int na = fp[a + 1] - fp[a], nb = fp[b + 1] - fp[b];
+            for (int x = 0; x < na; x++) if (rng() % 2) { f0.push_back(x); f1.push_back(rng() % nb); }
+            mp.push_back((int)f0.size());
+        }
+        const int nm = (int)f0.size();
+        std::vector<int32_t> tracks(fp[nk]), ocam(2 * nm + 1), opt(2 * nm + 1); std::vector<uint8_t> alive(nm + 1); std::vector<double> oxy(4 * nm + 2);
+        int32_t npts = 0; int64_t nobs = 0;
+        ssfm_build_tracks(nk, fp.data(), fxy.data(), (int)i0.size(), i0.data(), i1.data(), mp.data(), f0.data(), f1.data(), 0.0, 0.0, 1, tracks.data(), &npts, alive.data(), &nobs,
+                          ocam.data(), opt.data(), oxy.data());
+        acc += npts + nobs;
+    }
+    std::printf("SANITIZE_OK %ld\n", acc);
+    return 0;
+}

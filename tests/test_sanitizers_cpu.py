@@ -1,0 +1,24 @@
+"""Host code of the library under sanitizers (CPU build only; GPU sanitizers are not available on the pool): the planner
+(ba_flatten.h: flatten rules, sharding, S structure, pair lists, wave-task tables, std::thread sections) and the track builder,
+on random problems with out-of-range ids, duplicate keys, zero points, unsorted input, 1-3 ranks."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = [os.path.join(ROOT, "tests", "native", "plan_sanitize.cpp"), os.path.join(ROOT, "spherical_sfm_amd", "csrc", "tracks.cpp")]
+
+
+@pytest.mark.parametrize("flags,env", [("-fsanitize=address,undefined -fno-sanitize-recover=all", {}), ("-fsanitize=thread", {"SSFM_PLAN_THREADS": "4"})])
+def test_planner_and_tracks_under_sanitizers(tmp_path, flags, env):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "plan_sanitize")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", *flags.split(), "-I", os.path.join(ROOT, "include"), *SRC, "-o", exe, "-pthread"],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert run.returncode == 0 and "SANITIZE_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
+    assert "runtime error" not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr
