@@ -37,6 +37,10 @@ Vec3 Pose::getCenter() const { double mt[3] = {-t.v[0], -t.v[1], -t.v[2]}; Vec3 
 SfM::SfM(const Intrinsics& _intrinsics)
     : intrinsics(_intrinsics), focalFixed(true), numCameras(0), numPoints(0), nextCamera(-1), nextPoint(0), ctx(nullptr), last_summary() {}
 SfM::~SfM() { if (ctx) ssfm_ctx_destroy(ctx); }
+ssfm_ctx* SfM::GetContext() {
+    if (!ctx && ssfm_ctx_create(-1, nullptr, &ctx) != SSFM_OK) { std::cout << "error: " << ssfm_last_error(nullptr) << "\n"; exit(1); }
+    return ctx;
+}
 
 int SfM::AddCamera(const Pose& pose, const std::string& path) {                               // src/sfm.cpp:99-111
     nextCamera++; numCameras++;
@@ -101,10 +105,7 @@ void SfM::Flatten(FlatProblem& F) {
             F.xy.push_back(kv.second.x); F.xy.push_back(kv.second.y); F.oc.push_back(row.first); F.op.push_back(kv.first);
         }
     }
-    if (!ctx) {
-        int rc = ssfm_ctx_create(-1, nullptr, &ctx);
-        if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(nullptr) << "\n"; exit(1); }
-    }
+    GetContext();
     ssfm_ba_problem& P = F.P;
     P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)F.oc.size();
     P.cameras = F.cam.data(); P.points = F.pts.data(); P.focal = &intrinsics.focal;

@@ -107,6 +107,7 @@ public:
     void WriteCalib(const std::string& path);                                        // run_spherical_sfm_uncalib.cpp:225-228
     void FilterObservations(double thresh);                                          // src/sfm.cpp:297-339
     const ssfm_ba_summary& LastSummary() const { return last_summary; }
+    ssfm_ctx* GetContext();                       // the library context of this object (created on first use); for the tools around it
 };
 
 }  // namespace sphericalsfm

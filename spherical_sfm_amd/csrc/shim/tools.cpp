@@ -1,10 +1,150 @@
 // see tools.h
 #include "tools.h"
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <random>
 
+#include "../ssfm_math.h"
+
 namespace sphericalsfm {
+
+void write_feature_tracks(const std::string& outputpath, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches) {
+    if (FILE* f = std::fopen((outputpath + "/keyframes.txt").c_str(), "w")) {
+        std::fprintf(f, "%d\n", (int)keyframes.size());
+        for (const Keyframe& k : keyframes) std::fprintf(f, "%d %s\n", k.index, k.name.c_str());
+        std::fclose(f);
+    }
+    if (FILE* f = std::fopen((outputpath + "/features.dat").c_str(), "w")) {
+        for (const Keyframe& k : keyframes) {
+            const int nfeatures = k.features.size();
+            std::fwrite(&nfeatures, sizeof(int), 1, f);
+            for (int j = 0; j < nfeatures; j++) {
+                std::fwrite(&k.features.points[j].x, sizeof(float), 1, f); std::fwrite(&k.features.points[j].y, sizeof(float), 1, f);
+                static const float zeros[128] = {0};
+                std::fwrite(k.features.descs.size() >= (size_t)(j + 1) * 128 ? &k.features.descs[(size_t)j * 128] : zeros, sizeof(float), 128, f);
+            }
+        }
+        std::fclose(f);
+    }
+    if (FILE* f = std::fopen((outputpath + "/matches.dat").c_str(), "w")) {
+        const int n = (int)image_matches.size(); std::fwrite(&n, sizeof(int), 1, f);
+        for (const ImageMatch& m : image_matches) {
+            std::fwrite(&m.index0, sizeof(int), 1, f); std::fwrite(&m.index1, sizeof(int), 1, f);
+            const int nm = (int)m.matches.size(); std::fwrite(&nm, sizeof(int), 1, f);
+            for (auto& kv : m.matches) { const int a = (int)kv.first, b = (int)kv.second; std::fwrite(&a, sizeof(int), 1, f); std::fwrite(&b, sizeof(int), 1, f); }
+            std::fwrite(m.R.data(), sizeof(double), 9, f);                              // Eigen column-major
+        }
+        std::fclose(f);
+    }
+}
+
+bool read_feature_tracks(const std::string& outputpath, std::vector<Keyframe>& keyframes, std::vector<ImageMatch>& image_matches) {
+    FILE* kf = std::fopen((outputpath + "/keyframes.txt").c_str(), "r");
+    if (!kf) return false;
+    int nkeyframes = 0;
+    if (std::fscanf(kf, "%d\n", &nkeyframes) != 1 || nkeyframes < 0) { std::fclose(kf); return false; }
+    std::vector<int> indices(nkeyframes);
+    for (int i = 0; i < nkeyframes; i++) {
+        if (std::fscanf(kf, "%d", &indices[i]) != 1) { std::fclose(kf); return false; }
+        int ch; while ((ch = std::fgetc(kf)) != EOF && ch != '\n') {}                  // the rest of the line is the name
+    }
+    std::fclose(kf);
+    std::cout << "read " << indices.size() << " indices\n";
+    FILE* ff = std::fopen((outputpath + "/features.dat").c_str(), "r");
+    if (!ff) return false;
+    for (int i = 0; i < nkeyframes; i++) {
+        int nfeatures = 0;
+        if (std::fread(&nfeatures, sizeof(int), 1, ff) != 1 || nfeatures < 0) { std::fclose(ff); return false; }
+        Features features; features.points.resize(nfeatures); features.descs.resize((size_t)nfeatures * 128);
+        for (int j = 0; j < nfeatures; j++) {
+            if (std::fread(&features.points[j].x, sizeof(float), 1, ff) != 1 || std::fread(&features.points[j].y, sizeof(float), 1, ff) != 1 ||
+                std::fread(&features.descs[(size_t)j * 128], sizeof(float), 128, ff) != 128) { std::fclose(ff); return false; }
+        }
+        char name[1024]; std::snprintf(name, sizeof name, "%06d.jpg", indices[i] + 1);
+        keyframes.push_back(Keyframe(indices[i], name, features));
+    }
+    std::fclose(ff);
+    FILE* mf = std::fopen((outputpath + "/matches.dat").c_str(), "r");
+    if (!mf) return false;
+    int nmatches = 0;
+    if (std::fread(&nmatches, sizeof(int), 1, mf) != 1) { std::fclose(mf); return false; }
+    for (int i = 0; i < nmatches; i++) {
+        int index0, index1, nm;
+        if (std::fread(&index0, sizeof(int), 1, mf) != 1 || std::fread(&index1, sizeof(int), 1, mf) != 1 || std::fread(&nm, sizeof(int), 1, mf) != 1) { std::fclose(mf); return false; }
+        Matches m;
+        for (int j = 0; j < nm; j++) { int a, b; if (std::fread(&a, sizeof(int), 1, mf) != 1 || std::fread(&b, sizeof(int), 1, mf) != 1) { std::fclose(mf); return false; } m[a] = b; }
+        Mat3 R; if (std::fread(R.data(), sizeof(double), 9, mf) != 9) { std::fclose(mf); return false; }
+        image_matches.push_back(ImageMatch(index0, index1, m, R));
+    }
+    std::fclose(mf);
+    return true;
+}
+
+void initialize_rotations_sequential(int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations) {
+    const Mat3 I = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    rotations.assign(num_cameras, I);
+    Mat3 R = I;
+    for (int index = 1; index < num_cameras; index++)
+        for (size_t i = 0; i < image_matches.size(); i++)
+            if (image_matches[i].index0 == index - 1 && image_matches[i].index1 == index) {
+                Mat3 Rn;                                                              // R = match.R * R, column-major 3x3
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += image_matches[i].R[r + 3 * k] * R[k + 3 * c]; Rn[r + 3 * c] = s; }
+                R = Rn; rotations[index] = R;
+                break;
+            }
+}
+
+double refine_rotations(ssfm_ctx* ctx, int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations) {
+    const int E = (int)image_matches.size();
+    std::vector<int32_t> i0(E), i1(E); std::vector<double> rel((size_t)9 * E), rot((size_t)9 * num_cameras);
+    for (int e = 0; e < E; e++) { i0[e] = image_matches[e].index0; i1[e] = image_matches[e].index1; for (int k = 0; k < 9; k++) rel[9 * (size_t)e + k] = image_matches[e].R[k]; }
+    for (int i = 0; i < num_cameras; i++) for (int k = 0; k < 9; k++) rot[9 * (size_t)i + k] = rotations[i][k];
+    ssfm_ba_summary S;
+    if (ssfm_rotavg_solve(ctx, num_cameras, rot.data(), E, i0.data(), i1.data(), rel.data(), nullptr, &S) != SSFM_OK || S.termination == SSFM_FAILURE) {
+        std::cout << "error: ceres failed.\n"; std::exit(1);                          // src/rotation_averaging.cpp:82-86
+    }
+    for (int i = 0; i < num_cameras; i++) for (int k = 0; k < 9; k++) rotations[i][k] = rot[9 * (size_t)i + k];
+    return S.final_cost;
+}
+
+void build_sfm(std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches, const std::vector<Mat3>& rotations, SfM& sfm,
+               bool spherical, bool merge, bool inward, int fix_camera) {
+    std::cout << "building tracks\n";
+    const int nk = (int)keyframes.size();
+    std::vector<int32_t> feat_ptr(nk + 1, 0);
+    for (int i = 0; i < nk; i++) feat_ptr[i + 1] = feat_ptr[i] + keyframes[i].features.size();
+    std::vector<double> feat_xy((size_t)feat_ptr[nk] * 2);
+    for (int i = 0; i < nk; i++) for (int j = 0; j < keyframes[i].features.size(); j++) {
+        feat_xy[2 * ((size_t)feat_ptr[i] + j)] = keyframes[i].features.points[j].x; feat_xy[2 * ((size_t)feat_ptr[i] + j) + 1] = keyframes[i].features.points[j].y; }
+    std::vector<int32_t> ms0, ms1, ms_ptr(1, 0), f0, f1;
+    for (const ImageMatch& m : image_matches) {
+        ms0.push_back(m.index0); ms1.push_back(m.index1);
+        for (auto& kv : m.matches) { f0.push_back((int32_t)kv.first); f1.push_back((int32_t)kv.second); }
+        ms_ptr.push_back((int32_t)f0.size());
+    }
+    const size_t nm = f0.size();
+    std::vector<int32_t> tracks(feat_ptr[nk]), ocam(2 * nm + 1), opt(2 * nm + 1); std::vector<uint8_t> alive(nm + 1); std::vector<double> oxy(4 * nm + 2);
+    int32_t npts = 0; int64_t nobs = 0;
+    std::cout << "adding cameras\n";
+    for (int index = 0; index < nk; index++) {
+        double Rm[9], r[3];                                                          // so3ln of the column-major rotation
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rm[3 * a + b] = rotations[index][a + 3 * b];
+        ssfm::so3ln(Rm, r);
+        const int camera = sfm.AddCamera(Pose(Vec3(0, 0, inward ? 1 : -1), Vec3(r[0], r[1], r[2])), keyframes[index].name);
+        sfm.SetRotationFixed(camera, index == fix_camera);
+        sfm.SetTranslationFixed(camera, spherical ? true : (index == fix_camera));
+    }
+    std::cout << "adding tracks\nnumber of keyframes is " << nk << "\n";
+    ssfm_build_tracks(nk, feat_ptr.data(), feat_xy.data(), (int32_t)image_matches.size(), ms0.data(), ms1.data(), ms_ptr.data(), f0.data(), f1.data(),
+                      sfm.GetIntrinsics().centerx, sfm.GetIntrinsics().centery, merge ? 1 : 0, tracks.data(), &npts, alive.data(), &nobs, ocam.data(), opt.data(), oxy.data());
+    for (int i = 0; i < nk; i++) keyframes[i].features.tracks.assign(tracks.begin() + feat_ptr[i], tracks.begin() + feat_ptr[i + 1]);
+    for (int j = 0; j < npts; j++) { const int p = sfm.AddPoint(Point(0, 0, 0)); sfm.SetPointFixed(p, false); }
+    for (int j = 0; j < npts; j++) if (!alive[j]) sfm.RemovePoint(j);                    // points consumed by MergePoint
+    for (int64_t o = 0; o < nobs; o++) sfm.AddObservation(ocam[o], opt[o], Observation(oxy[2 * o], oxy[2 * o + 1]));
+    std::cout << "retriangulating...\n";
+    sfm.Retriangulate();
+}
 
 bool find_best_focal_length_random(ssfm_ctx* ctx, int num_cameras, std::vector<ImageMatch>& image_matches, bool inward, bool sequential,
                                    double focal_guess, double min_focal, double max_focal, int num_trials, std::vector<Mat3>& rotations,

@@ -5,8 +5,10 @@
 #include <array>
 #include <cstddef>
 #include <map>
+#include <string>
 #include <vector>
 #include "../../../include/ssfm.h"
+#include "sfm.h"
 
 namespace sphericalsfm {
 
@@ -19,6 +21,31 @@ struct ImageMatch {                                       // spherical_sfm_tools
     Mat3 R;
     ImageMatch(int _index0, int _index1, const Matches& _matches, const Mat3& _R) : index0(_index0), index1(_index1), matches(_matches), R(_R) {}
 };
+
+struct Point2f { float x, y; };
+struct Features {                                         // spherical_sfm_tools.h:19-28 (cv::Mat descs -> flat 128 floats per feature)
+    std::vector<int> tracks;
+    std::vector<Point2f> points;
+    std::vector<std::array<unsigned char, 3>> colors;
+    std::vector<float> descs;
+    int size() const { return (int)points.size(); }
+    bool empty() const { return points.empty(); }
+};
+struct Keyframe {                                         // spherical_sfm_tools.h:30-39 (images are not part of this path)
+    int index; std::string name; Features features;
+    Keyframe(int _index, const std::string& _name, const Features& _features) : index(_index), name(_name), features(_features) {}
+};
+
+// keyframes.txt / features.dat / matches.dat (examples/spherical_sfm_io.cpp:10-120).  The reference prints the keyframe name with
+// "%s" of a std::string object and reads back only the indices; here the name is written as text and skipped on input.
+void write_feature_tracks(const std::string& outputpath, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches);
+bool read_feature_tracks(const std::string& outputpath, std::vector<Keyframe>& keyframes, std::vector<ImageMatch>& image_matches);
+
+void initialize_rotations_sequential(int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations);   // tools.cpp:794-813
+double refine_rotations(ssfm_ctx* ctx, int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations); // tools.cpp:851-860
+// tools.cpp:862-955: tracks (ssfm_build_tracks, ids bit-exact with the reference's AddPoint sequence), cameras, observations, Retriangulate
+void build_sfm(std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches, const std::vector<Mat3>& rotations, SfM& sfm,
+               bool spherical, bool merge, bool inward, int fix_camera = 0);
 
 // The reference seeds std::mt19937 from std::random_device and draws inside an OpenMP loop; here the draw is sequential from
 // `seed` (deterministic), everything after it follows the reference: costs of all trials in one GPU launch, first minimum,

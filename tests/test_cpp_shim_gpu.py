@@ -76,3 +76,35 @@ def test_cpp_focal_search_wrapper(tmp_path):
     r = dict(kv.split("=") for kv in line.split()[1:])
     assert r["ok"] == "1" and r["n"] == "48"
     assert abs(float(r["focal"]) - 1000.0) < 10.0 and float(r["max_rot_err"]) < 2e-3
+
+
+def test_run_spherical_sfm_driver_from_feature_tracks(tmp_path):
+    """The calibrated pipeline from the feature tracks on (examples/run_spherical_sfm.cpp:71-121) through the C++ driver:
+    read tracks -> sequential rotations -> rotation averaging -> build_sfm (+ Retriangulate) -> spherical BA x2 -> general BA x2 with
+    Normalize -> poses.txt / OBJ / COLMAP.  Checked against the generating scene (gauge-free quantities)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from _tracks_dataset import write_tracks
+    from scipy.spatial.transform import Rotation
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "run_spherical_sfm")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    out = str(tmp_path / "run"); Nc, Np = 60, 2000
+    gt = write_tracks(out, Nc, Np)
+    res = subprocess.run([exe, "-intrinsics", os.path.join(out, "intrinsics.txt"), "-output", out], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("PIPELINE_RESULT")][0]
+    r = dict(kv.split("=") for kv in line.split()[1:])
+    assert r["ok"] == "1111" and r["cameras"] == str(Nc) and int(r["residuals"]) >= 0.98 * 6 * Np
+    poses = np.loadtxt(os.path.join(out, "poses.txt"))
+    assert poses.shape == (Nc, 7) and np.array_equal(poses[:, 0].astype(int), np.arange(Nc))
+    Rs = Rotation.from_rotvec(poses[:, 4:7]).as_matrix()
+    # gauge-free: relative rotations between neighbours vs the generating scene; unit-radius ring after Normalize()
+    rel_err = [np.linalg.norm(Rotation.from_matrix((Rs[(i + 1) % Nc] @ Rs[i].T) @ (gt["R_gt"][(i + 1) % Nc] @ gt["R_gt"][i].T).T).as_rotvec()) for i in range(Nc)]
+    assert max(rel_err) < 2e-3
+    centres = np.array([-Rs[i].T @ poses[i, 1:4] for i in range(Nc)])
+    assert abs(np.linalg.norm(centres, axis=1).mean() - 1.0) < 1e-9 and np.abs(centres.mean(0)).max() < 1e-9
+    npts = sum(1 for l in open(os.path.join(out, "points.obj")) if l.startswith("v "))
+    assert npts >= 0.98 * Np
+    assert len(open(os.path.join(out, "images.txt")).read().splitlines()) == 4 + 2 * Nc
+    assert float(r["cost_general"]) <= float(r["cost_spherical"]) * 1.0001 and float(r["cost_general"]) / (6 * Np) < 0.5     # ~0.3 px noise
