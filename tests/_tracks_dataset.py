@@ -8,7 +8,10 @@ import numpy as np
 from spherical_sfm_amd import synth
 
 
-def write_tracks(outdir, num_cameras=40, num_points=1500, K=6, max_offset=3, focal=1000.0, cx=960.0, cy=540.0, pixel_noise=0.3, rot_noise_deg=0.05, seed=5):
+def write_tracks(outdir, num_cameras=40, num_points=1500, K=6, max_offset=3, focal=1000.0, cx=960.0, cy=540.0, pixel_noise=0.3, rot_noise_deg=0.05, seed=5,
+                 focal_guess=None, oracle=None):
+    """focal_guess + oracle: the matches carry the rotations a pairwise estimator would find in coordinates normalised by the GUESSED
+    focal (decomposition of T^-1 E_true T^-1, T = diag(f/f_guess, f/f_guess, 1)), as in the uncalibrated pipeline."""
     rng = np.random.default_rng(seed)
     prob = synth.make_circle(num_cameras, num_points, K, spherical=True, focal_fixed=True, pixel_noise=pixel_noise, rot_noise_deg=0.0, seed=seed, focal=focal)
     R_gt = synth.so3exp(prob.gt_cameras[:, 3:])
@@ -39,6 +42,10 @@ def write_tracks(outdir, num_cameras=40, num_points=1500, K=6, max_offset=3, foc
             a, b = (i, j) if i < j else (i, j)                               # index0 = i (the chain needs (k-1, k)); closures keep (Nc-1, 0)
             noise = synth.so3exp(rng.normal(0, np.deg2rad(rot_noise_deg), (1, 3)))[0]
             Rrel = noise @ R_gt[b] @ R_gt[a].T
+            if focal_guess is not None:
+                Tinv = np.diag([focal_guess / focal, focal_guess / focal, 1.0])
+                r, _ = oracle.decompose_spherical_essential_matrix(Tinv @ oracle.make_spherical_essential_matrix(Rrel, False) @ Tinv, False)
+                Rrel = synth.so3exp(np.asarray(r)[None])[0]
             matches.append((a, b, sorted((fid[(a, p)], fid[(b, p)]) for p in shared), Rrel))
     with open(os.path.join(outdir, "matches.dat"), "wb") as f:
         f.write(struct.pack("i", len(matches)))

@@ -108,3 +108,32 @@ def test_run_spherical_sfm_driver_from_feature_tracks(tmp_path):
     assert npts >= 0.98 * Np
     assert len(open(os.path.join(out, "images.txt")).read().splitlines()) == 4 + 2 * Nc
     assert float(r["cost_general"]) <= float(r["cost_spherical"]) * 1.0001 and float(r["cost_general"]) / (6 * Np) < 0.5     # ~0.3 px noise
+
+
+def test_run_spherical_sfm_uncalib_driver_recovers_the_focal(oracle, tmp_path):
+    """The uncalibrated pipeline from the feature tracks on (examples/run_spherical_sfm_uncalib.cpp:101-228): the matches were
+    estimated at the guessed focal (1920 + 1080) / 2 = 1500 while the images have f = 1000; focal search (1024 trials on the GPU) +
+    refinement, then bundle adjustment with the shared focal free, spherical then general."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from _tracks_dataset import write_tracks
+    from scipy.spatial.transform import Rotation
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "run_spherical_sfm_uncalib")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    out = str(tmp_path / "run"); Nc, Np = 60, 2000
+    gt = write_tracks(out, Nc, Np, focal=1000.0, focal_guess=1500.0, oracle=oracle)
+    res = subprocess.run([exe, "-output", out, "-width", "1920", "-height", "1080", "-generalba", "-seed", "3"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("PIPELINE_RESULT")][0]
+    r = dict(kv.split("=") for kv in line.split()[1:])
+    assert r["ok"] == "1111" and float(r["focal_guess"]) == 1500.0
+    assert abs(float(r["focal_search"]) - 1000.0) < 80.0                      # pose-graph search: within a few percent
+    assert abs(float(r["focal_spherical"]) - 1000.0) < 2.0 and abs(float(r["focal_final"]) - 1000.0) < 2.0    # BA with the focal free: 0.3 px noise
+    calib = open(os.path.join(out, "calib.txt")).read().split()
+    assert abs(float(calib[0]) - float(r["focal_final"])) < 1e-5 and float(calib[1]) == 960.0 and float(calib[2]) == 540.0   # %0.15f vs the %.6f of the result line
+    poses = np.loadtxt(os.path.join(out, "poses.txt"))
+    Rs = Rotation.from_rotvec(poses[:, 4:7]).as_matrix()
+    rel_err = [np.linalg.norm(Rotation.from_matrix((Rs[(i + 1) % Nc] @ Rs[i].T) @ (gt["R_gt"][(i + 1) % Nc] @ gt["R_gt"][i].T).T).as_rotvec()) for i in range(Nc)]
+    assert max(rel_err) < 2e-3
+    assert len(open(os.path.join(out, "costs.txt")).read().splitlines()) == 1024
