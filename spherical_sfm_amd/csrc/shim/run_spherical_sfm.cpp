@@ -13,7 +13,7 @@
 using namespace sphericalsfm;
 
 int main(int argc, char** argv) {
-    std::string intrinsics_path, output; bool inward = false; int width = 1920, height = 1080;
+    std::string intrinsics_path, output; bool inward = false, pairwise = false; int width = 1920, height = 1080, mininliers = 100; double inlierthresh = 2.0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-intrinsics" && i + 1 < argc) intrinsics_path = argv[++i];
@@ -21,6 +21,9 @@ int main(int argc, char** argv) {
         else if (a == "-width" && i + 1 < argc) width = std::atoi(argv[++i]);
         else if (a == "-height" && i + 1 < argc) height = std::atoi(argv[++i]);
         else if (a == "-inward") inward = true;
+        else if (a == "-pairwise") pairwise = true;                         // matches.dat holds raw matches: run estimate_pairwise (GPU RANSAC) first
+        else if (a == "-inlierthresh" && i + 1 < argc) inlierthresh = std::atof(argv[++i]);
+        else if (a == "-mininliers" && i + 1 < argc) mininliers = std::atoi(argv[++i]);
         else if (a == "-sequential") {}                                     // the only rotation initialisation available here
         else { std::cout << "unknown argument " << a << "\n"; return 2; }
     }
@@ -35,11 +38,19 @@ int main(int argc, char** argv) {
     if (!read_feature_tracks(output, keyframes, image_matches)) { std::cout << "error: no feature tracks in " << output << "\n"; return 1; }
     if (image_matches.empty()) { std::cout << "error: no loop closures found\n"; return 1; }
 
+    SfM sfm(intrinsics);
+    int loop_closures = -1;
+    if (pairwise) {                                                          // run_spherical_sfm.cpp:56-63
+        std::cout << "detecting loop closures\n";
+        std::vector<ImageMatch> all_image_matches; all_image_matches.swap(image_matches);
+        loop_closures = estimate_pairwise(sfm.GetContext(), intrinsics, keyframes, all_image_matches, inlierthresh, mininliers, inward, image_matches);
+        if (loop_closures == 0) { std::cout << "error: no loop closures found\n"; return 1; }
+        std::cout << "kept " << image_matches.size() << " of " << all_image_matches.size() << " image pairs, " << loop_closures << " loop closures\n";
+    }
     std::cout << "initializing rotations\n";
     std::vector<Mat3> rotations;
     initialize_rotations_sequential((int)keyframes.size(), image_matches, rotations);
 
-    SfM sfm(intrinsics);
     std::cout << "refining rotations\n";
     const double rot_cost = refine_rotations(sfm.GetContext(), (int)keyframes.size(), image_matches, rotations);
 
@@ -71,6 +82,7 @@ int main(int argc, char** argv) {
     sfm.WritePointsOBJ(output + "/points.obj");
     sfm.WriteCameraCentersOBJ(output + "/cameras.obj");
     sfm.WriteCOLMAP(output, width, height);
+    std::printf("PAIRWISE_RESULT pairs=%zu loop_closures=%d\n", image_matches.size(), loop_closures);
     std::printf("PIPELINE_RESULT ok=%d%d%d%d cameras=%d points=%d rot_cost=%.6e cost_spherical=%.6e cost_general=%.6e residuals=%lld\n", ok1, ok2, ok3, ok4,
                 sfm.GetNumCameras(), sfm.GetNumPoints(), rot_cost, cost_spherical, sfm.LastSummary().final_cost, (long long)sfm.LastSummary().num_residual_blocks);
     return 0;

@@ -81,6 +81,46 @@ bool read_feature_tracks(const std::string& outputpath, std::vector<Keyframe>& k
     return true;
 }
 
+int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches,
+                      double inlier_threshold, int min_num_inliers, bool inward, std::vector<ImageMatch>& image_matches_out) {
+    const double kinv = 1.0 / intrinsics.focal;                                           // Kinv(0,0)
+    const double sq_thresh = inlier_threshold * inlier_threshold * kinv * kinv;           // :315
+    // the reference enumerates all (index0 < index1) and takes the FIRST stored match set of each pair
+    std::map<std::pair<int, int>, const ImageMatch*> first;
+    for (const ImageMatch& m : image_matches) if (m.index0 < m.index1) first.emplace(std::make_pair(m.index0, m.index1), &m);
+    std::vector<const ImageMatch*> cand;
+    for (auto& kv : first) if ((int)kv.second->matches.size() >= min_num_inliers && !kv.second->matches.empty()) cand.push_back(kv.second);   // :353
+    if (cand.empty()) return 0;
+    std::vector<int32_t> pair_ptr(1, 0); std::vector<double> u, v;
+    for (const ImageMatch* m : cand) {
+        const Features& f0 = keyframes[m->index0].features; const Features& f1 = keyframes[m->index1].features;
+        for (auto& kv : m->matches) {                                                     // rays Kinv * (x, y, 1), :362-376
+            const Point2f p0 = f0.points[kv.first], p1 = f1.points[kv.second];
+            u.push_back((p0.x - intrinsics.centerx) * kinv); u.push_back((p0.y - intrinsics.centery) * kinv); u.push_back(1.0);
+            v.push_back((p1.x - intrinsics.centerx) * kinv); v.push_back((p1.y - intrinsics.centery) * kinv); v.push_back(1.0);
+        }
+        pair_ptr.push_back((int32_t)(u.size() / 3));
+    }
+    ssfm_ransac_options O; ssfm_ransac_default_options(&O);
+    O.min_num_inliers = min_num_inliers; O.inward = inward ? 1 : 0; O.final_least_squares = 1;                                 // :316-318
+    const int P = (int)cand.size();
+    std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(u.size() / 3); std::vector<int32_t> nin(P);
+    if (ssfm_ransac_batch(ctx, P, pair_ptr.data(), u.data(), v.data(), sq_thresh, &O, nullptr, R.data(), mask.data(), nin.data(), nullptr) != SSFM_OK) {
+        std::cout << "error: " << ssfm_last_error(ctx) << "\n"; std::exit(1);
+    }
+    int loop_closure_count = 0;
+    for (int k = 0; k < P; k++) {
+        if (!(nin[k] > min_num_inliers)) continue;                                        // :410
+        Matches inl; size_t j = (size_t)pair_ptr[k];
+        for (auto& kv : cand[k]->matches) { if (mask[j++]) inl[kv.first] = kv.second; }
+        if (inl.empty()) continue;
+        Mat3 Rk; for (int q = 0; q < 9; q++) Rk[q] = R[9 * (size_t)k + q];
+        if (cand[k]->index0 + 1 != cand[k]->index1) loop_closure_count++;
+        image_matches_out.push_back(ImageMatch(cand[k]->index0, cand[k]->index1, inl, Rk));
+    }
+    return loop_closure_count;
+}
+
 void initialize_rotations_sequential(int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations) {
     const Mat3 I = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     rotations.assign(num_cameras, I);

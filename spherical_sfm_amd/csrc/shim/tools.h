@@ -41,6 +41,13 @@ struct Keyframe {                                         // spherical_sfm_tools
 void write_feature_tracks(const std::string& outputpath, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches);
 bool read_feature_tracks(const std::string& outputpath, std::vector<Keyframe>& keyframes, std::vector<ImageMatch>& image_matches);
 
+// estimate_pairwise (spherical_sfm_tools.cpp:309-431): every candidate pair (index0 < index1) with at least min_num_inliers matches goes
+// through the spherical 3-point LO-MSAC -- all pairs in ONE ssfm_ransac_batch launch instead of the OpenMP loop; pairs with more than
+// min_num_inliers inliers come back with their inlier matches and R = so3exp(decompose(E)).  Returns the number of loop closures
+// (accepted pairs that are not consecutive).
+int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches,
+                      double inlier_threshold, int min_num_inliers, bool inward, std::vector<ImageMatch>& image_matches_out);
+
 void initialize_rotations_sequential(int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations);   // tools.cpp:794-813
 double refine_rotations(ssfm_ctx* ctx, int num_cameras, const std::vector<ImageMatch>& image_matches, std::vector<Mat3>& rotations); // tools.cpp:851-860
 // tools.cpp:862-955: tracks (ssfm_build_tracks, ids bit-exact with the reference's AddPoint sequence), cameras, observations, Retriangulate

@@ -9,7 +9,7 @@ from spherical_sfm_amd import synth
 
 
 def write_tracks(outdir, num_cameras=40, num_points=1500, K=6, max_offset=3, focal=1000.0, cx=960.0, cy=540.0, pixel_noise=0.3, rot_noise_deg=0.05, seed=5,
-                 focal_guess=None, oracle=None):
+                 focal_guess=None, oracle=None, raw_matches=False, wrong_match_frac=0.0):
     """focal_guess + oracle: the matches carry the rotations a pairwise estimator would find in coordinates normalised by the GUESSED
     focal (decomposition of T^-1 E_true T^-1, T = diag(f/f_guess, f/f_guess, 1)), as in the uncalibrated pipeline."""
     rng = np.random.default_rng(seed)
@@ -39,14 +39,21 @@ def write_tracks(outdir, num_cameras=40, num_points=1500, K=6, max_offset=3, foc
             shared = sorted(pts_of[i] & pts_of[j])
             if len(shared) < 8:
                 continue
-            a, b = (i, j) if i < j else (i, j)                               # index0 = i (the chain needs (k-1, k)); closures keep (Nc-1, 0)
+            a, b = (i, j)                                                   # index0 = i (the chain needs (k-1, k)); closures keep (Nc-1, 0)
+            if raw_matches and a > b:
+                a, b = b, a                                                 # a matcher stores every pair once, index0 < index1
             noise = synth.so3exp(rng.normal(0, np.deg2rad(rot_noise_deg), (1, 3)))[0]
             Rrel = noise @ R_gt[b] @ R_gt[a].T
             if focal_guess is not None:
                 Tinv = np.diag([focal_guess / focal, focal_guess / focal, 1.0])
                 r, _ = oracle.decompose_spherical_essential_matrix(Tinv @ oracle.make_spherical_essential_matrix(Rrel, False) @ Tinv, False)
                 Rrel = synth.so3exp(np.asarray(r)[None])[0]
-            matches.append((a, b, sorted((fid[(a, p)], fid[(b, p)]) for p in shared), Rrel))
+            pairs = dict((fid[(a, p)], fid[(b, p)]) for p in shared)
+            if raw_matches:
+                Rrel = np.eye(3)
+                for fa in list(pairs)[::max(1, int(round(1 / wrong_match_frac)))] if wrong_match_frac > 0 else []:
+                    pairs[fa] = int(rng.integers(len(feats[b])))            # wrong pairing
+            matches.append((a, b, sorted(pairs.items()), Rrel))
     with open(os.path.join(outdir, "matches.dat"), "wb") as f:
         f.write(struct.pack("i", len(matches)))
         for (a, b, m, R) in matches:

@@ -137,3 +137,29 @@ def test_run_spherical_sfm_uncalib_driver_recovers_the_focal(oracle, tmp_path):
     rel_err = [np.linalg.norm(Rotation.from_matrix((Rs[(i + 1) % Nc] @ Rs[i].T) @ (gt["R_gt"][(i + 1) % Nc] @ gt["R_gt"][i].T).T).as_rotvec()) for i in range(Nc)]
     assert max(rel_err) < 2e-3
     assert len(open(os.path.join(out, "costs.txt")).read().splitlines()) == 1024
+
+
+def test_run_spherical_sfm_driver_with_gpu_pairwise_estimation(tmp_path):
+    """Same driver, but matches.dat holds RAW matches (identity rotations, 20 % wrong pairings): estimate_pairwise runs all pairs through
+    ssfm_ransac_batch in one launch (examples/spherical_sfm_tools.cpp:309-431), keeps the inlier matches and the decomposed rotations."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from _tracks_dataset import write_tracks
+    from scipy.spatial.transform import Rotation
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "run_spherical_sfm")
+    out = str(tmp_path / "run"); Nc, Np = 60, 2000
+    gt = write_tracks(out, Nc, Np, raw_matches=True, wrong_match_frac=0.2)
+    res = subprocess.run([exe, "-intrinsics", os.path.join(out, "intrinsics.txt"), "-output", out, "-pairwise", "-inlierthresh", "2", "-mininliers", "30"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    pw = dict(kv.split("=") for kv in [l for l in res.stdout.splitlines() if l.startswith("PAIRWISE_RESULT")][0].split()[1:])
+    assert int(pw["pairs"]) == gt["num_matches"] and int(pw["loop_closures"]) >= Nc       # every pair survives; all d = 2, 3 pairs + wrap-arounds are closures
+    r = dict(kv.split("=") for kv in [l for l in res.stdout.splitlines() if l.startswith("PIPELINE_RESULT")][0].split()[1:])
+    assert r["ok"] == "1111"
+    poses = np.loadtxt(os.path.join(out, "poses.txt"))
+    Rs = Rotation.from_rotvec(poses[:, 4:7]).as_matrix()
+    rel_err = [np.linalg.norm(Rotation.from_matrix((Rs[(i + 1) % Nc] @ Rs[i].T) @ (gt["R_gt"][(i + 1) % Nc] @ gt["R_gt"][i].T).T).as_rotvec()) for i in range(Nc)]
+    assert max(rel_err) < 2e-3
+    # the wrong pairings were rejected: the reprojection cost per residual stays at the pixel-noise level
+    assert float(r["cost_general"]) / int(r["residuals"]) < 0.5
