@@ -21,7 +21,7 @@ enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PC
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
                 KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
-static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_S", "k_pcg_init",
+static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_sym_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2"};
@@ -53,6 +53,7 @@ struct ssfm_ba_handle {
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
     bool scale_ready = false;
+    bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
     int pcg_prev_iters = 16;
     // profiling
     bool profile = false;
@@ -187,8 +188,11 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
     if (stage == 0) {
     if (!h->zone_views) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
-    LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
-    hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
+    if (!h->band_filled) {                                       // the BA path fills the band in its fused finalize kernel
+        LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
+    }
+    h->band_filled = false;
     // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
     if (use_lds) {
         if (lds_win > 48 * 1024) {

@@ -115,8 +115,14 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->scal.p, h->red_scal, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
             rc = allreduce(h, h->scal.p + SC_GMAX, 1, ncclMax); if (rc) return rc;
         }
-        LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-               radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
+        if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
+            LAUNCH(h, KID_FINALIZE, k_finalize_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                   radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+            h->band_filled = true;
+        } else {
+            LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                   radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
+        }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[2], st));
         // ================= solve the reduced system, then step / candidate / model cost / candidate cost =================
         // The direct solve and the tail are enqueued back to back; the solver's residual flags come back with the

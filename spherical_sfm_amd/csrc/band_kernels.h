@@ -48,6 +48,53 @@ __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __rest
         if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e];
     }
 }
+// k_finalize_S + k_band_gather + k_band_permute_rhs in one launch for the BA path with the banded preconditioner (one workgroup per
+// camera, which owns its diagonal block, its band row and its slice of the right-hand sides): LM diagonal on the diagonal block
+// (in S_val too: the residual check multiplies by S), gradient max-norm, band row, permuted [rhs | S_fc]; workgroup 0 also folds the
+// focal sums and writes the focal row.  The block-Jacobi inverse of k_finalize_S is only needed by preconditioner 1 and is not built here.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ diag_slot,
+                  const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ Udiag,
+                  const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos, int b,
+                  double* __restrict__ S_val, double* __restrict__ rhs, const double* __restrict__ Sfc, double* __restrict__ Sff,
+                  double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal) {
+    constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int i = pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    double gmax = 0.0;
+    if (tid < DC) {
+        double* blk = S_val + ((size_t)rb + diag_slot[c]) * BB;
+        const double s = scale_cam[c * 6 + off + tid];
+        blk[tid * DC + tid] += (s > 0.0) ? fmin(fmax(Udiag[c * DC + tid], min_diag), max_diag) / radius : 1.0;
+        if (s > 0.0) gmax = fabs(gcraw[c * DC + tid] / s);
+        Y[(size_t)i * DC + tid] = rhs[c * DC + tid];
+        Y[(size_t)Nc * DC + (size_t)i * DC + tid] = Sfc[c * DC + tid];
+    }
+    if (tid < 64) { gmax = wave_max(gmax); if (tid == 0 && gmax > 0.0) atomic_max_nonneg(&scal[(size_t)(c & (SC_NSLOT - 1)) * SC_TOTAL + SC_GMAX], gmax); }
+    double* row = band + (size_t)i * (b + 1) * BB;
+    for (int e = tid; e < (b + 1) * BB; e += blockDim.x) row[e] = 0.0;
+    __syncthreads();                                               // damped diagonal block and cleared row visible to the whole workgroup
+    for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
+        const int sidx = rb + idx / BB, e = idx % BB;
+        const int k = pos[col_idx[sidx]];
+        if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)sidx * BB + e];
+    }
+    if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
+        const int l = tid - 64;
+        const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;
+        const double fjj = wave_sum(sl[SC_FJJ]), fww = wave_sum(sl[SC_FWW]), fjr = wave_sum(sl[SC_FJR]), fwg = wave_sum(sl[SC_FWG]);
+        if (l == 0) {
+            const double sf = scale_f[0];
+            if (sf > 0.0) {
+                Sff[0] = fjj + fmin(fmax(fjj, min_diag), max_diag) / radius - fww;
+                rhs[Nc * DC] = fjr - fwg;
+                atomic_max_nonneg(&scal[SC_GMAX], fabs(fjr / sf));
+            } else { Sff[0] = 1.0; rhs[Nc * DC] = 0.0; }
+        }
+    }
+}
+
 template <int DC>
 __global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double* __restrict__ Sfc, const int* __restrict__ pos, int Nc,
                                    double* __restrict__ Y) {
