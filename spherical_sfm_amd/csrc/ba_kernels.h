@@ -835,13 +835,25 @@ k_point_cost(const double* __restrict__ cam, const double* __restrict__ rot, con
 // fold the SC_NSLOT replicas of the scalar block into replica 0 (sums; SC_GMAX by max) and clear the others: run before a
 // collective reduces the block, by ONE workgroup of SC_TOTAL * 64 lanes
 static __global__ void __launch_bounds__(SC_TOTAL * 64)
-k_scal_fold(double* __restrict__ scal) {
+k_scal_fold(double* __restrict__ scal, double* __restrict__ packed, int rank) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* p = scal + (size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k;
     const double v = *p;
     const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);           // non-negative doubles order like their bit patterns
     __syncthreads();
     *p = (lane == 0) ? r : 0.0;
+    // packed (optional): what one sum all-reduce carries -- the SC_NSUM sums, then one gradient-max slot per rank (the others stay
+    // zero, so the sum over ranks leaves every rank's maximum side by side and no second, max-type collective is needed)
+    if (packed && lane == 0) { if (k < SC_NSUM) packed[k] = r; else if (k == SC_GMAX) packed[SC_NSUM + rank] = r; }
+}
+// after the all-reduce: sums back into replica 0, gradient max = max over the per-rank slots
+static __global__ void __launch_bounds__(64)
+k_scal_unpack(double* __restrict__ scal, const double* __restrict__ packed, int nranks) {
+    const int lane = threadIdx.x;
+    if (lane < SC_NSUM) scal[lane] = packed[lane];
+    double g = 0.0; for (int j = lane; j < nranks; j += 64) g = fmax(g, packed[SC_NSUM + j]);
+    g = wave_max(g);
+    if (lane == 0) scal[SC_GMAX] = g;
 }
 
 // |x|^2 over free parameters (iteration 0)

@@ -108,12 +108,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
         if (ctx->collective) {
-            hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p);
-            // scalar sums ride at the tail of the same buffer
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->red_scal, h->scal.p, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
+            // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
+            hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->red_scal, ctx->rank);
             int rc = allreduce(h, h->redbuf.p, (size_t)h->n_red, ncclSum); if (rc) return rc;
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->scal.p, h->red_scal, SC_NSUM * sizeof(double), hipMemcpyDeviceToDevice, st));
-            rc = allreduce(h, h->scal.p + SC_GMAX, 1, ncclMax); if (rc) return rc;
+            hipLaunchKernelGGL(k_scal_unpack, dim3(1), dim3(64), 0, st, h->scal.p, h->red_scal, ctx->nranks);
         }
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             LAUNCH(h, KID_FINALIZE, k_finalize_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -139,7 +137,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
             if (nP > 0)
                 LAUNCH(h, KID_COST, k_point_cost, gp_pts_lm, PTB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST, (int)SC_TOTAL);
-            if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p);
+            if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
             hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
@@ -277,7 +275,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     AL(diag_cam, (size_t)Nc * 6); AL(diag_pt, (size_t)nP * 3); AL(diag_f, 1);
     AL(Vinv, (size_t)nP * 6); AL(Vs, (size_t)nP * 12); AL(gp, (size_t)nP * 3); AL(Wf, (size_t)nP * 3);
     const size_t nnzb = (size_t)F.row_ptr[Nc], n = (size_t)Nc * DC;
-    const size_t n_red = nnzb * DC * DC + (n + 1) + 3 * n + SC_NSUM;
+    const size_t n_red = nnzb * DC * DC + (n + 1) + 3 * n + SC_NSUM + (size_t)ctx->nranks;   // ... | scalar sums | gradient-max slot per rank
     h->n_red = (int)n_red;
     // [scal | pcg flags + factorisation fail word | redbuf] share one allocation: one memset per LM iteration zeroes them all,
     // and one copy brings both scalar groups back
