@@ -58,7 +58,36 @@ def rot_case():
                 cost_focal=cost2, edges=np.array(edges))
 
 
+def ransac_case():
+    """3-point solvers (both variants), Sampson values, make/decompose round trip, Sampson least squares, LO-MSAC on a
+    100-correspondence / 30 % outlier pair (SURVEY 8c list)."""
+    rng = np.random.default_rng(17)
+    u, v, R, E, inl = synth.make_relative_pose_problem(100, seed=4, noise=1 / 600, outlier_frac=0.3, rotation_deg=12)
+    samples = np.array([rng.choice(100, 3, replace=False) for _ in range(12)], np.int32)
+    Es_am = np.array([np.array(O.spherical_solver(u, v, s)) for s in samples])
+    poly = [O.spherical_solver_poly(u, v, s) for s in samples]
+    Es_poly = np.array([np.array(p[0]) for p in poly]); im_poly = np.array([p[1] for p in poly])
+    samp = np.array([O.sampson(E, u[i], v[i]) for i in range(100)])
+    Rs = synth.so3exp(rng.normal(size=(6, 3)) * 0.5)
+    Em = np.array([O.make_spherical_essential_matrix(Ri, False) for Ri in Rs]); Emi = np.array([O.make_spherical_essential_matrix(Ri, True) for Ri in Rs])
+    dec = np.array([np.concatenate(O.decompose_spherical_essential_matrix(Ei, False)) for Ei in Em])
+    thr = (2 / 600) ** 2
+    o = O.ransac_pair(u, v, thr, min_num_inliers=20)
+    return dict(u=u, v=v, R=R, E=E, inlier_gt=inl, samples=samples, Es_action=Es_am, Es_poly=Es_poly, poly_imag=im_poly, sampson=samp, Rs=Rs, E_outward=Em,
+                E_inward=Emi, decomposed=dec, thr=thr, ransac_E=o["E"], ransac_R=o["R"], ransac_inliers=o["inliers"], ransac_num_inliers=o["num_inliers"],
+                ransac_iterations=o["iterations"], ransac_score=o["score"])
+
+
+def retri_case():
+    p = synth.make_circle(60, 400, 6, rot_noise_deg=0.0, pixel_noise=0.4, seed=23)
+    bad = synth.corrupt_observations(p, 0.1, seed=9)
+    X, nin = O.retriangulate(p, 4)
+    return dict(cameras=p.cameras, focal=p.focal, obs_xy=p.obs_xy, obs_cam=p.obs_cam, obs_pt=p.obs_pt, corrupted=bad, points=X, num_inliers=nin)
+
+
 if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "ransac.npz"), **ransac_case())
+    np.savez_compressed(os.path.join(HERE, "retriangulate.npz"), **retri_case())
     np.savez_compressed(os.path.join(HERE, "so3.npz"), **so3_cases())
     for sph in (True, False):
         for ff in (True, False):

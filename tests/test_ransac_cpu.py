@@ -127,3 +127,22 @@ def test_quartic_roots_against_numpy(oracle):
     Eb, im = oracle.spherical_solver_poly(u, v, [0, 1, 2])
     real_b = [e for e, i in zip(Eb, im) if abs(i) < 1e-9]
     assert 2 <= len(real_b) <= 4 and all(min(frob_err(e, a) for a in Ea) < 1e-7 for e in real_b)
+
+
+def test_ransac_golden(oracle):
+    """tests/golden/ransac.npz (generated by tests/golden/make_golden.py): both minimal solvers, Sampson values, make/decompose,
+    LO-MSAC on the 100-correspondence / 30 % outlier pair -- the oracle reproduces its committed outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ransac.npz"))
+    u, v = g["u"], g["v"]
+    for s, Ea, Eb in zip(g["samples"], g["Es_action"], g["Es_poly"]):
+        assert np.allclose(np.array(oracle.spherical_solver(u, v, s)), Ea, rtol=0, atol=1e-9)
+        assert np.allclose(np.array(oracle.spherical_solver_poly(u, v, s)[0]), Eb, rtol=0, atol=1e-7)
+    assert np.allclose([oracle.sampson(g["E"], u[i], v[i]) for i in range(len(u))], g["sampson"], rtol=1e-12, atol=1e-300)
+    for R, Eo, Ei, d in zip(g["Rs"], g["E_outward"], g["E_inward"], g["decomposed"]):
+        assert np.allclose(oracle.make_spherical_essential_matrix(R, False), Eo, atol=1e-15) and np.allclose(oracle.make_spherical_essential_matrix(R, True), Ei, atol=1e-15)
+        assert np.allclose(np.concatenate(oracle.decompose_spherical_essential_matrix(Eo, False)), d, atol=1e-12)
+    o = oracle.ransac_pair(u, v, float(g["thr"]), min_num_inliers=20)
+    assert o["num_inliers"] == int(g["ransac_num_inliers"]) and o["iterations"] == int(g["ransac_iterations"]) and np.array_equal(o["inliers"], g["ransac_inliers"])
+    assert np.allclose(o["R"], g["ransac_R"], atol=1e-10) and abs(o["score"] - float(g["ransac_score"])) <= 1e-12
+    assert (o["inliers"][g["inlier_gt"]]).mean() >= 0.85 and (o["inliers"][~g["inlier_gt"]]).mean() < 0.1

@@ -135,3 +135,19 @@ def test_polynomial_solver_recovers_ground_truth_and_batch_runs_with_it(gpu_ctx)
     b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=0)
     for k, p in enumerate(probs):
         assert rot_err(p[2], a["R"][k]) < 5e-3 and abs(int(a["num_inliers"][k]) - int(b["num_inliers"][k])) <= 0.02 * len(p[0])
+
+
+def test_gpu_against_ransac_golden(gpu_ctx):
+    """HIP path vs the committed fixture tests/golden/ransac.npz (no oracle call): both solver variants on the golden samples,
+    and the batch RANSAC on the golden pair."""
+    import os
+    from spherical_sfm_amd import ransac
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ransac.npz"))
+    u, v = g["u"], g["v"]
+    for poly, ref_all in ((False, g["Es_action"]), (True, g["Es_poly"])):
+        got = ransac.solver_probe(gpu_ctx, u, v, g["samples"], poly=poly)
+        errs = [min(frob_err(e, r) for r in ref) for Es, ref in zip(got, ref_all) for e in Es]
+        assert len(errs) >= 2 * len(g["samples"]) and np.median(errs) < 1e-9 and max(errs) < 1e-5
+    out = ransac.estimate_pairs(gpu_ctx, [(u, v)], float(g["thr"]), min_num_inliers=20)
+    assert (out["inliers"][0] == g["ransac_inliers"]).mean() >= 0.97
+    assert rot_err(g["ransac_R"], out["R"][0]) < 2e-3 and rot_err(g["R"], out["R"][0]) < 5e-3

@@ -48,3 +48,17 @@ def test_point_behind_all_cameras_or_inconsistent_becomes_zero(oracle):
     X, nin = oracle.retriangulate(prob, 2)
     assert not X[7].any() and nin[7] < 3
     assert X[np.arange(100) != 7].any(axis=1).all()
+
+
+def test_retriangulate_golden(oracle):
+    """tests/golden/retriangulate.npz: the oracle reproduces its committed points and inlier counts (std::mt19937 streams included)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "retriangulate.npz"))
+    Np = len(g["points"])
+    p = synth.BAProblem(cameras=g["cameras"], points=np.ones((Np, 3)), focal=float(g["focal"]), obs_xy=g["obs_xy"], obs_cam=g["obs_cam"], obs_pt=g["obs_pt"],
+                        rot_fixed=np.zeros(len(g["cameras"]), np.uint8), trans_fixed=np.ones(len(g["cameras"]), np.uint8), pt_fixed=np.zeros(Np, np.uint8),
+                        focal_fixed=True, gt_cameras=g["cameras"], gt_points=g["points"], gt_focal=0.0)
+    X, nin = oracle.retriangulate(p, 2)
+    assert np.array_equal(nin, g["num_inliers"]) and np.allclose(X, g["points"], rtol=1e-9, atol=1e-12)
+    mask = np.zeros(Np, bool); mask[g["corrupted"]] = True
+    assert (nin[mask] <= 5).all() and (nin[~mask] == 6).mean() > 0.99

@@ -92,3 +92,18 @@ def test_duplicate_and_unsorted_observations(oracle, gpu_ctx):
     p2 = dataclasses.replace(prob, obs_xy=dup_xy, obs_cam=dup_c, obs_pt=dup_p)
     X1, n1 = ba.retriangulate(gpu_ctx, p2)
     assert np.array_equal(n0, n1) and np.abs(X0 - X1).max() <= 1e-9 * np.abs(X0).max()
+
+
+def test_gpu_against_retriangulate_golden(gpu_ctx):
+    """HIP path vs the committed fixture tests/golden/retriangulate.npz (no oracle call)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "retriangulate.npz"))
+    Np = len(g["points"])
+    p = synth.BAProblem(cameras=g["cameras"], points=np.ones((Np, 3)), focal=float(g["focal"]), obs_xy=g["obs_xy"], obs_cam=g["obs_cam"], obs_pt=g["obs_pt"],
+                        rot_fixed=np.zeros(len(g["cameras"]), np.uint8), trans_fixed=np.ones(len(g["cameras"]), np.uint8), pt_fixed=np.zeros(Np, np.uint8),
+                        focal_fixed=True, gt_cameras=g["cameras"], gt_points=g["points"], gt_focal=0.0)
+    X, nin = ba.retriangulate(gpu_ctx, p)
+    assert (nin == g["num_inliers"]).mean() >= 0.99
+    same = nin == g["num_inliers"]
+    rel = np.linalg.norm(X - g["points"], axis=1)[same] / np.linalg.norm(g["points"][same], axis=1)
+    assert np.median(rel) < 1e-5 and np.quantile(rel, 0.99) < 2e-4
