@@ -120,7 +120,11 @@ typedef struct {
 int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
                  uint8_t* obs_used, int32_t* cam_pos);
 
-/* One call = flatten (src/sfm.cpp:240-263 rules) + upload + device LM loop + scatter back. */
+/* One call = flatten (src/sfm.cpp:240-263 rules) + upload + device LM loop + scatter back.
+ * The context keeps the resident plan of the last problem STRUCTURE it solved (observation ids in order, fixed masks, which
+ * points are zero, sizes): a call with the same structure only uploads parameters and pixels -- the drivers' Optimize ->
+ * Retriangulate -> Optimize pattern.  summary.t_flatten_s is 0 on such a call.  SSFM_NO_PLAN_CACHE=1 in the environment
+ * disables the cache; ssfm_ctx_destroy releases it. */
 int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s);
 
 /* Staged form: problem stays resident in HBM between runs (bench.py, multi-GPU sharding). */
