@@ -770,8 +770,13 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC];
-        double b[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+        const double g3[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+        double b[3] = {g3[0], g3[1], g3[2]};
         const int j0 = pt_start[p], j1 = pt_start[p + 1];
+        // ONE sweep over the observations: with M_j = a_j + B_j z  (a_j = camera/focal part of J s, B_j = Jp_j diag(s_p), z = point step)
+        // the model cost change  -sum M_j.(r_j - M_j/2)  expands into sums that do not depend on z -- sum a.a, sum a.r, B^T a, B^T B --
+        // so the second re-linearisation of every observation (after z is known) is not needed
+        double Saa = 0.0, Sar = 0.0, Vr[6] = {0, 0, 0, 0, 0, 0};
         for (int j = j0; j < j1; j++) {
             const int c = obs_cam[j]; const double2 o = obs_xy[j];
             ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
@@ -779,8 +784,12 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
 #pragma unroll
             for (int a = 0; a < DC; a++) { const double ya = y[c * DC + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
+            Saa += m0 * m0 + m1 * m1; Sar += m0 * L.r[0] + m1 * L.r[1];
+            const double B0[3] = {L.Jp[0][0] * sp[0], L.Jp[0][1] * sp[1], L.Jp[0][2] * sp[2]}, B1[3] = {L.Jp[1][0] * sp[0], L.Jp[1][1] * sp[1], L.Jp[1][2] * sp[2]};
+            Vr[0] += B0[0] * B0[0] + B1[0] * B1[0]; Vr[1] += B0[0] * B0[1] + B1[0] * B1[1]; Vr[2] += B0[0] * B0[2] + B1[0] * B1[2];
+            Vr[3] += B0[1] * B0[1] + B1[1] * B1[1]; Vr[4] += B0[1] * B0[2] + B1[1] * B1[2]; Vr[5] += B0[2] * B0[2] + B1[2] * B1[2];
 #pragma unroll
-            for (int k = 0; k < 3; k++) b[k] -= (L.Jp[0][k] * m0 + L.Jp[1][k] * m1) * sp[k];
+            for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
         }
         const double* Vi = Vinv + 6 * p;
         double yp[3];
@@ -788,18 +797,11 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         yp[1] = Vi[1] * b[0] + Vi[3] * b[1] + Vi[4] * b[2];
         yp[2] = Vi[2] * b[0] + Vi[4] * b[1] + Vi[5] * b[2];
         if (!(sp[0] > 0.0)) yp[0] = yp[1] = yp[2] = 0.0;
-        // second sweep: model residual with the full step (= -y)
-        for (int j = j0; j < j1; j++) {
-            const int c = obs_cam[j]; const double2 o = obs_xy[j];
-            ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
-            double Jc[2][DC]; cam_block<DC>(L, scale_cam + 6 * c, Jc);
-            double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
-#pragma unroll
-            for (int a = 0; a < DC; a++) { const double ya = y[c * DC + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
-#pragma unroll
-            for (int k = 0; k < 3; k++) { m0 += L.Jp[0][k] * sp[k] * yp[k]; m1 += L.Jp[1][k] * sp[k] * yp[k]; }
-            m0 = -m0; m1 = -m1;
-            acc[0] += m0 * (L.r[0] + 0.5 * m0) + m1 * (L.r[1] + 0.5 * m1);
+        {
+            const double zg = yp[0] * g3[0] + yp[1] * g3[1] + yp[2] * g3[2];
+            const double zBa = yp[0] * (g3[0] - b[0]) + yp[1] * (g3[1] - b[1]) + yp[2] * (g3[2] - b[2]);       // z . sum B^T a
+            const double zVz = Vr[0] * yp[0] * yp[0] + Vr[3] * yp[1] * yp[1] + Vr[5] * yp[2] * yp[2] + 2.0 * (Vr[1] * yp[0] * yp[1] + Vr[2] * yp[0] * yp[2] + Vr[4] * yp[1] * yp[2]);
+            acc[0] = -(Sar + zg) + 0.5 * (Saa + 2.0 * zBa + zVz);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
