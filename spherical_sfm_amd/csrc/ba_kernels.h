@@ -733,7 +733,7 @@ template <int DC>
 __global__ void __launch_bounds__(1024)
 k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
              const double* __restrict__ scale_f, const double* __restrict__ y, int Nc,
-             double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ scal) {
+             double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c, double* __restrict__ scal) {
     __shared__ double red[2 * 16];
     constexpr int off = (DC == 6) ? 0 : 3;
     double acc[2] = {0, 0};
@@ -749,8 +749,15 @@ k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, c
         if (s > 0.0) { const double d = -y[Nc * DC] * s; v += d; acc[0] += d * d; acc[1] += v * v; }
         focal_c[0] = v;
     }
-    block_sum<2>(acc, red);
+    block_sum<2>(acc, red);                                       // (its barriers also publish cam_c to the whole workgroup)
     if (threadIdx.x == 0) { scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; }
+    // rotation tables of the candidate cameras (what a separate k_cam_rot launch did)
+    for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
+        const double aa[3] = {cam_c[c * 6 + 3], cam_c[c * 6 + 4], cam_c[c * 6 + 5]};
+        double R[9], Rd[9], M[9];
+        angle_axis_derivative_aid(aa, R, Rd, M);
+        for (int i = 0; i < 9; i++) { rot_c[c * 27 + i] = R[i]; rot_c[c * 27 + 9 + i] = Rd[i]; rot_c[c * 27 + 18 + i] = M[i]; }
+    }
 }
 
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
@@ -762,10 +769,11 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
                 const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                 const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
                 const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
-                const double* __restrict__ y, int Nc, int loss, double la, double* __restrict__ pts_c, double* __restrict__ scal) {
-    __shared__ double red[3 * 4];
+                const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
+                const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal) {
+    __shared__ double red[4 * 4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[3] = {0, 0, 0};   // model, step2, xn2
+    double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
     if (p < nP) {
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
@@ -803,15 +811,22 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             const double zVz = Vr[0] * yp[0] * yp[0] + Vr[3] * yp[1] * yp[1] + Vr[5] * yp[2] * yp[2] + 2.0 * (Vr[1] * yp[0] * yp[1] + Vr[2] * yp[0] * yp[2] + Vr[4] * yp[1] * yp[2]);
             acc[0] = -(Sar + zg) + 0.5 * (Saa + 2.0 * zBa + zVz);
         }
+        double Xc[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const double d = -yp[k] * sp[k]; const double v = X[k] + d;
-            pts_c[3 * p + k] = v;
+            pts_c[3 * p + k] = v; Xc[k] = v;
             if (sp[k] > 0.0) { acc[1] += d * d; acc[2] += v * v; }
         }
+        // robustified cost at the candidate (cameras, focal, this point): what a separate k_point_cost launch did
+        const double fcand = focal_c[0];
+        for (int j = j0; j < j1; j++) { const int c = obs_cam[j]; const double2 o = obs_xy[j]; acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la); }
     }
-    block_sum<3>(acc, red);
-    if (threadIdx.x == 0) { double* sl = scal_slot(scal); unsafeAtomicAdd(&sl[SC_MODEL], acc[0]); unsafeAtomicAdd(&sl[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&sl[SC_XN2_PT], acc[2]); }
+    block_sum<4>(acc, red);
+    if (threadIdx.x == 0) {
+        double* sl = scal_slot(scal);
+        unsafeAtomicAdd(&sl[SC_MODEL], acc[0]); unsafeAtomicAdd(&sl[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&sl[SC_XN2_PT], acc[2]); unsafeAtomicAdd(&sl[SC_CAND_COST], acc[3]);
+    }
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------

@@ -130,13 +130,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         auto enqueue_tail = [&]() -> int {
-            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, h->scal.p);
+            // candidate cameras + their rotation tables; then per point: back-substitution, candidate, model cost change, candidate cost
+            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p);
             if (nP > 0)
                 LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
-                       h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, pts_c, h->scal.p);
-            LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
-            if (nP > 0)
-                LAUNCH(h, KID_COST, k_point_cost, gp_pts_lm, PTB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, loss, la, h->scal.p + SC_CAND_COST, (int)SC_TOTAL);
+                       h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p);
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
             hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
