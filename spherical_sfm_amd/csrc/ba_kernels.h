@@ -521,6 +521,64 @@ k_sym_matvec(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, c
     if (c < Nc && lane == 0) { double s = 0.0; for (int a = 0; a < DC; a++) s += part[w][a]; pqpart[c] = s; }
 }
 
+// focal arrow + q = S x in one launch: every workgroup recomputes phi = (rho - S_fc.V) / (S_ff - S_fc.U) (two short dot products),
+// forms x = [V - U phi ; phi] on the fly (V, U in elimination order) and multiplies its four block rows; x is written out for the
+// kernels that follow.  Replaces k_band_combine + k_sym_matvec for the lower-triangle storage.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_arrow_matvec(const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
+               const double* __restrict__ rho_ptr, const int* __restrict__ pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
+               const int* __restrict__ trans_ptr, const int* __restrict__ trans_blk, const int* __restrict__ trans_row,
+               const double* __restrict__ S_val, int Nc, double* __restrict__ x, double* __restrict__ q) {
+    __shared__ double red[2 * 4];
+    __shared__ double part[4][64];
+    __shared__ double sphi;
+    constexpr int BB = DC * DC;
+    constexpr int LW = (64 / DC) * DC;
+    const int n = Nc * DC, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double acc[2] = {0, 0};
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a; acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi]; }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) sphi = (rho_ptr[0] - acc[0]) / (Sff[0] - acc[1]);
+    __syncthreads();
+    const double phi = sphi;
+    const int c = blockIdx.x * 4 + w;
+    if (c < Nc) {
+        const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tb = trans_ptr[c], nt = trans_ptr[c + 1] - tb;
+        double s = 0.0;
+        if (lane < LW) {
+            const int a = lane % DC;
+            for (int idx = lane; idx < (nnb + nt) * DC; idx += LW) {
+                const int b = idx / DC;
+                const int col = (b < nnb) ? col_idx[rb + b] : trans_row[tb + (b - nnb)];
+                const int pc = pos[col] * DC;
+                double xv[DC];
+#pragma unroll
+                for (int k = 0; k < DC; k++) xv[k] = V[pc + k] - U[pc + k] * phi;
+                if (b < nnb) {
+                    const double* row = S_val + ((size_t)(rb + b)) * BB + a * DC;
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += row[k] * xv[k];
+                } else {
+                    const double* blk = S_val + (size_t)trans_blk[tb + (b - nnb)] * BB;      // block (row r, col c): use its transpose
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += blk[k * DC + a] * xv[k];
+                }
+            }
+        }
+        part[w][lane] = s;
+    }
+    __syncthreads();
+    if (c < Nc && lane < DC) {
+        double s = 0.0;
+        for (int l = lane; l < LW; l += DC) s += part[w][l];
+        q[c * DC + lane] = s + Sfc[c * DC + lane] * phi;
+        const int pi = pos[c] * DC + lane;
+        x[c * DC + lane] = V[pi] - U[pi] * phi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) x[n] = phi;
+}
+
 // ---- K2b: after the (optional) all-reduce: LM diagonal on the camera blocks, block-Jacobi inverse, focal row
 template <int DC>
 __global__ void k_finalize_S(const int* __restrict__ row_ptr, const int* __restrict__ diag_slot, const double* __restrict__ scale_cam,
