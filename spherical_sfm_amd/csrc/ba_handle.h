@@ -52,6 +52,7 @@ struct ssfm_ba_handle {
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
+    double* host_sp = nullptr;           // pinned read-back buffer of the LM loop
     bool scale_ready = false;
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
     int pcg_prev_iters = 16;
@@ -82,6 +83,7 @@ struct ssfm_ba_handle {
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
+        if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         for (auto& e : phase_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }

@@ -41,7 +41,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
     // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
-    double host_sp[SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1];            // [scalar replicas | solver flags], one copy per iteration
+    // [scalar replicas | solver flags], one copy per iteration, into pinned memory (a pageable target adds a staging hop to the
+    // only host round trip of the iteration)
+    if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
+    double* host_sp = h->host_sp;
     double* host_scal = host_sp; double* host_pcg1 = host_sp + SC_NSLOT * SC_TOTAL;
     auto fold_host_scal = [&]() {                                    // replicas -> replica 0 (sums; the gradient max by max)
         for (int k = 0; k < SC_TOTAL; k++) {
