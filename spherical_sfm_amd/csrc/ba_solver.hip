@@ -86,7 +86,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     S->num_successful_steps = 1; S->num_unsuccessful_steps = 0; S->num_linearizations = 0; S->pcg_iterations_total = 0;
     S->termination = SSFM_NO_CONVERGENCE;
     float ms_lin = 0, ms_schur = 0, ms_pcg = 0, ms_upd = 0;
-    for (auto& e : h->phase_ev) if (!e) SSFM_HIP_CHECK(ctx, hipEventCreate(&e));
+    // per-phase device times (summary.t_kernel_*_ms) cost five event records and four queries per iteration, the queries on the
+    // host's critical path between two iterations: only with profiling on (ssfm_ba_set_profiling) or options.verbose
+    const bool phases = h->profile || O.verbose;
+    if (phases) for (auto& e : h->phase_ev) if (!e) SSFM_HIP_CHECK(ctx, hipEventCreate(&e));
 
     while (true) {
         if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
@@ -94,11 +97,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         iteration++;
         // ================= assemble at x with the current radius =================
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));   // scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]
-        SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
+        if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0)
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p);
-        SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
+        if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         if (!F.cs_task_cam.empty()) {
             const int ntasks = (int)F.cs_task_cam.size();
             LAUNCH(h, KID_CAM_SUMS, k_cam_sums2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->cam_obs.p, h->cam_obs_pt.p, h->cs_task_cam.p,
@@ -124,14 +127,14 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
                    radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         }
-        SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[2], st));
+        if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[2], st));
         // ================= solve the reduced system, then step / candidate / model cost / candidate cost =================
         // The direct solve and the tail are enqueued back to back; the solver's residual flags come back with the
         // iteration scalars in ONE host synchronisation.  Only if the residual test failed (rare) does PCG refinement
         // run and the tail get redone.
         int pcg_iters = 0; bool pcg_ok = false;
         { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
-        SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
+        if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         auto enqueue_tail = [&]() -> int {
             // candidate cameras + their rotation tables; then per point: back-substitution, candidate, model cost change, candidate cost
             LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p);
@@ -145,7 +148,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             return SSFM_OK;
         };
         { int rc = enqueue_tail(); if (rc) return rc; }
-        SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
+        if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         fold_host_scal();
         if (O.preconditioner == 0) {
@@ -160,7 +163,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             }
         }
         h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
-        { float ms;
+        if (phases) { float ms;
           if (hipEventElapsedTime(&ms, h->phase_ev[0], h->phase_ev[1]) == hipSuccess) ms_lin += ms;
           if (hipEventElapsedTime(&ms, h->phase_ev[1], h->phase_ev[2]) == hipSuccess) ms_schur += ms;
           if (hipEventElapsedTime(&ms, h->phase_ev[2], h->phase_ev[3]) == hipSuccess) ms_pcg += ms;
