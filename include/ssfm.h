@@ -180,6 +180,14 @@ void ssfm_ransac_default_options(ssfm_ransac_options* o);
 int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
                       double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
                       int32_t* num_inliers, double* scores);
+/* Multi-GPU form of the same call (BASELINE configs[3]: exhaustive pairwise RANSAC over several GPUs; the reference's
+ * counterpart is the `#pragma omp parallel for` over matches, spherical_sfm_tools.cpp:332).  Every rank of the context's
+ * communicator (ssfm_comm_init / ssfm_comm_init_host) passes the SAME full arguments; rank r estimates pairs r, r + nranks, ...
+ * with the random streams of their global indices, and one sum all-reduce returns every pair's result on every rank --
+ * bit-identical to ssfm_ransac_batch on one GPU.  Without a communicator it is ssfm_ransac_batch. */
+int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
+                              double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R,
+                              uint8_t* inlier_mask, int32_t* num_inliers, double* scores);
 /* parity probe: spherical_solver_action_matrix (src/spherical_solvers.cpp:102-311) on S given 3-point samples
  * (samples: [S*3] indices into the n rays).  Es: [S*36] = up to 4 column-major 3x3 per sample (real solutions only),
  * counts: [S]. */

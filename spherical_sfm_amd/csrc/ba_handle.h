@@ -117,29 +117,11 @@ static hipError_t upload(DevBuf<T>& b, const std::vector<T>& v, hipStream_t s) {
 }
 
 static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
-    ssfm_ctx* ctx = h->ctx;
-    if (!ctx->collective) return SSFM_OK;
-    if (ctx->host_allreduce) {                       // caller-supplied host collective (MPI, gloo, ...): stage through pinned memory
-        if (ctx->host_stage_n < n) {
-            if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
-            ctx->host_stage = nullptr; ctx->host_stage_n = 0;
-            SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_stage, n * sizeof(double), hipHostMallocDefault));
-            ctx->host_stage_n = n;
-        }
-        h->span_begin(KID_ALLREDUCE);
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_stage, buf, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->host_allreduce(ctx->host_allreduce_user, ctx->host_stage, (uint64_t)n, op == ncclMax ? SSFM_REDUCE_MAX : SSFM_REDUCE_SUM) != 0)
-            return fail(ctx, SSFM_ERR_COMM, "host all-reduce hook failed");
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->host_stage, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        h->span_end();
-        return SSFM_OK;
-    }
+    if (!h->ctx->collective) return SSFM_OK;
     h->span_begin(KID_ALLREDUCE);
-    ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, op, h->ctx->comm, h->ctx->stream);
+    const int rc = ctx_allreduce(h->ctx, buf, n, op);
     h->span_end();
-    if (r != ncclSuccess) return fail(h->ctx, SSFM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    return SSFM_OK;
+    return rc;
 }
 
 // Solve S y = rhs (block-CSR S with dense focal border) into h->px.

@@ -335,10 +335,12 @@ __global__ void k_solver_probe(int S, const int* __restrict__ sample, const doub
 template <bool POLY>
 __global__ void __launch_bounds__(256)
 k_ransac_hypotheses(const int* __restrict__ pair_ptr, const double* __restrict__ u, const double* __restrict__ v, double sq_thresh,
-                    int num_hyp, unsigned long long seed, double* __restrict__ bestE, double* __restrict__ bestScore) {
+                    int num_hyp, unsigned long long seed, const int* __restrict__ pair_id, double* __restrict__ bestE,
+                    double* __restrict__ bestScore) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sScore[256]; __shared__ int sIdx[256];
     const int pair = blockIdx.x;
+    const int stream_id = pair_id ? pair_id[pair] : pair;      // a sharded batch keeps the random stream of the pair's global index
     const int r0 = pair_ptr[pair], n = pair_ptr[pair + 1] - r0;
     double* su = lds; double* sv = lds + (size_t)3 * n;
     for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) { su[i] = u[(size_t)3 * r0 + i]; sv[i] = v[(size_t)3 * r0 + i]; }
@@ -347,7 +349,7 @@ k_ransac_hypotheses(const int* __restrict__ pair_ptr, const double* __restrict__
     if (n >= 3) {
         for (int h = threadIdx.x; h < num_hyp; h += blockDim.x) {
             // three distinct indices from a counter-based generator (sampling without replacement, sampling.h:77-97)
-            int idx[3]; unsigned long long ctr = splitmix64(seed ^ ((unsigned long long)pair << 32) ^ (unsigned long long)h);
+            int idx[3]; unsigned long long ctr = splitmix64(seed ^ ((unsigned long long)stream_id << 32) ^ (unsigned long long)h);
             for (int i = 0; i < 3; i++) {
                 bool dup = true;
                 while (dup) { ctr = splitmix64(ctr); idx[i] = (int)((ctr >> 11) % (unsigned long long)n); dup = false; for (int j = 0; j < i; j++) if (idx[j] == idx[i]) dup = true; }
@@ -623,20 +625,19 @@ extern "C" void ssfm_ransac_default_options(ssfm_ransac_options* o) {
     o->use_poly_solver = 0;            // estimate_pairwise passes use_poly_solver = false (spherical_sfm_tools.cpp:378)
 }
 
-extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,
-                                 const ssfm_ransac_options* opt, double* E_out, double* R_out, uint8_t* inlier_mask, int32_t* num_inliers,
-                                 double* scores) {
-    if (!ctx || !pair_ptr || !u || !v || num_pairs <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: bad arguments");
+static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,
+                             const ssfm_ransac_options& O, const int32_t* pair_id, double* E_out, double* R_out, uint8_t* inlier_mask,
+                             int32_t* num_inliers, double* scores) {
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    ssfm_ransac_options O; if (opt) O = *opt; else ssfm_ransac_default_options(&O);
     const int total = pair_ptr[num_pairs];
     int max_n = 0; for (int p = 0; p < num_pairs; p++) max_n = std::max(max_n, pair_ptr[p + 1] - pair_ptr[p]);
     const size_t lds = (size_t)6 * max_n * sizeof(double);
     if (lds > 150 * 1024) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: more than 3200 correspondences in one pair");
-    DevBuf<int> dptr, dnin; DevBuf<double> du, dv, dE, dS, dR; DevBuf<unsigned char> dmask;
+    DevBuf<int> dptr, dnin, dpid; DevBuf<double> du, dv, dE, dS, dR; DevBuf<unsigned char> dmask;
     std::vector<int> ptr(pair_ptr, pair_ptr + num_pairs + 1);
     SSFM_HIP_CHECK(ctx, upload(dptr, ptr, st));
+    if (pair_id) { std::vector<int> ids(pair_id, pair_id + num_pairs); SSFM_HIP_CHECK(ctx, upload(dpid, ids, st)); }
     SSFM_HIP_CHECK(ctx, du.alloc((size_t)3 * total)); SSFM_HIP_CHECK(ctx, dv.alloc((size_t)3 * total));
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(du.p, u, (size_t)3 * total * sizeof(double), hipMemcpyHostToDevice, st));
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(dv.p, v, (size_t)3 * total * sizeof(double), hipMemcpyHostToDevice, st));
@@ -644,10 +645,10 @@ extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t
     SSFM_HIP_CHECK(ctx, dmask.alloc(total)); SSFM_HIP_CHECK(ctx, dnin.alloc(num_pairs));
     if (O.use_poly_solver) {
         if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_hypotheses<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, dE.p, dS.p);
+        hipLaunchKernelGGL(k_ransac_hypotheses<true>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, pair_id ? dpid.p : nullptr, dE.p, dS.p);
     } else {
         if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_hypotheses<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, dE.p, dS.p);
+        hipLaunchKernelGGL(k_ransac_hypotheses<false>, dim3(num_pairs), dim3(256), lds, st, dptr.p, du.p, dv.p, sq_thresh, O.num_hypotheses, (unsigned long long)O.seed, pair_id ? dpid.p : nullptr, dE.p, dS.p);
     }
     hipLaunchKernelGGL(k_ransac_refine, dim3(num_pairs), dim3(256), 0, st, dptr.p, du.p, dv.p, sq_thresh, O.inward, O.min_num_inliers, O.final_least_squares,
                        dE.p, dS.p, dR.p, dmask.p, dnin.p);
@@ -659,7 +660,78 @@ extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t
     if (num_inliers) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(num_inliers, dnin.p, num_pairs * sizeof(int), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     for (int p = 0; p < num_pairs; p++) { if (E_out) rm_to_cm(&hE[9 * (size_t)p], E_out + 9 * (size_t)p); if (R_out) rm_to_cm(&hR[9 * (size_t)p], R_out + 9 * (size_t)p); if (scores) scores[p] = hS[p]; }
-    dptr.free(); dnin.free(); du.free(); dv.free(); dE.free(); dS.free(); dR.free(); dmask.free();
+    dptr.free(); dnin.free(); dpid.free(); du.free(); dv.free(); dE.free(); dS.free(); dR.free(); dmask.free();
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,
+                                 const ssfm_ransac_options* opt, double* E_out, double* R_out, uint8_t* inlier_mask, int32_t* num_inliers,
+                                 double* scores) {
+    if (!ctx || !pair_ptr || !u || !v || num_pairs <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: bad arguments");
+    ssfm_ransac_options O; if (opt) O = *opt; else ssfm_ransac_default_options(&O);
+    return ransac_batch_impl(ctx, num_pairs, pair_ptr, u, v, sq_thresh, O, nullptr, E_out, R_out, inlier_mask, num_inliers, scores);
+}
+
+// Multi-GPU estimate_pairwise (BASELINE configs[3]): image pairs are independent, so rank r of the context's
+// communicator takes pairs r, r + nranks, ... (round robin keeps neighbouring-frame pairs, which have the most correspondences,
+// spread over the ranks), runs them as one local batch with the random streams of their global indices, and one sum all-reduce
+// of a zero-filled result table hands every rank every pair: [E 9 | R 9 | score | num_inliers] per pair + the inlier masks packed
+// 32 per double (exact: one rank contributes each word).  Same results as ssfm_ransac_batch on one GPU, bit for bit.
+extern "C" int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
+                                         double sq_thresh, const ssfm_ransac_options* opt, double* E_out, double* R_out,
+                                         uint8_t* inlier_mask, int32_t* num_inliers, double* scores) {
+    if (!ctx || !pair_ptr || !u || !v || num_pairs <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_sharded: bad arguments");
+    ssfm_ransac_options O; if (opt) O = *opt; else ssfm_ransac_default_options(&O);
+    const int nr = ctx->collective ? ctx->nranks : 1, rk = ctx->collective ? ctx->rank : 0;
+    if (nr == 1 && !ctx->collective) return ransac_batch_impl(ctx, num_pairs, pair_ptr, u, v, sq_thresh, O, nullptr, E_out, R_out, inlier_mask, num_inliers, scores);
+    const int total = pair_ptr[num_pairs];
+    // local batch
+    std::vector<int> ids, lptr(1, 0);
+    for (int p = rk; p < num_pairs; p += nr) { ids.push_back(p); lptr.push_back(lptr.back() + pair_ptr[p + 1] - pair_ptr[p]); }
+    const int nl = (int)ids.size(), ltotal = lptr.back();
+    std::vector<double> lu((size_t)3 * ltotal), lv((size_t)3 * ltotal), lE((size_t)9 * nl), lR((size_t)9 * nl), lS(nl);
+    std::vector<uint8_t> lmask(ltotal); std::vector<int> lnin(nl);
+    for (int i = 0; i < nl; i++) {
+        const size_t src = (size_t)3 * pair_ptr[ids[i]], cnt = (size_t)3 * (lptr[i + 1] - lptr[i]);
+        if (cnt) { std::memcpy(&lu[(size_t)3 * lptr[i]], u + src, cnt * sizeof(double)); std::memcpy(&lv[(size_t)3 * lptr[i]], v + src, cnt * sizeof(double)); }
+    }
+    if (nl > 0) {
+        const int rc = ransac_batch_impl(ctx, nl, lptr.data(), lu.data(), lv.data(), sq_thresh, O, ids.data(), lE.data(), lR.data(), lmask.data(), lnin.data(), lS.data());
+        if (rc) return rc;
+    }
+    // result table; every mask word belongs to exactly one pair's rank only if words do not straddle pairs: pack per pair
+    std::vector<size_t> wptr(num_pairs + 1, 0);
+    for (int p = 0; p < num_pairs; p++) wptr[p + 1] = wptr[p] + (size_t)(pair_ptr[p + 1] - pair_ptr[p] + 31) / 32;
+    const size_t per = 20, n_tab = per * num_pairs + wptr[num_pairs];
+    std::vector<double> tab(n_tab, 0.0);
+    for (int i = 0; i < nl; i++) {
+        const int p = ids[i]; double* t = &tab[per * (size_t)p];
+        std::memcpy(t, &lE[9 * (size_t)i], 9 * sizeof(double)); std::memcpy(t + 9, &lR[9 * (size_t)i], 9 * sizeof(double));
+        t[18] = lS[i]; t[19] = (double)lnin[i];
+        double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+        const int n = lptr[i + 1] - lptr[i];
+        for (int k = 0; k < n; k += 32) { uint32_t bits = 0; for (int q = 0; q < 32 && k + q < n; q++) bits |= (uint32_t)(lmask[lptr[i] + k + q] != 0) << q; w[k / 32] = (double)bits; }
+    }
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> dtab;
+    SSFM_HIP_CHECK(ctx, upload(dtab, tab, ctx->stream));
+    { const int rc = ctx_allreduce(ctx, dtab.p, n_tab, ncclSum); if (rc) { dtab.free(); return rc; } }
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(tab.data(), dtab.p, n_tab * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    dtab.free();
+    for (int p = 0; p < num_pairs; p++) {
+        const double* t = &tab[per * (size_t)p];
+        if (E_out) std::memcpy(E_out + 9 * (size_t)p, t, 9 * sizeof(double));
+        if (R_out) std::memcpy(R_out + 9 * (size_t)p, t + 9, 9 * sizeof(double));
+        if (scores) scores[p] = t[18];
+        if (num_inliers) num_inliers[p] = (int32_t)t[19];
+        if (inlier_mask) {
+            const double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+            const int n = pair_ptr[p + 1] - pair_ptr[p];
+            for (int k = 0; k < n; k++) inlier_mask[pair_ptr[p] + k] = (uint8_t)(((uint32_t)w[k / 32] >> (k % 32)) & 1u);
+        }
+    }
+    (void)total;
     return SSFM_OK;
 }
 

@@ -44,4 +44,27 @@ inline int fail(ssfm_ctx* ctx, int code, const std::string& msg) {
             return ssfm::fail(ctx, SSFM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
     } while (0)
 
+// Sum / max all-reduce of a device buffer of doubles over the ranks attached to the context (RCCL on the context's stream, or
+// the caller-supplied host collective staged through pinned memory).  No-op without a communicator.
+inline int ctx_allreduce(ssfm_ctx* ctx, double* buf, size_t n, ncclRedOp_t op) {
+    if (!ctx->collective) return SSFM_OK;
+    if (ctx->host_allreduce) {
+        if (ctx->host_stage_n < n) {
+            if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+            ctx->host_stage = nullptr; ctx->host_stage_n = 0;
+            SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_stage, n * sizeof(double), hipHostMallocDefault));
+            ctx->host_stage_n = n;
+        }
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_stage, buf, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->host_allreduce(ctx->host_allreduce_user, ctx->host_stage, (uint64_t)n, op == ncclMax ? SSFM_REDUCE_MAX : SSFM_REDUCE_SUM) != 0)
+            return fail(ctx, SSFM_ERR_COMM, "host all-reduce hook failed");
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(buf, ctx->host_stage, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        return SSFM_OK;
+    }
+    ncclResult_t r = ncclAllReduce(buf, buf, n, ncclDouble, op, ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return fail(ctx, SSFM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return SSFM_OK;
+}
+
 }  // namespace ssfm

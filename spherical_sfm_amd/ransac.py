@@ -20,8 +20,9 @@ def _unflat(a):
     return np.transpose(np.asarray(a).reshape(-1, 3, 3), (0, 2, 1)).copy()
 
 
-def estimate_pairs(ctx, pairs, squared_inlier_threshold, options=None, **kw):
-    """pairs: list of (u (n,3), v (n,3)).  -> dict(E (P,3,3), R (P,3,3), inliers [list of bool arrays], num_inliers, scores)"""
+def estimate_pairs(ctx, pairs, squared_inlier_threshold, options=None, sharded=False, **kw):
+    """pairs: list of (u (n,3), v (n,3)).  -> dict(E (P,3,3), R (P,3,3), inliers [list of bool arrays], num_inliers, scores).
+    sharded=True: ssfm_ransac_batch_sharded -- every rank of ctx's communicator passes the same list and gets every result."""
     ptr = np.zeros(len(pairs) + 1, np.int32)
     for i, (u, v) in enumerate(pairs):
         ptr[i + 1] = ptr[i] + len(u)
@@ -30,7 +31,8 @@ def estimate_pairs(ctx, pairs, squared_inlier_threshold, options=None, **kw):
     o = options or default_options(**kw)
     P = len(pairs)
     E = np.zeros(9 * P); R = np.zeros(9 * P); mask = np.zeros(int(ptr[-1]), np.uint8); nin = np.zeros(P, np.int32); sc = np.zeros(P)
-    _lib.check(_lib.lib().ssfm_ransac_batch(ctx._p, P, ptr.ctypes.data_as(c_i32_p), U.ctypes.data_as(c_double_p), V.ctypes.data_as(c_double_p),
+    fn = _lib.lib().ssfm_ransac_batch_sharded if sharded else _lib.lib().ssfm_ransac_batch
+    _lib.check(fn(ctx._p, P, ptr.ctypes.data_as(c_i32_p), U.ctypes.data_as(c_double_p), V.ctypes.data_as(c_double_p),
                                             squared_inlier_threshold, C.byref(o), E.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p),
                                             mask.ctypes.data_as(c_u8_p), nin.ctypes.data_as(c_i32_p), sc.ctypes.data_as(c_double_p)), ctx._p)
     return dict(E=_unflat(E), R=_unflat(R), inliers=[mask[ptr[i]:ptr[i + 1]].astype(bool) for i in range(P)], num_inliers=nin, scores=sc)

@@ -26,6 +26,16 @@ def main():
         ctx.comm_init_host(world, rank, hook)
     elif mode == "rccl1":
         ctx.comm_init(ba.Context.unique_id(), 1, 0)
+    if len(sys.argv) > 5 and sys.argv[5] == "ransac":
+        # ssfm_ransac_batch_sharded: every rank passes the same ragged pair list (one pair below the minimal sample size)
+        from spherical_sfm_amd import ransac
+        pairs = [synth.make_relative_pose_problem(n, seed=100 + i, noise=1 / 600, outlier_frac=0.3, rotation_deg=10)[:2]
+                 for i, n in enumerate([120, 75, 33, 2, 200, 64, 97])]
+        o = ransac.estimate_pairs(ctx, pairs, (2 / 600) ** 2, sharded=True, min_num_inliers=12, num_hypotheses=256)
+        np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=np.concatenate(o["inliers"]))
+        if mode == "host":
+            dist.barrier(); dist.destroy_process_group()
+        return
     cams, pts, focal, summ = ba.optimize(ctx, prob)
     np.savez(out + f".{rank}.npz", cams=cams, pts=pts, focal=focal, iterations=summ["iterations"], final_cost=summ["final_cost"],
              initial_cost=summ["initial_cost"], termination=summ["termination"])
