@@ -104,15 +104,26 @@ typedef struct {
     double t_kernel_linearize_ms, t_kernel_schur_ms, t_kernel_pcg_ms, t_kernel_update_ms; /* hipEvent sums */
     int32_t reduced_blocks;       /* non-zero DCxDC blocks of the reduced camera system */
     int32_t band_half_width;      /* block half-bandwidth of S in the Cuthill-McKee order */
+    int32_t band_segments;        /* workgroups of the reduced-system factorisation: connected components, long ones cut */
+    int32_t band_separators;      /* into segments by this many separators of band_half_width block rows (0 = none cut) */
 } ssfm_ba_summary;
 
 void ssfm_ba_default_options(ssfm_ba_options* o);
+
+/* Test probe for the reduced-system solver (the stand-in for Ceres' SPARSE_SCHUR Cholesky, src/sfm.cpp:276-279): factor + solve
+ * a caller-supplied symmetric positive definite block band.  band: [N][b+1][dc*dc], block d of row i = (i, i-d), rows in band
+ * order; comp_ptr: [ncomp+1] contiguous row ranges of independent components; Y: [2][N*dc] right-hand sides in, solutions out.
+ * segs_seps_fail: [3] = factorisation workgroups, separators (0 = no component was cut), non-positive-pivot flag.
+ * Zdump [b*dc][N*dc], Ddump [seps][b*dc][b*dc], Tdump [seps][2][b*dc]: intermediates of the substructured path, or NULL. */
+int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32_t b, int32_t ncomp, const int32_t* comp_ptr, const double* band,
+                          double* Y, int32_t* segs_seps_fail, double* Zdump, double* Ddump, double* Tdump);
 
 /* Host-only planning (no GPU needed): what the flatten rules of src/sfm.cpp:240-263 keep, how the used points
  * are sharded over ranks (contiguous ranges balanced by observations), and the camera elimination order. */
 typedef struct {
     int32_t camera_dof, num_points_used, num_points_used_global, reduced_blocks, band_half_width, max_row_blocks;
     int64_t num_observations_used, num_observations_used_global;
+    int32_t band_segments, band_separators;   /* as in ssfm_ba_summary (SSFM_BAND_SEGMENTS=1 disables cutting, =P forces P per component) */
 } ssfm_ba_plan_info;
 /* point_ids: [num_points] capacity or NULL (receives the original ids of this rank's used points, in order);
  * obs_used: [num_observations] or NULL (1 where the observation enters this rank's problem);

@@ -40,7 +40,8 @@ class BASummaryC(C.Structure):
                 ("num_residual_blocks_global", C.c_int64), ("num_points_used", C.c_int32), ("camera_dof", C.c_int32),
                 ("t_flatten_s", C.c_double), ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double),
                 ("t_kernel_linearize_ms", C.c_double), ("t_kernel_schur_ms", C.c_double), ("t_kernel_pcg_ms", C.c_double),
-                ("t_kernel_update_ms", C.c_double), ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32)]
+                ("t_kernel_update_ms", C.c_double), ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32),
+                ("band_segments", C.c_int32), ("band_separators", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -49,7 +50,8 @@ class BASummaryC(C.Structure):
 class BAPlanInfoC(C.Structure):
     _fields_ = [("camera_dof", C.c_int32), ("num_points_used", C.c_int32), ("num_points_used_global", C.c_int32),
                 ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32), ("max_row_blocks", C.c_int32),
-                ("num_observations_used", C.c_int64), ("num_observations_used_global", C.c_int64)]
+                ("num_observations_used", C.c_int64), ("num_observations_used_global", C.c_int64),
+                ("band_segments", C.c_int32), ("band_separators", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -68,7 +70,7 @@ DECLARED_SYMBOLS = [
     "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
-    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_retriangulate", "ssfm_focal_search",
+    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_band_solve_probe", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_retriangulate", "ssfm_focal_search",
 ]
 
 
@@ -118,6 +120,8 @@ def lib():
     L.ssfm_posegraph_focal_solve.argtypes = [vp, C.c_int32, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_double_p, c_double_p, C.c_double, C.c_double,
                                              C.POINTER(BAOptionsC), C.POINTER(BASummaryC)]
     L.ssfm_posegraph_focal_solve.restype = C.c_int
+    L.ssfm_band_solve_probe.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32_p, c_double_p, c_double_p, c_i32_p, c_double_p, c_double_p, c_double_p]
+    L.ssfm_band_solve_probe.restype = C.c_int
     L.ssfm_ransac_default_options.argtypes = [C.POINTER(RansacOptionsC)]; L.ssfm_ransac_default_options.restype = None
     L.ssfm_ransac_batch.argtypes = [vp, C.c_int32, c_i32_p, c_double_p, c_double_p, C.c_double, C.POINTER(RansacOptionsC), c_double_p, c_double_p,
                                     c_u8_p, c_i32_p, c_double_p]

@@ -105,6 +105,21 @@ def optimize(ctx, prob, options=None, **kw):
     return b.cams, b.pts, float(b.focal[0]), s.as_dict()
 
 
+def band_solve_probe(ctx, dc, comp_ptr, band, Y, dump=False):
+    """ssfm_band_solve_probe: band (N, b+1, dc, dc) lower block band, Y (2, N*dc) -> (X (2, N*dc), info dict[, Z, D, T])."""
+    band = np.ascontiguousarray(band, np.float64); N, W = band.shape[0], band.shape[1]; b = W - 1
+    Yc = np.ascontiguousarray(Y, np.float64).copy(); cp = np.ascontiguousarray(comp_ptr, np.int32)
+    info = np.zeros(3, np.int32); Q = b * dc
+    Z = np.zeros((Q, N * dc)) if dump else None
+    D = np.zeros((max(N // max(b, 1), 1), Q, Q)) if dump else None
+    T = np.zeros((max(N // max(b, 1), 1), 2, Q)) if dump else None
+    ptr = lambda a: a.ctypes.data_as(c_double_p) if a is not None else None
+    _lib.check(_lib.lib().ssfm_band_solve_probe(ctx._p, dc, N, b, len(cp) - 1, cp.ctypes.data_as(c_i32_p), ptr(band), ptr(Yc),
+                                                info.ctypes.data_as(c_i32_p), ptr(Z), ptr(D), ptr(T)), ctx._p)
+    d = dict(segments=int(info[0]), separators=int(info[1]), failed=int(info[2]))
+    return (Yc, d, Z, D, T) if dump else (Yc, d)
+
+
 def retriangulate(ctx, prob):
     """SfM::Retriangulate (reference src/sfm.cpp:156-192) on the GPU -> (points (Np,3), num_inliers (Np,))."""
     b = _ProblemBuffers(prob)

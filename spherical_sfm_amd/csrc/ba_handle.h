@@ -11,6 +11,7 @@
 #include "ba_flatten.h"
 #include "ba_kernels.h"
 #include "band_kernels2.h"
+#include "band_sub.h"
 #include "ssfm_ctx.h"
 
 namespace ssfm {
@@ -19,12 +20,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
-                                              "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2"};
+                                              "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left"};
 
 template <typename T>
 struct DevBuf {
@@ -49,6 +51,9 @@ struct ssfm_ba_handle {
     DevBuf<double> zone; bool zone_views = false;      // BA: scal, pcg and redbuf are views into zone (zeroed by one memset per iteration)
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
+    // substructured factorisation of long components (band_sub.h); disabled => segments == components
+    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr;
+    DevBuf<double> subZ, subD, subT, subF, subL, subW;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
@@ -80,6 +85,8 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
+        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free();
+        subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
@@ -124,6 +131,70 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     return rc;
 }
 
+// Factor the band in h->band (block-band Cholesky in Cuthill-McKee order) and solve for the two right-hand-side columns of Y
+// (band order), in place.  Long components go through the substructured path (band_sub.h) when the plan holds one.
+template <int DC>
+static int band_direct(ssfm_ba_handle* h, double* Y) {
+    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
+    const BAFlat& F = h->F;
+    const int Nc = F.Nc, b = F.band;
+    constexpr int BB = DC * DC;
+    const int ncomp = (int)F.comp_ptr.size() - 1;
+    // LDS-resident factorisation (band_kernels2.h): window ring + panel + right-hand-side rows + scratch + pair table
+    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
+    const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
+    const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
+    // wave roles of k_band_chol_v2: 1 look-ahead + trailing-update waves (one block task per lane) + loaders + 1 writer
+    const int tr_tasks = (b * (b + 1) / 2) * ((DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC) + b * DC;
+    const int chol_threads = 64 * (2 + CHOL2_LOADERS + std::min(std::max((tr_tasks + 63) / 64, 1), 7));
+    const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
+    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
+        if (h->sub.enabled && use_lds && back_v2) {
+            // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
+            const BandSub& B = h->sub;
+            const int Q = b * DC;
+            const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2 + 1) * Q) * sizeof(double);
+            if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+            if (lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+            int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b, failp);
+            h->span_begin(KID_SUB_SPIKE);
+            hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, Q), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+            h->span_end();
+            const int ntl = (Q + SUB_TS - 1) / SUB_TS;
+            h->span_begin(KID_SUB_ASM);
+            hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2 + 1), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
+            h->span_end();
+            LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
+            int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
+            h->span_begin(KID_SUB_APPLY);
+            hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + 255) / 256), dim3(256), (size_t)2 * Q * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
+            h->span_end();
+            h->span_begin(KID_BAND_BACK);
+            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.nseg, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b);
+            h->span_end();
+            return SSFM_OK;
+        }
+        // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
+        if (use_lds) {
+            if (lds_win > 48 * 1024) {
+                SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+            }
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            if (back_v2) {
+                h->span_begin(KID_BAND_BACK);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b);
+                h->span_end();
+            } else {
+                LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
+            }
+        } else {
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, Y, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
+        }
+        return SSFM_OK;
+    }
+
 // Solve S y = rhs (block-CSR S with dense focal border) into h->px.
 //   preconditioner 0: exact block-banded Cholesky in Cuthill-McKee order, then PCG refinement on the residual
 //   preconditioner 1: block-Jacobi PCG (kept for comparison; needs ~10^3 iterations on a camera ring)
@@ -163,13 +234,8 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
     const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
     const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
-    // wave roles of k_band_chol_v2: 1 look-ahead + trailing-update waves (one block task per lane) + loaders + 1 writer
-    const int tr_tasks = (b * (b + 1) / 2) * ((DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC) + b * DC;
-    const int chol_threads = 64 * (2 + CHOL2_LOADERS + std::min(std::max((tr_tasks + 63) / 64, 1), 7));
-    // ---- banded Cholesky: gather, factor + forward-substitute [rhs | S_fc], back-substitute, arrow combine
-    const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
-    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
     const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
+    const bool sub_on = h->sub.enabled && use_lds && back_v2;
     if (stage == 0) {
     if (!h->zone_views) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
     if (!h->band_filled) {                                       // the BA path fills the band in its fused finalize kernel
@@ -177,23 +243,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
     }
     h->band_filled = false;
-    // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
-    if (use_lds) {
-        if (lds_win > 48 * 1024) {
-            SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        }
-        LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, h->comp_ptr.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-        if (back_v2) {
-            h->span_begin(KID_BAND_BACK);
-            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
-            h->span_end();
-        } else {
-            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, h->comp_ptr.p, Nc, b);
-        }
-    } else {
-        LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, h->Yb.p, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, h->Yb.p, Nc, b);
-    }
+    { const int rc = band_direct<DC>(h, h->Yb.p); if (rc) return rc; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
     if (F.sym_lower) {
         LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
@@ -211,11 +261,15 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
       if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
     while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
-        if (use_lds) {
+        if (sub_on) {
+            // the substructured factor has no stand-alone substitution kernels: rebuild the band from S and solve again (rare path)
+            LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
+            const int rc = band_direct<DC>(h, h->Yr.p); if (rc) return rc;
+        } else if (use_lds) {
             LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b);
                 h->span_end();
             } else {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);

@@ -234,6 +234,63 @@ extern "C" void ssfm_ba_default_options(ssfm_ba_options* o) {
     o->verbose = 0;
 }
 
+// segment / separator tables of the substructured factorisation (band_sub.h) and its work buffers
+static int sub_upload(ssfm_ba_handle* h, int DC) {
+    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; const BAFlat& F = h->F;
+    sub_build(F.comp_ptr, F.band, DC, h->sub);
+    if (!h->sub.enabled) return SSFM_OK;
+    const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)F.Nc * DC;
+    SSFM_HIP_CHECK(ctx, upload(h->sub_seg_lo, B.seg_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_hi, B.seg_hi, st));
+    SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
+    SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));
+    SSFM_HIP_CHECK(ctx, upload(h->sub_chain_ptr, B.chain_ptr, st));
+    SSFM_HIP_CHECK(ctx, h->subZ.alloc(Q * n)); SSFM_HIP_CHECK(ctx, h->subD.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subT.alloc((size_t)B.nsep * 2 * Q));
+    SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
+    return SSFM_OK;
+}
+
+// Test probe: the reduced-system factor + solve on a caller-supplied block band (band order, lower storage [N][b+1][dc*dc], block d
+// of row i = (i, i-d)) and two right-hand-side columns Y [2][N*dc] (in/out).  Optional dumps of the substructured intermediates.
+extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32_t b, int32_t ncomp, const int32_t* comp_ptr, const double* band,
+                                     double* Y, int32_t* segs_seps_fail, double* Zdump, double* Ddump, double* Tdump) {
+    if (!ctx || (dc != 3 && dc != 6) || N <= 0 || b < 1 || ncomp < 1 || !comp_ptr || !band || !Y) return fail(ctx, SSFM_ERR_INVALID, "ssfm_band_solve_probe: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ssfm_ba_handle hh; ssfm_ba_handle* h = &hh;
+    h->ctx = ctx; ssfm_ba_default_options(&h->opt);
+    std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
+    BAFlat& F = h->F; F.Nc = N; F.band = b; F.DC = dc; F.comp_ptr.assign(comp_ptr, comp_ptr + ncomp + 1);
+    for (int ir = 1; ir <= b; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
+    const size_t nb = (size_t)N * (b + 1) * dc * dc, n = (size_t)N * dc;
+    int rc = SSFM_OK;
+    auto run = [&]() -> int {
+        SSFM_HIP_CHECK(ctx, h->band.alloc(nb)); SSFM_HIP_CHECK(ctx, h->Linv.alloc((size_t)N * dc * dc)); SSFM_HIP_CHECK(ctx, h->Yb.alloc(2 * n));
+        SSFM_HIP_CHECK(ctx, h->pcg.alloc(PCG_TOTAL + 1));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->Linv.p, 0, (size_t)N * dc * dc * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->band.p, band, nb * sizeof(double), hipMemcpyHostToDevice, st));
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->Yb.p, Y, 2 * n * sizeof(double), hipMemcpyHostToDevice, st));
+        SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st)); SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
+        { const int r = sub_upload(h, dc); if (r) return r; }
+        if (h->sub.enabled) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subZ.p, 0, h->subZ.n * sizeof(double), st));
+        { const int r = (dc == 3) ? band_direct<3>(h, h->Yb.p) : band_direct<6>(h, h->Yb.p); if (r) return r; }
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Y, h->Yb.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+        int flag = 0;
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&flag, h->pcg.p + PCG_TOTAL, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (h->sub.enabled) {
+            if (Zdump) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Zdump, h->subZ.p, h->subZ.n * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (Ddump) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Ddump, h->subD.p, h->subD.n * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (Tdump) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Tdump, h->subT.p, h->subT.n * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (segs_seps_fail) { segs_seps_fail[0] = h->sub.enabled ? h->sub.nseg : ncomp; segs_seps_fail[1] = h->sub.nsep; segs_seps_fail[2] = flag; }
+        return SSFM_OK;
+    };
+    rc = run();
+    h->free_all();
+    return rc;
+}
+
 extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
                             uint8_t* obs_used, int32_t* cam_pos) {
     if (!p || !info || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ba_plan: bad arguments");
@@ -244,6 +301,8 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     info->camera_dof = F.DC; info->num_points_used = F.nP; info->num_points_used_global = F.nP_global;
     info->reduced_blocks = F.row_ptr[F.Nc]; info->band_half_width = F.band; info->max_row_blocks = F.max_row_blocks;
     info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
+    { BandSub B; sub_build(F.comp_ptr, F.band, F.DC, B);
+      info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep; }
     if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];
     if (obs_used) for (int64_t j = 0; j < F.M; j++) obs_used[F.obs_orig[j]] = 1;
     if (cam_pos) for (int c = 0; c < F.Nc; c++) cam_pos[c] = F.cam_pos[c];
@@ -294,6 +353,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
 #undef AL
     SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
+    { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
     SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st));
     SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
@@ -322,12 +382,14 @@ extern "C" int ssfm_ba_run(ssfm_ba_handle* h, ssfm_ba_summary* s) {
     const int32_t nblk = F.nothing_to_do ? 0 : F.row_ptr[F.Nc];
     s->num_residual_blocks = F.M; s->num_residual_blocks_global = F.M_global; s->num_points_used = F.nP; s->camera_dof = F.DC;
     s->reduced_blocks = F.nothing_to_do ? 0 : F.row_ptr[F.Nc]; s->band_half_width = F.band;
+    const int32_t nsegs = h->sub.enabled ? h->sub.nseg : (int32_t)F.comp_ptr.size() - 1, nseps = h->sub.nsep;
+    s->band_segments = F.nothing_to_do ? 0 : nsegs; s->band_separators = nseps;
     if (F.nothing_to_do) { s->termination = SSFM_NOTHING_TO_DO; return SSFM_OK; }
     SSFM_HIP_CHECK(h->ctx, hipSetDevice(h->ctx->device));
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     const double t0 = wall_s();
     int rc = (F.DC == 3) ? lm_loop<3>(h, s) : lm_loop<6>(h, s);
-    s->t_solve_s = wall_s() - t0; s->reduced_blocks = nblk; s->band_half_width = F.band;
+    s->t_solve_s = wall_s() - t0; s->reduced_blocks = nblk; s->band_half_width = F.band; s->band_segments = nsegs; s->band_separators = nseps;
     return rc;
 }
 

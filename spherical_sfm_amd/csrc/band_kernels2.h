@@ -68,7 +68,8 @@ constexpr int CHOL2_LOADERS = 2;
 template <int DC, int NR>
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
-               const int* __restrict__ comp_ptr, int N, int b, int* __restrict__ fail_flag) {
+               const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi, int N, int b,
+               int* __restrict__ fail_flag) {
     constexpr int BB = DC * DC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int R = b + 1, W = b + 1, RW = W * BB;
@@ -82,10 +83,13 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     const int n = N * DC, tid = threadIdx.x, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int ntw = nw - 2 - CHOL2_LOADERS;                 // trailing-update waves
-    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    // pivots [r0, r1); the window (panels, trailing update, right-hand sides) runs on to row re >= r1.  re == r1 for a whole
+    // component; a SEGMENT of a substructured component (band_sub.h) has re = r1 + b: the rows of the separator behind it
+    // receive their factor blocks L(r, k) and their Schur update, and are written back by the epilogue instead of being pivots.
+    const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
     if (r0 >= r1) return;
     for (int e = tid; e < b * (b + 1) / 2; e += nt) sPairs[e] = pairs[e];
-    for (int row = r0; row < min(r0 + R, r1); row++) {
+    for (int row = r0; row < min(r0 + R, re); row++) {
         for (int e = tid; e < RW; e += nt) sWin[(size_t)(row % R) * RW + e] = band[(size_t)row * RW + e];
         for (int e = tid; e < NR * DC; e += nt) sYr[(size_t)(row % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
     }
@@ -133,10 +137,10 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         // ---- look-ahead: next diagonal block, its factor and inverse.  No global memory traffic.
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
-            const int nb = min(b, r1 - 1 - j);
+            const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
             lds_barrier();
-            if (nb >= 1) {
+            if (j + 1 < r1) {
                 int s1 = jm + 1; if (s1 >= R) s1 -= R;
                 const double* dblk = sWin + (size_t)s1 * RW;                        // block (j+1, j+1)
                 if (lane < BB) {
@@ -155,6 +159,17 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 #pragma unroll
                     for (int r = 0; r < DC; r++) sG[r * DC + lane] = g[r];
                 }
+            } else if (nb >= 1) {
+                // last pivot of a segment: row j+1 is the first separator row, its diagonal block takes the update in place
+                int s1 = jm + 1; if (s1 >= R) s1 -= R;
+                double* dblk = sWin + (size_t)s1 * RW;
+                if (lane < BB) {
+                    const int a = lane / DC, c = lane - a * DC;
+                    double v = dblk[lane];
+#pragma unroll
+                    for (int m = 0; m < DC; m++) v -= sP[a * DC + m] * sP[c * DC + m];
+                    dblk[lane] = v;
+                }
             }
             lds_barrier();
         }
@@ -165,7 +180,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         const int cw = ntw * 64, ct = tid - 64;
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
-            const int nb = min(b, r1 - 1 - j);
+            const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
             lds_barrier();
             const int work = (nb * (nb + 1) / 2) * TPB;
@@ -211,7 +226,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         double preA[PRE], preB[PRE];                        // two rows in flight: the factor comes from another XCD's L2 / MALL, more than a step away
 #define CHOL2_ISSUE(pre_, jn_)                                                                                        \
         do {                                                                                                          \
-            const int jc_ = min((jn_), r1 - 1);                                                                       \
+            const int jc_ = min((jn_), re - 1);                                                                       \
             _Pragma("unroll") for (int u = 0; u < PRE; u++) {                                                         \
                 const int e = le0 + u * 64 * CHOL2_LOADERS;                                                           \
                 const int q = max(min(e - RW, NR * DC - 1), 0);                                                       \
@@ -221,7 +236,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         } while (0)
 #define CHOL2_STEP(pre_, j_)                                                                                          \
         do {                                                                                                          \
-            const int nb = min(b, r1 - 1 - (j_)), jn = (j_) + R;                                                      \
+            const int nb = min(b, re - 1 - (j_)), jn = (j_) + R;                                                      \
             phaseB((j_), jm, nb);                                                                                     \
             lds_barrier();                                                                                            \
             /* row j's slot is dead (its blocks left as panels of earlier steps): it takes row j + R */               \
@@ -231,7 +246,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                 const int e = le0 + u * 64 * CHOL2_LOADERS;                                                           \
                 if (e < RW) rowj[e] = pre_[u]; else if (e < RW + NR * DC) yrow[e - RW] = pre_[u];                     \
             }                                                                                                         \
-            if (jn < r1) for (int e = le0 + PRE * 64 * CHOL2_LOADERS; e < RW + NR * DC; e += 64 * CHOL2_LOADERS) {    \
+            if (jn < re) for (int e = le0 + PRE * 64 * CHOL2_LOADERS; e < RW + NR * DC; e += 64 * CHOL2_LOADERS) {    \
                 if (e < RW) rowj[e] = band[(size_t)jn * RW + e];                                                      \
                 else { const int q = e - RW; yrow[q] = Y[(size_t)(q / DC) * n + (size_t)jn * DC + (q % DC)]; }        \
             }                                                                                                         \
@@ -252,13 +267,23 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         // ---- writer: panel, y_j and G to global memory (stores only, never waited on)
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
-            const int nb = min(b, r1 - 1 - j);
+            const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
             if (lane < BB) Ginv[(size_t)j * BB + lane] = sG[lane];                   // before wave 0 replaces it
             lds_barrier();
             for (int e = lane; e < nb * BB; e += 64) { const int k = e / BB; band[((size_t)(j + 1 + k) * W + (k + 1)) * BB + (e - k * BB)] = sP[e]; }
             if (lane < NR * DC) Y[(size_t)(lane / DC) * n + (size_t)j * DC + (lane % DC)] = sYj[lane];
             lds_barrier();
+        }
+    }
+    // ---- epilogue of a segment: the window now holds rows [r1, re) = the separator behind it, reduced by this segment
+    if (re > r1) {
+        __syncthreads();
+        for (int row = r1; row < re; row++) {
+            const int nin = (row - r1 + 1) * BB;                                   // blocks (row, r1..row): d = 0..row-r1
+            const double* src = sWin + (size_t)(row % R) * RW;
+            for (int e = tid; e < nin; e += nt) band[(size_t)row * RW + e] = src[e];
+            for (int e = tid; e < NR * DC; e += nt) Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)] = sYr[(size_t)(row % R) * NR * DC + e];
         }
     }
 }
@@ -269,11 +294,12 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 constexpr int BACK_PD = 4;
 template <int DC>
 __global__ void __launch_bounds__(64)
-k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ comp_ptr,
-               int N, int b) {
+k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
+               const int* __restrict__ piv_hi, const int* __restrict__ win_hi, int N, int b) {
     constexpr int BB = DC * DC;
     const int W = b + 1, n = N * DC, lane = threadIdx.x;
-    const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
+    // rows [r1, re) (the separator behind a segment, band_sub.h) already hold their solution: they only feed the pending sums
+    const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
     if (r0 >= r1) return;
     double* y = Y + (size_t)blockIdx.y * n;
     const int T = b * DC;
@@ -294,9 +320,9 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
         s.yv = y[(size_t)jc * DC + lc];
     };
 #pragma unroll
-    for (int u = 0; u < BACK_PD; u++) fetch(r1 - 1 - u, st[u]);
+    for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
     double acc0 = 0.0, acc1 = 0.0;         // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
-    for (int jb = r1 - 1; jb >= r0; jb -= BACK_PD) {
+    for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
 #pragma unroll
         for (int u = 0; u < BACK_PD; u++) {
             const int j = jb - u;
@@ -317,7 +343,8 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             double x = 0.0;
 #pragma unroll
             for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
-            if (lane < DC) y[(size_t)j * DC + lane] = x;
+            if (j >= r1) x = cy;                                               // given
+            else if (lane < DC) y[(size_t)j * DC + lane] = x;
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; s1 += c1[m] * xm; }

@@ -1,0 +1,51 @@
+"""The reduced-system solver alone (ssfm_band_solve_probe): random symmetric positive definite block bands against numpy's dense
+solve, single-workgroup factorisation and the substructured one (csrc/band_sub.h), both camera block sizes, several components."""
+import numpy as np
+import pytest
+
+import _band_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dc,b,rows,P", [(6, 12, [75, 75, 80], 1), (3, 12, [60, 90], 1), (6, 4, [40, 47], 2), (3, 5, [60, 67], 3),
+                                         (6, 19, [300, 307], 4), (6, 12, [75, 75, 75, 75], 3), (3, 19, [400], 8), (6, 7, [200, 30, 9], 5)])
+def test_band_solver_matches_dense_solve(gpu_ctx, monkeypatch, dc, b, rows, P):
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P))
+    band, A, cp, rhs = R.random_band_system(rows, b, dc, seed=dc * 100 + b)
+    X, info = ba.band_solve_probe(gpu_ctx, dc, cp, band, rhs)
+    segs, seps = R.segment_table(cp, b, P)
+    assert info["failed"] == 0 and info["separators"] == len(seps) and info["segments"] == len(segs)
+    xr = np.linalg.solve(A, rhs.T).T
+    assert np.abs(X - xr).max() <= 1e-12 * np.abs(xr).max()
+
+
+def test_substructured_intermediates(gpu_ctx, monkeypatch):
+    """Spikes Z, separator blocks D and right-hand sides t against the numpy statement of the same elimination."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "3")
+    dc, b = 6, 5
+    band, A, cp, rhs = R.random_band_system([70, 64], b, dc, seed=9)
+    X, info, Z, D, T = ba.band_solve_probe(gpu_ctx, dc, cp, band, rhs, dump=True)
+    segs, seps = R.segment_table(cp, b, 3)
+    Zr, Dr, Tr = R.substructure_intermediates(A, rhs, segs, seps, b, dc)
+    for (r0, r1, re, has_left) in segs:
+        if has_left:
+            assert np.abs(Z[:, r0*dc:re*dc] - Zr[:, r0*dc:re*dc]).max() <= 1e-13
+    for s in range(len(seps)):
+        assert np.abs(np.tril(D[s]) - Dr[s]).max() <= 1e-12 * np.abs(Dr).max() and np.abs(T[s] - Tr[s]).max() <= 1e-13
+
+
+def test_indefinite_band_raises_the_flag(gpu_ctx, monkeypatch):
+    from spherical_sfm_amd import ba
+    for P in (1, 2):
+        monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P))
+        band, A, cp, rhs = R.random_band_system([60], 4, 6, seed=2)
+        band[30, 0] -= np.eye(6) * 1e3                     # a pivot inside a segment
+        assert ba.band_solve_probe(gpu_ctx, 6, cp, band, rhs)[1]["failed"] == 1
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "2")
+    band, A, cp, rhs = R.random_band_system([60], 4, 6, seed=2)
+    segs, seps = R.segment_table(cp, 4, 2)
+    band[seps[0][0] + 1, 0] -= np.eye(6) * 1e3             # a pivot inside the separator chain
+    assert ba.band_solve_probe(gpu_ctx, 6, cp, band, rhs)[1]["failed"] == 1
