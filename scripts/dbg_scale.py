@@ -13,7 +13,7 @@ s = adj.run(); adj.reset(); adj.set_profiling(True)
 t = time.time(); s = adj.run(); dt = time.time() - t
 cams, pts, f = adj.download()
 M = s['num_residual_blocks']
-print({k: (round(s[k], 4) if isinstance(s[k], float) else s[k]) for k in ('termination', 'iterations', 'num_linearizations', 'pcg_iterations_total', 'final_cost', 't_solve_s', 'reduced_blocks', 'band_half_width', 't_kernel_linearize_ms', 't_kernel_schur_ms', 't_kernel_pcg_ms', 't_kernel_update_ms')})
+print({k: (round(s[k], 4) if isinstance(s[k], float) else s[k]) for k in ('termination', 'iterations', 'num_linearizations', 'pcg_iterations_total', 'final_cost', 't_solve_s', 'reduced_blocks', 'band_half_width', 'band_segments', 'band_separators', 't_kernel_linearize_ms', 't_kernel_schur_ms', 't_kernel_pcg_ms', 't_kernel_update_ms')})
 print("obs/s = %.3e ; B_alg = %.1f MB/iter ; achieved %.1f GB/s" % (M * s['num_linearizations'] / dt, (72 * M + 240 * Np) / 1e6, (72 * M + 240 * Np) * s['num_linearizations'] / dt / 1e9))
 for k, v in adj.kernel_times().items(): print("    %-18s launches %6d avg %9.2f us" % (k, v['launches'], 1e3 * v['total_ms'] / v['launches']))
 if int(os.environ.get("CHECK", 1)):

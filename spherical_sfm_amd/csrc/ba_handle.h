@@ -153,20 +153,23 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
             const BandSub& B = h->sub;
             const int Q = b * DC;
-            const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2 + 1) * Q) * sizeof(double);
+            const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
             if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
             if (lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
             LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b, failp);
             h->span_begin(KID_SUB_SPIKE);
-            hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, Q), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+            hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, (Q + SPIKE_NC - 1) / SPIKE_NC), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
             h->span_end();
             const int ntl = (Q + SUB_TS - 1) / SUB_TS;
+            int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
+            const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subD.p, 0, h->subD.n * sizeof(double), st));
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subT.p, 0, h->subT.n * sizeof(double), st));
             h->span_begin(KID_SUB_ASM);
-            hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2 + 1), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
+            hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
             h->span_end();
             LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
-            int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             h->span_begin(KID_SUB_APPLY);
             hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + 255) / 256), dim3(256), (size_t)2 * Q * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
             h->span_end();

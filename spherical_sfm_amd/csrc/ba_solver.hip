@@ -535,7 +535,7 @@ int upload_state(ssfm_ba_handle* h, const ssfm_ba_problem* p) {
 
 extern "C" int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s) {
     if (!ctx || !p || !s) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_solve: null argument");
-    static const bool no_cache = std::getenv("SSFM_NO_PLAN_CACHE") != nullptr;
+    const bool no_cache = std::getenv("SSFM_NO_PLAN_CACHE") != nullptr;       // read per call: tests switch it
     const double t0 = wall_s();
     PlanCache key; key.Nc = p->num_cameras; key.Np = p->num_points; key.M = p->num_observations; key.nranks = ctx->nranks; key.rank = ctx->rank;
     key.focal_fixed = p->focal_fixed ? 1 : 0;

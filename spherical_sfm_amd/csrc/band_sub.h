@@ -16,6 +16,7 @@
 // scripts/lab/substructure_proto.py is the numpy statement of the same algebra.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 #include "band_kernels2.h"
@@ -32,17 +33,20 @@ struct BandSub {
     std::vector<int> chain_ptr;                     // separators of chain c: [chain_ptr[c], chain_ptr[c+1])  (one chain per cut component)
 };
 
-// Rough cost model in microseconds (MI355X measurements of the kernels involved): a factorisation step, a separator step of the
-// chain, and the fixed cost of the extra launches.  Segments must be at least b + 1 rows.
-constexpr int SUB_MIN_ROWS = 256;                  // shorter components stay on one workgroup (measured break-even, profiles/r01_notes.md)
+// Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
+// (0.13 b - 0.17), the spike (1.1) and the back substitution (0.43); per separator 150 (b dc / 114)^2.5 for the chain; 170 fixed for the
+// extra launches, the assembly and the memsets.  Segments must be at least b + 1 rows.  Components shorter than SUB_MIN_ROWS stay on
+// one workgroup (config 2's rings of 75: 135 us uncut against ~180 us cut in two).
+constexpr int SUB_MIN_ROWS = 256;
 inline int sub_choose_segments(int rows, int b, int dc) {
     if (rows < SUB_MIN_ROWS) return 1;
-    const double t_step = 0.55 + 0.085 * b, t_sep = 40.0 * (b * dc / 114.0) * (b * dc / 114.0) + 6.0, t_fixed = 30.0;
-    int best = 1; double best_t = rows * t_step * 1.3;                      // factorisation + back substitution of the plain path
+    const double t_chol = std::max(0.13 * b - 0.17, 0.4), t_spike = 1.1, t_back = 0.43;
+    const double t_sep = 150.0 * std::pow(b * dc / 114.0, 2.5), t_fixed = 170.0;
+    int best = 1; double best_t = rows * (t_chol + t_back);
     for (int P = 2; P <= 64; P++) {
         const int m = (rows - (P - 1) * b) / P;
         if (m < b + 1) break;
-        const double t = (m + b) * t_step * 1.5 + (P - 1) * t_sep + t_fixed;
+        const double t = (m + b) * (t_chol + t_spike + t_back) + (P - 1) * t_sep + t_fixed;
         if (t < best_t) { best_t = t; best = P; }
     }
     return best;
@@ -73,77 +77,86 @@ inline void sub_build(const std::vector<int>& comp_ptr, int b, int dc, BandSub& 
     if (!S.enabled) S = BandSub();
 }
 
-// ---- 2. spike: Z(:, q) = L_seg^-1 C_left(:, q), one wave per (segment, column) ---------------------------------------------
+// ---- 2. spike: Z(:, q) = L_seg^-1 C_left(:, q), one wave per (segment, SPIKE_NC columns) -----------------------------------
 // Column q = (separator row r0 - b + q / DC, component q % DC).  C_left lives in the band rows of the segment's first b rows
 // (blocks whose column lies in front of r0).  Right-looking: task t = (d-1)*DC + a (d = 1..b) owns the pending sum of row
 // k + (d-1), component a; lanes carry tasks t = lane and t = lane + 64.  Rows [r1, re) take no pivot: they receive -sum = E.
-// Z: [b*DC][N*DC], row index = global scalar row.
-constexpr int SPIKE_PD = 4;
+// Z: [b*DC][N*DC], row index = global scalar row.  A step is latency bound and every column streams the same factor rows, so a
+// wave carries SPIKE_NC columns through one stream of L (one column per wave made the kernel L2-bandwidth bound: 12 TB/s).
+constexpr int SPIKE_PD = 4, SPIKE_NC = 4;
 template <int DC>
 __global__ void __launch_bounds__(64)
 k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Z, const int* __restrict__ seg_lo,
                 const int* __restrict__ seg_hi, const int* __restrict__ seg_wend, const int* __restrict__ left_segs, int N, int b) {
-    constexpr int BB = DC * DC;
-    const int W = b + 1, n = N * DC, lane = threadIdx.x;
-    const int seg = left_segs[blockIdx.x], q = blockIdx.y;
+    constexpr int BB = DC * DC, NC = SPIKE_NC;
+    const int W = b + 1, n = N * DC, lane = threadIdx.x, Q = b * DC;
+    const int seg = left_segs[blockIdx.x], q0 = blockIdx.y * NC;
     const int r0 = seg_lo[seg], r1 = seg_hi[seg], re = seg_wend[seg];
-    const int cs = q / DC, cc = q - cs * DC;
-    double* z = Z + (size_t)q * n;
+    int cs[NC], cc[NC]; bool qv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { const int q = min(q0 + c, Q - 1); qv[c] = q0 + c < Q; cs[c] = q / DC; cc[c] = q - cs[c] * DC; }
     const int T = b * DC;
     const int t0 = min(lane, T - 1), t1 = min(lane + 64, T - 1);
     const int d0 = t0 / DC + 1, a0 = t0 - (d0 - 1) * DC, d1 = t1 / DC + 1, a1 = t1 - (d1 - 1) * DC;
     const bool has0 = lane < T, has1 = lane + 64 < T;
     const int lc = min(lane, DC - 1);
-    struct Stage { double row0[DC], row1[DC], g[DC], cv; };
+    struct Stage { double row0[DC], row1[DC], g[DC], cv[NC]; };
     Stage st[SPIKE_PD];
     auto fetch = [&](int k, Stage& s) {    // row a of L(k+d, k) for this lane's tasks; row `lane` of G_k; C_left(k, q)[lane]
         const int kc = min(k, re - 1);
         const int k0 = min(kc + d0, re - 1), k1 = min(kc + d1, re - 1);
-        const int dl = min(kc - r0 + b - cs, b);
 #pragma unroll
         for (int m = 0; m < DC; m++) {
             s.row0[m] = band[((size_t)k0 * W + d0) * BB + a0 * DC + m];
             s.row1[m] = band[((size_t)k1 * W + d1) * BB + a1 * DC + m];
             s.g[m] = Ginv[(size_t)kc * BB + lc * DC + m];                 // G[lane][m], zero for m > lane
         }
-        s.cv = band[((size_t)kc * W + dl) * BB + lc * DC + cc];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { const int dl = min(kc - r0 + b - cs[c], b); s.cv[c] = band[((size_t)kc * W + dl) * BB + lc * DC + cc[c]]; }
     };
 #pragma unroll
     for (int u = 0; u < SPIKE_PD; u++) fetch(r0 + u, st[u]);
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0[NC], acc1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { acc0[c] = 0.0; acc1[c] = 0.0; }
     for (int kb = r0; kb < re; kb += SPIKE_PD) {
 #pragma unroll
         for (int u = 0; u < SPIKE_PD; u++) {
             const int k = kb + u;
             if (k >= re) break;
-            double c0[DC], c1[DC], cg[DC];
+            double c0[DC], c1[DC], cg[DC], cvv[NC];
             const bool v0 = has0 && k + d0 < re, v1 = has1 && k + d1 < re;
-            const double cv = (k - r0 + b - cs <= b) ? st[u].cv : 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) cvv[c] = (k - r0 <= cs[c]) ? st[u].cv[c] : 0.0;
 #pragma unroll
             for (int m = 0; m < DC; m++) { c0[m] = v0 ? st[u].row0[m] : 0.0; c1[m] = v1 ? st[u].row1[m] : 0.0; cg[m] = st[u].g[m]; }
             fetch(k + SPIKE_PD, st[u]);
-            const double w = cv - acc0;                                 // lanes 0..DC-1: C_left(k, q) - pending sum of row k
-            const double sh0 = lane_shift_down(acc0, DC), sh1 = lane_shift_down(acc1, DC);
-            double sft0 = (lane + DC < 64) ? sh0 : sh1;
-            if (!(lane + DC < T)) sft0 = 0.0;
-            double sft1 = (lane + DC < 64) ? sh1 : 0.0;
-            if (!(lane + 64 + DC < T)) sft1 = 0.0;
-            double zz = 0.0;
-#pragma unroll
-            for (int m = 0; m < DC; m++) zz += cg[m] * lane_bcast(w, m);       // z_k[lane] = sum_m G[lane][m] w[m]
             const bool pivot = k < r1;
-            if (lane < DC) z[(size_t)k * DC + lane] = pivot ? zz : w;
-            if (!pivot) zz = 0.0;
-            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int m = 0; m < DC; m++) { const double zm = lane_bcast(zz, m); s0 += c0[m] * zm; s1 += c1[m] * zm; }
-            acc0 = sft0 + s0; acc1 = sft1 + s1;
+            for (int c = 0; c < NC; c++) {
+                const double w = cvv[c] - acc0[c];                      // lanes 0..DC-1: C_left(k, q) - pending sum of row k
+                const double sh0 = lane_shift_down(acc0[c], DC), sh1 = lane_shift_down(acc1[c], DC);
+                double sft0 = (lane + DC < 64) ? sh0 : sh1;
+                if (!(lane + DC < T)) sft0 = 0.0;
+                double sft1 = (lane + DC < 64) ? sh1 : 0.0;
+                if (!(lane + 64 + DC < T)) sft1 = 0.0;
+                double zz = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) zz += cg[m] * lane_bcast(w, m);   // z_k[lane] = sum_m G[lane][m] w[m]
+                if (lane < DC && qv[c]) Z[(size_t)(q0 + c) * n + (size_t)k * DC + lane] = pivot ? zz : w;
+                if (!pivot) zz = 0.0;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) { const double zm = lane_bcast(zz, m); s0 += c0[m] * zm; s1 += c1[m] * zm; }
+                acc0[c] = sft0 + s0; acc1[c] = sft1 + s1;
+            }
         }
     }
 }
 
 // ---- 3. separator blocks: D = inner - Z^T Z (lower triangle, dense [Q][Q]), t = y_sep - Z^T y_seg ----------------------------
-// grid (separators, lower 32x32 tiles + 1); the extra workgroup does the right-hand sides.
+// grid (separators, lower 32x32 tiles, K chunks).  Dd and tt are zeroed beforehand; every chunk adds its part, chunk 0 also the
+// inner blocks / y_sep.  The tiles of the first tile column carry the right-hand sides along (NR more columns of the product).
 constexpr int SUB_TS = 32, SUB_KC = 64;
 template <int DC, int NR>
 __global__ void __launch_bounds__(256)
@@ -151,26 +164,23 @@ k_sub_sep_assemble(const double* __restrict__ band, const double* __restrict__ Z
                    const int* __restrict__ sep_rseg, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int N, int b,
                    double* __restrict__ Dd, double* __restrict__ tt) {
     constexpr int BB = DC * DC;
-    __shared__ double sA[SUB_TS][SUB_KC + 1], sB[SUB_TS][SUB_KC + 1];
+    __shared__ double sA[SUB_TS][SUB_KC + 1], sB[SUB_TS][SUB_KC + 1], sY[NR][SUB_KC + 1];
     const int W = b + 1, n = N * DC, Q = b * DC, tid = threadIdx.x;
     const int s = blockIdx.x, p0 = sep_lo[s], rs = sep_rseg[s];
-    const int k0 = seg_lo[rs] * DC, k1 = seg_hi[rs] * DC;
-    const int ntl = (Q + SUB_TS - 1) / SUB_TS, ntiles = ntl * (ntl + 1) / 2;
-    if ((int)blockIdx.y == ntiles) {                        // right-hand sides: one wave per output, lanes stride the segment rows
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int o = wave; o < NR * Q; o += 4) {
-            const int r = o / Q, q = o - r * Q;
-            double acc = 0.0;
-            for (int kk = k0 + lane; kk < k1; kk += 64) acc += Z[(size_t)q * n + kk] * Y[(size_t)r * n + kk];
-            acc = wave_sum(acc);
-            if (lane == 0) tt[((size_t)s * NR + r) * Q + q] = Y[(size_t)r * n + (size_t)p0 * DC + q] - acc;
-        }
-        return;
-    }
+    const int ka = seg_lo[rs] * DC, kb = seg_hi[rs] * DC;
+    const int kchunk = (((kb - ka + (int)gridDim.z - 1) / (int)gridDim.z + SUB_KC - 1) / SUB_KC) * SUB_KC;
+    const int k0 = ka + (int)blockIdx.z * kchunk, k1 = min(kb, k0 + kchunk);
+    const bool first = blockIdx.z == 0;
+    if (k0 >= k1 && !first) return;
     int ti = 0, tj = blockIdx.y;                            // lower tiles, row-major: (0,0) (1,0) (1,1) (2,0) ...
     while (tj > ti) { tj -= ti + 1; ti++; }
     const int tx = tid & 15, ty = tid >> 4;                 // outputs (ti*32 + 2*ty + {0,1}, tj*32 + 2*tx + {0,1})
-    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    const bool with_rhs = tj == 0;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, accy[2][NR];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) accy[u][r] = 0.0;
     for (int kk0 = k0; kk0 < k1; kk0 += SUB_KC) {
         for (int e = tid; e < SUB_TS * SUB_KC; e += 256) {
             const int i = e / SUB_KC, kk = e - i * SUB_KC;
@@ -179,116 +189,212 @@ k_sub_sep_assemble(const double* __restrict__ band, const double* __restrict__ Z
             sA[i][kk] = (in && qa < Q) ? Z[(size_t)qa * n + kk0 + kk] : 0.0;
             sB[i][kk] = (in && qb < Q) ? Z[(size_t)qb * n + kk0 + kk] : 0.0;
         }
+        if (with_rhs) for (int e = tid; e < NR * SUB_KC; e += 256) {
+            const int r = e / SUB_KC, kk = e - r * SUB_KC;
+            sY[r][kk] = (kk0 + kk < k1) ? Y[(size_t)r * n + kk0 + kk] : 0.0;
+        }
         __syncthreads();
 #pragma unroll 8
         for (int kk = 0; kk < SUB_KC; kk++) {
             const double a0 = sA[2 * ty][kk], a1 = sA[2 * ty + 1][kk], b0 = sB[2 * tx][kk], b1 = sB[2 * tx + 1][kk];
             acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+            if (with_rhs && tx == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) { const double yv = sY[r][kk]; accy[0][r] += a0 * yv; accy[1][r] += a1 * yv; }
+            }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 2; u++) {
+        const int q = ti * SUB_TS + 2 * ty + u;
 #pragma unroll
         for (int v = 0; v < 2; v++) {
-            const int q = ti * SUB_TS + 2 * ty + u, q2 = tj * SUB_TS + 2 * tx + v;
+            const int q2 = tj * SUB_TS + 2 * tx + v;
             if (q < Q && q2 <= q) {
                 const int r = q / DC, a = q - r * DC, r2 = q2 / DC, a2 = q2 - r2 * DC;
-                const double inner = band[((size_t)(p0 + r) * W + (r - r2)) * BB + a * DC + a2];
-                Dd[((size_t)s * Q + q) * Q + q2] = inner - acc[u][v];
+                const double inner = first ? band[((size_t)(p0 + r) * W + (r - r2)) * BB + a * DC + a2] : 0.0;
+                unsafeAtomicAdd(&Dd[((size_t)s * Q + q) * Q + q2], inner - acc[u][v]);
             }
         }
+        if (with_rhs && tx == 0 && q < Q) {
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                unsafeAtomicAdd(&tt[((size_t)s * NR + r) * Q + q], (first ? Y[(size_t)r * n + (size_t)p0 * DC + q] : 0.0) - accy[u][r]);
+        }
+    }
 }
 
 // ---- 4. block-tridiagonal chain over the separators of one component -----------------------------------------------------------
 //   forward, j = 0..ns-1:  F_j = E_j Lc_{j-1}^-T,  D_j -= F_j F_j^T,  t_j -= F_j w_{j-1},  Lc_j = chol(D_j),  w_j = Lc_j^-1 t_j
 //   backward:              x_j = Lc_j^-T (w_j - F_{j+1}^T x_{j+1})          -> Y rows of the separator
 // E_j(i, c) = Z[c][(row of sep_j) i]: left by the spike kernel in the rows of sep_j.  One workgroup of 1024 per chain; LDS:
-// packed lower triangle (Lc / D) + full F (column-major) + vectors = 8 (Q(Q+1)/2 + Q^2 + (2 NR + 1) Q) bytes <= 160 KB  <=>  Q <= 114.
-// Right-looking eliminations with deferred scaling: column c is final after step c-1, every reader multiplies by 1/L_cc itself,
-// one barrier per column.
+// packed lower triangle (Lc / D) + full F (column-major) + vectors = 8 (Q(Q+1)/2 + Q^2 + 2 NR Q) bytes <= 160 KB  <=>  Q <= 114.
+// All three eliminations are blocked by DC columns: the DCxDC diagonal block is factored AND inverted by one wave
+// (wave_chol_inverse), its inverse G replaces it in the packed triangle, panels are products with G^T (no substitution chain),
+// trailing updates take DC columns per pass.  Thread (tx, ty) = (tid & 127, tid >> 7): tx = row, ty strides the columns.
 template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
 k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                 const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
                 double* __restrict__ Y, int* __restrict__ fail_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NB = DC;
     const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = blockDim.x, NP = Q * (Q + 1) / 2;
-    double* sL = lds;                  // [NP]   packed lower triangle, row-major: (i, c) at i(i+1)/2 + c
+    double* sL = lds;                  // [NP]   packed lower triangle, row-major: (i, c) at i(i+1)/2 + c; diagonal blocks hold G = L_blk^-1
     double* sF = sL + NP;              // [Q][Q] column-major: F(i, c) at c*Q + i
     double* sT = sF + (size_t)Q * Q;   // [NR][Q] t_j -> w_j   (backward: v -> x_j)
     double* sW = sT + NR * Q;          // [NR][Q] w_{j-1}      (backward: x_{j+1})
-    double* sInv = sW + NR * Q;        // [Q]    1 / L_cc
     const int s0 = chain_ptr[blockIdx.x], ns = chain_ptr[blockIdx.x + 1] - s0;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int tx = tid & 127, ty = tid >> 7;
+    const bool rowt = tx < Q;
+#define PK(i_, c_) ((i_) * ((i_) + 1) / 2 + (c_))
     for (int j = 0; j < ns; j++) {
         const int s = s0 + j, p0 = sep_lo[s];
         for (int e = tid; e < NR * Q; e += nt) sT[e] = tt[(size_t)s * NR * Q + e];
         if (j > 0) {
-            // ---- F = E Lc^-T with Lc = previous factor (still in sL, sInv)
-            for (int e = tid; e < Q * Q; e += nt) { const int c = e / Q, i = e - c * Q; sF[e] = Z[(size_t)c * n + (size_t)p0 * DC + i]; }
-            for (int c = 0; c < Q; c++) {
+            // ---- F = E Lc^-T with Lc = previous factor (still in sL)
+            if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx];
+            for (int c0 = 0; c0 < Q; c0 += NB) {
                 __syncthreads();
-                const double ic = sInv[c];
-                const int rem = Q - 1 - c;
-                for (int e = tid; e < rem * Q; e += nt) {
-                    const int cp = c + 1 + e / Q, i = e % Q;
-                    sF[cp * Q + i] -= sF[c * Q + i] * ic * sL[cp * (cp + 1) / 2 + c] ;
+                if (ty == 0 && rowt) {                                  // panel: F(:, c0..) = E'(:, c0..) G^T
+                    double ev[NB], pv[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) ev[k] = sF[(c0 + k) * Q + tx];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) { double a = 0.0;
+#pragma unroll
+                        for (int m = 0; m <= k; m++) a += ev[m] * sL[PK(c0 + k, c0 + m)];
+                        pv[k] = a; }
+#pragma unroll
+                    for (int k = 0; k < NB; k++) sF[(c0 + k) * Q + tx] = pv[k];
+                }
+                __syncthreads();
+                if (rowt) {
+                    double pv[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) pv[k] = sF[(c0 + k) * Q + tx];
+                    for (int cp = c0 + NB + ty; cp < Q; cp += 8) {
+                        const double* Lr = sL + PK(cp, c0);
+                        double v = sF[cp * Q + tx];
+#pragma unroll
+                        for (int k = 0; k < NB; k++) v -= pv[k] * Lr[k];
+                        sF[cp * Q + tx] = v;
+                    }
                 }
             }
             __syncthreads();
-            for (int e = tid; e < Q * Q; e += nt) sF[e] *= sInv[e / Q];
-            __syncthreads();
             // ---- t_j -= F w_{j-1};  F to global for the backward pass
-            for (int e = tid; e < NR * Q; e += nt) {
-                const int r = e / Q, i = e - r * Q;
+            if (rowt && ty < NR) {
                 double acc = 0.0;
-                for (int c = 0; c < Q; c++) acc += sF[c * Q + i] * sW[r * Q + c];
-                sT[e] -= acc;
+                for (int c = 0; c < Q; c++) acc += sF[c * Q + tx] * sW[ty * Q + c];
+                sT[ty * Q + tx] -= acc;
             }
             for (int e = tid; e < Q * Q; e += nt) Fbuf[(size_t)s * Q * Q + e] = sF[e];
-            __syncthreads();
         }
-        // ---- D_j (- F F^T) into the packed triangle
-        for (int e = tid; e < NP; e += nt) {
-            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (i * (i + 1) / 2 > e) i--;
-            while ((i + 1) * (i + 2) / 2 <= e) i++;
-            const int c = e - i * (i + 1) / 2;
-            double v = Dd[((size_t)s * Q + i) * Q + c];
-            if (j > 0) for (int m = 0; m < Q; m++) v -= sF[m * Q + i] * sF[m * Q + c];
-            sL[e] = v;
+        // ---- D_j into the packed triangle (previous factor is dead: it went to Lbuf)
+        __syncthreads();
+        if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = Dd[((size_t)s * Q + tx) * Q + cp];
+        __syncthreads();
+        if (j > 0) {
+            // ---- D_j -= F F^T, 4x4 register tiles over the lower triangle
+            const int R4 = (Q + 3) / 4, ntile = R4 * (R4 + 1) / 2;
+            if (tid < ntile) {
+                int ti = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+                while (ti * (ti + 1) / 2 > tid) ti--;
+                while ((ti + 1) * (ti + 2) / 2 <= tid) ti++;
+                const int tj = tid - ti * (ti + 1) / 2;
+                int ri[4], rj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { ri[u] = min(4 * ti + u, Q - 1); rj[u] = min(4 * tj + u, Q - 1); }
+                double acc[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[u][v] = 0.0;
+                for (int m = 0; m < Q; m++) {
+                    const double* col = sF + m * Q;
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { av[u] = col[ri[u]]; bv[u] = col[rj[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int v = 0; v < 4; v++) acc[u][v] += av[u] * bv[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int i = 4 * ti + u, c = 4 * tj + v;
+                        if (i < Q && c <= i) sL[PK(i, c)] -= acc[u][v];
+                    }
+            }
         }
-        // ---- Cholesky, right-looking, forward substitution of t riding along
-        for (int c = 0; c < Q; c++) {
+        // ---- blocked Cholesky, forward substitution of t riding along
+        for (int c0 = 0; c0 < Q; c0 += NB) {
             __syncthreads();
-            const double d = sL[c * (c + 1) / 2 + c];
-            if (!(d > 0.0)) { if (tid == 0) *fail_flag = 1; }
-            const double ic = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-            if (tid == 0) sInv[c] = ic;
-            const int rem = Q - 1 - c;
-            for (int e = tid; e < rem * (rem + NR); e += nt) {
-                const int i = c + 1 + e / (rem + NR), u = e % (rem + NR);
-                const double lic = sL[i * (i + 1) / 2 + c] * ic;
-                if (u < rem) {
-                    const int cp = c + 1 + u;
-                    if (cp <= i) sL[i * (i + 1) / 2 + cp] -= lic * sL[cp * (cp + 1) / 2 + c] * ic;
-                } else {
-                    const int r = u - rem;
-                    sT[r * Q + i] -= lic * sT[r * Q + c] * ic;
+            if (wave == 0) {
+                double row[NB], g[NB];
+#pragma unroll
+                for (int c = 0; c < NB; c++) row[c] = (lane < NB) ? sL[PK(c0 + max(lane, c), c0 + min(lane, c))] : ((lane == c) ? 1.0 : 0.0);
+                if (!wave_chol_inverse<NB>(row, g) && lane == 0) *fail_flag = 1;
+                if (lane < NB) {
+#pragma unroll
+                    for (int r = 0; r < NB; r++) if (r >= lane) sL[PK(c0 + r, c0 + lane)] = g[r];
+                }
+            }
+            __syncthreads();
+            if (ty == 0 && rowt && tx >= c0 + NB) {                     // panel rows: L(i, c0..) = A'(i, c0..) G^T
+                double* Pr = sL + PK(tx, c0);
+                double ev[NB], pv[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) ev[k] = Pr[k];
+#pragma unroll
+                for (int k = 0; k < NB; k++) { double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= k; m++) a += ev[m] * sL[PK(c0 + k, c0 + m)];
+                    pv[k] = a; }
+#pragma unroll
+                for (int k = 0; k < NB; k++) Pr[k] = pv[k];
+            }
+            if (ty == 1 && tx < NR) {                                   // w block = G t block
+                double ev[NB], pv[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) ev[k] = sT[tx * Q + c0 + k];
+#pragma unroll
+                for (int k = 0; k < NB; k++) { double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= k; m++) a += ev[m] * sL[PK(c0 + k, c0 + m)];
+                    pv[k] = a; }
+#pragma unroll
+                for (int k = 0; k < NB; k++) sT[tx * Q + c0 + k] = pv[k];
+            }
+            __syncthreads();
+            if (rowt && tx >= c0 + NB) {
+                const double* Pr = sL + PK(tx, c0);
+                double pv[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) pv[k] = Pr[k];
+                for (int cp = c0 + NB + ty; cp <= tx; cp += 8) {
+                    const double* Lr = sL + PK(cp, c0);
+                    double v = sL[PK(tx, cp)];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) v -= pv[k] * Lr[k];
+                    sL[PK(tx, cp)] = v;
+                }
+                if (ty < NR) {
+                    double v = sT[ty * Q + tx];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) v -= pv[k] * sT[ty * Q + c0 + k];
+                    sT[ty * Q + tx] = v;
                 }
             }
         }
         __syncthreads();
-        for (int e = tid; e < NP; e += nt) {
-            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (i * (i + 1) / 2 > e) i--;
-            while ((i + 1) * (i + 2) / 2 <= e) i++;
-            const int c = e - i * (i + 1) / 2;
-            const double v = (i == c) ? sqrt(fmax(sL[e], 0.0)) : sL[e] * sInv[c];
-            sL[e] = v; Lbuf[(size_t)s * NP + e] = v;
-        }
-        for (int e = tid; e < NR * Q; e += nt) { const double wv = sT[e] * sInv[e % Q]; sW[e] = wv; wbuf[(size_t)s * NR * Q + e] = wv; }
+        for (int e = tid; e < NP; e += nt) Lbuf[(size_t)s * NP + e] = sL[e];
+        for (int e = tid; e < NR * Q; e += nt) { const double wv = sT[e]; sW[e] = wv; wbuf[(size_t)s * NR * Q + e] = wv; }
         __syncthreads();
     }
     // ---- backward
@@ -298,7 +404,7 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
             for (int e = tid; e < NP; e += nt) sL[e] = Lbuf[(size_t)s * NP + e];
             const double* Fn = Fbuf + (size_t)(s + 1) * Q * Q;
             for (int o = wave; o < NR * Q; o += nw) {
-                const int r = o / Q, c = o - r * Q;
+                const int r = (o >= Q) ? o / Q : 0, c = o - r * Q;
                 double acc = 0.0;
                 for (int i = lane; i < Q; i += 64) acc += Fn[(size_t)c * Q + i] * sW[r * Q + i];
                 acc = wave_sum(acc);
@@ -307,23 +413,34 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
         } else {
             for (int e = tid; e < NR * Q; e += nt) sT[e] = sW[e];
         }
-        // x = Lc^-T v, right-looking from the last row, deferred scaling
-        for (int c = Q - 1; c >= 0; c--) {
+        // x = Lc^-T v, blocked from the last block row
+        for (int c0 = Q - NB; c0 >= 0; c0 -= NB) {
             __syncthreads();
-            const double ic = 1.0 / sL[c * (c + 1) / 2 + c];
-            for (int e = tid; e < NR * c; e += nt) {
-                const int r = e / c, cp = e - r * c;
-                sT[r * Q + cp] -= sL[c * (c + 1) / 2 + cp] * sT[r * Q + c] * ic;
+            double xv = 0.0;
+            const int br = tid / NB, bk = tid - br * NB;                 // (right-hand side, row in block) for tid < NR*NB
+            if (tid < NR * NB) {
+#pragma unroll
+                for (int m = 0; m < NB; m++) if (m >= bk) xv += sL[PK(c0 + m, c0 + bk)] * sT[br * Q + c0 + m];       // x = G^T v
+            }
+            __syncthreads();
+            if (tid < NR * NB) sT[br * Q + c0 + bk] = xv;
+            __syncthreads();
+            if (ty < NR && tx < c0) {
+                double v = sT[ty * Q + tx];
+#pragma unroll
+                for (int k = 0; k < NB; k++) v -= sL[PK(c0 + k, tx)] * sT[ty * Q + c0 + k];
+                sT[ty * Q + tx] = v;
             }
         }
         __syncthreads();
         for (int e = tid; e < NR * Q; e += nt) {
-            const int r = e / Q, c = e - r * Q;
-            const double x = sT[e] / sL[c * (c + 1) / 2 + c];
+            const int r = (e >= Q) ? e / Q : 0, c = e - r * Q;
+            const double x = sT[e];
             sW[e] = x; Y[(size_t)r * n + (size_t)p0 * DC + c] = x;
         }
         __syncthreads();
     }
+#undef PK
 }
 
 // ---- 5. y(seg) -= Z x(separator in front) ------------------------------------------------------------------------------------------
