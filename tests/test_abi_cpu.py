@@ -114,3 +114,26 @@ def test_config2_plan():
     info, ids, used, pos = ba.plan(p)
     assert info["num_observations_used_global"] == 600000 and info["num_points_used_global"] == 100000
     assert info["reduced_blocks"] == 300 * 6 and info["band_half_width"] <= 12
+
+
+def test_band_segment_plan_matches_reference_partition(monkeypatch):
+    """The segment / separator tables of the substructured factorisation (csrc/band_sub.h) are host logic: ssfm_ba_plan reports
+    their sizes; tests/_band_ref.py restates the partition rule."""
+    import _band_ref as R
+    from spherical_sfm_amd import ba, synth
+    p = synth.make_circle(1000, 4000, 6, spherical=False, focal_fixed=True)          # stride 13, coprime with 1000: one ring of 1000
+    monkeypatch.delenv("SSFM_BAND_SEGMENTS", raising=False)
+    info, _, _, pos = ba.plan(p)
+    assert info["band_separators"] >= 3 and info["band_segments"] == info["band_separators"] + 1        # cut without being asked
+    b = info["band_half_width"]
+    for P in (2, 5, 64):
+        monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P))
+        got, _, _, _ = ba.plan(p)
+        segs, seps = R.segment_table([0, 1000], b, P)
+        assert (got["band_segments"], got["band_separators"]) == (len(segs), len(seps))
+        assert all(hi - lo >= b + 1 for lo, hi, _, _ in segs) and sum(hi - lo for lo, hi, _, _ in segs) + b * len(seps) == 1000
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "1")
+    assert ba.plan(p)[0]["band_separators"] == 0
+    monkeypatch.delenv("SSFM_BAND_SEGMENTS")
+    small, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))       # config 2 shape: four rings of 75 stay whole
+    assert (small["band_segments"], small["band_separators"]) == (4, 0)
