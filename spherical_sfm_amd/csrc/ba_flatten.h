@@ -50,7 +50,13 @@ struct BAFlat {
     std::vector<int> cam_pos;           // [Nc] camera -> position
     int band = 0;                       // block half-bandwidth in that order
     std::vector<int> band_pairs;        // (i_rel | k_rel << 16), i_rel-major, 1 <= k_rel <= i_rel <= band
-    std::vector<int> comp_ptr;          // connected components of the camera graph = contiguous position ranges
+    std::vector<int> comp_ptr;          // connected components of the camera graph = contiguous ranges of BAND ROWS
+    // Band rows.  Normally band row = elimination position.  A "twisted" component (band_twist_plan) is eliminated from both
+    // ends towards a separator of `band` rows in the middle; its band rows are  seg_0 | sep | seg_1 reversed | second copy of sep
+    // (the copy receives the Schur update from seg_1), so the band has band_rows >= Nc rows.
+    std::vector<int> band_row, band_row2;   // [Nc] camera -> band row; second row of a separator camera of a twisted component, else -1
+    std::vector<char> comp_twist;       // [components] 1 = twisted
+    int band_rows = 0;
     // The stored structure (row_ptr/col_idx) is the LOWER triangle in elimination order: row c holds block (c, c2) iff
     // cam_pos[c2] <= cam_pos[c].  trans_* lists, for every camera c, the stored blocks of OTHER rows whose column is c
     // (the upper triangle by symmetry) for the symmetric mat-vec.
@@ -108,6 +114,41 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
     int band = 0;
     for (int u = 0; u < n; u++) for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) band = std::max(band, std::abs(pos[u] - pos[col_idx[e]]));
     return band;
+}
+
+// Twisted (two-sided) elimination of medium-sized components.  A component of n rows in Cuthill-McKee order with half-width b is
+// split as seg_0 (m0 rows) | sep (b rows) | seg_1 (m1 rows).  seg_0 is eliminated front to back and seg_1 BACK TO FRONT, so both
+// have the separator behind them: no fill, and the dependent chain of the factorisation is (n - b) / 2 + b steps instead of n.
+//   in : pos = Cuthill-McKee positions, comp_ptr = component ranges in that order
+//   out: pos = elimination order (seg_0 | seg_1 reversed | sep), band_row / band_row2 / band_rows, comp_ptr in band rows
+// A component is twisted when both segments are longer than the band (n >= 3 b + 2) and it is not long enough to be cut into
+// several segments (band_sub.h, SUB_MIN_ROWS); the kernels involved need the LDS-resident factorisation (b <= 20).
+constexpr int BAND_CUT_MIN_ROWS = 256;
+inline void band_twist_plan(int Nc, int b, std::vector<int>& pos, std::vector<int>& comp_ptr, std::vector<int>& band_row,
+                            std::vector<int>& band_row2, std::vector<char>& comp_twist, int& band_rows) {
+    const char* env = std::getenv("SSFM_BAND_TWIST");
+    const bool allow = !(env && env[0] == '0') && b >= 1 && b <= 20;      // b <= 20: the 6-dof factorisation window fits the LDS
+    const int ncomp = (int)comp_ptr.size() - 1;
+    band_row.assign(Nc, -1); band_row2.assign(Nc, -1); comp_twist.assign(ncomp, 0);
+    std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;      // Cuthill-McKee position -> camera
+    std::vector<int> new_ptr(1, 0);
+    int base = 0;
+    for (int k = 0; k < ncomp; k++) {
+        const int c0 = comp_ptr[k], n = comp_ptr[k + 1] - c0;
+        if (allow && n >= 3 * b + 2 && n < BAND_CUT_MIN_ROWS) {
+            comp_twist[k] = 1;
+            const int m0 = (n - b) / 2, m1 = n - b - m0;
+            for (int i = 0; i < m0; i++) { const int c = inv[c0 + i]; pos[c] = c0 + i; band_row[c] = base + i; }
+            for (int s = 0; s < b; s++) { const int c = inv[c0 + m0 + s]; pos[c] = c0 + m0 + m1 + s; band_row[c] = base + m0 + s; band_row2[c] = base + m0 + b + m1 + (b - 1 - s); }
+            for (int u = 0; u < m1; u++) { const int c = inv[c0 + m0 + b + u]; pos[c] = c0 + m0 + (m1 - 1 - u); band_row[c] = base + m0 + b + (m1 - 1 - u); }
+            base += n + b;
+        } else {
+            for (int i = 0; i < n; i++) { const int c = inv[c0 + i]; band_row[c] = base + i; }
+            base += n;
+        }
+        new_ptr.push_back(base);
+    }
+    comp_ptr.swap(new_ptr); band_rows = base;
 }
 
 inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
@@ -190,6 +231,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     }
     lap("S structure");
     F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
+    band_twist_plan(Nc, F.band, F.cam_pos, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     {   // keep the lower triangle (in elimination order) only
         std::vector<int> rp(Nc + 1, 0), ci; ci.reserve(F.col_idx.size() / 2 + Nc);

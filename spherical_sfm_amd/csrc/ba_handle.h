@@ -20,13 +20,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_TWIST, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_twist_merge"};
 
 template <typename T>
 struct DevBuf {
@@ -52,7 +52,8 @@ struct ssfm_ba_handle {
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
-    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr;
+    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy;
+    DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
     DevBuf<double> subZ, subD, subT, subF, subL, subW;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
@@ -85,7 +86,7 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free();
+        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); cam_pos2.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
@@ -137,7 +138,7 @@ template <int DC>
 static int band_direct(ssfm_ba_handle* h, double* Y) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
     const BAFlat& F = h->F;
-    const int Nc = F.Nc, b = F.band;
+    const int Nc = F.band_rows > 0 ? F.band_rows : F.Nc, b = F.band;      // Nc here = rows of the band (>= cameras: twisted components)
     constexpr int BB = DC * DC;
     const int ncomp = (int)F.comp_ptr.size() - 1;
     // LDS-resident factorisation (band_kernels2.h): window ring + panel + right-hand-side rows + scratch + pair table
@@ -155,24 +156,42 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             const int Q = b * DC;
             const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
             if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-            if (lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+            if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
             LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b, failp);
-            h->span_begin(KID_SUB_SPIKE);
-            hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, (Q + SPIKE_NC - 1) / SPIKE_NC), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
-            h->span_end();
-            const int ntl = (Q + SUB_TS - 1) / SUB_TS;
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
-            const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
-            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subD.p, 0, h->subD.n * sizeof(double), st));
-            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subT.p, 0, h->subT.n * sizeof(double), st));
-            h->span_begin(KID_SUB_ASM);
-            hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
-            h->span_end();
-            LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
-            h->span_begin(KID_SUB_APPLY);
-            hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + 255) / 256), dim3(256), (size_t)2 * Q * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
-            h->span_end();
+            if (B.nsep > 0) {
+                h->span_begin(KID_SUB_SPIKE);
+                hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, (Q + SPIKE_NC - 1) / SPIKE_NC), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+                h->span_end();
+                const int ntl = (Q + SUB_TS - 1) / SUB_TS;
+                const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
+                SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subD.p, 0, h->subD.n * sizeof(double), st));
+                SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subT.p, 0, h->subT.n * sizeof(double), st));
+                h->span_begin(KID_SUB_ASM);
+                hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
+                h->span_end();
+                LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
+            }
+            if (B.ntwist > 0) {
+                // twisted components: both segments left their Schur updates in the separator and in its copy; merge, factor + solve the
+                // separator as a component of b rows, hand its solution to the copy
+                h->span_begin(KID_TWIST);
+                hipLaunchKernelGGL((k_twist_merge<DC, 2>), dim3(B.ntwist, b), dim3(256), 0, st, h->band.p, Y, h->sub_tw_lo.p, h->sub_tw_copy.p, Nc, b);
+                h->span_end();
+                LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.ntwist, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, Nc, b, failp);
+                h->span_begin(KID_BAND_BACK);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.ntwist, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, Nc, b);
+                h->span_end();
+                h->span_begin(KID_TWIST);
+                hipLaunchKernelGGL((k_twist_copy<DC, 2>), dim3(B.ntwist), dim3(256), 0, st, Y, h->sub_tw_lo.p, h->sub_tw_copy.p, Nc, b);
+                h->span_end();
+            }
+            if (B.nleft > 0) {
+                h->span_begin(KID_SUB_APPLY);
+                hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + 255) / 256), dim3(256), (size_t)2 * Q * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
+                h->span_end();
+            }
             h->span_begin(KID_BAND_BACK);
             hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.nseg, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b);
             h->span_end();
@@ -209,6 +228,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
     const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
     const int Nc = F.Nc, n = Nc * DC, b = F.band;
+    const int Nb = F.band_rows > 0 ? F.band_rows : Nc, nb = Nb * DC;       // rows of the band / stride of the right-hand-side columns in band order
     constexpr int BB = DC * DC;
     const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
     if (O.preconditioner == 1) {
@@ -242,17 +262,17 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     if (stage == 0) {
     if (!h->zone_views) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
     if (!h->band_filled) {                                       // the BA path fills the band in its fused finalize kernel
-        LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
-        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, Nc, h->Yb.p);
+        LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, Nc, b, h->band.p);
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, h->cam_pos2.p, Nc, Nb, h->Yb.p);
     }
     h->band_filled = false;
     { const int rc = band_direct<DC>(h, h->Yb.p); if (rc) return rc; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
     if (F.sym_lower) {
-        LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
+        LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
                h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p);
     } else {
-        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
+        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
         MATVEC(h, DC, h->px.p);
     }
     LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
@@ -263,25 +283,25 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     { int fail_flag; std::memcpy(&fail_flag, &host_pcg[PCG_TOTAL], sizeof(int));
       if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
     while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
-        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, Nc, h->Yr.p);
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, h->cam_pos2.p, Nc, Nb, h->Yr.p);
         if (sub_on) {
             // the substructured factor has no stand-alone substitution kernels: rebuild the band from S and solve again (rare path)
-            LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, Nc, b, h->band.p);
+            LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, Nc, b, h->band.p);
             const int rc = band_direct<DC>(h, h->Yr.p); if (rc) return rc;
         } else if (use_lds) {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+            LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nb, b);
                 h->span_end();
             } else {
-                LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nc, b);
+                LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);
             }
         } else {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
-            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nc, b);
+            LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nb, b);
+            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nb, b);
         }
-        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + n, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
+        LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
         LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);
         MATVEC(h, DC, h->pp.p);
         LAUNCH(h, KID_REF_VEC, k_ref_step<DC>, 1, 1024, 0, h->Sfc, h->Sff.p, Nc, tol2, h->pp.p, h->pq.p, h->pqpart.p, h->px.p, h->pr.p, h->pcg.p);

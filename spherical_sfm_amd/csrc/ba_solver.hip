@@ -121,7 +121,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         }
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             LAUNCH(h, KID_FINALIZE, k_finalize_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                   radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+                   radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, F.band_rows, F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -237,13 +237,15 @@ extern "C" void ssfm_ba_default_options(ssfm_ba_options* o) {
 // segment / separator tables of the substructured factorisation (band_sub.h) and its work buffers
 static int sub_upload(ssfm_ba_handle* h, int DC) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; const BAFlat& F = h->F;
-    sub_build(F.comp_ptr, F.band, DC, h->sub);
+    sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub);
     if (!h->sub.enabled) return SSFM_OK;
-    const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)F.Nc * DC;
+    const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
+    SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_lo, B.seg_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_hi, B.seg_hi, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_chain_ptr, B.chain_ptr, st));
+    if (B.nsep == 0) return SSFM_OK;                             // twisted components only: no spikes, no chain
     SSFM_HIP_CHECK(ctx, h->subZ.alloc(Q * n)); SSFM_HIP_CHECK(ctx, h->subD.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subT.alloc((size_t)B.nsep * 2 * Q));
     SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
     return SSFM_OK;
@@ -259,7 +261,7 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
     ssfm_ba_handle hh; ssfm_ba_handle* h = &hh;
     h->ctx = ctx; ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
-    BAFlat& F = h->F; F.Nc = N; F.band = b; F.DC = dc; F.comp_ptr.assign(comp_ptr, comp_ptr + ncomp + 1);
+    BAFlat& F = h->F; F.Nc = N; F.band_rows = N; F.band = b; F.DC = dc; F.comp_ptr.assign(comp_ptr, comp_ptr + ncomp + 1);
     for (int ir = 1; ir <= b; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     const size_t nb = (size_t)N * (b + 1) * dc * dc, n = (size_t)N * dc;
     int rc = SSFM_OK;
@@ -272,7 +274,7 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
         SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->Yb.p, Y, 2 * n * sizeof(double), hipMemcpyHostToDevice, st));
         SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st)); SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
         { const int r = sub_upload(h, dc); if (r) return r; }
-        if (h->sub.enabled) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subZ.p, 0, h->subZ.n * sizeof(double), st));
+        if (h->sub.enabled && h->subZ.p) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subZ.p, 0, h->subZ.n * sizeof(double), st));
         { const int r = (dc == 3) ? band_direct<3>(h, h->Yb.p) : band_direct<6>(h, h->Yb.p); if (r) return r; }
         SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Y, h->Yb.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st));
         int flag = 0;
@@ -301,8 +303,8 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     info->camera_dof = F.DC; info->num_points_used = F.nP; info->num_points_used_global = F.nP_global;
     info->reduced_blocks = F.row_ptr[F.Nc]; info->band_half_width = F.band; info->max_row_blocks = F.max_row_blocks;
     info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
-    { BandSub B; sub_build(F.comp_ptr, F.band, F.DC, B);
-      info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep; }
+    { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.DC, B);
+      info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep + B.ntwist; }
     if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];
     if (obs_used) for (int64_t j = 0; j < F.M; j++) obs_used[F.obs_orig[j]] = 1;
     if (cam_pos) for (int c = 0; c < F.Nc; c++) cam_pos[c] = F.cam_pos[c];
@@ -349,9 +351,11 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
-    AL(band, (size_t)Nc * (F.band + 1) * DC * DC); AL(Linv, (size_t)Nc * DC * DC); AL(Yb, 2 * n); AL(Yr, 2 * n); AL(band_fail, 1);
+    const size_t Nb = (size_t)F.band_rows, nbr = Nb * DC;         // band rows >= cameras (twisted components carry a second copy of their separator)
+    AL(band, Nb * (F.band + 1) * DC * DC); AL(Linv, Nb * DC * DC); AL(Yb, 2 * nbr); AL(Yr, 2 * nbr); AL(band_fail, 1);
 #undef AL
-    SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.cam_pos, st)); SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
+    SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.band_row, st)); SSFM_HIP_CHECK(ctx, upload(h->cam_pos2, F.band_row2, st));   // the device only needs band rows
+    SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
@@ -382,7 +386,7 @@ extern "C" int ssfm_ba_run(ssfm_ba_handle* h, ssfm_ba_summary* s) {
     const int32_t nblk = F.nothing_to_do ? 0 : F.row_ptr[F.Nc];
     s->num_residual_blocks = F.M; s->num_residual_blocks_global = F.M_global; s->num_points_used = F.nP; s->camera_dof = F.DC;
     s->reduced_blocks = F.nothing_to_do ? 0 : F.row_ptr[F.Nc]; s->band_half_width = F.band;
-    const int32_t nsegs = h->sub.enabled ? h->sub.nseg : (int32_t)F.comp_ptr.size() - 1, nseps = h->sub.nsep;
+    const int32_t nsegs = h->sub.enabled ? h->sub.nseg : (int32_t)F.comp_ptr.size() - 1, nseps = h->sub.nsep + h->sub.ntwist;
     s->band_segments = F.nothing_to_do ? 0 : nsegs; s->band_separators = nseps;
     if (F.nothing_to_do) { s->termination = SSFM_NOTHING_TO_DO; return SSFM_OK; }
     SSFM_HIP_CHECK(h->ctx, hipSetDevice(h->ctx->device));

@@ -34,18 +34,21 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 // S (block-CSR, camera order) -> band storage (permuted), right-hand sides permuted alongside
 template <int DC>
 __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
-                              const int* __restrict__ pos, int Nc, int b, double* __restrict__ band) {
+                              const int* __restrict__ pos, const int* __restrict__ pos2, int Nc, int b, double* __restrict__ band) {
     constexpr int BB = DC * DC;
     const int c = blockIdx.x;
-    const int i = pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    // the workgroup owns band row i (its blocks all come from S row c): clear it, then scatter
+    const int i = pos[c], i2 = pos2 ? pos2[c] : -1, rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    // the workgroup owns band row i (its blocks all come from S row c): clear it, then scatter.  A separator camera of a twisted
+    // component owns a second row i2 behind the reversed segment: blocks whose column lies there go to that row (pos = band rows).
     double* row = band + (size_t)i * (b + 1) * BB;
-    for (int e = threadIdx.x; e < (b + 1) * BB; e += blockDim.x) row[e] = 0.0;
+    double* row2 = band + (size_t)max(i2, 0) * (b + 1) * BB;
+    for (int e = threadIdx.x; e < (b + 1) * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
     __syncthreads();
     for (int idx = threadIdx.x; idx < nnb * BB; idx += blockDim.x) {
         const int s = rb + idx / BB, e = idx % BB;
         const int k = pos[col_idx[s]];
         if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e];
+        else if (i2 >= 0) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
     }
 }
 // k_finalize_S + k_band_gather + k_band_permute_rhs in one launch for the BA path with the banded preconditioner (one workgroup per
@@ -56,12 +59,12 @@ template <int DC>
 __global__ void __launch_bounds__(256)
 k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ diag_slot,
                   const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ Udiag,
-                  const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos, int b,
-                  double* __restrict__ S_val, double* __restrict__ rhs, const double* __restrict__ Sfc, double* __restrict__ Sff,
+                  const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,
+                  const int* __restrict__ pos2, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs, const double* __restrict__ Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int i = pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    const int i = pos[c], i2 = pos2[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;     // pos / pos2: band rows (second row: twisted separators)
     double gmax = 0.0;
     if (tid < DC) {
         double* blk = S_val + ((size_t)rb + diag_slot[c]) * BB;
@@ -69,16 +72,19 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
         blk[tid * DC + tid] += (s > 0.0) ? fmin(fmax(Udiag[c * DC + tid], min_diag), max_diag) / radius : 1.0;
         if (s > 0.0) gmax = fabs(gcraw[c * DC + tid] / s);
         Y[(size_t)i * DC + tid] = rhs[c * DC + tid];
-        Y[(size_t)Nc * DC + (size_t)i * DC + tid] = Sfc[c * DC + tid];
+        Y[(size_t)Nb * DC + (size_t)i * DC + tid] = Sfc[c * DC + tid];
+        if (i2 >= 0) { Y[(size_t)i2 * DC + tid] = 0.0; Y[(size_t)Nb * DC + (size_t)i2 * DC + tid] = 0.0; }
     }
     if (tid < 64) { gmax = wave_max(gmax); if (tid == 0 && gmax > 0.0) atomic_max_nonneg(&scal[(size_t)(c & (SC_NSLOT - 1)) * SC_TOTAL + SC_GMAX], gmax); }
     double* row = band + (size_t)i * (b + 1) * BB;
-    for (int e = tid; e < (b + 1) * BB; e += blockDim.x) row[e] = 0.0;
+    double* row2 = band + (size_t)max(i2, 0) * (b + 1) * BB;
+    for (int e = tid; e < (b + 1) * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
     __syncthreads();                                               // damped diagonal block and cleared row visible to the whole workgroup
     for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
         const int sidx = rb + idx / BB, e = idx % BB;
         const int k = pos[col_idx[sidx]];
         if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)sidx * BB + e];
+        else if (i2 >= 0) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)sidx * BB + e];
     }
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;
@@ -96,13 +102,15 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
 }
 
 template <int DC>
-__global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double* __restrict__ Sfc, const int* __restrict__ pos, int Nc,
-                                   double* __restrict__ Y) {
+__global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double* __restrict__ Sfc, const int* __restrict__ pos,
+                                   const int* __restrict__ pos2, int Nc, int Nb, double* __restrict__ Y) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Nc * DC) return;
     const int c = t / DC, a = t - c * DC;
     Y[pos[c] * DC + a] = rhs[t];
-    Y[(size_t)Nc * DC + pos[c] * DC + a] = Sfc[t];
+    Y[(size_t)Nb * DC + pos[c] * DC + a] = Sfc[t];
+    const int i2 = pos2 ? pos2[c] : -1;
+    if (i2 >= 0) { Y[i2 * DC + a] = 0.0; Y[(size_t)Nb * DC + i2 * DC + a] = 0.0; }
 }
 
 // Factorise in place (lower), store inverse diagonal factors, forward-substitute NR right-hand sides Y[r][N*DC].

@@ -31,6 +31,10 @@ struct BandSub {
     std::vector<int> left_segs;                     // segments with a separator in front
     std::vector<int> sep_lo, sep_rseg;              // first row of the separator; the segment behind it
     std::vector<int> chain_ptr;                     // separators of chain c: [chain_ptr[c], chain_ptr[c+1])  (one chain per cut component)
+    // twisted components (ba_flatten.h: band_twist_plan): seg_0 | sep | seg_1 reversed | copy of sep.  Both segments have their separator
+    // rows behind them; tw_lo / tw_hi = the separator as a small component of its own, tw_copy = first row of its second copy
+    int ntwist = 0;
+    std::vector<int> tw_lo, tw_hi, tw_copy;
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
@@ -52,15 +56,24 @@ inline int sub_choose_segments(int rows, int b, int dc) {
     return best;
 }
 
-inline void sub_build(const std::vector<int>& comp_ptr, int b, int dc, BandSub& S) {
+inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>& comp_twist, int b, int dc, BandSub& S) {
     S = BandSub();
     const char* env = std::getenv("SSFM_BAND_SEGMENTS");               // 1 = never cut; P >= 2 = cut every component that can take it into P
     const int forced = env ? std::atoi(env) : 0;
-    if (b < 1 || b * dc > 114 || forced == 1) return;                  // separator blocks must fit the chain kernel's LDS (see k_sub_sep_chain)
+    const bool can_cut = b >= 1 && b * dc <= 114 && forced != 1;       // separator blocks must fit the chain kernel's LDS (see k_sub_sep_chain)
     S.chain_ptr.assign(1, 0);
     for (size_t c = 0; c + 1 < comp_ptr.size(); c++) {
         const int c0 = comp_ptr[c], rows = comp_ptr[c + 1] - c0;
-        int P = forced >= 2 ? forced : sub_choose_segments(rows, b, dc);
+        if (c < comp_twist.size() && comp_twist[c]) {                  // rows = n + b: seg_0 | sep | seg_1 reversed | copy of sep
+            const int n = rows - b, m0 = (n - b) / 2, m1 = n - b - m0;
+            S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b);
+            S.seg_lo.push_back(c0 + m0 + b); S.seg_hi.push_back(c0 + m0 + b + m1); S.seg_wend.push_back(c0 + rows);
+            S.tw_lo.push_back(c0 + m0); S.tw_hi.push_back(c0 + m0 + b); S.tw_copy.push_back(c0 + m0 + b + m1);
+            S.enabled = true;
+            continue;
+        }
+        int P = (forced >= 2 ? forced : sub_choose_segments(rows, b, dc));
+        if (!can_cut) P = 1;
         while (P > 1 && (rows - (P - 1) * b) / P < b + 1) P--;
         const int m_total = rows - (P - 1) * b;
         int pos = c0;
@@ -74,6 +87,7 @@ inline void sub_build(const std::vector<int>& comp_ptr, int b, int dc, BandSub& 
         if (P > 1) { S.enabled = true; S.chain_ptr.push_back((int)S.sep_lo.size()); }
     }
     S.nseg = (int)S.seg_lo.size(); S.nsep = (int)S.sep_lo.size(); S.nchain = (int)S.chain_ptr.size() - 1; S.nleft = (int)S.left_segs.size();
+    S.ntwist = (int)S.tw_lo.size();
     if (!S.enabled) S = BandSub();
 }
 
@@ -441,6 +455,33 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
         __syncthreads();
     }
 #undef PK
+}
+
+// ---- twisted components: the separator is reduced from both sides --------------------------------------------------------------
+// k_twist_merge: the copy behind seg_1 (rows in REVERSED order) holds -(Schur update of seg_1) and seg_1's share of the forward
+// substitution; add both to the separator proper.  Block (s, s-d) of the separator = transpose of block (b-1-s+d, d) of the copy.
+template <int DC, int NR>
+__global__ void __launch_bounds__(256)
+k_twist_merge(double* __restrict__ band, double* __restrict__ Y, const int* __restrict__ tw_lo, const int* __restrict__ tw_copy, int N, int b) {
+    constexpr int BB = DC * DC;
+    const int W = b + 1, n = N * DC, x0 = tw_lo[blockIdx.x], y0 = tw_copy[blockIdx.x], s = blockIdx.y;
+    for (int e = threadIdx.x; e < (s + 1) * BB; e += blockDim.x) {
+        const int d = e / BB, rc = e - d * BB, a = rc / DC, a2 = rc - a * DC;
+        band[((size_t)(x0 + s) * W + d) * BB + a * DC + a2] += band[((size_t)(y0 + b - 1 - s + d) * W + d) * BB + a2 * DC + a];
+    }
+    if (threadIdx.x < NR * DC) {
+        const int r = threadIdx.x / DC, a = threadIdx.x - r * DC;
+        Y[(size_t)r * n + (size_t)(x0 + s) * DC + a] += Y[(size_t)r * n + (size_t)(y0 + b - 1 - s) * DC + a];
+    }
+}
+// k_twist_copy: the separator's solution into the rows of its copy (where seg_1's back substitution expects it)
+template <int DC, int NR>
+__global__ void k_twist_copy(double* __restrict__ Y, const int* __restrict__ tw_lo, const int* __restrict__ tw_copy, int N, int b) {
+    const int n = N * DC, x0 = tw_lo[blockIdx.x], y0 = tw_copy[blockIdx.x];
+    for (int e = threadIdx.x; e < NR * b * DC; e += blockDim.x) {
+        const int r = e / (b * DC), q = e - r * b * DC, s = q / DC, a = q - s * DC;
+        Y[(size_t)r * n + (size_t)(y0 + b - 1 - s) * DC + a] = Y[(size_t)r * n + (size_t)(x0 + s) * DC + a];
+    }
 }
 
 // ---- 5. y(seg) -= Z x(separator in front) ------------------------------------------------------------------------------------------

@@ -259,6 +259,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         for (int i = 0; i < n; i++) { std::copy(nb[i].begin(), nb[i].end(), F.col_idx.begin() + F.row_ptr[i]);
                                       F.diag_slot[i] = (int)(std::lower_bound(nb[i].begin(), nb[i].end(), i) - nb[i].begin()); }
         F.band = cuthill_mckee(n, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
+        F.band_rows = n;                                    // band row = elimination position (no twisted components here)
         for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     }
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];

@@ -96,16 +96,34 @@ def test_sharding_partitions_the_used_points(nranks):
     assert max(sizes) - min(sizes) <= 6 * 2                               # balanced by observation count
 
 
-def test_elimination_order_is_a_banded_permutation():
+def test_elimination_order_is_a_banded_permutation(monkeypatch):
     p = synth.make_circle(60, 600, 6)
+    cams = p.obs_cam.reshape(-1, 6)
+    monkeypatch.setenv("SSFM_BAND_TWIST", "0")                    # plain Cuthill-McKee order
     info, ids, used, pos = ba.plan(p)
     assert sorted(pos.tolist()) == list(range(60))
     # cameras that share a point must sit within the reported half-bandwidth of each other
-    cams = p.obs_cam.reshape(-1, 6)
     d = np.abs(pos[cams][:, :, None] - pos[cams][:, None, :]).max()
     assert d == info["band_half_width"]
     assert info["band_half_width"] <= 12          # a ring with reach 5 folds into a band of ~2*5
     assert info["reduced_blocks"] == 60 * 6 and info["max_row_blocks"] <= 11      # lower triangle: 10 neighbours / 2 + diagonal
+    assert (info["band_segments"], info["band_separators"]) == (1, 0)
+    # default: the ring is eliminated from both ends (csrc/ba_flatten.h: band_twist_plan): seg_0 | seg_1 reversed | separator last
+    monkeypatch.delenv("SSFM_BAND_TWIST")
+    info2, _, _, pos2 = ba.plan(p)
+    b = info2["band_half_width"]; m0 = (60 - b) // 2; m1 = 60 - b - m0
+    assert sorted(pos2.tolist()) == list(range(60)) and b == info["band_half_width"]
+    assert (info2["band_segments"], info2["band_separators"]) == (2, 1) and info2["reduced_blocks"] == 60 * 6
+    seg = np.where(pos2 < m0, 0, np.where(pos2 < m0 + m1, 1, 2))      # 2 = separator
+    a, c = pos2[cams][:, :, None], pos2[cams][:, None, :]
+    sa, sc = seg[cams][:, :, None], seg[cams][:, None, :]
+    assert not ((sa == 0) & (sc == 1)).any()                          # the separator really separates the two segments
+    same = (sa == sc) & (sa < 2)
+    assert np.abs(a - c)[same].max() <= b                             # each segment is still a band of the same width
+    assert np.array_equal(np.sort(pos2[pos < m0]), np.arange(m0))     # seg_0 = the first m0 Cuthill-McKee positions, in the same order
+    assert np.array_equal(pos2[pos < m0], pos[pos < m0])
+    tail = pos >= m0 + b                                              # seg_1 = the last m1 positions, reversed
+    assert np.array_equal(pos2[tail], m0 + (m1 - 1 - (pos[tail] - m0 - b)))
 
 
 def test_config2_plan():
@@ -135,5 +153,9 @@ def test_band_segment_plan_matches_reference_partition(monkeypatch):
     monkeypatch.setenv("SSFM_BAND_SEGMENTS", "1")
     assert ba.plan(p)[0]["band_separators"] == 0
     monkeypatch.delenv("SSFM_BAND_SEGMENTS")
-    small, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))       # config 2 shape: four rings of 75 stay whole
+    monkeypatch.setenv("SSFM_BAND_TWIST", "0")
+    small, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))       # config 2 shape: four rings of 75 are not cut into chains ...
     assert (small["band_segments"], small["band_separators"]) == (4, 0)
+    monkeypatch.delenv("SSFM_BAND_TWIST")
+    small, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))       # ... but eliminated from both ends
+    assert (small["band_segments"], small["band_separators"]) == (8, 4)

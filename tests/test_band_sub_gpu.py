@@ -22,7 +22,7 @@ def point_rel_err(a, b):
                                                             (False, True, 2, 120, 6)])
 def test_forced_segments_match_oracle(gpu_ctx, oracle, monkeypatch, spherical, focal_fixed, P, Nc, K):
     from spherical_sfm_amd import ba
-    monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P)); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P)); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.setenv("SSFM_BAND_TWIST", "0")
     p = synth.make_circle(Nc, 40 * Nc, K, spherical=spherical, focal_fixed=focal_fixed, check_in_frame=False, seed=77 + P)
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
     assert s["band_separators"] >= 1 and s["band_segments"] > s["band_separators"]
@@ -40,7 +40,7 @@ def test_forced_segments_match_oracle(gpu_ctx, oracle, monkeypatch, spherical, f
 def test_refinement_path_with_segments(gpu_ctx, monkeypatch):
     """An impossible PCG tolerance forces refinement sweeps; with a substructured factor each sweep rebuilds and re-solves."""
     from spherical_sfm_amd import ba
-    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "2"); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "2"); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.setenv("SSFM_BAND_TWIST", "0")
     p = synth.make_circle(120, 4000, 6, spherical=False, focal_fixed=False, seed=5)
     cams, pts, f, s = ba.optimize(gpu_ctx, p, pcg_tolerance=1e-30, pcg_max_iterations=2)
     assert s["band_separators"] >= 1 and s["pcg_iterations_total"] >= s["num_linearizations"]
@@ -52,7 +52,7 @@ def test_long_component_is_cut_by_default(gpu_ctx, oracle):
     Config 2 (four rings of 75) stays on one workgroup per ring."""
     from spherical_sfm_amd import ba
     info2, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))
-    assert info2["band_separators"] == 0 and info2["band_segments"] == 4
+    assert info2["band_separators"] == 4 and info2["band_segments"] == 8          # twisted, not cut into chains
     p = synth.make_circle(1000, 40000, 6, spherical=False, focal_fixed=True, seed=3)
     info, _, _, _ = ba.plan(p)
     assert info["band_separators"] >= 3 and info["band_segments"] == info["band_separators"] + 1
@@ -60,3 +60,30 @@ def test_long_component_is_cut_by_default(gpu_ctx, oracle):
     assert s["band_separators"] == info["band_separators"] and s["pcg_iterations_total"] == 0
     ocams, opts, of, os_ = oracle.ba_solve(p)
     assert s["iterations"] == os_["iterations"] and rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+
+
+@pytest.mark.parametrize("spherical,focal_fixed,Nc,K", [(False, True, 300, 6), (True, False, 240, 6), (False, False, 60, 6), (False, True, 210, 8)])
+def test_twisted_elimination_matches_oracle_and_plain(gpu_ctx, oracle, monkeypatch, spherical, focal_fixed, Nc, K):
+    """Default plan for medium components: elimination from both ends towards a separator in the middle (band_twist_plan).  Same
+    LM run as the oracle, no refinement sweeps, and equal to the one-sided factorisation to rounding."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.delenv("SSFM_BAND_TWIST", raising=False); monkeypatch.delenv("SSFM_BAND_SEGMENTS", raising=False)
+    p = synth.make_circle(Nc, 40 * Nc, K, spherical=spherical, focal_fixed=focal_fixed, check_in_frame=False, seed=5 + Nc)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["band_separators"] >= 1 and s["band_segments"] == 2 * s["band_separators"]
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    monkeypatch.setenv("SSFM_BAND_TWIST", "0")
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
+    assert s1["band_separators"] == 0 and s1["iterations"] == s["iterations"]
+    assert rel_err(cams, c1) <= 1e-8 and point_rel_err(pts, p1) <= 1e-8
+
+
+def test_twisted_refinement_path(gpu_ctx, monkeypatch):
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.delenv("SSFM_BAND_TWIST", raising=False)
+    p = synth.make_circle(120, 4000, 6, spherical=False, focal_fixed=False, seed=5)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, pcg_tolerance=1e-30, pcg_max_iterations=2)
+    assert s["band_separators"] >= 1 and s["pcg_iterations_total"] >= s["num_linearizations"]
+    assert np.isfinite(cams).all() and np.isfinite(pts).all()
