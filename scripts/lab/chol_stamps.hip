@@ -26,7 +26,7 @@ int main() {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int rep = 0; rep < 3; rep++) {
         CK(hipMemcpy(dband, band.data(), band.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dY, Y.data(), Y.size() * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds, 0, dband, dG, dY, dp, dc, dc + 1, dc + 1, N, b, df, ddbg);
+        hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds, 0, dband, dG, dY, dp, dc, dc + 1, dc + 1, (const int*)nullptr, N, b, df, ddbg);
         CK(hipDeviceSynchronize());
     }
     std::vector<long long> dbg((size_t)ncam * nw * 4); CK(hipMemcpy(dbg.data(), ddbg, dbg.size() * 8, hipMemcpyDeviceToHost));

@@ -3,8 +3,8 @@ workgroup 0 in LDS (before / after the panel phase, after barrier 1, after the r
 import os, re
 here = os.path.dirname(os.path.abspath(__file__))
 src = open(os.path.join(here, "..", "..", "spherical_sfm_amd", "csrc", "band_kernels2.h")).read()
-src = src.replace("const int* __restrict__ win_hi, int N, int b,\n               int* __restrict__ fail_flag) {\n    constexpr int BB = DC * DC;\n    extern __shared__",
-                  "const int* __restrict__ win_hi, int N, int b,\n               int* __restrict__ fail_flag, long long* __restrict__ dbg) {\n    constexpr int BB = DC * DC;\n    extern __shared__", 1)
+src = src.replace("const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag) {\n    constexpr int BB = DC * DC;\n    extern __shared__",
+                  "const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag, long long* __restrict__ dbg) {\n    constexpr int BB = DC * DC;\n    extern __shared__", 1)
 src = src.replace("    int* sPairs = reinterpret_cast<int*>(sD + BB);",
                   "    int* sPairs = reinterpret_cast<int*>(sD + BB);\n    long long* sStamp = reinterpret_cast<long long*>(sPairs + b * (b + 1) / 2 + 2 + ((b * (b + 1) / 2) & 1));\n"
                   "#define STAMP(j_, k_) do { if (blockIdx.x == 0 && lane == 0) sStamp[((size_t)((j_) - r0) * nw + wave) * 4 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)", 1)

@@ -20,13 +20,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_TWIST, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_twist_merge"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left"};
 
 template <typename T>
 struct DevBuf {
@@ -52,7 +52,7 @@ struct ssfm_ba_handle {
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
-    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy;
+    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
     DevBuf<double> subZ, subD, subT, subF, subL, subW;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
@@ -86,7 +86,7 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); cam_pos2.free();
+        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
@@ -158,7 +158,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
-            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b, failp);
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
                 h->span_begin(KID_SUB_SPIKE);
@@ -174,17 +174,12 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
             }
             if (B.ntwist > 0) {
-                // twisted components: both segments left their Schur updates in the separator and in its copy; merge, factor + solve the
-                // separator as a component of b rows, hand its solution to the copy
-                h->span_begin(KID_TWIST);
-                hipLaunchKernelGGL((k_twist_merge<DC, 2>), dim3(B.ntwist, b), dim3(256), 0, st, h->band.p, Y, h->sub_tw_lo.p, h->sub_tw_copy.p, Nc, b);
-                h->span_end();
-                LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.ntwist, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, Nc, b, failp);
+                // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
+                // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
+                // reads that solution through seg_given
+                LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.ntwist, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.ntwist, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, Nc, b);
-                h->span_end();
-                h->span_begin(KID_TWIST);
-                hipLaunchKernelGGL((k_twist_copy<DC, 2>), dim3(B.ntwist), dim3(256), 0, st, Y, h->sub_tw_lo.p, h->sub_tw_copy.p, Nc, b);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.ntwist, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
             }
             if (B.nleft > 0) {
@@ -193,7 +188,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_end();
             }
             h->span_begin(KID_BAND_BACK);
-            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.nseg, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, Nc, b);
+            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.nseg, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_seg_given.p, Nc, b);
             h->span_end();
             return SSFM_OK;
         }
@@ -202,10 +197,10 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             if (lds_win > 48 * 1024) {
                 SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
             }
-            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nc, b);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);
                 h->span_end();
             } else {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
@@ -292,7 +287,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
             LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, Nb, b);
+                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nb, b);
                 h->span_end();
             } else {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);

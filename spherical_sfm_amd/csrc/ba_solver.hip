@@ -240,7 +240,7 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub);
     if (!h->sub.enabled) return SSFM_OK;
     const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
-    SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st));
+    SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_given, B.seg_given, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_lo, B.seg_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_hi, B.seg_hi, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));

@@ -68,8 +68,8 @@ constexpr int CHOL2_LOADERS = 2;
 template <int DC, int NR>
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
-               const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi, int N, int b,
-               int* __restrict__ fail_flag) {
+               const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
+               const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag) {
     constexpr int BB = DC * DC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int R = b + 1, W = b + 1, RW = W * BB;
@@ -89,9 +89,25 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
     if (r0 >= r1) return;
     for (int e = tid; e < b * (b + 1) / 2; e += nt) sPairs[e] = pairs[e];
+    // merge_from (twisted components, band_sub.h): this component is a separator of b rows whose second copy, rows mf..mf+b-1 in
+    // REVERSED order, holds the Schur update and the forward-substitution share of the reversed segment: block (s, s-d) takes the
+    // transpose of the copy's block (b-1-s+d, d).  The whole separator sits in the initial window (b < R), so merging is free here.
+    const int mf = merge_from ? merge_from[blockIdx.x] : -1;
     for (int row = r0; row < min(r0 + R, re); row++) {
-        for (int e = tid; e < RW; e += nt) sWin[(size_t)(row % R) * RW + e] = band[(size_t)row * RW + e];
-        for (int e = tid; e < NR * DC; e += nt) sYr[(size_t)(row % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
+        const int s = row - r0;
+        for (int e = tid; e < RW; e += nt) {
+            double v = band[(size_t)row * RW + e];
+            if (mf >= 0) {
+                const int d = e / BB, rc = e - d * BB, a = rc / DC, a2 = rc - a * DC;
+                if (d <= s) v += band[((size_t)(mf + b - 1 - s + d) * W + d) * BB + a2 * DC + a];
+            }
+            sWin[(size_t)(row % R) * RW + e] = v;
+        }
+        for (int e = tid; e < NR * DC; e += nt) {
+            double v = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
+            if (mf >= 0) v += Y[(size_t)(e / DC) * n + (size_t)(mf + b - 1 - s) * DC + (e % DC)];
+            sYr[(size_t)(row % R) * NR * DC + e] = v;
+        }
     }
     __syncthreads();
     if (wave == 0) {                                        // factor the first diagonal block
@@ -295,12 +311,15 @@ constexpr int BACK_PD = 4;
 template <int DC>
 __global__ void __launch_bounds__(64)
 k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
-               const int* __restrict__ piv_hi, const int* __restrict__ win_hi, int N, int b) {
+               const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b) {
     constexpr int BB = DC * DC;
     const int W = b + 1, n = N * DC, lane = threadIdx.x;
     // rows [r1, re) (the separator behind a segment, band_sub.h) already hold their solution: they only feed the pending sums
+    // given_from (reversed segment of a twisted component): its given rows are a reversed copy of the separator at rows gf..gf+b-1,
+    // row j of the copy = row gf + (re-1-j) of the separator proper, where the solution is
     const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
     if (r0 >= r1) return;
+    const int gf = given_from ? given_from[blockIdx.x] : -1;
     double* y = Y + (size_t)blockIdx.y * n;
     const int T = b * DC;
     const int t0 = min(lane, T - 1), t1 = min(lane + 64, T - 1);            // clamped: lanes without a task recompute a valid one and are masked
@@ -317,7 +336,8 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             s.col1[m] = band[(((size_t)jc) * W + d1) * BB + m * DC + a1];
             s.li[m] = Ginv[(size_t)jc * BB + m * DC + lc];                // G[m][lane], zero for m < lane
         }
-        s.yv = y[(size_t)jc * DC + lc];
+        const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
+        s.yv = y[(size_t)jy * DC + lc];
     };
 #pragma unroll
     for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);

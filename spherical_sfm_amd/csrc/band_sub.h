@@ -35,6 +35,7 @@ struct BandSub {
     // rows behind them; tw_lo / tw_hi = the separator as a small component of its own, tw_copy = first row of its second copy
     int ntwist = 0;
     std::vector<int> tw_lo, tw_hi, tw_copy;
+    std::vector<int> seg_given;                     // per segment: rows where the solution of its given rows really is (reversed segments), else -1
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
@@ -66,8 +67,8 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
         const int c0 = comp_ptr[c], rows = comp_ptr[c + 1] - c0;
         if (c < comp_twist.size() && comp_twist[c]) {                  // rows = n + b: seg_0 | sep | seg_1 reversed | copy of sep
             const int n = rows - b, m0 = (n - b) / 2, m1 = n - b - m0;
-            S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b);
-            S.seg_lo.push_back(c0 + m0 + b); S.seg_hi.push_back(c0 + m0 + b + m1); S.seg_wend.push_back(c0 + rows);
+            S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b); S.seg_given.push_back(-1);
+            S.seg_lo.push_back(c0 + m0 + b); S.seg_hi.push_back(c0 + m0 + b + m1); S.seg_wend.push_back(c0 + rows); S.seg_given.push_back(c0 + m0);
             S.tw_lo.push_back(c0 + m0); S.tw_hi.push_back(c0 + m0 + b); S.tw_copy.push_back(c0 + m0 + b + m1);
             S.enabled = true;
             continue;
@@ -80,7 +81,7 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
         for (int i = 0; i < P; i++) {
             const int m = m_total / P + (i < m_total % P ? 1 : 0);
             if (i > 0) S.left_segs.push_back((int)S.seg_lo.size());
-            S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + m); S.seg_wend.push_back(i + 1 < P ? pos + m + b : pos + m);
+            S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + m); S.seg_wend.push_back(i + 1 < P ? pos + m + b : pos + m); S.seg_given.push_back(-1);
             pos += m;
             if (i + 1 < P) { S.sep_lo.push_back(pos); S.sep_rseg.push_back((int)S.seg_lo.size()); pos += b; }
         }
@@ -455,33 +456,6 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
         __syncthreads();
     }
 #undef PK
-}
-
-// ---- twisted components: the separator is reduced from both sides --------------------------------------------------------------
-// k_twist_merge: the copy behind seg_1 (rows in REVERSED order) holds -(Schur update of seg_1) and seg_1's share of the forward
-// substitution; add both to the separator proper.  Block (s, s-d) of the separator = transpose of block (b-1-s+d, d) of the copy.
-template <int DC, int NR>
-__global__ void __launch_bounds__(256)
-k_twist_merge(double* __restrict__ band, double* __restrict__ Y, const int* __restrict__ tw_lo, const int* __restrict__ tw_copy, int N, int b) {
-    constexpr int BB = DC * DC;
-    const int W = b + 1, n = N * DC, x0 = tw_lo[blockIdx.x], y0 = tw_copy[blockIdx.x], s = blockIdx.y;
-    for (int e = threadIdx.x; e < (s + 1) * BB; e += blockDim.x) {
-        const int d = e / BB, rc = e - d * BB, a = rc / DC, a2 = rc - a * DC;
-        band[((size_t)(x0 + s) * W + d) * BB + a * DC + a2] += band[((size_t)(y0 + b - 1 - s + d) * W + d) * BB + a2 * DC + a];
-    }
-    if (threadIdx.x < NR * DC) {
-        const int r = threadIdx.x / DC, a = threadIdx.x - r * DC;
-        Y[(size_t)r * n + (size_t)(x0 + s) * DC + a] += Y[(size_t)r * n + (size_t)(y0 + b - 1 - s) * DC + a];
-    }
-}
-// k_twist_copy: the separator's solution into the rows of its copy (where seg_1's back substitution expects it)
-template <int DC, int NR>
-__global__ void k_twist_copy(double* __restrict__ Y, const int* __restrict__ tw_lo, const int* __restrict__ tw_copy, int N, int b) {
-    const int n = N * DC, x0 = tw_lo[blockIdx.x], y0 = tw_copy[blockIdx.x];
-    for (int e = threadIdx.x; e < NR * b * DC; e += blockDim.x) {
-        const int r = e / (b * DC), q = e - r * b * DC, s = q / DC, a = q - s * DC;
-        Y[(size_t)r * n + (size_t)(y0 + b - 1 - s) * DC + a] = Y[(size_t)r * n + (size_t)(x0 + s) * DC + a];
-    }
 }
 
 // ---- 5. y(seg) -= Z x(separator in front) ------------------------------------------------------------------------------------------
