@@ -50,6 +50,33 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Transposing wave reduction: every lane enters with N <= 64 values; lane L leaves with the wave-wide sum of value wave_tr_index()
+// = its six lane bits reversed (0 when that index is >= N).  Halving butterfly: at every step a lane keeps the even- or the
+// odd-indexed half of its values (by one lane bit), sends the other half to its partner and adds what it receives -- N/2 + N/4 + ...
+// < N exchanges instead of 6 N for N separate wave_sum calls.
+template <int N, int MASK>
+struct WaveTR {
+    static __device__ __forceinline__ double run(double (&v)[N]) {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (threadIdx.x & MASK) != 0;
+        double w[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const double lo = v[2 * j], hi = (2 * j + 1 < N) ? v[2 * j + 1] : 0.0;
+            const double mine = up ? hi : lo, send = up ? lo : hi;
+            w[j] = mine + __shfl_xor(send, MASK, 64);
+        }
+        return WaveTR<H, MASK / 2>::run(w);
+    }
+};
+template <int N>
+struct WaveTR<N, 0> { static __device__ __forceinline__ double run(double (&v)[N]) { static_assert(N == 1, "at most 64 values"); return v[0]; } };
+template <int N>
+__device__ __forceinline__ double wave_transpose_sum(double (&v)[N]) { return WaveTR<N, 32>::run(v); }
+__device__ __forceinline__ int wave_tr_index() {
+    const int l = threadIdx.x & 63;
+    return ((l >> 5) & 1) | (((l >> 4) & 1) << 1) | (((l >> 3) & 1) << 2) | (((l >> 2) & 1) << 3) | (((l >> 1) & 1) << 4) | ((l & 1) << 5);
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -371,19 +398,18 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
     }
 #undef CS2_LOAD
 #undef CS2_COMPUTE
-    // fold: value i ends up in lane i, which owns its destination(s)
-    double mine = 0.0;
-#pragma unroll
-    for (int i = 0; i < NSM; i++) { const double v = wave_sum(sm[i]); if (lane == i) mine = v; }
-    if (lane < NU) {
-        int a = 0, rem = lane; while (rem >= DC - a) { rem -= DC - a; a++; }
+    // fold: value i ends up in the lane with wave_tr_index() == i, which owns its destination(s)
+    const double mine = wave_transpose_sum(sm);
+    const int slot = wave_tr_index();
+    if (slot < NU) {
+        int a = 0, rem = slot; while (rem >= DC - a) { rem -= DC - a; a++; }
         const int b = a + rem;
         double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;
         unsafeAtomicAdd(&blk[a * DC + b], mine); if (b != a) unsafeAtomicAdd(&blk[b * DC + a], mine);
-    } else if (lane < NU + DC) { const int a = lane - NU; unsafeAtomicAdd(&rhs[c * DC + a], mine); unsafeAtomicAdd(&gcraw[c * DC + a], mine); }
-    else if (lane < NU + 2 * DC) unsafeAtomicAdd(&rhs[c * DC + lane - NU - DC], mine);
-    else if (lane < NU + 3 * DC) unsafeAtomicAdd(&Sfc[c * DC + lane - NU - 2 * DC], mine);
-    else if (lane < NSM) unsafeAtomicAdd(&Udiag[c * DC + lane - NU - 3 * DC], mine);
+    } else if (slot < NU + DC) { const int a = slot - NU; unsafeAtomicAdd(&rhs[c * DC + a], mine); unsafeAtomicAdd(&gcraw[c * DC + a], mine); }
+    else if (slot < NU + 2 * DC) unsafeAtomicAdd(&rhs[c * DC + slot - NU - DC], mine);
+    else if (slot < NU + 3 * DC) unsafeAtomicAdd(&Sfc[c * DC + slot - NU - 2 * DC], mine);
+    else if (slot < NSM) unsafeAtomicAdd(&Udiag[c * DC + slot - NU - 3 * DC], mine);
 }
 
 // ---- Schur complement from the slot-sorted pair lists, second generation ------------------------------------------
@@ -425,12 +451,16 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 #pragma unroll
         for (int b = 0; b < DC; b++) blk[a][b] = 0.0;
     int cur = -1;
-    auto fold = [&]() {                                    // wave-uniform: add the finished block to S
+    const int tr_slot = wave_tr_index();
+    auto fold = [&]() {                                    // wave-uniform: add the finished block to S (transposing reduction: element e lands in one lane)
         double* dst = S_val + ((size_t)rb + cur) * BB;
+        double flat[BB];
 #pragma unroll
         for (int a = 0; a < DC; a++)
 #pragma unroll
-            for (int b = 0; b < DC; b++) { const double v = wave_sum(blk[a][b]); if (lane == a * DC + b) unsafeAtomicAdd(&dst[a * DC + b], v); blk[a][b] = 0.0; }
+            for (int b = 0; b < DC; b++) { flat[a * DC + b] = blk[a][b]; blk[a][b] = 0.0; }
+        const double v = wave_transpose_sum(flat);
+        if (tr_slot < BB) unsafeAtomicAdd(&dst[tr_slot], v);
     };
 #define SP2_COMPUTE(bt_, X_, V_, o_, o2_, wgt_)                                                                       \
     do {                                                                                                              \
