@@ -311,7 +311,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
     lap("camera-major lists");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
-    int task_batches = 16;                                   // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
+    int task_batches = 8;                                    // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
     if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
     F.cam_batch_ptr.assign(Nc + 1, 0);
     {

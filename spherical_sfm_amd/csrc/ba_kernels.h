@@ -85,9 +85,10 @@ __device__ __forceinline__ double wave_max(double v) {
 // block-wide sum of N values per thread; result valid in thread 0.  red: LDS scratch [N * (blockDim/64)]
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* red) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int i = 0; i < N; i++) { v[i] = wave_sum(v[i]); if (lane == 0) red[i * nw + w] = v[i]; }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double t = wave_transpose_sum(v);                // value i of the wave in the lane with wave_tr_index() == i
+    const int slot = wave_tr_index();
+    if (slot < N) red[slot * nw + w] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
