@@ -874,8 +874,12 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         // the model cost change  -sum M_j.(r_j - M_j/2)  expands into sums that do not depend on z -- sum a.a, sum a.r, B^T a, B^T B --
         // so the second re-linearisation of every observation (after z is known) is not needed
         double Saa = 0.0, Sar = 0.0, Vr[6] = {0, 0, 0, 0, 0, 0};
+        // the camera index and pixel of observation j+1 are fetched while observation j is processed: one dependent round trip
+        // per observation (its camera tables) instead of two
+        int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
         for (int j = j0; j < j1; j++) {
-            const int c = obs_cam[j]; const double2 o = obs_xy[j];
+            const int c = c_nx; const double2 o = o_nx;
+            { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
             ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
             double Jc[2][DC]; cam_block<DC>(L, scale_cam + 6 * c, Jc);
             double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
@@ -909,7 +913,12 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         }
         // robustified cost at the candidate (cameras, focal, this point): what a separate k_point_cost launch did
         const double fcand = focal_c[0];
-        for (int j = j0; j < j1; j++) { const int c = obs_cam[j]; const double2 o = obs_xy[j]; acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la); }
+        c_nx = obs_cam[j0]; o_nx = obs_xy[j0];
+        for (int j = j0; j < j1; j++) {
+            const int c = c_nx; const double2 o = o_nx;
+            { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
+            acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la);
+        }
     }
     block_sum<4>(acc, red);
     if (threadIdx.x == 0) {
