@@ -150,6 +150,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         { int rc = enqueue_tail(); if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        SSFM_HIP_CHECK(ctx, hipGetLastError());                      // a launch that was refused (bad configuration) must not pass silently
         fold_host_scal();
         if (O.preconditioner == 0) {
             int fail_flag; std::memcpy(&fail_flag, &host_pcg1[PCG_TOTAL], sizeof(int));

@@ -14,7 +14,10 @@ def main():
     mode, out, spherical, focal_fixed = sys.argv[1], sys.argv[2], sys.argv[3] == "1", sys.argv[4] == "1"
     import torch
     from spherical_sfm_amd import ba, synth
-    prob = synth.make_circle(60, 6000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
+    if len(sys.argv) > 5 and sys.argv[5] == "weak2":        # the shape bench.py --gpus 2 runs: 2 x config 2's cameras, 8 rings of 75
+        prob = synth.make_circle(600, 24000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
+    else:
+        prob = synth.make_circle(60, 6000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
     ctx = ba.Context(0)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if mode == "host":

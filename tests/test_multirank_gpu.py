@@ -79,3 +79,16 @@ def test_sharded_pair_batch_is_bit_identical(gpu_ctx, tmp_path, mode, world):
     for r in res:
         assert np.array_equal(r["E"], ref["E"]) and np.array_equal(r["R"], ref["R"]) and np.array_equal(r["scores"], ref["scores"])
         assert np.array_equal(r["num_inliers"], ref["num_inliers"]) and np.array_equal(r["mask"], np.concatenate(ref["inliers"]))
+
+
+def test_weak_scaling_shape_two_ranks(gpu_ctx, tmp_path):
+    """The problem shape of `bench.py --gpus 2` (weak scaling: 600 cameras = 8 twisted rings of 75), two ranks sharing GPU 0."""
+    prob = synth.make_circle(600, 24000, 6, spherical=False, focal_fixed=True, seed=21)
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, prob)
+    assert s1["band_segments"] == 16 and s1["band_separators"] == 8
+    res = _run("host", 2, str(tmp_path / "w"), False, True, task="weak2")
+    for r in res:
+        assert int(r["iterations"]) == s1["iterations"] and int(r["termination"]) == s1["termination"]
+        assert np.abs(r["cams"] - c1).max() <= 1e-8 * np.abs(c1).max()
+        assert (np.linalg.norm(r["pts"] - p1, axis=1) / np.linalg.norm(p1, axis=1)).max() <= 1e-8
+    assert np.array_equal(res[0]["cams"], res[1]["cams"]) and np.array_equal(res[0]["pts"], res[1]["pts"])
