@@ -123,11 +123,11 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
 //   out: pos = elimination order (seg_0 | seg_1 reversed | sep), band_row / band_row2 / band_rows, comp_ptr in band rows
 // A component is twisted when both segments are longer than the band (n >= 3 b + 2) and it is not long enough to be cut into
 // several segments (band_sub.h, SUB_MIN_ROWS); the kernels involved need the LDS-resident factorisation (b <= 20).
-constexpr int BAND_CUT_MIN_ROWS = 256;
+constexpr int BAND_CUT_MIN_ROWS = 512;            // below: twisted (two workgroups, no spike); from here on: cut into a chain of segments (band_sub.h)
 inline void band_twist_plan(int Nc, int b, std::vector<int>& pos, std::vector<int>& comp_ptr, std::vector<int>& band_row,
-                            std::vector<int>& band_row2, std::vector<char>& comp_twist, int& band_rows) {
+                            std::vector<int>& band_row2, std::vector<char>& comp_twist, int& band_rows, int max_b = 20) {
     const char* env = std::getenv("SSFM_BAND_TWIST");
-    const bool allow = !(env && env[0] == '0') && b >= 1 && b <= 20;      // b <= 20: the 6-dof factorisation window fits the LDS
+    const bool allow = !(env && env[0] == '0') && b >= 1 && b <= max_b;   // 20: the 6-dof factorisation window fits the LDS (3-dof blocks: 40)
     const int ncomp = (int)comp_ptr.size() - 1;
     band_row.assign(Nc, -1); band_row2.assign(Nc, -1); comp_twist.assign(ncomp, 0);
     std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;      // Cuthill-McKee position -> camera

@@ -235,23 +235,6 @@ extern "C" void ssfm_ba_default_options(ssfm_ba_options* o) {
     o->verbose = 0;
 }
 
-// segment / separator tables of the substructured factorisation (band_sub.h) and its work buffers
-static int sub_upload(ssfm_ba_handle* h, int DC) {
-    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; const BAFlat& F = h->F;
-    sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub);
-    if (!h->sub.enabled) return SSFM_OK;
-    const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
-    SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_given, B.seg_given, st));
-    SSFM_HIP_CHECK(ctx, upload(h->sub_seg_lo, B.seg_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_hi, B.seg_hi, st));
-    SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
-    SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));
-    SSFM_HIP_CHECK(ctx, upload(h->sub_chain_ptr, B.chain_ptr, st));
-    if (B.nsep == 0) return SSFM_OK;                             // twisted components only: no spikes, no chain
-    SSFM_HIP_CHECK(ctx, h->subZ.alloc(Q * n)); SSFM_HIP_CHECK(ctx, h->subD.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subT.alloc((size_t)B.nsep * 2 * Q));
-    SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
-    return SSFM_OK;
-}
-
 // Test probe: the reduced-system factor + solve on a caller-supplied block band (band order, lower storage [N][b+1][dc*dc], block d
 // of row i = (i, i-d)) and two right-hand-side columns Y [2][N*dc] (in/out).  Optional dumps of the substructured intermediates.
 extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32_t b, int32_t ncomp, const int32_t* comp_ptr, const double* band,

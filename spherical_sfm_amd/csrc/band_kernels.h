@@ -47,8 +47,9 @@ __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __rest
     for (int idx = threadIdx.x; idx < nnb * BB; idx += blockDim.x) {
         const int s = rb + idx / BB, e = idx % BB;
         const int k = pos[col_idx[s]];
-        if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e];
-        else if (i2 >= 0) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
+        // S may hold both triangles (pose graphs): only blocks inside the band of this row / of the second row are taken
+        if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e]; }
+        else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
     }
 }
 // k_finalize_S + k_band_gather + k_band_permute_rhs in one launch for the BA path with the banded preconditioner (one workgroup per
@@ -83,8 +84,8 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
     for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
         const int sidx = rb + idx / BB, e = idx % BB;
         const int k = pos[col_idx[sidx]];
-        if (k <= i) row[(size_t)(i - k) * BB + e] = S_val[(size_t)sidx * BB + e];
-        else if (i2 >= 0) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)sidx * BB + e];
+        if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)sidx * BB + e]; }
+        else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)sidx * BB + e];
     }
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;

@@ -42,7 +42,7 @@ struct BandSub {
 // (0.13 b - 0.17), the spike (1.1) and the back substitution (0.43); per separator 150 (b dc / 114)^2.5 for the chain; 170 fixed for the
 // extra launches, the assembly and the memsets.  Segments must be at least b + 1 rows.  Components shorter than SUB_MIN_ROWS stay on
 // one workgroup (config 2's rings of 75: 135 us uncut against ~180 us cut in two).
-constexpr int SUB_MIN_ROWS = 256;
+constexpr int SUB_MIN_ROWS = 512;                  // = BAND_CUT_MIN_ROWS (ba_flatten.h): shorter components are twisted instead
 inline int sub_choose_segments(int rows, int b, int dc) {
     if (rows < SUB_MIN_ROWS) return 1;
     const double t_chol = std::max(0.13 * b - 0.17, 0.4), t_spike = 1.1, t_back = 0.43;
