@@ -275,11 +275,13 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
 #define ALV(buf, count) SSFM_HIP_CHECK(ctx, buf.alloc(count))
     ALV(xc, nn); ALV(sc3, nn); ALV(sc6, 6 * (size_t)n); ALV(scf, 1); ALV(step, nn + 1);
     const size_t n_red = nnzb * 9 + (nn + 1) + 3 * nn;
-    ALV(h->redbuf, n_red);
+    // [scalar block x replicas | solver flags | S | rhs | ...] in one allocation: one memset per assembly, one copy per iteration
+    ALV(h->zone, SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red);
+    h->scal.p = h->zone.p; h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.p = h->zone.p + SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
+    h->redbuf.p = h->pcg.p + PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
     h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * 9; h->Udiag = h->rhs + (nn + 1); h->Sfc = h->Udiag + nn; h->gcraw = h->Sfc + nn;
     ALV(h->Minv, (size_t)n * 9); ALV(h->Sff, 1); ALV(h->px, nn + 1); ALV(h->pr, nn + 1); ALV(h->pz, nn + 1); ALV(h->pp, nn + 1); ALV(h->pq, nn + 1);
-    ALV(h->pqpart, (size_t)n); ALV(h->scal, SC_NSLOT * SC_TOTAL); ALV(h->pcg, PCG_TOTAL + 1);
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_NSLOT * SC_TOTAL * sizeof(double), st));    // this solver only ever writes replica 0 (k_finalize_S folds all of them)
+    ALV(h->pqpart, (size_t)n);
     { const size_t Nb = (size_t)F.band_rows;
       ALV(h->band, Nb * (F.band + 1) * 9); ALV(h->Linv, Nb * 9); ALV(h->Yb, 2 * 3 * Nb); ALV(h->Yr, 2 * 3 * Nb); }
     { const int rc = sub_upload(h, 3); if (rc) return rc; }
@@ -287,10 +289,10 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
     const int ge = (E + 63) / 64, gn = (n + 63) / 64;
     const double la = O.loss_scale;
-    double host_scal[SC_TOTAL], host_pcg[PCG_TOTAL + 1];
+    if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
+    double* host_scal = h->host_sp; double* host_pcg = h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
     auto assemble = [&](const double* s3, const double* sf) -> int {
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->redbuf.p, 0, n_red * sizeof(double), st));
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
         hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
                            (const double*)nullptr, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
         return SSFM_OK;
@@ -329,8 +331,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
             hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
                                step.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
             hipLaunchKernelGGL(k_rot_cost, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xcand, fmc, h->scal.p + SC_CAND_COST);
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-            if (O.preconditioner == 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_pcg, h->pcg.p, (PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             return SSFM_OK;
         };
