@@ -56,7 +56,13 @@ struct BAFlat {
     // (the copy receives the Schur update from seg_1), so the band has band_rows >= Nc rows.
     std::vector<int> band_row, band_row2;   // [Nc] camera -> band row; second row of a separator camera of a twisted component, else -1
     std::vector<char> comp_twist;       // [components] 1 = twisted
-    int band_rows = 0;
+    int band_rows = 0;                  // rows of the band in units of its blocks (band_block x band_block)
+    // Block merging (band_plan): with 3-dof camera blocks the factorisation is pure per-step latency, so two consecutive cameras of the
+    // elimination order share one 6x6 block row of the band: half the dependent steps.  band_row / band_row2 stay in CAMERA rows
+    // (camera c sits in block row band_row[c] / 2, upper or lower half by parity); band, comp_ptr, band_rows are in block rows.
+    int band_block = 0;                 // size of the band's blocks: DC, or 6 when DC = 3 and pairs are merged
+    std::vector<unsigned char> pair_dummy;   // [Nc] 1 = this (even) camera's partner slot is empty (odd-sized component)
+    int y_rows(int dc) const { return band_rows * (band_block > 0 ? band_block : dc) / dc; }   // rows of the right-hand sides in camera units
     // The stored structure (row_ptr/col_idx) is the LOWER triangle in elimination order: row c holds block (c, c2) iff
     // cam_pos[c2] <= cam_pos[c].  trans_* lists, for every camera c, the stored blocks of OTHER rows whose column is c
     // (the upper triangle by symmetry) for the symmetric mat-vec.
@@ -151,6 +157,51 @@ inline void band_twist_plan(int Nc, int b, std::vector<int>& pos, std::vector<in
     comp_ptr.swap(new_ptr); band_rows = base;
 }
 
+// Elimination order + band layout of the reduced camera system: Cuthill-McKee, then (3-dof blocks) merging of consecutive cameras into
+// 6x6 block rows, then the twisted layout of medium components (band_twist_plan), in block rows.
+//   out: pos (elimination order, a permutation), band (half-width in blocks), comp_ptr / band_rows (block rows), band_row / band_row2
+//        (camera rows), comp_twist, band_block, pair_dummy
+inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos, int& band,
+                      std::vector<int>& comp_ptr, std::vector<int>& band_row, std::vector<int>& band_row2, std::vector<char>& comp_twist,
+                      int& band_rows, int& band_block, std::vector<unsigned char>& pair_dummy) {
+    band = cuthill_mckee(Nc, row_ptr, col_idx, pos, &comp_ptr);
+    pair_dummy.assign(Nc, 0);
+    const char* env = std::getenv("SSFM_BAND_MERGE");
+    const bool merge = dc == 3 && !(env && env[0] == '0');
+    if (!merge) {
+        band_block = dc;
+        band_twist_plan(Nc, band, pos, comp_ptr, band_row, band_row2, comp_twist, band_rows, dc == 3 ? 40 : 20);
+        return;
+    }
+    // ---- super nodes = pairs of consecutive Cuthill-McKee positions inside a component
+    const int ncomp = (int)comp_ptr.size() - 1;
+    std::vector<int> sup(Nc), par(Nc), sup_ptr(1, 0);
+    {
+        std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;
+        for (int k = 0; k < ncomp; k++) {
+            const int c0 = comp_ptr[k], n = comp_ptr[k + 1] - c0, s0 = sup_ptr.back();
+            for (int i = 0; i < n; i++) { const int c = inv[c0 + i]; sup[c] = s0 + i / 2; par[c] = i & 1; }
+            if (n & 1) pair_dummy[inv[c0 + n - 1]] = 1;
+            sup_ptr.push_back(s0 + (n + 1) / 2);
+        }
+    }
+    const int ns = sup_ptr.back();
+    int bs = 0;
+    for (int u = 0; u < Nc; u++) for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) bs = std::max(bs, std::abs(sup[u] - sup[col_idx[e]]));
+    bs = std::max(bs, 1);
+    std::vector<int> spos(ns), srow, srow2;
+    for (int i = 0; i < ns; i++) spos[i] = i;
+    band_twist_plan(ns, bs, spos, sup_ptr, srow, srow2, comp_twist, band_rows, 20);
+    // cameras: elimination key 2 * spos + parity, compressed to a permutation
+    std::vector<int> key(Nc), order(Nc);
+    for (int c = 0; c < Nc; c++) { key[c] = 2 * spos[sup[c]] + par[c]; order[c] = c; }
+    std::sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
+    for (int r = 0; r < Nc; r++) pos[order[r]] = r;
+    band_row.assign(Nc, -1); band_row2.assign(Nc, -1);
+    for (int c = 0; c < Nc; c++) { band_row[c] = 2 * srow[sup[c]] + par[c]; if (srow2[sup[c]] >= 0) band_row2[c] = 2 * srow2[sup[c]] + par[c]; }
+    band = bs; comp_ptr.swap(sup_ptr); band_block = 6;
+}
+
 inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
     const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -230,8 +281,12 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         }
     }
     lap("S structure");
-    F.band = cuthill_mckee(Nc, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
-    band_twist_plan(Nc, F.band, F.cam_pos, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows);
+    {   // camera block size first: it decides whether pairs of cameras are merged in the band
+        bool all_t_fixed = true;
+        for (int c = 0; c < Nc; c++) if (cam_in[c] && !(P.trans_fixed && P.trans_fixed[c])) { all_t_fixed = false; break; }
+        F.DC = all_t_fixed ? 3 : 6;
+    }
+    band_plan(Nc, F.DC, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     {   // keep the lower triangle (in elimination order) only
         std::vector<int> rp(Nc + 1, 0), ci; ci.reserve(F.col_idx.size() / 2 + Nc);

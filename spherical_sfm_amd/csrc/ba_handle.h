@@ -53,6 +53,7 @@ struct ssfm_ba_handle {
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
     BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
+    DevBuf<unsigned char> pair_dummy;    // merged 3-dof pairs: 1 = the partner slot of this camera is empty
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
     DevBuf<double> subZ, subD, subT, subF, subL, subW;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
@@ -86,7 +87,7 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
         band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free();
+        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
@@ -135,6 +136,7 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
 // segment / separator tables of the substructured factorisation (band_sub.h) and its work buffers
 static int sub_upload(ssfm_ba_handle* h, int DC) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; const BAFlat& F = h->F;
+    if (F.band_block > 0) DC = F.band_block;                     // block size of the band (merged 3-dof pairs: 6)
     sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub);
     if (!h->sub.enabled) return SSFM_OK;
     const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
@@ -229,6 +231,38 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
         return SSFM_OK;
     }
 
+// Second solve with the factor of band_direct (PCG refinement): forward + back substitution of the first column of Y with the stored
+// factor.  needs_refactor is set when the plan is substructured (no stand-alone substitution kernels: the caller rebuilds the band
+// and calls band_direct again).
+template <int DC>
+static int band_resolve(ssfm_ba_handle* h, double* Y, bool* needs_refactor) {
+    hipStream_t st = h->ctx->stream;
+    const BAFlat& F = h->F;
+    const int Nb = F.band_rows > 0 ? F.band_rows : F.Nc, b = F.band;
+    constexpr int BB = DC * DC;
+    const int ncomp = (int)F.comp_ptr.size() - 1;
+    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
+    const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
+    const bool back_v2 = use_lds && b * DC <= 128;
+    const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
+    *needs_refactor = h->sub.enabled && use_lds && back_v2;
+    if (*needs_refactor) return SSFM_OK;
+    if (use_lds) {
+        LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nb, b);
+        if (back_v2) {
+            h->span_begin(KID_BAND_BACK);
+            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nb, b);
+            h->span_end();
+        } else {
+            LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nb, b);
+        }
+    } else {
+        LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, Y, Nb, b);
+        LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, Y, Nb, b);
+    }
+    return SSFM_OK;
+}
+
 // Solve S y = rhs (block-CSR S with dense focal border) into h->px.
 //   preconditioner 0: exact block-banded Cholesky in Cuthill-McKee order, then PCG refinement on the residual
 //   preconditioner 1: block-Jacobi PCG (kept for comparison; needs ~10^3 iterations on a camera ring)
@@ -240,7 +274,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
     const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
     const int Nc = F.Nc, n = Nc * DC, b = F.band;
-    const int Nb = F.band_rows > 0 ? F.band_rows : Nc, nb = Nb * DC;       // rows of the band / stride of the right-hand-side columns in band order
+    const int Nb = F.band_rows > 0 ? F.y_rows(DC) : Nc, nb = Nb * DC;      // rows (camera units) / stride of the right-hand-side columns in band order
     constexpr int BB = DC * DC;
     const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
     if (O.preconditioner == 1) {
@@ -264,21 +298,21 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         *ok_out = done && host_pcg[PCG_BREAKDOWN] == 0.0;
         return SSFM_OK;
     }
-    const int ncomp = (int)F.comp_ptr.size() - 1;
-    // LDS-resident factorisation (band_kernels2.h): window ring + panel + right-hand-side rows + scratch + pair table
-    const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
-    const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
-    const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
-    const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
-    const bool sub_on = h->sub.enabled && use_lds && back_v2;
+    // the band may use bigger blocks than S (two 3-dof cameras per 6x6 block row, ba_flatten.h: band_plan)
+    const bool merged = F.band_block > 0 && F.band_block != DC;
+    auto gather = [&]() {
+        if (merged) LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, b, h->band.p);
+        else LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, (const unsigned char*)nullptr, Nc, b, h->band.p);
+    };
+    auto direct = [&](double* Y) -> int { return merged ? band_direct<6>(h, Y) : band_direct<DC>(h, Y); };
     if (stage == 0) {
     if (!h->zone_views) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st));      // flags + the factorisation fail word behind them
     if (!h->band_filled) {                                       // the BA path fills the band in its fused finalize kernel
-        LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, Nc, b, h->band.p);
-        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, h->cam_pos2.p, Nc, Nb, h->Yb.p);
+        gather();
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, Nb, h->Yb.p);
     }
     h->band_filled = false;
-    { const int rc = band_direct<DC>(h, h->Yb.p); if (rc) return rc; }
+    { const int rc = direct(h->Yb.p); if (rc) return rc; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
     if (F.sym_lower) {
         LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
@@ -295,23 +329,13 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     { int fail_flag; std::memcpy(&fail_flag, &host_pcg[PCG_TOTAL], sizeof(int));
       if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
     while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
-        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, h->cam_pos2.p, Nc, Nb, h->Yr.p);
-        if (sub_on) {
+        hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, Nb, h->Yr.p);
+        bool refactor = false;
+        { const int rc = merged ? band_resolve<6>(h, h->Yr.p, &refactor) : band_resolve<DC>(h, h->Yr.p, &refactor); if (rc) return rc; }
+        if (refactor) {
             // the substructured factor has no stand-alone substitution kernels: rebuild the band from S and solve again (rare path)
-            LAUNCH(h, KID_BAND_GATHER, k_band_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, Nc, b, h->band.p);
-            const int rc = band_direct<DC>(h, h->Yr.p); if (rc) return rc;
-        } else if (use_lds) {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);
-            if (back_v2) {
-                h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nb, b);
-                h->span_end();
-            } else {
-                LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, h->comp_ptr.p, Nb, b);
-            }
-        } else {
-            LAUNCH(h, KID_BAND_FWD, (k_band_fwd<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nb, b);
-            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 1>), 1, 256, lds_sub1, h->band.p, h->Linv.p, h->Yr.p, Nb, b);
+            gather();
+            const int rc = direct(h->Yr.p); if (rc) return rc;
         }
         LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yr.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->pr.p + n, h->cam_pos.p, Nc, h->pz.p);
         LAUNCH(h, KID_REF_VEC, k_ref_direction, 1, 1024, 0, h->pr.p, h->pz.p, n + 1, it == 0 ? 1 : 0, h->pp.p, h->pcg.p);

@@ -120,8 +120,12 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             hipLaunchKernelGGL(k_scal_unpack, dim3(1), dim3(64), 0, st, h->scal.p, h->red_scal, ctx->nranks);
         }
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
-            LAUNCH(h, KID_FINALIZE, k_finalize_gather<DC>, Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                   radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, F.band_rows, F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+            if (F.band_block != DC)      // 3-dof cameras merged in pairs into 6x6 block rows of the band
+                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+            else
+                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -245,7 +249,7 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
     ssfm_ba_handle hh; ssfm_ba_handle* h = &hh;
     h->ctx = ctx; ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
-    BAFlat& F = h->F; F.Nc = N; F.band_rows = N; F.band = b; F.DC = dc; F.comp_ptr.assign(comp_ptr, comp_ptr + ncomp + 1);
+    BAFlat& F = h->F; F.Nc = N; F.band_rows = N; F.band_block = dc; F.band = b; F.DC = dc; F.comp_ptr.assign(comp_ptr, comp_ptr + ncomp + 1);
     for (int ir = 1; ir <= b; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     const size_t nb = (size_t)N * (b + 1) * dc * dc, n = (size_t)N * dc;
     int rc = SSFM_OK;
@@ -287,7 +291,7 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     info->camera_dof = F.DC; info->num_points_used = F.nP; info->num_points_used_global = F.nP_global;
     info->reduced_blocks = F.row_ptr[F.Nc]; info->band_half_width = F.band; info->max_row_blocks = F.max_row_blocks;
     info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
-    { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.DC, B);
+    { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.band_block, B);
       info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep + B.ntwist; }
     if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];
     if (obs_used) for (int64_t j = 0; j < F.M; j++) obs_used[F.obs_orig[j]] = 1;
@@ -335,10 +339,13 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
-    const size_t Nb = (size_t)F.band_rows, nbr = Nb * DC;         // band rows >= cameras (twisted components carry a second copy of their separator)
-    AL(band, Nb * (F.band + 1) * DC * DC); AL(Linv, Nb * DC * DC); AL(Yb, 2 * nbr); AL(Yr, 2 * nbr); AL(band_fail, 1);
+    // band: F.band_rows block rows of F.band_block x F.band_block blocks (>= cameras: twisted components carry a second copy of their
+    // separator; 3-dof cameras are merged in pairs); right-hand sides in camera rows
+    const size_t Nb = (size_t)F.band_rows, DCB = (size_t)F.band_block, nbr = (size_t)F.y_rows(DC) * DC;
+    AL(band, Nb * (F.band + 1) * DCB * DCB); AL(Linv, Nb * DCB * DCB); AL(Yb, 2 * nbr); AL(Yr, 2 * nbr); AL(band_fail, 1);
 #undef AL
     SSFM_HIP_CHECK(ctx, upload(h->cam_pos, F.band_row, st)); SSFM_HIP_CHECK(ctx, upload(h->cam_pos2, F.band_row2, st));   // the device only needs band rows
+    SSFM_HIP_CHECK(ctx, upload(h->pair_dummy, F.pair_dummy, st));
     SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)

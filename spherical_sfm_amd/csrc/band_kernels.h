@@ -31,41 +31,79 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
     return y;
 }
 
-// S (block-CSR, camera order) -> band storage (permuted), right-hand sides permuted alongside
-template <int DC>
-__global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
-                              const int* __restrict__ pos, const int* __restrict__ pos2, int Nc, int b, double* __restrict__ band) {
+// Band row(s) of camera c from its row of S.  The workgroup owns band row i = pos[c] (its blocks all come from S row c): clear it,
+// then scatter.  A separator camera of a twisted component owns a second row i2 behind the reversed segment: blocks whose column
+// lies there go to that row.  S may hold both triangles (pose graphs): only blocks inside the band of a row are taken.
+// MERGE (DC = 3): two consecutive camera rows share one 6x6 block row R = i >> 1 (upper / lower half u = i & 1); the camera owns its
+// three scalar rows of every block of R, except that the off-diagonal 3x3 parts of the DIAGONAL block both belong to the lower
+// camera (it mirrors its (1,0) part into (0,1)); an even camera without partner (pair_dummy) also owns the partner's rows: identity.
+template <int DC, bool MERGE>
+__device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+                                               const int* __restrict__ pos, int i, int i2, int c, int b, bool dummy, double* __restrict__ band) {
     constexpr int BB = DC * DC;
-    const int c = blockIdx.x;
-    const int i = pos[c], i2 = pos2 ? pos2[c] : -1, rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    // the workgroup owns band row i (its blocks all come from S row c): clear it, then scatter.  A separator camera of a twisted
-    // component owns a second row i2 behind the reversed segment: blocks whose column lies there go to that row (pos = band rows).
-    double* row = band + (size_t)i * (b + 1) * BB;
-    double* row2 = band + (size_t)max(i2, 0) * (b + 1) * BB;
-    for (int e = threadIdx.x; e < (b + 1) * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < nnb * BB; idx += blockDim.x) {
-        const int s = rb + idx / BB, e = idx % BB;
-        const int k = pos[col_idx[s]];
-        // S may hold both triangles (pose graphs): only blocks inside the band of this row / of the second row are taken
-        if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e]; }
-        else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
+    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tid = threadIdx.x, W = b + 1;
+    if (!MERGE) {
+        double* row = band + (size_t)i * W * BB;
+        double* row2 = band + (size_t)max(i2, 0) * W * BB;
+        for (int e = tid; e < W * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
+        __syncthreads();
+        for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
+            const int s = rb + idx / BB, e = idx % BB;
+            const int k = pos[col_idx[s]];
+            if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e]; }
+            else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
+        }
+    } else {
+        constexpr int BM = 4 * BB, D2 = 2 * DC;                    // 6x6 blocks of 3x3 parts
+        const int R = i >> 1, u = i & 1, R2 = max(i2, 0) >> 1, u2 = max(i2, 0) & 1;
+        double* row = band + (size_t)R * W * BM;
+        double* row2 = band + (size_t)R2 * W * BM;
+        for (int e = tid; e < W * DC * D2; e += blockDim.x) {      // this camera's DC rows of every block
+            const int d = e / (DC * D2), q = e - d * (DC * D2), r = q / D2, col = q - r * D2;
+            if (!(d == 0 && u == 0 && col >= DC && !dummy)) row[(size_t)d * BM + (u * DC + r) * D2 + col] = 0.0;
+            if (i2 >= 0 && !(d == 0 && u2 == 0 && col >= DC)) row2[(size_t)d * BM + (u2 * DC + r) * D2 + col] = 0.0;
+            if (dummy) row[(size_t)d * BM + (DC + r) * D2 + col] = (d == 0 && col == DC + r) ? 1.0 : 0.0;       // the empty partner slot: identity
+        }
+        if (tid < BB) {                                            // part (0,1) of the diagonal block belongs to the lower camera
+            const int r = tid / DC, col = tid - r * DC;
+            if (u == 1) row[r * D2 + DC + col] = 0.0;
+            if (i2 >= 0 && u2 == 1) row2[r * D2 + DC + col] = 0.0;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
+            const int s = rb + idx / BB, e = idx % BB, a = e / DC, a2 = e - a * DC;
+            const int k = pos[col_idx[s]], C = k >> 1, v = k & 1;
+            const double val = S_val[(size_t)s * BB + e];
+            if (C < R) { if (R - C <= b) row[(size_t)(R - C) * BM + (u * DC + a) * D2 + v * DC + a2] = val; }
+            else if (C == R) { if (v <= u) { row[(u * DC + a) * D2 + v * DC + a2] = val; if (v < u) row[(v * DC + a2) * D2 + u * DC + a] = val; } }
+            else if (i2 >= 0 && R2 > C && R2 - C <= b) row2[(size_t)(R2 - C) * BM + (u2 * DC + a) * D2 + v * DC + a2] = val;
+        }
     }
+}
+
+// S (block-CSR, camera order) -> band storage (permuted)
+template <int DC, bool MERGE>
+__global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+                              const int* __restrict__ pos, const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nc, int b,
+                              double* __restrict__ band) {
+    const int c = blockIdx.x;
+    band_rows_fill<DC, MERGE>(row_ptr, col_idx, S_val, pos, pos[c], pos2 ? pos2[c] : -1, c, b, pair_dummy && pair_dummy[c], band);
 }
 // k_finalize_S + k_band_gather + k_band_permute_rhs in one launch for the BA path with the banded preconditioner (one workgroup per
 // camera, which owns its diagonal block, its band row and its slice of the right-hand sides): LM diagonal on the diagonal block
 // (in S_val too: the residual check multiplies by S), gradient max-norm, band row, permuted [rhs | S_fc]; workgroup 0 also folds the
 // focal sums and writes the focal row.  The block-Jacobi inverse of k_finalize_S is only needed by preconditioner 1 and is not built here.
-template <int DC>
+template <int DC, bool MERGE>
 __global__ void __launch_bounds__(256)
 k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ diag_slot,
                   const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ Udiag,
                   const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,
-                  const int* __restrict__ pos2, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs, const double* __restrict__ Sfc, double* __restrict__ Sff,
+                  const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs,
+                  const double* __restrict__ Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int i = pos[c], i2 = pos2[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;     // pos / pos2: band rows (second row: twisted separators)
+    const int i = pos[c], i2 = pos2[c], rb = row_ptr[c];     // pos / pos2: band rows in camera units (second row: twisted separators)
     double gmax = 0.0;
     if (tid < DC) {
         double* blk = S_val + ((size_t)rb + diag_slot[c]) * BB;
@@ -75,18 +113,11 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
         Y[(size_t)i * DC + tid] = rhs[c * DC + tid];
         Y[(size_t)Nb * DC + (size_t)i * DC + tid] = Sfc[c * DC + tid];
         if (i2 >= 0) { Y[(size_t)i2 * DC + tid] = 0.0; Y[(size_t)Nb * DC + (size_t)i2 * DC + tid] = 0.0; }
+        if (MERGE && pair_dummy[c]) { Y[(size_t)(i + 1) * DC + tid] = 0.0; Y[(size_t)Nb * DC + (size_t)(i + 1) * DC + tid] = 0.0; }
     }
     if (tid < 64) { gmax = wave_max(gmax); if (tid == 0 && gmax > 0.0) atomic_max_nonneg(&scal[(size_t)(c & (SC_NSLOT - 1)) * SC_TOTAL + SC_GMAX], gmax); }
-    double* row = band + (size_t)i * (b + 1) * BB;
-    double* row2 = band + (size_t)max(i2, 0) * (b + 1) * BB;
-    for (int e = tid; e < (b + 1) * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
-    __syncthreads();                                               // damped diagonal block and cleared row visible to the whole workgroup
-    for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
-        const int sidx = rb + idx / BB, e = idx % BB;
-        const int k = pos[col_idx[sidx]];
-        if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)sidx * BB + e]; }
-        else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)sidx * BB + e];
-    }
+    __syncthreads();                                               // damped diagonal block visible to the whole workgroup
+    band_rows_fill<DC, MERGE>(row_ptr, col_idx, S_val, pos, i, i2, c, b, MERGE && pair_dummy[c], band);
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;
         const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;
@@ -104,7 +135,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
 
 template <int DC>
 __global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double* __restrict__ Sfc, const int* __restrict__ pos,
-                                   const int* __restrict__ pos2, int Nc, int Nb, double* __restrict__ Y) {
+                                   const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nc, int Nb, double* __restrict__ Y) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Nc * DC) return;
     const int c = t / DC, a = t - c * DC;
@@ -112,6 +143,7 @@ __global__ void k_band_permute_rhs(const double* __restrict__ rhs, const double*
     Y[(size_t)Nb * DC + pos[c] * DC + a] = Sfc[t];
     const int i2 = pos2 ? pos2[c] : -1;
     if (i2 >= 0) { Y[i2 * DC + a] = 0.0; Y[(size_t)Nb * DC + i2 * DC + a] = 0.0; }
+    if (pair_dummy && pair_dummy[c]) { Y[(pos[c] + 1) * DC + a] = 0.0; Y[(size_t)Nb * DC + (pos[c] + 1) * DC + a] = 0.0; }   // empty partner slot of a merged pair
 }
 
 // Factorise in place (lower), store inverse diagonal factors, forward-substitute NR right-hand sides Y[r][N*DC].

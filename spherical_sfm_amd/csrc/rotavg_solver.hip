@@ -258,8 +258,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         F.col_idx.resize(F.row_ptr[n]);
         for (int i = 0; i < n; i++) { std::copy(nb[i].begin(), nb[i].end(), F.col_idx.begin() + F.row_ptr[i]);
                                       F.diag_slot[i] = (int)(std::lower_bound(nb[i].begin(), nb[i].end(), i) - nb[i].begin()); }
-        F.band = cuthill_mckee(n, F.row_ptr, F.col_idx, F.cam_pos, &F.comp_ptr);
-        band_twist_plan(n, F.band, F.cam_pos, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, 40);    // rings of a video pose graph: two-sided elimination
+        // Cuthill-McKee, pairs of nodes merged into 6x6 block rows, rings of a video pose graph eliminated from both ends
+        band_plan(n, 3, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy);
         for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     }
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
@@ -269,7 +269,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     std::vector<double> fmv = {1.0, 1.0};
 #define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
     UPV(x, G.x0); UPV(fm2, fmv); UPV(e0, G.e0); UPV(e1, G.e1); UPV(ec, G.ec);
-    UPV(h->row_ptr, F.row_ptr); UPV(h->col_idx, F.col_idx); UPV(h->diag_slot, F.diag_slot); UPV(h->cam_pos, F.band_row); UPV(h->cam_pos2, F.band_row2);   // the device only needs band rows
+    UPV(h->row_ptr, F.row_ptr); UPV(h->col_idx, F.col_idx); UPV(h->diag_slot, F.diag_slot); UPV(h->cam_pos, F.band_row); UPV(h->cam_pos2, F.band_row2); UPV(h->pair_dummy, F.pair_dummy);   // the device only needs band rows
     UPV(h->band_pairs, F.band_pairs); UPV(h->comp_ptr, F.comp_ptr);
 #undef UPV
 #define ALV(buf, count) SSFM_HIP_CHECK(ctx, buf.alloc(count))
@@ -282,8 +282,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * 9; h->Udiag = h->rhs + (nn + 1); h->Sfc = h->Udiag + nn; h->gcraw = h->Sfc + nn;
     ALV(h->Minv, (size_t)n * 9); ALV(h->Sff, 1); ALV(h->px, nn + 1); ALV(h->pr, nn + 1); ALV(h->pz, nn + 1); ALV(h->pp, nn + 1); ALV(h->pq, nn + 1);
     ALV(h->pqpart, (size_t)n);
-    { const size_t Nb = (size_t)F.band_rows;
-      ALV(h->band, Nb * (F.band + 1) * 9); ALV(h->Linv, Nb * 9); ALV(h->Yb, 2 * 3 * Nb); ALV(h->Yr, 2 * 3 * Nb); }
+    { const size_t Nb = (size_t)F.band_rows, DCB = (size_t)F.band_block, ny = (size_t)F.y_rows(3) * 3;
+      ALV(h->band, Nb * (F.band + 1) * DCB * DCB); ALV(h->Linv, Nb * DCB * DCB); ALV(h->Yb, 2 * ny); ALV(h->Yr, 2 * ny); }
     { const int rc = sub_upload(h, 3); if (rc) return rc; }
 #undef ALV
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;

@@ -97,7 +97,7 @@ def test_sharding_partitions_the_used_points(nranks):
 
 
 def test_elimination_order_is_a_banded_permutation(monkeypatch):
-    p = synth.make_circle(60, 600, 6)
+    p = synth.make_circle(60, 600, 6, spherical=False)           # 6-dof camera blocks: band rows = cameras
     cams = p.obs_cam.reshape(-1, 6)
     monkeypatch.setenv("SSFM_BAND_TWIST", "0")                    # plain Cuthill-McKee order
     info, ids, used, pos = ba.plan(p)
@@ -124,6 +124,25 @@ def test_elimination_order_is_a_banded_permutation(monkeypatch):
     assert np.array_equal(pos2[pos < m0], pos[pos < m0])
     tail = pos >= m0 + b                                              # seg_1 = the last m1 positions, reversed
     assert np.array_equal(pos2[tail], m0 + (m1 - 1 - (pos[tail] - m0 - b)))
+
+
+def test_three_dof_cameras_are_merged_in_pairs(monkeypatch):
+    """Spherical BA (3-dof camera blocks): two consecutive cameras of the Cuthill-McKee order share one 6x6 block row of the band
+    (csrc/ba_flatten.h: band_plan), so the band is half as long and about half as wide in blocks."""
+    p = synth.make_circle(61, 610, 6)                             # odd: the last pair has an empty slot
+    cams = p.obs_cam.reshape(-1, 6)
+    monkeypatch.setenv("SSFM_BAND_MERGE", "0"); monkeypatch.setenv("SSFM_BAND_TWIST", "0")
+    plain, _, _, pos0 = ba.plan(p)
+    monkeypatch.delenv("SSFM_BAND_MERGE")
+    merged, _, _, pos1 = ba.plan(p)
+    assert plain["camera_dof"] == merged["camera_dof"] == 3
+    assert sorted(pos1.tolist()) == list(range(61)) and np.array_equal(pos0, pos1)         # same order, paired up
+    assert merged["band_half_width"] == (plain["band_half_width"] + 1) // 2
+    d = np.abs(pos1[cams][:, :, None] // 2 - pos1[cams][:, None, :] // 2).max()
+    assert d == merged["band_half_width"]
+    monkeypatch.delenv("SSFM_BAND_TWIST")
+    tw, _, _, pos2 = ba.plan(p)
+    assert (tw["band_segments"], tw["band_separators"]) == (2, 1) and sorted(pos2.tolist()) == list(range(61))
 
 
 def test_config2_plan():
