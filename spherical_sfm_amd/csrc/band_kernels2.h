@@ -159,12 +159,13 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             if (j + 1 < r1) {
                 int s1 = jm + 1; if (s1 >= R) s1 -= R;
                 const double* dblk = sWin + (size_t)s1 * RW;                        // block (j+1, j+1)
-                if (lane < BB) {
-                    const int a = lane / DC, c = lane - a * DC;
-                    double v = dblk[lane];
+#pragma unroll
+                for (int e = lane; e < BB; e += 64) {                               // one pass for DC <= 8
+                    const int a = e / DC, c = e - a * DC;
+                    double v = dblk[e];
 #pragma unroll
                     for (int m = 0; m < DC; m++) v -= sP[a * DC + m] * sP[c * DC + m];
-                    sD[lane] = v;
+                    sD[e] = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // wave-local LDS round trip
                 double row[DC], g[DC];
@@ -179,12 +180,13 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                 // last pivot of a segment: row j+1 is the first separator row, its diagonal block takes the update in place
                 int s1 = jm + 1; if (s1 >= R) s1 -= R;
                 double* dblk = sWin + (size_t)s1 * RW;
-                if (lane < BB) {
-                    const int a = lane / DC, c = lane - a * DC;
-                    double v = dblk[lane];
+#pragma unroll
+                for (int e = lane; e < BB; e += 64) {
+                    const int a = e / DC, c = e - a * DC;
+                    double v = dblk[e];
 #pragma unroll
                     for (int m = 0; m < DC; m++) v -= sP[a * DC + m] * sP[c * DC + m];
-                    dblk[lane] = v;
+                    dblk[e] = v;
                 }
             }
             lds_barrier();
@@ -285,7 +287,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
-            if (lane < BB) Ginv[(size_t)j * BB + lane] = sG[lane];                   // before wave 0 replaces it
+            for (int e = lane; e < BB; e += 64) Ginv[(size_t)j * BB + e] = sG[e];    // before wave 0 replaces it
             lds_barrier();
             for (int e = lane; e < nb * BB; e += 64) { const int k = e / BB; band[((size_t)(j + 1 + k) * W + (k + 1)) * BB + (e - k * BB)] = sP[e]; }
             if (lane < NR * DC) Y[(size_t)(lane / DC) * n + (size_t)j * DC + (lane % DC)] = sYj[lane];
