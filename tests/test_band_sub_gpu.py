@@ -87,3 +87,21 @@ def test_twisted_refinement_path(gpu_ctx, monkeypatch):
     cams, pts, f, s = ba.optimize(gpu_ctx, p, pcg_tolerance=1e-30, pcg_max_iterations=2)
     assert s["band_separators"] >= 1 and s["pcg_iterations_total"] >= s["num_linearizations"]
     assert np.isfinite(cams).all() and np.isfinite(pts).all()
+
+
+@pytest.mark.parametrize("Nc,twist,merge", [(61, "1", "1"), (61, "0", "1"), (75, "1", "1"), (90, "1", "0"), (37, "1", "1")])
+def test_three_dof_pairs_merged_match_oracle(gpu_ctx, oracle, monkeypatch, Nc, twist, merge):
+    """Spherical BA (3-dof camera blocks): pairs of cameras merged into 6x6 block rows of the band (band_plan), odd component
+    sizes (one empty slot), with and without the twisted layout, against the oracle and against the unmerged factorisation."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.setenv("SSFM_BAND_TWIST", twist); monkeypatch.setenv("SSFM_BAND_MERGE", merge)
+    p = synth.make_circle(Nc, 30 * Nc, 6, spherical=True, focal_fixed=False, check_in_frame=False, seed=100 + Nc)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["camera_dof"] == 3 and s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    monkeypatch.setenv("SSFM_BAND_TWIST", "0"); monkeypatch.setenv("SSFM_BAND_MERGE", "0")
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
+    if merge == "1":
+        assert s["band_half_width"] == (s1["band_half_width"] + 1) // 2
+    assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and point_rel_err(pts, p1) <= 1e-8

@@ -12,7 +12,7 @@ def rot_angle(A, B):
     return np.array([np.linalg.norm(Rotation.from_matrix(a @ b.T).as_rotvec()) for a, b in zip(A, B)])
 
 
-@pytest.mark.parametrize("n,d", [(24, 4), (60, 6), (300, 8)])
+@pytest.mark.parametrize("n,d", [(24, 4), (25, 3), (60, 6), (75, 5), (300, 8), (301, 8)])      # odd sizes: an empty slot in the last merged pair
 def test_optimize_rotations_matches_oracle(gpu_ctx, oracle, n, d):
     from spherical_sfm_amd import rotavg
     R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(n, d)
