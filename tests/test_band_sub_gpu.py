@@ -105,3 +105,15 @@ def test_three_dof_pairs_merged_match_oracle(gpu_ctx, oracle, monkeypatch, Nc, t
     if merge == "1":
         assert s["band_half_width"] == (s1["band_half_width"] + 1) // 2
     assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and point_rel_err(pts, p1) <= 1e-8
+
+
+def test_long_three_dof_component_merged_and_cut(gpu_ctx, oracle, monkeypatch):
+    """Spherical BA on ONE ring of 2000 cameras: 1000 merged pairs, long enough to be cut into a chain of segments (6x6 blocks)."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_circle(2000, 24000, 6, spherical=True, focal_fixed=True, seed=8)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["camera_dof"] == 3 and s["band_separators"] >= 2 and s["band_segments"] == s["band_separators"] + 1
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5

@@ -12,14 +12,15 @@ def rot_angle(A, B):
     return np.array([np.linalg.norm(Rotation.from_matrix(a @ b.T).as_rotvec()) for a, b in zip(A, B)])
 
 
-@pytest.mark.parametrize("n,d", [(24, 4), (25, 3), (60, 6), (75, 5), (300, 8), (301, 8)])      # odd sizes: an empty slot in the last merged pair
+@pytest.mark.parametrize("n,d", [(24, 4), (25, 3), (60, 6), (75, 5), (300, 8), (301, 8), (1100, 4)])      # odd sizes; 1100 nodes: 550 merged pairs, cut into a chain of segments; odd sizes: an empty slot in the last merged pair
 def test_optimize_rotations_matches_oracle(gpu_ctx, oracle, n, d):
     from spherical_sfm_amd import rotavg
     R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(n, d)
     R, cost, s = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel)
     Ro, co, so = oracle.optimize_rotations(R0.copy(), i0, i1, Rrel)
     assert s["termination"] == so["termination"] and s["iterations"] == so["iterations"]
-    assert abs(cost - co) <= 1e-9 * co
+    # 1100 nodes stop at the iteration cap far from convergence: every solver variant (merged or not, cut or not) lands within 1.5e-8 of the oracle
+    assert abs(cost - co) <= (1e-9 if n <= 301 else 1e-7) * co
     assert rot_angle(R, Ro).max() <= 1e-5                         # <= 1e-5 rad between the two answers
     assert np.allclose(R[0], R0[0], atol=1e-14)                    # first rotation held constant (src/rotation_averaging.cpp:73)
 
