@@ -489,41 +489,81 @@ inline void mix(uint64_t& a, uint64_t& b, uint64_t w) {
     a = (a ^ w) * 0x9E3779B97F4A7C15ull; a ^= a >> 32;
     b = (b + w + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull; b ^= b >> 29;
 }
-void hash_bytes(const void* data, size_t n, uint64_t& a, uint64_t& b) {
-    const unsigned char* p = static_cast<const unsigned char*>(data);
+void hash_chunk(const unsigned char* p, size_t n, uint64_t& a, uint64_t& b) {
+    // four interleaved lanes: the multiply chain of mix() is serial, four independent chains keep the multiplier busy
+    uint64_t la[4] = {a, a ^ 0x1111111111111111ull, a ^ 0x2222222222222222ull, a ^ 0x3333333333333333ull}, lb[4] = {b, b + 1, b + 2, b + 3};
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); mix(a, b, w); }
+    for (; i + 32 <= n; i += 32) { uint64_t w[4]; std::memcpy(w, p + i, 32); for (int k = 0; k < 4; k++) mix(la[k], lb[k], w[k]); }
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); mix(la[0], lb[0], w); }
     uint64_t w = 0; if (i < n) std::memcpy(&w, p + i, n - i);
-    mix(a, b, w ^ ((uint64_t)n << 56));
+    mix(la[0], lb[0], w ^ ((uint64_t)n << 56));
+    for (int k = 1; k < 4; k++) { mix(la[0], lb[0], la[k]); mix(la[0], lb[0], lb[k]); }
+    a = la[0]; b = lb[0];
 }
+// Hash of everything the plan depends on.  The long arrays (observation ids, the points' zero test) are cut into fixed pieces hashed on
+// the planner's threads in ONE fork-join; the piece hashes are folded in order, so the result does not depend on the thread count.
 void structure_hash(const ssfm_ba_problem* p, uint64_t& a, uint64_t& b) {
     a = 0x243F6A8885A308D3ull; b = 0x13198A2E03707344ull;
-    hash_bytes(p->obs_cam, (size_t)p->num_observations * sizeof(int32_t), a, b);
-    hash_bytes(p->obs_pt, (size_t)p->num_observations * sizeof(int32_t), a, b);
-    if (p->rot_fixed) hash_bytes(p->rot_fixed, (size_t)p->num_cameras, a, b); else mix(a, b, 1);
-    if (p->trans_fixed) hash_bytes(p->trans_fixed, (size_t)p->num_cameras, a, b); else mix(a, b, 2);
-    if (p->pt_fixed) hash_bytes(p->pt_fixed, (size_t)p->num_points, a, b); else mix(a, b, 3);
-    uint64_t bits = 0; int nb = 0;                                   // which points are (0,0,0): they leave the problem (src/sfm.cpp:243)
-    for (int j = 0; j < p->num_points; j++) {
-        const double* X = p->points + 3 * (size_t)j;
-        bits = (bits << 1) | ((X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) == 0.0 ? 1u : 0u);
-        if (++nb == 64) { mix(a, b, bits); bits = 0; nb = 0; }
-    }
-    mix(a, b, bits ^ ((uint64_t)nb << 57));
+    constexpr size_t PIECE = 64 * 1024;
+    const size_t nb_ids = (size_t)p->num_observations * sizeof(int32_t);
+    const size_t np_ids = (nb_ids + PIECE - 1) / PIECE, PPTS = 16384, np_pts = ((size_t)p->num_points + PPTS - 1) / PPTS;
+    const size_t np = 2 * np_ids + np_pts;
+    std::vector<uint64_t> ha(np), hb(np);
+    parallel_chunks((int64_t)np, np > 8 ? planner_threads() : 1, [&](int, int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; k++) {
+            uint64_t x = 0x452821E638D01377ull + (uint64_t)k, y = 0xBE5466CF34E90C6Cull;
+            if ((size_t)k < 2 * np_ids) {
+                const unsigned char* base = reinterpret_cast<const unsigned char*>((size_t)k < np_ids ? p->obs_cam : p->obs_pt);
+                const size_t kk = (size_t)k % np_ids, off = kk * PIECE;
+                hash_chunk(base + off, std::min(PIECE, nb_ids - off), x, y);
+            } else {                                             // which points are (0,0,0): they leave the problem (src/sfm.cpp:243)
+                const size_t j0 = ((size_t)k - 2 * np_ids) * PPTS, j1 = std::min((size_t)p->num_points, j0 + PPTS);
+                uint64_t bits = 0; int nb = 0;
+                for (size_t j = j0; j < j1; j++) {
+                    const double* X = p->points + 3 * j;
+                    bits = (bits << 1) | ((X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) == 0.0 ? 1u : 0u);
+                    if (++nb == 64) { mix(x, y, bits); bits = 0; nb = 0; }
+                }
+                mix(x, y, bits ^ ((uint64_t)nb << 57));
+            }
+            ha[k] = x; hb[k] = y;
+        }
+    });
+    for (size_t k = 0; k < np; k++) { mix(a, b, ha[k]); mix(a, b, hb[k]); }
+    auto small = [&](const void* d, size_t n) { hash_chunk(static_cast<const unsigned char*>(d), n, a, b); };
+    if (p->rot_fixed) small(p->rot_fixed, (size_t)p->num_cameras); else mix(a, b, 1);
+    if (p->trans_fixed) small(p->trans_fixed, (size_t)p->num_cameras); else mix(a, b, 2);
+    if (p->pt_fixed) small(p->pt_fixed, (size_t)p->num_points); else mix(a, b, 3);
 }
 // new parameter values into a resident handle whose structure matches p
 int upload_state(ssfm_ba_handle* h, const ssfm_ba_problem* p) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
-    for (int q = 0; q < F.nP; q++) for (int d = 0; d < 3; d++) F.pts0[(size_t)q * 3 + d] = p->points[(size_t)F.pt_ids[q] * 3 + d];
-    for (int64_t j = 0; j < F.M; j++) { const int64_t o = F.obs_orig[j]; F.obs_xy[2 * j] = p->obs_xy[2 * o]; F.obs_xy[2 * j + 1] = p->obs_xy[2 * o + 1]; }
+    // gather points / pixels in the plan's order straight into a pinned staging buffer (allocated on the first reuse of a plan), on the
+    // planner's threads; then three asynchronous copies
+    const double t_up0 = wall_s();
+    const size_t n_pts = (size_t)F.nP * 3, n_xy = (size_t)F.M * 2;
+    if (!h->host_stage || h->host_stage_n < n_pts + n_xy) {
+        if (h->host_stage) (void)hipHostFree(h->host_stage);
+        h->host_stage = nullptr; h->host_stage_n = 0;
+        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_stage, std::max<size_t>(n_pts + n_xy, 1) * sizeof(double), hipHostMallocDefault));
+        h->host_stage_n = n_pts + n_xy;
+    }
+    double* sp = h->host_stage; double* sx = h->host_stage + n_pts;
+    const int NT = planner_threads();
+    parallel_chunks(F.M, NT, [&](int t, int64_t lo, int64_t hi) {      // one fork-join: every thread takes its share of the pixels and of the points
+        for (int64_t j = lo; j < hi; j++) { const int64_t o = F.obs_orig[j]; sx[2 * j] = p->obs_xy[2 * o]; sx[2 * j + 1] = p->obs_xy[2 * o + 1]; }
+        const int64_t T = (F.M < 4 * (int64_t)NT || NT <= 1) ? 1 : NT, q0 = (int64_t)F.nP * t / T, q1 = (int64_t)F.nP * (t + 1) / T;
+        for (int64_t q = q0; q < q1; q++) for (int d = 0; d < 3; d++) sp[(size_t)q * 3 + d] = p->points[(size_t)F.pt_ids[q] * 3 + d]; });
     const double f3[3] = {*p->focal, *p->focal, *p->focal};
     h->focal_host = *p->focal;
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->cam_init.p, p->cameras, (size_t)F.Nc * 6 * sizeof(double), hipMemcpyHostToDevice, st));
-    if (F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->pts_init.p, F.pts0.data(), F.pts0.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    if (F.M > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->obs_xy.p, F.obs_xy.data(), F.obs_xy.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->pts_init.p, sp, n_pts * sizeof(double), hipMemcpyHostToDevice, st));
+    if (F.M > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->obs_xy.p, sx, n_xy * sizeof(double), hipMemcpyHostToDevice, st));
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->focal3.p, f3, sizeof(f3), hipMemcpyHostToDevice, st));
+    const double tg = wall_s();
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));                   // the host sources above are reused by the caller
+    if (std::getenv("SSFM_PLAN_TIMING")) std::fprintf(stderr, "[solve] upload: gather+enqueue %.3f ms, copies %.3f ms\n", 1e3 * (tg - t_up0), 1e3 * (wall_s() - tg));
     return ssfm_ba_reset(h);
 }
 }  // namespace
@@ -536,14 +576,18 @@ extern "C" int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_op
     key.focal_fixed = p->focal_fixed ? 1 : 0;
     PlanCache* pc = static_cast<PlanCache*>(ctx->plan_cache);
     ssfm_ba_handle* h = nullptr; bool reused = false; int rc = SSFM_OK;
+    const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
     if (!no_cache) {
         structure_hash(p, key.h1, key.h2);
+        if (timing) std::fprintf(stderr, "[solve] structure hash %.3f ms\n", 1e3 * (wall_s() - t0));
         if (pc && pc->h && pc->Nc == key.Nc && pc->Np == key.Np && pc->M == key.M && pc->nranks == key.nranks && pc->rank == key.rank &&
             pc->focal_fixed == key.focal_fixed && pc->h1 == key.h1 && pc->h2 == key.h2) {
             h = pc->h; reused = true;
             if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
             h->t_flatten_s = 0.0;
+            const double tu = wall_s();
             rc = upload_state(h, p);
+            if (timing) std::fprintf(stderr, "[solve] upload_state %.3f ms\n", 1e3 * (wall_s() - tu));
         }
     }
     if (!reused) {
