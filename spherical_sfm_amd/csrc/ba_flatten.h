@@ -71,6 +71,7 @@ struct BAFlat {
     // Schur pair lists (this rank's observations): for row c the entries (j, j2) = (observation of c, observation of the
     // same point by a camera c2 of row c), grouped by slot and padded with -1 to whole 64-lane batches.
     std::vector<int> pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr;
+    int64_t pair_batches = 0;           // 64-entry batches of the pair lists (the lists themselves may live on the device only)
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
 };
@@ -202,7 +203,75 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
     band = bs; comp_ptr.swap(sup_ptr); band_block = 6;
 }
 
-inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F) {
+// ---- Schur pair lists ---------------------------------------------------------------------------------------------------------
+// For row camera c the entries (j, j2, p) = (observation of c, observation of the same point p by a camera c2 that precedes c in the
+// elimination order), grouped by the slot of c2 in row c of S and padded with -1 to whole 64-entry batches.  Three steps: count per
+// slot, layout (serial, tiny), fill.  ssfm_ba_create runs count and fill on the GPU (ba_kernels.h: k_pair_count / k_pair_fill) and only
+// the layout here; the host versions serve the host-only callers (sanitizer test) and SSFM_HOST_PAIRS=1.
+inline void pair_counts_host(const BAFlat& F, int NT, std::vector<int>& slot_cnt) {
+    const int Nc = F.Nc;
+    slot_cnt.assign(F.col_idx.size(), 0);
+    parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+        std::vector<int> slot_of(Nc, -1);
+        for (int c = (int)c0; c < (int)c1; c++) {
+            const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
+            for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
+            for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
+                const int p = F.cam_obs_pt[q];
+                for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) { const int c2 = F.obs_cam[j2]; if (F.cam_pos[c2] < pc) slot_cnt[rb + slot_of[c2]]++; }   // diagonal blocks: k_cam_sums2
+            }
+            for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
+        }
+    });
+}
+// batches of every slot, wave tasks of <= task_batches batches of ONE camera; slot_off = first pair entry of every slot; returns the
+// number of 64-entry batches
+inline int64_t pair_layout(BAFlat& F, const std::vector<int>& slot_cnt, std::vector<int64_t>& slot_off) {
+    int task_batches = 8;                                    // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
+    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
+    const int Nc = F.Nc;
+    F.cam_batch_ptr.assign(Nc + 1, 0); F.batch_slot.clear(); F.chunk_cam.clear(); F.chunk_b0.clear(); F.chunk_b1.clear();
+    slot_off.assign(F.col_idx.size(), 0);
+    int64_t nbatch_total = 0;
+    for (int c = 0; c < Nc; c++) {
+        int nbatch = 0;
+        for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) {
+            if (slot_cnt[e] == 0) continue;
+            const int nb = (slot_cnt[e] + 63) / 64;
+            slot_off[e] = (nbatch_total + nbatch) * 64;
+            for (int b2 = 0; b2 < nb; b2++) F.batch_slot.push_back(e - F.row_ptr[c]);
+            nbatch += nb;
+        }
+        F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch; nbatch_total += nbatch;
+        for (int b2 = F.cam_batch_ptr[c]; b2 < F.cam_batch_ptr[c + 1]; b2 += task_batches) {
+            F.chunk_cam.push_back(c); F.chunk_b0.push_back(b2); F.chunk_b1.push_back(std::min(b2 + task_batches, F.cam_batch_ptr[c + 1]));
+        }
+    }
+    F.pair_batches = nbatch_total;
+    return nbatch_total;
+}
+inline void pair_fill_host(BAFlat& F, int NT, std::vector<int64_t>& slot_off) {
+    const int Nc = F.Nc;
+    F.pair_j.assign((size_t)F.pair_batches * 64, -1); F.pair_j2.assign((size_t)F.pair_batches * 64, -1); F.pair_p.assign((size_t)F.pair_batches * 64, -1);
+    parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+        std::vector<int> slot_of(Nc, -1);
+        for (int c = (int)c0; c < (int)c1; c++) {
+            const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
+            for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
+            for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
+                const int j = F.cam_obs[q], p = F.cam_obs_pt[q];
+                for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
+                    const int c2 = F.obs_cam[j2]; if (!(F.cam_pos[c2] < pc)) continue;
+                    const int64_t w = slot_off[rb + slot_of[c2]]++;
+                    F.pair_j[w] = j; F.pair_j2[w] = j2; F.pair_p[w] = p;
+                }
+            }
+            for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
+        }
+    });
+}
+
+inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F, bool host_pairs = true) {
     const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; const auto t = std::chrono::steady_clock::now();
@@ -366,59 +435,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
     lap("camera-major lists");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
-    int task_batches = 8;                                    // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
-    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
-    F.cam_batch_ptr.assign(Nc + 1, 0);
-    {
-        // two sweeps per camera, both parallel over cameras: count the pairs of every slot; (serial) offsets of the 64-padded
-        // batches; fill in place
-        const size_t nnzb = F.col_idx.size();
-        std::vector<int> slot_cnt(nnzb, 0);
-        parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
-            std::vector<int> slot_of(Nc, -1);
-            for (int c = (int)c0; c < (int)c1; c++) {
-                const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
-                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
-                for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
-                    const int p = F.cam_obs_pt[q];
-                    for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) { const int c2 = F.obs_cam[j2]; if (F.cam_pos[c2] < pc) slot_cnt[rb + slot_of[c2]]++; }   // diagonal blocks: k_cam_sums2
-                }
-                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
-            }
-        });
-        std::vector<int64_t> slot_off(nnzb, 0);                       // first pair entry of every slot
-        int64_t nbatch_total = 0;
-        for (int c = 0; c < Nc; c++) {
-            int nbatch = 0;
-            for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) {
-                if (slot_cnt[e] == 0) continue;
-                const int nb = (slot_cnt[e] + 63) / 64;
-                slot_off[e] = (nbatch_total + nbatch) * 64;
-                for (int b2 = 0; b2 < nb; b2++) F.batch_slot.push_back(e - F.row_ptr[c]);
-                nbatch += nb;
-            }
-            F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch; nbatch_total += nbatch;
-            for (int b2 = F.cam_batch_ptr[c]; b2 < F.cam_batch_ptr[c + 1]; b2 += task_batches) {
-                F.chunk_cam.push_back(c); F.chunk_b0.push_back(b2); F.chunk_b1.push_back(std::min(b2 + task_batches, F.cam_batch_ptr[c + 1]));
-            }
-        }
-        F.pair_j.assign((size_t)nbatch_total * 64, -1); F.pair_j2.assign((size_t)nbatch_total * 64, -1); F.pair_p.assign((size_t)nbatch_total * 64, -1);
-        parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
-            std::vector<int> slot_of(Nc, -1);
-            for (int c = (int)c0; c < (int)c1; c++) {
-                const int rb = F.row_ptr[c], nnb = F.row_ptr[c + 1] - rb, pc = F.cam_pos[c];
-                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
-                for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
-                    const int j = F.cam_obs[q], p = F.cam_obs_pt[q];
-                    for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
-                        const int c2 = F.obs_cam[j2]; if (!(F.cam_pos[c2] < pc)) continue;
-                        const int64_t w = slot_off[rb + slot_of[c2]]++;
-                        F.pair_j[w] = j; F.pair_j2[w] = j2; F.pair_p[w] = p;
-                    }
-                }
-                for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
-            }
-        });
+    if (host_pairs) {
+        std::vector<int> slot_cnt; pair_counts_host(F, NT, slot_cnt);
+        std::vector<int64_t> slot_off; pair_layout(F, slot_cnt, slot_off);
+        pair_fill_host(F, NT, slot_off);
     }
     lap("pair lists");
 }

@@ -817,6 +817,30 @@ k_pcg_vecops(const double* __restrict__ Minv, const double* __restrict__ Sfc, co
     }
 }
 
+// ---- Schur pair lists on the device (what ba_flatten.h: pair_counts_host / pair_fill_host do on the host) ---------------------
+// One thread per camera-major entry q = (observation j of camera c, point p): every other observation j2 of p by a camera c2 that
+// precedes c in the elimination order is one pair of row c, slot = position of c2 in row c of S (columns sorted by camera id).
+// k_pair_count counts per slot; the host lays out the 64-padded batches (pair_layout); k_pair_fill writes (j, j2, p) through atomic
+// cursors that start at the slots' first entries (the order inside a slot is arbitrary: the sums over a slot go through atomics anyway).
+template <bool FILL>
+static __global__ void __launch_bounds__(256)
+k_pair_lists(int M, const int* __restrict__ cam_obs, const int* __restrict__ cam_obs_pt, const int* __restrict__ obs_cam,
+             const int* __restrict__ pt_start, const int* __restrict__ elim_pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
+             unsigned int* __restrict__ slot_ctr, int* __restrict__ pair_j, int* __restrict__ pair_j2, int* __restrict__ pair_p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M) return;
+    const int j = cam_obs[q], p = cam_obs_pt[q], c = obs_cam[j];
+    const int pc = elim_pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
+    for (int j2 = pt_start[p]; j2 < pt_start[p + 1]; j2++) {
+        const int c2 = obs_cam[j2];
+        if (!(elim_pos[c2] < pc)) continue;
+        int lo = 0, hi = nnb;                                    // first column >= c2
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (col_idx[rb + mid] < c2) lo = mid + 1; else hi = mid; }
+        const unsigned int w = atomicAdd(&slot_ctr[rb + lo], 1u);
+        if (FILL) { pair_j[w] = j; pair_j2[w] = j2; pair_p[w] = p; }
+    }
+}
+
 // ---- K3a: candidate cameras/focal from the PCG solution (replicated on every rank) --------------------
 template <int DC>
 __global__ void __launch_bounds__(1024)

@@ -284,7 +284,7 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
 extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
                             uint8_t* obs_used, int32_t* cam_pos) {
     if (!p || !info || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ba_plan: bad arguments");
-    BAFlat F; ba_flatten(*p, nranks, rank, F);
+    BAFlat F; ba_flatten(*p, nranks, rank, F, false);     // the pair lists are not part of what the plan reports
     std::memset(info, 0, sizeof(*info));
     if (obs_used) std::memset(obs_used, 0, (size_t)p->num_observations);
     if (F.nothing_to_do) return SSFM_OK;
@@ -306,7 +306,8 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->ctx = ctx;
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
-    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F); h->t_flatten_s = wall_s() - tf; }
+    const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
+    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs); h->t_flatten_s = wall_s() - tf; }
     *out = h;
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
@@ -350,8 +351,42 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
-    SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st));
-    SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st)); SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
+    SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st));
+    if (host_pairs) {
+        SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st));
+    } else if (F.M > 0) {
+        // pair lists on the device: count per slot, lay the batches out on the host (tiny), fill through atomic cursors
+        BAFlat& Fm = h->F;
+        DevBuf<int> elim; DevBuf<unsigned int> ctr;
+        const size_t nnzb_s = Fm.col_idx.size();
+        int rc2 = SSFM_OK;
+        auto build = [&]() -> int {
+            SSFM_HIP_CHECK(ctx, upload(elim, Fm.cam_pos, st)); SSFM_HIP_CHECK(ctx, ctr.alloc(nnzb_s));
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(ctr.p, 0, nnzb_s * sizeof(unsigned int), st));
+            const int gq = (int)((Fm.M + 255) / 256);
+            hipLaunchKernelGGL((k_pair_lists<false>), dim3(gq), dim3(256), 0, st, (int)Fm.M, h->cam_obs.p, h->cam_obs_pt.p, h->obs_cam.p, h->pt_start.p, elim.p, h->row_ptr.p,
+                               h->col_idx.p, ctr.p, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+            std::vector<int> slot_cnt(nnzb_s);
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(slot_cnt.data(), ctr.p, nnzb_s * sizeof(int), hipMemcpyDeviceToHost, st));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            std::vector<int64_t> slot_off; const int64_t nbat = pair_layout(Fm, slot_cnt, slot_off);
+            if (nbat * 64 >= (int64_t)1 << 31) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_create: more than 2^31 Schur pairs on one rank");
+            std::vector<unsigned int> start(nnzb_s); for (size_t e = 0; e < nnzb_s; e++) start[e] = (unsigned int)slot_off[e];
+            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(ctr.p, start.data(), nnzb_s * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+            const size_t npair = (size_t)nbat * 64;
+            SSFM_HIP_CHECK(ctx, h->pair_j.alloc(npair)); SSFM_HIP_CHECK(ctx, h->pair_j2.alloc(npair)); SSFM_HIP_CHECK(ctx, h->pair_p.alloc(npair));
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_j.p, 0xFF, npair * sizeof(int), st)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_j2.p, 0xFF, npair * sizeof(int), st));
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_p.p, 0xFF, npair * sizeof(int), st));
+            hipLaunchKernelGGL((k_pair_lists<true>), dim3(gq), dim3(256), 0, st, (int)Fm.M, h->cam_obs.p, h->cam_obs_pt.p, h->obs_cam.p, h->pt_start.p, elim.p, h->row_ptr.p,
+                               h->col_idx.p, ctr.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p);
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));           // `start` and the temporaries go out of scope
+            return SSFM_OK;
+        };
+        rc2 = build();
+        elim.free(); ctr.free();
+        if (rc2) return rc2;
+    }
+    SSFM_HIP_CHECK(ctx, upload(h->batch_slot, F.batch_slot, st));
     SSFM_HIP_CHECK(ctx, upload(h->cam_batch_ptr, F.cam_batch_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_cam, F.chunk_cam, st));
     SSFM_HIP_CHECK(ctx, upload(h->chunk_b0, F.chunk_b0, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_b1, F.chunk_b1, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
