@@ -426,11 +426,13 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     F.cam_start.assign(Nc + 1, 0);
     for (int64_t j = 0; j < F.M; j++) F.cam_start[F.obs_cam[j] + 1]++;
     for (int c = 0; c < Nc; c++) F.cam_start[c + 1] += F.cam_start[c];
-    F.cam_obs.resize(F.M);
-    { std::vector<int> fill(F.cam_start.begin(), F.cam_start.end() - 1);
-      for (int64_t j = 0; j < F.M; j++) F.cam_obs[fill[F.obs_cam[j]]++] = (int)j; }
-    F.cam_obs_pt.resize(F.M);
-    for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
+    if (host_pairs) {                                                  // otherwise filled on the device (k_cam_lists), like the pair lists
+        F.cam_obs.resize(F.M);
+        { std::vector<int> fill(F.cam_start.begin(), F.cam_start.end() - 1);
+          for (int64_t j = 0; j < F.M; j++) F.cam_obs[fill[F.obs_cam[j]]++] = (int)j; }
+        F.cam_obs_pt.resize(F.M);
+        for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
+    }
     for (int c = 0; c < Nc; c++)
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
     lap("camera-major lists");

@@ -822,6 +822,39 @@ k_pcg_vecops(const double* __restrict__ Minv, const double* __restrict__ Sfc, co
 // precedes c in the elimination order is one pair of row c, slot = position of c2 in row c of S (columns sorted by camera id).
 // k_pair_count counts per slot; the host lays out the 64-padded batches (pair_layout); k_pair_fill writes (j, j2, p) through atomic
 // cursors that start at the slots' first entries (the order inside a slot is arbitrary: the sums over a slot go through atomics anyway).
+// camera-major view of the point-major observation list: cursor[c] starts at cam_start[c]; the order inside a camera is arbitrary
+static __global__ void __launch_bounds__(256)
+k_cam_lists(int M, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt, unsigned int* __restrict__ cursor, int* __restrict__ cam_obs,
+            int* __restrict__ cam_obs_pt) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const unsigned int w = atomicAdd(&cursor[obs_cam[j]], 1u);
+    cam_obs[w] = j; cam_obs_pt[w] = obs_pt[j];
+}
+// ... then every camera's segment is put back in ascending observation order (= ascending point order: neighbouring lanes of
+// k_cam_sums2 read neighbouring points; the unsorted lists cost it 2 us per launch): bitonic sort in LDS, segments of <= 4096 entries
+static __global__ void __launch_bounds__(256)
+k_cam_lists_sort(const int* __restrict__ cam_start, const int* __restrict__ obs_pt, int* __restrict__ cam_obs, int* __restrict__ cam_obs_pt) {
+    __shared__ int sv[4096];
+    const int c = blockIdx.x, q0 = cam_start[c], n = cam_start[c + 1] - q0;
+    if (n <= 1 || n > 4096) return;
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) sv[i] = (i < n) ? cam_obs[q0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int l = i ^ jj;
+                if (l > i) {
+                    const int a = sv[i], b = sv[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { sv[i] = b; sv[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const int j = sv[i]; cam_obs[q0 + i] = j; cam_obs_pt[q0 + i] = obs_pt[j]; }
+}
 template <bool FILL>
 static __global__ void __launch_bounds__(256)
 k_pair_lists(int M, const int* __restrict__ cam_obs, const int* __restrict__ cam_obs_pt, const int* __restrict__ obs_cam,

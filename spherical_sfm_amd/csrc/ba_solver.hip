@@ -321,7 +321,19 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     UP(cam_x, cams); UP(cam_init, cams); UP(pts_x, F.pts0); UP(pts_init, F.pts0); UP(focal3, f3);
     UP(mask_cam, F.mask_cam); UP(mask_pt, F.mask_pt); UP(mask_f, maskf);
     UP(obs_xy, F.obs_xy); UP(obs_cam, F.obs_cam); UP(obs_pt, F.obs_pt); UP(pt_start, F.pt_start);
-    UP(cam_start, F.cam_start); UP(cam_obs, F.cam_obs); UP(cam_obs_pt, F.cam_obs_pt); UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
+    UP(cam_start, F.cam_start);
+    if (host_pairs) { UP(cam_obs, F.cam_obs); UP(cam_obs_pt, F.cam_obs_pt); }
+    else if (F.M > 0) {                                               // camera-major lists on the device
+        DevBuf<unsigned int> cur;
+        SSFM_HIP_CHECK(ctx, h->cam_obs.alloc((size_t)F.M)); SSFM_HIP_CHECK(ctx, h->cam_obs_pt.alloc((size_t)F.M)); SSFM_HIP_CHECK(ctx, cur.alloc((size_t)Nc));
+        hipError_t e1 = hipMemcpyAsync(cur.p, h->cam_start.p, (size_t)Nc * sizeof(int), hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(k_cam_lists, dim3((unsigned)((F.M + 255) / 256)), dim3(256), 0, st, (int)F.M, h->obs_cam.p, h->obs_pt.p, cur.p, h->cam_obs.p, h->cam_obs_pt.p);
+        hipLaunchKernelGGL(k_cam_lists_sort, dim3(Nc), dim3(256), 0, st, h->cam_start.p, h->obs_pt.p, h->cam_obs.p, h->cam_obs_pt.p);
+        hipError_t e2 = hipStreamSynchronize(st);
+        cur.free();
+        SSFM_HIP_CHECK(ctx, e1); SSFM_HIP_CHECK(ctx, e2);
+    }
+    UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
 #undef UP
 #define AL(buf, count) SSFM_HIP_CHECK(ctx, h->buf.alloc(count))
     AL(cam_c, (size_t)Nc * 6); AL(pts_c, (size_t)nP * 3); AL(rot_x, (size_t)Nc * 27); AL(rot_c, (size_t)Nc * 27);
