@@ -28,11 +28,26 @@ static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_sch
                                               "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
                                               "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left"};
 
+static bool g_alloc_timing = false; static double g_alloc_s = 0.0; static int g_alloc_n = 0;   // SSFM_PLAN_TIMING: time spent in hipMalloc
 template <typename T>
 struct DevBuf {
-    T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { n = count; return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); }
-    void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    T* p = nullptr; size_t n = 0; size_t cap_bytes = 0; int dev = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        const double t0 = g_alloc_timing ? wall_s() : 0.0;
+        (void)hipGetDevice(&dev);
+        hipError_t e = hipSuccess;
+        p = static_cast<T*>(g_dev_pool.take(bytes, dev, &cap_bytes));
+        if (!p) { e = hipMalloc((void**)&p, bytes); cap_bytes = bytes; }
+        if (g_alloc_timing) { g_alloc_s += wall_s() - t0; g_alloc_n++; }
+        return e;
+    }
+    void free() {
+        if (p && cap_bytes > 0 && g_dev_pool.give(p, cap_bytes, dev)) { p = nullptr; n = 0; cap_bytes = 0; return; }   // recycled (ssfm_ctx.h: DevPool)
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0; cap_bytes = 0;
+    }
 };
 
 }  // namespace ssfm

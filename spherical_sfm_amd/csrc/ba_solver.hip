@@ -307,6 +307,8 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
+    g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_s = 0.0; g_alloc_n = 0;
+    const double t_create0 = wall_s();
     { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs); h->t_flatten_s = wall_s() - tf; }
     *out = h;
     const BAFlat& F = h->F;
@@ -403,6 +405,8 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     SSFM_HIP_CHECK(ctx, upload(h->chunk_b0, F.chunk_b0, st)); SSFM_HIP_CHECK(ctx, upload(h->chunk_b1, F.chunk_b1, st));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (g_alloc_timing) std::fprintf(stderr, "[create] total %.2f ms: host plan %.2f, %d hipMalloc %.2f ms, uploads + device lists %.2f ms\n", 1e3 * (wall_s() - t_create0),
+                                     1e3 * h->t_flatten_s, g_alloc_n, 1e3 * g_alloc_s, 1e3 * (wall_s() - t_create0 - h->t_flatten_s - g_alloc_s));
     return SSFM_OK;
 }
 

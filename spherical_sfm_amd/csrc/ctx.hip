@@ -36,6 +36,7 @@ extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->plan_cache && ctx->plan_cache_free) ctx->plan_cache_free(ctx->plan_cache);
+    g_dev_pool.drain(ctx->device);                               // recycled device buffers of this device
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstdio>
+#include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/ssfm.h"
 
 struct ssfm_ctx {
@@ -22,6 +24,37 @@ struct ssfm_ctx {
 };
 
 namespace ssfm {
+
+// Device-memory recycling.  A handle owns ~80 buffers; hipFree synchronises the device, and tearing a handle down on a structure
+// change cost 3 ms of the 16 ms of a first call.  Freed buffers go to this pool and the next handle's allocations are served from it
+// (best fit, at most twice the requested size); ssfm_ctx_destroy drains it.
+struct DevPool {
+    struct Blk { void* p; size_t bytes; int dev; };
+    std::vector<Blk> blocks; std::mutex m; size_t total = 0;
+    void* take(size_t bytes, int dev, size_t* got) {
+        std::lock_guard<std::mutex> g(m);
+        int best = -1;
+        for (int i = 0; i < (int)blocks.size(); i++)
+            if (blocks[i].dev == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + 4096 && (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void* p = blocks[best].p; *got = blocks[best].bytes; total -= blocks[best].bytes;
+        blocks[best] = blocks.back(); blocks.pop_back();
+        return p;
+    }
+    bool give(void* p, size_t bytes, int dev) {
+        std::lock_guard<std::mutex> g(m);
+        if (blocks.size() >= 1024 || total + bytes > ((size_t)16 << 30)) return false;
+        blocks.push_back({p, bytes, dev}); total += bytes;
+        return true;
+    }
+    void drain(int dev) {
+        std::lock_guard<std::mutex> g(m);
+        for (size_t i = 0; i < blocks.size();) {
+            if (blocks[i].dev == dev) { (void)hipFree(blocks[i].p); total -= blocks[i].bytes; blocks[i] = blocks.back(); blocks.pop_back(); } else i++;
+        }
+    }
+};
+inline DevPool g_dev_pool;
 
 extern std::string g_last_error;   // for failures before a context exists
 
