@@ -144,11 +144,11 @@ def main():
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us == dom_us else None
         asm_us = dom_us + kern.get("k_cam_sums2", {}).get("avg_us", float("nan"))
         iter_ms = 1e3 * elapsed / max(1, n_lm)          # wall time of the timed loop per LM iteration (host round trips included)
-        traffic = None
+        traffic = None; valu = None
         tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(dom)
+                pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -161,6 +161,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
+            # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
+            # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
+            "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4,
+                           "frac": (valu / (256 * dom_us * 1e-6 * 2.4e9) if valu and dom_us == dom_us else None)},
             "roofline_schur_assembly": {"bound": "hbm", "kernels": ["k_cam_sums2", dom], "algorithmic_bytes": schur_bytes / world,
                                         "avg_us": asm_us, "achieved": (schur_bytes / world) / (asm_us * 1e-6) / 1e9 if asm_us == asm_us else None,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
