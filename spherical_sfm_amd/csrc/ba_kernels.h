@@ -879,7 +879,7 @@ template <int DC>
 __global__ void __launch_bounds__(1024)
 k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
              const double* __restrict__ scale_f, const double* __restrict__ y, int Nc,
-             double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c, double* __restrict__ scal) {
+             double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c, double* __restrict__ scal, int with_rot) {
     __shared__ double red[2 * 16];
     constexpr int off = (DC == 6) ? 0 : 3;
     double acc[2] = {0, 0};
@@ -897,8 +897,9 @@ k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, c
     }
     block_sum<2>(acc, red);                                       // (its barriers also publish cam_c to the whole workgroup)
     if (threadIdx.x == 0) { scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; }
-    // rotation tables of the candidate cameras (what a separate k_cam_rot launch did)
-    for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
+    // rotation tables of the candidate cameras (what a separate k_cam_rot launch did; large camera sets leave them to k_cam_rot again:
+    // one workgroup walking 4000 cameras took 64 us)
+    if (with_rot) for (int c = threadIdx.x; c < Nc; c += blockDim.x) {
         const double aa[3] = {cam_c[c * 6 + 3], cam_c[c * 6 + 4], cam_c[c * 6 + 5]};
         double R[9], Rd[9], M[9];
         angle_axis_derivative_aid(aa, R, Rd, M);

@@ -141,7 +141,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         auto enqueue_tail = [&]() -> int {
             // candidate cameras + their rotation tables; then per point: back-substitution, candidate, model cost change, candidate cost
-            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p);
+            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p, Nc <= 1024 ? 1 : 0);
+            if (Nc > 1024) LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
             if (nP > 0)
                 LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                        h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p);
