@@ -368,24 +368,28 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
         ObsLin L_; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X_, o_.x, o_.y, loss, la, L_);                      \
         double Jc_[2][DC]; cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                                 \
         const double jf0 = L_.Jf[0] * sf, jf1 = L_.Jf[1] * sf;                                                        \
-        double Wm[DC][3];                                                                                             \
-        _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                              \
-            Jc_[0][a] *= wgt_; Jc_[1][a] *= wgt_;                                                                     \
-            Wm[a][0] = Jc_[0][a] * L_.Jp[0][0] + Jc_[1][a] * L_.Jp[1][0];                                             \
-            Wm[a][1] = Jc_[0][a] * L_.Jp[0][1] + Jc_[1][a] * L_.Jp[1][1];                                             \
-            Wm[a][2] = Jc_[0][a] * L_.Jp[0][2] + Jc_[1][a] * L_.Jp[1][2];                                             \
+        _Pragma("unroll") for (int a = 0; a < DC; a++) { Jc_[0][a] *= wgt_; Jc_[1][a] *= wgt_; }                      \
+        /* everything through 2-vectors: Jc^T (I - Jp PS_V Jp^T) Jc, Jc^T (Jp PS_g), Jc^T (J_f - Jp PS_w); W = Jc^T Jp is never formed */ \
+        double Q_[2][3], y_[2], z_[2];                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 2; r++) {                                                               \
+            const double j0 = L_.Jp[r][0], j1 = L_.Jp[r][1], j2 = L_.Jp[r][2];                                        \
+            Q_[r][0] = j0 * P_[0] + j1 * P_[1] + j2 * P_[2];                                                          \
+            Q_[r][1] = j0 * P_[1] + j1 * P_[3] + j2 * P_[4];                                                          \
+            Q_[r][2] = j0 * P_[2] + j1 * P_[4] + j2 * P_[5];                                                          \
+            y_[r] = j0 * P_[6] + j1 * P_[7] + j2 * P_[8];                                                             \
+            z_[r] = ((r == 0) ? jf0 : jf1) - (j0 * P_[9] + j1 * P_[10] + j2 * P_[11]);                                \
         }                                                                                                             \
+        const double c00 = 1.0 - (Q_[0][0] * L_.Jp[0][0] + Q_[0][1] * L_.Jp[0][1] + Q_[0][2] * L_.Jp[0][2]);          \
+        const double c01 = -(Q_[0][0] * L_.Jp[1][0] + Q_[0][1] * L_.Jp[1][1] + Q_[0][2] * L_.Jp[1][2]);               \
+        const double c11 = 1.0 - (Q_[1][0] * L_.Jp[1][0] + Q_[1][1] * L_.Jp[1][1] + Q_[1][2] * L_.Jp[1][2]);          \
         int u = 0;                                                                                                    \
         _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                              \
-            const double w0 = Wm[a][0], w1 = Wm[a][1], w2 = Wm[a][2];                                                 \
-            const double t0 = w0 * P_[0] + w1 * P_[1] + w2 * P_[2], t1 = w0 * P_[1] + w1 * P_[3] + w2 * P_[4],        \
-                         t2 = w0 * P_[2] + w1 * P_[4] + w2 * P_[5];                                                   \
+            const double e0 = c00 * Jc_[0][a] + c01 * Jc_[1][a], e1 = c01 * Jc_[0][a] + c11 * Jc_[1][a];              \
             sm[NU + a] += Jc_[0][a] * L_.r[0] + Jc_[1][a] * L_.r[1];                                                  \
-            sm[NU + DC + a] -= w0 * P_[6] + w1 * P_[7] + w2 * P_[8];                                                  \
-            sm[NU + 2 * DC + a] += jf0 * Jc_[0][a] + jf1 * Jc_[1][a] - (w0 * P_[9] + w1 * P_[10] + w2 * P_[11]);      \
+            sm[NU + DC + a] -= Jc_[0][a] * y_[0] + Jc_[1][a] * y_[1];                                                 \
+            sm[NU + 2 * DC + a] += Jc_[0][a] * z_[0] + Jc_[1][a] * z_[1];                                             \
             sm[NU + 3 * DC + a] += Jc_[0][a] * Jc_[0][a] + Jc_[1][a] * Jc_[1][a];                                     \
-            _Pragma("unroll") for (int b = a; b < DC; b++)                                                            \
-                sm[u++] += Jc_[0][a] * Jc_[0][b] + Jc_[1][a] * Jc_[1][b] - (t0 * Wm[b][0] + t1 * Wm[b][1] + t2 * Wm[b][2]); \
+            _Pragma("unroll") for (int b = a; b < DC; b++) sm[u++] += e0 * Jc_[0][b] + e1 * Jc_[1][b];                \
         }                                                                                                             \
     } while (0)
     double Xa[3], Pa[12], wa; double2 oa;
@@ -468,27 +472,28 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
         const int slot_ = __builtin_amdgcn_readfirstlane(batch_slot[bt_]);                                            \
         if (slot_ != cur) { if (cur >= 0) fold(); cur = slot_; }                                                      \
         const int c2_ = __builtin_amdgcn_readfirstlane(col_idx[rb + slot_]);                                          \
-        double T_[DC][3];                                                                                             \
+        /* block -= Jc_i^T (Jp_i Vs Jp_j^T) Jc_j : the 2x2 core first, W = Jc^T Jp is never formed */                 \
+        double Jc_[2][DC], Q_[2][3];                                                                                  \
         {                                                                                                             \
             ObsLin L_; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X_, o_.x, o_.y, loss, la, L_);                  \
-            double Jc_[2][DC]; cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                             \
-            _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                          \
-                const double w0 = (Jc_[0][a] * L_.Jp[0][0] + Jc_[1][a] * L_.Jp[1][0]) * wgt_;                         \
-                const double w1 = (Jc_[0][a] * L_.Jp[0][1] + Jc_[1][a] * L_.Jp[1][1]) * wgt_;                         \
-                const double w2 = (Jc_[0][a] * L_.Jp[0][2] + Jc_[1][a] * L_.Jp[1][2]) * wgt_;                         \
-                T_[a][0] = w0 * V_[0] + w1 * V_[1] + w2 * V_[2];                                                      \
-                T_[a][1] = w0 * V_[1] + w1 * V_[3] + w2 * V_[4];                                                      \
-                T_[a][2] = w0 * V_[2] + w1 * V_[4] + w2 * V_[5];                                                      \
+            cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                                                \
+            _Pragma("unroll") for (int r = 0; r < 2; r++) {                                                           \
+                const double j0 = L_.Jp[r][0] * wgt_, j1 = L_.Jp[r][1] * wgt_, j2 = L_.Jp[r][2] * wgt_;               \
+                Q_[r][0] = j0 * V_[0] + j1 * V_[1] + j2 * V_[2];                                                      \
+                Q_[r][1] = j0 * V_[1] + j1 * V_[3] + j2 * V_[4];                                                      \
+                Q_[r][2] = j0 * V_[2] + j1 * V_[4] + j2 * V_[5];                                                      \
             }                                                                                                         \
         }                                                                                                             \
         ObsLin L2_; lin_obs<DC == 6>(f, cam + 6 * c2_, rot + 27 * c2_, X_, o2_.x, o2_.y, loss, la, L2_);              \
         double Jc2_[2][DC]; cam_block<DC>(L2_, scale_cam + 6 * c2_, Jc2_);                                            \
-        _Pragma("unroll") for (int b = 0; b < DC; b++) {                                                              \
-            const double w0 = Jc2_[0][b] * L2_.Jp[0][0] + Jc2_[1][b] * L2_.Jp[1][0];                                  \
-            const double w1 = Jc2_[0][b] * L2_.Jp[0][1] + Jc2_[1][b] * L2_.Jp[1][1];                                  \
-            const double w2 = Jc2_[0][b] * L2_.Jp[0][2] + Jc2_[1][b] * L2_.Jp[1][2];                                  \
-            _Pragma("unroll") for (int a = 0; a < DC; a++) blk[a][b] -= T_[a][0] * w0 + T_[a][1] * w1 + T_[a][2] * w2; \
-        }                                                                                                             \
+        double C_[2][2], D_[2][DC];                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 2; r++)                                                                 \
+            _Pragma("unroll") for (int q = 0; q < 2; q++)                                                             \
+                C_[r][q] = Q_[r][0] * L2_.Jp[q][0] + Q_[r][1] * L2_.Jp[q][1] + Q_[r][2] * L2_.Jp[q][2];               \
+        _Pragma("unroll") for (int r = 0; r < 2; r++)                                                                 \
+            _Pragma("unroll") for (int b = 0; b < DC; b++) D_[r][b] = C_[r][0] * Jc2_[0][b] + C_[r][1] * Jc2_[1][b];  \
+        _Pragma("unroll") for (int a = 0; a < DC; a++)                                                                \
+            _Pragma("unroll") for (int b = 0; b < DC; b++) blk[a][b] -= Jc_[0][a] * D_[0][b] + Jc_[1][a] * D_[1][b];  \
     } while (0)
     double Xa[3], Va[6], wa; double2 oa, o2a;
     double Xb[3], Vb[6], wb; double2 ob, o2b;
