@@ -105,12 +105,33 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
 struct ObsLin {
     double r[2], Jf[2], Jt[2][3], Jr[2][3], Jp[2][3], half_rho;
 };
+// fp64 reciprocal / reciprocal square root from the hardware estimates + two Newton steps each (the IEEE division and sqrt sequences
+// are 14-15 instructions; every re-linearised observation paid one division for 1/z, one for rho' and one sqrt)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+// sqrt(rho'(s)) of robust_loss (ssfm_math.h): Cauchy 1/sqrt(1 + s/a^2) is ONE reciprocal square root
+__device__ __forceinline__ double loss_sqrt_weight(int type, double a, double s) {
+    if (type == 1) return fast_rsqrt(1.0 + s * fast_rcp(a * a));
+    if (type == 2) return sqrt(fast_rsqrt(1.0 + s * fast_rcp(a * a)));      // SoftLOne: rho' = (1 + s/a^2)^(-1/2)
+    return 1.0;
+}
 __device__ __forceinline__ bool project(double f, const double* t, const double* R, const double* X, double ox, double oy,
                                         double& xp, double& yp, double& iz, double& r0, double& r1) {
     const double p0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
     const double p1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
     const double p2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
-    iz = 1.0 / p2; xp = p0 * iz; yp = p1 * iz;
+    iz = fast_rcp(p2); xp = p0 * iz; yp = p1 * iz;
     r0 = f * xp - ox; r1 = f * yp - oy;
     return true;
 }
@@ -124,8 +145,8 @@ __device__ __forceinline__ void lin_obs(double f, const double* t, const double*
                                         int loss, double la, ObsLin& L) {
     const double* R = rot; const double* Rd = rot + 9; const double* Mm = rot + 18;
     double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
-    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);
-    const double sr = sqrt(rho1);
+    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);      // only rho(s) is used from here: dead code where the cost is not
+    const double sr = loss_sqrt_weight(loss, la, r0 * r0 + r1 * r1);
     L.half_rho = 0.5 * rho0;
     L.r[0] = sr * r0; L.r[1] = sr * r1;
     L.Jf[0] = sr * xp; L.Jf[1] = sr * yp;
@@ -155,8 +176,8 @@ constexpr int OBS_UNROLL = 3;
 __device__ __forceinline__ void lin_obs_point(double f, const double* t, const double* R, const double* X, double ox, double oy, int loss, double la,
                                               ObsPoint& L) {
     double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
-    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);
-    const double sr = sqrt(rho1);
+    double rho0, rho1; robust_loss(loss, la, r0 * r0 + r1 * r1, rho0, rho1);      // only rho(s) is used from here: dead code where the cost is not
+    const double sr = loss_sqrt_weight(loss, la, r0 * r0 + r1 * r1);
     L.half_rho = 0.5 * rho0;
     L.r[0] = sr * r0; L.r[1] = sr * r1;
     L.Jf[0] = sr * xp; L.Jf[1] = sr * yp;

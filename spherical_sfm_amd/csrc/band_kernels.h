@@ -23,14 +23,6 @@ namespace ssfm {
 // latency of the global prefetches / write-backs that the LDS-resident kernels deliberately leave in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ double fast_rsqrt(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
-}
-
 // Band row(s) of camera c from its row of S.  The workgroup owns band row i = pos[c] (its blocks all come from S row c): clear it,
 // then scatter.  A separator camera of a twisted component owns a second row i2 behind the reversed segment: blocks whose column
 // lies there go to that row.  S may hold both triangles (pose graphs): only blocks inside the band of a row are taken.
