@@ -198,6 +198,18 @@ __device__ __forceinline__ void cam_block(const ObsLin& L, const double* sc6, do
     }
 }
 
+// unscaled camera block (the pair kernel applies the Jacobi scales once per folded block instead of once per pair)
+template <int DC>
+__device__ __forceinline__ void cam_block_raw(const ObsLin& L, double (&Jc)[2][DC]) {
+    if (DC == 6) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Jc[0][k] = L.Jt[0][k]; Jc[1][k] = L.Jt[1][k]; Jc[0][3 + k] = L.Jr[0][k]; Jc[1][3 + k] = L.Jr[1][k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Jc[0][k] = L.Jr[0][k]; Jc[1][k] = L.Jr[1][k]; }
+    }
+}
+
 // ---- K0: per-camera rotation tables ----------------------------------------------------------------
 static __global__ void k_cam_rot(const double* __restrict__ cam, double* __restrict__ rot, int Nc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,18 +498,23 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 #pragma unroll
             for (int b = 0; b < DC; b++) { flat[a * DC + b] = blk[a][b]; blk[a][b] = 0.0; }
         const double v = wave_transpose_sum(flat);
-        if (tr_slot < BB) unsafeAtomicAdd(&dst[tr_slot], v);
+        if (tr_slot < BB) {                                // Jacobi scales of both cameras, once per folded block
+            constexpr int off = (DC == 6) ? 0 : 3;
+            const int a = tr_slot / DC, b = tr_slot - a * DC, c2f = col_idx[rb + cur];
+            unsafeAtomicAdd(&dst[tr_slot], v * scale_cam[6 * c + off + a] * scale_cam[6 * c2f + off + b]);
+        }
     };
 #define SP2_COMPUTE(bt_, X_, V_, o_, o2_, wgt_)                                                                       \
     do {                                                                                                              \
         const int slot_ = __builtin_amdgcn_readfirstlane(batch_slot[bt_]);                                            \
         if (slot_ != cur) { if (cur >= 0) fold(); cur = slot_; }                                                      \
         const int c2_ = __builtin_amdgcn_readfirstlane(col_idx[rb + slot_]);                                          \
-        /* block -= Jc_i^T (Jp_i Vs Jp_j^T) Jc_j : the 2x2 core first, W = Jc^T Jp is never formed */                 \
+        /* block -= Jc_i^T (Jp_i Vs Jp_j^T) Jc_j : the 2x2 core first, W = Jc^T Jp is never formed; unscaled Jc (scales at the  \
+           fold); for 6-dof blocks d/dt = [a 0 -a x; 0 a -a y]: its two zeros are skipped explicitly */               \
         double Jc_[2][DC], Q_[2][3];                                                                                  \
         {                                                                                                             \
             ObsLin L_; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X_, o_.x, o_.y, loss, la, L_);                  \
-            cam_block<DC>(L_, scale_cam + 6 * c, Jc_);                                                                \
+            cam_block_raw<DC>(L_, Jc_);                                                                               \
             _Pragma("unroll") for (int r = 0; r < 2; r++) {                                                           \
                 const double j0 = L_.Jp[r][0] * wgt_, j1 = L_.Jp[r][1] * wgt_, j2 = L_.Jp[r][2] * wgt_;               \
                 Q_[r][0] = j0 * V_[0] + j1 * V_[1] + j2 * V_[2];                                                      \
@@ -506,15 +523,23 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
             }                                                                                                         \
         }                                                                                                             \
         ObsLin L2_; lin_obs<DC == 6>(f, cam + 6 * c2_, rot + 27 * c2_, X_, o2_.x, o2_.y, loss, la, L2_);              \
-        double Jc2_[2][DC]; cam_block<DC>(L2_, scale_cam + 6 * c2_, Jc2_);                                            \
+        double Jc2_[2][DC]; cam_block_raw<DC>(L2_, Jc2_);                                                             \
         double C_[2][2], D_[2][DC];                                                                                   \
         _Pragma("unroll") for (int r = 0; r < 2; r++)                                                                 \
             _Pragma("unroll") for (int q = 0; q < 2; q++)                                                             \
                 C_[r][q] = Q_[r][0] * L2_.Jp[q][0] + Q_[r][1] * L2_.Jp[q][1] + Q_[r][2] * L2_.Jp[q][2];               \
         _Pragma("unroll") for (int r = 0; r < 2; r++)                                                                 \
-            _Pragma("unroll") for (int b = 0; b < DC; b++) D_[r][b] = C_[r][0] * Jc2_[0][b] + C_[r][1] * Jc2_[1][b];  \
+            _Pragma("unroll") for (int b = 0; b < DC; b++) {                                                          \
+                if (DC == 6 && b == 0) D_[r][b] = C_[r][0] * Jc2_[0][0];                                              \
+                else if (DC == 6 && b == 1) D_[r][b] = C_[r][1] * Jc2_[1][1];                                         \
+                else D_[r][b] = C_[r][0] * Jc2_[0][b] + C_[r][1] * Jc2_[1][b];                                        \
+            }                                                                                                         \
         _Pragma("unroll") for (int a = 0; a < DC; a++)                                                                \
-            _Pragma("unroll") for (int b = 0; b < DC; b++) blk[a][b] -= Jc_[0][a] * D_[0][b] + Jc_[1][a] * D_[1][b];  \
+            _Pragma("unroll") for (int b = 0; b < DC; b++) {                                                          \
+                if (DC == 6 && a == 0) blk[a][b] -= Jc_[0][0] * D_[0][b];                                             \
+                else if (DC == 6 && a == 1) blk[a][b] -= Jc_[1][1] * D_[1][b];                                        \
+                else blk[a][b] -= Jc_[0][a] * D_[0][b] + Jc_[1][a] * D_[1][b];                                        \
+            }                                                                                                         \
     } while (0)
     double Xa[3], Va[6], wa; double2 oa, o2a;
     double Xb[3], Vb[6], wb; double2 ob, o2b;
