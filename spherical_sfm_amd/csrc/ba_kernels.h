@@ -161,13 +161,13 @@ __device__ __forceinline__ void lin_obs(double f, const double* t, const double*
         B0[k] = A0[0] * Rd[k] + A0[2] * Rd[6 + k];
         B1[k] = A1[1] * Rd[3 + k] + A1[2] * Rd[6 + k];
     }
-    // Y = [X]x M  (column k = X x M[:,k]);  Jr = -(A Rd) Y
+    // Jr = -(A Rd) [X]x M.  B . (X x m) = (B x X) . m: two cross products with X instead of three
+    const double w0[3] = {B0[1] * X[2] - B0[2] * X[1], B0[2] * X[0] - B0[0] * X[2], B0[0] * X[1] - B0[1] * X[0]};
+    const double w1[3] = {B1[1] * X[2] - B1[2] * X[1], B1[2] * X[0] - B1[0] * X[2], B1[0] * X[1] - B1[1] * X[0]};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const double m0 = Mm[k], m1 = Mm[3 + k], m2 = Mm[6 + k];
-        const double y0 = X[1] * m2 - X[2] * m1, y1 = X[2] * m0 - X[0] * m2, y2 = X[0] * m1 - X[1] * m0;
-        L.Jr[0][k] = -(B0[0] * y0 + B0[1] * y1 + B0[2] * y2);
-        L.Jr[1][k] = -(B1[0] * y0 + B1[1] * y1 + B1[2] * y2);
+        L.Jr[0][k] = -(w0[0] * Mm[k] + w0[1] * Mm[3 + k] + w0[2] * Mm[6 + k]);
+        L.Jr[1][k] = -(w1[0] * Mm[k] + w1[1] * Mm[3 + k] + w1[2] * Mm[6 + k]);
     }
 }
 // point-side view of the same linearisation (no camera blocks, R only): residual, focal column, point block
