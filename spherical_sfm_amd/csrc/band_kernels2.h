@@ -93,20 +93,49 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     // REVERSED order, holds the Schur update and the forward-substitution share of the reversed segment: block (s, s-d) takes the
     // transpose of the copy's block (b-1-s+d, d).  The whole separator sits in the initial window (b < R), so merging is free here.
     const int mf = merge_from ? merge_from[blockIdx.x] : -1;
-    for (int row = r0; row < min(r0 + R, re); row++) {
-        const int s = row - r0;
-        for (int e = tid; e < RW; e += nt) {
-            double v = band[(size_t)row * RW + e];
-            if (mf >= 0) {
-                const int d = e / BB, rc = e - d * BB, a = rc / DC, a2 = rc - a * DC;
-                if (d <= s) v += band[((size_t)(mf + b - 1 - s + d) * W + d) * BB + a2 * DC + a];
+    if (mf < 0) {
+        // the first window is one contiguous piece of the band: eight loads per lane in flight before the first LDS write (a plain
+        // row-by-row copy pays one memory round trip per row: ~10 us of the 56 us of a 32-pivot segment)
+        const int nrow0 = min(r0 + R, re) - r0, total = nrow0 * RW;
+        const double* src = band + (size_t)r0 * RW;
+        for (int base = 0; base < total; base += 8 * nt) {
+            double tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) tmp[u] = src[min(base + u * nt + tid, total - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = base + u * nt + tid;
+                if (idx < total) { const int rr = idx / RW, e = idx - rr * RW; sWin[(size_t)((r0 + rr) % R) * RW + e] = tmp[u]; }
             }
-            sWin[(size_t)(row % R) * RW + e] = v;
         }
-        for (int e = tid; e < NR * DC; e += nt) {
-            double v = Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)];
-            if (mf >= 0) v += Y[(size_t)(e / DC) * n + (size_t)(mf + b - 1 - s) * DC + (e % DC)];
-            sYr[(size_t)(row % R) * NR * DC + e] = v;
+        for (int idx = tid; idx < nrow0 * NR * DC; idx += nt) {
+            const int rr = idx / (NR * DC), e = idx - rr * (NR * DC);
+            sYr[(size_t)((r0 + rr) % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)(r0 + rr) * DC + (e % DC)];
+        }
+    } else {
+        // separator of a twisted component: same batching, two sources per entry (the copy's block (b-1-s+d, d), transposed)
+        const int nrow0 = min(r0 + R, re) - r0, total = nrow0 * RW;
+        const double* src = band + (size_t)r0 * RW;
+        for (int base = 0; base < total; base += 8 * nt) {
+            double tmp[8], tmp2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = min(base + u * nt + tid, total - 1);
+                const int s = idx / RW, e = idx - s * RW, d = e / BB, rc = e - d * BB, a = rc / DC, a2 = rc - a * DC;
+                tmp[u] = src[idx];
+                const int dd = min(d, s);                                  // clamped address; entries with d > s take nothing
+                const double v2 = band[((size_t)(mf + b - 1 - s + dd) * W + dd) * BB + a2 * DC + a];
+                tmp2[u] = (d <= s) ? v2 : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = base + u * nt + tid;
+                if (idx < total) { const int rr = idx / RW, e = idx - rr * RW; sWin[(size_t)((r0 + rr) % R) * RW + e] = tmp[u] + tmp2[u]; }
+            }
+        }
+        for (int idx = tid; idx < nrow0 * NR * DC; idx += nt) {
+            const int s = idx / (NR * DC), e = idx - s * (NR * DC);
+            sYr[(size_t)((r0 + s) % R) * NR * DC + e] = Y[(size_t)(e / DC) * n + (size_t)(r0 + s) * DC + (e % DC)] + Y[(size_t)(e / DC) * n + (size_t)(mf + b - 1 - s) * DC + (e % DC)];
         }
     }
     __syncthreads();
