@@ -63,7 +63,13 @@ struct ssfm_ba_handle {
     DevBuf<double> cam_x, cam_c, cam_init, pts_x, pts_c, pts_init, focal3;   // focal3: [x, cand, init]
     DevBuf<double> rot_x, rot_c, scale_cam, scale_pt, scale_f, mask_cam, mask_pt, mask_f, diag_cam, diag_pt, diag_f;
     DevBuf<double> obs_xy; DevBuf<int> obs_cam, obs_pt, pt_start, cam_start, cam_obs, row_ptr, col_idx, diag_slot;
-    DevBuf<double> zone; bool zone_views = false;      // BA: scal, pcg and redbuf are views into zone (zeroed by one memset per iteration)
+    // BA: scal, pcg and redbuf are views into one of two zones; an LM iteration works in one while the memset of the other (for the next
+    // iteration) is already queued behind it, off the host's critical path
+    DevBuf<double> zone; bool zone_views = false; size_t zone_len = 0, zone_nnz = 0, zone_n = 0;
+    void set_zone(int which) {
+        scal.p = zone.p + (size_t)which * zone_len; pcg.p = scal.p + scal.n; redbuf.p = pcg.p + pcg.n;
+        S_val = redbuf.p; rhs = S_val + zone_nnz; Udiag = rhs + (zone_n + 1); Sfc = Udiag + zone_n; gcraw = Sfc + zone_n; red_scal = gcraw + zone_n;
+    }
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
@@ -78,6 +84,8 @@ struct ssfm_ba_handle {
     double* host_stage = nullptr; size_t host_stage_n = 0;   // pinned staging of the parameter upload when a plan is reused
     bool scale_ready = false;
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
+    // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
+    struct { bool on = false, residual_later = false; const double *cam = nullptr, *focal = nullptr; double *cam_c = nullptr, *focal_c = nullptr, *rot_c = nullptr; } tail;
     int pcg_prev_iters = 16;
     // profiling
     bool profile = false;
@@ -331,14 +339,19 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     h->band_filled = false;
     { const int rc = direct(h->Yb.p); if (rc) return rc; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
-    if (F.sym_lower) {
+    if (F.sym_lower && h->tail.on) {
+        LAUNCH(h, KID_PCG_MATVEC, k_arrow_update<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
+               h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p, h->tail.cam, h->tail.focal, h->scale_cam.p, h->scale_f.p,
+               h->tail.cam_c, h->tail.focal_c, h->tail.rot_c, h->scal.p);
+    } else if (F.sym_lower) {
         LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
                h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p);
     } else {
         LAUNCH(h, KID_BAND_COMBINE, k_band_combine<DC>, 1, 1024, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, Nc, h->px.p);
         MATVEC(h, DC, h->px.p);
     }
-    LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
+    if (!h->tail.residual_later)     // (else: an extra workgroup of k_point_backsub does it)
+        LAUNCH(h, KID_REF_VEC, k_ref_residual<DC>, 1, 1024, 0, h->rhs, h->pq.p, h->px.p, h->Sfc, h->Sff.p, Nc, tol2, h->pr.p, h->pcg.p);
     *iters_out = 0; *ok_out = true;
     return SSFM_OK;
     }

@@ -958,6 +958,101 @@ k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, c
     }
 }
 
+// ---- K3a': k_arrow_matvec and k_cam_update in one launch (the usual tail of an LM iteration): every wave owns one camera -- its row of
+// q = S x for the residual check, its part of the step x, its candidate parameters and their rotation tables; the two camera norms
+// go to the replicated scalar slots by one atomic pair per workgroup.  Saves a single-workgroup launch (7 us) per iteration.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
+               const double* __restrict__ rho_ptr, const int* __restrict__ pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
+               const int* __restrict__ trans_ptr, const int* __restrict__ trans_blk, const int* __restrict__ trans_row,
+               const double* __restrict__ S_val, int Nc, double* __restrict__ x, double* __restrict__ q,
+               const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
+               const double* __restrict__ scale_f, double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c,
+               double* __restrict__ scal) {
+    __shared__ double red[2 * 4];
+    __shared__ double part[4][64];
+    __shared__ double part2[4][2];
+    __shared__ double sphi;
+    constexpr int BB = DC * DC;
+    constexpr int LW = (64 / DC) * DC;
+    constexpr int off = (DC == 6) ? 0 : 3;
+    const int n = Nc * DC, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double acc[2] = {0, 0};
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a; acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi]; }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) sphi = (rho_ptr[0] - acc[0]) / (Sff[0] - acc[1]);
+    __syncthreads();
+    const double phi = sphi;
+    const int c = blockIdx.x * 4 + w;
+    if (lane < 2) part2[w][lane] = 0.0;
+    if (c < Nc) {
+        const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tb = trans_ptr[c], nt = trans_ptr[c + 1] - tb;
+        double s = 0.0;
+        if (lane < LW) {
+            const int a = lane % DC;
+            for (int idx = lane; idx < (nnb + nt) * DC; idx += LW) {
+                const int b = idx / DC;
+                const int col = (b < nnb) ? col_idx[rb + b] : trans_row[tb + (b - nnb)];
+                const int pc = pos[col] * DC;
+                double xv[DC];
+#pragma unroll
+                for (int k = 0; k < DC; k++) xv[k] = V[pc + k] - U[pc + k] * phi;
+                if (b < nnb) {
+                    const double* row = S_val + ((size_t)(rb + b)) * BB + a * DC;
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += row[k] * xv[k];
+                } else {
+                    const double* blk = S_val + (size_t)trans_blk[tb + (b - nnb)] * BB;      // block (row r, col c): use its transpose
+#pragma unroll
+                    for (int k = 0; k < DC; k++) s += blk[k * DC + a] * xv[k];
+                }
+            }
+        }
+        part[w][lane] = s;
+        // candidate camera: lanes 0..5 hold its six parameters
+        double v = 0.0, d2 = 0.0, v2 = 0.0;
+        if (lane < 6) {
+            v = cam[c * 6 + lane];
+            const double sc = scale_cam[c * 6 + lane];
+            if (sc > 0.0 && lane >= off) {
+                const int pi = pos[c] * DC + (lane - off);
+                const double d = -(V[pi] - U[pi] * phi) * sc;
+                v += d; d2 = d * d; v2 = v * v;
+            }
+            cam_c[c * 6 + lane] = v;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { d2 += __shfl_xor(d2, o, 64); v2 += __shfl_xor(v2, o, 64); }
+        const double aa[3] = {__shfl(v, 3, 64), __shfl(v, 4, 64), __shfl(v, 5, 64)};
+        if (lane == 0) {
+            part2[w][0] = d2; part2[w][1] = v2;
+            double R[9], Rd[9], M[9];
+            angle_axis_derivative_aid(aa, R, Rd, M);
+            for (int i = 0; i < 9; i++) { rot_c[c * 27 + i] = R[i]; rot_c[c * 27 + 9 + i] = Rd[i]; rot_c[c * 27 + 18 + i] = M[i]; }
+        }
+    }
+    __syncthreads();
+    if (c < Nc && lane < DC) {
+        double s = 0.0;
+        for (int l = lane; l < LW; l += DC) s += part[w][l];
+        q[c * DC + lane] = s + Sfc[c * DC + lane] * phi;
+        const int pi = pos[c] * DC + lane;
+        x[c * DC + lane] = V[pi] - U[pi] * phi;
+    }
+    if (threadIdx.x == 0) {
+        double a0 = part2[0][0] + part2[1][0] + part2[2][0] + part2[3][0], a1 = part2[0][1] + part2[1][1] + part2[2][1] + part2[3][1];
+        if (blockIdx.x == 0) {
+            x[n] = phi;
+            double vf = focal[0]; const double sf = scale_f[0];
+            if (sf > 0.0) { const double d = -phi * sf; vf += d; a0 += d * d; a1 += vf * vf; }
+            focal_c[0] = vf;
+        }
+        double* sl = scal_slot(scal);
+        unsafeAtomicAdd(&sl[SC_STEP2_CAM], a0); unsafeAtomicAdd(&sl[SC_XN2_CAM], a1);
+    }
+}
+
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
 //   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
 //   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
@@ -968,8 +1063,33 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
                 const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
                 const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
                 const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
-                const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal) {
+                const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
+                // residual check of the reduced solve (what k_ref_residual does), by one extra workgroup behind the point workgroups when
+                // res_r is given: the single-workgroup launch leaves the critical path of the iteration
+                const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
+                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg) {
     __shared__ double red[4 * 4];
+    if (res_r && blockIdx.x == gridDim.x - 1) {
+        __shared__ double sqf;
+        const int n = Nc * DC;
+        double a0[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += blockDim.x) a0[0] += res_Sfc[i] * y[i];
+        block_sum<1>(a0, red);
+        if (threadIdx.x == 0) sqf = res_Sff[0] * y[n] + a0[0];
+        __syncthreads();
+        double a2[2] = {0.0, 0.0};
+        for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+            const double qi = (i < n) ? res_q[i] : sqf;
+            const double ri = res_b[i] - qi; res_r[i] = ri;
+            a2[0] += ri * ri; a2[1] += res_b[i] * res_b[i];
+        }
+        block_sum<2>(a2, red);
+        if (threadIdx.x == 0) {
+            res_pcg[PCG_RR] = a2[0]; res_pcg[PCG_BN2] = a2[1]; res_pcg[PCG_ITERS] = 0.0; res_pcg[PCG_BREAKDOWN] = 0.0;
+            res_pcg[PCG_DONE] = (a2[0] <= res_tol2 * a2[1]) ? 1.0 : 0.0;
+        }
+        return;
+    }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
     if (p < nP) {

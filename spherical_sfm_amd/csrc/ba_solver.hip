@@ -54,6 +54,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         }
     };
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
+    h->set_zone(0);
     LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
     if (!h->scale_ready) {
@@ -79,6 +80,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     double x_norm = std::sqrt(host_scal[SC_X0N2_PT] + host_scal[SC_X0N2_CAM]);
 
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + h->zone_len, 0, h->zone_len * sizeof(double), st));   // zone of iteration 1
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0;
     double x_cost = 0.0, minimum_cost = std::numeric_limits<double>::max();
     int iteration = 0, num_invalid = 0;
@@ -96,7 +98,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
         iteration++;
         // ================= assemble at x with the current radius =================
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));   // scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]
+        // this iteration's zone (scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]) was zeroed behind the previous iteration
+        h->set_zone(iteration & 1);
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0)
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
@@ -137,23 +140,34 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         // iteration scalars in ONE host synchronisation.  Only if the residual test failed (rare) does PCG refinement
         // run and the tail get redone.
         int pcg_iters = 0; bool pcg_ok = false;
-        { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
+        // with the banded factor and the lower-triangle storage the arrow kernel of the solve also writes the candidate cameras
+        const bool fused_cams = O.preconditioner == 0 && F.sym_lower;
+        const bool residual_later = fused_cams && nP > 0;
+        h->tail.on = fused_cams; h->tail.residual_later = residual_later; h->tail.cam = cam_x; h->tail.focal = fx; h->tail.cam_c = cam_c; h->tail.focal_c = fc; h->tail.rot_c = rot_c;
+        { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); h->tail.on = false; h->tail.residual_later = false; if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
-        auto enqueue_tail = [&]() -> int {
+        auto enqueue_tail = [&](bool with_cams) -> int {
             // candidate cameras + their rotation tables; then per point: back-substitution, candidate, model cost change, candidate cost
-            LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p, Nc <= 1024 ? 1 : 0);
-            if (Nc > 1024) LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
-            if (nP > 0)
-                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
-                       h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p);
+            if (with_cams) {
+                LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p, Nc <= 1024 ? 1 : 0);
+                if (Nc > 1024) LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
+            }
+            if (nP > 0) {
+                const bool res = !with_cams && residual_later;      // first pass of the iteration: the residual check rides along
+                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                       h->scale_pt.p, h->scale_f.p, h->Vinv.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                       h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p);
+            }
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
-            hipError_t e = hipMemcpyAsync(host_sp, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
+            hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;
         };
-        { int rc = enqueue_tail(); if (rc) return rc; }
+        { int rc = enqueue_tail(!fused_cams); if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
+        // the next iteration's zone is cleared while the host wakes up and decides
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         SSFM_HIP_CHECK(ctx, hipGetLastError());                      // a launch that was refused (bad configuration) must not pass silently
         fold_host_scal();
@@ -163,7 +177,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             else if (host_pcg1[PCG_DONE] == 0.0) {
                 int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 1); if (rc) return rc;
                 SSFM_HIP_CHECK(ctx, hipMemset2DAsync(h->scal.p + SC_MODEL, SC_TOTAL * sizeof(double), 0, 4 * sizeof(double), SC_NSLOT, st));   // MODEL..CAND_COST of every replica
-                rc = enqueue_tail(); if (rc) return rc;
+                SSFM_HIP_CHECK(ctx, hipMemset2DAsync(h->scal.p + SC_STEP2_CAM, SC_TOTAL * sizeof(double), 0, 2 * sizeof(double), SC_NSLOT, st));   // and the camera norms
+                rc = enqueue_tail(true); if (rc) return rc;
                 SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 fold_host_scal();
             }
@@ -348,11 +363,11 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     h->n_red = (int)n_red;
     // [scal | pcg flags + factorisation fail word | redbuf] share one allocation: one memset per LM iteration zeroes them all,
     // and one copy brings both scalar groups back
-    AL(zone, SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red);
-    h->scal.p = h->zone.p; h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.p = h->zone.p + SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
-    h->redbuf.p = h->pcg.p + PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
-    h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * DC * DC; h->Udiag = h->rhs + (n + 1); h->Sfc = h->Udiag + n;
-    h->gcraw = h->Sfc + n; h->red_scal = h->gcraw + n;
+    // (two of them, each a multiple of 512 bytes so that the memset is a single fill: ba_handle.h set_zone)
+    h->zone_len = (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red + 63) / 64 * 64; h->zone_nnz = nnzb * DC * DC; h->zone_n = n;
+    AL(zone, 2 * h->zone_len);
+    h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
+    h->set_zone(0);
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
     // band: F.band_rows block rows of F.band_block x F.band_block blocks (>= cameras: twisted components carry a second copy of their
