@@ -81,6 +81,7 @@ struct ssfm_ba_handle {
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
     double* host_sp = nullptr;           // pinned read-back buffer of the LM loop
+    double* host_pub = nullptr; unsigned long long pub_seq = 0;   // k_publish target (coherent pinned memory) and its sequence number
     double* host_stage = nullptr; size_t host_stage_n = 0;   // pinned staging of the parameter upload when a plan is reused
     bool scale_ready = false;
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
@@ -117,6 +118,7 @@ struct ssfm_ba_handle {
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
+        if (host_pub) { (void)hipHostFree(host_pub); host_pub = nullptr; }
         if (host_stage) { (void)hipHostFree(host_stage); host_stage = nullptr; host_stage_n = 0; }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();

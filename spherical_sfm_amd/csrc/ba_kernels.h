@@ -1190,6 +1190,24 @@ k_scal_fold(double* __restrict__ scal, double* __restrict__ packed, int rank) {
     // zero, so the sum over ranks leaves every rank's maximum side by side and no second, max-type collective is needed)
     if (packed && lane == 0) { if (k < SC_NSUM) packed[k] = r; else if (k == SC_GMAX) packed[SC_NSUM + rank] = r; }
 }
+// End of an LM iteration: the folded scalars and the solver flags go straight into pinned host memory, then a sequence number the host
+// spins on -- no copy engine, no completion interrupt between the last kernel of an iteration and the host's decision.
+// ONE workgroup of SC_TOTAL * 64 lanes; wave 0 does all the host writes so that its system-scope fence orders them before the flag.
+static __global__ void __launch_bounds__(SC_TOTAL * 64)
+k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq) {
+    __shared__ double folded[SC_TOTAL];
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double v = scal[(size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k];
+    const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);
+    if (lane == 0) folded[k] = r;
+    __syncthreads();
+    if (k == 0) {
+        if (lane < SC_TOTAL) host_out[lane] = folded[lane];
+        else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = pcg[lane - SC_TOTAL];
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SC_TOTAL + PCG_TOTAL + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // after the all-reduce: sums back into replica 0, gradient max = max over the per-rank slots
 static __global__ void __launch_bounds__(64)
 k_scal_unpack(double* __restrict__ scal, const double* __restrict__ packed, int nranks) {

@@ -8,6 +8,7 @@
 //
 // Multi-GPU: points are sharded, cameras replicated.  Per LM iteration one RCCL all-reduce of
 // the partial reduced system [S | rhs | diag U | S_fc | J_c^T r | scalars] and one of the step scalars.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -45,7 +46,31 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     // only host round trip of the iteration)
     if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
     double* host_sp = h->host_sp;
-    double* host_scal = host_sp; double* host_pcg1 = host_sp + SC_NSLOT * SC_TOTAL;
+    // default: the last kernel of an iteration (k_publish) writes the folded scalars + flags into coherent pinned memory and the host
+    // spins on its sequence number; SSFM_LM_POLL=0: copy of all replicas + stream synchronisation + host fold
+    static const bool poll = !(std::getenv("SSFM_LM_POLL") && std::atoi(std::getenv("SSFM_LM_POLL")) == 0);
+    if (poll && !h->host_pub) {
+        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_pub, 32 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(h->host_pub, 0, 32 * sizeof(double));
+    }
+    double* host_scal = poll ? h->host_pub : host_sp; double* host_pcg1 = poll ? h->host_pub + SC_TOTAL : host_sp + SC_NSLOT * SC_TOTAL;
+    auto wait_iteration = [&]() -> int {
+        if (!poll || h->profile || (h->opt.verbose != 0)) SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (!poll) return SSFM_OK;
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_pub + SC_TOTAL + PCG_TOTAL + 1);
+        const unsigned long long want = h->pub_seq;
+        unsigned spins = 0;
+        while (*flag != want) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0) {                          // every millisecond or so: is the stream still alive?
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) { if (*flag == want) break; return fail(ctx, SSFM_ERR_HIP, "an LM iteration ended without publishing its scalars"); }
+                if (q != hipErrorNotReady) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(q));
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return SSFM_OK;
+    };
     auto fold_host_scal = [&]() {                                    // replicas -> replica 0 (sums; the gradient max by max)
         for (int k = 0; k < SC_TOTAL; k++) {
             double a = host_sp[k];
@@ -160,6 +185,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             }
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
+            if (poll) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->pcg.p, h->host_pub, ++h->pub_seq); return SSFM_OK; }
             hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;
@@ -168,9 +194,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         // the next iteration's zone is cleared while the host wakes up and decides
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        { int rc = wait_iteration(); if (rc) return rc; }
         SSFM_HIP_CHECK(ctx, hipGetLastError());                      // a launch that was refused (bad configuration) must not pass silently
-        fold_host_scal();
+        if (!poll) fold_host_scal();
         if (O.preconditioner == 0) {
             int fail_flag; std::memcpy(&fail_flag, &host_pcg1[PCG_TOTAL], sizeof(int));
             if (fail_flag) pcg_ok = false;
@@ -179,8 +205,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                 SSFM_HIP_CHECK(ctx, hipMemset2DAsync(h->scal.p + SC_MODEL, SC_TOTAL * sizeof(double), 0, 4 * sizeof(double), SC_NSLOT, st));   // MODEL..CAND_COST of every replica
                 SSFM_HIP_CHECK(ctx, hipMemset2DAsync(h->scal.p + SC_STEP2_CAM, SC_TOTAL * sizeof(double), 0, 2 * sizeof(double), SC_NSLOT, st));   // and the camera norms
                 rc = enqueue_tail(true); if (rc) return rc;
-                SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                fold_host_scal();
+                rc = wait_iteration(); if (rc) return rc;
+                if (!poll) fold_host_scal();
             }
         }
         h->pcg_prev_iters = pcg_iters; S->pcg_iterations_total += pcg_iters;
