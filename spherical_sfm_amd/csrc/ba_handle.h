@@ -1,6 +1,7 @@
 // spherical_sfm_amd -- state shared by the device solvers: the BA handle (also used by the pose-graph solver as the
 // container of its reduced system) and the reduced-system solve (banded Cholesky + PCG refinement, or block-Jacobi PCG).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -81,7 +82,7 @@ struct ssfm_ba_handle {
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
     double* host_sp = nullptr;           // pinned read-back buffer of the LM loop
-    double* host_pub = nullptr; unsigned long long pub_seq = 0;   // k_publish target (coherent pinned memory) and its sequence number
+    double* host_pub = nullptr;          // = ctx->host_pub once publish_alloc ran (k_publish target, coherent pinned memory)
     double* host_stage = nullptr; size_t host_stage_n = 0;   // pinned staging of the parameter upload when a plan is reused
     bool scale_ready = false;
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
@@ -118,7 +119,7 @@ struct ssfm_ba_handle {
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
-        if (host_pub) { (void)hipHostFree(host_pub); host_pub = nullptr; }
+        host_pub = nullptr;
         if (host_stage) { (void)hipHostFree(host_stage); host_stage = nullptr; host_stage_n = 0; }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
@@ -158,6 +159,41 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     const int rc = ctx_allreduce(h->ctx, buf, n, op);
     h->span_end();
     return rc;
+}
+
+// ---- end-of-iteration hand-over to the host without a copy or a stream synchronisation (k_publish, ba_kernels.h) ----
+static bool lm_poll() {
+    static const bool on = !(std::getenv("SSFM_LM_POLL") && std::atoi(std::getenv("SSFM_LM_POLL")) == 0);
+    return on;
+}
+static int publish_alloc(ssfm_ba_handle* h) {
+    ssfm_ctx* ctx = h->ctx;
+    if (!ctx->host_pub) {
+        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_pub, 32 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(ctx->host_pub, 0, 32 * sizeof(double));
+    }
+    h->host_pub = ctx->host_pub;
+    return SSFM_OK;
+}
+static void publish(ssfm_ba_handle* h) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq);
+}
+// spin until the sequence number of the last publish() shows up; now and then ask the stream whether it is still alive
+static int wait_published(ssfm_ba_handle* h) {
+    ssfm_ctx* ctx = h->ctx;
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_pub + SC_TOTAL + PCG_TOTAL + 1);
+    const unsigned long long want = ctx->pub_seq;
+    unsigned spins = 0;
+    while (*flag != want) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0) {                          // every millisecond or so
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { if (*flag == want) break; return fail(ctx, SSFM_ERR_HIP, "an LM iteration ended without publishing its scalars"); }
+            if (q != hipErrorNotReady) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(q));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SSFM_OK;
 }
 
 // segment / separator tables of the substructured factorisation (band_sub.h) and its work buffers

@@ -41,35 +41,18 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
     constexpr int BB = DC * DC;
-    // k_schur_pairs: one LDS copy of the camera's (lower-triangle) block row + the camera constants
-    // [scalar replicas | solver flags], one copy per iteration, into pinned memory (a pageable target adds a staging hop to the
-    // only host round trip of the iteration)
-    if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
-    double* host_sp = h->host_sp;
+    // the only host round trip of an iteration = its scalars [sums | gradient max | solver flags].
     // default: the last kernel of an iteration (k_publish) writes the folded scalars + flags into coherent pinned memory and the host
-    // spins on its sequence number; SSFM_LM_POLL=0: copy of all replicas + stream synchronisation + host fold
-    static const bool poll = !(std::getenv("SSFM_LM_POLL") && std::atoi(std::getenv("SSFM_LM_POLL")) == 0);
-    if (poll && !h->host_pub) {
-        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_pub, 32 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-        std::memset(h->host_pub, 0, 32 * sizeof(double));
-    }
+    // spins on its sequence number (ba_handle.h lm_poll / publish_alloc / wait_published); SSFM_LM_POLL=0: copy of all replicas +
+    // stream synchronisation + host fold
+    const bool poll = lm_poll();
+    if (!poll && !h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
+    double* host_sp = h->host_sp;
+    if (poll) { const int rc = publish_alloc(h); if (rc) return rc; }
     double* host_scal = poll ? h->host_pub : host_sp; double* host_pcg1 = poll ? h->host_pub + SC_TOTAL : host_sp + SC_NSLOT * SC_TOTAL;
     auto wait_iteration = [&]() -> int {
         if (!poll || h->profile || (h->opt.verbose != 0)) SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (!poll) return SSFM_OK;
-        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_pub + SC_TOTAL + PCG_TOTAL + 1);
-        const unsigned long long want = h->pub_seq;
-        unsigned spins = 0;
-        while (*flag != want) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFu) == 0) {                          // every millisecond or so: is the stream still alive?
-                const hipError_t q = hipStreamQuery(st);
-                if (q == hipSuccess) { if (*flag == want) break; return fail(ctx, SSFM_ERR_HIP, "an LM iteration ended without publishing its scalars"); }
-                if (q != hipErrorNotReady) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(q));
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return SSFM_OK;
+        return poll ? wait_published(h) : SSFM_OK;
     };
     auto fold_host_scal = [&]() {                                    // replicas -> replica 0 (sums; the gradient max by max)
         for (int k = 0; k < SC_TOTAL; k++) {
@@ -185,7 +168,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             }
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
-            if (poll) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->pcg.p, h->host_pub, ++h->pub_seq); return SSFM_OK; }
+            if (poll) { publish(h); return SSFM_OK; }
             hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;

@@ -39,6 +39,7 @@ extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     g_dev_pool.drain(ctx->device);                               // recycled device buffers of this device
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->host_pub) (void)hipHostFree(ctx->host_pub);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

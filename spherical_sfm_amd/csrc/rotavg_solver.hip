@@ -289,8 +289,10 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
     const int ge = (E + 63) / 64, gn = (n + 63) / 64;
     const double la = O.loss_scale;
-    if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
-    double* host_scal = h->host_sp; double* host_pcg = h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
+    const bool poll = lm_poll();                                    // scalars published by the last kernel of an iteration (ba_handle.h)
+    if (poll) { const int rc = publish_alloc(h); if (rc) return rc; }
+    else if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
+    double* host_scal = poll ? h->host_pub : h->host_sp; double* host_pcg = poll ? h->host_pub + SC_TOTAL : h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
     auto assemble = [&](const double* s3, const double* sf) -> int {
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
         hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
@@ -331,6 +333,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
             hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
                                step.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
             hipLaunchKernelGGL(k_rot_cost, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xcand, fmc, h->scal.p + SC_CAND_COST);
+            if (poll) { publish(h); return wait_published(h); }
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             return SSFM_OK;
