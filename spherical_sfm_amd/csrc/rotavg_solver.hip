@@ -173,8 +173,18 @@ k_rot_update(int n_nodes, const double* __restrict__ x, const double* __restrict
     }
     block_sum<2>(acc, red);
     gmax = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&scal[SC_GMAX], gmax);
-    if (threadIdx.x == 0) { scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; }
+    if ((threadIdx.x & 63) == 0) red[32 + (threadIdx.x >> 6)] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) g = fmax(g, red[32 + w]);
+        scal[SC_GMAX] = g;                                          // overwrites what k_finalize_S left there (no memset in between)
+        scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1];
+    }
+}
+// Jacobi scales of the 3-dof nodes in the 6-wide camera layout the shared kernels expect: [0 0 0 | s]
+static __global__ void k_scale3to6(const double* __restrict__ s3, int n_nodes, double* __restrict__ s6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * n_nodes) { const int c = i / 6, k = i - 6 * c; s6[i] = (k >= 3) ? s3[3 * c + (k - 3)] : 0.0; }
 }
 
 struct RotGraph {
@@ -276,10 +286,12 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     ALV(xc, nn); ALV(sc3, nn); ALV(sc6, 6 * (size_t)n); ALV(scf, 1); ALV(step, nn + 1);
     const size_t n_red = nnzb * 9 + (nn + 1) + 3 * nn;
     // [scalar block x replicas | solver flags | S | rhs | ...] in one allocation: one memset per assembly, one copy per iteration
-    ALV(h->zone, SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red);
-    h->scal.p = h->zone.p; h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.p = h->zone.p + SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1;
-    h->redbuf.p = h->pcg.p + PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
-    h->S_val = h->redbuf.p; h->rhs = h->S_val + nnzb * 9; h->Udiag = h->rhs + (nn + 1); h->Sfc = h->Udiag + nn; h->gcraw = h->Sfc + nn;
+    // two of them: an iteration works in one while the memset of the other is queued behind its tail (ba_handle.h set_zone)
+    h->zone_len = (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1 + n_red + nn + 63) / 64 * 64; h->zone_nnz = nnzb * 9; h->zone_n = nn;
+    ALV(h->zone, 2 * h->zone_len);
+    h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
+    h->set_zone(0);
+    int zi = 0;
     ALV(h->Minv, (size_t)n * 9); ALV(h->Sff, 1); ALV(h->px, nn + 1); ALV(h->pr, nn + 1); ALV(h->pz, nn + 1); ALV(h->pp, nn + 1); ALV(h->pq, nn + 1);
     ALV(h->pqpart, (size_t)n);
     { const size_t Nb = (size_t)F.band_rows, DCB = (size_t)F.band_block, ny = (size_t)F.y_rows(3) * 3;
@@ -293,8 +305,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     if (poll) { const int rc = publish_alloc(h); if (rc) return rc; }
     else if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
     double* host_scal = poll ? h->host_pub : h->host_sp; double* host_pcg = poll ? h->host_pub + SC_TOTAL : h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
-    auto assemble = [&](const double* s3, const double* sf) -> int {
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
+    auto assemble = [&](const double* s3, const double* sf) -> int {      // into the current zone, which is clean
         hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
                            (const double*)nullptr, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
         return SSFM_OK;
@@ -306,12 +318,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         int rc = assemble(m3.p, mf.p); if (rc) return rc;
         hipLaunchKernelGGL(k_make_scale, dim3((3 * n + 255) / 256), dim3(256), 0, st, h->Udiag, m3.p, sc3.p, 3 * n, O.jacobi_scaling);
         hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->scal.p + SC_FJJ, mf.p, scf.p, 1, O.jacobi_scaling);
-        std::vector<double> s3h(nn), s6h((size_t)6 * n, 0.0);
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s3h.data(), sc3.p, nn * sizeof(double), hipMemcpyDeviceToHost, st));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) s6h[6 * i + 3 + k] = s3h[3 * i + k];
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(sc6.p, s6h.data(), s6h.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_scale3to6, dim3((6 * n + 255) / 256), dim3(256), 0, st, sc3.p, n, sc6.p);
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));              // m3 / mf go back to the pool
         m3.free(); mf.free();
     }
     double x_norm = 0; { double s2 = with_f ? 1.0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
@@ -322,23 +330,30 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
         iteration++;
+        zi ^= 1; h->set_zone(zi);
         { int rc = assemble(sc3.p, scf.p); if (rc) return rc; }
         LAUNCH(h, KID_FINALIZE, k_finalize_S<3>, gn, 64, 0, h->row_ptr.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal,
                O.max_lm_diagonal, n, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         int pcg_iters = 0; bool pcg_ok = false;
         { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
         auto tail = [&]() -> int {
-            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_GMAX, 0, sizeof(double), st));
             hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, xcand, fmc, step.p, h->scal.p);
             hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
                                step.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
             hipLaunchKernelGGL(k_rot_cost, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xcand, fmc, h->scal.p + SC_CAND_COST);
-            if (poll) { publish(h); return wait_published(h); }
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->zone.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (poll) publish(h);
+            else SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+            return SSFM_OK;
+        };
+        auto wait_tail = [&]() -> int {
+            if (poll) return wait_published(h);
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             return SSFM_OK;
         };
         { int rc = tail(); if (rc) return rc; }
+        // the other zone (the previous iteration's) is cleared while the host waits and decides
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)(zi ^ 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
+        { int rc = wait_tail(); if (rc) return rc; }
         if (O.preconditioner == 0) {
             int ff; std::memcpy(&ff, &host_pcg[PCG_TOTAL], sizeof(int));
             if (ff) pcg_ok = false;
@@ -346,6 +361,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
                 int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 1); if (rc) return rc;
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p + SC_MODEL, 0, 4 * sizeof(double), st));
                 rc = tail(); if (rc) return rc;
+                rc = wait_tail(); if (rc) return rc;
             }
         }
         S->pcg_iterations_total += pcg_iters; S->num_linearizations++;
