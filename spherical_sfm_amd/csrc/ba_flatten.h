@@ -71,6 +71,7 @@ struct BAFlat {
     // Schur pair lists (this rank's observations): for row c the entries (j, j2) = (observation of c, observation of the
     // same point by a camera c2 of row c), grouped by slot and padded with -1 to whole 64-lane batches.
     std::vector<int> pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr;
+    int task_batches = 8;               // batches per wave task of k_schur_pairs2 (pair_layout)
     int64_t pair_batches = 0;           // 64-entry batches of the pair lists (the lists themselves may live on the device only)
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
@@ -226,9 +227,7 @@ inline void pair_counts_host(const BAFlat& F, int NT, std::vector<int>& slot_cnt
 }
 // batches of every slot, wave tasks of <= task_batches batches of ONE camera; slot_off = first pair entry of every slot; returns the
 // number of 64-entry batches
-inline int64_t pair_layout(BAFlat& F, const std::vector<int>& slot_cnt, std::vector<int64_t>& slot_off) {
-    int task_batches = 8;                                    // batches per wave task of k_schur_pairs2 (tuning knob: SSFM_TASK_BATCHES)
-    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
+inline int64_t pair_layout(BAFlat& F, const std::vector<int>& slot_cnt, std::vector<int64_t>& slot_off, int num_cus = 256) {
     const int Nc = F.Nc;
     F.cam_batch_ptr.assign(Nc + 1, 0); F.batch_slot.clear(); F.chunk_cam.clear(); F.chunk_b0.clear(); F.chunk_b1.clear();
     slot_off.assign(F.col_idx.size(), 0);
@@ -243,11 +242,27 @@ inline int64_t pair_layout(BAFlat& F, const std::vector<int>& slot_cnt, std::vec
             nbatch += nb;
         }
         F.cam_batch_ptr[c + 1] = F.cam_batch_ptr[c] + nbatch; nbatch_total += nbatch;
+    }
+    // batches per wave task of k_schur_pairs2.  A workgroup = 4 tasks, the CUs take whole workgroups in rounds, and a task costs its
+    // batches + about one batch for the folds: 6..12 batches, whichever needs the least rounds x (batches + 1).  At config 2: 8 batches =
+    // 808 workgroups = 4 rounds on 256 CUs (36), 9 batches = 720 workgroups = 3 rounds (30): 3.31 -> 3.27 ms per solve, and the measured
+    // order of 6..12 follows the model.  SSFM_TASK_BATCHES overrides.
+    int task_batches = 8;
+    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
+    else {
+        int64_t best = -1;
+        for (int tb = 6; tb <= 12; tb++) {
+            int64_t tasks = 0;
+            for (int c = 0; c < Nc; c++) tasks += (F.cam_batch_ptr[c + 1] - F.cam_batch_ptr[c] + tb - 1) / tb;
+            const int64_t wgs = (tasks + 3) / 4, rounds = (wgs + num_cus - 1) / std::max(1, num_cus), cost = rounds * (tb + 1);
+            if (best < 0 || cost < best) { best = cost; task_batches = tb; }
+        }
+    }
+    for (int c = 0; c < Nc; c++)
         for (int b2 = F.cam_batch_ptr[c]; b2 < F.cam_batch_ptr[c + 1]; b2 += task_batches) {
             F.chunk_cam.push_back(c); F.chunk_b0.push_back(b2); F.chunk_b1.push_back(std::min(b2 + task_batches, F.cam_batch_ptr[c + 1]));
         }
-    }
-    F.pair_batches = nbatch_total;
+    F.pair_batches = nbatch_total; F.task_batches = task_batches;
     return nbatch_total;
 }
 inline void pair_fill_host(BAFlat& F, int NT, std::vector<int64_t>& slot_off) {
@@ -433,8 +448,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         F.cam_obs_pt.resize(F.M);
         for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
     }
+    int cs_run = 256;                                                  // entries per wave task of k_cam_sums2 (SSFM_CS_TASK_OBS, multiple of 64)
+    if (const char* e = std::getenv("SSFM_CS_TASK_OBS")) cs_run = std::max(64, std::atoi(e) / 64 * 64);
     for (int c = 0; c < Nc; c++)
-        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += 256) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + 256, F.cam_start[c + 1])); }
+        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += cs_run) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + cs_run, F.cam_start[c + 1])); }
     lap("camera-major lists");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     if (host_pairs) {

@@ -408,7 +408,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
             std::vector<int> slot_cnt(nnzb_s);
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(slot_cnt.data(), ctr.p, nnzb_s * sizeof(int), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            std::vector<int64_t> slot_off; const int64_t nbat = pair_layout(Fm, slot_cnt, slot_off);
+            std::vector<int64_t> slot_off; const int64_t nbat = pair_layout(Fm, slot_cnt, slot_off, ctx->num_cus);
             if (nbat * 64 >= (int64_t)1 << 31) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_create: more than 2^31 Schur pairs on one rank");
             std::vector<unsigned int> start(nnzb_s); for (size_t e = 0; e < nnzb_s; e++) start[e] = (unsigned int)slot_off[e];
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(ctr.p, start.data(), nnzb_s * sizeof(unsigned int), hipMemcpyHostToDevice, st));
