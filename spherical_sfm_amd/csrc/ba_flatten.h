@@ -248,7 +248,8 @@ inline int64_t pair_layout(BAFlat& F, const std::vector<int>& slot_cnt, std::vec
     // 808 workgroups = 4 rounds on 256 CUs (36), 9 batches = 720 workgroups = 3 rounds (30): 3.31 -> 3.27 ms per solve, and the measured
     // order of 6..12 follows the model.  SSFM_TASK_BATCHES overrides.
     int task_batches = 8;
-    if (const char* e = std::getenv("SSFM_TASK_BATCHES")) task_batches = std::max(1, std::atoi(e));
+    const char* e_tb = std::getenv("SSFM_TASK_BATCHES");
+    if (e_tb && std::atoi(e_tb) > 0) task_batches = std::atoi(e_tb);
     else {
         int64_t best = -1;
         for (int tb = 6; tb <= 12; tb++) {
@@ -286,7 +287,7 @@ inline void pair_fill_host(BAFlat& F, int NT, std::vector<int64_t>& slot_off) {
     });
 }
 
-inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F, bool host_pairs = true) {
+inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F, bool host_pairs = true, int num_cus = 256) {
     const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; const auto t = std::chrono::steady_clock::now();
@@ -448,8 +449,21 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         F.cam_obs_pt.resize(F.M);
         for (int64_t q = 0; q < F.M; q++) F.cam_obs_pt[q] = F.obs_pt[F.cam_obs[q]];
     }
-    int cs_run = 256;                                                  // entries per wave task of k_cam_sums2 (SSFM_CS_TASK_OBS, multiple of 64)
-    if (const char* e = std::getenv("SSFM_CS_TASK_OBS")) cs_run = std::max(64, std::atoi(e) / 64 * 64);
+    // entries per wave task of k_cam_sums2: 192..512, whichever needs the least rounds of workgroups (4 tasks each) over the CUs x
+    // (batches + 2 for the fold and its atomics) -- the same reasoning as pair_layout; 384 at config 2 (450 workgroups = 2 rounds
+    // instead of 600 = 3 with 256).  SSFM_CS_TASK_OBS overrides.
+    int cs_run = 256;
+    const char* e_cs = std::getenv("SSFM_CS_TASK_OBS");
+    if (e_cs && std::atoi(e_cs) > 0) cs_run = std::max(64, std::atoi(e_cs) / 64 * 64);
+    else {
+        int64_t best = -1;
+        for (int run = 192; run <= 512; run += 64) {
+            int64_t tasks = 0;
+            for (int c = 0; c < Nc; c++) tasks += (F.cam_start[c + 1] - F.cam_start[c] + run - 1) / run;
+            const int64_t wgs = (tasks + 3) / 4, rounds = (wgs + num_cus - 1) / std::max(1, num_cus), cost = rounds * (run / 64 + 2);
+            if (best < 0 || cost < best) { best = cost; cs_run = run; }
+        }
+    }
     for (int c = 0; c < Nc; c++)
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += cs_run) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + cs_run, F.cam_start[c + 1])); }
     lap("camera-major lists");

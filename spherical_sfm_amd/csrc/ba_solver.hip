@@ -334,7 +334,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
     g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_s = 0.0; g_alloc_n = 0;
     const double t_create0 = wall_s();
-    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs); h->t_flatten_s = wall_s() - tf; }
+    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs, ctx->num_cus); h->t_flatten_s = wall_s() - tf; }
     *out = h;
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
