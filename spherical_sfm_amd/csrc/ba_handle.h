@@ -162,18 +162,21 @@ static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
 }
 
 // ---- end-of-iteration hand-over to the host without a copy or a stream synchronisation (k_publish, ba_kernels.h) ----
-static bool lm_poll() {
-    static const bool on = !(std::getenv("SSFM_LM_POLL") && std::atoi(std::getenv("SSFM_LM_POLL")) == 0);
-    return on;
+static bool lm_poll() {                                             // read per solve (tests switch it within one process)
+    const char* e = std::getenv("SSFM_LM_POLL");
+    return !(e && std::atoi(e) == 0);
 }
-static int publish_alloc(ssfm_ba_handle* h) {
+// false: no coherent pinned block to be had -- the caller falls back to the copy + stream synchronisation hand-over
+static bool publish_alloc(ssfm_ba_handle* h) {
     ssfm_ctx* ctx = h->ctx;
     if (!ctx->host_pub) {
-        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_pub, 32 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+        if (hipHostMalloc((void**)&ctx->host_pub, 32 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError(); ctx->host_pub = nullptr; return false;
+        }
         std::memset(ctx->host_pub, 0, 32 * sizeof(double));
     }
     h->host_pub = ctx->host_pub;
-    return SSFM_OK;
+    return true;
 }
 static void publish(ssfm_ba_handle* h) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq);

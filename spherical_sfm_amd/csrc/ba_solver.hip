@@ -45,10 +45,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     // default: the last kernel of an iteration (k_publish) writes the folded scalars + flags into coherent pinned memory and the host
     // spins on its sequence number (ba_handle.h lm_poll / publish_alloc / wait_published); SSFM_LM_POLL=0: copy of all replicas +
     // stream synchronisation + host fold
-    const bool poll = lm_poll();
+    const bool poll = lm_poll() && publish_alloc(h);
     if (!poll && !h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
     double* host_sp = h->host_sp;
-    if (poll) { const int rc = publish_alloc(h); if (rc) return rc; }
     double* host_scal = poll ? h->host_pub : host_sp; double* host_pcg1 = poll ? h->host_pub + SC_TOTAL : host_sp + SC_NSLOT * SC_TOTAL;
     auto wait_iteration = [&]() -> int {
         if (!poll || h->profile || (h->opt.verbose != 0)) SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));

@@ -301,9 +301,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
     const int ge = (E + 63) / 64, gn = (n + 63) / 64;
     const double la = O.loss_scale;
-    const bool poll = lm_poll();                                    // scalars published by the last kernel of an iteration (ba_handle.h)
-    if (poll) { const int rc = publish_alloc(h); if (rc) return rc; }
-    else if (!h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
+    const bool poll = lm_poll() && publish_alloc(h);                // scalars published by the last kernel of an iteration (ba_handle.h)
+    if (!poll && !h->host_sp) SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_sp, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipHostMallocDefault));
     double* host_scal = poll ? h->host_pub : h->host_sp; double* host_pcg = poll ? h->host_pub + SC_TOTAL : h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
     auto assemble = [&](const double* s3, const double* sf) -> int {      // into the current zone, which is clean

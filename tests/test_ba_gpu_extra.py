@@ -136,3 +136,24 @@ def test_plan_cache_reuses_structure_and_detects_changes(gpu_ctx, oracle):
     tf = prob.trans_fixed.copy(); tf[7] = 1
     c5, p5, f5, s5 = ba.optimize(gpu_ctx, dataclasses.replace(prob, trans_fixed=tf))
     assert s5["t_flatten_s"] > 0.0 and np.array_equal(c5[7, :3], prob.cameras[7, :3])
+
+
+@pytest.mark.parametrize("spherical", [True, False])
+def test_copy_and_synchronise_handover_matches_the_published_scalars(gpu_ctx, oracle, monkeypatch, spherical):
+    """SSFM_LM_POLL=0: the end-of-iteration scalars come back by a device->host copy + stream synchronisation + host fold instead
+    of k_publish into pinned memory; same LM run, same answer (the folds differ in summation order only)."""
+    from spherical_sfm_amd import ba, rotavg
+    p = synth.make_circle(48, 1200, 6, spherical=spherical, focal_fixed=False)
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    monkeypatch.setenv("SSFM_LM_POLL", "0")
+    cams0, pts0, f0, s0 = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == s0["termination"] == os_["termination"] == 0 and s["iterations"] == s0["iterations"] == os_["iterations"]
+    assert rel_err(cams, cams0) <= 1e-9 and point_rel_err(pts, pts0) <= 1e-9 and abs(f - f0) <= 1e-9 * f0
+    assert rel_err(cams0, ocams) <= 1e-5 and point_rel_err(pts0, opts) <= 1e-5
+    R0, i0, i1, Rrel, _ = synth.make_rotation_graph(40, 4, seed=3, outlier_frac=0.0)
+    Ra, ca, sa = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel)
+    monkeypatch.delenv("SSFM_LM_POLL")
+    Rb, cb, sb = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel)
+    assert sa["iterations"] == sb["iterations"] and np.abs(Ra - Rb).max() <= 1e-9
