@@ -2,9 +2,10 @@
 //
 // Replaces what ceres::Solve does for SfM::Optimize (reference src/sfm.cpp:273-289): the trust-region loop
 // of Ceres 2.2.0 (TrustRegionMinimizer + LevenbergMarquardtStrategy, restated -- Ceres is not vendored in the
-// reference), with the SPARSE_SCHUR direct solve replaced by an explicit block-sparse Schur complement and a
-// block-Jacobi PCG that never leaves the GPU.  One host synchronisation per LM iteration (a 128-byte read of
-// the scalar block) drives accept/reject, radius update and the termination tests.
+// reference), with the SPARSE_SCHUR direct solve done by an explicit block-sparse Schur complement and an exact block-banded
+// Cholesky of the reduced camera system on the GPU (band_kernels2.h, band_sub.h; a block-Jacobi PCG is kept for comparison).
+// One hand-over to the host per LM iteration: the last kernel publishes the 16 folded scalars + solver flags into coherent
+// pinned memory, the host spins on a sequence number and decides accept/reject, radius update and the termination tests.
 //
 // Multi-GPU: points are sharded, cameras replicated.  Per LM iteration one RCCL all-reduce of
 // the partial reduced system [S | rhs | diag U | S_fc | J_c^T r | scalars] and one of the step scalars.
