@@ -181,6 +181,13 @@ static bool publish_alloc(ssfm_ba_handle* h) {
 static void publish(ssfm_ba_handle* h) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq);
 }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 // spin until the sequence number of the last publish() shows up; now and then ask the stream whether it is still alive
 static int wait_published(ssfm_ba_handle* h) {
     ssfm_ctx* ctx = h->ctx;
@@ -188,7 +195,7 @@ static int wait_published(ssfm_ba_handle* h) {
     const unsigned long long want = ctx->pub_seq;
     unsigned spins = 0;
     while (*flag != want) {
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((++spins & 0xFFFFu) == 0) {                          // every millisecond or so
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) { if (*flag == want) break; return fail(ctx, SSFM_ERR_HIP, "an LM iteration ended without publishing its scalars"); }
