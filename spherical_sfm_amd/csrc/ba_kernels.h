@@ -958,6 +958,21 @@ k_cam_update(const double* __restrict__ cam, const double* __restrict__ focal, c
     }
 }
 
+// The two dot products of the focal step phi = (rho - S_fc . v) / (S_ff - S_fc . u) in `gridDim.x` contiguous parts, for camera sets
+// where the per-workgroup recomputation in k_arrow_update (O(Nc) per workgroup, O(Nc^2) in total: 70 us at 4000 cameras) costs more than
+// a launch.  The parts are summed in a fixed order by the reader: every rank of a multi-GPU solve gets the same bits.
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_arrow_phi(const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const int* __restrict__ pos, int Nc,
+            double* __restrict__ part) {
+    __shared__ double red[2 * 4];
+    const int n = Nc * DC, per = (n + gridDim.x - 1) / gridDim.x, t0 = blockIdx.x * per, t1 = min(n, t0 + per);
+    double acc[2] = {0, 0};
+    for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) { const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a; acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi]; }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = acc[0]; part[2 * blockIdx.x + 1] = acc[1]; }
+}
+
 // ---- K3a': k_arrow_matvec and k_cam_update in one launch (the usual tail of an LM iteration): every wave owns one camera -- its row of
 // q = S x for the residual check, its part of the step x, its candidate parameters and their rotation tables; the two camera norms
 // go to the replicated scalar slots by one atomic pair per workgroup.  Saves a single-workgroup launch (7 us) per iteration.
@@ -969,7 +984,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
                const double* __restrict__ S_val, int Nc, double* __restrict__ x, double* __restrict__ q,
                const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
                const double* __restrict__ scale_f, double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c,
-               double* __restrict__ scal) {
+               double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts) {
     __shared__ double red[2 * 4];
     __shared__ double part[4][64];
     __shared__ double part2[4][2];
@@ -978,12 +993,19 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
     constexpr int LW = (64 / DC) * DC;
     constexpr int off = (DC == 6) ? 0 : 3;
     const int n = Nc * DC, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double acc[2] = {0, 0};
-    for (int t = threadIdx.x; t < n; t += blockDim.x) { const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a; acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi]; }
-    block_sum<2>(acc, red);
-    if (threadIdx.x == 0) sphi = (rho_ptr[0] - acc[0]) / (Sff[0] - acc[1]);
-    __syncthreads();
-    const double phi = sphi;
+    double phi;
+    if (phi_parts > 0) {                                            // large camera sets: the dot products come from k_arrow_phi
+        double a0 = 0.0, a1 = 0.0;
+        for (int b = 0; b < phi_parts; b++) { a0 += phi_part[2 * b]; a1 += phi_part[2 * b + 1]; }
+        phi = (rho_ptr[0] - a0) / (Sff[0] - a1);
+    } else {                                                          // small ones: every workgroup recomputes it (no extra launch)
+        double acc[2] = {0, 0};
+        for (int t = threadIdx.x; t < n; t += blockDim.x) { const int c = t / DC, a = t - c * DC; const int pi = pos[c] * DC + a; acc[0] += Sfc[t] * V[pi]; acc[1] += Sfc[t] * U[pi]; }
+        block_sum<2>(acc, red);
+        if (threadIdx.x == 0) sphi = (rho_ptr[0] - acc[0]) / (Sff[0] - acc[1]);
+        __syncthreads();
+        phi = sphi;
+    }
     const int c = blockIdx.x * 4 + w;
     if (lane < 2) part2[w][lane] = 0.0;
     if (c < Nc) {
