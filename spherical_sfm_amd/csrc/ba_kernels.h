@@ -882,6 +882,27 @@ k_cam_lists(int M, const int* __restrict__ obs_cam, const int* __restrict__ obs_
     const unsigned int w = atomicAdd(&cursor[obs_cam[j]], 1u);
     cam_obs[w] = j; cam_obs_pt[w] = obs_pt[j];
 }
+// The same for <= 4096 cameras with one global atomic per (workgroup, camera) instead of one per observation: a workgroup ranks its
+// 4096 observations per camera in LDS, reserves every camera's run with one add, then writes.  (600k same-address-heavy atomics on
+// 300 cursors took 0.55 ms at config 2, 12M on 4000 took 6 ms.)
+constexpr int CAM_LISTS_MAX_CAMS = 4096, CAM_LISTS_CHUNK = 4096;
+static __global__ void __launch_bounds__(256)
+k_cam_lists_agg(int M, int Nc, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt, unsigned int* __restrict__ cursor,
+                int* __restrict__ cam_obs, int* __restrict__ cam_obs_pt) {
+    __shared__ unsigned int cnt[CAM_LISTS_MAX_CAMS];
+    constexpr int PER = CAM_LISTS_CHUNK / 256;
+    for (int c = threadIdx.x; c < Nc; c += blockDim.x) cnt[c] = 0u;
+    __syncthreads();
+    const int j0 = blockIdx.x * CAM_LISTS_CHUNK + threadIdx.x;
+    int cc[PER]; unsigned int rk[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int j = j0 + u * 256; if (j < M) { cc[u] = obs_cam[j]; rk[u] = atomicAdd(&cnt[cc[u]], 1u); } }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Nc; c += blockDim.x) { const unsigned int n = cnt[c]; if (n) cnt[c] = atomicAdd(&cursor[c], n); }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int j = j0 + u * 256; if (j < M) { const unsigned int w = cnt[cc[u]] + rk[u]; cam_obs[w] = j; cam_obs_pt[w] = obs_pt[j]; } }
+}
 // ... then every camera's segment is put back in ascending observation order (= ascending point order: neighbouring lanes of
 // k_cam_sums2 read neighbouring points; the unsorted lists cost it 2 us per launch): bitonic sort in LDS, segments of <= 4096 entries
 static __global__ void __launch_bounds__(256)
@@ -906,22 +927,54 @@ k_cam_lists_sort(const int* __restrict__ cam_start, const int* __restrict__ obs_
         }
     for (int i = threadIdx.x; i < n; i += blockDim.x) { const int j = sv[i]; cam_obs[q0 + i] = j; cam_obs_pt[q0 + i] = obs_pt[j]; }
 }
+// A workgroup's 256 camera-major entries belong to one or two cameras, so its pairs fall into a short contiguous run of slots
+// [row_ptr[first camera], row_ptr[last camera + 1]): they are counted in LDS, every slot's run is reserved with ONE global add, and
+// (FILL) a second walk over the same pairs writes them at run start + LDS rank.  One global atomic per pair (all lanes of a
+// workgroup on the same ~10 counters) took 0.47 + 0.54 ms at config 2 and 4.9 + 9.5 ms at the configs[4] size.  Runs longer
+// than PAIR_LISTS_SLOTS (many tiny cameras in one workgroup) keep the direct atomics.
+constexpr int PAIR_LISTS_SLOTS = 2048;
 template <bool FILL>
 static __global__ void __launch_bounds__(256)
 k_pair_lists(int M, const int* __restrict__ cam_obs, const int* __restrict__ cam_obs_pt, const int* __restrict__ obs_cam,
              const int* __restrict__ pt_start, const int* __restrict__ elim_pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
              unsigned int* __restrict__ slot_ctr, int* __restrict__ pair_j, int* __restrict__ pair_j2, int* __restrict__ pair_p) {
+    __shared__ unsigned int cnt[PAIR_LISTS_SLOTS];
+    __shared__ unsigned int base[FILL ? PAIR_LISTS_SLOTS : 1];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= M) return;
-    const int j = cam_obs[q], p = cam_obs_pt[q], c = obs_cam[j];
-    const int pc = elim_pos[c], rb = row_ptr[c], nnb = row_ptr[c + 1] - rb;
-    for (int j2 = pt_start[p]; j2 < pt_start[p + 1]; j2++) {
+    const int q_first = blockIdx.x * blockDim.x, q_last = min(M, q_first + (int)blockDim.x) - 1;
+    const int s0 = row_ptr[obs_cam[cam_obs[q_first]]], s1 = row_ptr[obs_cam[cam_obs[q_last]] + 1];     // camera-major: cameras ascend with q
+    const bool local = (s1 - s0) <= PAIR_LISTS_SLOTS;
+    if (local) { for (int i = threadIdx.x; i < s1 - s0; i += blockDim.x) cnt[i] = 0u; __syncthreads(); }
+    int j = 0, p = 0, c = 0, pc = 0, rb = 0, nnb = 0, ja = 0, jb = 0;
+    if (q < M) { j = cam_obs[q]; p = cam_obs_pt[q]; c = obs_cam[j]; pc = elim_pos[c]; rb = row_ptr[c]; nnb = row_ptr[c + 1] - rb; ja = pt_start[p]; jb = pt_start[p + 1]; }
+    for (int j2 = ja; j2 < jb; j2++) {
         const int c2 = obs_cam[j2];
         if (!(elim_pos[c2] < pc)) continue;
         int lo = 0, hi = nnb;                                    // first column >= c2
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (col_idx[rb + mid] < c2) lo = mid + 1; else hi = mid; }
-        const unsigned int w = atomicAdd(&slot_ctr[rb + lo], 1u);
-        if (FILL) { pair_j[w] = j; pair_j2[w] = j2; pair_p[w] = p; }
+        if (local) atomicAdd(&cnt[rb + lo - s0], 1u);
+        else {
+            const unsigned int w = atomicAdd(&slot_ctr[rb + lo], 1u);
+            if (FILL) { pair_j[w] = j; pair_j2[w] = j2; pair_p[w] = p; }
+        }
+    }
+    if (!local) return;                                          // (uniform over the workgroup)
+    __syncthreads();
+    for (int i = threadIdx.x; i < s1 - s0; i += blockDim.x) {
+        const unsigned int n = cnt[i];
+        if (n) { const unsigned int b = atomicAdd(&slot_ctr[s0 + i], n); if (FILL) base[i] = b; }
+        if (FILL) cnt[i] = 0u;
+    }
+    if (!FILL) return;
+    __syncthreads();
+    for (int j2 = ja; j2 < jb; j2++) {
+        const int c2 = obs_cam[j2];
+        if (!(elim_pos[c2] < pc)) continue;
+        int lo = 0, hi = nnb;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (col_idx[rb + mid] < c2) lo = mid + 1; else hi = mid; }
+        const int sl = rb + lo - s0;
+        const unsigned int w = base[sl] + atomicAdd(&cnt[sl], 1u);
+        pair_j[w] = j; pair_j2[w] = j2; pair_p[w] = p;
     }
 }
 

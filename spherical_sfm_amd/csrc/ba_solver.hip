@@ -354,7 +354,11 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
         DevBuf<unsigned int> cur;
         SSFM_HIP_CHECK(ctx, h->cam_obs.alloc((size_t)F.M)); SSFM_HIP_CHECK(ctx, h->cam_obs_pt.alloc((size_t)F.M)); SSFM_HIP_CHECK(ctx, cur.alloc((size_t)Nc));
         hipError_t e1 = hipMemcpyAsync(cur.p, h->cam_start.p, (size_t)Nc * sizeof(int), hipMemcpyDeviceToDevice, st);
-        hipLaunchKernelGGL(k_cam_lists, dim3((unsigned)((F.M + 255) / 256)), dim3(256), 0, st, (int)F.M, h->obs_cam.p, h->obs_pt.p, cur.p, h->cam_obs.p, h->cam_obs_pt.p);
+        if (Nc <= CAM_LISTS_MAX_CAMS)
+            hipLaunchKernelGGL(k_cam_lists_agg, dim3((unsigned)((F.M + CAM_LISTS_CHUNK - 1) / CAM_LISTS_CHUNK)), dim3(256), 0, st, (int)F.M, Nc, h->obs_cam.p, h->obs_pt.p, cur.p,
+                               h->cam_obs.p, h->cam_obs_pt.p);
+        else
+            hipLaunchKernelGGL(k_cam_lists, dim3((unsigned)((F.M + 255) / 256)), dim3(256), 0, st, (int)F.M, h->obs_cam.p, h->obs_pt.p, cur.p, h->cam_obs.p, h->cam_obs_pt.p);
         hipLaunchKernelGGL(k_cam_lists_sort, dim3(Nc), dim3(256), 0, st, h->cam_start.p, h->obs_pt.p, h->cam_obs.p, h->cam_obs_pt.p);
         hipError_t e2 = hipStreamSynchronize(st);
         cur.free();
