@@ -24,9 +24,9 @@ enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PC
                 KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
-                                              "k_arrow_matvec", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
+                                              "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
-                                              "k_band_back_v2", "k_band_combine", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
+                                              "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
                                               "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left"};
 
 static bool g_alloc_timing = false; static double g_alloc_s = 0.0; static int g_alloc_n = 0;   // SSFM_PLAN_TIMING: time spent in hipMalloc
