@@ -117,3 +117,16 @@ def test_long_three_dof_component_merged_and_cut(gpu_ctx, oracle, monkeypatch):
     ocams, opts, of, os_ = oracle.ba_solve(p)
     assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
     assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_shared_focal_free_above_1024_cameras(gpu_ctx, oracle, monkeypatch, spherical):
+    """More than 1024 cameras with the shared focal free: the two dot products of the focal step come from k_arrow_phi (contiguous
+    parts summed in a fixed order) instead of being recomputed by every workgroup of k_arrow_update."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_circle(1100, 33000, 6, spherical=spherical, focal_fixed=False, seed=12)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
