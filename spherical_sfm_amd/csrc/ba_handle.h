@@ -71,6 +71,7 @@ struct ssfm_ba_handle {
         scal.p = zone.p + (size_t)which * zone_len; pcg.p = scal.p + scal.n; redbuf.p = pcg.p + pcg.n;
         S_val = redbuf.p; rhs = S_val + zone_nnz; Udiag = rhs + (zone_n + 1); Sfc = Udiag + zone_n; gcraw = Sfc + zone_n; red_scal = gcraw + zone_n;
     }
+    DevBuf<double> lmdev;                 // [go, radius] of the device-side step decision (k_publish -> speculative k_point_lin)
     DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
@@ -112,7 +113,7 @@ struct ssfm_ba_handle {
         rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
-        band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
+        lmdev.free(); band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
@@ -178,8 +179,9 @@ static bool publish_alloc(ssfm_ba_handle* h) {
     h->host_pub = ctx->host_pub;
     return true;
 }
-static void publish(ssfm_ba_handle* h) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq);
+static void publish(ssfm_ba_handle* h, const LmGate* gate = nullptr, double* spec = nullptr) {
+    LmGate g; std::memset(&g, 0, sizeof(g)); if (gate) g = *gate;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq, g, spec);
 }
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)

@@ -274,8 +274,11 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
             const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
             int loss, double la, double radius, double min_diag, double max_diag,
-            double* __restrict__ Vinv, double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal) {
+            double* __restrict__ Vinv, double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal,
+            const double* __restrict__ spec) {
     __shared__ double red[5 * 4];
+    // spec (speculative launch behind k_publish of the previous iteration): [go, radius] as decided on the device
+    if (spec) { if (spec[0] == 0.0) return; radius = spec[1]; }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[5] = {0, 0, 0, 0, 0};   // cost, FJJ, FJR, FWW, FWG
     double gmax = 0.0;
@@ -1268,8 +1271,16 @@ k_scal_fold(double* __restrict__ scal, double* __restrict__ packed, int rank) {
 // End of an LM iteration: the folded scalars and the solver flags go straight into pinned host memory, then a sequence number the host
 // spins on -- no copy engine, no completion interrupt between the last kernel of an iteration and the host's decision.
 // ONE workgroup of SC_TOTAL * 64 lanes; wave 0 does all the host writes so that its system-scope fence orders them before the flag.
+// LmGate: what the host knows when it queues the end of iteration k -- enough for the device to decide "step accepted, go on" by the
+// rules of the host loop (ba_solver.hip) and to compute the next trust-region radius.  The decision only gates a speculative launch of
+// the next iteration's k_point_lin (queued before the host has seen the scalars); the host decides for itself and stays authoritative.
+struct LmGate {
+    int enabled, last_successful;
+    double radius, x_norm, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius;
+};
 static __global__ void __launch_bounds__(SC_TOTAL * 64)
-k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq) {
+k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
+          const LmGate gate, double* __restrict__ spec) {
     __shared__ double folded[SC_TOTAL];
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double v = scal[(size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k];
@@ -1279,6 +1290,29 @@ k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, doubl
     if (k == 0) {
         if (lane < SC_TOTAL) host_out[lane] = folded[lane];
         else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = pcg[lane - SC_TOTAL];
+        if (spec && lane == 0) {
+            double go = 0.0, new_radius = gate.radius;
+            if (gate.enabled) {
+                int fail_word; { const double fw = pcg[PCG_TOTAL]; __builtin_memcpy(&fail_word, &fw, sizeof(int)); }
+                const double x_cost = folded[SC_COST], gmax = folded[SC_GMAX], model = -folded[SC_MODEL], cand = folded[SC_CAND_COST];
+                bool ok = isfinite(x_cost) && !(gate.last_successful && gmax <= gate.gradient_tolerance);
+                ok = ok && fail_word == 0 && pcg[PCG_DONE] != 0.0 && isfinite(model) && model > 0.0 && isfinite(cand);
+                const double step_norm = sqrt(folded[SC_STEP2_PT] + folded[SC_STEP2_CAM]);
+                ok = ok && !(step_norm <= gate.parameter_tolerance * (gate.x_norm + gate.parameter_tolerance));
+                const double cost_change = x_cost - cand;
+                ok = ok && !(fabs(cost_change) <= gate.function_tolerance * x_cost);
+                const double rel = cost_change / model;
+                ok = ok && rel > gate.min_relative_decrease;
+                if (ok) {
+                    const double t = 2.0 * rel - 1.0;
+                    new_radius = fmin(gate.max_radius, gate.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                    ok = new_radius > gate.min_radius;
+                }
+                go = ok ? 1.0 : 0.0;
+            }
+            spec[0] = go; spec[1] = new_radius;
+            host_out[SC_TOTAL + PCG_TOTAL + 2] = go; host_out[SC_TOTAL + PCG_TOTAL + 3] = new_radius;
+        }
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SC_TOTAL + PCG_TOTAL + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

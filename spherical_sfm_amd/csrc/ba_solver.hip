@@ -96,6 +96,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     S->num_successful_steps = 1; S->num_unsuccessful_steps = 0; S->num_linearizations = 0; S->pcg_iterations_total = 0;
     S->termination = SSFM_NO_CONVERGENCE;
     float ms_lin = 0, ms_schur = 0, ms_pcg = 0, ms_upd = 0;
+    // Speculation: k_publish also decides "accepted, go on" + the next radius on the device (LmGate), and the next iteration's
+    // k_point_lin is queued right behind it, reading both from device memory -- it runs while the host wakes up, decides and
+    // launches the rest.  The host's own decision stays authoritative: a speculative launch that should not have run only touched
+    // scratch arrays and the next zone, which is then cleared again.  SSFM_LM_SPECULATE=0 turns it off.
+    const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
+    const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
+    bool lin_done = false, spec_launched = false;
     // per-phase device times (summary.t_kernel_*_ms) cost five event records and four queries per iteration, the queries on the
     // host's critical path between two iterations: only with profiling on (ssfm_ba_set_profiling) or options.verbose
     const bool phases = h->profile || O.verbose;
@@ -109,9 +116,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         // this iteration's zone (scalars, solver flags, [S | rhs | diag U | S_fc | Jc^T r | sums]) was zeroed behind the previous iteration
         h->set_zone(iteration & 1);
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
-        if (nP > 0)
+        if (nP > 0 && !lin_done)             // (lin_done: it ran speculatively behind the previous iteration, with this radius)
             LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts_lm, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
-                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p);
+                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, h->scal.p, (const double*)nullptr);
+        lin_done = false;
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         if (!F.cs_task_cam.empty()) {
             const int ntasks = (int)F.cs_task_cam.size();
@@ -168,7 +176,16 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             }
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
-            if (poll) { publish(h); return SSFM_OK; }
+            if (poll) {
+                spec_launched = false;
+                if (spec_on && !with_cams && !(h->profile || O.verbose) && iteration < O.max_num_iterations) {
+                    LmGate g; g.enabled = 1; g.last_successful = last_successful ? 1 : 0; g.radius = radius; g.x_norm = x_norm;
+                    g.function_tolerance = O.function_tolerance; g.gradient_tolerance = O.gradient_tolerance; g.parameter_tolerance = O.parameter_tolerance;
+                    g.min_relative_decrease = O.min_relative_decrease; g.max_radius = O.max_trust_region_radius; g.min_radius = O.min_trust_region_radius;
+                    publish(h, &g, h->lmdev.p); spec_launched = true;
+                } else publish(h);
+                return SSFM_OK;
+            }
             hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
             if (e != hipSuccess) return fail(ctx, SSFM_ERR_HIP, hipGetErrorString(e));
             return SSFM_OK;
@@ -176,8 +193,19 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         { int rc = enqueue_tail(!fused_cams); if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         // the next iteration's zone is cleared while the host wakes up and decides
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
+        double* next_zone = h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len;
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
+        if (spec_launched)                   // x = this iteration's candidate, scalars into the next zone (scal is its first block)
+            LAUNCH(h, KID_POINT_LIN, k_point_lin, gp_pts_lm, PTB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
+                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vinv.p, h->Vs.p, h->gp.p, h->Wf.p, next_zone, (const double*)h->lmdev.p);
         { int rc = wait_iteration(); if (rc) return rc; }
+        // what the device decided for the speculative k_point_lin (it ran iff dev_go)
+        const bool dev_go = spec_launched && h->host_pub[SC_TOTAL + PCG_TOTAL + 2] == 1.0;
+        const double dev_radius = spec_launched ? h->host_pub[SC_TOTAL + PCG_TOTAL + 3] : 0.0;
+        auto undo_speculation = [&]() -> int {                       // the host goes another way: the next zone must be clean again
+            if (dev_go) SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
+            return SSFM_OK;
+        };
         SSFM_HIP_CHECK(ctx, hipGetLastError());                      // a launch that was refused (bad configuration) must not pass silently
         if (!poll) fold_host_scal();
         if (O.preconditioner == 0) {
@@ -211,6 +239,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (!valid) {
             if (++num_invalid >= O.max_num_consecutive_invalid_steps) { S->termination = SSFM_FAILURE; break; }
             radius /= decrease_factor; decrease_factor *= 2.0; last_successful = false; S->num_unsuccessful_steps++;
+            { int rc = undo_speculation(); if (rc) return rc; }
             if (O.verbose) std::printf("[ssfm ba] iter %4d invalid step (pcg %d its, model %.3e), radius %.3e\n", iteration, pcg_iters, model_cost_change, radius);
             continue;
         }
@@ -225,12 +254,16 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (rel > O.min_relative_decrease) {
             std::swap(cam_x, cam_c); std::swap(pts_x, pts_c); std::swap(rot_x, rot_c); std::swap(fx, fc);
             x_norm = std::sqrt(host_scal[SC_XN2_PT] + host_scal[SC_XN2_CAM]);
-            radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
-            radius = std::fmin(O.max_trust_region_radius, radius);
+            if (dev_go) { radius = dev_radius; lin_done = true; }     // the linearisation at the new x is already running with that radius
+            else {
+                radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+                radius = std::fmin(O.max_trust_region_radius, radius);
+            }
             decrease_factor = 2.0; last_successful = true; S->num_successful_steps++;
             x_cost = cand_cost; if (x_cost < minimum_cost) minimum_cost = x_cost;
         } else {
             radius /= decrease_factor; decrease_factor *= 2.0; last_successful = false; S->num_unsuccessful_steps++;
+            { int rc = undo_speculation(); if (rc) return rc; }
         }
         if (O.verbose)
             std::printf("[ssfm ba] iter %4d cost %.12e change %.3e |g|inf %.3e |step| %.3e rho %.3e radius %.3e pcg %d %s\n", iteration,
@@ -370,6 +403,7 @@ extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssf
     AL(cam_c, (size_t)Nc * 6); AL(pts_c, (size_t)nP * 3); AL(rot_x, (size_t)Nc * 27); AL(rot_c, (size_t)Nc * 27);
     AL(scale_cam, (size_t)Nc * 6); AL(scale_pt, (size_t)nP * 3); AL(scale_f, 1);
     AL(diag_cam, (size_t)Nc * 6); AL(diag_pt, (size_t)nP * 3); AL(diag_f, 1);
+    AL(lmdev, 2);
     AL(Vinv, (size_t)nP * 6); AL(Vs, (size_t)nP * 12); AL(gp, (size_t)nP * 3); AL(Wf, (size_t)nP * 3);
     const size_t nnzb = (size_t)F.row_ptr[Nc], n = (size_t)Nc * DC;
     const size_t n_red = nnzb * DC * DC + (n + 1) + 3 * n + SC_NSUM + (size_t)ctx->nranks;   // ... | scalar sums | gradient-max slot per rank
