@@ -350,7 +350,6 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
     const int Nc = F.Nc, n = Nc * DC, b = F.band;
     const int Nb = F.band_rows > 0 ? F.y_rows(DC) : Nc, nb = Nb * DC;      // rows (camera units) / stride of the right-hand-side columns in band order
-    constexpr int BB = DC * DC;
     const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
     if (O.preconditioner == 1) {
         if (stage == 1) return SSFM_OK;

@@ -31,7 +31,7 @@ template <int DC>
 static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
     const BAFlat& F = h->F; const ssfm_ba_options& O = h->opt;
-    const int Nc = F.Nc, nP = F.nP; const int n = Nc * DC;
+    const int Nc = F.Nc, nP = F.nP;
     const int loss = O.loss_type; const double la = O.loss_scale;
     const int gp_pts = (nP + 255) / 256, gp_cam = (Nc + 63) / 64;
     // lane-per-point kernels of the LM loop run as single-wave workgroups: 4x more workgroups spread evenly over the CUs
@@ -41,7 +41,6 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     double* fx = h->focal3.p; double* fc = h->focal3.p + 1;
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
     double* rot_x = h->rot_x.p; double* rot_c = h->rot_c.p;
-    constexpr int BB = DC * DC;
     // the only host round trip of an iteration = its scalars [sums | gradient max | solver flags].
     // default: the last kernel of an iteration (k_publish) writes the folded scalars + flags into coherent pinned memory and the host
     // spins on its sequence number (ba_handle.h lm_poll / publish_alloc / wait_published); SSFM_LM_POLL=0: copy of all replicas +

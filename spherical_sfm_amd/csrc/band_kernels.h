@@ -443,7 +443,7 @@ k_band_back_lds(const double* __restrict__ band, const double* __restrict__ Linv
     double* sX = lds;                               // ring [b][NR*DC]
     double* sPart = sX + (size_t)b * NR * DC;       // [b][NR*DC]
     double* sAcc = sPart + (size_t)b * NR * DC;     // NR*DC
-    const int W = b + 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x;
+    const int W = b + 1, n = N * DC, tid = threadIdx.x;
     const int r0 = comp_ptr[blockIdx.x], r1 = comp_ptr[blockIdx.x + 1];
     const int d = tid / DC + 1, a = tid - (d - 1) * DC;     // this lane's (offset, column) of the L column, valid if tid < b*DC
     const bool has = tid < b * DC;

@@ -275,7 +275,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
     // scale laid out 6 per node (slots 3..5) so that k_finalize_S<3> can be reused unchanged
     std::vector<double> mask6((size_t)6 * n, 0.0); for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) mask6[6 * i + 3 + k] = G.mask[3 * i + k];
-    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, redz; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
     std::vector<double> fmv = {1.0, 1.0};
 #define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
     UPV(x, G.x0); UPV(fm2, fmv); UPV(e0, G.e0); UPV(e1, G.e1); UPV(ec, G.ec);
