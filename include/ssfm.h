@@ -178,19 +178,45 @@ int ssfm_posegraph_focal_solve(ssfm_ctx* ctx, int32_t n, double* rotations, int3
  * u / v ([total*3]; u = first view, v = second view, as RayPair, include/sphericalsfm/ray.h:8-10).
  * squared_inlier_threshold = (inlier_threshold_px * Kinv(0,0))^2 (spherical_sfm_tools.cpp:315).
  * Outputs (any may be NULL): E, R [num_pairs*9] column-major; inlier_mask [total]; num_inliers, scores [num_pairs].
- * R is the identity where num_inliers <= min_num_inliers (the reference skips such pairs, :410). */
+ * R is the identity where num_inliers <= min_num_inliers (the reference skips such pairs, :410).
+ *
+ * mode: how the hypotheses of a pair are generated.
+ *   SSFM_RANSAC_REFERENCE_TRACE (default): RansacLib's LocallyOptimizedMSAC control flow, draw for draw -- both std::mt19937 streams
+ *     (seeded with `seed`, include/RansacLib/sampling.h:52, ransac.h:145-146) and libstdc++'s uniform_int_distribution are restated
+ *     on the device, so a pair evaluates the reference's minimal samples, runs LocalOptimization (ransac.h:341-407: the initial
+ *     least-squares fit on <= min_sample_multiplicator * 3 shuffled inliers, then num_lo_steps x [NonMinimalSolver + iterated fits])
+ *     at the reference's iterations, adapts max_num_iterations from the inlier ratio (utils.h:110-140) and stops where the reference
+ *     stops.  Differences to a CPU build are floating-point rounding.  A chunk of iterations is evaluated in parallel, one lane each.
+ *   SSFM_RANSAC_FIXED_BUDGET: num_hypotheses counter-based samples per pair scored in parallel, best one refined on its inliers
+ *     (no LO, no adaptive stopping; statistically equivalent result, more arithmetic). */
+#define SSFM_RANSAC_FIXED_BUDGET 0
+#define SSFM_RANSAC_REFERENCE_TRACE 1
 typedef struct {
-    int32_t num_hypotheses;      /* minimal samples per pair (fixed budget; default 1024) */
+    int32_t num_hypotheses;      /* FIXED_BUDGET: minimal samples per pair (default 1024) */
     uint32_t seed;               /* RansacOptions::random_seed_ (default 0) */
     int32_t min_num_inliers;     /* acceptance threshold of estimate_pairwise */
     int32_t final_least_squares; /* LORansacOptions::final_least_squares_ (default 1, spherical_sfm_tools.cpp:318) */
     int32_t inward;              /* SphericalEstimator(..., inward) */
     int32_t use_poly_solver;     /* SphericalEstimator(..., use_poly_solver, ...): 0 = action matrix (estimate_pairwise's choice), 1 = quartic */
+    int32_t mode;                /* SSFM_RANSAC_REFERENCE_TRACE */
+    uint32_t min_num_iterations, max_num_iterations;   /* RansacOptions: 100, 10000 (ransac.h:50-51) */
+    double success_probability;  /* 0.9999 (ransac.h:52) */
+    int32_t num_lo_steps;        /* estimate_pairwise sets 0 (spherical_sfm_tools.cpp:316); LORansacOptions default 10 */
+    int32_t num_lsq_iterations;  /* estimate_pairwise sets 0 (:317); default 4 */
+    double threshold_multiplier; /* sqrt(2) (ransac.h:67) */
+    int32_t min_sample_multiplicator;   /* 7: least-squares fits use <= 7 * 3 inliers (ransac.h:69,412); 1..21 */
+    int32_t non_min_sample_multiplier;  /* 3: non-minimal samples hold max(4, min(3 * 3, inliers / 2)) rays (ransac.h:70,369-373); 1..3 */
+    uint32_t lo_starting_iterations;    /* 50 (ransac.h:71) */
+    int32_t fast_shuffle;        /* 1: the draws of a Fisher-Yates tail that is thrown away are only checked for rejections, in parallel (same stream) */
 } ssfm_ransac_options;
 void ssfm_ransac_default_options(ssfm_ransac_options* o);
+/* stats: [num_pairs*2] = RansacStatistics::num_iterations, number_lo_iterations per pair (zeros in FIXED_BUDGET mode), or NULL.
+ * Pairs are streamed through the GPU in slabs (two pinned staging buffers, the upload of slab k+1 under the kernels of slab k), so one
+ * call may hold any number of pairs (BASELINE configs[3]: 2000 frames = 1 999 000 pairs); pairs with more than ~2700 correspondences
+ * keep their rays in HBM/L2 instead of LDS. */
 int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
                       double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
-                      int32_t* num_inliers, double* scores);
+                      int32_t* num_inliers, double* scores, uint32_t* stats);
 /* Multi-GPU form of the same call (BASELINE configs[3]: exhaustive pairwise RANSAC over several GPUs; the reference's
  * counterpart is the `#pragma omp parallel for` over matches, spherical_sfm_tools.cpp:332).  Every rank of the context's
  * communicator (ssfm_comm_init / ssfm_comm_init_host) passes the SAME full arguments; rank r estimates pairs r, r + nranks, ...
@@ -198,7 +224,24 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
  * bit-identical to ssfm_ransac_batch on one GPU.  Without a communicator it is ssfm_ransac_batch. */
 int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
                               double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R,
-                              uint8_t* inlier_mask, int32_t* num_inliers, double* scores);
+                              uint8_t* inlier_mask, int32_t* num_inliers, double* scores, uint32_t* stats);
+/* ---- deterministic probes of the estimator's pieces (parity tests; one workgroup per task) --------------------------------------
+ * ssfm_sampson_refine_probe: SphericalEstimator::LeastSquares (src/spherical_estimator.cpp:110-157) -- task t refines E_inout[t] (column-
+ *   major, in/out) on the rays lists[task_ptr[t] .. task_ptr[t+1]) of the ONE pair (u, v).
+ * ssfm_decompose_probe: decompose_spherical_essential_matrix (src/spherical_utils.cpp:16-66) + so3exp = SphericalEstimator::Decompose
+ *   (src/spherical_estimator.cpp:159-164): r_out [tasks*3] angle-axis, R_out [tasks*9] column-major (either may be NULL).
+ * ssfm_nonminimal_probe: SphericalEstimator::NonMinimalSolver (src/spherical_estimator.cpp:86-108) on samples of 3..9 rays.
+ * ssfm_so3_probe (row a9): what = 0 so3exp (src/so3.cpp:16-23), 1 so3ln (:25-69), 2 ceres::AngleAxisToRotationMatrix,
+ *   3 ceres::RotationMatrixToAngleAxis, as the device code evaluates them; matrices column-major.
+ * ssfm_mt19937_probe: nraw raw words of std::mt19937(seed), then uniform_int_distribution<int>(lo[i], hi[i]) draws from the same
+ *   engine, through the device generator of the reference-trace mode. */
+int ssfm_sampson_refine_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
+                              const int32_t* lists, int32_t inward, double* E_inout);
+int ssfm_decompose_probe(ssfm_ctx* ctx, int32_t tasks, const double* E, int32_t inward, double* r_out, double* R_out);
+int ssfm_nonminimal_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
+                          const int32_t* lists, double* E_out, int32_t* ok_out);
+int ssfm_so3_probe(ssfm_ctx* ctx, int32_t what, int32_t n, const double* in, double* out);
+int ssfm_mt19937_probe(ssfm_ctx* ctx, uint32_t seed, int32_t n, const int32_t* lo, const int32_t* hi, int32_t* draws, int32_t nraw, uint32_t* raw);
 /* parity probe: spherical_solver_action_matrix (src/spherical_solvers.cpp:102-311) on S given 3-point samples
  * (samples: [S*3] indices into the n rays).  Es: [S*36] = up to 4 column-major 3x3 per sample (real solutions only),
  * counts: [S]. */

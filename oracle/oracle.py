@@ -91,6 +91,12 @@ def lib():
         L.oracle_ransac_pair.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                          c_double_p, c_double_p, c_u8_p, C.POINTER(C.c_uint32), c_double_p]
         L.oracle_ransac_pair.restype = C.c_int
+        L.oracle_lomsac_pair.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_int32, C.c_double, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
+                                         C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, c_double_p, c_double_p,
+                                         c_u8_p, C.POINTER(C.c_uint32), c_double_p]
+        L.oracle_lomsac_pair.restype = C.c_int
+        L.oracle_nonminimal_solver.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p]; L.oracle_nonminimal_solver.restype = C.c_int
+        L.oracle_mt19937_draws.argtypes = [C.c_uint32, C.c_int32, c_i32_p, c_i32_p, c_i32_p, C.c_int32, C.POINTER(C.c_uint32)]; L.oracle_mt19937_draws.restype = None
         L.oracle_retriangulate.argtypes = [C.POINTER(BAProblemC), C.c_int32, c_i32_p]; L.oracle_retriangulate.restype = C.c_int
         _LIB = L
     return _LIB
@@ -278,6 +284,33 @@ def ransac_pair(u, v, sq_thresh, inward=False, min_iterations=100, max_iteration
     n = lib().oracle_ransac_pair(len(u), _dp(u), _dp(v), int(inward), sq_thresh, min_iterations, max_iterations, seed, min_num_inliers,
                                  _dp(E), _dp(R), _up(mask), C.byref(it), C.byref(sc))
     return dict(E=_um(E), R=_um(R), inliers=mask.astype(bool), num_inliers=n, iterations=it.value, score=sc.value)
+
+
+def lomsac_pair(u, v, sq_thresh, inward=False, use_poly=False, min_iterations=100, max_iterations=10000, success_probability=0.9999, seed=0,
+                num_lo_steps=0, num_lsq_iterations=0, threshold_multiplier=2.0 ** 0.5, min_sample_multiplicator=7, non_min_sample_multiplier=3,
+                lo_starting_iterations=50, final_least_squares=True, min_num_inliers=0):
+    """LocallyOptimizedMSAC + estimate_pairwise's tail with every option exposed (defaults = estimate_pairwise's, spherical_sfm_tools.cpp:314-318)."""
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    E = np.zeros(9); R = np.zeros(9); mask = np.zeros(max(len(u), 1), np.uint8); st = (C.c_uint32 * 2)(); sc = C.c_double(0)
+    n = lib().oracle_lomsac_pair(len(u), _dp(u), _dp(v), int(inward), int(use_poly), sq_thresh, min_iterations, max_iterations, success_probability, seed,
+                                 num_lo_steps, num_lsq_iterations, threshold_multiplier, min_sample_multiplicator, non_min_sample_multiplier,
+                                 lo_starting_iterations, int(final_least_squares), min_num_inliers, _dp(E), _dp(R), _up(mask), st, C.byref(sc))
+    return dict(E=_um(E), R=_um(R), inliers=mask[:len(u)].astype(bool), num_inliers=n, iterations=st[0], lo_runs=st[1], score=sc.value)
+
+
+def nonminimal_solver(u, v, sample):
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(sample, np.int32)
+    out = np.zeros(9)
+    ok = lib().oracle_nonminimal_solver(len(u), _dp(u), _dp(v), len(s), _ip(s), _dp(out))
+    return ok, _um(out)
+
+
+def mt19937_draws(seed, lo, hi, nraw=0):
+    """(raw words (nraw,), uniform_int_distribution<int>(lo[i], hi[i]) draws) of one std::mt19937(seed)"""
+    lo = np.ascontiguousarray(lo, np.int32); hi = np.ascontiguousarray(hi, np.int32)
+    out = np.zeros(max(len(lo), 1), np.int32); raw = np.zeros(max(nraw, 1), np.uint32)
+    lib().oracle_mt19937_draws(seed, len(lo), _ip(lo), _ip(hi), _ip(out), nraw, raw.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return raw[:nraw], out[:len(lo)]
 
 
 def reference_style_flatten(prob):

@@ -440,3 +440,52 @@ extern "C" int oracle_ransac_pair(int32_t n, const double* u, const double* v, i
     rm_to_cm(Rm, R_cm);
     return nin;
 }
+
+// LocallyOptimizedMSAC with every LORansacOptions field exposed (tests of the reference-trace GPU mode): lo_steps / lsq_iterations as in
+// LORansacOptions (ransac.h:62-88), final_lsq = final_least_squares_.  stats: [2] = num_iterations, number_lo_iterations.
+extern "C" int oracle_lomsac_pair(int32_t n, const double* u, const double* v, int32_t inward, int32_t use_poly, double sq_thresh, uint32_t min_it, uint32_t max_it,
+                                  double success_prob, uint32_t seed, int32_t num_lo_steps, int32_t num_lsq_it, double thresh_mult, int32_t min_sample_mult,
+                                  int32_t non_min_mult, uint32_t lo_start, int32_t final_lsq, int32_t min_num_inliers, double E_cm[9], double R_cm[9],
+                                  uint8_t* inlier_mask, uint32_t* stats, double* best_score) {
+    Rays R{n, u, v};
+    MSACOptions o; o.sq_thresh = sq_thresh; o.num_lo_steps = num_lo_steps; o.num_lsq_it = num_lsq_it; o.final_lsq = final_lsq != 0; o.min_it = min_it; o.max_it = max_it;
+    o.seed = seed; o.prob = success_prob; o.thresh_mult = thresh_mult; o.min_sample_mult = min_sample_mult; o.non_min_mult = non_min_mult; o.lo_start = lo_start;
+    struct PolySolver : SphericalSolver {
+        bool poly;
+        PolySolver(const Rays& r, bool in, bool p) : SphericalSolver{r, in}, poly(p) {}
+        int MinimalSolver(const std::vector<int>& sample, std::vector<EMat>* Es) const {          // src/spherical_estimator.cpp:80-84
+            if (!poly) return SphericalSolver::MinimalSolver(sample, Es);
+            double buf[36]; const int k = solver_polynomial(R, sample.data(), (int)sample.size(), buf);
+            Es->resize(k); for (int i = 0; i < k; i++) std::memcpy((*Es)[i].data(), buf + 9 * i, 72);
+            return k;
+        }
+    } solver(R, inward != 0, use_poly != 0);
+    LoMsac<PolySolver, EMat> M(solver, o);
+    EMat Em{}; MSACStats st;
+    M.estimate(&Em, &st);
+    double E[9]; std::memcpy(E, Em.data(), 72);
+    int nin = 0;
+    const bool have = st.best_score < std::numeric_limits<double>::max();
+    for (int i = 0; i < n; i++) { const bool in = have && sampson(E, u + 3 * i, v + 3 * i) < sq_thresh; if (inlier_mask) inlier_mask[i] = in; nin += in; }
+    if (stats) { stats[0] = st.iterations; stats[1] = (uint32_t)st.lo_count; }
+    if (best_score) *best_score = st.best_score;
+    rm_to_cm(E, E_cm);
+    double Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (have && nin > min_num_inliers) { double r[3], t[3]; decompose_E(E, inward != 0, r, t); rm_so3exp(r, Rm); }
+    rm_to_cm(Rm, R_cm);
+    return nin;
+}
+// SphericalEstimator::NonMinimalSolver (src/spherical_estimator.cpp:86-108)
+extern "C" int oracle_nonminimal_solver(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, double E_cm[9]) {
+    Rays R{n, u, v}; SphericalSolver S{R, false};
+    std::vector<int> s(sample, sample + ns); EMat E{};
+    const int ok = S.NonMinimalSolver(s, &E);
+    rm_to_cm(E.data(), E_cm);
+    return ok;
+}
+// nraw raw words of std::mt19937(seed), then std::uniform_int_distribution<int>(lo[i], hi[i]) draws of the same engine (libstdc++)
+extern "C" void oracle_mt19937_draws(uint32_t seed, int32_t n, const int32_t* lo, const int32_t* hi, int32_t* out, int32_t nraw, uint32_t* raw) {
+    std::mt19937 rng; rng.seed(seed);
+    for (int i = 0; i < nraw; i++) raw[i] = (uint32_t)rng();
+    for (int i = 0; i < n; i++) { std::uniform_int_distribution<int> d(lo[i], hi[i]); out[i] = d(rng); }
+}

@@ -106,6 +106,15 @@ int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inwa
                        uint32_t max_iterations, uint32_t seed, int32_t min_num_inliers, double E[9], double R[9], uint8_t* inlier_mask,
                        uint32_t* iterations, double* best_score);
 
+/* LocallyOptimizedMSAC (include/RansacLib/ransac.h:128-420) with every LORansacOptions field exposed; stats[2] = num_iterations, number_lo_iterations */
+int oracle_lomsac_pair(int32_t n, const double* u, const double* v, int32_t inward, int32_t use_poly, double sq_thresh, uint32_t min_it, uint32_t max_it,
+                       double success_prob, uint32_t seed, int32_t num_lo_steps, int32_t num_lsq_it, double thresh_mult, int32_t min_sample_mult,
+                       int32_t non_min_mult, uint32_t lo_start, int32_t final_lsq, int32_t min_num_inliers, double E[9], double R[9],
+                       uint8_t* inlier_mask, uint32_t* stats, double* best_score);
+int oracle_nonminimal_solver(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, double E[9]);
+/* std::mt19937(seed): nraw raw words, then uniform_int_distribution<int>(lo[i], hi[i]) draws (libstdc++, as a build of the reference draws them) */
+void oracle_mt19937_draws(uint32_t seed, int32_t n, const int32_t* lo, const int32_t* hi, int32_t* out, int32_t nraw, uint32_t* raw);
+
 /* SfM::Retriangulate (src/sfm.cpp:156-192): every point is re-estimated from its observations with the per-point LO-MSAC
  * of TriangulationEstimator; points with < 3 observations or < 3 inliers become (0,0,0).  num_inliers_out: [num_points] or NULL */
 int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out);

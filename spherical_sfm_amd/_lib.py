@@ -14,6 +14,7 @@ c_double_p = C.POINTER(C.c_double)
 c_i32_p = C.POINTER(C.c_int32)
 c_i64_p = C.POINTER(C.c_int64)
 c_u8_p = C.POINTER(C.c_uint8)
+c_u32_p = C.POINTER(C.c_uint32)
 
 
 class BAProblemC(C.Structure):
@@ -59,7 +60,13 @@ class BAPlanInfoC(C.Structure):
 
 class RansacOptionsC(C.Structure):
     _fields_ = [("num_hypotheses", C.c_int32), ("seed", C.c_uint32), ("min_num_inliers", C.c_int32), ("final_least_squares", C.c_int32),
-                ("inward", C.c_int32), ("use_poly_solver", C.c_int32)]
+                ("inward", C.c_int32), ("use_poly_solver", C.c_int32), ("mode", C.c_int32), ("min_num_iterations", C.c_uint32),
+                ("max_num_iterations", C.c_uint32), ("success_probability", C.c_double), ("num_lo_steps", C.c_int32),
+                ("num_lsq_iterations", C.c_int32), ("threshold_multiplier", C.c_double), ("min_sample_multiplicator", C.c_int32),
+                ("non_min_sample_multiplier", C.c_int32), ("lo_starting_iterations", C.c_uint32), ("fast_shuffle", C.c_int32)]
+
+
+RANSAC_FIXED_BUDGET, RANSAC_REFERENCE_TRACE = 0, 1
 
 
 # every symbol include/ssfm.h declares (tests check that the library exports all of them)
@@ -71,6 +78,7 @@ DECLARED_SYMBOLS = [
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
     "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_band_solve_probe", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_retriangulate", "ssfm_focal_search",
+    "ssfm_sampson_refine_probe", "ssfm_decompose_probe", "ssfm_nonminimal_probe", "ssfm_so3_probe", "ssfm_mt19937_probe",
 ]
 
 
@@ -124,8 +132,13 @@ def lib():
     L.ssfm_band_solve_probe.restype = C.c_int
     L.ssfm_ransac_default_options.argtypes = [C.POINTER(RansacOptionsC)]; L.ssfm_ransac_default_options.restype = None
     L.ssfm_ransac_batch.argtypes = [vp, C.c_int32, c_i32_p, c_double_p, c_double_p, C.c_double, C.POINTER(RansacOptionsC), c_double_p, c_double_p,
-                                    c_u8_p, c_i32_p, c_double_p]
+                                    c_u8_p, c_i32_p, c_double_p, c_u32_p]
     L.ssfm_ransac_batch.restype = C.c_int
+    L.ssfm_sampson_refine_probe.argtypes = [vp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_i32_p, C.c_int32, c_double_p]; L.ssfm_sampson_refine_probe.restype = C.c_int
+    L.ssfm_decompose_probe.argtypes = [vp, C.c_int32, c_double_p, C.c_int32, c_double_p, c_double_p]; L.ssfm_decompose_probe.restype = C.c_int
+    L.ssfm_nonminimal_probe.argtypes = [vp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_i32_p, c_double_p, c_i32_p]; L.ssfm_nonminimal_probe.restype = C.c_int
+    L.ssfm_so3_probe.argtypes = [vp, C.c_int32, C.c_int32, c_double_p, c_double_p]; L.ssfm_so3_probe.restype = C.c_int
+    L.ssfm_mt19937_probe.argtypes = [vp, C.c_uint32, C.c_int32, c_i32_p, c_i32_p, c_i32_p, C.c_int32, c_u32_p]; L.ssfm_mt19937_probe.restype = C.c_int
     L.ssfm_ransac_batch_sharded.argtypes = L.ssfm_ransac_batch.argtypes; L.ssfm_ransac_batch_sharded.restype = C.c_int
     L.ssfm_spherical_solver_probe.argtypes = [vp, C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p, c_i32_p]
     L.ssfm_spherical_solver_probe.restype = C.c_int

@@ -105,7 +105,7 @@ int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::ve
     O.min_num_inliers = min_num_inliers; O.inward = inward ? 1 : 0; O.final_least_squares = 1;                                 // :316-318
     const int P = (int)cand.size();
     std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(u.size() / 3); std::vector<int32_t> nin(P);
-    if (ssfm_ransac_batch_sharded(ctx, P, pair_ptr.data(), u.data(), v.data(), sq_thresh, &O, nullptr, R.data(), mask.data(), nin.data(), nullptr) != SSFM_OK) {   // = ssfm_ransac_batch without a communicator
+    if (ssfm_ransac_batch_sharded(ctx, P, pair_ptr.data(), u.data(), v.data(), sq_thresh, &O, nullptr, R.data(), mask.data(), nin.data(), nullptr, nullptr) != SSFM_OK) {   // = ssfm_ransac_batch without a communicator
         std::cout << "error: " << ssfm_last_error(ctx) << "\n"; std::exit(1);
     }
     int loop_closure_count = 0;

@@ -181,3 +181,40 @@ def corrupt_observations(prob, frac=0.1, seed=5, lo=30.0, hi=80.0):
     prob.obs_xy = xy
     return pts
 
+
+
+def make_circle_pairs(num_frames=200, num_points=3000, *, focal=600.0, half_fov_tan=0.8, noise_px=0.5, outlier_frac=0.2, seed=7):
+    """Exhaustive pair list of an outward-facing camera circle -- the input estimate_pairwise loops over
+    (examples/spherical_sfm_tools.cpp:320-332: every (index0 < index1)).  Frame i sits on the unit sphere with
+    x_cam = R_i X + t, t = (0,0,-1), R_i = so3exp((0, 2 pi i / N, 0)) (the reference's spherical camera model,
+    tools.cpp:879-881); scene points on a ring at depth U(4,8).  Frames see the points inside their field of view,
+    so neighbouring frames share many points and opposite frames none: most far pairs have no correspondence at all.
+    Matches of a pair = the shared points (pixel noise noise_px / focal on both rays) + outlier_frac wrong associations.
+    Returns pair_ptr (P+1,), U (total,3), V (total,3), pairs (P,2) frame indices, R_rel (P,3,3) ground truth R_j R_i^T."""
+    rng = np.random.default_rng(seed)
+    N = num_frames
+    ang = 2.0 * np.pi * np.arange(N) / N
+    Rs = np.stack([so3exp(np.array([0.0, a, 0.0])) for a in ang])
+    t = np.array([0.0, 0.0, -1.0])
+    phi = rng.uniform(0, 2 * np.pi, num_points); d = rng.uniform(4.0, 8.0, num_points); h = rng.uniform(-2.5, 2.5, num_points)
+    X = np.stack([d * np.sin(phi), h, d * np.cos(phi)], axis=1)
+    vis, proj = [], []
+    for i in range(N):
+        pc = X @ Rs[i].T + t
+        ok = (pc[:, 2] > 0.5) & (np.abs(pc[:, 0]) < half_fov_tan * pc[:, 2]) & (np.abs(pc[:, 1]) < half_fov_tan * pc[:, 2])
+        ids = np.nonzero(ok)[0]
+        xy = pc[ids, :2] / pc[ids, 2:3] + (noise_px / focal) * rng.normal(size=(len(ids), 2))
+        vis.append(ids); proj.append(xy)
+    ptr = [0]; Us, Vs, pairs, Rrel = [], [], [], []
+    for i in range(N):
+        for j in range(i + 1, N):
+            common, ia, ib = np.intersect1d(vis[i], vis[j], assume_unique=True, return_indices=True)
+            n = len(common)
+            u = np.concatenate([proj[i][ia], np.ones((n, 1))], axis=1); v = np.concatenate([proj[j][ib], np.ones((n, 1))], axis=1)
+            n_out = int(round(outlier_frac * n))
+            if n_out:
+                sel = rng.choice(n, n_out, replace=False)
+                v[sel, :2] = rng.uniform(-half_fov_tan, half_fov_tan, size=(n_out, 2))
+            Us.append(u); Vs.append(v); ptr.append(ptr[-1] + n); pairs.append((i, j)); Rrel.append(Rs[j] @ Rs[i].T)
+    return (np.asarray(ptr, np.int32), np.ascontiguousarray(np.concatenate(Us)), np.ascontiguousarray(np.concatenate(Vs)),
+            np.asarray(pairs, np.int32), np.stack(Rrel))

@@ -34,8 +34,9 @@ def main():
         from spherical_sfm_amd import ransac
         pairs = [synth.make_relative_pose_problem(n, seed=100 + i, noise=1 / 600, outlier_frac=0.3, rotation_deg=10)[:2]
                  for i, n in enumerate([120, 75, 33, 2, 200, 64, 97])]
-        o = ransac.estimate_pairs(ctx, pairs, (2 / 600) ** 2, sharded=True, min_num_inliers=12, num_hypotheses=256)
-        np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=np.concatenate(o["inliers"]))
+        o = ransac.estimate_pairs(ctx, pairs, (2 / 600) ** 2, sharded=True, min_num_inliers=12, num_hypotheses=256, mode=int(os.environ.get("RANSAC_MODE", "1")))
+        np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=np.concatenate(o["inliers"]),
+                 iterations=o["iterations"], lo_runs=o["lo_runs"])
         if mode == "host":
             dist.barrier(); dist.destroy_process_group()
         return

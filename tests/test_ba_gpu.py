@@ -126,3 +126,19 @@ def test_config2_full_size_parity(gpu_ctx, oracle, spherical, focal_fixed):
     assert rel_err(cams, ocams) <= 1e-5
     assert point_rel_err(pts, opts) <= 1e-5
     assert abs(f - of) <= 1e-5 * of
+
+
+def test_config5_full_size_parity(gpu_ctx, oracle):
+    """BASELINE.json configs[4] at its full size on one GPU: 4000 cameras / 1.5 M points / 12 M observations (K = 8, stride 38: two rings
+    of 2000 cameras, long components -> the substructured factorisation of band_sub.h).  Oracle on the host cores: ~10 s."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(4000, 1500000, 8, spherical=False, focal_fixed=True)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["num_residual_blocks"] == os_["num_residual_blocks"] == 12000000
+    assert s["termination"] == os_["termination"] == 0
+    assert s["iterations"] == os_["iterations"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-9 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5
+    assert point_rel_err(pts, opts) <= 1e-5
+    assert s["band_separators"] > 0                       # the long rings were cut

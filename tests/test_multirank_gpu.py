@@ -65,20 +65,24 @@ def test_rccl_single_rank_communicator(gpu_ctx, tmp_path):
     assert np.abs(r["cams"] - c1).max() <= 1e-10 * np.abs(c1).max() and np.abs(r["pts"] - p1).max() <= 1e-10 * np.abs(p1).max()
 
 
+@pytest.mark.parametrize("rmode", [0, 1])
 @pytest.mark.parametrize("mode,world", [("host", 2), ("host", 3), ("rccl1", 1)])
-def test_sharded_pair_batch_is_bit_identical(gpu_ctx, tmp_path, mode, world):
+def test_sharded_pair_batch_is_bit_identical(gpu_ctx, tmp_path, mode, world, rmode):
     """ssfm_ransac_batch_sharded (round-robin pairs + one sum all-reduce of the result table): every rank must hold
     exactly what the single-GPU batch returns, masks included."""
     from spherical_sfm_amd import ransac
     pairs = [synth.make_relative_pose_problem(n, seed=100 + i, noise=1 / 600, outlier_frac=0.3, rotation_deg=10)[:2]
              for i, n in enumerate([120, 75, 33, 2, 200, 64, 97])]
-    ref = ransac.estimate_pairs(gpu_ctx, pairs, (2 / 600) ** 2, min_num_inliers=12, num_hypotheses=256)
-    env = {"SSFM_COMM_SINGLE_RANK": "1"} if mode == "rccl1" else None
+    ref = ransac.estimate_pairs(gpu_ctx, pairs, (2 / 600) ** 2, min_num_inliers=12, num_hypotheses=256, mode=rmode)   # fixed budget / reference trace
+    env = {"RANSAC_MODE": str(rmode)}
+    if mode == "rccl1":
+        env["SSFM_COMM_SINGLE_RANK"] = "1"
     res = _run(mode, world, str(tmp_path / "p"), False, True, env, task="ransac")
     assert (ref["num_inliers"] > 12).sum() >= 5
     for r in res:
         assert np.array_equal(r["E"], ref["E"]) and np.array_equal(r["R"], ref["R"]) and np.array_equal(r["scores"], ref["scores"])
         assert np.array_equal(r["num_inliers"], ref["num_inliers"]) and np.array_equal(r["mask"], np.concatenate(ref["inliers"]))
+        assert np.array_equal(r["iterations"], ref["iterations"]) and np.array_equal(r["lo_runs"], ref["lo_runs"])
 
 
 def test_weak_scaling_shape_two_ranks(gpu_ctx, tmp_path):

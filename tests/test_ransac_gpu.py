@@ -1,4 +1,5 @@
-"""GPU parity of the batched spherical RANSAC against the oracle, through the C ABI.
+"""GPU parity of the batched spherical RANSAC against the oracle, through the C ABI: minimal solvers, Sampson
+score and the FIXED-BUDGET mode.  The default mode (the reference's own LO-MSAC trace) is covered by tests/test_ransac_trace_gpu.py.
 
 The GPU evaluates a fixed budget of counter-based samples in parallel instead of the reference's sequential,
 adaptively stopped std::mt19937 stream, so the comparison is on what the reference's callers consume -- the inlier set
@@ -61,7 +62,7 @@ def test_batch_matches_oracle_on_inliers_and_rotation(gpu_ctx, oracle):
     from spherical_sfm_amd import ransac
     thr = (2 / 600) ** 2
     probs = _pairs(48, 150, 0.3, 1 / 600)
-    out = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, num_hypotheses=1024, min_num_inliers=20)
+    out = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, num_hypotheses=1024, min_num_inliers=20, mode=ransac.RANSAC_FIXED_BUDGET)
     agree, ang, gt_gpu, gt_cpu = [], [], [], []
     for k, (u, v, R, E, inl) in enumerate(probs):
         o = oracle.ransac_pair(u, v, thr, min_num_inliers=20)
@@ -85,8 +86,8 @@ def test_batch_is_deterministic_and_handles_ragged_and_tiny_pairs(gpu_ctx):
     from spherical_sfm_amd import ransac
     thr = (2 / 600) ** 2
     probs = [synth.make_relative_pose_problem(n, seed=n, noise=1 / 600, outlier_frac=0.2) for n in (2, 3, 7, 50, 333, 1000)]
-    a = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, seed=5)
-    b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, seed=5)
+    a = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, seed=5, mode=ransac.RANSAC_FIXED_BUDGET)
+    b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, seed=5, mode=ransac.RANSAC_FIXED_BUDGET)
     assert (a["E"] == b["E"]).all() and (a["R"] == b["R"]).all() and all((x == y).all() for x, y in zip(a["inliers"], b["inliers"]))
     assert a["num_inliers"][0] == 0 and np.allclose(a["R"][0], np.eye(3))        # fewer than 3 correspondences (ransac.h:137-141)
     for k in (3, 4, 5):
@@ -96,7 +97,9 @@ def test_batch_is_deterministic_and_handles_ragged_and_tiny_pairs(gpu_ctx):
 def test_noise_free_pair_is_solved_exactly(gpu_ctx):
     from spherical_sfm_amd import ransac
     u, v, R, E, _ = synth.make_relative_pose_problem(80, seed=9, rotation_deg=17)
-    out = ransac.estimate_pairs(gpu_ctx, [(u, v)], 1e-10)
+    for mode in (ransac.RANSAC_FIXED_BUDGET, ransac.RANSAC_REFERENCE_TRACE):
+        out = ransac.estimate_pairs(gpu_ctx, [(u, v)], 1e-10, mode=mode)
+        assert out["num_inliers"][0] == 80 and rot_err(R, out["R"][0]) < 1e-7 and frob_err(E, out["E"][0]) < 1e-7
     assert out["num_inliers"][0] == 80 and rot_err(R, out["R"][0]) < 1e-7 and frob_err(E, out["E"][0]) < 1e-7
 
 
@@ -131,8 +134,8 @@ def test_polynomial_solver_recovers_ground_truth_and_batch_runs_with_it(gpu_ctx)
     assert worst < 1e-8
     probs = _pairs(16, 300, 0.3, 1 / 600)
     thr = (2 / 600) ** 2
-    a = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=1)
-    b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=0)
+    a = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=1, mode=ransac.RANSAC_FIXED_BUDGET)
+    b = ransac.estimate_pairs(gpu_ctx, [(p[0], p[1]) for p in probs], thr, use_poly_solver=0, mode=ransac.RANSAC_FIXED_BUDGET)
     for k, p in enumerate(probs):
         assert rot_err(p[2], a["R"][k]) < 5e-3 and abs(int(a["num_inliers"][k]) - int(b["num_inliers"][k])) <= 0.02 * len(p[0])
 
@@ -148,6 +151,10 @@ def test_gpu_against_ransac_golden(gpu_ctx):
         got = ransac.solver_probe(gpu_ctx, u, v, g["samples"], poly=poly)
         errs = [min(frob_err(e, r) for r in ref) for Es, ref in zip(got, ref_all) for e in Es]
         assert len(errs) >= 2 * len(g["samples"]) and np.median(errs) < 1e-9 and max(errs) < 1e-5
-    out = ransac.estimate_pairs(gpu_ctx, [(u, v)], float(g["thr"]), min_num_inliers=20)
+    out = ransac.estimate_pairs(gpu_ctx, [(u, v)], float(g["thr"]), min_num_inliers=20, mode=ransac.RANSAC_FIXED_BUDGET)
     assert (out["inliers"][0] == g["ransac_inliers"]).mean() >= 0.97
     assert rot_err(g["ransac_R"], out["R"][0]) < 2e-3 and rot_err(g["R"], out["R"][0]) < 5e-3
+    # the reference-trace mode reruns the golden pair's own RansacLib trace: same inlier flags, same rotation
+    out = ransac.estimate_pairs(gpu_ctx, [(u, v)], float(g["thr"]), min_num_inliers=20)
+    assert (out["inliers"][0] == g["ransac_inliers"]).all() and rot_err(g["ransac_R"], out["R"][0]) < 1e-7
+    assert out["iterations"][0] == int(g["ransac_iterations"]) and abs(out["scores"][0] - float(g["ransac_score"])) <= 1e-9 * float(g["ransac_score"])
