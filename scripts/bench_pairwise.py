@@ -19,12 +19,14 @@ probs = [synth.make_relative_pose_problem(NC, seed=1000 + k, noise=1 / F, outlie
 reps = (per_call + POOL - 1) // POOL
 U = np.ascontiguousarray(np.concatenate([p[0] for p in probs] * reps)[:per_call * NC]); V = np.ascontiguousarray(np.concatenate([p[1] for p in probs] * reps)[:per_call * NC])
 ptr = (np.arange(per_call + 1, dtype=np.int64) * NC).astype(np.int32)
+import os
+KW = {k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in os.environ.get("SSFM_PW_OPTS", "").split(",") if kv)}   # option overrides, e.g. final_least_squares=0
 ctx = ba.Context(0)
-ransac.estimate_flat(ctx, ptr[:2001], U[:2000 * NC], V[:2000 * NC], THR, min_num_inliers=20, mode=mode)      # warm-up (module load, pinned buffers)
+ransac.estimate_flat(ctx, ptr[:2001], U[:2000 * NC], V[:2000 * NC], THR, min_num_inliers=20, mode=mode, **KW)      # warm-up (module load, pinned buffers)
 done = 0; t0 = time.perf_counter(); its = 0; acc = 0
 while done < total:
     n = min(per_call, total - done)
-    o = ransac.estimate_flat(ctx, ptr[:n + 1], U[:n * NC], V[:n * NC], THR, min_num_inliers=20, mode=mode)
+    o = ransac.estimate_flat(ctx, ptr[:n + 1], U[:n * NC], V[:n * NC], THR, min_num_inliers=20, mode=mode, **KW)
     its += int(o["iterations"].sum()) if mode == 1 else n * 1024; acc += int((o["num_inliers"] > 20).sum()); done += n
 dt = time.perf_counter() - t0
 flop = its * 4 * NC * 48.0                     # models per sample x rays x flop of one Sampson score (48)

@@ -211,11 +211,23 @@ k_lomsac_trace(const int* __restrict__ pair_ptr, const double* __restrict__ gu, 
                 double B[6][3], Es[36];
                 spherical_nullspace<3>(u3, v3, 3, B);
                 myNm = spherical_models_from_basis<POLY, true>(B, Es);
-                for (int m = 0; m < myNm; m++) {
-                    const double* E = Es + 9 * m;
-                    double sc = 0.0;
-                    for (int i = 0; i < n; i++) sc += fmin(sampson_err(E, pu + 3 * i, pv + 3 * i), o.sq_thresh);
-                    if (sc < myScore) { myScore = sc; for (int k = 0; k < 9; k++) myE[k] = E[k]; }
+                if (myNm == 4) {
+                    // ScoreModel of the four candidates in ONE sweep over the rays: a ray is read from LDS once (a broadcast read) and
+                    // the four independent chains fill the FP64 pipe; the quotient by hardware reciprocal + two Newton steps
+                    double sc[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int i = 0; i < n; i++) {
+                        const double u0 = pu[3 * i], u1 = pu[3 * i + 1], u2 = pu[3 * i + 2], v0 = pv[3 * i], v1 = pv[3 * i + 1], v2 = pv[3 * i + 2];
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+                            const double* E = Es + 9 * m;
+                            const double e0 = E[0] * u0 + E[1] * u1 + E[2] * u2, e1 = E[3] * u0 + E[4] * u1 + E[5] * u2, e2 = E[6] * u0 + E[7] * u1 + E[8] * u2;
+                            const double f0 = E[0] * v0 + E[3] * v1 + E[6] * v2, f1 = E[1] * v0 + E[4] * v1 + E[7] * v2;
+                            const double d = v0 * e0 + v1 * e1 + v2 * e2;
+                            sc[m] += fmin((d * d) * fast_rcp(e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1), o.sq_thresh);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; m++) if (sc[m] < myScore) { myScore = sc[m]; for (int k = 0; k < 9; k++) myE[k] = Es[9 * m + k]; }
                 }
             }
             S.score[tid] = myScore; S.nm[tid] = myNm;

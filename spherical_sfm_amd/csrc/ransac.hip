@@ -16,6 +16,7 @@
 // part of such eigenvectors, which is never a valid model.
 #include <algorithm>
 #include <cstdio>
+#include <thread>
 #include "ransac_device.h"
 
 namespace ssfm {
@@ -230,6 +231,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
     const size_t lds_fixed = (size_t)6 * max_n * sizeof(double);
     if (!trace && lds_fixed > 150 * 1024) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: more than 3200 correspondences in one pair (fixed-budget mode keeps the rays in LDS; use the reference-trace mode)");
     const size_t SLAB_RAYS = getenv("SSFM_RANSAC_SLAB_RAYS") ? (size_t)atoll(getenv("SSFM_RANSAC_SLAB_RAYS")) : ((size_t)4 << 20);   // 4 M rays = 200 MB of u, v per slab
+    const size_t stage_threads = getenv("SSFM_RANSAC_STAGE_THREADS") ? (size_t)std::max(1, atoi(getenv("SSFM_RANSAC_STAGE_THREADS"))) : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
     const int SLAB_PAIRS = getenv("SSFM_RANSAC_SLAB_PAIRS") ? atoi(getenv("SSFM_RANSAC_SLAB_PAIRS")) : 65536;
     // slab boundaries
     std::vector<int> slab(1, 0);
@@ -272,7 +274,20 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             Slot& s = slot[k % nslot]; hipStream_t up = (nslot > 1) ? cs : st;
             const int p0 = slab[k], np = slab[k + 1] - p0, r0 = pair_ptr[p0]; const size_t nr = (size_t)(pair_ptr[slab[k + 1]] - r0);
             if (k >= nslot) SSFM_HIP_CHECK(ctx, hipEventSynchronize(compute_done[k % nslot]));      // the slot's previous slab has been read back
-            std::memcpy(s.h_uv, u + (size_t)3 * r0, 3 * nr * sizeof(double)); std::memcpy(s.h_uv + 3 * cap_rays, v + (size_t)3 * r0, 3 * nr * sizeof(double));
+            // pageable -> pinned on several threads (one thread moves ~10 GB/s; configs[3] stages 48 GB)
+            {
+                const size_t bytes = 3 * nr * sizeof(double);
+                const int nt = (int)std::max<size_t>(1, std::min<size_t>(stage_threads, bytes / (4u << 20)));
+                auto part = [&](int t) {
+                    const size_t a = bytes * t / nt, b = bytes * (t + 1) / nt;
+                    std::memcpy((char*)s.h_uv + a, (const char*)(u + (size_t)3 * r0) + a, b - a);
+                    std::memcpy((char*)(s.h_uv + 3 * cap_rays) + a, (const char*)(v + (size_t)3 * r0) + a, b - a);
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+                part(0);
+                for (auto& x : th) x.join();
+            }
             for (int i = 0; i <= np; i++) s.h_ptr[i] = pair_ptr[p0 + i] - r0;
             for (int i = 0; i < np; i++) s.h_ptr[cap_pairs + 1 + i] = pair_id ? pair_id[p0 + i] : p0 + i;      // the random stream of a pair is that of its global index
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.u.p, s.h_uv, 3 * nr * sizeof(double), hipMemcpyHostToDevice, up));
