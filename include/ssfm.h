@@ -106,6 +106,9 @@ typedef struct {
     int32_t band_half_width;      /* block half-bandwidth of S in the Cuthill-McKee order */
     int32_t band_segments;        /* workgroups of the reduced-system factorisation: connected components, long ones cut */
     int32_t band_separators;      /* into segments by this many separators of band_half_width block rows (0 = none cut) */
+    /* bounded problems (ssfm_posegraph_focal_solve): Ceres' projected line search inside the trust-region loop */
+    int32_t num_line_search_evaluations;   /* function evaluations beyond the candidate's */
+    int32_t num_line_search_contractions;  /* iterations whose step the search shortened */
 } ssfm_ba_summary;
 
 void ssfm_ba_default_options(ssfm_ba_options* o);

@@ -23,12 +23,20 @@
 //     else radius /= decrease_factor, decrease_factor *= 2;
 //   * after an accepted step: gradient max-norm |x - Plus(x, -g)|_inf <= 1e-10 -> CONVERGENCE;
 //   * iteration >= max_num_iterations -> NO_CONVERGENCE; radius <= 1e-32 -> CONVERGENCE;
-//   * invalid steps (solver failure or model_cost_change <= 0) count consecutively -> FAILURE.
+//   * invalid steps (solver failure or model_cost_change <= 0) count consecutively -> FAILURE;
+//   * bounds-constrained problems only (Program::IsBoundsConstrained -- the reference has one: the focal multiplier of
+//     src/uncalibrated_pose_graph.cpp:181-182): IterationZero projects the start point, and every valid step goes through the
+//     projected Armijo line search of line_search.hpp before the candidate is evaluated (delta *= step size on success;
+//     model_cost_change stays that of the full step).
+// Not restated (uncertain for 2.2.0, no effect on the tests here): newer Ceres only tests the parameter tolerance after at least
+// one successful step.
 #pragma once
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
+#include "line_search.hpp"
 
 namespace oracle {
 
@@ -56,6 +64,7 @@ struct LMSummary {
     int num_successful_steps = 0;
     int num_unsuccessful_steps = 0;
     int num_linear_solves = 0;
+    int num_line_search_contractions = 0;   // iterations whose step the line search shortened
     double initial_cost = 0, final_cost = 0;
 };
 
@@ -75,6 +84,9 @@ struct LMProblem {
     virtual double model_cost_change(const double* scale, const double* step) = 0;
     // x_plus = x + delta, projected on bounds where present
     virtual void plus(const double* x, const double* delta, double* x_plus) = 0;
+    // bounds-constrained problems: cost and gradient J^T r at x WITHOUT touching the stored linearisation (line-search evaluations)
+    virtual bool is_constrained() const { return false; }
+    virtual bool cost_and_gradient(const double* /*x*/, double* /*cost*/, double* /*gradient*/) { return false; }
 };
 
 inline double vec_norm(const std::vector<double>& v) {
@@ -153,6 +165,25 @@ inline LMSummary lm_minimize(LMProblem& prob, const LMOptions& opt, double* para
         }
         num_consecutive_invalid = 0;
         for (int i = 0; i < n; i++) delta[i] = step[i] * scale[i];
+        // ---- DoLineSearch (is_constrained && max_num_line_search_step_size_iterations > 0)
+        if (prob.is_constrained()) {
+            std::vector<double> g2(n);
+            auto eval = [&](double a) {
+                FunctionSample fs; fs.x = a;
+                for (int i = 0; i < n; i++) tmp[i] = a * delta[i];
+                prob.plus(x.data(), tmp.data(), cand.data());
+                double c;
+                if (!prob.cost_and_gradient(cand.data(), &c, g2.data()) || !std::isfinite(c)) return fs;
+                fs.value = c; fs.value_is_valid = true;
+                double d = 0; for (int i = 0; i < n; i++) d += delta[i] * g2[i];
+                if (std::isfinite(d)) { fs.gradient = d; fs.gradient_is_valid = true; }
+                return fs;
+            };
+            double g0 = 0, dmax = 0; for (int i = 0; i < n; i++) { g0 += grad[i] * delta[i]; dmax = std::fmax(dmax, std::fabs(delta[i])); }
+            double a = 1.0;
+            if (getenv("ORACLE_LS_DEBUG")) { FunctionSample f1 = eval(1.0); std::printf("[ls] it %d cost %.12e g0 %.6e f(1) %.12e armijo_rhs %.12e\n", iteration, x_cost, g0, f1.value, x_cost + 1e-4 * g0); }
+            if (armijo_line_search(eval, x_cost, g0, dmax, &a)) { for (int i = 0; i < n; i++) delta[i] *= a; if (a != 1.0) sum.num_line_search_contractions++; }
+        }
         // ---- ComputeCandidatePointAndEvaluateCost
         prob.plus(x.data(), delta.data(), cand.data());
         double cand_cost;

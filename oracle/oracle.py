@@ -223,6 +223,17 @@ def optimize_rotations_and_focal_length(R, i0, i1, Rrel, focal, min_focal, max_f
     return np.transpose(buf.reshape(-1, 3, 3), (0, 2, 1)).copy(), f.value, cost, s.as_dict()
 
 
+def pose_graph_test_options(max_iterations=0, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
+    """Tolerances of the following pose-graph solves (0 iterations = back to the reference's Ceres defaults)."""
+    lib().oracle_pose_graph_test_options.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double]
+    lib().oracle_pose_graph_test_options(max_iterations, function_tolerance, gradient_tolerance, parameter_tolerance)
+
+
+def pose_graph_last_line_search_contractions():
+    lib().oracle_pose_graph_last_line_search_contractions.restype = C.c_int32
+    return lib().oracle_pose_graph_last_line_search_contractions()
+
+
 def rotation_edge(kind, r0, r1, f, Rmeas, scale):
     r0 = np.ascontiguousarray(r0, np.float64); r1 = np.ascontiguousarray(r1, np.float64)
     Rm = np.ascontiguousarray(np.asarray(Rmeas, np.float64).T).reshape(-1).copy()

@@ -116,7 +116,10 @@ struct PoseGraphOracle : LMProblem {
         }
         *cost = c; return std::isfinite(c);
     }
-    bool linearize(const double* x, double* cost, double* g) override {
+    bool linearize(const double* x, double* cost, double* g) override { return eval(x, cost, g, true); }
+    bool is_constrained() const override { return with_f; }                       // src/uncalibrated_pose_graph.cpp:181-182
+    bool cost_and_gradient(const double* x, double* cost, double* g) override { return eval(x, cost, g, false); }
+    bool eval(const double* x, double* cost, double* g, bool store) {
         typedef Jet<7> J;
         double c = 0; std::fill(g, g + nx, 0.0);
         for (int e = 0; e < E; e++) {
@@ -127,7 +130,7 @@ struct PoseGraphOracle : LMProblem {
             double rho[3]; softlone(loss_a, res[0].a * res[0].a + res[1].a * res[1].a + res[2].a * res[2].a, rho);
             c += 0.5 * rho[0];
             const double sr = std::sqrt(rho[1]);
-            EdgeLin& L = lin[e];
+            EdgeLin tmp; EdgeLin& L = store ? lin[e] : tmp;
             for (int a = 0; a < 3; a++) {
                 L.r[a] = sr * res[a].a;
                 for (int k = 0; k < 3; k++) { L.J0[a][k] = sr * res[a].v[k]; L.J1[a][k] = sr * res[a].v[3 + k]; }
@@ -230,6 +233,9 @@ struct PoseGraphOracle : LMProblem {
     }
 };
 
+// test hook (tests/test_scipy_anchor_cpu.py solves to the exact minimum): 0 = the reference's Ceres defaults
+static int g_pg_max_it = 0; static double g_pg_ftol = 1e-6, g_pg_gtol = 1e-10, g_pg_ptol = 1e-8; static int g_pg_last_contractions = 0;
+
 static double run_pose_graph(int kind, int32_t n, double* rotations, int32_t E, const int32_t* i0, const int32_t* i1,
                              const double* rel, double* focal_length, double min_focal, double max_focal, oracle_summary* s) {
     PoseGraphOracle P;
@@ -238,7 +244,9 @@ static double run_pose_graph(int kind, int32_t n, double* rotations, int32_t E, 
     for (int i = 0; i < n; i++) if (P.node_idx[i] >= 0) for (int d = 0; d < 3; d++) x[P.node_idx[i] + d] = P.data0[i * 3 + d];
     if (P.with_f) { x[P.f_idx] = 1.0; P.f_lo = min_focal / *focal_length; P.f_hi = max_focal / *focal_length; }
     LMOptions opt;   // Ceres defaults (src/rotation_averaging.cpp:75-78)
+    if (g_pg_max_it > 0) { opt.max_num_iterations = g_pg_max_it; opt.function_tolerance = g_pg_ftol; opt.gradient_tolerance = g_pg_gtol; opt.parameter_tolerance = g_pg_ptol; }
     LMSummary r = lm_minimize(P, opt, x.data());
+    g_pg_last_contractions = r.num_line_search_contractions;
     for (int i = 0; i < n; i++) {
         double v[3]; P.node(x.data(), i, v);
         so3exp(v, &rotations[i * 9]);      // src/rotation_averaging.cpp:88 -- every rotation is re-exponentiated
@@ -283,4 +291,38 @@ extern "C" void oracle_rotation_edge(int32_t kind, const double r0[3], const dou
     J a0[3] = {J(r0[0], 0), J(r0[1], 1), J(r0[2], 2)}, a1[3] = {J(r1[0], 3), J(r1[1], 4), J(r1[2], 5)}, ff(f, 6), out[3];
     edge_residual<J>(kind, e, scale, a0, a1, ff, out);
     for (int a = 0; a < 3; a++) { res[a] = out[a].a; for (int k = 0; k < 7; k++) jac[a * 7 + k] = out[a].v[k]; }
+}
+
+extern "C" void oracle_pose_graph_test_options(int32_t max_iterations, double function_tolerance, double gradient_tolerance, double parameter_tolerance) {
+    g_pg_max_it = max_iterations; g_pg_ftol = function_tolerance; g_pg_gtol = gradient_tolerance; g_pg_ptol = parameter_tolerance;
+}
+extern "C" int32_t oracle_pose_graph_last_line_search_contractions() { return g_pg_last_contractions; }
+
+// ---- line_search.hpp through C, for tests/test_line_search_cpu.py
+extern "C" int32_t oracle_ls_polynomial(int32_t ns, const double* x, const double* f, const double* df, const uint8_t* valid /* [2*ns]: f, df per sample */, double* coeff) {
+    std::vector<FunctionSample> s(ns);
+    for (int i = 0; i < ns; i++) { s[i].x = x[i]; s[i].value = f[i]; s[i].gradient = df[i]; s[i].value_is_valid = valid[2 * i]; s[i].gradient_is_valid = valid[2 * i + 1]; }
+    const std::vector<double> p = find_interpolating_polynomial(s);
+    for (size_t i = 0; i < p.size(); i++) coeff[i] = p[i];
+    return (int32_t)p.size();
+}
+extern "C" int32_t oracle_ls_roots(int32_t degree, const double* coeff, double* real_parts) {
+    const std::vector<double> r = polynomial_root_real_parts(std::vector<double>(coeff, coeff + degree + 1));
+    for (size_t i = 0; i < r.size(); i++) real_parts[i] = r[i];
+    return (int32_t)r.size();
+}
+// s = [f(0), f'(0), a, f(a), f'(a)]: the next trial step on [lo a, hi a]
+extern "C" double oracle_ls_step(const double* s, double lo, double hi) {
+    FunctionSample z, c, prev; z.x = 0; z.value = s[0]; z.gradient = s[1]; z.value_is_valid = z.gradient_is_valid = true;
+    c.x = s[2]; c.value = s[3]; c.gradient = s[4]; c.value_is_valid = c.gradient_is_valid = true;
+    return interpolating_step_size(z, prev, c, lo * c.x, hi * c.x);
+}
+extern "C" int32_t oracle_ls_armijo_poly(int32_t degree, const double* coeff, double direction_norm, double* step, int32_t* evaluations) {
+    std::vector<double> p(coeff, coeff + degree + 1), d(degree);
+    for (int i = 0; i < degree; i++) d[i] = (degree - i) * p[i];
+    int ne = 0;
+    auto eval = [&](double a) { FunctionSample q; q.x = a; q.value = evaluate_polynomial(p, a); q.gradient = evaluate_polynomial(d, a); q.value_is_valid = q.gradient_is_valid = true; ne++; return q; };
+    const bool ok = armijo_line_search(eval, evaluate_polynomial(p, 0.0), evaluate_polynomial(d, 0.0), direction_norm, step);
+    *evaluations = ne;
+    return ok ? 1 : 0;
 }

@@ -88,6 +88,10 @@ double oracle_optimize_rotations_and_focal_length(int32_t n, double* rotations, 
                                                   const int32_t* index0, const int32_t* index1,
                                                   const double* rel_rotations, double* focal_length,
                                                   double min_focal, double max_focal, oracle_summary* s);
+/* test hooks: tolerances of the next pose-graph solves (max_iterations = 0 restores the reference's Ceres defaults); how many iterations
+ * of the last solve had their step shortened by the projected line search (bounded problems only) */
+void oracle_pose_graph_test_options(int32_t max_iterations, double function_tolerance, double gradient_tolerance, double parameter_tolerance);
+int32_t oracle_pose_graph_last_line_search_contractions(void);
 /* residual + 3x6 (or 3x7 with focal) Jacobian of one edge, for kernel parity tests.
  * kind: 0 RotationError (meas = R), 1 PoseGraphError, 2 UncalibratedPoseGraphError */
 void oracle_rotation_edge(int32_t kind, const double r0[3], const double r1[3], double f,

@@ -42,7 +42,8 @@ class BASummaryC(C.Structure):
                 ("t_flatten_s", C.c_double), ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double),
                 ("t_kernel_linearize_ms", C.c_double), ("t_kernel_schur_ms", C.c_double), ("t_kernel_pcg_ms", C.c_double),
                 ("t_kernel_update_ms", C.c_double), ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32),
-                ("band_segments", C.c_int32), ("band_separators", C.c_int32)]
+                ("band_segments", C.c_int32), ("band_separators", C.c_int32),
+                ("num_line_search_evaluations", C.c_int32), ("num_line_search_contractions", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include "ba_handle.h"
 #include "dual.h"
+#include "line_search.h"
 
 namespace ssfm {
 
@@ -145,41 +146,74 @@ k_rot_cost(int kind, int E, const int* __restrict__ e0, const int* __restrict__ 
     if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, c);
 }
 
-// candidate = Plus(x, scale o step) with the box projection on the focal multiplier (Ceres ParameterBlock::Plus);
-// also |x - candidate|^2, |candidate|^2 and the projected-gradient max norm |x - Plus(x, -g)|_inf
+// candidate = Plus(x, alpha (scale o step)) with the box projection on the focal multiplier (Ceres ParameterBlock::Plus; alpha = 1 except
+// after a line search); also |x - candidate|^2, |candidate|^2, the projected-gradient max norm |x - Plus(x, -g)|_inf, and for the line
+// search of bounded problems g . delta (slot SC_GDELTA) and |delta|_inf (SC_DMAX) with delta = scale o step, g = the unscaled gradient
+enum { SC_GDELTA = 14, SC_DMAX = 15 };
 __global__ void __launch_bounds__(1024)
 k_rot_update(int n_nodes, const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node,
-             const double* __restrict__ sc_f, const double* __restrict__ y, const double* __restrict__ rhs_raw, double f_lo, double f_hi,
+             const double* __restrict__ sc_f, const double* __restrict__ y, const double* __restrict__ rhs_raw, double f_lo, double f_hi, double alpha,
              double* __restrict__ xc, double* __restrict__ fmc, double* __restrict__ step, double* __restrict__ scal) {
-    __shared__ double red[3 * 16];
-    double acc[2] = {0, 0}; double gmax = 0.0;
+    __shared__ double red[3 * 16 + 16];
+    double acc[3] = {0, 0, 0}; double gmax = 0.0, dmax = 0.0;
     const int n = 3 * n_nodes;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double s = sc_node[i]; double v = x[i];
         const double st = -y[i]; step[i] = st;
-        if (s > 0.0) { const double d = st * s; v += d; acc[0] += d * d; acc[1] += v * v; gmax = fmax(gmax, fabs(rhs_raw[i] / s)); }
+        if (s > 0.0) { const double d = alpha * st * s; v += d; acc[0] += d * d; acc[1] += v * v; gmax = fmax(gmax, fabs(rhs_raw[i] / s)); acc[2] += rhs_raw[i] * st; dmax = fmax(dmax, fabs(st * s)); }
         xc[i] = v;
     }
     if (threadIdx.x == 0) {
         const double s = sc_f[0]; double v = fm[0]; const double st = -y[n]; step[n] = st;
         if (s > 0.0) {
-            const double nv = fmin(fmax(v + st * s, f_lo), f_hi);
+            const double nv = fmin(fmax(v + alpha * st * s, f_lo), f_hi);
             acc[0] += (nv - v) * (nv - v); acc[1] += nv * nv;
             const double g = rhs_raw[n] / s;                       // unscaled gradient of the focal multiplier
             gmax = fmax(gmax, fabs(v - fmin(fmax(v - g, f_lo), f_hi)));
+            acc[2] += rhs_raw[n] * st; dmax = fmax(dmax, fabs(st * s));
             v = nv;
         }
         fmc[0] = v;
     }
-    block_sum<2>(acc, red);
-    gmax = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0) red[32 + (threadIdx.x >> 6)] = gmax;
+    block_sum<3>(acc, red);
+    gmax = wave_max(gmax); dmax = wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) { red[48 + (threadIdx.x >> 6)] = gmax; red[32 + (threadIdx.x >> 6)] = dmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double g = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) g = fmax(g, red[32 + w]);
+        double g = 0.0, d = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) { g = fmax(g, red[48 + w]); d = fmax(d, red[32 + w]); }
         scal[SC_GMAX] = g;                                          // overwrites what k_finalize_S left there (no memset in between)
-        scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1];
+        scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; scal[SC_GDELTA] = acc[2]; scal[SC_DMAX] = d;
     }
+}
+// One evaluation of the line-search function of a bounded problem (line_search.h): f(a) = cost(Plus(x, a delta)) and its slope
+// delta . gradient there, delta = scale o step.  out[0] += cost, out[1] += slope.  Lane per edge, the trial point is formed on the fly.
+__global__ void __launch_bounds__(64)
+k_rot_ls_eval(int kind, int E, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
+              const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node, const double* __restrict__ sc_f,
+              const double* __restrict__ step, double alpha, double f_lo, double f_hi, int n_nodes, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0.0, slope = 0.0;
+    if (e < E) {
+        typedef Dual<7> D;
+        const int i0 = e0[e], i1 = e1[e];
+        double d0[3], d1[3]; D r0[3], r1[3];
+        for (int k = 0; k < 3; k++) {
+            d0[k] = sc_node[3 * i0 + k] * step[3 * i0 + k]; d1[k] = sc_node[3 * i1 + k] * step[3 * i1 + k];
+            r0[k] = D(x[3 * i0 + k] + alpha * d0[k], k); r1[k] = D(x[3 * i1 + k] + alpha * d1[k], 3 + k);
+        }
+        const double df = sc_f[0] * step[3 * n_nodes];
+        D f(fmin(fmax(fm[0] + alpha * df, f_lo), f_hi), 6), res[3];
+        edge_residual<D>(kind, ec[e], scale, r0, r1, f, res);
+        double rho0, rho1; robust_loss(2, loss_a, res[0].a * res[0].a + res[1].a * res[1].a + res[2].a * res[2].a, rho0, rho1);
+        c = 0.5 * rho0;
+        for (int a = 0; a < 3; a++) {
+            double jd = res[a].v[6] * df;
+            for (int k = 0; k < 3; k++) jd += res[a].v[k] * d0[k] + res[a].v[3 + k] * d1[k];
+            slope += rho1 * res[a].a * jd;
+        }
+    }
+    c = wave_sum(c); slope = wave_sum(slope);
+    if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(&out[0], c); unsafeAtomicAdd(&out[1], slope); }
 }
 // Jacobi scales of the 3-dof nodes in the 6-wide camera layout the shared kernels expect: [0 0 0 | s]
 static __global__ void k_scale3to6(const double* __restrict__ s3, int n_nodes, double* __restrict__ s6) {
@@ -275,8 +309,9 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
     // scale laid out 6 per node (slots 3..5) so that k_finalize_S<3> can be reused unchanged
     std::vector<double> mask6((size_t)6 * n, 0.0); for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) mask6[6 * i + 3 + k] = G.mask[3 * i + k];
-    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
-    std::vector<double> fmv = {1.0, 1.0};
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    const double fm0 = with_f ? std::fmin(std::fmax(1.0, f_lo), f_hi) : 1.0;      // IterationZero projects the start point of a bounded problem
+    std::vector<double> fmv = {fm0, fm0};
 #define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
     UPV(x, G.x0); UPV(fm2, fmv); UPV(e0, G.e0); UPV(e1, G.e1); UPV(ec, G.ec);
     UPV(h->row_ptr, F.row_ptr); UPV(h->col_idx, F.col_idx); UPV(h->diag_slot, F.diag_slot); UPV(h->cam_pos, F.band_row); UPV(h->cam_pos2, F.band_row2); UPV(h->pair_dummy, F.pair_dummy);   // the device only needs band rows
@@ -321,7 +356,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));              // m3 / mf go back to the pool
         m3.free(); mf.free();
     }
-    double x_norm = 0; { double s2 = with_f ? 1.0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
+    double x_norm = 0; { double s2 = with_f ? fm0 * fm0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
     int iteration = 0, num_invalid = 0; bool last_successful = true;
     S->num_successful_steps = 1; S->termination = SSFM_NO_CONVERGENCE; S->camera_dof = 3; S->num_residual_blocks = S->num_residual_blocks_global = E;
@@ -336,7 +371,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         int pcg_iters = 0; bool pcg_ok = false;
         { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
         auto tail = [&]() -> int {
-            hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, xcand, fmc, step.p, h->scal.p);
+            hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, 1.0, xcand, fmc, step.p, h->scal.p);
             hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
                                step.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
             hipLaunchKernelGGL(k_rot_cost, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xcand, fmc, h->scal.p + SC_CAND_COST);
@@ -378,14 +413,46 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         }
         num_invalid = 0;
         double cand_cost = host_scal[SC_CAND_COST]; if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
-        const double step_norm = std::sqrt(host_scal[SC_STEP2_CAM]);
+        double step_norm = std::sqrt(host_scal[SC_STEP2_CAM]), cand_xn2 = host_scal[SC_XN2_CAM];
+        if (with_f) {
+            // TrustRegionMinimizer::DoLineSearch (line_search.h).  f(1) is the candidate cost that is already here: only when it misses the
+            // sufficient decrease does the search run (function evaluations = k_rot_ls_eval launches with a read-back each).
+            const double g0 = host_scal[SC_GDELTA], dmax = host_scal[SC_DMAX];
+            if (!(cand_cost <= x_cost + 1e-4 * g0)) {
+                if (!ls_out.p) SSFM_HIP_CHECK(ctx, ls_out.alloc(2));
+                int ls_rc = SSFM_OK; double last_f = 0;
+                auto eval = [&](double a) {
+                    LsSample q; q.a = a; double hv[2] = {0, 0};
+                    hipError_t er = hipMemsetAsync(ls_out.p, 0, 2 * sizeof(double), st);
+                    hipLaunchKernelGGL(k_rot_ls_eval, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, step.p, a, f_lo, f_hi, n, ls_out.p);
+                    if (er == hipSuccess) er = hipMemcpyAsync(hv, ls_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st);
+                    if (er == hipSuccess) er = hipStreamSynchronize(st);
+                    if (er != hipSuccess) { ls_rc = fail(ctx, SSFM_ERR_HIP, std::string("line search evaluation: ") + hipGetErrorString(er)); return q; }
+                    S->num_line_search_evaluations++;
+                    if (std::isfinite(hv[0])) { q.f = hv[0]; q.has_f = true; last_f = hv[0]; if (std::isfinite(hv[1])) { q.df = hv[1]; q.has_df = true; } }
+                    return q;
+                };
+                double a = 1.0;
+                const bool found = ls_armijo(eval, x_cost, g0, dmax, &a);
+                if (ls_rc) return ls_rc;
+                if (found && a != 1.0) {
+                    // delta *= a: rebuild the candidate and its norms; the model cost change stays that of the full step
+                    hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, a, xcand, fmc, step.p, h->scal.p);
+                    double hs[SC_TOTAL];
+                    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hs, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
+                    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                    step_norm = std::sqrt(hs[SC_STEP2_CAM]); cand_xn2 = hs[SC_XN2_CAM]; cand_cost = last_f;
+                    S->num_line_search_contractions++;
+                }
+            }
+        }
         if (step_norm <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) { S->termination = SSFM_CONVERGENCE; break; }
         const double cost_change = x_cost - cand_cost;
         if (std::fabs(cost_change) <= O.function_tolerance * x_cost) { S->termination = SSFM_CONVERGENCE; break; }
         const double rel = (cand_cost >= std::numeric_limits<double>::max()) ? std::numeric_limits<double>::lowest() : cost_change / model_cost_change;
         if (rel > O.min_relative_decrease) {
             std::swap(xx, xcand); std::swap(fmx, fmc);
-            x_norm = std::sqrt(host_scal[SC_XN2_CAM]);
+            x_norm = std::sqrt(cand_xn2);
             radius = std::fmin(O.max_trust_region_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
             decrease_factor = 2.0; last_successful = true; S->num_successful_steps++;
             x_cost = cand_cost; if (x_cost < minimum_cost) minimum_cost = x_cost;
@@ -402,7 +469,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < n; i++) { double R[9]; so3exp(&xf[3 * i], R); for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rotations[9 * i + a + 3 * b] = R[3 * a + b]; }
     if (with_f) *focal_length *= fmult;                                         // src/uncalibrated_pose_graph.cpp:200
-    x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); e0.free(); e1.free(); ec.free();
+    x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); ls_out.free(); e0.free(); e1.free(); ec.free();
     h->free_all();
     S->t_solve_s = wall_s() - t0;
     return SSFM_OK;

@@ -31,3 +31,23 @@ def make_uncalibrated_loop(O, num_cameras=60, max_offset=3, *, focal_true=1000.0
         r, _ = O.decompose_spherical_essential_matrix(Eg, False)
         R_rel[k] = synth.so3exp(np.asarray(r)[None])[0]
     return i0, i1, R_rel, R_gt
+
+
+def make_hard_bounded_case(O, seed):
+    """optimize_rotations_and_focal_length started far from the solution (random or drifting initial rotations, 10 % corrupted edges,
+    focal guess / bounds drawn per seed): the trust-region steps overshoot, so Ceres' projected line search contracts some of them
+    (seeds 4, 5, 9, 12, 28, 32 do; oracle.pose_graph_last_line_search_contractions()).  -> R0, i0, i1, R_rel, focal_guess, lo, hi"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(12, 50)); fg = float(rng.choice([400, 700, 1300, 2500, 4000])); nd = float(rng.choice([0.05, 1.0, 3.0, 8.0]))
+    i0, i1, Rrel, Rgt = make_uncalibrated_loop(O, n, 3, focal_guess=fg, noise_deg=nd, seed=seed)
+    for k in rng.choice(len(i0), max(1, len(i0) // 10), replace=False):
+        Rrel[k] = synth.so3exp(rng.normal(size=(1, 3)) * 0.8)[0] @ Rrel[k]
+    R0 = np.tile(np.eye(3), (n, 1, 1))
+    if seed % 2 == 0:
+        for k in range(1, n):
+            e = [q for q in range(len(i0)) if i0[q] == k - 1 and i1[q] == k][0]
+            R0[k] = Rrel[e] @ R0[k - 1]
+    else:
+        R0 = synth.so3exp(rng.normal(size=(n, 3)) * 0.5)
+    lo, hi = fg * rng.choice([0.2, 0.5, 0.9]), fg * rng.choice([1.1, 2.0, 5.0])
+    return R0, i0, i1, Rrel, fg, float(lo), float(hi)

@@ -75,3 +75,24 @@ def test_irregular_pose_graphs_match_oracle(gpu_ctx, oracle, seed):
     Ro, co, so = oracle.optimize_rotations(R0.copy(), i0, i1, Rrel)
     assert s["termination"] == so["termination"] and abs(s["iterations"] - so["iterations"]) <= 1
     assert abs(cost - co) <= 1e-7 * max(co, 1e-12) and rot_angle(R, Ro).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [4, 5, 9, 12, 28, 32, 7, 13, 0, 3])
+def test_bounded_solve_with_projected_line_search_matches_oracle(gpu_ctx, oracle, seed):
+    """optimize_rotations_and_focal_length is a bounded problem (src/uncalibrated_pose_graph.cpp:181-182), so Ceres runs its projected
+    Armijo line search inside the trust-region loop.  Hard starts where the search really shortens steps (seeds 4 .. 32; the last two
+    end on an active bound where the search gives up and the full step stands): same iterate path as the oracle."""
+    from spherical_sfm_amd import rotavg
+    import _uncalib_graph as U
+    R0, i0, i1, Rrel, fg, lo, hi = U.make_hard_bounded_case(oracle, seed)
+    R, f, cost, s = rotavg.optimize_rotations_and_focal_length(gpu_ctx, R0, i0, i1, Rrel, fg, lo, hi)
+    Ro, fo, co, so = oracle.optimize_rotations_and_focal_length(R0.copy(), i0, i1, Rrel, fg, lo, hi)
+    nc = oracle.pose_graph_last_line_search_contractions()
+    if seed in (4, 5, 9, 12, 28, 32):
+        assert nc > 0
+    assert s["num_line_search_contractions"] == nc
+    assert s["termination"] == so["termination"] and s["iterations"] == so["iterations"]
+    assert s["num_unsuccessful_steps"] == so["num_unsuccessful_steps"]
+    assert lo - 1e-9 <= f <= hi + 1e-9
+    assert abs(cost - co) <= 1e-8 * co and abs(f - fo) <= 1e-6 * fo
+    assert rot_angle(R, Ro).max() <= 1e-5
