@@ -228,6 +228,26 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
 int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
                               double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R,
                               uint8_t* inlier_mask, int32_t* num_inliers, double* scores, uint32_t* stats);
+/* ---- the reference's estimator interface for ONE pair (rays resident on the device) ------------------------------------------------
+ * One entry point per virtual of sphericalsfm::Estimator<Eigen::Matrix3d> / EssentialEstimator (include/sphericalsfm/estimator.h:7-29) as
+ * SphericalEstimator implements them (include/sphericalsfm/spherical_estimator.h:8-35, src/spherical_estimator.cpp:67-164): what a host-side
+ * RANSAC driver such as ransac_lib::LocallyOptimizedMSAC (include/RansacLib/ransac.h:128) calls.  The C++ mirror of the class is
+ * spherical_sfm_amd/csrc/shim/spherical_estimator.h.  Thousands of pairs go through ssfm_ransac_batch instead.  Matrices column-major.
+ *   create(u, v [n*3], use_poly_solver, inward)      SphericalEstimator(correspondences, use_poly_solver, inward)   spherical_estimator.h:15
+ *   minimal_solver(sample [3..9]) -> Es [36], 0 | 4    MinimalSolver: always four candidates, real parts of complex ones       :80-84
+ *   non_minimal_solver(sample [3..9]) -> E, ok         NonMinimalSolver                                                          :86-108
+ *   evaluate_model(E) -> errors [n]                    EvaluateModelOnPoint(E, i) for every i                                     :67-78
+ *   least_squares(sample [0..n], E in/out)             LeastSquares                                                              :110-157
+ *   decompose(E) -> R [9], t [3]                       Decompose                                                                  :159-164 */
+typedef struct ssfm_estimator ssfm_estimator;
+int ssfm_estimator_create(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t use_poly_solver, int32_t inward, ssfm_estimator** out);
+void ssfm_estimator_destroy(ssfm_estimator* e);
+int ssfm_estimator_minimal_solver(ssfm_estimator* e, const int32_t* sample, int32_t sample_size, double* Es, int32_t* num_models);
+int ssfm_estimator_non_minimal_solver(ssfm_estimator* e, const int32_t* sample, int32_t sample_size, double* E, int32_t* ok);
+int ssfm_estimator_evaluate_model(ssfm_estimator* e, const double* E, double* errors);
+int ssfm_estimator_least_squares(ssfm_estimator* e, const int32_t* sample, int32_t sample_size, double* E);
+int ssfm_estimator_decompose(ssfm_estimator* e, const double* E, double* R, double* t);
+
 /* ---- deterministic probes of the estimator's pieces (parity tests; one workgroup per task) --------------------------------------
  * ssfm_sampson_refine_probe: SphericalEstimator::LeastSquares (src/spherical_estimator.cpp:110-157) -- task t refines E_inout[t] (column-
  *   major, in/out) on the rays lists[task_ptr[t] .. task_ptr[t+1]) of the ONE pair (u, v).
@@ -237,7 +257,13 @@ int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* p
  * ssfm_so3_probe (row a9): what = 0 so3exp (src/so3.cpp:16-23), 1 so3ln (:25-69), 2 ceres::AngleAxisToRotationMatrix,
  *   3 ceres::RotationMatrixToAngleAxis, as the device code evaluates them; matrices column-major.
  * ssfm_mt19937_probe: nraw raw words of std::mt19937(seed), then uniform_int_distribution<int>(lo[i], hi[i]) draws from the same
- *   engine, through the device generator of the reference-trace mode. */
+ *   engine, through the device generator of the reference-trace mode.
+ * ssfm_minimal_solver_probe: SphericalEstimator::MinimalSolver as the reference returns it (src/spherical_estimator.cpp:80-84): always four
+ *   candidates per 3-point sample, the real parts of complex solutions included; Es [S*36] column-major, counts [S] (0 or 4).
+ * ssfm_sampson_probe: EvaluateModelOnPoint (src/spherical_estimator.cpp:67-78) of T models on every ray: errors [T*n]. */
+int ssfm_minimal_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t S, const int32_t* samples, int32_t use_poly_solver,
+                              double* Es, int32_t* counts);
+int ssfm_sampson_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t T, const double* Es, double* errors);
 int ssfm_sampson_refine_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
                               const int32_t* lists, int32_t inward, double* E_inout);
 int ssfm_decompose_probe(ssfm_ctx* ctx, int32_t tasks, const double* E, int32_t inward, double* r_out, double* R_out);

@@ -80,6 +80,9 @@ DECLARED_SYMBOLS = [
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
     "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_band_solve_probe", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_retriangulate", "ssfm_focal_search",
     "ssfm_sampson_refine_probe", "ssfm_decompose_probe", "ssfm_nonminimal_probe", "ssfm_so3_probe", "ssfm_mt19937_probe",
+    "ssfm_minimal_solver_probe", "ssfm_sampson_probe",
+    "ssfm_estimator_create", "ssfm_estimator_destroy", "ssfm_estimator_minimal_solver", "ssfm_estimator_non_minimal_solver",
+    "ssfm_estimator_evaluate_model", "ssfm_estimator_least_squares", "ssfm_estimator_decompose",
 ]
 
 

@@ -13,7 +13,7 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the C-ABI library is a build artefact (git-ignored); build it when a fresh checkout runs the tests directly
-    built = [os.path.join(ROOT, "spherical_sfm_amd", f) for f in ("libssfm_hip.so", "demo_circle", "demo_formats", "demo_focal", "run_spherical_sfm", "run_spherical_sfm_uncalib")]
+    built = [os.path.join(ROOT, "spherical_sfm_amd", f) for f in ("libssfm_hip.so", "demo_circle", "demo_formats", "demo_focal", "demo_estimator", "run_spherical_sfm", "run_spherical_sfm_uncalib")]
     if not all(os.path.exists(f) for f in built) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
         subprocess.call(["make", "-C", os.path.join(ROOT, "spherical_sfm_amd", "csrc"), "all"])

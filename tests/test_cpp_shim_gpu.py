@@ -163,3 +163,28 @@ def test_run_spherical_sfm_driver_with_gpu_pairwise_estimation(tmp_path):
     assert max(rel_err) < 2e-3
     # the wrong pairings were rejected: the reprojection cost per residual stays at the pixel-noise level
     assert float(r["cost_general"]) / int(r["residuals"]) < 0.5
+
+
+@pytest.mark.parametrize("args", [("400", "0", "0", "0"), ("400", "1", "0", "0"), ("300", "0", "10", "4"), ("4", "0", "0", "0")])
+def test_estimator_class_api_and_reference_signatures(args):
+    """shim/demo_estimator.cpp: one pair through `ransac_lib::LocallyOptimizedMSAC<Mat3, std::vector<Mat3>, SphericalEstimator>` (the class
+    interface of include/sphericalsfm/estimator.h + spherical_estimator.h, every virtual on the GPU, the host driving as RansacLib does) and
+    through ssfm_ransac_batch (same control flow on the device): identical trace, E / R to rounding.  Then optimize_rotations / get_cost /
+    optimize_rotations_and_focal_length with the reference's own signatures (rotation_averaging.h:16, uncalibrated_pose_graph.h:8-19)."""
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "demo_estimator")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    r = {}
+    for line in out.stdout.splitlines():
+        for kv in line.split():
+            if "=" in kv and not kv.startswith("t="):
+                k, v = kv.split("=", 1); r[k] = v
+    assert r["class_inliers"] == r["batch_inliers"] and r["class_iterations"] == r["batch_iterations"] and r["class_lo"] == r["batch_lo"]
+    assert int(r["mask_diff"]) == 0 and float(r["dE"]) <= 1e-9 and float(r["dR"]) <= 1e-9
+    assert abs(float(r["score_class"]) - float(r["score_batch"])) <= 1e-9 * float(r["score_batch"])
+    if int(args[0]) >= 100:
+        assert int(r["class_inliers"]) >= 0.6 * int(args[0]) and float(r["dR_ground_truth"]) < 5e-3 and int(r["class_iterations"]) >= 100
+    # pose graphs: the returned cost is the cost of the returned rotations, lower than at the sequential start; noise-level accuracy
+    assert float(r["cost_returned"]) < float(r["cost_before"]) and abs(float(r["cost_after"]) - float(r["cost_returned"])) <= 1e-9 * float(r["cost_returned"]) + 1e-15
+    assert float(r["max_rotation_error"]) < 2e-2 and 400.0 <= float(r["focal"]) <= 1600.0 and float(r["cost_focal"]) <= float(r["cost_returned"]) * (1 + 1e-6)
