@@ -14,10 +14,12 @@ HBM before the timed region (ssfm_ba_create); each step restores the initial par
 (SURVEY.md 8d), whole job, max time over ranks.
 
 N > 1: points are sharded over ranks (cameras replicated), one RCCL all-reduce of the partial reduced system per
-LM iteration.  Default ("weak"): the circle grows with the job -- N x 300 cameras / N x 100k points / N x 600k observations
-from the same generator rule (stride round(Nc/75), i.e. 4N rings of 75 cameras), so every rank keeps 600k
-observations and value = (all observations) * n_LM / t.  `--scaling strong` keeps the configs[1] size fixed instead; there
-the replicated reduced solve (about half of an iteration) caps the speed-up near 2x.
+LM iteration.  Default ("strong"): BASELINE.json's metric is THIS 300-camera problem at 1/2/4/8 GPUs, so the problem stays
+fixed and is sharded N ways; the reduced solve is replicated (about half of an N = 1 iteration), which caps the speed-up
+near 2x -- that is what the line reports.  The same JSON line also carries `configs4_sharded`: the BASELINE
+configs[4] problem (4000 cameras / 1.5 M points / 12 M observations, the 8-GPU config) sharded over the same N ranks.
+`--scaling weak` (opt-in): the circle grows with the job instead -- N x 300 cameras / N x 100k points / N x 600k observations
+from the same generator rule (stride round(Nc/75), i.e. 4N rings of 75 cameras), every rank keeps 600k observations.
 """
 import argparse
 import json
@@ -29,6 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
+PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
+
+
+def pair_kernel_flops(pairs):
+    """k_schur_pairs2, per (observation of camera c, observation of camera c2) pair of one point: two re-linearisations
+    (reprojection + analytic 2x6 camera / 2x3 point blocks, ~150 flop each) and the DCxDC block update through the 2x2 core
+    Jc_i^T (Jp_i Vs Jp_j^T) Jc_j (126 multiply-adds = 252 flop at DC = 6)."""
+    return pairs * (2 * 150.0 + 252.0)
 
 
 def algorithmic_bytes(M, nP, nnzb, dc, focal_free):
@@ -59,8 +70,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the configs[4]-sized single-GPU side measurement")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1 only: weak = N x (cameras, points) per job, strong = the N = 1 problem sharded N ways")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1 only: strong (default) = the BASELINE configs[1] problem sharded N ways; weak = N x (cameras, points) per job")
+    ap.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: rccl (one GPU per rank, RCCL over xGMI) or host (ranks share the visible GPUs, reductions staged through gloo: "
+                         "exercises the sharded path on a 1-GPU box; not a performance configuration)")
+    ap.add_argument("--no-configs4", action="store_true", help="N > 1: skip the configs[4] problem sharded over the N ranks")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,13 +90,24 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    host_comm = world > 1 and args.comm == "host"
+    if host_comm:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if host_comm:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     stream = torch.cuda.Stream()
     ctx = ba.Context(local_rank, stream=stream.cuda_stream)
-    if world > 1:
+    if host_comm:
+        def hook(arr, op):
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        ctx.comm_init_host(world, rank, hook)
+    elif world > 1:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.tensor(list(ba.Context.unique_id()), dtype=torch.uint8, device="cuda")
@@ -117,7 +143,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     M = int(s["num_residual_blocks_global"])
@@ -134,6 +160,9 @@ def main():
     out = None
     if rank == 0:
         dc = s["camera_dof"]
+        # (observation, observation) pairs of the off-diagonal Schur blocks: k (k - 1) / 2 per used point with k observations
+        kk = np.bincount(prob.obs_pt, minlength=args.points).astype(np.float64); kk = kk[(kk >= 3)]
+        pairs = float((kk * (kk - 1) / 2).sum())
         # structure sizes for the byte model
         nnzb = s["reduced_blocks"]
         per_iter_bytes, schur_bytes = algorithmic_bytes(M, args.points, nnzb, dc, args.focal_free)
@@ -145,7 +174,7 @@ def main():
         asm_us = dom_us + kern.get("k_cam_sums2", {}).get("avg_us", float("nan"))
         iter_ms = 1e3 * elapsed / max(1, n_lm)          # wall time of the timed loop per LM iteration (host round trips included)
         traffic = None; valu = None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tp = os.path.join(ROOT, PMC_PROFILE)
         if os.path.exists(tp):
             try:
                 pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom)
@@ -157,13 +186,20 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.cameras} cams x {args.points} pts x {M} obs synthetic circle (BASELINE configs[1]" + (f" x {world}" if world > 1 and args.scaling == "weak" else "") + "), "
                                    f"{args.mode} BA, focal {'free' if args.focal_free else 'fixed'}, CauchyLoss(1.0), Ceres-default LM",
-                       "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}"},
+                       "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}", "comm": ("none" if world == 1 else ("host-staged gloo (test configuration)" if host_comm else "rccl"))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
+                                           "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
+            # HBM is not what bounds this kernel (the working set is cache resident and the traffic is 5 % of peak): its arithmetic against the FP64 vector peak
+            "roofline_compute": {"bound": "fp64-vector", "kernel": dom, "pairs_per_launch": pairs / world, "flop_per_pair": pair_kernel_flops(1),
+                                 "achieved": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
+                                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None},
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
             # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
-            "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4,
+            "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4, "source": f"committed profile {PMC_PROFILE} (SQ_INSTS_VALU), not measured in this run",
                            "frac": (valu / (256 * dom_us * 1e-6 * 2.4e9) if valu and dom_us == dom_us else None)},
             "roofline_schur_assembly": {"bound": "hbm", "kernels": ["k_cam_sums2", dom], "algorithmic_bytes": schur_bytes / world,
                                         "avg_us": asm_us, "achieved": (schur_bytes / world) / (asm_us * 1e-6) / 1e9 if asm_us == asm_us else None,
@@ -227,6 +263,24 @@ def main():
                 "workload": "4000 cams x 1500000 pts x 12000000 obs, general BA, focal fixed", "value": sb["num_residual_blocks"] * nb / tb, "unit": "obs/s",
                 "ms_per_solve": 1e3 * tb / 2, "lm_iterations": sb["num_linearizations"], "band_half_width": sb["band_half_width"],
                 "factorisation_workgroups": sb["band_segments"], "separators": sb["band_separators"]}
+    if world > 1 and not args.no_configs4 and not spherical and not args.focal_free and args.cameras == 300 and args.scaling == "strong":
+        # BASELINE configs[4] (the 8-GPU config): 4000 cameras / 1.5 M points / 12 M observations sharded over the N ranks of this job
+        adj.close()
+        big = synth.make_circle(4000, 1500000, 8, spherical=False, focal_fixed=True)
+        adj = ba.BundleAdjuster(ctx, big)
+        adj.run(); barrier()
+        tb = time.perf_counter(); nb = 0
+        for _ in range(2):
+            adj.reset(); sb = adj.run(); nb += sb["num_linearizations"]
+        barrier(); tb = time.perf_counter() - tb
+        t = torch.tensor([tb], dtype=torch.float64, device="cpu" if host_comm else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); tb = float(t.item())
+        if rank == 0:
+            out["configs4_sharded"] = {
+                "workload": "BASELINE configs[4]: 4000 cams x 1500000 pts x 12000000 obs, general BA, focal fixed, points sharded over the ranks, one all-reduce per LM iteration",
+                "n_gpus": world, "scaling": "strong", "value": sb["num_residual_blocks_global"] * nb / tb, "unit": "obs/s", "ms_per_solve": 1e3 * tb / 2,
+                "lm_iterations": sb["num_linearizations"], "observations_this_rank": sb["num_residual_blocks"], "band_half_width": sb["band_half_width"],
+                "factorisation_workgroups": sb["band_segments"], "separators": sb["band_separators"]}
+    if rank == 0:
         print(json.dumps(out))
     adj.close(); ctx.close()
     if world > 1:
