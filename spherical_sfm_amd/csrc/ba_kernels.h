@@ -558,6 +558,75 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
     if (cur >= 0) fold();
 }
 
+// EXPERIMENT (SSFM_PAIRS_Y_PROBE=1, not part of the solve): the pair pass if every observation carried a stored half product
+// Y_i = Jc_i^T Jp_i L (DC x 3, V^-1 = L L^T) -- a pair would be blk -= Y_i Y_j^T (DC*DC*3 multiply-adds) and two DC*3*8-byte reads instead of two
+// re-linearisations.  Same wave tasks, same slot folds and atomics as k_schur_pairs2, into a scratch copy of S; Y holds arbitrary data.
+// Measured next to the real kernel under rocprofv3 (profiles/r02_pairs_y_probe.md): the reads lose what the arithmetic saves.
+template <int DC>
+__global__ void __launch_bounds__(256, 3)
+k_pairs_y_probe(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ task_cam, const int* __restrict__ task_b0,
+                const int* __restrict__ task_b1, int ntasks, const int* __restrict__ batch_slot, const int* __restrict__ pair_j,
+                const int* __restrict__ pair_j2, const double* __restrict__ scale_cam, const double* __restrict__ Y, double* __restrict__ S_scratch) {
+    constexpr int BB = DC * DC, YW = DC * 3;
+    const int lane = threadIdx.x & 63;
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (task >= ntasks) return;
+    const int c = __builtin_amdgcn_readfirstlane(task_cam[task]);
+    const int b0 = __builtin_amdgcn_readfirstlane(task_b0[task]), b1 = __builtin_amdgcn_readfirstlane(task_b1[task]);
+    const int rb = __builtin_amdgcn_readfirstlane(row_ptr[c]);
+    double blk[DC][DC];
+#pragma unroll
+    for (int a = 0; a < DC; a++)
+#pragma unroll
+        for (int b = 0; b < DC; b++) blk[a][b] = 0.0;
+    int cur = -1;
+    const int tr_slot = wave_tr_index();
+    auto fold = [&]() {
+        double* dst = S_scratch + ((size_t)rb + cur) * BB;
+        double flat[BB];
+#pragma unroll
+        for (int a = 0; a < DC; a++)
+#pragma unroll
+            for (int b = 0; b < DC; b++) { flat[a * DC + b] = blk[a][b]; blk[a][b] = 0.0; }
+        const double v = wave_transpose_sum(flat);
+        if (tr_slot < BB) {
+            constexpr int off = (DC == 6) ? 0 : 3;
+            const int a = tr_slot / DC, b = tr_slot - a * DC, c2f = col_idx[rb + cur];
+            unsafeAtomicAdd(&dst[tr_slot], v * scale_cam[6 * c + off + a] * scale_cam[6 * c2f + off + b]);
+        }
+    };
+#define PY_LOAD(bt_, A_, B_, wgt_)                                                                                    \
+    do {                                                                                                              \
+        const size_t e_ = (size_t)(bt_) * 64 + lane;                                                                  \
+        const int j_ = pair_j[e_], j2_ = pair_j2[e_];                                                                 \
+        wgt_ = (j_ >= 0) ? 1.0 : 0.0;                                                                                 \
+        const double2* ya_ = reinterpret_cast<const double2*>(Y + (size_t)max(j_, 0) * YW);                           \
+        const double2* yb_ = reinterpret_cast<const double2*>(Y + (size_t)max(j2_, 0) * YW);                          \
+        _Pragma("unroll") for (int k = 0; k < YW / 2; k++) { const double2 t_ = ya_[k]; A_[2 * k] = t_.x; A_[2 * k + 1] = t_.y; }  \
+        _Pragma("unroll") for (int k = 0; k < YW / 2; k++) { const double2 t_ = yb_[k]; B_[2 * k] = t_.x; B_[2 * k + 1] = t_.y; }  \
+    } while (0)
+#define PY_COMPUTE(bt_, A_, B_, wgt_)                                                                                 \
+    do {                                                                                                              \
+        const int slot_ = __builtin_amdgcn_readfirstlane(batch_slot[bt_]);                                            \
+        if (slot_ != cur) { if (cur >= 0) fold(); cur = slot_; }                                                      \
+        _Pragma("unroll") for (int a = 0; a < DC; a++) {                                                              \
+            const double a0 = A_[3 * a] * wgt_, a1 = A_[3 * a + 1] * wgt_, a2 = A_[3 * a + 2] * wgt_;                 \
+            _Pragma("unroll") for (int b = 0; b < DC; b++) blk[a][b] -= a0 * B_[3 * b] + a1 * B_[3 * b + 1] + a2 * B_[3 * b + 2];  \
+        }                                                                                                             \
+    } while (0)
+    double Aa[YW], Ba[YW], wa, Ab[YW], Bb[YW], wb;
+    PY_LOAD(b0, Aa, Ba, wa);
+    for (int bt = b0; bt < b1; bt += 2) {
+        PY_LOAD(min(bt + 1, b1 - 1), Ab, Bb, wb);
+        PY_COMPUTE(bt, Aa, Ba, wa);
+        PY_LOAD(min(bt + 2, b1 - 1), Aa, Ba, wa);
+        if (bt + 1 < b1) PY_COMPUTE(bt + 1, Ab, Bb, wb);
+    }
+#undef PY_LOAD
+#undef PY_COMPUTE
+    if (cur >= 0) fold();
+}
+
 // symmetric mat-vec with only the lower triangle stored: q_c = sum_{s in row c} S_s p_col(s) + sum_{t in trans(c)} S_t^T p_row(t)
 template <int DC>
 __global__ void __launch_bounds__(256)

@@ -107,6 +107,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const bool phases = h->profile || O.verbose;
     if (phases) for (auto& e : h->phase_ev) if (!e) SSFM_HIP_CHECK(ctx, hipEventCreate(&e));
 
+    // SSFM_PAIRS_Y_PROBE=1: the half-product variant of the pair pass runs next to the real kernel, on scratch data, for rocprofv3
+    const bool y_probe = std::getenv("SSFM_PAIRS_Y_PROBE") && std::atoi(std::getenv("SSFM_PAIRS_Y_PROBE")) != 0;
+    DevBuf<double> probe_Y, probe_S;
+    if (y_probe) {
+        SSFM_HIP_CHECK(ctx, probe_Y.alloc((size_t)F.M * DC * 3)); SSFM_HIP_CHECK(ctx, probe_S.alloc(h->zone_nnz));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(probe_Y.p, 0x3c, (size_t)F.M * DC * 3 * sizeof(double), st)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(probe_S.p, 0, h->zone_nnz * sizeof(double), st));
+    }
     while (true) {
         if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
@@ -130,6 +137,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             const int ntasks = (int)F.chunk_cam.size();
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
+        }
+        if (y_probe && !F.chunk_cam.empty()) {                     // experiment only (ba_kernels.h: k_pairs_y_probe)
+            const int ntasks = (int)F.chunk_cam.size();
+            hipLaunchKernelGGL(k_pairs_y_probe<DC>, dim3((ntasks + 3) / 4), dim3(256), 0, st, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, ntasks,
+                               h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, probe_Y.p, probe_S.p);
         }
         if (ctx->collective) {
             // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
@@ -275,6 +287,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     }
     if (fx != h->focal3.p) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->focal3.p, fx, sizeof(double), hipMemcpyDeviceToDevice, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    probe_Y.free(); probe_S.free();
     S->iterations = iteration;
     S->final_cost = (minimum_cost == std::numeric_limits<double>::max()) ? x_cost : minimum_cost;
     S->t_kernel_linearize_ms = ms_lin; S->t_kernel_schur_ms = ms_schur; S->t_kernel_pcg_ms = ms_pcg; S->t_kernel_update_ms = ms_upd;
