@@ -1,5 +1,7 @@
 // C++ mirror of sphericalsfm::SfM over the C ABI (see sfm.h).  Host-only code; the solve runs in libssfm_hip.so.
 #include "sfm.h"
+#include <algorithm>
+#include <initializer_list>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +52,8 @@ int SfM::AddCamera(const Pose& pose, const std::string& path) {                 
 }
 int SfM::AddPoint(const Point& X) { numPoints++; points[nextPoint] = X; pointFixed[nextPoint] = false; return nextPoint++; }   // src/sfm.cpp:113-127
 int SfM::AddPoint(const Point& X, const std::array<unsigned char, 3>& color_bgr) { const int p = AddPoint(X); colors[p] = color_bgr; return p; }
+int SfM::AddPoint(const Point& X, const std::vector<float>& descriptor, const std::array<unsigned char, 3>& color_bgr) { const int p = AddPoint(X, color_bgr); descriptors[p] = descriptor; return p; }
+std::vector<float> SfM::GetDescriptor(int point) { auto it = descriptors.find(point); return it == descriptors.end() ? std::vector<float>() : it->second; }
 std::array<unsigned char, 3> SfM::GetColor(int point) { auto it = colors.find(point); return it == colors.end() ? std::array<unsigned char, 3>{0, 0, 0} : it->second; }
 void SfM::AddObservation(int camera, int point, const Observation& o) { observations[camera][point] = o; }                 // src/sfm.cpp:143-146
 bool SfM::GetObservation(int camera, int point, Observation& o) {
@@ -67,7 +71,7 @@ void SfM::MergePoint(int point1, int point2) {                                  
 }
 void SfM::RemovePoint(int point) {                                                            // src/sfm.cpp:435-444
     for (auto& row : observations) if (row.first >= 0 && row.first < numCameras) row.second.erase(point);
-    points.erase(point); colors.erase(point);
+    points.erase(point); colors.erase(point); descriptors.erase(point);
 }
 void SfM::RemoveCamera(int camera) {                                                          // src/sfm.cpp:446-461
     cameras.erase(camera); observations.erase(camera);
@@ -213,93 +217,108 @@ void SfM::WriteCameraCentersOBJ(const std::string& path) {                      
     for (int i = 0; i < numCameras; i++) { const Vec3 c = GetPose(i).getCenter(); std::fprintf(f, "v %0.15lf %0.15lf %0.15lf\n", c.v[0], c.v[1], c.v[2]); }
     std::fclose(f);
 }
-void SfM::WriteCOLMAP(const std::string& sparse_dir, int width, int height) {                 // src/sfm.cpp:573-647
+// COLMAP text model (the byte layout of src/sfm.cpp:573-647: header comments, "%lf" fields, 1-based ids, pixel coordinates with the
+// principal point added back, colours stored BGR and written RGB, points at the origin skipped everywhere).  Written from one pass over
+// the sparse observation rows: each image line is emitted while its row is walked, and the (image, index-in-line) pairs of a point's
+// track are collected as flat records that a stable sort by point id turns into the TRACK[] lists of points3D.txt.
+namespace {
+struct TextOut {
+    FILE* f;
+    explicit TextOut(const std::string& path) : f(std::fopen(path.c_str(), "w")) {}
+    ~TextOut() { if (f) std::fclose(f); }
+    void lines(std::initializer_list<const char*> ls) { for (const char* l : ls) std::fputs(l, f); }
+};
+struct TrackEntry { int point, image, slot; };
+// Eigen::Quaterniond(Eigen::AngleAxisd(|r|, r / |r|)): (cos(th/2), sin(th/2) r/|r|); the identity for r = 0
+void angle_axis_to_quaternion(const Vec3& r, double q[4]) {
+    const double th = r.norm();
+    q[0] = 1; q[1] = q[2] = q[3] = 0;
+    if (th == 0) return;
+    const double k = std::sin(0.5 * th) / th;
+    q[0] = std::cos(0.5 * th); q[1] = k * r.v[0]; q[2] = k * r.v[1]; q[3] = k * r.v[2];
+}
+}  // namespace
+
+void SfM::WriteCOLMAP(const std::string& sparse_dir, int width, int height) {
     mkdir(sparse_dir.c_str(), 0777);
-    FILE* camerasf = std::fopen((sparse_dir + "/cameras.txt").c_str(), "w"); if (!camerasf) return;
-    std::fprintf(camerasf, "# Camera list with one line of data per camera:\n");
-    std::fprintf(camerasf, "#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n");
-    std::fprintf(camerasf, "# Number of cameras: 1\n");
-    std::fprintf(camerasf, "1 SIMPLE_PINHOLE %d %d %lf %lf %lf\n", width, height, intrinsics.focal, intrinsics.centerx, intrinsics.centery);
-    std::fclose(camerasf);
-    FILE* imagesf = std::fopen((sparse_dir + "/images.txt").c_str(), "w"); if (!imagesf) return;
-    std::fprintf(imagesf, "# Image list with two lines of data per image:\n");
-    std::fprintf(imagesf, "#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n");
-    std::fprintf(imagesf, "#   POINTS2D[] as (X, Y, POINT3D_ID)\n");
-    std::fprintf(imagesf, "# Number of images: %d, mean observations per image:\n", GetNumCameras());
-    std::vector<std::vector<std::pair<int, int>>> point_obs(GetNumPoints());
-    for (int i = 0; i < GetNumCameras(); i++) {
-        const Pose pose = GetPose(i);
-        std::fprintf(imagesf, "%d ", i + 1);
-        double qw = 1, qx = 0, qy = 0, qz = 0;                      // Eigen::Quaterniond(AngleAxisd(|r|, r/|r|))
-        const double th = pose.r.norm();
-        if (th != 0) { const double s = std::sin(0.5 * th) / th; qw = std::cos(0.5 * th); qx = pose.r.v[0] * s; qy = pose.r.v[1] * s; qz = pose.r.v[2] * s; }
-        std::fprintf(imagesf, "%lf %lf %lf %lf ", qw, qx, qy, qz);
-        std::fprintf(imagesf, "%lf %lf %lf ", pose.t.v[0], pose.t.v[1], pose.t.v[2]);
-        std::fprintf(imagesf, "1 ");
-        std::fprintf(imagesf, "%s\n", paths[i].c_str());
-        int k = 0;
-        auto row = observations.find(i);
-        if (row != observations.end() && cameras.count(i))
-            for (auto& kv : row->second) {                            // std::map order = ascending point id = the reference's j loop
-                const int j = kv.first; if (j < 0 || j >= GetNumPoints()) continue;
-                if (GetPoint(j).norm() == 0) continue;
-                std::fprintf(imagesf, "%lf %lf %d ", kv.second.x + intrinsics.centerx, kv.second.y + intrinsics.centery, j + 1);
-                point_obs[j].push_back(std::make_pair(i + 1, k));
-                k++;
+    {
+        TextOut out(sparse_dir + "/cameras.txt"); if (!out.f) return;
+        out.lines({"# Camera list with one line of data per camera:\n", "#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n", "# Number of cameras: 1\n"});
+        std::fprintf(out.f, "1 SIMPLE_PINHOLE %d %d %lf %lf %lf\n", width, height, intrinsics.focal, intrinsics.centerx, intrinsics.centery);
+    }
+    const int nc = GetNumCameras(), np = GetNumPoints();
+    std::vector<char> live(np, 0);                                  // points that exist and are not at the origin
+    for (const auto& kv : points) if (kv.first >= 0 && kv.first < np && kv.second.norm() != 0) live[kv.first] = 1;
+    std::vector<TrackEntry> tracks;
+    {
+        TextOut out(sparse_dir + "/images.txt"); if (!out.f) return;
+        out.lines({"# Image list with two lines of data per image:\n", "#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n", "#   POINTS2D[] as (X, Y, POINT3D_ID)\n"});
+        std::fprintf(out.f, "# Number of images: %d, mean observations per image:\n", nc);
+        for (int image = 0; image < nc; image++) {
+            const Pose pose = GetPose(image);
+            double q[4]; angle_axis_to_quaternion(pose.r, q);
+            std::fprintf(out.f, "%d %lf %lf %lf %lf %lf %lf %lf 1 %s\n", image + 1, q[0], q[1], q[2], q[3], pose.t.v[0], pose.t.v[1], pose.t.v[2], paths[image].c_str());
+            const auto row = observations.find(image);
+            if (row != observations.end() && cameras.count(image)) {
+                int slot = 0;
+                for (const auto& ob : row->second) {                  // ascending point id
+                    if (ob.first < 0 || ob.first >= np || !live[ob.first]) continue;
+                    std::fprintf(out.f, "%lf %lf %d ", ob.second.x + intrinsics.centerx, ob.second.y + intrinsics.centery, ob.first + 1);
+                    tracks.push_back(TrackEntry{ob.first, image + 1, slot++});
+                }
             }
-        std::fprintf(imagesf, "\n");
+            std::fputc('\n', out.f);
+        }
     }
-    std::fclose(imagesf);
-    FILE* pointsf = std::fopen((sparse_dir + "/points3D.txt").c_str(), "w"); if (!pointsf) return;
-    std::fprintf(pointsf, "# 3D point list with one line of data per point:\n");
-    std::fprintf(pointsf, "#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[] as (IMAGE_ID, POINT2D_IDX)\n");
-    std::fprintf(pointsf, "# Number of points: %d, mean track length: \n", GetNumPoints());
-    for (int j = 0; j < GetNumPoints(); j++) {
-        const Point point = GetPoint(j);
-        const std::array<unsigned char, 3> color = GetColor(j);
-        if (point.norm() == 0) continue;
-        std::fprintf(pointsf, "%d ", j + 1);
-        std::fprintf(pointsf, "%lf %lf %lf ", point.v[0], point.v[1], point.v[2]);
-        std::fprintf(pointsf, "%d %d %d ", color[2], color[1], color[0]);   // RGB
-        std::fprintf(pointsf, "0 ");                                        // error
-        for (size_t k = 0; k < point_obs[j].size(); k++) std::fprintf(pointsf, "%d %d ", point_obs[j][k].first, point_obs[j][k].second);
-        std::fprintf(pointsf, "\n");
+    std::stable_sort(tracks.begin(), tracks.end(), [](const TrackEntry& x, const TrackEntry& y) { return x.point < y.point; });   // images stay ascending inside a point
+    TextOut out(sparse_dir + "/points3D.txt"); if (!out.f) return;
+    out.lines({"# 3D point list with one line of data per point:\n", "#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[] as (IMAGE_ID, POINT2D_IDX)\n"});
+    std::fprintf(out.f, "# Number of points: %d, mean track length: \n", np);
+    size_t cursor = 0;
+    for (int id = 0; id < np; id++) {
+        if (!live[id]) { while (cursor < tracks.size() && tracks[cursor].point == id) cursor++; continue; }
+        const Point X = GetPoint(id); const std::array<unsigned char, 3> bgr = GetColor(id);
+        std::fprintf(out.f, "%d %lf %lf %lf %d %d %d 0 ", id + 1, X.v[0], X.v[1], X.v[2], bgr[2], bgr[1], bgr[0]);
+        for (; cursor < tracks.size() && tracks[cursor].point == id; cursor++) std::fprintf(out.f, "%d %d ", tracks[cursor].image, tracks[cursor].slot);
+        std::fputc('\n', out.f);
     }
-    std::fclose(pointsf);
 }
 void SfM::WriteCalib(const std::string& path) {                                               // run_spherical_sfm_uncalib.cpp:225-228
     FILE* f = std::fopen(path.c_str(), "w"); if (!f) return;
     std::fprintf(f, "%0.15f %0.15f %0.15f\n", GetFocal(), intrinsics.centerx, intrinsics.centery);
     std::fclose(f);
 }
-void SfM::FilterObservations(double thresh) {                                                 // src/sfm.cpp:297-339
-    int nremoved = 0;
-    for (int j = 0; j < numPoints; j++) {
-        if (!points.count(j)) continue;
-        if (GetPoint(j).norm() == 0) continue;
-        int nobs = 0;
-        for (auto& row : observations) if (row.first >= 0 && row.first < numCameras && cameras.count(row.first) && row.second.count(j)) nobs++;
-        if (nobs < 3) continue;
-        const Point X = GetPoint(j);
-        for (auto& row : observations) {
-            const int i = row.first;
-            if (i < 0 || i >= numCameras || !cameras.count(i)) continue;
-            auto it = row.second.find(j); if (it == row.second.end()) continue;
-            // ReprojectionError without loss (src/sfm.cpp:38-63): p = R(r) X + t with Ceres' AngleAxisRotatePoint
-            const Camera& c = cameras[i];
-            double R[9], p[3]; ssfm::angle_axis_to_matrix(&c[3], R);
-            ssfm::mat3_vec(R, GetPoint(j).v, p);
-            p[0] += c[0]; p[1] += c[1]; p[2] += c[2];
-            const double r0 = intrinsics.focal * (p[0] / p[2]) - it->second.x, r1 = intrinsics.focal * (p[1] / p[2]) - it->second.y;
-            const double err = std::sqrt(r0 * r0 + r1 * r1);
-            if (err > thresh) {
-                row.second.erase(it);
-                nobs--; nremoved++;
-                if (nobs == 0) SetPoint(j, Point(0, 0, 0));
+// Drops every observation whose reprojection error exceeds thresh pixels, for points that are seen by at least three cameras and are not
+// at the origin; a point that loses all its observations is moved to the origin (so later Optimize() calls skip it).  Same outcome as
+// src/sfm.cpp:297-339 -- the removals of a point do not depend on each other, so instead of probing every (point, camera) key this counts
+// the observations of all points in one sweep over the sparse rows and tests them in a second one.
+void SfM::FilterObservations(double thresh) {
+    std::vector<int> seen(numPoints, 0);
+    auto usable_row = [&](int cam) { return cam >= 0 && cam < numCameras && cameras.count(cam) != 0; };
+    for (const auto& row : observations)
+        if (usable_row(row.first)) for (const auto& ob : row.second) if (ob.first >= 0 && ob.first < numPoints) seen[ob.first]++;
+    std::vector<char> tested(numPoints, 0);
+    for (const auto& kv : points) if (kv.first >= 0 && kv.first < numPoints && kv.second.norm() != 0 && seen[kv.first] >= 3) tested[kv.first] = 1;
+    std::vector<int> left(seen);
+    int dropped = 0;
+    for (auto& row : observations) {
+        if (!usable_row(row.first)) continue;
+        const Camera& cam = cameras[row.first];
+        double R[9]; ssfm::angle_axis_to_matrix(&cam[3], R);                  // ReprojectionError without the loss (src/sfm.cpp:38-63)
+        for (auto it = row.second.begin(); it != row.second.end();) {
+            const int id = it->first;
+            bool drop = false;
+            if (id >= 0 && id < numPoints && tested[id]) {
+                double p[3]; ssfm::mat3_vec(R, points[id].v, p);
+                p[0] += cam[0]; p[1] += cam[1]; p[2] += cam[2];
+                const double ex = intrinsics.focal * (p[0] / p[2]) - it->second.x, ey = intrinsics.focal * (p[1] / p[2]) - it->second.y;
+                drop = std::sqrt(ex * ex + ey * ey) > thresh;
             }
+            if (drop) { it = row.second.erase(it); left[id]--; dropped++; } else ++it;
         }
     }
-    std::cout << "removed " << nremoved << " observations\n";
+    for (int id = 0; id < numPoints; id++) if (tested[id] && left[id] == 0) SetPoint(id, Point(0, 0, 0));
+    std::cout << "removed " << dropped << " observations\n";
 }
 
 }  // namespace sphericalsfm

@@ -56,6 +56,7 @@ protected:
     std::map<int, std::map<int, Observation>> observations;   // [camera][point]
     std::map<int, std::string> paths;
     std::map<int, std::array<unsigned char, 3>> colors;        // BGR like cv::Vec3b (the reference's SparseVector<cv::Vec3b>)
+    std::map<int, std::vector<float>> descriptors;             // SparseVector<cv::Mat>, one row of floats per point
     bool focalFixed;
     std::map<int, bool> rotationFixed, translationFixed, pointFixed;
     int numCameras, numPoints, nextCamera, nextPoint;
@@ -74,7 +75,11 @@ public:
     Intrinsics GetIntrinsics() const { return intrinsics; }
     int AddCamera(const Pose& initial_pose, const std::string& path = "");
     int AddPoint(const Point& initial_position);
-    int AddPoint(const Point& initial_position, const std::array<unsigned char, 3>& color_bgr);   // descriptors are opaque to this path and not kept
+    int AddPoint(const Point& initial_position, const std::array<unsigned char, 3>& color_bgr);
+    // cv::Mat descriptor -> a flat float vector (128 floats for SIFT): opaque to this path, kept per point and erased with it (src/sfm.cpp:113-127,443)
+    int AddPoint(const Point& initial_position, const std::vector<float>& descriptor, const std::array<unsigned char, 3>& color_bgr = {{0, 0, 0}});
+    std::vector<float> GetDescriptor(int point);                                                // include/sphericalsfm/sfm.h:72
+    // (GetMeasurement, include/sphericalsfm/sfm.h:71, is declared by the reference and defined nowhere in it: nothing to mirror)
     std::array<unsigned char, 3> GetColor(int point);
     void AddObservation(int camera, int point, const Observation& observation);
     void RemoveCamera(int camera);
