@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     }
     for (int j = 0; j < Np; j++) {
         const Point X(0.4 * std::cos(0.7 * j), 0.3 * std::sin(1.3 * j), 4.0 + 0.25 * j);
-        sfm.AddPoint(j == 7 ? Point(0, 0, 0) : X, {(unsigned char)(10 * j), (unsigned char)(255 - 10 * j), (unsigned char)(3 * j)});   // point 7 is "removed" (zero)
+        sfm.AddPoint(j == 7 ? Point(0, 0, 0) : X, std::array<unsigned char, 3>{{(unsigned char)(10 * j), (unsigned char)(255 - 10 * j), (unsigned char)(3 * j)}});   // point 7 is "removed" (zero)
         for (int i = 0; i < Nc; i++) {
             if ((i + j) % 4 == 3) continue;                                       // ragged tracks
             const Pose P = sfm.GetPose(i);
