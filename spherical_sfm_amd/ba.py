@@ -30,6 +30,7 @@ class Context:
         if rc != 0:
             raise _lib.SsfmError(f"ssfm_ctx_create failed ({rc}): {L.ssfm_last_error(None).decode()}")
         self.nranks, self.rank = 1, 0
+        self._adjusters = []          # weak references to the live BundleAdjusters of this context: closed with it (handles die before their context)
 
     @staticmethod
     def unique_id():
@@ -57,6 +58,11 @@ class Context:
 
     def close(self):
         if self._p:
+            for ref in self._adjusters:
+                adj = ref()
+                if adj is not None:
+                    adj.close()
+            self._adjusters = []
             _lib.lib().ssfm_ctx_destroy(self._p)
             self._p = C.c_void_p()
 
@@ -134,7 +140,12 @@ class BundleAdjuster:
         self.buf = _ProblemBuffers(prob)
         self.opt = options or default_options(**kw)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().ssfm_ba_create(ctx._p, C.byref(self.buf.c), C.byref(self.opt), C.byref(self._h)), ctx._p)
+        rc = _lib.lib().ssfm_ba_create(ctx._p, C.byref(self.buf.c), C.byref(self.opt), C.byref(self._h))
+        if rc != 0:                    # the library has already torn the half-built handle down (*out is null on failure)
+            self._h = C.c_void_p()
+            _lib.check(rc, ctx._p)
+        import weakref
+        ctx._adjusters.append(weakref.ref(self))
 
     def reset(self):
         _lib.check(_lib.lib().ssfm_ba_reset(self._h), self.ctx._p)

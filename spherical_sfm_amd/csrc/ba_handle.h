@@ -40,7 +40,14 @@ struct DevBuf {
         (void)hipGetDevice(&dev);
         hipError_t e = hipSuccess;
         p = static_cast<T*>(g_dev_pool.take(bytes, dev, &cap_bytes));
-        if (!p) { e = hipMalloc((void**)&p, bytes); cap_bytes = bytes; }
+        if (!p) {
+            e = hipMalloc((void**)&p, bytes); cap_bytes = bytes;
+            if (e != hipSuccess) {                    // the pool may be sitting on the memory: give it back to the driver and try once more
+                (void)hipGetLastError(); g_dev_pool.drain(dev);
+                e = hipMalloc((void**)&p, bytes);
+                if (e != hipSuccess) { p = nullptr; cap_bytes = 0; }
+            }
+        }
         if (g_alloc_timing) { g_alloc_s += wall_s() - t0; g_alloc_n++; }
         return e;
     }
@@ -57,6 +64,7 @@ using namespace ssfm;
 
 struct ssfm_ba_handle {
     ssfm_ctx* ctx = nullptr;
+    int device = 0;              // cached at creation: destroy must not read through ctx (Python may finalise the context first)
     ssfm_ba_options opt;
     BAFlat F;
     int n_red = 0;                       // length of the all-reduced assembly buffer

@@ -369,11 +369,19 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     return SSFM_OK;
 }
 
+static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_handle** out);
+// A failed create leaves nothing behind: the half-built handle is destroyed here and *out is null.
 extern "C" int ssfm_ba_create(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_handle** out) {
     if (!ctx || !p || !out) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ba_create: null argument");
+    *out = nullptr;
+    const int rc = ba_create_impl(ctx, p, o, out);
+    if (rc != SSFM_OK && *out) { const std::string msg = ctx->err; ssfm_ba_destroy(*out); *out = nullptr; ctx->err = msg; }
+    return rc;
+}
+static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_handle** out) {
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ssfm_ba_handle* h = new ssfm_ba_handle();
-    h->ctx = ctx;
+    h->ctx = ctx; h->device = ctx->device;
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
@@ -552,7 +560,10 @@ extern "C" int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p) {
 
 extern "C" void ssfm_ba_destroy(ssfm_ba_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    (void)hipSetDevice(h->device);
+    // nothing of this handle may still be in flight when its buffers go back to the pool (asynchronous copies of ssfm_ba_reset, a
+    // speculative launch); the device-wide wait does not touch the context, which the caller may already have destroyed
+    (void)hipDeviceSynchronize();
     h->free_all();
     delete h;
 }

@@ -261,7 +261,8 @@ extern "C" void ssfm_rotavg_default_options(ssfm_ba_options* o) {
 
 extern "C" int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
                                 const double* rel_rotations, double* cost) {
-    if (!ctx || !rotations || !cost || E <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg_cost: bad arguments");
+    if (!ctx || !rotations || !cost || E <= 0 || n <= 0 || !index0 || !index1 || !rel_rotations) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg_cost: bad arguments");
+    for (int e = 0; e < E; e++) if (index0[e] < 0 || index0[e] >= n || index1[e] < 0 || index1[e] >= n) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg_cost: edge index out of range");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     RotGraph G; build_graph(n, rotations, E, index0, index1, rel_rotations, 1, false, G);   // PoseGraphError, src/uncalibrated_pose_graph.cpp:131
@@ -276,10 +277,23 @@ extern "C" int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotation
     return SSFM_OK;
 }
 
+// the buffers of one pose-graph solve; released on every exit path of rot_solve (after the stream has drained: the pool rule of ssfm_ctx.h)
+struct RotScratch {
+    ssfm_ctx* ctx; ssfm_ba_handle H;
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out, m3, mf; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    explicit RotScratch(ssfm_ctx* c) : ctx(c) {}
+    ~RotScratch() {
+        (void)hipStreamSynchronize(ctx->stream);
+        x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); ls_out.free(); m3.free(); mf.free(); e0.free(); e1.free(); ec.free();
+        H.free_all();
+    }
+};
+
 static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int32_t E, const int32_t* index0, const int32_t* index1,
                      const double* rel, double* focal_length, double min_focal, double max_focal, const ssfm_ba_options* opt_in,
                      ssfm_ba_summary* S) {
-    if (!ctx || !rotations || !S || E <= 0 || n <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg: bad arguments");
+    if (!ctx || !rotations || !S || E <= 0 || n <= 0 || !index0 || !index1 || !rel) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg: bad arguments");
+    for (int e = 0; e < E; e++) if (index0[e] < 0 || index0[e] >= n || index1[e] < 0 || index1[e] >= n) return fail(ctx, SSFM_ERR_INVALID, "ssfm_rotavg: edge index out of range");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::memset(S, 0, sizeof(*S));
@@ -289,8 +303,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     const bool with_f = kind == 2;
     const double f_lo = with_f ? min_focal / *focal_length : 0.0, f_hi = with_f ? max_focal / *focal_length : 0.0;   // :181-182
     // ---- reduced-system container (the BA handle's solver state with DC = 3)
-    ssfm_ba_handle H; ssfm_ba_handle* h = &H;
-    h->ctx = ctx; h->opt = O;
+    RotScratch RS(ctx); ssfm_ba_handle* h = &RS.H;
+    h->ctx = ctx; h->device = ctx->device; h->opt = O;
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     BAFlat& F = h->F; F.Nc = n; F.DC = 3;
     {
@@ -309,7 +323,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
     // scale laid out 6 per node (slots 3..5) so that k_finalize_S<3> can be reused unchanged
     std::vector<double> mask6((size_t)6 * n, 0.0); for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) mask6[6 * i + 3 + k] = G.mask[3 * i + k];
-    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    DevBuf<double>&x = RS.x, &xc = RS.xc, &fm2 = RS.fm2, &sc3 = RS.sc3, &sc6 = RS.sc6, &scf = RS.scf, &step = RS.step, &ls_out = RS.ls_out;
+    DevBuf<int>&e0 = RS.e0, &e1 = RS.e1; DevBuf<EdgeConst>& ec = RS.ec;
     const double fm0 = with_f ? std::fmin(std::fmax(1.0, f_lo), f_hi) : 1.0;      // IterationZero projects the start point of a bounded problem
     std::vector<double> fmv = {fm0, fm0};
 #define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
@@ -347,14 +362,13 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     };
     // ---- Jacobi scaling from the initial Jacobian: s = mask / (1 + |J_col|)
     {
-        DevBuf<double> m3, mf; std::vector<double> mfv = {with_f ? 1.0 : 0.0};
+        DevBuf<double>&m3 = RS.m3, &mf = RS.mf; std::vector<double> mfv = {with_f ? 1.0 : 0.0};
         SSFM_HIP_CHECK(ctx, upload(m3, G.mask, st)); SSFM_HIP_CHECK(ctx, upload(mf, mfv, st));
         int rc = assemble(m3.p, mf.p); if (rc) return rc;
         hipLaunchKernelGGL(k_make_scale, dim3((3 * n + 255) / 256), dim3(256), 0, st, h->Udiag, m3.p, sc3.p, 3 * n, O.jacobi_scaling);
         hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->scal.p + SC_FJJ, mf.p, scf.p, 1, O.jacobi_scaling);
         hipLaunchKernelGGL(k_scale3to6, dim3((6 * n + 255) / 256), dim3(256), 0, st, sc3.p, n, sc6.p);
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));              // m3 / mf go back to the pool
-        m3.free(); mf.free();
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
     double x_norm = 0; { double s2 = with_f ? fm0 * fm0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
@@ -469,9 +483,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < n; i++) { double R[9]; so3exp(&xf[3 * i], R); for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rotations[9 * i + a + 3 * b] = R[3 * a + b]; }
     if (with_f) *focal_length *= fmult;                                         // src/uncalibrated_pose_graph.cpp:200
-    x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); ls_out.free(); e0.free(); e1.free(); ec.free();
-    h->free_all();
-    S->t_solve_s = wall_s() - t0;
+    S->t_solve_s = wall_s() - t0;                          // RotScratch releases the buffers
     return SSFM_OK;
 }
 

@@ -30,7 +30,10 @@ namespace ssfm {
 
 // Device-memory recycling.  A handle owns ~80 buffers; hipFree synchronises the device, and tearing a handle down on a structure
 // change cost 3 ms of the 16 ms of a first call.  Freed buffers go to this pool and the next handle's allocations are served from it
-// (best fit, at most twice the requested size); ssfm_ctx_destroy drains it.
+// (best fit, at most twice the requested size); ssfm_ctx_destroy drains it, and so does an allocation that the driver refuses.
+// RULE (the pool is keyed by device, not by stream): a buffer is only given to the pool after the stream that used it has been
+// synchronised -- ssfm_ba_destroy / free_all and every entry point that frees its temporaries do so -- which is what hipFree's implicit
+// synchronisation used to guarantee.
 struct DevPool {
     struct Blk { void* p; size_t bytes; int dev; };
     std::vector<Blk> blocks; std::mutex m; size_t total = 0;
