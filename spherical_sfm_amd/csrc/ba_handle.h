@@ -259,6 +259,8 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
             if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+            if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+            static const bool chain_mfma = !(std::getenv("SSFM_CHAIN_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_MFMA")) == 0);     // matrix-core separator chain (band_sub.h 4b)
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
             LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
@@ -273,7 +275,19 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_begin(KID_SUB_ASM);
                 hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
                 h->span_end();
-                LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
+                if (chain_mfma) {
+                    // SSFM_CHAIN_STAMPS=1: s_memtime stamps of the phases of one separator, printed once (profiles/*_notes.md)
+                    static long long* d_stamps = nullptr; static int stamp_state = std::getenv("SSFM_CHAIN_STAMPS") ? 1 : 0;
+                    if (stamp_state == 1) { (void)hipMalloc((void**)&d_stamps, 16 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(long long), st); stamp_state = 2; }
+                    LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps);
+                    if (stamp_state == 2) {
+                        long long hs[16]; (void)hipMemcpyAsync(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st);
+                        std::fprintf(stderr, "[chain stamps, cycles] load E %lld | F solve %lld | t update + F store %lld | load D %lld | syrk %lld | chol J=0: diag %lld panel %lld trailing %lld | chol total %lld | stores %lld\n",
+                                     hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6], hs[9] - hs[7], hs[8] - hs[5], hs[10] - hs[8]);
+                        stamp_state = 3;
+                    }
+                }
+                else LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
             }
             if (B.ntwist > 0) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges

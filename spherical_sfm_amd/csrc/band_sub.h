@@ -39,14 +39,14 @@ struct BandSub {
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
-// (0.13 b - 0.17), the spike (1.1) and the back substitution (0.43); per separator 150 (b dc / 114)^2.5 for the chain; 170 fixed for the
+// (0.13 b - 0.17), the spike (1.1) and the back substitution (0.43); per separator 125 (b dc / 114)^2.5 for the chain (matrix-core kernel, r02); 170 fixed for the
 // extra launches, the assembly and the memsets.  Segments must be at least b + 1 rows.  Components shorter than SUB_MIN_ROWS stay on
 // one workgroup (config 2's rings of 75: 135 us uncut against ~180 us cut in two).
 constexpr int SUB_MIN_ROWS = 512;                  // = BAND_CUT_MIN_ROWS (ba_flatten.h): shorter components are twisted instead
 inline int sub_choose_segments(int rows, int b, int dc) {
     if (rows < SUB_MIN_ROWS) return 1;
     const double t_chol = std::max(0.13 * b - 0.17, 0.4), t_spike = 1.1, t_back = 0.43;
-    const double t_sep = 150.0 * std::pow(b * dc / 114.0, 2.5), t_fixed = 170.0;
+    const double t_sep = 125.0 * std::pow(b * dc / 114.0, 2.5), t_fixed = 170.0;
     int best = 1; double best_t = rows * (t_chol + t_back);
     for (int P = 2; P <= 64; P++) {
         const int m = (rows - (P - 1) * b) / P;
@@ -456,6 +456,268 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
         __syncthreads();
     }
 #undef PK
+}
+
+// ---- 4b. the same chain on the matrix cores ------------------------------------------------------------------------------------------
+// The three dense phases of a separator -- F = E Lc^-T (Q^3 flop), D -= F F^T (Q^3) and chol(D) (Q^3 / 3), Q = b DC <= 114 -- as
+// 16x16 tiles of v_mfma_f64_16x16x4_f64 (one wave per tile, operands straight from LDS: A(i, k) on lane (i = l & 15, k = l >> 4), B(k, j)
+// likewise, four accumulators per lane at rows (l >> 4) + 4 q, column l & 15).  A tile product of 16 columns is four instructions of
+// 1024 multiply-adds each instead of ~4000 LDS reads feeding scalar FMAs, which is what bounded the VALU kernel above (profiles/r01_notes.md).
+// The blocked algorithms take 16 columns per step instead of DC:
+//   * F = E Lc^-T: rows of E are independent, so wave I owns row tile I and walks the block columns J = 0.. on its own -- F(I, J) =
+//     (E(I, J) - sum_{K<J} F(I, K) Lc(J, K)^T) G_J^T with G_J = Lc(J, J)^-1 -- without a single workgroup barrier;
+//   * D -= F F^T: the 36 lower tiles over the 16 waves, K = Q in steps of 4;
+//   * chol(D): per block column J one wave factors AND inverts the 16x16 diagonal block (wave_chol_inverse16: lane per row, v_readlane
+//     broadcasts), panels L(I, J) = A(I, J) G_J^T and trailing tiles A(I, K) -= L(I, J) L(K, J)^T on the matrix cores; 3 barriers per
+//     block column (24 per separator instead of 57); the forward substitution of the right-hand sides rides along.
+// Q is not a multiple of 16: the last tile is partial.  Rows / columns beyond Q are never stored; operand rows beyond Q only feed such
+// outputs and are left as they are (they stay inside the LDS allocation), the K index is masked where it can run past Q.  The diagonal
+// blocks of the packed triangle hold G_J (16x16) here, so the substitutions work on 16-blocks too.  Same arguments and buffers as
+// k_sub_sep_chain (SSFM_CHAIN_MFMA=0 selects that one).
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+// lane r < 16 enters with row r of an SPD 16x16 block; on exit lane c holds column c of G = L^-1 (g[r] = G[r][c], zero above the diagonal)
+__device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&g)[16]) {
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        double d = lane_bcast(row[c], c);
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        const double l = row[c] * fast_rsqrt(d);             // L[r][c] on lane r (meaningful for r >= c); replaces row[c]
+        row[c] = l;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; c2++) row[c2] -= l * lane_bcast(l, c2);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {                           // G[r][c] = ( [r == c] - sum_{k<r} L[r][k] G[k][c] ) / L[r][r]  on lane c
+        double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++) acc -= lane_bcast(row[k], r) * g[k];
+        g[r] = acc * fast_rcp(lane_bcast(row[r], r));
+    }
+    return ok;
+}
+
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
+                     const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
+                     double* __restrict__ Y, int* __restrict__ fail_flag, long long* __restrict__ stamps /* null, or [16] phase stamps of chain 0, separator 1 */) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int TB = 16;
+#define STAMP(k_) do { if (stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = blockDim.x, NP = Q * (Q + 1) / 2, TQ = (Q + TB - 1) / TB;
+    double* sL = lds;                  // [NP]   packed lower triangle, row-major; the 16x16 diagonal blocks hold G_J = L_JJ^-1
+    double* sF = sL + NP;              // [Q][Q] column-major: F(i, c) at c*Q + i
+    double* sT = sF + (size_t)Q * Q;   // [NR][Q]
+    double* sW = sT + NR * Q;          // [NR][Q]
+    const int s0 = chain_ptr[blockIdx.x], ns = chain_ptr[blockIdx.x + 1] - s0;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int tx = tid & 127, ty = tid >> 7;
+    const bool rowt = tx < Q;
+#define PK(i_, c_) ((i_) * ((i_) + 1) / 2 + (c_))
+#define MFMA64(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+    for (int j = 0; j < ns; j++) {
+        const int s = s0 + j, p0 = sep_lo[s];
+        STAMP(0);
+        for (int e = tid; e < NR * Q; e += nt) sT[e] = tt[(size_t)s * NR * Q + e];
+        if (j > 0) {
+            if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx];
+            __syncthreads();
+            STAMP(1);
+            // ---- F = E Lc^-T: wave I = row tile I, block columns in order, no barrier
+            if (wave < TQ) {
+                const int I = wave, r0 = TB * I;
+                for (int J = 0; J < TQ; J++) {
+                    const int c0 = TB * J;
+                    v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int K = 0; K < J; K++) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int kc = TB * K + 4 * kk + lk;                   // < c0 <= Q - 1: always a real column
+                            acc = MFMA64(sF[kc * Q + r0 + li], sL[PK(c0 + li, kc)], acc);
+                        }
+                    }
+                    // T = E(I, J) - acc, in place (accumulator layout: rows lk + 4 q, column li)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int row = r0 + lk + 4 * q, col = c0 + li;
+                        if (row < Q && col < Q) sF[col * Q + row] -= acc[q];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    v4d_t f = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int k = 4 * kk + lk, kc = c0 + k;
+                        const double a = (kc < Q) ? sF[kc * Q + r0 + li] : 0.0;                                   // T(r0 + li, kc)
+                        const double g = (k <= li && c0 + li < Q) ? sL[PK(c0 + li, kc)] : 0.0;                    // G_J[li][k]
+                        f = MFMA64(a, g, f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int row = r0 + lk + 4 * q, col = c0 + li;
+                        if (row < Q && col < Q) sF[col * Q + row] = f[q];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            __syncthreads();
+            STAMP(2);
+            // ---- t_j -= F w_{j-1};  F to global for the backward pass
+            if (rowt && ty < NR) {
+                double acc = 0.0;
+                for (int c = 0; c < Q; c++) acc += sF[c * Q + tx] * sW[ty * Q + c];
+                sT[ty * Q + tx] -= acc;
+            }
+            for (int e = tid; e < Q * Q; e += nt) Fbuf[(size_t)s * Q * Q + e] = sF[e];
+        }
+        // ---- D_j into the packed triangle (previous factor is dead: it went to Lbuf)
+        __syncthreads();
+        STAMP(3);
+        if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = Dd[((size_t)s * Q + tx) * Q + cp];
+        __syncthreads();
+        STAMP(4);
+        if (j > 0) {
+            // ---- D_j -= F F^T: lower tiles over the waves
+            const int ntile = TQ * (TQ + 1) / 2;
+            for (int t = wave; t < ntile; t += nw) {
+                int I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++;
+                const int J = t - I * (I + 1) / 2, r0 = TB * I, c0 = TB * J;
+                v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < Q; k0 += 4) {
+                    const int kc = k0 + lk; const bool in = kc < Q; const int kcc = in ? kc : Q - 1;
+                    const double a = in ? sF[kcc * Q + r0 + li] : 0.0, bb = in ? sF[kcc * Q + c0 + li] : 0.0;
+                    acc = MFMA64(a, bb, acc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = r0 + lk + 4 * q, col = c0 + li;
+                    if (row < Q && col <= row) sL[PK(row, col)] -= acc[q];
+                }
+            }
+        }
+        // ---- blocked Cholesky (16 columns per step), forward substitution of t riding along
+        for (int J = 0; J < TQ; J++) {
+            const int c0 = TB * J, nJ = min(TB, Q - c0);
+            __syncthreads();
+            if (J == 0) STAMP(5);
+            if (J == 1) STAMP(9);
+            if (wave == 0) {
+                double row[16], g[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) row[c] = (li < nJ && c < nJ && lane < 16) ? sL[PK(c0 + max(li, c), c0 + min(li, c))] : ((lane == c) ? 1.0 : 0.0);
+                if (!wave_chol_inverse16(row, g) && lane == 0) *fail_flag = 1;
+                if (lane < nJ) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) if (r >= lane && r < nJ) sL[PK(c0 + r, c0 + lane)] = g[r];
+                }
+            }
+            __syncthreads();
+            if (J == 0) STAMP(6);
+            const int below = TQ - 1 - J;                                   // row tiles under the diagonal block
+            if (wave < below) {                                             // panel: L(I, J) = A(I, J) G_J^T
+                const int r0 = TB * (J + 1 + wave);
+                v4d_t pacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int k = 4 * kk + lk, kc = c0 + k;
+                    const double a = (k < nJ) ? sL[PK(r0 + li, kc)] : 0.0;
+                    const double g = (k <= li && li < nJ) ? sL[PK(c0 + li, kc)] : 0.0;
+                    pacc = MFMA64(a, g, pacc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = r0 + lk + 4 * q;
+                    if (row < Q && li < nJ) sL[PK(row, c0 + li)] = pacc[q];
+                }
+            } else if (wave == nw - 1 && lane < NR * TB) {                  // w block = G_J t block
+                const int r = lane / TB, k = lane - r * TB;
+                double acc = 0.0;
+                if (k < nJ) for (int m = 0; m <= k; m++) acc += sL[PK(c0 + k, c0 + m)] * sT[r * Q + c0 + m];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (k < nJ) sT[r * Q + c0 + k] = acc;
+            }
+            __syncthreads();
+            if (J == 0) STAMP(7);
+            if (below > 0) {                                                // trailing tiles (I, K), J < K <= I
+                const int ntile = below * (below + 1) / 2;
+                for (int t = wave; t < ntile; t += nw) {
+                    int a = 0; while ((a + 1) * (a + 2) / 2 <= t) a++;
+                    const int r0 = TB * (J + 1 + a), k0r = TB * (J + 1 + (t - a * (a + 1) / 2));
+                    v4d_t u = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int kc = c0 + 4 * kk + lk;                    // nJ = 16 whenever a tile lies below this block
+                        u = MFMA64(sL[PK(r0 + li, kc)], sL[PK(k0r + li, kc)], u);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int row = r0 + lk + 4 * q, col = k0r + li;
+                        if (row < Q && col <= row) sL[PK(row, col)] -= u[q];
+                    }
+                }
+                if (rowt && tx >= c0 + TB && ty >= 8 - NR) {                // t(rows below) -= L(rows, block) w block   (threads of the last waves)
+                    const int r = ty - (8 - NR);
+                    double v = sT[r * Q + tx];
+                    const double* Pr = sL + PK(tx, c0);
+#pragma unroll
+                    for (int k = 0; k < TB; k++) v -= Pr[k] * sT[r * Q + c0 + k];
+                    sT[r * Q + tx] = v;
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(8);
+        for (int e = tid; e < NP; e += nt) Lbuf[(size_t)s * NP + e] = sL[e];
+        for (int e = tid; e < NR * Q; e += nt) { const double wv = sT[e]; sW[e] = wv; wbuf[(size_t)s * NR * Q + e] = wv; }
+        __syncthreads();
+        STAMP(10);
+    }
+#undef STAMP
+    // ---- backward
+    for (int j = ns - 1; j >= 0; j--) {
+        const int s = s0 + j, p0 = sep_lo[s];
+        if (j < ns - 1) {                                   // reload this separator's factor and w; v = w - F_{j+1}^T x_{j+1}
+            for (int e = tid; e < NP; e += nt) sL[e] = Lbuf[(size_t)s * NP + e];
+            const double* Fn = Fbuf + (size_t)(s + 1) * Q * Q;
+            for (int o = wave; o < NR * Q; o += nw) {
+                const int r = (o >= Q) ? o / Q : 0, c = o - r * Q;
+                double acc = 0.0;
+                for (int i = lane; i < Q; i += 64) acc += Fn[(size_t)c * Q + i] * sW[r * Q + i];
+                acc = wave_sum(acc);
+                if (lane == 0) sT[o] = wbuf[(size_t)s * NR * Q + o] - acc;
+            }
+        } else {
+            for (int e = tid; e < NR * Q; e += nt) sT[e] = sW[e];
+        }
+        // x = Lc^-T v, 16 rows per step from the last block
+        for (int J = TQ - 1; J >= 0; J--) {
+            const int c0 = TB * J, nJ = min(TB, Q - c0);
+            __syncthreads();
+            double xv = 0.0;
+            const int br = tid / TB, bk = tid - br * TB;
+            if (tid < NR * TB && bk < nJ) for (int m = bk; m < nJ; m++) xv += sL[PK(c0 + m, c0 + bk)] * sT[br * Q + c0 + m];       // x = G^T v
+            __syncthreads();
+            if (tid < NR * TB && bk < nJ) sT[br * Q + c0 + bk] = xv;
+            __syncthreads();
+            if (ty < NR && tx < c0) {
+                double v = sT[ty * Q + tx];
+                for (int k = 0; k < nJ; k++) v -= sL[PK(c0 + k, tx)] * sT[ty * Q + c0 + k];
+                sT[ty * Q + tx] = v;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < NR * Q; e += nt) {
+            const int r = (e >= Q) ? e / Q : 0, c = e - r * Q;
+            const double x = sT[e];
+            sW[e] = x; Y[(size_t)r * n + (size_t)p0 * DC + c] = x;
+        }
+        __syncthreads();
+    }
+#undef PK
+#undef MFMA64
 }
 
 // ---- 5. y(seg) -= Z x(separator in front) ------------------------------------------------------------------------------------------
