@@ -142,3 +142,19 @@ def test_config5_full_size_parity(gpu_ctx, oracle):
     assert rel_err(cams, ocams) <= 1e-5
     assert point_rel_err(pts, opts) <= 1e-5
     assert s["band_separators"] > 0                       # the long rings were cut
+
+
+@pytest.mark.parametrize("spherical", [True, False])
+def test_config3_size_shared_focal_free_parity(gpu_ctx, oracle, spherical):
+    """BASELINE.json configs[2] at its size: 500 frames / 170k points / 1.02 M observations, the uncalibrated
+    pipeline's bundle adjustments -- shared focal FREE, first spherical (translations fixed) then general (-generalba),
+    examples/run_spherical_sfm_uncalib.cpp:176-211.  Stride 7: seven rings of 71-72 cameras."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(500, 170000, 6, spherical=spherical, focal_fixed=False)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["num_residual_blocks"] == os_["num_residual_blocks"] == 1020000
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"]
+    assert s["camera_dof"] == (3 if spherical else 6)
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    assert abs(f - p.gt_focal) <= 2e-3 * p.gt_focal                     # 1.1 x f at the start, recovered
