@@ -252,17 +252,26 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
     const int chol_threads = 64 * (2 + CHOL2_LOADERS + std::min(std::max((tr_tasks + 63) / 64, 1), 7));
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
+    // matrix-core panel + trailing update (band_kernels2.h, MF): 6x6 blocks only; SSFM_BAND_MFMA=0 keeps the VALU version
+    static const int band_mfma_env = std::getenv("SSFM_BAND_MFMA") ? std::atoi(std::getenv("SSFM_BAND_MFMA")) : 0;      // bit 0: panel, bit 1: trailing update (experiment)
+    constexpr int MFP = (DC == 6) ? 1 : 0, MFT = (DC == 6) ? 2 : 0, MFB = (DC == 6) ? 3 : 0;
+    const int mf = (DC == 6 && b * DC <= 127) ? (band_mfma_env & 3) : 0;
+#define SSFM_LAUNCH_CHOL2_V(V_, grid_, ...)                                                                                                 \
+    do { if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win)); \
+         LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2, V_>), grid_, chol_threads, lds_win, __VA_ARGS__); } while (0)
+#define SSFM_LAUNCH_CHOL2(grid_, ...)                                                                                                       \
+    do { if (mf == 3) SSFM_LAUNCH_CHOL2_V(MFB, grid_, __VA_ARGS__); else if (mf == 2) SSFM_LAUNCH_CHOL2_V(MFT, grid_, __VA_ARGS__);          \
+         else if (mf == 1) SSFM_LAUNCH_CHOL2_V(MFP, grid_, __VA_ARGS__); else SSFM_LAUNCH_CHOL2_V(0, grid_, __VA_ARGS__); } while (0)
         if (h->sub.enabled && use_lds && back_v2) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
             const BandSub& B = h->sub;
             const int Q = b * DC;
             const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
-            if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             static const bool chain_mfma = !(std::getenv("SSFM_CHAIN_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_MFMA")) == 0);     // matrix-core separator chain (band_sub.h 4b)
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
-            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.nseg, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
+            SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
                 h->span_begin(KID_SUB_SPIKE);
@@ -293,7 +302,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
-                LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), B.ntwist, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
+                SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
                 h->span_begin(KID_BAND_BACK);
                 hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.ntwist, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
@@ -310,10 +319,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
         }
         // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
         if (use_lds) {
-            if (lds_win > 48 * 1024) {
-                SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-            }
-            LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2>), ncomp, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            SSFM_LAUNCH_CHOL2(ncomp, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
                 hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);
@@ -326,6 +332,8 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
         }
         return SSFM_OK;
+#undef SSFM_LAUNCH_CHOL2
+#undef SSFM_LAUNCH_CHOL2_V
     }
 
 // Second solve with the factor of band_direct (PCG refinement): forward + back substitution of the first column of Y with the stored

@@ -65,7 +65,14 @@ __device__ __forceinline__ bool wave_chol_inverse(double (&row)[DC], double (&g)
 // Every wave takes its share of the panel product in phase B.
 constexpr int CHOL2_LOADERS = 2;
 
-template <int DC, int NR>
+// MF = true (DC = 6 only): the panel product and the trailing update run on the matrix cores -- v_mfma_f64_16x16x4_f64 tiles in
+// window-relative coordinates (row i of the window = block i / 6 + 1 behind the pivot, scalar row i % 6), K = the pivot's six columns in two
+// instructions (the second one half masked).  Operands come straight from the panel in LDS (row-major 6 doubles per scalar row: the 16
+// rows of a tile at one k sit in 16 different bank pairs); the four accumulators of a lane go back into the ring of window rows by
+// read-modify-write.  Against the 3x3 register tiles of the VALU version (54 LDS operations per 54 multiply-adds and lane, scattered over
+// the panel: the phase was LDS-conflict bound at ~80 B/clk) a tile is 8 conflict-free operand reads + 4 read-modify-writes per 1536
+// multiply-adds.  SSFM_BAND_MFMA=0 selects the VALU version.
+template <int DC, int NR, int MF = 0>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
@@ -155,7 +162,26 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     const bool is_writer = wave == nw - 1;
     const int lw = wave - 1 - ntw;                          // loader index, valid when 0 <= lw < CHOL2_LOADERS
     // ---- phase B, shared by every role: panel X_k = A_k G^T and y_j = G y_j into LDS
+    const int li = lane & 15, lk = lane >> 4;
     auto phaseB = [&](int j, int jm, int nb) {
+        if constexpr ((MF & 1) != 0) {
+            // panel X = A G^T, 16 window rows per wave: X(i, c) = sum_m A(i, m) G(c, m); tile rows 16 wave .. + 15, columns c = li < 6
+            const int nrow = nb * DC;
+            if (16 * wave < nrow) {
+                const int i = 16 * wave + li; const bool vi = i < nrow; const int ic = vi ? i : 0;
+                const int k = (ic * 43) >> 8, a = ic - 6 * k;                    // i / 6, i % 6 (exact below 128)
+                int sl = jm + 1 + k; if (sl >= R) sl -= R;
+                const double* A = sWin + (size_t)sl * RW + (size_t)(k + 1) * BB + a * DC;
+                const double a0 = vi ? A[lk] : 0.0, a1 = (vi && lk < 2) ? A[4 + lk] : 0.0;
+                const double b0 = (li < DC) ? sG[li * DC + lk] : 0.0, b1 = (li < DC && lk < 2) ? sG[li * DC + 4 + lk] : 0.0;
+                typedef double v4d_ __attribute__((ext_vector_type(4)));
+                v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int row = 16 * wave + lk + 4 * q; if (row < nrow && li < DC) sP[row * DC + li] = acc[q]; }
+            }
+        } else
         for (int e = tid; e < nb * BB; e += nt) {
             const int k = e / BB, rc = e - k * BB, a = rc / DC, c = rc - a * DC;
             int sl = jm + 1 + k; if (sl >= R) sl -= R;
@@ -226,6 +252,72 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         constexpr int TR = (DC % 3 == 0) ? 3 : 1, TP = DC / TR, TPB = TP * TP;
         const int cw = ntw * 64, ct = tid - 64;
         int jm = jm0;
+        if constexpr ((MF & 2) != 0) {
+            typedef double v4d_ __attribute__((ext_vector_type(4)));
+            for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+                const int nb = min(b, re - 1 - j);
+                phaseB(j, jm, nb);
+                lds_barrier();
+                const int nrow = nb * DC, TQp = (nrow + 15) >> 4, ntile = TQp * (TQp + 1) / 2;
+                // three tiles in flight per pass: operand reads of all three, then the six instructions, then the read-modify-writes
+                for (int t0 = wave - 1; t0 < ntile; t0 += 3 * ntw) {
+                    int TI[3], TJ[3]; bool on[3]; v4d_ acc[3];
+                    double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const int t = t0 + u * ntw; on[u] = t < ntile; const int tc = on[u] ? t : 0;
+                        int I = 0; while ((I + 1) * (I + 2) / 2 <= tc) I++;
+                        TI[u] = I; TJ[u] = tc - I * (I + 1) / 2;
+                        const int i = 16 * TI[u] + li, jj = 16 * TJ[u] + li; const bool vi = on[u] && i < nrow, vj = on[u] && jj < nrow;
+                        const double* Pi = sP + (vi ? i : 0) * DC; const double* Pj = sP + (vj ? jj : 0) * DC;
+                        a0[u] = vi ? Pi[lk] : 0.0; b0[u] = vj ? Pj[lk] : 0.0;
+                        a1[u] = (vi && lk < 2) ? Pi[4 + lk] : 0.0; b1[u] = (vj && lk < 2) ? Pj[4 + lk] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { acc[u] = v4d_{0.0, 0.0, 0.0, 0.0}; acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[u], 0, 0, 0); }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[u], 0, 0, 0);
+                    // read-modify-write of the twelve accumulators: all addresses first, then all reads, then all writes (pointer-wise the
+                    // compiler has to assume that a write may hit the next read and would run the twelve round trips one after the other)
+                    double* dst[3][4]; double* dstm[3][4]; bool ok[3][4], mir[3][4]; double cur[3][4], curm[3][4];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const int c = 16 * TJ[u] + li, kr = ((c * 43) >> 8) + 1, w = c - 6 * (kr - 1);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int r = 16 * TI[u] + lk + 4 * q, ir = ((r * 43) >> 8) + 1, a = r - 6 * (ir - 1);
+                            ok[u][q] = on[u] && r < nrow && c < nrow && kr <= ir && !(ir == 1 && kr == 1);      // block (1, 1) belongs to wave 0
+                            // diagonal blocks are stored whole: an element whose mirror image lies in a tile above the diagonal (never
+                            // enumerated) writes that one too (P P^T is symmetric)
+                            mir[u][q] = ok[u][q] && ir == kr && TI[u] > TJ[u];
+                            const int irc = ok[u][q] ? ir : 1, krc = ok[u][q] ? kr : 1;
+                            int si = jm + irc; if (si >= R) si -= R;
+                            double* blk = sWin + (size_t)si * RW + (size_t)(irc - krc) * BB;
+                            dst[u][q] = blk + (ok[u][q] ? a * DC + w : 0); dstm[u][q] = blk + (mir[u][q] ? w * DC + a : 0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { cur[u][q] = *dst[u][q]; curm[u][q] = *dstm[u][q]; }
+#pragma unroll
+                    for (int u = 0; u < 3; u++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { if (ok[u][q]) *dst[u][q] = cur[u][q] - acc[u][q]; if (mir[u][q]) *dstm[u][q] = curm[u][q] - acc[u][q]; }
+                }
+                for (int qq = ct; qq < nb * DC; qq += cw) {                                    // right-hand sides: y_{j+kr} -= X_kr y_j
+                    const int kr = qq / DC + 1, a = qq - (kr - 1) * DC;
+                    int sk = jm + kr; if (sk >= R) sk -= R;
+                    const double* Lk_ = sP + (size_t)(kr - 1) * BB + a * DC;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) { double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < DC; m++) v += Lk_[m] * sYj[r * DC + m];
+                        sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
+                }
+                lds_barrier();
+            }
+        } else
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
