@@ -60,7 +60,7 @@ __device__ int nonminimal_solver_dev(const int* sample, int ns, const double* pu
 }
 
 struct LoShared {                    // static LDS of the trace kernel
-    double score[LO_T]; double red[10 * (LO_T / 64)]; double sh[16]; double bc; double E[9];
+    double score[LO_T]; double red[10 * (LO_T / 64)]; double sh[64]; double bc; double E[9];
     int sample[3 * LO_T]; int nm[LO_T]; int cnt[LO_T / 64]; int dr[64]; int flag;
 };
 
@@ -307,7 +307,7 @@ k_lomsac_trace(const int* __restrict__ pair_ptr, const double* __restrict__ gu, 
 __global__ void __launch_bounds__(LO_T)
 k_estimator_probe(int what, int n, const double* __restrict__ u, const double* __restrict__ v, const int* __restrict__ task_ptr,
                   const int* __restrict__ lists, const double* __restrict__ Ein /* [tasks*9] row-major */, int inward, double* __restrict__ out /* [tasks*12] */) {
-    __shared__ double red[10 * (LO_T / 64)]; __shared__ double sh[16];
+    __shared__ double red[10 * (LO_T / 64)]; __shared__ double sh[64];
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = blockIdx.x, l0 = task_ptr[t], cnt = task_ptr[t + 1] - l0;
     int* list = reinterpret_cast<int*>(lds);

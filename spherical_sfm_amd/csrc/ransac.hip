@@ -88,7 +88,7 @@ k_ransac_refine(const int* __restrict__ pair_ptr, const double* __restrict__ u, 
                 double* __restrict__ bestE, double* __restrict__ bestScore, double* __restrict__ outR,
                 unsigned char* __restrict__ inlier_mask, int* __restrict__ num_inliers) {
     __shared__ double red[10 * 4];
-    __shared__ double sh[16];
+    __shared__ double sh[64];
     __shared__ double bc;
     __shared__ int s_cnt[4];
     const int pair = blockIdx.x;

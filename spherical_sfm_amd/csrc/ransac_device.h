@@ -285,6 +285,9 @@ __device__ int spherical_models_from_basis(const double (*B)[3], double* Es) {
     const double c3 = cc[0], c2 = cc[1], c1 = cc[2], c0 = cc[3];
     const double scale = 1.0 + fabs(c3) + sqrt(fabs(c2)) + cbrt(fabs(c1)) + sqrt(sqrt(fabs(c0)));
     double zr[4] = {0.4 * scale, -0.9 * scale, -0.4 * scale, 0.9 * scale}, zi[4] = {0.9 * scale, 0.4 * scale, -0.9 * scale, -0.4 * scale};
+    // simple roots converge quadratically: once the largest correction is below 1e-13 of the root bound, one more sweep leaves every root at
+    // rounding level (a 1e-15 test is met by rounding noise only now and then -- 2 % of the samples ran all sweeps, and a wave waits for its slowest lane)
+    bool last = false;
     for (int it = 0; it < (ALL ? 200 : 100); it++) {
         double change = 0;
 #pragma unroll
@@ -301,7 +304,8 @@ __device__ int spherical_models_from_basis(const double (*B)[3], double* Es) {
             const double qr_ = (pr * dr + pi * di) / dn, qi = (pi * dr - pr * di) / dn;
             zr[i] -= qr_; zi[i] -= qi; change = fmax(change, ALL ? hypot(qr_, qi) : fabs(qr_) + fabs(qi));
         }
-        if (change < 1e-15 * scale) break;
+        if (last) break;
+        if (change < 1e-13 * scale) last = true;
     }
     int count = 0;
 #pragma unroll
@@ -434,29 +438,104 @@ __device__ double block_msac_score(const double* E, const double* pu, const doub
     return r;
 }
 
+// E(r) = [t]x R(r), t = -R(r) t0 + t0, t0 = (0, 0, tz) -- the essential matrix SampsonError builds from (r0 = 0, t0, r1 = r, t1 = t0)
+// (src/spherical_estimator.cpp:23-65) -- and, when dE != nullptr, its three partial derivatives dE[k] = dE / dr_k (row-major 3x3 each).
+// R is Ceres' AngleAxisToRotationMatrix (theta^2 > eps: Rodrigues, else I + [r]x), differentiated in closed form:
+//   R = c I + (1 - c) w w^T + s [w]x,  dw/dr_k = (e_k - w w_k) / theta,  dc/dr_k = -s w_k,  ds/dr_k = c w_k.
+// The same numbers the reference's Jets carry, without running every ray through the dual-number trigonometry.
+__device__ void sampson_E_and_derivatives(const double* r, double tz, double* E, double* dE /* [27] or null */) {
+    double R[9], Rk[3][9];
+    const double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    if (t2 > DBL_EPSILON) {
+        const double th = sqrt(t2), w[3] = {r[0] / th, r[1] / th, r[2] / th};
+        const double c = cos(th), s = sin(th), omc = 1.0 - c;
+        R[0] = c + w[0] * w[0] * omc;        R[1] = w[0] * w[1] * omc - w[2] * s; R[2] = w[1] * s + w[0] * w[2] * omc;
+        R[3] = w[2] * s + w[0] * w[1] * omc; R[4] = c + w[1] * w[1] * omc;        R[5] = w[1] * w[2] * omc - w[0] * s;
+        R[6] = w[0] * w[2] * omc - w[1] * s; R[7] = w[0] * s + w[1] * w[2] * omc; R[8] = c + w[2] * w[2] * omc;
+        if (dE) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double dw[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) dw[i] = (((i == k) ? 1.0 : 0.0) - w[i] * w[k]) / th;
+                const double dc = -s * w[k], ds = c * w[k];              // d cos / d r_k, d sin / d r_k;  d(1 - c) = -dc
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        Rk[k][3 * i + j] = ((i == j) ? dc : 0.0) - dc * w[i] * w[j] + omc * (dw[i] * w[j] + w[i] * dw[j]);
+                // + d(s [w]x): [w]x = [0 -w2 w1; w2 0 -w0; -w1 w0 0]
+                Rk[k][1] += -(ds * w[2] + s * dw[2]); Rk[k][2] += ds * w[1] + s * dw[1];
+                Rk[k][3] += ds * w[2] + s * dw[2];    Rk[k][5] += -(ds * w[0] + s * dw[0]);
+                Rk[k][6] += -(ds * w[1] + s * dw[1]); Rk[k][7] += ds * w[0] + s * dw[0];
+            }
+        }
+    } else {
+        R[0] = 1; R[1] = -r[2]; R[2] = r[1]; R[3] = r[2]; R[4] = 1; R[5] = -r[0]; R[6] = -r[1]; R[7] = r[0]; R[8] = 1;
+        if (dE) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int i = 0; i < 9; i++) Rk[k][i] = 0.0;
+            Rk[0][5] = -1; Rk[0][7] = 1; Rk[1][2] = 1; Rk[1][6] = -1; Rk[2][1] = -1; Rk[2][3] = 1;
+        }
+    }
+    const double t[3] = {R[2] * (-tz), R[5] * (-tz), R[8] * (-tz) + tz};
+#pragma unroll
+    for (int j = 0; j < 3; j++) { E[j] = t[1] * R[6 + j] - t[2] * R[3 + j]; E[3 + j] = t[2] * R[j] - t[0] * R[6 + j]; E[6 + j] = t[0] * R[3 + j] - t[1] * R[j]; }
+    if (dE) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double* Q = Rk[k]; double* D = dE + 9 * k;
+            const double tk[3] = {Q[2] * (-tz), Q[5] * (-tz), Q[8] * (-tz)};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                D[j] = tk[1] * R[6 + j] - tk[2] * R[3 + j] + t[1] * Q[6 + j] - t[2] * Q[3 + j];
+                D[3 + j] = tk[2] * R[j] - tk[0] * R[6 + j] + t[2] * Q[j] - t[0] * Q[6 + j];
+                D[6 + j] = tk[0] * R[3 + j] - tk[1] * R[j] + t[0] * Q[3 + j] - t[1] * Q[j];
+            }
+        }
+    }
+}
+
 // SphericalEstimator::LeastSquares (src/spherical_estimator.cpp:110-157) on the rays list[0..cnt): decompose E -> r, Levenberg-
 // Marquardt on the Sampson residuals with only r free (Ceres 2.2 TrustRegionMinimizer rules as restated in oracle/lm.hpp:
 // Jacobi scaling from the iteration-0 Jacobian, 200 iterations, 10 consecutive invalid steps, default tolerances, DENSE_NORMAL_CHOLESKY
 // on the 3x3 system), E <- make_spherical_essential_matrix(so3exp(r)).  E: registers, identical in every thread, in/out.
-// red: LDS double[10 * blockDim/64]; sh: LDS double[16].
+// The essential matrix of the current rotation and its three derivatives are the same for every ray: one thread evaluates them
+// (sampson_E_and_derivatives) and publishes 36 numbers through LDS; a ray then costs ~120 multiply-adds for its residual and gradient
+// instead of a pass through dual-number trigonometry.
+// red: LDS double[10 * blockDim/64]; sh: LDS double[64].
 __device__ void block_sampson_lsq(const int* list, int cnt, const double* pu, const double* pv, bool inward, double* E, double* red, double* sh) {
     const double tz = inward ? 1.0 : -1.0;
-    if (threadIdx.x == 0) { double r[3]; decompose_E_dev(E, inward, r); sh[0] = r[0]; sh[1] = r[1]; sh[2] = r[2]; }
+    double* sE = sh + 16; double* sdE = sh + 25;
+    if (threadIdx.x == 0) { double r[3]; decompose_E_dev(E, inward, r); sh[0] = r[0]; sh[1] = r[1]; sh[2] = r[2]; sampson_E_and_derivatives(r, tz, sE, sdE); }
     __syncthreads();
     double x[3] = {sh[0], sh[1], sh[2]};
-    __syncthreads();
     double radius = 1e4, decrease = 2.0, scale[3] = {1, 1, 1}, x_cost = 0, x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     double A[6], g[3];
     bool finite_ok = true;
+    // sums over the rays at the point whose E / dE are in LDS; every lane ends up with the same sums
     auto linearize = [&]() {
         double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // JtJ (00 01 02 11 12 22), Jtr (3), cost
         for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
             const int i = list[q];
-            typedef Dual<3> D3; D3 r1[3] = {D3(x[0], 0), D3(x[1], 1), D3(x[2], 2)}, res;
-            sampson_residual_r<D3>(r1, tz, pu + 3 * i, pv + 3 * i, &res);
-            const double j0 = res.v[0] * scale[0], j1 = res.v[1] * scale[1], j2 = res.v[2] * scale[2];
-            acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j1 * j1; acc[4] += j1 * j2; acc[5] += j2 * j2;
-            acc[6] += j0 * res.a; acc[7] += j1 * res.a; acc[8] += j2 * res.a; acc[9] += 0.5 * res.a * res.a;
+            const double u0 = pu[3 * i], u1 = pu[3 * i + 1], u2 = pu[3 * i + 2], v0 = pv[3 * i], v1 = pv[3 * i + 1], v2 = pv[3 * i + 2];
+            const double e0 = sE[0] * u0 + sE[1] * u1 + sE[2] * u2, e1 = sE[3] * u0 + sE[4] * u1 + sE[5] * u2, e2 = sE[6] * u0 + sE[7] * u1 + sE[8] * u2;
+            const double f0 = sE[0] * v0 + sE[3] * v1 + sE[6] * v2, f1 = sE[1] * v0 + sE[4] * v1 + sE[7] * v2;
+            const double d = e0 * v0 + e1 * v1 + e2 * v2, den = e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1;
+            const double res = (d * d) / den;
+            double j[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double* D = sdE + 9 * k;
+                const double a0 = D[0] * u0 + D[1] * u1 + D[2] * u2, a1 = D[3] * u0 + D[4] * u1 + D[5] * u2, a2 = D[6] * u0 + D[7] * u1 + D[8] * u2;
+                const double b0 = D[0] * v0 + D[3] * v1 + D[6] * v2, b1 = D[1] * v0 + D[4] * v1 + D[7] * v2;
+                const double dk = a0 * v0 + a1 * v1 + a2 * v2, denk = 2.0 * (e0 * a0 + e1 * a1 + f0 * b0 + f1 * b1);
+                j[k] = ((2.0 * d * dk - res * denk) / den) * scale[k];
+            }
+            acc[0] += j[0] * j[0]; acc[1] += j[0] * j[1]; acc[2] += j[0] * j[2]; acc[3] += j[1] * j[1]; acc[4] += j[1] * j[2]; acc[5] += j[2] * j[2];
+            acc[6] += j[0] * res; acc[7] += j[1] * res; acc[8] += j[2] * res; acc[9] += 0.5 * res * res;
         }
         block_sum<10>(acc, red);
         if (threadIdx.x == 0) for (int k = 0; k < 10; k++) sh[k] = acc[k];
@@ -497,10 +576,13 @@ __device__ void block_sampson_lsq(const int* list, int cnt, const double* pu, co
             }
             invalid = 0;
             const double xc[3] = {x[0] + st[0] * scale[0], x[1] + st[1] * scale[1], x[2] + st[2] * scale[2]};
+            // candidate: its E (and, in case it is accepted, the derivatives) into LDS; the accepted point's copy stays in sh[52..60] for a rejected step
+            if (threadIdx.x == 0) { for (int k = 0; k < 9; k++) sh[52 + k] = sE[k]; sampson_E_and_derivatives(xc, tz, sE, nullptr); }
+            __syncthreads();
             double c[1] = {0.0};
             for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
                 const int i = list[q];
-                double r; sampson_residual_r<double>(xc, tz, pu + 3 * i, pv + 3 * i, &r); c[0] += 0.5 * r * r;
+                const double r = sampson_err(sE, pu + 3 * i, pv + 3 * i); c[0] += 0.5 * r * r;
             }
             block_sum<1>(c, red);
             if (threadIdx.x == 0) sh[10] = c[0];
@@ -509,18 +591,25 @@ __device__ void block_sampson_lsq(const int* list, int cnt, const double* pu, co
             __syncthreads();
             if (!isfinite(cand)) cand = 1.79769313486231570815e308;
             const double step_norm = sqrt((xc[0] - x[0]) * (xc[0] - x[0]) + (xc[1] - x[1]) * (xc[1] - x[1]) + (xc[2] - x[2]) * (xc[2] - x[2]));
-            if (step_norm <= 1e-8 * (x_norm + 1e-8)) break;
             const double change = x_cost - cand;
-            if (fabs(change) <= 1e-6 * x_cost) break;
             const double rho = (cand >= 1.79769313486231570815e308) ? -1.79769313486231570815e308 : change / model;
-            if (rho > 1e-3) {
+            const bool stop = (step_norm <= 1e-8 * (x_norm + 1e-8)) || (fabs(change) <= 1e-6 * x_cost);
+            if (!stop && rho > 1e-3) {
                 const double xp[3] = {x[0], x[1], x[2]};
                 x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
+                if (threadIdx.x == 0) sampson_E_and_derivatives(x, tz, sE, sdE);
+                __syncthreads();
                 linearize();                      // scale[] is applied inside: the sums come back Jacobi-scaled
                 if (!finite_ok) { x[0] = xp[0]; x[1] = xp[1]; x[2] = xp[2]; break; }      // evaluation failure: the last good x stands
                 x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
                 radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3))); decrease = 2.0; last_ok = true;
-            } else { radius /= decrease; decrease *= 2.0; last_ok = false; }
+            } else {
+                // the derivatives in LDS still belong to x (only E was overwritten): restore E for the next candidate's bookkeeping
+                if (threadIdx.x == 0) for (int k = 0; k < 9; k++) sE[k] = sh[52 + k];
+                __syncthreads();
+                if (stop) break;
+                radius /= decrease; decrease *= 2.0; last_ok = false;
+            }
         }
     }
     double Rm[9]; so3exp(x, Rm); make_E_dev(Rm, inward, E);
