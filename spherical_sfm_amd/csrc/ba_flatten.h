@@ -19,11 +19,27 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/ssfm.h"
 
 namespace ssfm {
+
+// std::vector whose resize() leaves new elements uninitialised: the planner's per-observation arrays (19 MB at 600k observations) are written
+// once, in parallel, right after they are sized -- value-initialising them first was a serial 1 ms memset of the cold plan.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using raw_vector = std::vector<T, NoInitAlloc<T>>;
 
 struct BAFlat {
     int Nc = 0;
@@ -32,18 +48,19 @@ struct BAFlat {
     int64_t M = 0, M_global = 0;
     int DC = 6;               // 3: every translation fixed (spherical BA) -> only rotations vary
     bool focal_free = false;
-    std::vector<int> pt_ids;            // [nP] original point id
+    raw_vector<int> pt_ids;             // [nP] original point id
     std::vector<int> pt_start;          // [nP+1]
-    std::vector<int> obs_cam;           // [M]
-    std::vector<int> obs_pt;            // [M] compact local point
-    std::vector<int64_t> obs_orig;      // [M] index into the caller's arrays
-    std::vector<double> obs_xy;         // [2M]
-    std::vector<int> cam_start, cam_obs;   // camera-major lists over local observations
-    std::vector<int> cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;   // point of each camera-major entry; k_cam_sums2 wave tasks (<= 256 entries)
+    raw_vector<int> obs_cam;            // [M]
+    raw_vector<int> obs_pt;             // [M] compact local point
+    raw_vector<int64_t> obs_orig;       // [M] index into the caller's arrays
+    raw_vector<double> obs_xy;          // [2M]
+    std::vector<int> cam_start;         // camera-major lists over local observations
+    raw_vector<int> cam_obs, cam_obs_pt;   // observation / point of each camera-major entry
+    std::vector<int> cs_task_cam, cs_task_q0, cs_task_q1;   // point of each camera-major entry; k_cam_sums2 wave tasks (<= 256 entries)
     std::vector<int> row_ptr, col_idx, diag_slot;   // block-CSR structure of S (global), sorted columns
     std::vector<double> mask_cam;       // [Nc*6] 1 = free parameter that is in the problem
-    std::vector<double> mask_pt;        // [nP*3]
-    std::vector<double> pts0;           // [nP*3]
+    raw_vector<double> mask_pt;         // [nP*3]
+    raw_vector<double> pts0;            // [nP*3]
     int max_row_blocks = 0;
     bool nothing_to_do = false;
     // elimination order of the camera blocks for the banded Cholesky preconditioner
@@ -77,11 +94,48 @@ struct BAFlat {
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
 };
 
-// fork-join over [0, n) in T contiguous chunks on std::thread (the planner's loops over cameras / points are independent once the
-// prefix sums are known); f(thread index, begin, end)
+// fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
+// once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
+// section cost more than some of the sections they ran (0.1 ms each on the MI355X hosts; a plan has six sections).  SSFM_PLAN_POOL=0 goes
+// back to one std::thread per chunk.
+class PlanPool {
+    std::vector<std::thread> workers;
+    std::mutex m; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job; int generation = 0, pending = 0, active = 0; bool stop = false;
+    void loop(int id) {
+        int seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            { std::unique_lock<std::mutex> lk(m);
+              cv_go.wait(lk, [&] { return stop || (generation != seen && id < active); });
+              if (stop) return;
+              seen = generation; f = job; }
+            f(id + 1);
+            { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_one(); }
+        }
+    }
+public:
+    ~PlanPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for (auto& t : workers) t.join(); }
+    // runs f(0) here and f(1) .. f(T-1) on the helpers; returns when all are done.  One caller at a time (the planner is single-entry per context;
+    // callers from different threads serialise on run_mutex).
+    std::mutex run_mutex;
+    void run(int T, const std::function<void(int)>& f) {
+        std::lock_guard<std::mutex> one(run_mutex);
+        while ((int)workers.size() < T - 1) { const int id = (int)workers.size(); workers.emplace_back([this, id] { loop(id); }); }
+        { std::lock_guard<std::mutex> lk(m); job = f; active = T - 1; pending = T - 1; generation++; }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        active = 0;
+    }
+};
+inline PlanPool& plan_pool() { static PlanPool p; return p; }      // helpers are joined at static destruction (they are parked on the condition variable)
 template <class Fn>
 inline void parallel_chunks(int64_t n, int T, Fn f) {
     if (T <= 1 || n < 4 * (int64_t)T) { f(0, (int64_t)0, n); return; }
+    static const bool use_pool = !(std::getenv("SSFM_PLAN_POOL") && std::atoi(std::getenv("SSFM_PLAN_POOL")) == 0);
+    if (use_pool) { plan_pool().run(T, [&](int t) { f(t, n * t / T, n * (t + 1) / T); }); return; }
     std::vector<std::thread> th; th.reserve(T);
     for (int t = 0; t < T; t++) th.emplace_back([=]() { f(t, n * t / T, n * (t + 1) / T); });
     for (auto& x : th) x.join();
@@ -300,8 +354,14 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     if (Nc == 0 || Np == 0 || M == 0) { F.nothing_to_do = true; return; }
     // ---- order observations point-major / camera-ascending (skip the sort if they already are)
     bool sorted = true;
-    for (int64_t i = 1; i < M && sorted; i++)
-        if (P.obs_pt[i] < P.obs_pt[i - 1] || (P.obs_pt[i] == P.obs_pt[i - 1] && P.obs_cam[i] <= P.obs_cam[i - 1])) sorted = false;
+    {
+        std::vector<char> bad(NT, 0);
+        parallel_chunks(M - 1, M >= 200000 ? NT : 1, [&](int t, int64_t a, int64_t b) {
+            for (int64_t i = a + 1; i <= b; i++)
+                if (P.obs_pt[i] < P.obs_pt[i - 1] || (P.obs_pt[i] == P.obs_pt[i - 1] && P.obs_cam[i] <= P.obs_cam[i - 1])) { bad[t] = 1; break; }
+        });
+        for (char c : bad) if (c) sorted = false;
+    }
     std::vector<int64_t> order;
     if (!sorted) {
         order.resize(M); std::iota(order.begin(), order.end(), (int64_t)0);
@@ -310,17 +370,29 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             return P.obs_cam[a] < P.obs_cam[b]; });
     }
     auto at = [&](int64_t i) { return sorted ? i : order[i]; };
-    // ---- pass 1: which points are used (global), with their observation counts
+    // ---- pass 1: which points are used (global), with their observation counts.  Chunks of the observation array, cut at point boundaries.
     struct Seg { int pt; int64_t begin, end; int nobs; };
-    std::vector<Seg> segs; segs.reserve(Np);
-    for (int64_t i = 0; i < M;) {
-        const int p = P.obs_pt[at(i)];
-        int64_t e = i; int nobs = 0; int last_cam = -1;
-        while (e < M && P.obs_pt[at(e)] == p) { const int c = P.obs_cam[at(e)]; if (c != last_cam && c >= 0 && c < Nc) { nobs++; last_cam = c; } e++; }
-        bool valid = p >= 0 && p < Np && nobs >= 3;
-        if (valid) { const double* X = &P.points[(size_t)p * 3]; valid = (X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) != 0.0; }
-        if (valid) segs.push_back({p, i, e, nobs});
-        i = e;
+    std::vector<Seg> segs;
+    {
+        const int TS = (M >= 200000) ? NT : 1;
+        std::vector<std::vector<Seg>> part(TS);
+        parallel_chunks(M, TS, [&](int t, int64_t i0, int64_t i1) {
+            // a chunk owns the points that START inside it
+            while (i0 > 0 && i0 < M && P.obs_pt[at(i0)] == P.obs_pt[at(i0 - 1)]) i0++;
+            std::vector<Seg>& out = part[TS == 1 ? 0 : t]; out.reserve((size_t)((i1 - i0) / 4 + 16));
+            for (int64_t i = i0; i < i1;) {
+                const int p = P.obs_pt[at(i)];
+                int64_t e = i; int nobs = 0; int last_cam = -1;
+                while (e < M && P.obs_pt[at(e)] == p) { const int c = P.obs_cam[at(e)]; if (c != last_cam && c >= 0 && c < Nc) { nobs++; last_cam = c; } e++; }
+                bool valid = p >= 0 && p < Np && nobs >= 3;
+                if (valid) { const double* X = &P.points[(size_t)p * 3]; valid = (X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) != 0.0; }
+                if (valid) out.push_back({p, i, e, nobs});
+                i = e;
+            }
+        });
+        size_t tot = 0; for (auto& v : part) tot += v.size();
+        segs.reserve(tot);
+        for (auto& v : part) segs.insert(segs.end(), v.begin(), v.end());
     }
     lap("sorted check + segments");
     F.nP_global = (int)segs.size();
@@ -328,7 +400,40 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     if (segs.empty()) { F.nothing_to_do = true; return; }
     // ---- structure of S and camera activity come from ALL used points (identical on every rank)
     std::vector<char> cam_in(Nc, 0);
-    {
+    if (Nc <= 1024) {
+        // few cameras: the block structure is an Nc x Nc bit matrix (11 KB at 300 cameras).  Every planner thread marks the camera pairs of its
+        // share of the points in a private copy; the copies are OR-ed and the rows read off in ascending order.
+        const int WPR = (Nc + 63) / 64;                                   // 64-bit words per row
+        const int TB = (segs.size() >= 20000) ? NT : 1;
+        std::vector<std::vector<uint64_t>> bits(TB, std::vector<uint64_t>((size_t)Nc * WPR, 0));
+        parallel_chunks((int64_t)segs.size(), TB, [&](int t, int64_t k0, int64_t k1) {
+            std::vector<uint64_t>& B = bits[TB == 1 ? 0 : t];
+            int cams[64];
+            for (int64_t k = k0; k < k1; k++) {
+                const Seg& sg = segs[(size_t)k]; int n = 0, last = -1; bool overflow = false;
+                for (int64_t i = sg.begin; i < sg.end; i++) { const int c = P.obs_cam[at(i)]; if (c != last && c >= 0 && c < Nc) { if (n < 64) cams[n++] = c; else overflow = true; last = c; } }
+                if (overflow) {                                           // a track longer than 64 cameras: mark pair by pair from the array itself
+                    int la = -1;
+                    for (int64_t i = sg.begin; i < sg.end; i++) { const int a = P.obs_cam[at(i)]; if (a == la || a < 0 || a >= Nc) continue; la = a; int lb = -1;
+                        for (int64_t i2 = sg.begin; i2 < sg.end; i2++) { const int b2 = P.obs_cam[at(i2)]; if (b2 == lb || b2 < 0 || b2 >= Nc) continue; lb = b2; B[(size_t)a * WPR + (b2 >> 6)] |= 1ull << (b2 & 63); } }
+                    continue;
+                }
+                for (int a = 0; a < n; a++) { uint64_t* row = &B[(size_t)cams[a] * WPR]; for (int b2 = 0; b2 < n; b2++) row[cams[b2] >> 6] |= 1ull << (cams[b2] & 63); }
+            }
+        });
+        std::vector<uint64_t>& B0 = bits[0];
+        for (int t = 1; t < TB; t++) for (size_t w = 0; w < B0.size(); w++) B0[w] |= bits[t][w];
+        F.row_ptr.assign(Nc + 1, 0); F.diag_slot.assign(Nc, -1); F.col_idx.clear(); F.col_idx.reserve((size_t)Nc * 16);
+        for (int c = 0; c < Nc; c++) {
+            const size_t first = F.col_idx.size();
+            for (int wd = 0; wd < WPR; wd++) { uint64_t x = B0[(size_t)c * WPR + wd]; while (x) { const int bit = __builtin_ctzll(x); x &= x - 1; F.col_idx.push_back(64 * wd + bit); } }
+            if (F.col_idx.size() == first) F.col_idx.push_back(c);         // isolated camera: identity row
+            else cam_in[c] = 1;
+            F.diag_slot[c] = (int)(std::lower_bound(F.col_idx.begin() + first, F.col_idx.end(), c) - (F.col_idx.begin() + first));
+            F.row_ptr[c + 1] = (int)F.col_idx.size();
+            F.max_row_blocks = std::max(F.max_row_blocks, (int)(F.col_idx.size() - first));
+        }
+    } else {
         // camera-major view of the used observations (global), then per camera one sweep over its points' camera lists with a
         // "last row that saw this column" mark: O(M K) without sorting M K entries
         std::vector<int> gstart(Nc + 1, 0);

@@ -155,8 +155,8 @@ namespace ssfm {
         (h)->span_end();                                                                  \
     } while (0)
 
-template <typename T>
-static hipError_t upload(DevBuf<T>& b, const std::vector<T>& v, hipStream_t s) {
+template <typename T, typename A>
+static hipError_t upload(DevBuf<T>& b, const std::vector<T, A>& v, hipStream_t s) {
     hipError_t e = b.alloc(v.size()); if (e != hipSuccess) return e;
     if (v.empty()) return hipSuccess;
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);

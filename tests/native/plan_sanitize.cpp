@@ -2,6 +2,7 @@
 // degenerate problems under -fsanitize=address,undefined (and thread).  Built and run by tests/test_sanitizers_cpu.py.
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 #include "../../spherical_sfm_amd/csrc/ba_flatten.h"
 
@@ -53,6 +54,30 @@ int main() {
         P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
         P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = 1;
         for (int nr = 1; nr <= 3; nr++) for (int r = 0; r < nr; r++) { ssfm::BAFlat F; ssfm::ba_flatten(P, nr, r, F); acc += check(F, Nc); }
+    }
+    // large sorted problems: the threaded sections of the planner (segment pass cut at point boundaries, bit-matrix S structure at <= 1024 cameras,
+    // camera-major sweep above) must give the plan of the single-threaded run
+    for (int Nc : {300, 1500}) {
+        const int Np = 45000; std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
+        std::vector<uint8_t> rf(Nc, 0), tf(Nc, 0), pf(Np, 0);
+        for (auto& v : pts) v = (rng() % 100) / 10.0 + 0.5;
+        for (int j = 0; j < Np; j++) {
+            const int first = (int)(rng() % Nc), len = (j % 997 == 0) ? 80 : 3 + (int)(rng() % 6);   // a few tracks longer than 64 cameras
+            std::vector<int> cs; for (int q = 0; q < len; q++) cs.push_back((first + q) % Nc);
+            std::sort(cs.begin(), cs.end());
+            for (int c : cs) { oc.push_back(c); op.push_back(j); xy.push_back(1.0); xy.push_back(2.0); }
+        }
+        double focal = 800.0;
+        ssfm_ba_problem P;
+        P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
+        P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = 1;
+        const char* keep = std::getenv("SSFM_PLAN_THREADS"); const std::string saved = keep ? keep : "";
+        setenv("SSFM_PLAN_THREADS", "1", 1); ssfm::BAFlat F1; ssfm::ba_flatten(P, 1, 0, F1);
+        setenv("SSFM_PLAN_THREADS", "4", 1); ssfm::BAFlat F4; ssfm::ba_flatten(P, 1, 0, F4);
+        if (keep) setenv("SSFM_PLAN_THREADS", saved.c_str(), 1); else unsetenv("SSFM_PLAN_THREADS");
+        if (P.num_observations < 200000 || F1.row_ptr != F4.row_ptr || F1.col_idx != F4.col_idx || F1.diag_slot != F4.diag_slot || F1.obs_cam != F4.obs_cam || F1.obs_pt != F4.obs_pt ||
+            F1.nP_global != F4.nP_global || F1.M_global != F4.M_global || F1.max_row_blocks != F4.max_row_blocks) { std::printf("threaded plan differs at Nc=%d\n", Nc); std::abort(); }
+        acc += check(F4, Nc);
     }
     // tracks: random match sets incl. merges
     for (int trial = 0; trial < 20; trial++) {
