@@ -80,7 +80,7 @@ struct ssfm_ba_handle {
         S_val = redbuf.p; rhs = S_val + zone_nnz; Udiag = rhs + (zone_n + 1); Sfc = Udiag + zone_n; gcraw = Sfc + zone_n; red_scal = gcraw + zone_n;
     }
     DevBuf<double> lmdev;                 // [go, radius] of the device-side step decision (k_publish -> speculative k_point_lin)
-    DevBuf<double> Vinv, Vs, gp, Wf, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
+    DevBuf<double> Vs, gp, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
     BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
@@ -120,7 +120,7 @@ struct ssfm_ba_handle {
         cam_x.free(); cam_c.free(); cam_init.free(); pts_x.free(); pts_c.free(); pts_init.free(); focal3.free();
         rot_x.free(); rot_c.free(); scale_cam.free(); scale_pt.free(); scale_f.free(); mask_cam.free(); mask_pt.free(); mask_f.free();
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
-        cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vinv.free(); Vs.free(); gp.free(); Wf.free();
+        cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vs.free(); gp.free();
         lmdev.free(); band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();

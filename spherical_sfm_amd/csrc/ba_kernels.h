@@ -12,7 +12,7 @@
 //   pts[nP*3]                      obs_xy[M] double2, obs_cam[M], obs_pt[M]  point-major, pt_start[nP+1]
 //   cam_start[Nc+1], cam_obs[M]    camera-major view of the same observations
 //   scale_cam[Nc*6], scale_pt[nP*3], scale_f   Jacobi column scales, 0 for parameters that are constant
-//   Vinv[nP*6], gp[nP*3], Wf[nP*3]             per-point (V + D^2)^-1 (sym), J_p^T r, focal coupling
+//   gp[nP*3]                                   per-point J_p^T r  ((V + D^2)^-1 lives in the record PS only)
 //   S_val[nnzb*DC*DC]              block-CSR reduced camera system (row_ptr/col_idx), rhs[Nc*DC+1]
 // DC = 3 when every translation is fixed (spherical BA: only r varies), 6 otherwise.
 #pragma once
@@ -172,7 +172,6 @@ __device__ __forceinline__ void lin_obs(double f, const double* t, const double*
 }
 // point-side view of the same linearisation (no camera blocks, R only): residual, focal column, point block
 struct ObsPoint { double r[2], Jf[2], Jp[2][3], half_rho; };
-constexpr int OBS_UNROLL = 3;
 __device__ __forceinline__ void lin_obs_point(double f, const double* t, const double* R, const double* X, double ox, double oy, int loss, double la,
                                               ObsPoint& L) {
     double xp, yp, iz, r0, r1; project(f, t, R, X, ox, oy, xp, yp, iz, r0, r1);
@@ -269,14 +268,14 @@ static __global__ void k_make_scale(const double* __restrict__ diag, const doubl
 
 // ---- K1: point pass.  One lane per point: V = sum Jp^T Jp (+D^2), V^-1, g_p, focal coupling ----------
 // Ceres SchurEliminator "chunk" work for the e-block, with the LM diagonal D_p^2 = clamp(diag V)/radius.
+template <int OBS_UNROLL>
 static __global__ void __launch_bounds__(256)
 k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
             const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
             const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
             int loss, double la, double radius, double min_diag, double max_diag,
-            double* __restrict__ Vinv, double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ Wf, double* __restrict__ scal,
+            double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ scal,
             const double* __restrict__ spec) {
-    __shared__ double red[5 * 4];
     // spec (speculative launch behind k_publish of the previous iteration): [go, radius] as decided on the device
     if (spec) { if (spec[0] == 0.0) return; radius = spec[1]; }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,10 +290,13 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
         // dependent gathers of a group are in flight together (a point has 3-10 observations; lanes beyond the list recompute
         // the last one with zero weight)
         const int js = pt_start[p], je = pt_start[p + 1];
+        int cn[OBS_UNROLL]; double2 on[OBS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OBS_UNROLL; u++) { const int jj = min(js + u, je - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
         for (int jb = js; jb < je; jb += OBS_UNROLL) {
             int cc[OBS_UNROLL]; double2 oo[OBS_UNROLL]; double tR[OBS_UNROLL][12];
 #pragma unroll
-            for (int u = 0; u < OBS_UNROLL; u++) { const int jj = min(jb + u, je - 1); cc[u] = obs_cam[jj]; oo[u] = obs_xy[jj]; }
+            for (int u = 0; u < OBS_UNROLL; u++) { cc[u] = cn[u]; oo[u] = on[u]; }
 #pragma unroll
             for (int u = 0; u < OBS_UNROLL; u++) {
 #pragma unroll
@@ -302,6 +304,9 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
 #pragma unroll
                 for (int k = 0; k < 9; k++) tR[u][3 + k] = rot[27 * (size_t)cc[u] + k];
             }
+            // the indices of the next group travel with this group's camera tables: one dependent round trip per group
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) { const int jj = min(jb + OBS_UNROLL + u, je - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
 #pragma unroll
             for (int u = 0; u < OBS_UNROLL; u++) {
                 const double wgt = (jb + u < je) ? 1.0 : 0.0;
@@ -329,7 +334,8 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
         const double u2 = wf[0] * Vi[2] + wf[1] * Vi[4] + wf[2] * Vi[5];
         acc[3] = u0 * wf[0] + u1 * wf[1] + u2 * wf[2];
         acc[4] = u0 * g[0] + u1 * g[1] + u2 * g[2];
-        for (int k = 0; k < 6; k++) Vinv[6 * p + k] = Vi[k];
+        // (V^-1 itself and w_f are not stored: nothing reads w_f, and k_point_backsub recovers V^-1 b from the record below -- 9 doubles per
+        // point less to write back at the end of a kernel whose run time follows its store volume)
         // per-point record of the Schur kernels, Jacobi point scales folded in so that they need no scale loads:
         //   [ diag(s) V^-1 diag(s) (6) | s o (V^-1 g) (3) | s o (V^-1 w_f) (3) ]
         double* ps = Vs + 12 * (size_t)p;
@@ -338,16 +344,18 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
         ps[6] = sp[0] * (Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2]); ps[7] = sp[1] * (Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2]);
         ps[8] = sp[2] * (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
         ps[9] = sp[0] * u0; ps[10] = sp[1] * u1; ps[11] = sp[2] * u2;
-        for (int k = 0; k < 3; k++) { gp[3 * p + k] = g[k]; Wf[3 * p + k] = wf[k]; }
+        for (int k = 0; k < 3; k++) gp[3 * p + k] = g[k];
     }
-    block_sum<5>(acc, red);
+    // every wave folds its own five sums (one transposing reduction) and issues its own atomics into the slot replica of its wave index:
+    // no LDS, no workgroup barrier at the end of the kernel (the barrier made every wave wait for the slowest of its workgroup: 2.4 us of a
+    // wave's 9 at config 2; scripts/lab/point_lab.hip)
+    static_assert(SC_COST == 0 && SC_FJJ == 1 && SC_FJR == 2 && SC_FWW == 3 && SC_FWG == 4, "the five sums are the first five scalars");
+    const double t = wave_transpose_sum(acc);
     gmax = wave_max(gmax);
-    double* sl = scal_slot(scal);
+    const int slot = wave_tr_index();
+    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
+    if (slot < 5) unsafeAtomicAdd(&sl[slot], t);
     if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
-    if (threadIdx.x == 0) {
-        unsafeAtomicAdd(&sl[SC_COST], acc[0]); unsafeAtomicAdd(&sl[SC_FJJ], acc[1]); unsafeAtomicAdd(&sl[SC_FJR], acc[2]);
-        unsafeAtomicAdd(&sl[SC_FWW], acc[3]); unsafeAtomicAdd(&sl[SC_FWG], acc[4]);
-    }
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and every XCD has its own L2.  Wave-task lists
@@ -1203,12 +1211,12 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
 //   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
 //   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
-template <int DC>
+template <int DC, int GU>
 __global__ void __launch_bounds__(256)
 k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                 const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                 const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_cam, const double* __restrict__ scale_pt,
-                const double* __restrict__ scale_f, const double* __restrict__ Vinv, const double* __restrict__ gp,
+                const double* __restrict__ scale_f, const double* __restrict__ Vs, const double* __restrict__ gp,
                 const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
                 const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
                 // residual check of the reduced solve (what k_ref_residual does), by one extra workgroup behind the point workgroups when
@@ -1250,6 +1258,7 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         // the model cost change  -sum M_j.(r_j - M_j/2)  expands into sums that do not depend on z -- sum a.a, sum a.r, B^T a, B^T B --
         // so the second re-linearisation of every observation (after z is known) is not needed
         double Saa = 0.0, Sar = 0.0, Vr[6] = {0, 0, 0, 0, 0, 0};
+        if (GU <= 1) {
         // the camera index and pixel of observation j+1 are fetched while observation j is processed: one dependent round trip
         // per observation (its camera tables) instead of two
         int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
@@ -1268,12 +1277,61 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
 #pragma unroll
             for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
         }
-        const double* Vi = Vinv + 6 * p;
-        double yp[3];
-        yp[0] = Vi[0] * b[0] + Vi[1] * b[1] + Vi[2] * b[2];
-        yp[1] = Vi[1] * b[0] + Vi[3] * b[1] + Vi[4] * b[2];
-        yp[2] = Vi[2] * b[0] + Vi[4] * b[1] + Vi[5] * b[2];
-        if (!(sp[0] > 0.0)) yp[0] = yp[1] = yp[2] = 0.0;
+        } else {
+        // observations in groups of GU: the indices of the NEXT group and the camera tables of THIS group are in flight together, so a
+        // group costs one dependent round trip (a point has 3-10 observations: one or two groups instead of one trip per observation);
+        // slots beyond the list recompute the last observation with zero weight
+        constexpr int G = (GU > 1) ? GU : 1;
+        int cn[G]; double2 on[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) { const int jj = min(j0 + u, j1 - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
+        for (int jb = j0; jb < j1; jb += G) {
+            int cc[G]; double2 oo[G]; double tb[G][36 + DC];      // [t (3) | R Rd M (27) | camera scales (6) | y_c (DC)]
+#pragma unroll
+            for (int u = 0; u < G; u++) { cc[u] = cn[u]; oo[u] = on[u]; }
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const size_t c = (size_t)cc[u];
+#pragma unroll
+                for (int k = 0; k < 3; k++) tb[u][k] = cam[6 * c + k];
+#pragma unroll
+                for (int k = 0; k < 27; k++) tb[u][3 + k] = rot[27 * c + k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) tb[u][30 + k] = scale_cam[6 * c + k];
+#pragma unroll
+                for (int k = 0; k < DC; k++) tb[u][36 + k] = y[c * DC + k];
+            }
+#pragma unroll
+            for (int u = 0; u < G; u++) { const int jj = min(jb + G + u, j1 - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const double wgt = (jb + u < j1) ? 1.0 : 0.0;
+                ObsLin L; lin_obs<DC == 6>(f, tb[u], tb[u] + 3, X, oo[u].x, oo[u].y, loss, la, L);
+                double Jc[2][DC]; cam_block<DC>(L, tb[u] + 30, Jc);
+                double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
+#pragma unroll
+                for (int a = 0; a < DC; a++) { const double ya = tb[u][36 + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
+                m0 *= wgt; m1 *= wgt;
+                Saa += m0 * m0 + m1 * m1; Sar += m0 * L.r[0] + m1 * L.r[1];
+                const double B0[3] = {L.Jp[0][0] * sp[0] * wgt, L.Jp[0][1] * sp[1] * wgt, L.Jp[0][2] * sp[2] * wgt};
+                const double B1[3] = {L.Jp[1][0] * sp[0] * wgt, L.Jp[1][1] * sp[1] * wgt, L.Jp[1][2] * sp[2] * wgt};
+                Vr[0] += B0[0] * B0[0] + B1[0] * B1[0]; Vr[1] += B0[0] * B0[1] + B1[0] * B1[1]; Vr[2] += B0[0] * B0[2] + B1[0] * B1[2];
+                Vr[3] += B0[1] * B0[1] + B1[1] * B1[1]; Vr[4] += B0[1] * B0[2] + B1[1] * B1[2]; Vr[5] += B0[2] * B0[2] + B1[2] * B1[2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
+            }
+        }
+        }
+        // V^-1 b from the record of the Schur kernels, PS_V = diag(s) V^-1 diag(s):  V^-1 b = s^-1 o (PS_V (s^-1 o b))
+        const double* Vi = Vs + 12 * (size_t)p;
+        double yp[3] = {0.0, 0.0, 0.0};
+        if (sp[0] > 0.0) {
+            const double is[3] = {fast_rcp(sp[0]), fast_rcp(sp[1]), fast_rcp(sp[2])};
+            const double bs[3] = {b[0] * is[0], b[1] * is[1], b[2] * is[2]};
+            yp[0] = (Vi[0] * bs[0] + Vi[1] * bs[1] + Vi[2] * bs[2]) * is[0];
+            yp[1] = (Vi[1] * bs[0] + Vi[3] * bs[1] + Vi[4] * bs[2]) * is[1];
+            yp[2] = (Vi[2] * bs[0] + Vi[4] * bs[1] + Vi[5] * bs[2]) * is[2];
+        }
         {
             const double zg = yp[0] * g3[0] + yp[1] * g3[1] + yp[2] * g3[2];
             const double zBa = yp[0] * (g3[0] - b[0]) + yp[1] * (g3[1] - b[1]) + yp[2] * (g3[2] - b[2]);       // z . sum B^T a
@@ -1289,18 +1347,37 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         }
         // robustified cost at the candidate (cameras, focal, this point): what a separate k_point_cost launch did
         const double fcand = focal_c[0];
-        c_nx = obs_cam[j0]; o_nx = obs_xy[j0];
+        if (GU <= 1) {
+        int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
         for (int j = j0; j < j1; j++) {
             const int c = c_nx; const double2 o = o_nx;
             { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
             acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la);
         }
+        } else {
+        constexpr int G2 = (GU > 1) ? 2 * GU : 1;                    // 12 doubles per observation here: twice the group
+        for (int jb = j0; jb < j1; jb += G2) {
+            int cc[G2]; double2 oo[G2]; double tR[G2][12];
+#pragma unroll
+            for (int u = 0; u < G2; u++) { const int jj = min(jb + u, j1 - 1); cc[u] = obs_cam[jj]; oo[u] = obs_xy[jj]; }
+#pragma unroll
+            for (int u = 0; u < G2; u++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) tR[u][k] = cam_c[6 * (size_t)cc[u] + k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) tR[u][3 + k] = rot_c[27 * (size_t)cc[u] + k];
+            }
+#pragma unroll
+            for (int u = 0; u < G2; u++) { const double cst = obs_cost(fcand, tR[u], tR[u] + 3, Xc, oo[u].x, oo[u].y, loss, la); acc[3] += (jb + u < j1) ? cst : 0.0; }
+        }
+        }
     }
-    block_sum<4>(acc, red);
-    if (threadIdx.x == 0) {
-        double* sl = scal_slot(scal);
-        unsafeAtomicAdd(&sl[SC_MODEL], acc[0]); unsafeAtomicAdd(&sl[SC_STEP2_PT], acc[1]); unsafeAtomicAdd(&sl[SC_XN2_PT], acc[2]); unsafeAtomicAdd(&sl[SC_CAND_COST], acc[3]);
-    }
+    // per-wave fold and atomics (see k_point_lin): no barrier at the end
+    static_assert(SC_STEP2_PT == SC_MODEL + 1 && SC_XN2_PT == SC_MODEL + 2 && SC_CAND_COST == SC_MODEL + 3, "the four sums are consecutive scalars");
+    const double t = wave_transpose_sum(acc);
+    const int slot = wave_tr_index();
+    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
+    if (slot < 4) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------

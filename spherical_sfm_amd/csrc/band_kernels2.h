@@ -451,13 +451,19 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
     const int lc = min(lane, DC - 1);
     struct Stage { double col0[DC], col1[DC], li[DC], yv; };
     Stage st[BACK_PD];
+    // the row is wave-uniform: a scalar base per row and a 32-bit lane offset per stream (the per-lane 64-bit products of a flat index cost
+    // ~16 vector instructions per step of a kernel whose step is bound by the instructions ONE wave can issue)
+    const int o0 = d0 * BB + a0, o1 = d1 * BB + a1;
+    const size_t row_stride = (size_t)W * BB;
     auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
         const int jc = max(j, r0);
+        const double* __restrict__ rowp = band + (size_t)jc * row_stride;
+        const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
 #pragma unroll
         for (int m = 0; m < DC; m++) {
-            s.col0[m] = band[(((size_t)jc) * W + d0) * BB + m * DC + a0];
-            s.col1[m] = band[(((size_t)jc) * W + d1) * BB + m * DC + a1];
-            s.li[m] = Ginv[(size_t)jc * BB + m * DC + lc];                // G[m][lane], zero for m < lane
+            s.col0[m] = rowp[o0 + m * DC];
+            s.col1[m] = rowp[o1 + m * DC];
+            s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
         }
         const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
         s.yv = y[(size_t)jy * DC + lc];
@@ -471,9 +477,9 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             const int j = jb - u;
             if (j < r0) break;
             double c0[DC], c1[DC], cl[DC]; const double cy = st[u].yv;
-            const bool v0 = has0 && j - d0 >= r0, v1 = has1 && j - d1 >= r0;       // rows above the component do not exist
+            const bool v0 = has0 && j - d0 >= r0, v1 = has1 && j - d1 >= r0;       // rows above the component do not exist: their terms are dropped below
 #pragma unroll
-            for (int m = 0; m < DC; m++) { c0[m] = v0 ? st[u].col0[m] : 0.0; c1[m] = v1 ? st[u].col1[m] : 0.0; cl[m] = st[u].li[m]; }
+            for (int m = 0; m < DC; m++) { c0[m] = st[u].col0[m]; c1[m] = st[u].col1[m]; cl[m] = st[u].li[m]; }
             fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
             // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc0
             const double z = cy - acc0;                             // lanes 0..DC-1
@@ -491,6 +497,7 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; s1 += c1[m] * xm; }
+            s0 = v0 ? s0 : 0.0; s1 = v1 ? s1 : 0.0;                            // (one select per sum instead of one per loaded entry)
             // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
             acc0 = sft0 + s0; acc1 = sft1 + s1;
         }
