@@ -181,6 +181,16 @@ k_point_lin_v2(const double* __restrict__ cam, const double* __restrict__ rot, c
     if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
 }
 
+static __global__ void k_empty(int* x) { if (x && threadIdx.x == 9999) x[0] = 1; }
+static __global__ void k_store_only(double* __restrict__ Vs, double* __restrict__ gp, int nP) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nP) { for (int k = 0; k < 12; k++) Vs[12 * (size_t)p + k] = (double)(p + k); for (int k = 0; k < 3; k++) gp[3 * (size_t)p + k] = (double)p; }
+}
+static __global__ void k_load_only(const double* __restrict__ pts, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam, const int* __restrict__ pt_start, int nP, double* out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x; double a = 0;
+    if (p < nP) { a = pts[3 * p] + pts[3 * p + 1] + pts[3 * p + 2]; for (int j = pt_start[p]; j < pt_start[p + 1]; j++) a += obs_xy[j].x + obs_xy[j].y + obs_cam[j]; }
+    if (a == 1e300) out[0] = a;
+}
 static void rodrigues(const double* r, double* R) {
     const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (th < 1e-12) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0); return; }
@@ -261,7 +271,12 @@ int main(int argc, char** argv) {
         std::vector<unsigned long long> life(nw); for (int w = 0; w < nw; w++) life[w] = T[8 * w + 7] - T[8 * w]; std::sort(life.begin(), life.end());
         printf("wave life: median %llu, max %llu\n", life[nw / 2], life[nw - 1]);
     }
-    for (int nt = 0; nt < 2; nt++) for (int bs : {256, 128, 64}) {
+    for (int bs : {256, 64}) {
+        char tag[64]; snprintf(tag, 64, "empty kernel, block %d", bs); timeit(tag, [&]() { hipLaunchKernelGGL(k_empty, dim3((Np + bs - 1) / bs), dim3(bs), 0, st, (int*)nullptr); });
+        snprintf(tag, 64, "stores only (15 dbl/pt), block %d", bs); timeit(tag, [&]() { hipLaunchKernelGGL(k_store_only, dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dVs, dgp, Np); });
+        snprintf(tag, 64, "loads only, block %d", bs); timeit(tag, [&]() { hipLaunchKernelGGL(k_load_only, dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dpts, dxy, doc, dps, Np, dVs); });
+    }
+    for (int nt = 0; nt < 1; nt++) for (int bs : {256, 64}) {
         char tag[64]; snprintf(tag, 64, "v2 (no barrier), block %d nt %d", bs, nt);
         auto v2 = [&]() { if (nt) hipLaunchKernelGGL((k_point_lin_v2<3, 1>), dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dcam, drot, dpts, dfocal, dxy, doc, dps, Np, dsp, dsf, 1, 1.0, 1e4, 1e-6, 1e32, dVs, dgp, dscal);
                           else hipLaunchKernelGGL((k_point_lin_v2<3, 0>), dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dcam, drot, dpts, dfocal, dxy, doc, dps, Np, dsp, dsf, 1, 1.0, 1e4, 1e-6, 1e32, dVs, dgp, dscal); };
@@ -269,6 +284,29 @@ int main(int argc, char** argv) {
         double worst = 0; for (size_t i = (size_t)Np * 6; i < got.size(); i++) { if (i >= (size_t)Np * 21 && i < (size_t)Np * 24) continue; worst = std::max(worst, std::fabs(got[i] - ref[i]) / (1e-300 + std::max(std::fabs(ref[i]), 1.0))); }
         printf("max rel difference to production %.3g ; ", worst);
         timeit(tag, v2);
+    }
+    // ---- k_point_backsub: group sizes x workgroup sizes ----
+    {
+        hipLaunchKernelGGL(k_cam_rot, dim3((Nc + 63) / 64), dim3(64), 0, st, dcam, drot, Nc);
+        clear(); prod(); CK(hipStreamSynchronize(st));               // Vs, gp of the current state
+        std::vector<double> y((size_t)Nc * 6 + 1), sc((size_t)Nc * 6);
+        for (auto& v : y) v = 1e-3 * N01(rng); for (auto& v : sc) v = 1.0 / (1.0 + 200.0 + 20 * Uxy(rng));
+        double *dy, *dsc, *dptsc, *dfc; CK(hipMalloc(&dy, y.size() * 8)); CK(hipMalloc(&dsc, sc.size() * 8)); CK(hipMalloc(&dptsc, pts.size() * 8)); CK(hipMalloc(&dfc, 8));
+        CK(hipMemcpy(dy, y.data(), y.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dsc, sc.data(), sc.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dfc, &focal, 8, hipMemcpyHostToDevice));
+        std::vector<double> pref, pgot(pts.size());
+        auto run_bs = [&](auto kernel, int bs, const char* tag) {
+            auto l = [&]() { hipLaunchKernelGGL(kernel, dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dcam, drot, dpts, dfocal, dxy, doc, dps, Np, dsc, dsp, dsf, dVs, dgp, dy, Nc, 1, 1.0, dcam, drot, dfc, dptsc, dscal,
+                                                   (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr, (double*)nullptr); };
+            CK(hipMemsetAsync(dscal, 0, SC_NSLOT * SC_TOTAL * 8, st)); l(); CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(pgot.data(), dptsc, pgot.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> scv(SC_NSLOT * SC_TOTAL); CK(hipMemcpy(scv.data(), dscal, scv.size() * 8, hipMemcpyDeviceToHost));
+            double model = 0, cand = 0; for (int q = 0; q < SC_NSLOT; q++) { model += scv[q * SC_TOTAL + SC_MODEL]; cand += scv[q * SC_TOTAL + SC_CAND_COST]; }
+            if (pref.empty()) pref = pgot;
+            double worst = 0; for (size_t i = 0; i < pgot.size(); i++) worst = std::max(worst, std::fabs(pgot[i] - pref[i]));
+            printf("model %.9g cand %.9g max |dX| vs first %.2g ; ", model, cand, worst);
+            timeit(tag, l);
+        };
+        run_bs(k_point_backsub<6>, 256, "backsub block 256"); run_bs(k_point_backsub<6>, 64, "backsub block 64");
     }
     return 0;
 }

@@ -1211,7 +1211,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
 //   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
 //   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
-template <int DC, int GU>
+template <int DC>
 __global__ void __launch_bounds__(256)
 k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                 const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
@@ -1258,7 +1258,9 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         // the model cost change  -sum M_j.(r_j - M_j/2)  expands into sums that do not depend on z -- sum a.a, sum a.r, B^T a, B^T B --
         // so the second re-linearisation of every observation (after z is known) is not needed
         double Saa = 0.0, Sar = 0.0, Vr[6] = {0, 0, 0, 0, 0, 0};
-        if (GU <= 1) {
+        // (Groups of two or three observations with all their camera tables in flight were slower -- 21.3 / 23.7 us against 18.8 in
+        // scripts/lab/point_lab.hip, as was a six- or eight-fold unroll of k_point_lin: the extra registers cost a wave per SIMD and the
+        // kernel is not bound by the length of a lane's chain of round trips.)
         // the camera index and pixel of observation j+1 are fetched while observation j is processed: one dependent round trip
         // per observation (its camera tables) instead of two
         int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
@@ -1276,51 +1278,6 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             Vr[3] += B0[1] * B0[1] + B1[1] * B1[1]; Vr[4] += B0[1] * B0[2] + B1[1] * B1[2]; Vr[5] += B0[2] * B0[2] + B1[2] * B1[2];
 #pragma unroll
             for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
-        }
-        } else {
-        // observations in groups of GU: the indices of the NEXT group and the camera tables of THIS group are in flight together, so a
-        // group costs one dependent round trip (a point has 3-10 observations: one or two groups instead of one trip per observation);
-        // slots beyond the list recompute the last observation with zero weight
-        constexpr int G = (GU > 1) ? GU : 1;
-        int cn[G]; double2 on[G];
-#pragma unroll
-        for (int u = 0; u < G; u++) { const int jj = min(j0 + u, j1 - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
-        for (int jb = j0; jb < j1; jb += G) {
-            int cc[G]; double2 oo[G]; double tb[G][36 + DC];      // [t (3) | R Rd M (27) | camera scales (6) | y_c (DC)]
-#pragma unroll
-            for (int u = 0; u < G; u++) { cc[u] = cn[u]; oo[u] = on[u]; }
-#pragma unroll
-            for (int u = 0; u < G; u++) {
-                const size_t c = (size_t)cc[u];
-#pragma unroll
-                for (int k = 0; k < 3; k++) tb[u][k] = cam[6 * c + k];
-#pragma unroll
-                for (int k = 0; k < 27; k++) tb[u][3 + k] = rot[27 * c + k];
-#pragma unroll
-                for (int k = 0; k < 6; k++) tb[u][30 + k] = scale_cam[6 * c + k];
-#pragma unroll
-                for (int k = 0; k < DC; k++) tb[u][36 + k] = y[c * DC + k];
-            }
-#pragma unroll
-            for (int u = 0; u < G; u++) { const int jj = min(jb + G + u, j1 - 1); cn[u] = obs_cam[jj]; on[u] = obs_xy[jj]; }
-#pragma unroll
-            for (int u = 0; u < G; u++) {
-                const double wgt = (jb + u < j1) ? 1.0 : 0.0;
-                ObsLin L; lin_obs<DC == 6>(f, tb[u], tb[u] + 3, X, oo[u].x, oo[u].y, loss, la, L);
-                double Jc[2][DC]; cam_block<DC>(L, tb[u] + 30, Jc);
-                double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
-#pragma unroll
-                for (int a = 0; a < DC; a++) { const double ya = tb[u][36 + a]; m0 += Jc[0][a] * ya; m1 += Jc[1][a] * ya; }
-                m0 *= wgt; m1 *= wgt;
-                Saa += m0 * m0 + m1 * m1; Sar += m0 * L.r[0] + m1 * L.r[1];
-                const double B0[3] = {L.Jp[0][0] * sp[0] * wgt, L.Jp[0][1] * sp[1] * wgt, L.Jp[0][2] * sp[2] * wgt};
-                const double B1[3] = {L.Jp[1][0] * sp[0] * wgt, L.Jp[1][1] * sp[1] * wgt, L.Jp[1][2] * sp[2] * wgt};
-                Vr[0] += B0[0] * B0[0] + B1[0] * B1[0]; Vr[1] += B0[0] * B0[1] + B1[0] * B1[1]; Vr[2] += B0[0] * B0[2] + B1[0] * B1[2];
-                Vr[3] += B0[1] * B0[1] + B1[1] * B1[1]; Vr[4] += B0[1] * B0[2] + B1[1] * B1[2]; Vr[5] += B0[2] * B0[2] + B1[2] * B1[2];
-#pragma unroll
-                for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
-            }
-        }
         }
         // V^-1 b from the record of the Schur kernels, PS_V = diag(s) V^-1 diag(s):  V^-1 b = s^-1 o (PS_V (s^-1 o b))
         const double* Vi = Vs + 12 * (size_t)p;
@@ -1347,29 +1304,11 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         }
         // robustified cost at the candidate (cameras, focal, this point): what a separate k_point_cost launch did
         const double fcand = focal_c[0];
-        if (GU <= 1) {
-        int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
+        c_nx = obs_cam[j0]; o_nx = obs_xy[j0];
         for (int j = j0; j < j1; j++) {
             const int c = c_nx; const double2 o = o_nx;
             { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
             acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la);
-        }
-        } else {
-        constexpr int G2 = (GU > 1) ? 2 * GU : 1;                    // 12 doubles per observation here: twice the group
-        for (int jb = j0; jb < j1; jb += G2) {
-            int cc[G2]; double2 oo[G2]; double tR[G2][12];
-#pragma unroll
-            for (int u = 0; u < G2; u++) { const int jj = min(jb + u, j1 - 1); cc[u] = obs_cam[jj]; oo[u] = obs_xy[jj]; }
-#pragma unroll
-            for (int u = 0; u < G2; u++) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) tR[u][k] = cam_c[6 * (size_t)cc[u] + k];
-#pragma unroll
-                for (int k = 0; k < 9; k++) tR[u][3 + k] = rot_c[27 * (size_t)cc[u] + k];
-            }
-#pragma unroll
-            for (int u = 0; u < G2; u++) { const double cst = obs_cost(fcand, tR[u], tR[u] + 3, Xc, oo[u].x, oo[u].y, loss, la); acc[3] += (jb + u < j1) ? cst : 0.0; }
-        }
         }
     }
     // per-wave fold and atomics (see k_point_lin): no barrier at the end

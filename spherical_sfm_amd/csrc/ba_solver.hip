@@ -27,14 +27,6 @@
 
 namespace ssfm {
 
-// k_point_lin by the number of observations whose gathers are in flight together (SSFM_PL_UNROLL = 3 | 6 | 8)
-static int point_lin_unroll() { static const int u = [] { const char* e = std::getenv("SSFM_PL_UNROLL"); const int v = e ? std::atoi(e) : 3; return (v == 6 || v == 8) ? v : 3; }(); return u; }
-static int backsub_group() { static const int u = [] { const char* e = std::getenv("SSFM_BS_GROUP"); const int v = e ? std::atoi(e) : 1; return (v == 2 || v == 3) ? v : 1; }(); return u; }
-#define LAUNCH_PL(h, kid, grid, block, shmem, ...)                                              \
-    do { const int u_ = point_lin_unroll();                                                      \
-         if (u_ == 8) LAUNCH(h, kid, k_point_lin<8>, grid, block, shmem, __VA_ARGS__);           \
-         else if (u_ == 6) LAUNCH(h, kid, k_point_lin<6>, grid, block, shmem, __VA_ARGS__);      \
-         else LAUNCH(h, kid, k_point_lin<3>, grid, block, shmem, __VA_ARGS__); } while (0)
 template <int DC>
 static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
@@ -132,7 +124,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         h->set_zone(iteration & 1);
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[0], st));
         if (nP > 0 && !lin_done)             // (lin_done: it ran speculatively behind the previous iteration, with this radius)
-            LAUNCH_PL(h, KID_POINT_LIN, (nP + PLB - 1) / PLB, PLB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
+            LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, h->scal.p, (const double*)nullptr);
         lin_done = false;
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
@@ -190,13 +182,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             }
             if (nP > 0) {
                 const bool res = !with_cams && residual_later;      // first pass of the iteration: the residual check rides along
-                auto launch_bs = [&](auto kernel) {
-                    LAUNCH(h, KID_BACKSUB, kernel, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
-                           h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
-                           h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p);
-                };
-                const int gu = backsub_group();
-                if (gu == 3) launch_bs(k_point_backsub<DC, 3>); else if (gu == 2) launch_bs(k_point_backsub<DC, 2>); else launch_bs(k_point_backsub<DC, 1>);
+                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                       h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                       h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p);
             }
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
@@ -220,7 +208,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         double* next_zone = h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len;
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
         if (spec_launched)                   // x = this iteration's candidate, scalars into the next zone (scal is its first block)
-            LAUNCH_PL(h, KID_POINT_LIN, (nP + PLB - 1) / PLB, PLB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
+            LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, next_zone, (const double*)h->lmdev.p);
         { int rc = wait_iteration(); if (rc) return rc; }
         // what the device decided for the speculative k_point_lin (it ran iff dev_go)
