@@ -57,6 +57,42 @@ def pair_kernel_bytes(M, nP, nnzb, Nc, dc):
     return 16.0 * M + 72.0 * nP + max(nnzb - Nc, 0) * dc * dc * 8.0
 
 
+def side_paths(ctx):
+    """The two other paths of SURVEY.md 8 next to the headline, each with its CPU port timed on a bounded sample and a parity figure
+    (side measurements: they never enter `value`):
+      * batched pairwise LO-MSAC (estimate_pairwise, examples/spherical_sfm_tools.cpp:300-420) in the reference-trace mode: 16384 pairs x 500
+        correspondences, 30 % outliers -- host buffers in, results out (PCIe inclusive);
+      * optimize_rotations (src/rotation_averaging.cpp:52-103) on the 300-camera graph of SURVEY 8d."""
+    import numpy as np
+    from spherical_sfm_amd import synth, ransac, rotavg
+    from oracle import oracle as O
+    res = {}
+    F = 1000.0; THR = (2 / F) ** 2; NC = 500; POOL = 256; P = 16384
+    probs = [synth.make_relative_pose_problem(NC, seed=1000 + k, noise=1 / F, outlier_frac=0.3, rotation_deg=1 + (k % 60)) for k in range(POOL)]
+    U = np.ascontiguousarray(np.concatenate([q[0] for q in probs] * (P // POOL))); V = np.ascontiguousarray(np.concatenate([q[1] for q in probs] * (P // POOL)))
+    ptr = (np.arange(P + 1, dtype=np.int64) * NC).astype(np.int32)
+    ransac.estimate_flat(ctx, ptr, U, V, THR, min_num_inliers=20)                       # warm-up: module load, pinned staging buffers
+    t = time.perf_counter(); o = ransac.estimate_flat(ctx, ptr, U, V, THR, min_num_inliers=20); dt = time.perf_counter() - t
+    ns = 24; tc = time.perf_counter(); worst = 0.0; same_its = 0
+    for k in range(ns):
+        r = O.lomsac_pair(probs[k][0], probs[k][1], THR, min_num_inliers=20)
+        worst = max(worst, float(np.linalg.norm(O.so3ln(r["R"] @ o["R"][k].T)))); same_its += int(r["iterations"] == int(o["iterations"][k]))
+    tc = (time.perf_counter() - tc) / ns
+    res["pairwise_lomsac"] = {"workload": f"{P} pairs x {NC} correspondences, 30% outliers, reference-trace LO-MSAC (std::mt19937 streams replayed on the device)",
+                              "value": P / dt, "unit": "pairs/s", "includes_pcie": True, "mean_iterations": float(o["iterations"].mean()),
+                              "cpu_baseline": {"value": 1.0 / tc, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"the first {ns} pairs"},
+                              "parity_vs_oracle": {"max_rotation_error_rad": worst, "pairs_with_identical_iteration_count": same_its, "pairs_checked": ns}}
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(300, 8)
+    rotavg.optimize_rotations(ctx, R0, i0, i1, Rrel)
+    t = time.perf_counter(); Rg, _, sg = rotavg.optimize_rotations(ctx, R0, i0, i1, Rrel); dt = time.perf_counter() - t
+    t = time.perf_counter(); Rc, _, sc = O.optimize_rotations(R0, i0, i1, Rrel); tc = time.perf_counter() - t
+    err = max(float(np.linalg.norm(O.so3ln(Rg[k] @ Rc[k].T))) for k in range(len(Rg)))
+    res["rotation_averaging"] = {"workload": f"optimize_rotations, 300 cameras, {len(i0)} edges, SoftLOne(0.03)", "value": 1e3 * dt, "unit": "ms per call", "higher_is_better": False,
+                                 "iterations": sg.get("iterations"), "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the same graph"},
+                                 "parity_vs_oracle": {"max_rotation_error_rad": err, "iterations_cpu": sc.get("iterations")}}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +111,7 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "host"], default="rccl",
                     help="N > 1: rccl (one GPU per rank, RCCL over xGMI) or host (ranks share the visible GPUs, reductions staged through gloo: "
                          "exercises the sharded path on a 1-GPU box; not a performance configuration)")
+    ap.add_argument("--no-side-paths", action="store_true", help="skip the pairwise-RANSAC and rotation-averaging side measurements (N = 1)")
     ap.add_argument("--no-configs4", action="store_true", help="N > 1: skip the configs[4] problem sharded over the N ranks")
     args = ap.parse_args()
 
@@ -248,6 +285,8 @@ def main():
             e2e["speedup_incl_reference_build_loop"] = (best["t_total_s"] - best["t_flatten_s"] + t_ref_flat) / e2e["gpu_s"]
             e2e["speedup_warm"] = best["t_total_s"] / warm["gpu_s"]
             out["end_to_end_optimize"] = e2e
+        if world == 1 and not args.no_side_paths and not args.no_cpu_baseline:
+            out["side_paths"] = side_paths(ctx)
         if world == 1 and not args.no_scale_probe and not spherical and not args.focal_free and args.cameras == 300:
             # side measurement, not the headline: the BASELINE configs[4] SIZE (4000 cameras / 1.5 M points / 12 M observations, two
             # rings of 2000 cameras) on this one GPU -- the long components go through the substructured factorisation
