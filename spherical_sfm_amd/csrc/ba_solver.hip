@@ -103,6 +103,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
     const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
     bool lin_done = false, spec_launched = false;
+    static const bool zone_clear_fused = !(std::getenv("SSFM_ZONE_CLEAR_FUSED") && std::atoi(std::getenv("SSFM_ZONE_CLEAR_FUSED")) == 0);
     // per-phase device times (summary.t_kernel_*_ms) cost five event records and four queries per iteration, the queries on the
     // host's critical path between two iterations: only with profiling on (ssfm_ba_set_profiling) or options.verbose
     const bool phases = h->profile || O.verbose;
@@ -150,13 +151,18 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             int rc = allreduce(h, h->redbuf.p, (size_t)h->n_red, ncclSum); if (rc) return rc;
             hipLaunchKernelGGL(k_scal_unpack, dim3(1), dim3(64), 0, st, h->scal.p, h->red_scal, ctx->nranks);
         }
+        // the next iteration's zone is cleared by the finalize kernel (a slice per workgroup) when its length allows 16-byte stores
+        double* next_zone = h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len;
+        const bool clear_in_finalize = O.preconditioner == 0 && zone_clear_fused && (h->zone_len % 2 == 0) && ((reinterpret_cast<uintptr_t>(next_zone) & 15) == 0);
+        double2* clear_next = clear_in_finalize ? reinterpret_cast<double2*>(next_zone) : (double2*)nullptr;
+        const size_t clear_len2 = clear_in_finalize ? h->zone_len / 2 : 0;
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             if (F.band_block != DC)      // 3-dof cameras merged in pairs into 6x6 block rows of the band
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2);
             else
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2);
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -204,9 +210,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         };
         { int rc = enqueue_tail(!fused_cams); if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
-        // the next iteration's zone is cleared while the host wakes up and decides
-        double* next_zone = h->zone.p + (size_t)((iteration + 1) & 1) * h->zone_len;
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
+        // (otherwise) the next iteration's zone is cleared while the host wakes up and decides
+        if (!clear_in_finalize) SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
         if (spec_launched)                   // x = this iteration's candidate, scalars into the next zone (scal is its first block)
             LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, next_zone, (const double*)h->lmdev.p);

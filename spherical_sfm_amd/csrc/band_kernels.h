@@ -92,9 +92,16 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
                   const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,
                   const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs,
                   const double* __restrict__ Sfc, double* __restrict__ Sff,
-                  double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal) {
+                  double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal,
+                  double2* __restrict__ clear = nullptr, size_t clear_len2 = 0) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
+    // the accumulation zone of the NEXT iteration (nothing has read it since the iteration before this one ended) is cleared here, a slice
+    // per workgroup: the separate memset was a launch of its own on the critical path behind k_publish (4.7 us per iteration)
+    if (clear) {
+        const size_t per = (clear_len2 + gridDim.x - 1) / gridDim.x, lo = (size_t)c * per, hi = (lo + per < clear_len2) ? lo + per : clear_len2;
+        for (size_t e = lo + tid; e < hi; e += blockDim.x) clear[e] = make_double2(0.0, 0.0);
+    }
     const int i = pos[c], i2 = pos2[c], rb = row_ptr[c];     // pos / pos2: band rows in camera units (second row: twisted separators)
     double gmax = 0.0;
     if (tid < DC) {
