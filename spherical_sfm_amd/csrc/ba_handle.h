@@ -148,6 +148,10 @@ namespace ssfm {
                    (h)->Sfc, vec, (h)->F.Nc, (h)->pcg.p, (h)->pq.p, (h)->pqpart.p);                                         \
     } while (0)
 
+// back substitution: the narrow variant when every task fits one lane set (b * DC <= 64)
+#define BACK_V2_LAUNCH(grid, ...)                                                                                          \
+    do { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), grid, dim3(64), 0, st, __VA_ARGS__);             \
+         else hipLaunchKernelGGL((k_band_back_v2<DC, false>), grid, dim3(64), 0, st, __VA_ARGS__); } while (0)
 #define LAUNCH(h, kid, kernel, grid, block, shmem, ...)                                   \
     do {                                                                                  \
         (h)->span_begin(kid);                                                             \
@@ -304,7 +308,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // reads that solution through seg_given
                 SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.ntwist, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
+                BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
             }
             if (B.nleft > 0) {
@@ -313,7 +317,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_end();
             }
             h->span_begin(KID_BAND_BACK);
-            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(B.nseg, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_seg_given.p, Nc, b);
+            BACK_V2_LAUNCH(dim3(B.nseg, 2), h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_seg_given.p, Nc, b);
             h->span_end();
             return SSFM_OK;
         }
@@ -322,7 +326,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             SSFM_LAUNCH_CHOL2(ncomp, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
-                hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 2), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);
+                BACK_V2_LAUNCH(dim3(ncomp, 2), h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);
                 h->span_end();
             } else {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
@@ -356,7 +360,7 @@ static int band_resolve(ssfm_ba_handle* h, double* Y, bool* needs_refactor) {
         LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nb, b);
         if (back_v2) {
             h->span_begin(KID_BAND_BACK);
-            hipLaunchKernelGGL((k_band_back_v2<DC>), dim3(ncomp, 1), dim3(64), 0, st, h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nb, b);
+            BACK_V2_LAUNCH(dim3(ncomp, 1), h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nb, b);
             h->span_end();
         } else {
             LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nb, b);

@@ -431,7 +431,8 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 // sum of row j-(d-1), component a; lanes carry tasks t = lane and t = lane + 64 (b*DC <= 128).  The factor streams from
 // global memory BACK_PD steps ahead (a step is shorter than one memory latency), loads unconditional from clamped addresses.
 constexpr int BACK_PD = 4;
-template <int DC>
+// WIDE: b * DC > 64, a lane carries two tasks (lane and lane + 64); narrow bands (half-width <= 10 at 6-dof blocks) skip the second set altogether
+template <int DC, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
                const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b) {
@@ -462,7 +463,7 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
 #pragma unroll
         for (int m = 0; m < DC; m++) {
             s.col0[m] = rowp[o0 + m * DC];
-            s.col1[m] = rowp[o1 + m * DC];
+            if (WIDE) s.col1[m] = rowp[o1 + m * DC];
             s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
         }
         const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
@@ -479,12 +480,12 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             double c0[DC], c1[DC], cl[DC]; const double cy = st[u].yv;
             const bool v0 = has0 && j - d0 >= r0, v1 = has1 && j - d1 >= r0;       // rows above the component do not exist: their terms are dropped below
 #pragma unroll
-            for (int m = 0; m < DC; m++) { c0[m] = st[u].col0[m]; c1[m] = st[u].col1[m]; cl[m] = st[u].li[m]; }
+            for (int m = 0; m < DC; m++) { c0[m] = st[u].col0[m]; c1[m] = WIDE ? st[u].col1[m] : 0.0; cl[m] = st[u].li[m]; }
             fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
             // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc0
             const double z = cy - acc0;                             // lanes 0..DC-1
             // the shift does not depend on x_j: issue it before the dependent chain
-            const double sh0 = lane_shift_down(acc0, DC), sh1 = lane_shift_down(acc1, DC);
+            const double sh0 = lane_shift_down(acc0, DC), sh1 = WIDE ? lane_shift_down(acc1, DC) : 0.0;
             double sft0 = (lane + DC < 64) ? sh0 : sh1;             // lanes near the top of set 0 take from the bottom of set 1
             if (!(lane + DC < T)) sft0 = 0.0;
             double sft1 = (lane + DC < 64) ? sh1 : 0.0;
@@ -496,10 +497,10 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
             else if (lane < DC) y[(size_t)j * DC + lane] = x;
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; s1 += c1[m] * xm; }
+            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; if (WIDE) s1 += c1[m] * xm; }
             s0 = v0 ? s0 : 0.0; s1 = v1 ? s1 : 0.0;                            // (one select per sum instead of one per loaded entry)
             // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
-            acc0 = sft0 + s0; acc1 = sft1 + s1;
+            acc0 = sft0 + s0; if (WIDE) acc1 = sft1 + s1;
         }
     }
 }
