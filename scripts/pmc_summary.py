@@ -27,7 +27,7 @@ for k, d in out.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         traffic[re.sub(r"<.*>", "", k)] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
 traffic["_valu_wave_instructions"] = {re.sub(r"<.*>", "", k): d["SQ_INSTS_VALU"] for k, d in out.items() if "SQ_INSTS_VALU" in d}   # per launch, all waves
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     d = out[k]
     print(f"{k:28s} fetch {2*d.get('FETCH_SIZE',0)/1024:8.2f} MB  write {d.get('WRITE_SIZE',0)/1024:8.2f} MB  "
