@@ -86,7 +86,7 @@ struct ssfm_ba_handle {
     BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
     DevBuf<unsigned char> pair_dummy;    // merged 3-dof pairs: 1 = the partner slot of this camera is empty
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
-    DevBuf<double> subZ, subD, subT, subF, subL, subW;
+    DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags; int sub_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
@@ -123,7 +123,7 @@ struct ssfm_ba_handle {
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vs.free(); gp.free();
         lmdev.free(); band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
-        subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free();
+        subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free(); subC.free(); subTc.free(); sub_flags.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
@@ -234,7 +234,9 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     SSFM_HIP_CHECK(ctx, upload(h->sub_chain_ptr, B.chain_ptr, st));
     if (B.nsep == 0) return SSFM_OK;                             // twisted components only: no spikes, no chain
     SSFM_HIP_CHECK(ctx, h->subZ.alloc(Q * n)); SSFM_HIP_CHECK(ctx, h->subD.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subT.alloc((size_t)B.nsep * 2 * Q));
-    SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
+    SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)(B.nsep + B.nchain) * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
+    SSFM_HIP_CHECK(ctx, h->subC.alloc((size_t)B.nchain * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subTc.alloc((size_t)B.nchain * 2 * Q)); SSFM_HIP_CHECK(ctx, h->sub_flags.alloc((size_t)2 * B.nchain));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->sub_flags.p, 0, (size_t)2 * B.nchain * sizeof(int), st)); h->sub_seq = 0;
     return SSFM_OK;
 }
 
@@ -292,7 +294,12 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     // SSFM_CHAIN_STAMPS=1: s_memtime stamps of the phases of one separator, printed once (profiles/*_notes.md)
                     static long long* d_stamps = nullptr; static int stamp_state = std::getenv("SSFM_CHAIN_STAMPS") ? 1 : 0;
                     if (stamp_state == 1) { (void)hipMalloc((void**)&d_stamps, 16 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(long long), st); stamp_state = 2; }
-                    LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps);
+                    // chains of three or more separators are eliminated from both ends by two workgroups each (SSFM_CHAIN_TWIST=0: one workgroup, front to back)
+                    static const bool chain_twist = !(std::getenv("SSFM_CHAIN_TWIST") && std::atoi(std::getenv("SSFM_CHAIN_TWIST")) == 0);
+                    const int tw = chain_twist ? 1 : 0;
+                    h->sub_seq++;
+                    LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
+                           tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq);
                     if (stamp_state == 2) {
                         long long hs[16]; (void)hipMemcpyAsync(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st);
                         std::fprintf(stderr, "[chain stamps, cycles] load E %lld | F solve %lld | t update + F store %lld | load D %lld | syrk %lld | chol J=0: diag %lld panel %lld trailing %lld | chol total %lld | stores %lld\n",

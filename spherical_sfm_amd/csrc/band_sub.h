@@ -503,7 +503,8 @@ template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
-                     double* __restrict__ Y, int* __restrict__ fail_flag, long long* __restrict__ stamps /* null, or [16] phase stamps of chain 0, separator 1 */) {
+                     double* __restrict__ Y, int* __restrict__ fail_flag, long long* __restrict__ stamps /* null, or [16] phase stamps of chain 0, separator 1 */,
+                     int twist, int nsep_total, double* __restrict__ Cbuf, double* __restrict__ Tcbuf, int* __restrict__ flags, int seq) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TB = 16;
 #define STAMP(k_) do { if (stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -512,19 +513,41 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
     double* sF = sL + NP;              // [Q][Q] column-major: F(i, c) at c*Q + i
     double* sT = sF + (size_t)Q * Q;   // [NR][Q]
     double* sW = sT + NR * Q;          // [NR][Q]
-    const int s0 = chain_ptr[blockIdx.x], ns = chain_ptr[blockIdx.x + 1] - s0;
+    // Two-sided elimination of a chain (twist): workgroup 2c takes the separators from the front up to and including the middle one,
+    // workgroup 2c + 1 the ones behind it from the BACK (coupling blocks read transposed) and ends with a virtual step on the middle
+    // separator that only produces its Schur contribution (-F'F'^T, -F'w); the front workgroup adds it before it factors the middle,
+    // publishes x_middle, and both substitute backwards on their own halves.  Depth ceil(ns / 2) + 1 instead of ns.  The two workgroups of
+    // a chain meet through two flags in global memory (release: __threadfence + barrier + atomic store; acquire: spin + fence).
+    const int chain = twist ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, side = twist ? (int)(blockIdx.x & 1) : 0;
+    const int s0 = chain_ptr[chain], ns = chain_ptr[chain + 1] - s0;
+    const bool tw = twist && ns >= 3;
+    if (side == 1 && !tw) return;
+    const int mid = tw ? ns / 2 : ns - 1;                          // position of the front side's last separator
+    const int npos = (side == 0) ? mid + 1 : ns - mid;              // back side: ns - 1 - mid real separators + the virtual step
+    int* flag_contrib = flags + 2 * chain; int* flag_x = flags + 2 * chain + 1;
+    auto publish_flag = [&](int* f) { __threadfence(); __syncthreads(); if (tid == 0) __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };
+    auto await_flag = [&](int* f) {
+        if (tid == 0) while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(16);
+        __syncthreads(); __threadfence();
+    };
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int tx = tid & 127, ty = tid >> 7;
     const bool rowt = tx < Q;
 #define PK(i_, c_) ((i_) * ((i_) + 1) / 2 + (c_))
 #define MFMA64(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
-    for (int j = 0; j < ns; j++) {
-        const int s = s0 + j, p0 = sep_lo[s];
+    for (int j = 0; j < npos; j++) {
+        const int s = (side == 0) ? s0 + j : s0 + ns - 1 - j, p0 = sep_lo[s];
+        const bool virt = side == 1 && j == npos - 1;               // the back side's step on the middle separator: contribution only
+        const size_t fslot = virt ? (size_t)(nsep_total + chain) : (size_t)s;
         STAMP(0);
-        for (int e = tid; e < NR * Q; e += nt) sT[e] = tt[(size_t)s * NR * Q + e];
+        for (int e = tid; e < NR * Q; e += nt) sT[e] = virt ? 0.0 : tt[(size_t)s * NR * Q + e];
         if (j > 0) {
-            if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx];
+            if (side == 0) { if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx]; }
+            else {                                                  // E' = E_{s+1}^T: rows = this separator, columns = the one behind it (s + 1)
+                const int pn = sep_lo[s + 1];
+                if (rowt) for (int r = ty; r < Q; r += 8) sF[tx * Q + r] = Z[(size_t)r * n + (size_t)pn * DC + tx];
+            }
             __syncthreads();
             STAMP(1);
             // ---- F = E Lc^-T: wave I = row tile I, block columns in order, no barrier
@@ -571,12 +594,12 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 for (int c = 0; c < Q; c++) acc += sF[c * Q + tx] * sW[ty * Q + c];
                 sT[ty * Q + tx] -= acc;
             }
-            for (int e = tid; e < Q * Q; e += nt) Fbuf[(size_t)s * Q * Q + e] = sF[e];
+            for (int e = tid; e < Q * Q; e += nt) Fbuf[fslot * Q * Q + e] = sF[e];
         }
         // ---- D_j into the packed triangle (previous factor is dead: it went to Lbuf)
         __syncthreads();
         STAMP(3);
-        if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = Dd[((size_t)s * Q + tx) * Q + cp];
+        if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp];
         __syncthreads();
         STAMP(4);
         if (j > 0) {
@@ -597,6 +620,18 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                     if (row < Q && col <= row) sL[PK(row, col)] -= acc[q];
                 }
             }
+        }
+        if (virt) {                                                 // -F'F'^T and -F'w of the back side go to the front side; no factorisation
+            __syncthreads();
+            for (int e = tid; e < NP; e += nt) Cbuf[(size_t)chain * NP + e] = sL[e];
+            for (int e = tid; e < NR * Q; e += nt) Tcbuf[(size_t)chain * NR * Q + e] = sT[e];
+            publish_flag(flag_contrib);
+            break;
+        }
+        if (tw && side == 0 && j == mid) {                          // the middle separator: add the back side's contribution
+            await_flag(flag_contrib);
+            for (int e = tid; e < NP; e += nt) sL[e] += Cbuf[(size_t)chain * NP + e];
+            for (int e = tid; e < NR * Q; e += nt) sT[e] += Tcbuf[(size_t)chain * NR * Q + e];
         }
         // ---- blocked Cholesky (16 columns per step), forward substitution of t riding along
         for (int J = 0; J < TQ; J++) {
@@ -677,11 +712,19 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
     }
 #undef STAMP
     // ---- backward
-    for (int j = ns - 1; j >= 0; j--) {
-        const int s = s0 + j, p0 = sep_lo[s];
-        if (j < ns - 1) {                                   // reload this separator's factor and w; v = w - F_{j+1}^T x_{j+1}
+    if (side == 1) {                                        // x of the middle separator, from the front side
+        await_flag(flag_x);
+        const int pm = sep_lo[s0 + mid];
+        for (int e = tid; e < NR * Q; e += nt) { const int r = (e >= Q) ? e / Q : 0, c = e - r * Q; sW[e] = Y[(size_t)r * n + (size_t)pm * DC + c]; }
+        __syncthreads();
+    }
+    const int jlast = (side == 0) ? npos - 1 : npos - 2;    // last REAL separator of this side (the back side's virtual step has no unknowns)
+    for (int j = jlast; j >= 0; j--) {
+        const int s = (side == 0) ? s0 + j : s0 + ns - 1 - j, p0 = sep_lo[s];
+        if (side == 1 || j < jlast) {                       // reload this separator's factor and w; v = w - F_next^T x_next (next = the step after this one)
             for (int e = tid; e < NP; e += nt) sL[e] = Lbuf[(size_t)s * NP + e];
-            const double* Fn = Fbuf + (size_t)(s + 1) * Q * Q;
+            const size_t nslot = (side == 0) ? (size_t)(s + 1) : ((j + 1 == npos - 1) ? (size_t)(nsep_total + chain) : (size_t)(s - 1));
+            const double* Fn = Fbuf + nslot * Q * Q;
             for (int o = wave; o < NR * Q; o += nw) {
                 const int r = (o >= Q) ? o / Q : 0, c = o - r * Q;
                 double acc = 0.0;
@@ -715,6 +758,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             sW[e] = x; Y[(size_t)r * n + (size_t)p0 * DC + c] = x;
         }
         __syncthreads();
+        if (tw && side == 0 && j == mid) publish_flag(flag_x);     // the back side may start its substitution
     }
 #undef PK
 #undef MFMA64
