@@ -178,3 +178,14 @@ def test_band_segment_plan_matches_reference_partition(monkeypatch):
     monkeypatch.delenv("SSFM_BAND_TWIST")
     small, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))       # ... but eliminated from both ends
     assert (small["band_segments"], small["band_separators"]) == (8, 4)
+
+
+def test_ring_components_fold_to_twice_their_reach():
+    """Camera ordering (csrc/ba_flatten.h: cuthill_mckee): a ring whose cameras share points with their +-r neighbours is a periodic band of
+    half-width r; folded into a plain band it cannot be narrower than 2 r, and the planner reaches that (the root's children go closest first)."""
+    for nc, k, reach in ((300, 6, 5), (75, 6, 5), (60, 6, 5), (500, 6, 5), (4000, 8, 7)):
+        p = synth.make_circle(nc, 2000 if nc < 1000 else 16000, k, spherical=False, focal_fixed=True)
+        info = ba.plan(p)[0]
+        assert info["band_half_width"] == 2 * reach, (nc, k, info["band_half_width"])
+    p = synth.make_circle(300, 2000, 6, spherical=True, focal_fixed=True)      # 3-dof cameras: pairs merged into 6x6 band blocks
+    assert ba.plan(p)[0]["band_half_width"] == 5

@@ -21,6 +21,22 @@ def test_band_solver_matches_dense_solve(gpu_ctx, monkeypatch, dc, b, rows, P):
     assert np.abs(X - xr).max() <= 1e-12 * np.abs(xr).max()
 
 
+@pytest.mark.parametrize("dc,b,rows,P", [(6, 5, [130], 4), (6, 5, [160, 171], 5), (6, 14, [420], 6), (3, 9, [300, 310], 7), (6, 7, [330], 10), (6, 3, [64], 4)])
+def test_two_sided_separator_chain(gpu_ctx, monkeypatch, dc, b, rows, P):
+    """Chains of three or more separators are eliminated from both ends by two workgroups that meet at the middle separator (band_sub.h 4b):
+    odd and even chain lengths, partial last 16-tiles, several components, against numpy's dense solve."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P))
+    band, A, cp, rhs = R.random_band_system(rows, b, dc, seed=7 * dc + b + P)
+    X, info = ba.band_solve_probe(gpu_ctx, dc, cp, band, rhs)
+    assert info["failed"] == 0 and info["separators"] == (P - 1) * len(rows)
+    xr = np.linalg.solve(A, rhs.T).T
+    assert np.abs(X - xr).max() <= 1e-12 * np.abs(xr).max()
+    for _ in range(3):                                      # the hand-over flags carry a launch number: repeated solves on fresh handles agree bit for bit
+        X2, _ = ba.band_solve_probe(gpu_ctx, dc, cp, band, rhs)
+        assert np.array_equal(X, X2)
+
+
 def test_substructured_intermediates(gpu_ctx, monkeypatch):
     """Spikes Z, separator blocks D and right-hand sides t against the numpy statement of the same elimination."""
     from spherical_sfm_amd import ba
