@@ -86,7 +86,7 @@ struct ssfm_ba_handle {
     BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
     DevBuf<unsigned char> pair_dummy;    // merged 3-dof pairs: 1 = the partner slot of this camera is empty
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
-    DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags; int sub_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
+    DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags, sub_fz_lo, sub_fz_hi, sub_fz_wend, sub_fz_merge, sub_fz_await, sub_fz_signal, sub_fz_flags; int sub_seq = 0, sub_fz_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
@@ -123,7 +123,7 @@ struct ssfm_ba_handle {
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vs.free(); gp.free();
         lmdev.free(); band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
         sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
-        subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free(); subC.free(); subTc.free(); sub_flags.free();
+        subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free(); subC.free(); subTc.free(); sub_flags.free(); sub_fz_lo.free(); sub_fz_hi.free(); sub_fz_wend.free(); sub_fz_merge.free(); sub_fz_await.free(); sub_fz_signal.free(); sub_fz_flags.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
@@ -232,6 +232,11 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_chain_ptr, B.chain_ptr, st));
+    if (B.ntwist > 0) {
+        SSFM_HIP_CHECK(ctx, upload(h->sub_fz_lo, B.fz_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_fz_hi, B.fz_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_fz_wend, B.fz_wend, st));
+        SSFM_HIP_CHECK(ctx, upload(h->sub_fz_merge, B.fz_merge, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_fz_await, B.fz_await, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_fz_signal, B.fz_signal, st));
+        SSFM_HIP_CHECK(ctx, h->sub_fz_flags.alloc((size_t)4 * B.ntwist)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->sub_fz_flags.p, 0, (size_t)4 * B.ntwist * sizeof(int), st)); h->sub_fz_seq = 0;
+    }
     if (B.nsep == 0) return SSFM_OK;                             // twisted components only: no spikes, no chain
     SSFM_HIP_CHECK(ctx, h->subZ.alloc(Q * n)); SSFM_HIP_CHECK(ctx, h->subD.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->subT.alloc((size_t)B.nsep * 2 * Q));
     SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)(B.nsep + B.nchain) * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
@@ -277,7 +282,15 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             static const bool chain_mfma = !(std::getenv("SSFM_CHAIN_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_MFMA")) == 0);     // matrix-core separator chain (band_sub.h 4b)
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
-            SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
+            // SSFM_CHOL_FUSE=1 (experiment, off): one launch for the segments AND the separators of twisted components, which then wait for their two halves
+            // through flags in global memory.  Measured at config 2: 70.7 us for the fused launch against 2 x 35.2, 2.958 vs 2.919 ms per solve -- the fence + flag
+            // hand-over costs what the launch boundary did (profiles/r02_notes.md)
+            static const bool chol_fuse = std::getenv("SSFM_CHOL_FUSE") && std::atoi(std::getenv("SSFM_CHOL_FUSE")) != 0;
+            const bool fused = chol_fuse && B.ntwist > 0;
+            if (fused) { h->sub_fz_seq++;
+                SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp,
+                                  h->sub_fz_await.p, h->sub_fz_signal.p, h->sub_fz_flags.p, h->sub_fz_seq); }
+            else SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
                 h->span_begin(KID_SUB_SPIKE);
@@ -313,7 +326,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
-                SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
+                if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();

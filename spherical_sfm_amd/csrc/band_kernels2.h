@@ -76,7 +76,10 @@ template <int DC, int NR, int MF = 0>      // MF bit 0: matrix-core panel, bit 1
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
-               const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag) {
+               const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag,
+               // fused launch of segments and the separators that wait for them (ba_handle.h band_direct): per workgroup the first of two flags to await
+               // before its window is loaded (-1: none) and the flag to raise when its rows are in global memory (-1: none); flags hold launch numbers
+               const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0) {
     constexpr int BB = DC * DC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int R = b + 1, W = b + 1, RW = W * BB;
@@ -94,8 +97,14 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     // component; a SEGMENT of a substructured component (band_sub.h) has re = r1 + b: the rows of the separator behind it
     // receive their factor blocks L(r, k) and their Schur update, and are written back by the epilogue instead of being pivots.
     const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
-    if (r0 >= r1) return;
+    const int sig = signal ? signal[blockIdx.x] : -1, aw = await2 ? await2[blockIdx.x] : -1;
+    if (r0 >= r1) { if (sig >= 0 && tid == 0) __hip_atomic_store(flags + sig, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); return; }
     for (int e = tid; e < b * (b + 1) / 2; e += nt) sPairs[e] = pairs[e];
+    if (aw >= 0) {                                         // the two segments in front of this separator have written its rows
+        if (tid == 0) { while (__hip_atomic_load(flags + aw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(8);
+                        while (__hip_atomic_load(flags + aw + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(8); }
+        __syncthreads(); __threadfence();
+    }
     // merge_from (twisted components, band_sub.h): this component is a separator of b rows whose second copy, rows mf..mf+b-1 in
     // REVERSED order, holds the Schur update and the forward-substitution share of the reversed segment: block (s, s-d) takes the
     // transpose of the copy's block (b-1-s+d, d).  The whole separator sits in the initial window (b < R), so merging is free here.
@@ -424,6 +433,10 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             for (int e = tid; e < nin; e += nt) band[(size_t)row * RW + e] = src[e];
             for (int e = tid; e < NR * DC; e += nt) Y[(size_t)(e / DC) * n + (size_t)row * DC + (e % DC)] = sYr[(size_t)(row % R) * NR * DC + e];
         }
+    }
+    if (sig >= 0) {                                        // this segment's share of its separator is in global memory
+        __threadfence(); __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + sig, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

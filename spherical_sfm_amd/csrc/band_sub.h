@@ -36,6 +36,9 @@ struct BandSub {
     int ntwist = 0;
     std::vector<int> tw_lo, tw_hi, tw_copy;
     std::vector<int> seg_given;                     // per segment: rows where the solution of its given rows really is (reversed segments), else -1
+    // fused launches (segments + the twisted separators that wait for them): tables over nseg + ntwist workgroups; flag 2t / 2t+1 = the halves of twisted component t
+    std::vector<int> seg_twist;                     // per segment: 2t + half of the twisted component it belongs to, else -1
+    std::vector<int> fz_lo, fz_hi, fz_wend, fz_merge, fz_await, fz_signal;
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
@@ -66,9 +69,9 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
     for (size_t c = 0; c + 1 < comp_ptr.size(); c++) {
         const int c0 = comp_ptr[c], rows = comp_ptr[c + 1] - c0;
         if (c < comp_twist.size() && comp_twist[c]) {                  // rows = n + b: seg_0 | sep | seg_1 reversed | copy of sep
-            const int n = rows - b, m0 = (n - b) / 2, m1 = n - b - m0;
-            S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b); S.seg_given.push_back(-1);
-            S.seg_lo.push_back(c0 + m0 + b); S.seg_hi.push_back(c0 + m0 + b + m1); S.seg_wend.push_back(c0 + rows); S.seg_given.push_back(c0 + m0);
+            const int n = rows - b, m0 = (n - b) / 2, m1 = n - b - m0, t2 = 2 * (int)S.tw_lo.size();
+            S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b); S.seg_given.push_back(-1); S.seg_twist.push_back(t2);
+            S.seg_lo.push_back(c0 + m0 + b); S.seg_hi.push_back(c0 + m0 + b + m1); S.seg_wend.push_back(c0 + rows); S.seg_given.push_back(c0 + m0); S.seg_twist.push_back(t2 + 1);
             S.tw_lo.push_back(c0 + m0); S.tw_hi.push_back(c0 + m0 + b); S.tw_copy.push_back(c0 + m0 + b + m1);
             S.enabled = true;
             continue;
@@ -81,7 +84,7 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
         for (int i = 0; i < P; i++) {
             const int m = m_total / P + (i < m_total % P ? 1 : 0);
             if (i > 0) S.left_segs.push_back((int)S.seg_lo.size());
-            S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + m); S.seg_wend.push_back(i + 1 < P ? pos + m + b : pos + m); S.seg_given.push_back(-1);
+            S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + m); S.seg_wend.push_back(i + 1 < P ? pos + m + b : pos + m); S.seg_given.push_back(-1); S.seg_twist.push_back(-1);
             pos += m;
             if (i + 1 < P) { S.sep_lo.push_back(pos); S.sep_rseg.push_back((int)S.seg_lo.size()); pos += b; }
         }
@@ -89,7 +92,9 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
     }
     S.nseg = (int)S.seg_lo.size(); S.nsep = (int)S.sep_lo.size(); S.nchain = (int)S.chain_ptr.size() - 1; S.nleft = (int)S.left_segs.size();
     S.ntwist = (int)S.tw_lo.size();
-    if (!S.enabled) S = BandSub();
+    if (!S.enabled) { S = BandSub(); return; }
+    S.fz_lo = S.seg_lo; S.fz_hi = S.seg_hi; S.fz_wend = S.seg_wend; S.fz_merge.assign(S.nseg, -1); S.fz_await.assign(S.nseg, -1); S.fz_signal = S.seg_twist;
+    for (int t = 0; t < S.ntwist; t++) { S.fz_lo.push_back(S.tw_lo[t]); S.fz_hi.push_back(S.tw_hi[t]); S.fz_wend.push_back(S.tw_hi[t]); S.fz_merge.push_back(S.tw_copy[t]); S.fz_await.push_back(2 * t); S.fz_signal.push_back(-1); }
 }
 
 // ---- 2. spike: Z(:, q) = L_seg^-1 C_left(:, q), one wave per (segment, SPIKE_NC columns) -----------------------------------
