@@ -10,7 +10,7 @@
 using namespace ssfm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 int main() {
-    constexpr int DC = 6, BB = 36, NR = 2; const int ncomp = 4, ncam = 75, b = 12, N = ncomp * ncam, W = b + 1, n = N * DC, nw = 10;
+    constexpr int DC = 6, BB = 36, NR = 2; const int ncomp = 4, ncam = 75, b = 10, N = ncomp * ncam, W = b + 1, n = N * DC, nw = 9;
     std::mt19937_64 rng(7); std::uniform_real_distribution<double> U(-1, 1);
     std::vector<double> band((size_t)N * W * BB, 0.0), Y((size_t)NR * n);
     for (int i = 0; i < N; i++) { for (int d = 1; d <= b && (i % ncam) - d >= 0; d++) for (int e = 0; e < BB; e++) band[((size_t)i * W + d) * BB + e] = U(rng);
@@ -24,13 +24,16 @@ int main() {
     CK(hipMemcpy(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dc, comp.data(), comp.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(df, 0, 4));
     const size_t lds = ((size_t)(b + 1) * W * BB + (size_t)b * BB + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * 8 + ((size_t)b * (b + 1) / 2 + 4) * 4 + (size_t)ncam * nw * 4 * 8;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int remap = getenv("REMAP") ? atoi(getenv("REMAP")) : 1;
+    const CholWaveMap wm = remap ? chol_wave_map(nw, nw - 4, 4) : chol_wave_map(0, 0, 0);
+    printf("wave map:"); for (int i = 0; i < nw; i++) printf(" p%d->role %d", i, wm.v[i]); printf("\n");
     for (int rep = 0; rep < 3; rep++) {
         CK(hipMemcpy(dband, band.data(), band.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dY, Y.data(), Y.size() * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds, 0, dband, dG, dY, dp, dc, dc + 1, dc + 1, (const int*)nullptr, N, b, df, ddbg);
+        hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds, 0, dband, dG, dY, dp, dc, dc + 1, dc + 1, (const int*)nullptr, N, b, df, wm, (const int*)nullptr, (const int*)nullptr, (int*)nullptr, 0, ddbg);
         CK(hipDeviceSynchronize());
     }
     std::vector<long long> dbg((size_t)ncam * nw * 4); CK(hipMemcpy(dbg.data(), ddbg, dbg.size() * 8, hipMemcpyDeviceToHost));
-    const char* role[10] = {"look-ahead", "trail", "trail", "trail", "trail", "trail", "trail", "loader", "loader", "writer"};
+    const char* role[10] = {"look-ahead", "trail", "trail", "trail", "trail", "trail(rhs)", "loader", "loader", "writer", ""};
     for (int j = 30; j < 33; j++) {
         const long long t0 = dbg[((size_t)j * nw) * 4];
         for (int w = 0; w < nw; w++) { printf("step %d wave %d %-10s:", j, w, role[w]); for (int k = 0; k < 4; k++) printf(" %6lld", dbg[((size_t)j * nw + w) * 4 + k] - t0); printf("\n"); }

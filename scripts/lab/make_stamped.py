@@ -3,8 +3,9 @@ workgroup 0 in LDS (before / after the panel phase, after barrier 1, after the r
 import os, re
 here = os.path.dirname(os.path.abspath(__file__))
 src = open(os.path.join(here, "..", "..", "spherical_sfm_amd", "csrc", "band_kernels2.h")).read()
-src = src.replace("const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag) {\n    constexpr int BB = DC * DC;\n    extern __shared__",
-                  "const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag, long long* __restrict__ dbg) {\n    constexpr int BB = DC * DC;\n    extern __shared__", 1)
+old_sig = "int* __restrict__ flags = nullptr, int seq = 0) {\n    constexpr int BB = DC * DC;\n    extern __shared__"
+assert old_sig in src
+src = src.replace(old_sig, "int* __restrict__ flags = nullptr, int seq = 0, long long* __restrict__ dbg = nullptr) {\n    constexpr int BB = DC * DC;\n    extern __shared__", 1)
 src = src.replace("    int* sPairs = reinterpret_cast<int*>(sD + BB);",
                   "    int* sPairs = reinterpret_cast<int*>(sD + BB);\n    long long* sStamp = reinterpret_cast<long long*>(sPairs + b * (b + 1) / 2 + 2 + ((b * (b + 1) / 2) & 1));\n"
                   "#define STAMP(j_, k_) do { if (blockIdx.x == 0 && lane == 0) sStamp[((size_t)((j_) - r0) * nw + wave) * 4 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)", 1)
@@ -25,8 +26,8 @@ for ln in lines:
     out.append(ln)
 src = "\n".join(out)
 # dump at the end of the kernel: find the end of k_band_chol_v2 (the closing of the writer branch)
-marker = "        }\n    }\n}\n\n// Back substitution"
+marker = "    if (sig >= 0) {                                        // this segment's share of its separator is in global memory"
 assert marker in src
-src = src.replace(marker, "        }\n    }\n    __syncthreads();\n    if (blockIdx.x == 0) for (int e = tid; e < (r1 - r0) * nw * 4; e += nt) dbg[e] = sStamp[e];\n}\n\n// Back substitution", 1)
+src = src.replace(marker, "    __syncthreads();\n    if (dbg && blockIdx.x == 0) for (int e = tid; e < (r1 - r0) * nw * 4; e += nt) dbg[e] = sStamp[e];\n" + marker, 1)
 open(os.path.join(here, "band_kernels2_stamped.h"), "w").write(src)
 print("stamped header written; STAMP count", src.count("STAMP("))

@@ -259,8 +259,14 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
     const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
     const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
     // wave roles of k_band_chol_v2: 1 look-ahead + trailing-update waves (one block task per lane) + loaders + 1 writer
-    const int tr_tasks = (b * (b + 1) / 2) * ((DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC) + b * DC;
-    const int chol_threads = 64 * (2 + CHOL2_LOADERS + std::min(std::max((tr_tasks + 63) / 64, 1), 7));
+    // (block tasks and right-hand-side tasks on waves of their own when seven waves allow it: see the trailing role of the kernel)
+    const int tpb_ = (DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC, blk_tasks = (b * (b + 1) / 2) * tpb_ - tpb_, rhs_tasks = b * DC;
+    const int tr_waves_split = (std::max(blk_tasks, 1) + 63) / 64 + (rhs_tasks + 63) / 64, tr_waves_packed = (blk_tasks + rhs_tasks + 63) / 64;
+    const int chol_ntw = std::min(std::max(tr_waves_split <= 7 ? tr_waves_split : tr_waves_packed, 1), 7);
+    const int chol_threads = 64 * (2 + CHOL2_LOADERS + chol_ntw);
+    static const bool chol_remap = !(std::getenv("SSFM_CHOL_WAVE_MAP") && std::atoi(std::getenv("SSFM_CHOL_WAVE_MAP")) == 0);
+    const CholWaveMap chol_map = chol_remap ? chol_wave_map(chol_threads / 64, chol_ntw, tr_waves_split <= 7 ? (std::max(blk_tasks, 1) + 63) / 64 : chol_ntw)
+                                            : chol_wave_map(0, 0, 0);
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
     // matrix-core panel + trailing update (band_kernels2.h, MF): 6x6 blocks only; SSFM_BAND_MFMA=0 keeps the VALU version
@@ -288,9 +294,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             static const bool chol_fuse = std::getenv("SSFM_CHOL_FUSE") && std::atoi(std::getenv("SSFM_CHOL_FUSE")) != 0;
             const bool fused = chol_fuse && B.ntwist > 0;
             if (fused) { h->sub_fz_seq++;
-                SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp,
+                SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp, chol_map,
                                   h->sub_fz_await.p, h->sub_fz_signal.p, h->sub_fz_flags.p, h->sub_fz_seq); }
-            else SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp);
+            else SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp, chol_map);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
                 h->span_begin(KID_SUB_SPIKE);
@@ -326,7 +332,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
-                if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp);
+                if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map);
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
@@ -343,7 +349,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
         }
         // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
         if (use_lds) {
-            SSFM_LAUNCH_CHOL2(ncomp, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            SSFM_LAUNCH_CHOL2(ncomp, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL), chol_map);
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(ncomp, 2), h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);

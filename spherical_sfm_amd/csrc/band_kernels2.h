@@ -64,6 +64,30 @@ __device__ __forceinline__ bool wave_chol_inverse(double (&row)[DC], double (&g)
 //   last wave                   writer: panel, y_j and G to global memory (stores only, never waited on)
 // Every wave takes its share of the panel product in phase B.
 constexpr int CHOL2_LOADERS = 2;
+// Role of every PHYSICAL wave of the workgroup (wave p runs on SIMD p % 4): v[p] = the role index the kernel's logic uses (0 look-ahead,
+// 1..ntw trailing update, then the loaders, the writer last).  With the identity a nine-wave workgroup puts the look-ahead (the dependent chain of
+// the step), a trailing wave and the writer on SIMD 0: their phases took 1.6k / 2.2k / 2.1k cycles against 1.3-1.5k for the trailing waves
+// that share a SIMD with one loader only, and the step waits for the slowest (s_memtime stamps, scripts/lab/chol_stamps.hip).
+struct CholWaveMap { unsigned char v[16]; };
+inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_tw: trailing waves that carry block tasks (the rest only right-hand sides)
+    CholWaveMap m; for (int i = 0; i < 16; i++) m.v[i] = (unsigned char)i;
+    if (nw > 16 || nw < 5) return m;
+    int weight[16], order[16];
+    for (int r = 0; r < nw; r++) {
+        weight[r] = (r == 0) ? 12 : (r <= ntw) ? ((r <= heavy_tw) ? 6 : 2) : (r == nw - 1) ? 5 : 4;
+        order[r] = r;
+    }
+    for (int a = 0; a < nw; a++) for (int c = a + 1; c < nw; c++) if (weight[order[c]] > weight[order[a]]) { const int t = order[a]; order[a] = order[c]; order[c] = t; }
+    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, cap[4];
+    for (int q = 0; q < 4; q++) cap[q] = (nw - q + 3) / 4;                // physical waves q, q + 4, ...
+    for (int a = 0; a < nw; a++) {                                        // heaviest role first onto the least loaded SIMD with a free wave
+        int best = -1;
+        for (int q = 0; q < 4; q++) if (used[q] < cap[q] && (best < 0 || load[q] < load[best])) best = q;
+        m.v[best + 4 * used[best]] = (unsigned char)order[a];
+        load[best] += weight[order[a]]; used[best]++;
+    }
+    return m;
+}
 
 // MF = true (DC = 6 only): the panel product and the trailing update run on the matrix cores -- v_mfma_f64_16x16x4_f64 tiles in
 // window-relative coordinates (row i of the window = block i / 6 + 1 behind the pivot, scalar row i % 6), K = the pivot's six columns in two
@@ -77,6 +101,7 @@ __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
                const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag,
+               const CholWaveMap wmap,                 // role of every physical wave (chol_wave_map; identity = roles in wave order)
                // fused launch of segments and the separators that wait for them (ba_handle.h band_direct): per workgroup the first of two flags to await
                // before its window is loaded (-1: none) and the flag to raise when its rows are in global memory (-1: none); flags hold launch numbers
                const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0) {
@@ -90,8 +115,9 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     double* sG = sYj + NR * DC;                             // [BB]       inverse factor of the current diagonal block
     double* sD = sG + BB;                                   // [BB]       scratch: updated next diagonal block
     int* sPairs = reinterpret_cast<int*>(sD + BB);
-    const int n = N * DC, tid = threadIdx.x, nt = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    // role index of this (physical) wave and the matching thread index: everything below is written in terms of these two
+    const int n = N * DC, nt = blockDim.x, lane = threadIdx.x & 63, nw = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)wmap.v[threadIdx.x >> 6]), tid = wave * 64 + lane;
     const int ntw = nw - 2 - CHOL2_LOADERS;                 // trailing-update waves
     // pivots [r0, r1); the window (panels, trailing update, right-hand sides) runs on to row re >= r1.  re == r1 for a whole
     // component; a SEGMENT of a substructured component (band_sub.h) has re = r1 + b: the rows of the separator behind it
@@ -332,37 +358,44 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             phaseB(j, jm, nb);
             lds_barrier();
             const int work = (nb * (nb + 1) / 2) * TPB;
-            for (int t = ct + TPB; t < work + nb * DC; t += cw) {
-                if (t < work) {
-                    const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
-                    const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
-                    const double* Li_ = sP + (size_t)(ir - 1) * BB + a0 * DC;
-                    const double* Lk_ = sP + (size_t)(kr - 1) * BB + c0 * DC;
-                    double la[TR][DC], lk[TR][DC];
+            auto block_task = [&](int t) {
+                const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
+                const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
+                const double* Li_ = sP + (size_t)(ir - 1) * BB + a0 * DC;
+                const double* Lk_ = sP + (size_t)(kr - 1) * BB + c0 * DC;
+                double la[TR][DC], lk[TR][DC];
 #pragma unroll
-                    for (int u = 0; u < TR; u++)
+                for (int u = 0; u < TR; u++)
 #pragma unroll
-                        for (int m = 0; m < DC; m++) { la[u][m] = Li_[u * DC + m]; lk[u][m] = Lk_[u * DC + m]; }
-                    int si = jm + ir; if (si >= R) si -= R;
-                    double* dst = sWin + (size_t)si * RW + (size_t)(ir - kr) * BB + a0 * DC + c0;
+                    for (int m = 0; m < DC; m++) { la[u][m] = Li_[u * DC + m]; lk[u][m] = Lk_[u * DC + m]; }
+                int si = jm + ir; if (si >= R) si -= R;
+                double* dst = sWin + (size_t)si * RW + (size_t)(ir - kr) * BB + a0 * DC + c0;
 #pragma unroll
-                    for (int u = 0; u < TR; u++)
+                for (int u = 0; u < TR; u++)
 #pragma unroll
-                        for (int w = 0; w < TR; w++) { double v = 0.0;
+                    for (int w = 0; w < TR; w++) { double v = 0.0;
 #pragma unroll
-                            for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
-                            dst[u * DC + w] -= v; }
-                } else {                                                          // right-hand sides: y_{j+kr} -= X_kr y_j
-                    const int qq = t - work;
-                    const int kr = qq / DC + 1, a = qq - (kr - 1) * DC;
-                    int sk = jm + kr; if (sk >= R) sk -= R;
-                    const double* Lk_ = sP + (size_t)(kr - 1) * BB + a * DC;
+                        for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
+                        dst[u * DC + w] -= v; }
+            };
+            auto rhs_task = [&](int qq) {                                         // right-hand sides: y_{j+kr} -= X_kr y_j
+                const int kr = qq / DC + 1, a = qq - (kr - 1) * DC;
+                int sk = jm + kr; if (sk >= R) sk -= R;
+                const double* Lk_ = sP + (size_t)(kr - 1) * BB + a * DC;
 #pragma unroll
-                    for (int r = 0; r < NR; r++) { double v = 0.0;
+                for (int r = 0; r < NR; r++) { double v = 0.0;
 #pragma unroll
-                        for (int m = 0; m < DC; m++) v += Lk_[m] * sYj[r * DC + m];
-                        sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
-                }
+                    for (int m = 0; m < DC; m++) v += Lk_[m] * sYj[r * DC + m];
+                    sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
+            };
+            // one task per lane; the right-hand-side tasks start on a wave of their own when the lanes allow it (a wave that held the tail of
+            // the block tasks AND right-hand-side tasks ran both bodies: 2.2k cycles against 1.5k for its neighbours, and the step waits for it)
+            const int nblk = work - TPB, nrhs = nb * DC, wbk = (nblk + 63) & ~63;
+            if (wbk + nrhs <= cw) {
+                if (ct < nblk) block_task(ct + TPB);
+                else if (ct >= wbk && ct - wbk < nrhs) rhs_task(ct - wbk);
+            } else {
+                for (int t = ct + TPB; t < work + nrhs; t += cw) { if (t < work) block_task(t); else rhs_task(t - work); }
             }
             lds_barrier();
         }
