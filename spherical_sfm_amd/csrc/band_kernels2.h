@@ -71,7 +71,10 @@ constexpr int CHOL2_LOADERS = 2;
 struct CholWaveMap { unsigned char v[16]; };
 inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_tw: trailing waves that carry block tasks (the rest only right-hand sides)
     CholWaveMap m; for (int i = 0; i < 16; i++) m.v[i] = (unsigned char)i;
-    if (nw > 16 || nw < 5) return m;
+    // Measured, not derived: the nine-wave workgroup of config 2 (6x6 blocks, half-width 10) gains 18 % per step; with eleven waves (half-width 14,
+    // where both loaders then sit with the look-ahead: 286 -> 340 us per launch at the configs[4] size) and with six (merged 3-dof pairs: 2.18 -> 2.20 ms per
+    // solve) the identity is better, so only the shape that was stamped is remapped.
+    if (nw != 9) return m;
     int weight[16], order[16];
     for (int r = 0; r < nw; r++) {
         weight[r] = (r == 0) ? 12 : (r <= ntw) ? ((r <= heavy_tw) ? 6 : 2) : (r == nw - 1) ? 5 : 4;
@@ -80,9 +83,15 @@ inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_
     for (int a = 0; a < nw; a++) for (int c = a + 1; c < nw; c++) if (weight[order[c]] > weight[order[a]]) { const int t = order[a]; order[a] = order[c]; order[c] = t; }
     int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, cap[4];
     for (int q = 0; q < 4; q++) cap[q] = (nw - q + 3) / 4;                // physical waves q, q + 4, ...
-    for (int a = 0; a < nw; a++) {                                        // heaviest role first onto the least loaded SIMD with a free wave
+    // SIMD 0: the look-ahead (first in the order) and the LIGHTEST roles for its other waves; everything else heaviest first onto the least
+    // loaded of the other three SIMDs
+    bool placed[16] = {false};
+    m.v[0] = (unsigned char)order[0]; placed[0] = true; used[0] = 1;
+    for (int a = nw - 1; a >= 1 && used[0] < cap[0]; a--) { m.v[4 * used[0]] = (unsigned char)order[a]; placed[a] = true; used[0]++; }
+    for (int a = 1; a < nw; a++) {
+        if (placed[a]) continue;
         int best = -1;
-        for (int q = 0; q < 4; q++) if (used[q] < cap[q] && (best < 0 || load[q] < load[best])) best = q;
+        for (int q = 1; q < 4; q++) if (used[q] < cap[q] && (best < 0 || load[q] < load[best])) best = q;
         m.v[best + 4 * used[best]] = (unsigned char)order[a];
         load[best] += weight[order[a]]; used[best]++;
     }
