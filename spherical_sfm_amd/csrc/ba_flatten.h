@@ -23,6 +23,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 #include "../../include/ssfm.h"
 
@@ -130,7 +131,20 @@ public:
         active = 0;
     }
 };
-inline PlanPool& plan_pool() { static PlanPool p; return p; }      // helpers are joined at static destruction (they are parked on the condition variable)
+// One pool per process, joined at exit.  A fork()ed child inherits the object but none of its threads: it abandons the inherited pool (whose
+// std::thread handles must not be destroyed) and starts a fresh one on first use.
+struct PlanPoolHolder {
+    PlanPool* pool = nullptr; long owner_pid = 0;
+    ~PlanPoolHolder() { if (pool && owner_pid == (long)getpid()) delete pool; }
+};
+inline PlanPool& plan_pool() {
+    static PlanPoolHolder h;
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lk(guard);
+    const long pid = (long)getpid();
+    if (!h.pool || h.owner_pid != pid) { h.pool = new PlanPool(); h.owner_pid = pid; }      // (the inherited pool of a forked child is leaked on purpose)
+    return *h.pool;
+}
 template <class Fn>
 inline void parallel_chunks(int64_t n, int T, Fn f) {
     if (T <= 1 || n < 4 * (int64_t)T) { f(0, (int64_t)0, n); return; }

@@ -189,3 +189,18 @@ def test_ring_components_fold_to_twice_their_reach():
         assert info["band_half_width"] == 2 * reach, (nc, k, info["band_half_width"])
     p = synth.make_circle(300, 2000, 6, spherical=True, focal_fixed=True)      # 3-dof cameras: pairs merged into 6x6 band blocks
     assert ba.plan(p)[0]["band_half_width"] == 5
+
+
+def test_planner_pool_survives_fork():
+    """The planner's helper threads do not exist in a fork()ed child; the child must start its own pool instead of waiting for them."""
+    import os
+    import signal
+    p = synth.make_circle(300, 50000, 6, spherical=False, focal_fixed=True)       # large enough for the threaded sections
+    want = ba.plan(p)[0]["band_half_width"]
+    pid = os.fork()
+    if pid == 0:
+        signal.alarm(30)                                                         # a deadlock ends the child with SIGALRM
+        ok = ba.plan(p)[0]["band_half_width"] == want
+        os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
