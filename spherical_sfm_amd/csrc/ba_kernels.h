@@ -1127,7 +1127,8 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
     constexpr int off = (DC == 6) ? 0 : 3;
     const int n = Nc * DC, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double phi;
-    if (phi_parts > 0) {                                            // large camera sets: the dot products come from k_arrow_phi
+    if (phi_parts < 0) phi = 0.0;                                   // focal fixed: S_fc = 0, S_ff = 1, rho = 0 -- no block-wide dot products, no barrier
+    else if (phi_parts > 0) {                                       // large camera sets: the dot products come from k_arrow_phi
         double a0 = 0.0, a1 = 0.0;
         for (int b = 0; b < phi_parts; b++) { a0 += phi_part[2 * b]; a1 += phi_part[2 * b + 1]; }
         phi = (rho_ptr[0] - a0) / (Sff[0] - a1);
