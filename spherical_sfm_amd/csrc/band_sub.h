@@ -122,17 +122,24 @@ k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv
     const int lc = min(lane, DC - 1);
     struct Stage { double row0[DC], row1[DC], g[DC], cv[NC]; };
     Stage st[SPIKE_PD];
+    // (wave-uniform row bases + 32-bit lane offsets instead of a flat 64-bit index per load, as in k_band_back_v2)
+    const size_t row_stride = (size_t)W * BB;
+    const int o0 = d0 * BB + a0 * DC, o1 = d1 * BB + a1 * DC;
     auto fetch = [&](int k, Stage& s) {    // row a of L(k+d, k) for this lane's tasks; row `lane` of G_k; C_left(k, q)[lane]
         const int kc = min(k, re - 1);
-        const int k0 = min(kc + d0, re - 1), k1 = min(kc + d1, re - 1);
+        const double* __restrict__ base = band + (size_t)kc * row_stride;
+        const double* __restrict__ gpt = Ginv + (size_t)kc * BB;
+        // rows kc + d of this lane's tasks: the lane offset carries d rows; rows past the window are clamped to its last row
+        const int k0 = min(kc + d0, re - 1) - kc, k1 = min(kc + d1, re - 1) - kc;
+        const int f0 = k0 * (int)row_stride + o0, f1 = k1 * (int)row_stride + o1;
 #pragma unroll
         for (int m = 0; m < DC; m++) {
-            s.row0[m] = band[((size_t)k0 * W + d0) * BB + a0 * DC + m];
-            s.row1[m] = band[((size_t)k1 * W + d1) * BB + a1 * DC + m];
-            s.g[m] = Ginv[(size_t)kc * BB + lc * DC + m];                 // G[lane][m], zero for m > lane
+            s.row0[m] = base[f0 + m];
+            s.row1[m] = base[f1 + m];
+            s.g[m] = gpt[lc * DC + m];                                    // G[lane][m], zero for m > lane
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) { const int dl = min(kc - r0 + b - cs[c], b); s.cv[c] = band[((size_t)kc * W + dl) * BB + lc * DC + cc[c]]; }
+        for (int c = 0; c < NC; c++) { const int dl = min(kc - r0 + b - cs[c], b); s.cv[c] = base[dl * BB + lc * DC + cc[c]]; }
     };
 #pragma unroll
     for (int u = 0; u < SPIKE_PD; u++) fetch(r0 + u, st[u]);
@@ -149,7 +156,7 @@ k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv
 #pragma unroll
             for (int c = 0; c < NC; c++) cvv[c] = (k - r0 <= cs[c]) ? st[u].cv[c] : 0.0;
 #pragma unroll
-            for (int m = 0; m < DC; m++) { c0[m] = v0 ? st[u].row0[m] : 0.0; c1[m] = v1 ? st[u].row1[m] : 0.0; cg[m] = st[u].g[m]; }
+            for (int m = 0; m < DC; m++) { c0[m] = st[u].row0[m]; c1[m] = st[u].row1[m]; cg[m] = st[u].g[m]; }      // rows past the window: their sums are dropped below
             fetch(k + SPIKE_PD, st[u]);
             const bool pivot = k < r1;
 #pragma unroll
@@ -168,7 +175,7 @@ k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int m = 0; m < DC; m++) { const double zm = lane_bcast(zz, m); s0 += c0[m] * zm; s1 += c1[m] * zm; }
-                acc0[c] = sft0 + s0; acc1[c] = sft1 + s1;
+                acc0[c] = sft0 + (v0 ? s0 : 0.0); acc1[c] = sft1 + (v1 ? s1 : 0.0);
             }
         }
     }
