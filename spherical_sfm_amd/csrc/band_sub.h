@@ -102,8 +102,10 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
 // (blocks whose column lies in front of r0).  Right-looking: task t = (d-1)*DC + a (d = 1..b) owns the pending sum of row
 // k + (d-1), component a; lanes carry tasks t = lane and t = lane + 64.  Rows [r1, re) take no pivot: they receive -sum = E.
 // Z: [b*DC][N*DC], row index = global scalar row.  A step is latency bound and every column streams the same factor rows, so a
-// wave carries SPIKE_NC columns through one stream of L (one column per wave made the kernel L2-bandwidth bound: 12 TB/s).
-constexpr int SPIKE_PD = 4, SPIKE_NC = 4;
+// wave carries SPIKE_NC columns through one stream of L.  Round 1 (half-width 19, flat 64-bit indices): one column per wave was L2-bandwidth bound and four
+// columns per wave won.  Round 2 (half-width 14 after the ordering change, scalar row bases): a step is bound by what one wave can issue, the columns of a
+// wave run one after the other inside a step, and there are CUs to spare -- 4 columns 210 us, 2 columns 169 us, 1 column 130 us per launch at the configs[4] size.
+constexpr int SPIKE_PD = 4, SPIKE_NC = 1;
 template <int DC>
 __global__ void __launch_bounds__(64)
 k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Z, const int* __restrict__ seg_lo,
