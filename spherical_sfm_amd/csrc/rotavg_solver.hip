@@ -374,12 +374,24 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
     int iteration = 0, num_invalid = 0; bool last_successful = true;
     S->num_successful_steps = 1; S->termination = SSFM_NO_CONVERGENCE; S->camera_dof = 3; S->num_residual_blocks = S->num_residual_blocks_global = E;
+    static const bool fused_finalize = !(std::getenv("SSFM_ROT_FUSED_FINALIZE") && std::atoi(std::getenv("SSFM_ROT_FUSED_FINALIZE")) == 0);
     while (true) {
         if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
         iteration++;
         zi ^= 1; h->set_zone(zi);
         { int rc = assemble(sc3.p, scf.p); if (rc) return rc; }
+        // LM diagonal + gradient max + band rows + permuted right-hand sides in one launch (the BA loop's fused kernel; the block-Jacobi inverse of
+        // k_finalize_S is only needed by the PCG preconditioner option)
+        if (O.preconditioner == 0 && fused_finalize) {
+            if (F.band_block != 3)
+                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<3, true>), n, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal, O.max_lm_diagonal,
+                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+            else
+                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<3, false>), n, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal, O.max_lm_diagonal,
+                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+            h->band_filled = true;
+        } else
         LAUNCH(h, KID_FINALIZE, k_finalize_S<3>, gn, 64, 0, h->row_ptr.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal,
                O.max_lm_diagonal, n, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         int pcg_iters = 0; bool pcg_ok = false;
