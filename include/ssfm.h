@@ -228,6 +228,17 @@ int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr,
 int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v,
                               double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R,
                               uint8_t* inlier_mask, int32_t* num_inliers, double* scores, uint32_t* stats);
+/* The same estimation from what estimate_pairwise really holds (examples/spherical_sfm_tools.cpp:340-375): per-frame feature lists and per-pair
+ * match lists.  feat_rays[feat_ptr[f] + k] = Kinv (x, y, 1) of feature k of frame f (:362-370, computed once per feature instead of once per
+ * match); pair p matches feature match_idx0[i] of frame pair_frame0[p] with feature match_idx1[i] of frame pair_frame1[p] for i in
+ * [match_ptr[p], match_ptr[p+1]).  The feature rays are uploaded once, the match lists stream through the pinned double buffer (8 bytes per
+ * correspondence instead of the 48 of ssfm_ransac_batch: BASELINE configs[3] moves 8 GB instead of 48 GB) and a gather kernel lays the ray
+ * pairs out on the device.  Outputs and random streams exactly as ssfm_ransac_batch on the gathered rays (inlier_mask indexed like the matches). */
+int ssfm_ransac_batch_indexed(ssfm_ctx* ctx, int32_t num_frames, const int32_t* feat_ptr, const double* feat_rays,
+                              int32_t num_pairs, const int32_t* pair_frame0, const int32_t* pair_frame1, const int32_t* match_ptr,
+                              const int32_t* match_idx0, const int32_t* match_idx1,
+                              double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
+                              int32_t* num_inliers, double* scores, uint32_t* stats);
 /* ---- the reference's estimator interface for ONE pair (rays resident on the device) ------------------------------------------------
  * One entry point per virtual of sphericalsfm::Estimator<Eigen::Matrix3d> / EssentialEstimator (include/sphericalsfm/estimator.h:7-29) as
  * SphericalEstimator implements them (include/sphericalsfm/spherical_estimator.h:8-35, src/spherical_estimator.cpp:67-164): what a host-side

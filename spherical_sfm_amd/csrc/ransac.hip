@@ -16,6 +16,7 @@
 // part of such eigenvectors, which is never a valid model.
 #include <algorithm>
 #include <cstdio>
+#include <atomic>
 #include <thread>
 #include "ransac_device.h"
 
@@ -217,9 +218,24 @@ bool lomsac_needs_global_lists(int max_n);
 // Pairs are streamed through the GPU in slabs (BASELINE configs[3]: 2000 frames = 2.0 M pairs x 500 correspondences = 48 GB of rays, more
 // than one allocation should hold and far more than one copy should block on): slab k+1 is packed into the second pinned buffer and copied
 // on the context's copy stream while slab k computes; results come back per slab.  One slab = at most SLAB_RAYS rays / SLAB_PAIRS pairs.
+// indexed input (ssfm_ransac_batch_indexed): rays come from per-frame feature tables through per-pair match lists
+struct RansacIndexed { int32_t num_frames; const int32_t* feat_ptr; const double* feat_rays; const int32_t* frame0; const int32_t* frame1; const int32_t* idx0; const int32_t* idx1; };
+// one workgroup per pair: u[i] = rays[off0 + idx0[i]], v[i] = rays[off1 + idx1[i]]
+static __global__ void __launch_bounds__(256)
+k_gather_rays(const int* __restrict__ ptr, const int* __restrict__ off01, const int* __restrict__ idx0, const int* __restrict__ idx1, const double* __restrict__ rays,
+              double* __restrict__ u, double* __restrict__ v) {
+    const int p = blockIdx.x, a = ptr[p], b = ptr[p + 1];
+    const size_t o0 = (size_t)off01[2 * p], o1 = (size_t)off01[2 * p + 1];
+    for (int i = a + threadIdx.x; i < b; i += blockDim.x) {
+        const double* r0 = rays + 3 * (o0 + (size_t)idx0[i]); const double* r1 = rays + 3 * (o1 + (size_t)idx1[i]);
+        u[3 * (size_t)i] = r0[0]; u[3 * (size_t)i + 1] = r0[1]; u[3 * (size_t)i + 2] = r0[2];
+        v[3 * (size_t)i] = r1[0]; v[3 * (size_t)i + 1] = r1[1]; v[3 * (size_t)i + 2] = r1[2];
+    }
+}
+
 static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,
                              const ssfm_ransac_options& O, const int32_t* pair_id, double* E_out, double* R_out, uint8_t* inlier_mask,
-                             int32_t* num_inliers, double* scores, uint32_t* stats_out) {
+                             int32_t* num_inliers, double* scores, uint32_t* stats_out, const RansacIndexed* X = nullptr) {
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (O.mode != SSFM_RANSAC_FIXED_BUDGET && O.mode != SSFM_RANSAC_REFERENCE_TRACE) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: unknown mode");
     if (O.mode == SSFM_RANSAC_REFERENCE_TRACE && (O.min_sample_multiplicator < 1 || O.min_sample_multiplicator > 21 || O.non_min_sample_multiplier < 1 || O.non_min_sample_multiplier > 3 ||
@@ -246,15 +262,21 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
     hipStream_t st = ctx->stream;
     hipStream_t cs = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
     // per-slab device buffers x 2 (upload of the next slab overlaps the kernels of this one); pinned staging x 2
-    struct Slot { DevBuf<int> ptr, pid, nin, lists; DevBuf<double> u, v, E, S, R; DevBuf<unsigned char> mask; DevBuf<unsigned> stats;
-                  double* h_uv = nullptr; int* h_ptr = nullptr; double* h_res = nullptr; unsigned char* h_mask = nullptr; int* h_nin = nullptr; unsigned* h_stats = nullptr; } slot[2];
-    DevBuf<unsigned> dmt;
+    struct Slot { DevBuf<int> ptr, pid, nin, lists, idx, off; DevBuf<double> u, v, E, S, R; DevBuf<unsigned char> mask; DevBuf<unsigned> stats;
+                  double* h_uv = nullptr; int* h_ptr = nullptr; int* h_idx = nullptr; double* h_res = nullptr; unsigned char* h_mask = nullptr; int* h_nin = nullptr; unsigned* h_stats = nullptr; } slot[2];
+    DevBuf<unsigned> dmt; DevBuf<double> frays;
     const int nslot = ns > 1 ? 2 : 1;
     const bool glists = trace ? lomsac_needs_global_lists(max_n) : true;
     int rc = SSFM_OK;
     auto body = [&]() -> int {
         if (trace) { std::vector<unsigned> seeded(624); mt_seed_host(O.seed, seeded.data()); SSFM_HIP_CHECK(ctx, upload(dmt, seeded, st)); }
         if (nslot > 1) { SSFM_HIP_CHECK(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking)); }
+        if (X) {                                              // the feature rays of every frame, once
+            const size_t nf = (size_t)X->feat_ptr[X->num_frames];
+            SSFM_HIP_CHECK(ctx, frays.alloc(std::max<size_t>(1, 3 * nf)));
+            if (nf) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(frays.p, X->feat_rays, 3 * nf * sizeof(double), hipMemcpyHostToDevice, st));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));   // (the upload stream of the slabs is another one)
+        }
         for (int b = 0; b < nslot; b++) {
             Slot& s = slot[b];
             SSFM_HIP_CHECK(ctx, hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming)); SSFM_HIP_CHECK(ctx, hipEventCreateWithFlags(&compute_done[b], hipEventDisableTiming));
@@ -263,7 +285,9 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             SSFM_HIP_CHECK(ctx, s.S.alloc(cap_pairs)); SSFM_HIP_CHECK(ctx, s.R.alloc((size_t)9 * cap_pairs)); SSFM_HIP_CHECK(ctx, s.mask.alloc(cap_rays));
             SSFM_HIP_CHECK(ctx, s.stats.alloc((size_t)2 * cap_pairs));
             if (glists) SSFM_HIP_CHECK(ctx, s.lists.alloc((trace ? 2 : 1) * cap_rays));
-            SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_uv, 6 * cap_rays * sizeof(double), hipHostMallocDefault));
+            if (X) { SSFM_HIP_CHECK(ctx, s.idx.alloc(2 * cap_rays)); SSFM_HIP_CHECK(ctx, s.off.alloc((size_t)2 * cap_pairs));
+                     SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_idx, (2 * cap_rays + (size_t)2 * cap_pairs) * sizeof(int), hipHostMallocDefault)); }
+            else SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_uv, 6 * cap_rays * sizeof(double), hipHostMallocDefault));
             SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_ptr, (size_t)(2 * cap_pairs + 1) * sizeof(int), hipHostMallocDefault));
             SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)19 * cap_pairs * sizeof(double), hipHostMallocDefault));
             SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&s.h_mask, cap_rays, hipHostMallocDefault));
@@ -274,6 +298,32 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             Slot& s = slot[k % nslot]; hipStream_t up = (nslot > 1) ? cs : st;
             const int p0 = slab[k], np = slab[k + 1] - p0, r0 = pair_ptr[p0]; const size_t nr = (size_t)(pair_ptr[slab[k + 1]] - r0);
             if (k >= nslot) SSFM_HIP_CHECK(ctx, hipEventSynchronize(compute_done[k % nslot]));      // the slot's previous slab has been read back
+            if (X) {                                          // match lists + the two feature offsets of every pair; the rays are gathered on the device
+                // copied AND range-checked here, on the staging threads (a check of the whole list up front would be a second pass over 8 GB at configs[3])
+                int* ho = s.h_idx + 2 * cap_rays;
+                std::atomic<int> bad(0);
+                const int nt = (int)std::max<size_t>(1, std::min<size_t>(stage_threads, nr / (1u << 18)));
+                auto part = [&](int t) {
+                    const int a = (int)((int64_t)np * t / nt), b = (int)((int64_t)np * (t + 1) / nt);
+                    for (int i = a; i < b; i++) {
+                        const int f0 = X->frame0[p0 + i], f1 = X->frame1[p0 + i];
+                        const int n0 = X->feat_ptr[f0 + 1] - X->feat_ptr[f0], n1 = X->feat_ptr[f1 + 1] - X->feat_ptr[f1];
+                        ho[2 * i] = X->feat_ptr[f0]; ho[2 * i + 1] = X->feat_ptr[f1];
+                        unsigned worst0 = 0, worst1 = 0;
+                        for (int q = pair_ptr[p0 + i]; q < pair_ptr[p0 + i + 1]; q++) {
+                            const int i0 = X->idx0[q], i1 = X->idx1[q];
+                            s.h_idx[q - r0] = i0; s.h_idx[cap_rays + (q - r0)] = i1;
+                            worst0 = std::max(worst0, (unsigned)i0); worst1 = std::max(worst1, (unsigned)i1);      // negative indices wrap to large values
+                        }
+                        if ((pair_ptr[p0 + i + 1] > pair_ptr[p0 + i]) && (worst0 >= (unsigned)n0 || worst1 >= (unsigned)n1)) bad.store(1);
+                    }
+                };
+                { std::vector<std::thread> th; for (int t = 1; t < nt; t++) th.emplace_back(part, t); part(0); for (auto& x : th) x.join(); }
+                if (bad.load()) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed: feature index out of range");
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.idx.p, s.h_idx, nr * sizeof(int), hipMemcpyHostToDevice, up));
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.idx.p + cap_rays, s.h_idx + cap_rays, nr * sizeof(int), hipMemcpyHostToDevice, up));
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.off.p, ho, (size_t)2 * np * sizeof(int), hipMemcpyHostToDevice, up));
+            } else
             // pageable -> pinned on several threads (one thread moves ~10 GB/s; configs[3] stages 48 GB)
             {
                 const size_t bytes = 3 * nr * sizeof(double);
@@ -290,8 +340,10 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             }
             for (int i = 0; i <= np; i++) s.h_ptr[i] = pair_ptr[p0 + i] - r0;
             for (int i = 0; i < np; i++) s.h_ptr[cap_pairs + 1 + i] = pair_id ? pair_id[p0 + i] : p0 + i;      // the random stream of a pair is that of its global index
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.u.p, s.h_uv, 3 * nr * sizeof(double), hipMemcpyHostToDevice, up));
-            SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.v.p, s.h_uv + 3 * cap_rays, 3 * nr * sizeof(double), hipMemcpyHostToDevice, up));
+            if (!X) {
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.u.p, s.h_uv, 3 * nr * sizeof(double), hipMemcpyHostToDevice, up));
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.v.p, s.h_uv + 3 * cap_rays, 3 * nr * sizeof(double), hipMemcpyHostToDevice, up));
+            }
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.ptr.p, s.h_ptr, (size_t)(np + 1) * sizeof(int), hipMemcpyHostToDevice, up));
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.pid.p, s.h_ptr + cap_pairs + 1, (size_t)np * sizeof(int), hipMemcpyHostToDevice, up));
             SSFM_HIP_CHECK(ctx, hipEventRecord(up_done[k % nslot], up));
@@ -317,6 +369,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             const int np = slab[k + 1] - slab[k]; const size_t nr = (size_t)(pair_ptr[slab[k + 1]] - pair_ptr[slab[k]]);
             int slab_max_n = 0; for (int p = slab[k]; p < slab[k + 1]; p++) slab_max_n = std::max(slab_max_n, pair_ptr[p + 1] - pair_ptr[p]);
             SSFM_HIP_CHECK(ctx, hipStreamWaitEvent(st, up_done[k % nslot], 0));
+            if (X && np > 0) hipLaunchKernelGGL(k_gather_rays, dim3(np), dim3(256), 0, st, s.ptr.p, s.off.p, s.idx.p, s.idx.p + cap_rays, frays.p, s.u.p, s.v.p);
             if (trace) {
                 const int r = lomsac_launch(ctx, st, np, slab_max_n, s.ptr.p, s.u.p, s.v.p, (int)nr, O, sq_thresh, dmt.p, glists ? s.lists.p : nullptr, s.E.p, s.S.p, s.R.p, s.mask.p, s.nin.p, s.stats.p);
                 if (r) return r;
@@ -350,13 +403,30 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
     for (int b = 0; b < 2; b++) {
         Slot& s = slot[b];
         s.ptr.free(); s.pid.free(); s.nin.free(); s.lists.free(); s.u.free(); s.v.free(); s.E.free(); s.S.free(); s.R.free(); s.mask.free(); s.stats.free();
+        s.idx.free(); s.off.free(); if (s.h_idx) (void)hipHostFree(s.h_idx);
         if (s.h_uv) (void)hipHostFree(s.h_uv); if (s.h_ptr) (void)hipHostFree(s.h_ptr); if (s.h_res) (void)hipHostFree(s.h_res);
         if (s.h_mask) (void)hipHostFree(s.h_mask); if (s.h_nin) (void)hipHostFree(s.h_nin); if (s.h_stats) (void)hipHostFree(s.h_stats);
         if (up_done[b]) (void)hipEventDestroy(up_done[b]); if (compute_done[b]) (void)hipEventDestroy(compute_done[b]);
     }
-    dmt.free();
+    dmt.free(); frays.free();
     if (cs) (void)hipStreamDestroy(cs);
     return rc;
+}
+
+extern "C" int ssfm_ransac_batch_indexed(ssfm_ctx* ctx, int32_t num_frames, const int32_t* feat_ptr, const double* feat_rays, int32_t num_pairs,
+                                         const int32_t* pair_frame0, const int32_t* pair_frame1, const int32_t* match_ptr, const int32_t* match_idx0,
+                                         const int32_t* match_idx1, double sq_thresh, const ssfm_ransac_options* opt, double* E_out, double* R_out,
+                                         uint8_t* inlier_mask, int32_t* num_inliers, double* scores, uint32_t* stats) {
+    if (!ctx || num_frames <= 0 || !feat_ptr || !feat_rays || num_pairs <= 0 || !pair_frame0 || !pair_frame1 || !match_ptr || !match_idx0 || !match_idx1)
+        return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed: bad arguments");
+    for (int f = 0; f < num_frames; f++) if (feat_ptr[f + 1] < feat_ptr[f]) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed: feat_ptr must ascend");
+    for (int p = 0; p < num_pairs; p++) {
+        const int f0 = pair_frame0[p], f1 = pair_frame1[p];
+        if (f0 < 0 || f0 >= num_frames || f1 < 0 || f1 >= num_frames || match_ptr[p + 1] < match_ptr[p]) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed: frame index out of range or match_ptr not ascending");
+    }
+    ssfm_ransac_options O; if (opt) O = *opt; else ssfm_ransac_default_options(&O);
+    const RansacIndexed X{num_frames, feat_ptr, feat_rays, pair_frame0, pair_frame1, match_idx0, match_idx1};
+    return ransac_batch_impl(ctx, num_pairs, match_ptr, nullptr, nullptr, sq_thresh, O, nullptr, E_out, R_out, inlier_mask, num_inliers, scores, stats, &X);
 }
 
 extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const double* u, const double* v, double sq_thresh,

@@ -212,3 +212,43 @@ def test_exhaustive_circle_streams_in_slabs(gpu_ctx, oracle, monkeypatch):
                    frob_err(out["E"][p], o["E"]) <= 1e-9 and rot_err(out["R"][p], o["R"]) <= 1e-9))
     ok = np.array(ok)
     assert ok[:, 0].mean() >= 0.97 and ok[:, 1].mean() >= 0.97 and ok[:, 2].mean() >= 0.97, ok.mean(axis=0)
+
+
+def test_indexed_entry_point_equals_materialised_rays(gpu_ctx):
+    """ssfm_ransac_batch_indexed (per-frame feature rays + per-pair match lists, rays gathered on the device) against ssfm_ransac_batch on the
+    same ray pairs laid out by the host: every output bit for bit (same kernels, same random streams), several slabs, an empty pair, and an
+    out-of-range feature index refused."""
+    import os
+    from spherical_sfm_amd import ransac, _lib
+    rng = np.random.default_rng(11)
+    nframes = 9
+    probs = [synth.make_relative_pose_problem(120 + 7 * k, seed=300 + k, noise=1e-3, outlier_frac=0.25, rotation_deg=3 + k) for k in range(nframes - 1)]
+    # frame f holds the u-rays of problem f (as its features, shuffled) and the v-rays of problem f-1 behind them
+    feat = [[] for _ in range(nframes)]; where_u = []; where_v = []
+    for k, (u, v, *_rest) in enumerate(probs):
+        pu = rng.permutation(len(u)); pv = rng.permutation(len(v))
+        base_u = len(feat[k]); feat[k].extend(u[pu]); iu = np.empty(len(u), np.int32); iu[pu] = base_u + np.arange(len(u)); where_u.append(iu)
+        base_v = len(feat[k + 1]); feat[k + 1].extend(v[pv]); iv = np.empty(len(v), np.int32); iv[pv] = base_v + np.arange(len(v)); where_v.append(iv)
+    feat_ptr = np.zeros(nframes + 1, np.int32)
+    for f in range(nframes): feat_ptr[f + 1] = feat_ptr[f] + len(feat[f])
+    rays = np.concatenate([np.asarray(f).reshape(-1, 3) for f in feat])
+    f0 = []; f1 = []; mp = [0]; m0 = []; m1 = []; U = []; V = []
+    for rep in range(3):                                   # 24 pairs + an empty one
+        for k, (u, v, *_rest) in enumerate(probs):
+            f0.append(k); f1.append(k + 1); m0.append(where_u[k]); m1.append(where_v[k]); mp.append(mp[-1] + len(u)); U.append(u); V.append(v)
+        if rep == 1: f0.append(2); f1.append(5); mp.append(mp[-1])
+    m0 = np.concatenate(m0); m1 = np.concatenate(m1); U = np.concatenate(U); V = np.concatenate(V); mp = np.array(mp, np.int32)
+    thr = (2e-3) ** 2
+    old = os.environ.get("SSFM_RANSAC_SLAB_PAIRS"); os.environ["SSFM_RANSAC_SLAB_PAIRS"] = "7"      # several slabs through the double buffer
+    try:
+        a = ransac.estimate_flat(gpu_ctx, mp, U, V, thr, min_num_inliers=20)
+        b = ransac.estimate_indexed(gpu_ctx, feat_ptr, rays, f0, f1, mp, m0, m1, thr, min_num_inliers=20)
+    finally:
+        if old is None: del os.environ["SSFM_RANSAC_SLAB_PAIRS"]
+        else: os.environ["SSFM_RANSAC_SLAB_PAIRS"] = old
+    for key in ("E", "R", "mask", "num_inliers", "scores", "iterations", "lo_runs"):
+        assert np.array_equal(a[key], b[key]), key
+    assert (a["num_inliers"] > 20).sum() >= 20
+    bad = m0.copy(); bad[5] = 10 ** 6
+    with pytest.raises(_lib.SsfmError):
+        ransac.estimate_indexed(gpu_ctx, feat_ptr, rays, f0, f1, mp, bad, m1, thr)
