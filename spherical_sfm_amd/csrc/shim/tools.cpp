@@ -91,21 +91,30 @@ int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::ve
     std::vector<const ImageMatch*> cand;
     for (auto& kv : first) if ((int)kv.second->matches.size() >= min_num_inliers && !kv.second->matches.empty()) cand.push_back(kv.second);   // :353
     if (cand.empty()) return 0;
-    std::vector<int32_t> pair_ptr(1, 0); std::vector<double> u, v;
-    for (const ImageMatch* m : cand) {
-        const Features& f0 = keyframes[m->index0].features; const Features& f1 = keyframes[m->index1].features;
-        for (auto& kv : m->matches) {                                                     // rays Kinv * (x, y, 1), :362-376
-            const Point2f p0 = f0.points[kv.first], p1 = f1.points[kv.second];
-            u.push_back((p0.x - intrinsics.centerx) * kinv); u.push_back((p0.y - intrinsics.centery) * kinv); u.push_back(1.0);
-            v.push_back((p1.x - intrinsics.centerx) * kinv); v.push_back((p1.y - intrinsics.centery) * kinv); v.push_back(1.0);
+    // per-frame feature rays Kinv * (x, y, 1) (:362-376, once per feature) + per-pair match lists: ssfm_ransac_batch_indexed gathers the ray pairs on the device
+    const int nf = (int)keyframes.size();
+    std::vector<int32_t> feat_ptr(nf + 1, 0);
+    for (int f = 0; f < nf; f++) feat_ptr[f + 1] = feat_ptr[f] + (int32_t)keyframes[f].features.points.size();
+    std::vector<double> rays((size_t)3 * std::max(1, (int)feat_ptr[nf]));
+    for (int f = 0; f < nf; f++) {
+        const Features& ft = keyframes[f].features;
+        for (size_t k = 0; k < ft.points.size(); k++) {
+            double* r = &rays[3 * ((size_t)feat_ptr[f] + k)];
+            r[0] = (ft.points[k].x - intrinsics.centerx) * kinv; r[1] = (ft.points[k].y - intrinsics.centery) * kinv; r[2] = 1.0;
         }
-        pair_ptr.push_back((int32_t)(u.size() / 3));
+    }
+    std::vector<int32_t> pair_ptr(1, 0), pf0, pf1, m0, m1;
+    for (const ImageMatch* m : cand) {
+        pf0.push_back(m->index0); pf1.push_back(m->index1);
+        for (auto& kv : m->matches) { m0.push_back((int32_t)kv.first); m1.push_back((int32_t)kv.second); }
+        pair_ptr.push_back((int32_t)m0.size());
     }
     ssfm_ransac_options O; ssfm_ransac_default_options(&O);
     O.min_num_inliers = min_num_inliers; O.inward = inward ? 1 : 0; O.final_least_squares = 1;                                 // :316-318
     const int P = (int)cand.size();
-    std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(u.size() / 3); std::vector<int32_t> nin(P);
-    if (ssfm_ransac_batch_sharded(ctx, P, pair_ptr.data(), u.data(), v.data(), sq_thresh, &O, nullptr, R.data(), mask.data(), nin.data(), nullptr, nullptr) != SSFM_OK) {   // = ssfm_ransac_batch without a communicator
+    std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(std::max<size_t>(1, m0.size())); std::vector<int32_t> nin(P);
+    if (ssfm_ransac_batch_indexed(ctx, nf, feat_ptr.data(), rays.data(), P, pf0.data(), pf1.data(), pair_ptr.data(), m0.data(), m1.data(), sq_thresh, &O, nullptr, R.data(),
+                                  mask.data(), nin.data(), nullptr, nullptr) != SSFM_OK) {
         std::cout << "error: " << ssfm_last_error(ctx) << "\n"; std::exit(1);
     }
     int loop_closure_count = 0;
