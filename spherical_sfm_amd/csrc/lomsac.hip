@@ -69,13 +69,25 @@ struct LoState {
     const double* pu; const double* pv; int n; int* listA; int* listB; unsigned* mtR; int posR; LoShared* S; LoOpts o;
 };
 
+// LeastSquares on the first wave (ransac_device.h: wave_sampson_lsq), the result handed to the other wave through LDS
+__device__ void lo_wave_lsq(const int* list, int cnt, const double* pu, const double* pv, bool inward, double* E, LoShared* S) {
+    __syncthreads();                                           // the list is complete and nobody reads S->E any more
+    if (threadIdx.x < 64) {
+        wave_sampson_lsq(list, cnt, pu, pv, inward, E);
+        if (threadIdx.x == 0) for (int k = 0; k < 9; k++) S->E[k] = E[k];
+    }
+    __syncthreads();
+    for (int k = 0; k < 9; k++) E[k] = S->E[k];
+    __syncthreads();
+}
+
 // LeastSquaresFit (ransac.h:409-420)
 __device__ void lo_lsq_fit(LoState& st, double thresh, double* model) {
     const int ni = block_inlier_list(model, st.pu, st.pv, st.n, thresh, st.listB, st.S->cnt);
     if (ni < 3) return;
     const int sz = min(st.o.min_sample_mult * 3, ni);
     block_shuffle_resize(st.listB, ni, sz, st.mtR, st.posR, st.o.fast_shuffle != 0, st.S->dr, &st.S->flag);
-    block_sampson_lsq(st.listB, sz, st.pu, st.pv, st.o.inward != 0, model, st.S->red, st.S->sh);
+    lo_wave_lsq(st.listB, sz, st.pu, st.pv, st.o.inward != 0, model, st.S);
 }
 __device__ __forceinline__ void lo_update(double sc, const double* m, double* best_sc, double* best) { if (sc < *best_sc) { *best_sc = sc; for (int k = 0; k < 9; k++) best[k] = m[k]; } }
 
@@ -277,7 +289,7 @@ k_lomsac_trace(const int* __restrict__ pair_ptr, const double* __restrict__ gu, 
             double refined[9]; for (int k = 0; k < 9; k++) refined[k] = best_model[k];
             // stats.inlier_indices is GetInliers(best_model) of the last update; LeastSquares on an empty list still rebuilds E from r
             const int ni = block_inlier_list(best_model, pu, pv, n, o.sq_thresh, listB, S.cnt);
-            block_sampson_lsq(listB, ni, pu, pv, o.inward != 0, refined, S.red, S.sh);
+            lo_wave_lsq(listB, ni, pu, pv, o.inward != 0, refined, &S);
             const double sc = block_msac_score(refined, pu, pv, n, o.sq_thresh, S.red, &S.bc);
             if (sc < best_score) { best_score = sc; for (int k = 0; k < 9; k++) best_model[k] = refined[k]; refresh_inliers(); }
         }
