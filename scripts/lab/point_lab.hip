@@ -181,6 +181,90 @@ k_point_lin_v2(const double* __restrict__ cam, const double* __restrict__ rot, c
     if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
 }
 
+template <int OBS_UNROLL, int NT>
+static __global__ void __launch_bounds__(256)
+k_point_lin_v3(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+            const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+            const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
+            int loss, double la, double radius, double min_diag, double max_diag,
+            double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ scal) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    double gmax = 0.0;
+    if (p < nP) {
+        const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+        const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
+        const double f = focal[0], sf = scale_f[0];
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, wf[3] = {0, 0, 0};
+        const int js = pt_start[p], je = pt_start[p + 1];
+        for (int jb = js; jb < je; jb += OBS_UNROLL) {
+            int cc[OBS_UNROLL]; double2 oo[OBS_UNROLL]; double tR[OBS_UNROLL][12];
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) { const int jj = min(jb + u, je - 1); cc[u] = obs_cam[jj]; oo[u] = obs_xy[jj]; }
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) {
+                // neighbouring points mostly see the same cameras: when the whole wave does, the table comes through the scalar cache
+                // (one s_load per wave instead of 64 lanes x 96 B through the vector L1)
+                const int cs = __builtin_amdgcn_readfirstlane(cc[u]);
+                if (__builtin_amdgcn_ballot_w64(cc[u] != cs) == 0) {
+                    const double* ct = cam + 6 * (size_t)cs; const double* cr = rot + 27 * (size_t)cs;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) tR[u][k] = ct[k];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) tR[u][3 + k] = cr[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) tR[u][k] = cam[6 * (size_t)cc[u] + k];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) tR[u][3 + k] = rot[27 * (size_t)cc[u] + k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OBS_UNROLL; u++) {
+                const double wgt = (jb + u < je) ? 1.0 : 0.0;
+                ObsPoint L; lin_obs_point(f, tR[u], tR[u] + 3, X, oo[u].x, oo[u].y, loss, la, L);
+                acc[0] += wgt * L.half_rho;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const double j0 = L.Jp[a][0] * sp[0] * wgt, j1 = L.Jp[a][1] * sp[1] * wgt, j2 = L.Jp[a][2] * sp[2] * wgt, jf = L.Jf[a] * sf * wgt;
+                    V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
+                    g[0] += j0 * L.r[a]; g[1] += j1 * L.r[a]; g[2] += j2 * L.r[a];
+                    wf[0] += jf * j0; wf[1] += jf * j1; wf[2] += jf * j2;
+                    acc[1] += jf * jf; acc[2] += jf * L.r[a];
+                }
+            }
+        }
+        if (sp[0] > 0.0) {
+            gmax = fmax(fabs(g[0] / sp[0]), fmax(fabs(g[1] / sp[1]), fabs(g[2] / sp[2])));
+            V[0] += fmin(fmax(V[0], min_diag), max_diag) / radius;
+            V[3] += fmin(fmax(V[3], min_diag), max_diag) / radius;
+            V[5] += fmin(fmax(V[5], min_diag), max_diag) / radius;
+        } else { V[0] = V[3] = V[5] = 1.0; }
+        double Vi[6]; sym3_inverse(V, Vi);
+        const double u0 = wf[0] * Vi[0] + wf[1] * Vi[1] + wf[2] * Vi[2];
+        const double u1 = wf[0] * Vi[1] + wf[1] * Vi[3] + wf[2] * Vi[4];
+        const double u2 = wf[0] * Vi[2] + wf[1] * Vi[4] + wf[2] * Vi[5];
+        acc[3] = u0 * wf[0] + u1 * wf[1] + u2 * wf[2];
+        acc[4] = u0 * g[0] + u1 * g[1] + u2 * g[2];
+        double* ps = Vs + 12 * (size_t)p;
+        double o[15];
+        o[0] = Vi[0] * sp[0] * sp[0]; o[1] = Vi[1] * sp[0] * sp[1]; o[2] = Vi[2] * sp[0] * sp[2];
+        o[3] = Vi[3] * sp[1] * sp[1]; o[4] = Vi[4] * sp[1] * sp[2]; o[5] = Vi[5] * sp[2] * sp[2];
+        o[6] = sp[0] * (Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2]); o[7] = sp[1] * (Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2]);
+        o[8] = sp[2] * (Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]);
+        o[9] = sp[0] * u0; o[10] = sp[1] * u1; o[11] = sp[2] * u2;
+        o[12] = g[0]; o[13] = g[1]; o[14] = g[2];
+        if (NT) { for (int k = 0; k < 12; k++) __builtin_nontemporal_store(o[k], ps + k); for (int k = 0; k < 3; k++) __builtin_nontemporal_store(o[12 + k], gp + 3 * p + k); }
+        else { for (int k = 0; k < 12; k++) ps[k] = o[k]; for (int k = 0; k < 3; k++) gp[3 * p + k] = o[12 + k]; }
+    }
+    const double t = wave_transpose_sum(acc);
+    gmax = wave_max(gmax);
+    const int slot = wave_tr_index();
+    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
+    if (slot < 5) unsafeAtomicAdd(&sl[slot == 0 ? SC_COST : slot == 1 ? SC_FJJ : slot == 2 ? SC_FJR : slot == 3 ? SC_FWW : SC_FWG], t);
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
+}
+
 static __global__ void k_empty(int* x) { if (x && threadIdx.x == 9999) x[0] = 1; }
 static __global__ void k_store_only(double* __restrict__ Vs, double* __restrict__ gp, int nP) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,6 +368,14 @@ int main(int argc, char** argv) {
         double worst = 0; for (size_t i = (size_t)Np * 6; i < got.size(); i++) { if (i >= (size_t)Np * 21 && i < (size_t)Np * 24) continue; worst = std::max(worst, std::fabs(got[i] - ref[i]) / (1e-300 + std::max(std::fabs(ref[i]), 1.0))); }
         printf("max rel difference to production %.3g ; ", worst);
         timeit(tag, v2);
+    }
+    for (int bs : {256, 64}) {
+        char tag[64]; snprintf(tag, 64, "v3 (scalar camera tables), block %d", bs);
+        auto v3 = [&]() { hipLaunchKernelGGL((k_point_lin_v3<3, 0>), dim3((Np + bs - 1) / bs), dim3(bs), 0, st, dcam, drot, dpts, dfocal, dxy, doc, dps, Np, dsp, dsf, 1, 1.0, 1e4, 1e-6, 1e32, dVs, dgp, dscal); };
+        clear(); v3(); CK(hipStreamSynchronize(st)); outputs(got);
+        double worst = 0; for (size_t i = (size_t)Np * 6; i < got.size(); i++) { if (i >= (size_t)Np * 21 && i < (size_t)Np * 24) continue; worst = std::max(worst, std::fabs(got[i] - ref[i]) / (1e-300 + std::max(std::fabs(ref[i]), 1.0))); }
+        printf("max rel difference to production %.3g ; ", worst);
+        timeit(tag, v3);
     }
     // ---- k_point_backsub: group sizes x workgroup sizes ----
     {
