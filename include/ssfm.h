@@ -261,7 +261,11 @@ int ssfm_estimator_decompose(ssfm_estimator* e, const double* E, double* R, doub
 
 /* ---- deterministic probes of the estimator's pieces (parity tests; one workgroup per task) --------------------------------------
  * ssfm_sampson_refine_probe: SphericalEstimator::LeastSquares (src/spherical_estimator.cpp:110-157) -- task t refines E_inout[t] (column-
- *   major, in/out) on the rays lists[task_ptr[t] .. task_ptr[t+1]) of the ONE pair (u, v).
+ *   major, in/out) on the rays lists[task_ptr[t] .. task_ptr[t+1]) of the ONE pair (u, v).  The fit has SIX free parameters [r1; t1]: the
+ *   reference sets r0, t0, u, v constant (:140-144) and leaves t1 free; t1 is dropped when E is rebuilt from so3exp(r1) (:156).
+ * ssfm_sampson_refine_probe_ex: the same with its trace -- variant 0 = the workgroup-cooperative fit, 1 = the one-wave fit of the batched
+ *   LO-MSAC kernel; trace [tasks*10] = [r1; t1], Levenberg-Marquardt iterations, status (0 converged / 1 iteration limit / 2 invalid
+ *   steps / 3 evaluation failure), initial cost, final cost (may be NULL).
  * ssfm_decompose_probe: decompose_spherical_essential_matrix (src/spherical_utils.cpp:16-66) + so3exp = SphericalEstimator::Decompose
  *   (src/spherical_estimator.cpp:159-164): r_out [tasks*3] angle-axis, R_out [tasks*9] column-major (either may be NULL).
  * ssfm_nonminimal_probe: SphericalEstimator::NonMinimalSolver (src/spherical_estimator.cpp:86-108) on samples of 3..9 rays.
@@ -277,6 +281,8 @@ int ssfm_minimal_solver_probe(ssfm_ctx* ctx, int32_t n, const double* u, const d
 int ssfm_sampson_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t T, const double* Es, double* errors);
 int ssfm_sampson_refine_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
                               const int32_t* lists, int32_t inward, double* E_inout);
+int ssfm_sampson_refine_probe_ex(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
+                                 const int32_t* lists, int32_t inward, int32_t variant, double* E_inout, double* trace);
 int ssfm_decompose_probe(ssfm_ctx* ctx, int32_t tasks, const double* E, int32_t inward, double* r_out, double* R_out);
 int ssfm_nonminimal_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
                           const int32_t* lists, double* E_out, int32_t* ok_out);

@@ -288,6 +288,18 @@ def sampson_least_squares(u, v, sample, E, inward=False):
     lib().oracle_sampson_least_squares(len(u), _dp(u), _dp(v), len(s), _ip(s), int(inward), _dp(Ec)); return _um(Ec)
 
 
+def sampson_least_squares_ex(u, v, sample, E, inward=False, r_only=False):
+    """-> dict(E, x = [r1; t1], iterations, termination, successful, unsuccessful, initial_cost, final_cost); r_only = the 3-parameter fit
+    that rounds 1-2 ran by mistake (t1 pinned), kept for the negative test"""
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64); s = np.ascontiguousarray(sample, np.int32)
+    Ec = _m(E); x = np.zeros(6); st = (C.c_int32 * 4)(); cs = np.zeros(2)
+    f = lib().oracle_sampson_least_squares_ex
+    f.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, C.c_int32, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int32), c_double_p]
+    f.restype = None
+    f(len(u), _dp(u), _dp(v), len(s), _ip(s), int(inward), int(r_only), _dp(Ec), _dp(x), st, _dp(cs))
+    return dict(E=_um(Ec), x=x, iterations=st[0], termination=st[1], successful=st[2], unsuccessful=st[3], initial_cost=cs[0], final_cost=cs[1])
+
+
 def ransac_pair(u, v, sq_thresh, inward=False, min_iterations=100, max_iterations=10000, seed=0, min_num_inliers=0):
     """estimate_pairwise's per-pair work.  -> dict(E, R, inliers mask, num_inliers, iterations, score)"""
     u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)

@@ -315,14 +315,21 @@ static void decompose_E(const double* E, bool inward, double r[3], double t[3]) 
     if (s1 > s2) { rm_so3ln(R1, r); std::memcpy(t, t1, 24); } else { rm_so3ln(R2, r); std::memcpy(t, t2, 24); }
 }
 
-// ---- LeastSquares (src/spherical_estimator.cpp:110-157): LM on r1 with SampsonError residuals
+// ---- LeastSquares (src/spherical_estimator.cpp:110-157): Ceres on SampsonError residuals (:23-65).
+// Parameter blocks of the problem are r0, t0, r1, t1, u[i], v[i]; the source sets u[i], v[i] (:140-141), r0 (:143) and t0 (:144)
+// constant and NOTHING ELSE: t1 (declared :118-119, initialised to t0) stays a free 3-vector.  Ceres therefore minimises over the six
+// parameters x = [r1; t1] (reduced program order = order of first appearance: r1 before t1), and the caller throws t1 away afterwards
+// (:156 rebuilds E from so3exp(r1) alone).  Rounds 1-2 of this oracle fitted r1 only, following SURVEY a12's sentence instead of the
+// source; the converged rotations of the two problems differ by 3e-5..7e-5 rad at 1/1000 noise (tests/test_ransac_lsq6_*).  The
+// 3-parameter fit is kept below as `r_only` for exactly that negative test.
 template <typename T>
-static void sampson_residual(const T r1[3], bool inward, const double* u, const double* v, T* res) {
-    // ri = 0, ti = tj = (0,0,-1) (or +1): R = Rj, t = Rj (-ti) + tj
-    T Rj[9]; AngleAxisToRotationMatrix(r1, Rj);   // column-major
+static void sampson_residual(const T rj[3], const T tj[3], bool inward, const double* u, const double* v, T* res) {
+    // :33-44 with ri = 0 (Ri = I: AngleAxisToRotationMatrix takes its first-order branch, I + [0]x), ti = (0, 0, tz):
+    // R = Rj Ri^T = Rj,  t = Rj (-Ri^T ti) + tj = -Rj ti + tj
+    T Rj[9]; AngleAxisToRotationMatrix(rj, Rj);   // column-major
     const double tz = inward ? 1.0 : -1.0;
-    T t[3] = {Rj[6] * (-tz), Rj[7] * (-tz), Rj[8] * (-tz) + tz};
-    // E = [t]x R, R(i,j) = Rj[i + 3j]
+    T t[3] = {Rj[6] * (-tz) + tj[0], Rj[7] * (-tz) + tj[1], Rj[8] * (-tz) + tj[2]};
+    // E = [t]x R, R(i,j) = Rj[i + 3j]   (:46-51)
     T E[9];
     for (int j = 0; j < 3; j++) {
         const T c0 = Rj[0 + 3 * j], c1 = Rj[1 + 3 * j], c2 = Rj[2 + 3 * j];
@@ -333,55 +340,67 @@ static void sampson_residual(const T r1[3], bool inward, const double* u, const 
     const T Eu[3] = {E[0] * u[0] + E[1] * u[1] + E[2] * u[2], E[3] * u[0] + E[4] * u[1] + E[5] * u[2], E[6] * u[0] + E[7] * u[1] + E[8] * u[2]};
     const T Etv0 = E[0] * v[0] + E[3] * v[1] + E[6] * v[2], Etv1 = E[1] * v[0] + E[4] * v[1] + E[7] * v[2];
     const T d = Eu[0] * v[0] + Eu[1] * v[1] + Eu[2] * v[2];
-    *res = (d * d) / (Eu[0] * Eu[0] + Eu[1] * Eu[1] + Etv0 * Etv0 + Etv1 * Etv1);
+    *res = (d * d) / (Eu[0] * Eu[0] + Eu[1] * Eu[1] + Etv0 * Etv0 + Etv1 * Etv1);      // :59-60
 }
+// NP = 6: x = [r1; t1] as the reference runs it.  NP = 3: x = r1 with t1 pinned to t0 (NOT the reference; negative test only).
+template <int NP>
 struct SampsonLSQ : LMProblem {
     const Rays& R; const std::vector<int>& idx; bool inward;
-    std::vector<double> res, J;   // per residual: value, 3 partials
-    SampsonLSQ(const Rays& r, const std::vector<int>& i, bool in) : R(r), idx(i), inward(in), res(i.size()), J(3 * i.size()) {}
-    int num_parameters() const override { return 3; }
+    std::vector<double> res, J;   // per residual: value, NP partials
+    SampsonLSQ(const Rays& r, const std::vector<int>& i, bool in) : R(r), idx(i), inward(in), res(i.size()), J(NP * i.size()) {}
+    int num_parameters() const override { return NP; }
+    template <typename T> void eval(const T* x, int k, T* r) const {
+        if (NP == 6) sampson_residual<T>(x, x + 3, inward, R.u + 3 * k, R.v + 3 * k, r);
+        else { const T t1[3] = {T(0.0), T(0.0), T(inward ? 1.0 : -1.0)}; sampson_residual<T>(x, t1, inward, R.u + 3 * k, R.v + 3 * k, r); }
+    }
     bool cost_only(const double* x, double* cost) override {
-        double c = 0; for (int k : idx) { double r; sampson_residual<double>(x, inward, R.u + 3 * k, R.v + 3 * k, &r); c += 0.5 * r * r; }
+        double c = 0; for (int k : idx) { double r; eval<double>(x, k, &r); c += 0.5 * r * r; }
         *cost = c; return std::isfinite(c);
     }
     bool linearize(const double* x, double* cost, double* g) override {
-        typedef Jet<3> J3; double c = 0; g[0] = g[1] = g[2] = 0;
+        typedef Jet<NP> JN; double c = 0; for (int k = 0; k < NP; k++) g[k] = 0;
         for (size_t q = 0; q < idx.size(); q++) {
-            J3 r1[3] = {J3(x[0], 0), J3(x[1], 1), J3(x[2], 2)}, r;
-            sampson_residual<J3>(r1, inward, R.u + 3 * idx[q], R.v + 3 * idx[q], &r);
-            res[q] = r.a; for (int k = 0; k < 3; k++) { J[3 * q + k] = r.v[k]; g[k] += r.v[k] * r.a; }
+            JN xs[NP], r; for (int k = 0; k < NP; k++) xs[k] = JN(x[k], k);
+            eval<JN>(xs, idx[q], &r);
+            res[q] = r.a; for (int k = 0; k < NP; k++) { J[NP * q + k] = r.v[k]; g[k] += r.v[k] * r.a; }
             c += 0.5 * r.a * r.a;
         }
         *cost = c; return std::isfinite(c);
     }
     void squared_column_norms(const double* s, double* out) override {
-        out[0] = out[1] = out[2] = 0; for (size_t q = 0; q < idx.size(); q++) for (int k = 0; k < 3; k++) out[k] += J[3 * q + k] * J[3 * q + k];
-        if (s) for (int k = 0; k < 3; k++) out[k] *= s[k] * s[k];
+        for (int k = 0; k < NP; k++) out[k] = 0;
+        for (size_t q = 0; q < idx.size(); q++) for (int k = 0; k < NP; k++) out[k] += J[NP * q + k] * J[NP * q + k];
+        if (s) for (int k = 0; k < NP; k++) out[k] *= s[k] * s[k];
     }
+    // DENSE_NORMAL_CHOLESKY (:147): lhs = Js^T Js + D^2, LL^T; a non-positive pivot is a failed linear solve (Eigen::LLT NumericalIssue)
     bool solve(const double* s, const double* D, double* y) override {
-        double A[9] = {0}, b[3] = {0};
-        for (size_t q = 0; q < idx.size(); q++) for (int a = 0; a < 3; a++) { const double ja = J[3 * q + a] * s[a]; b[a] += ja * res[q]; for (int c = 0; c < 3; c++) A[3 * a + c] += ja * J[3 * q + c] * s[c]; }
-        for (int a = 0; a < 3; a++) A[4 * a] += D[a] * D[a];
-        // Cholesky 3x3
-        double L[9] = {0};
-        for (int j = 0; j < 3; j++) { double d = A[4 * j]; for (int k = 0; k < j; k++) d -= L[3 * j + k] * L[3 * j + k]; if (!(d > 0)) return false; L[4 * j] = std::sqrt(d);
-            for (int i = j + 1; i < 3; i++) { double v = A[3 * i + j]; for (int k = 0; k < j; k++) v -= L[3 * i + k] * L[3 * j + k]; L[3 * i + j] = v / L[4 * j]; } }
-        double z[3]; for (int i = 0; i < 3; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[3 * i + k] * z[k]; z[i] = v / L[4 * i]; }
-        for (int i = 2; i >= 0; i--) { double v = z[i]; for (int k = i + 1; k < 3; k++) v -= L[3 * k + i] * y[k]; y[i] = v / L[4 * i]; }
+        double A[NP * NP] = {0}, b[NP] = {0};
+        for (size_t q = 0; q < idx.size(); q++) for (int a = 0; a < NP; a++) { const double ja = J[NP * q + a] * s[a]; b[a] += ja * res[q]; for (int c = 0; c < NP; c++) A[NP * a + c] += ja * J[NP * q + c] * s[c]; }
+        for (int a = 0; a < NP; a++) A[(NP + 1) * a] += D[a] * D[a];
+        double L[NP * NP] = {0};
+        for (int j = 0; j < NP; j++) { double d = A[(NP + 1) * j]; for (int k = 0; k < j; k++) d -= L[NP * j + k] * L[NP * j + k]; if (!(d > 0)) return false; L[(NP + 1) * j] = std::sqrt(d);
+            for (int i = j + 1; i < NP; i++) { double v = A[NP * i + j]; for (int k = 0; k < j; k++) v -= L[NP * i + k] * L[NP * j + k]; L[NP * i + j] = v / L[(NP + 1) * j]; } }
+        double z[NP]; for (int i = 0; i < NP; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[NP * i + k] * z[k]; z[i] = v / L[(NP + 1) * i]; }
+        for (int i = NP - 1; i >= 0; i--) { double v = z[i]; for (int k = i + 1; k < NP; k++) v -= L[NP * k + i] * y[k]; y[i] = v / L[(NP + 1) * i]; }
         return true;
     }
     double model_cost_change(const double* s, const double* step) override {
-        double a = 0; for (size_t q = 0; q < idx.size(); q++) { double m = 0; for (int k = 0; k < 3; k++) m += J[3 * q + k] * s[k] * step[k]; a += m * (res[q] + 0.5 * m); } return -a;
+        double a = 0; for (size_t q = 0; q < idx.size(); q++) { double m = 0; for (int k = 0; k < NP; k++) m += J[NP * q + k] * s[k] * step[k]; a += m * (res[q] + 0.5 * m); } return -a;
     }
-    void plus(const double* x, const double* d, double* o) override { for (int k = 0; k < 3; k++) o[k] = x[k] + d[k]; }
+    void plus(const double* x, const double* d, double* o) override { for (int k = 0; k < NP; k++) o[k] = x[k] + d[k]; }
 };
-static void least_squares(const Rays& R, bool inward, const std::vector<int>& sample, double* E) {
-    double r[3], t[3]; decompose_E(E, inward, r, t);
-    SampsonLSQ P(R, sample, inward);
-    LMOptions o; o.max_num_iterations = 200; o.max_num_consecutive_invalid_steps = 10;    // src/spherical_estimator.cpp:146-150
-    const LMSummary sm = lm_minimize(P, o, r);
+static bool g_lsq_r_only = false;          // negative test only: the 3-parameter fit of rounds 1-2
+static void least_squares(const Rays& R, bool inward, const std::vector<int>& sample, double* E, LMSummary* out_sm = nullptr, double* out_x = nullptr) {
+    double x[6], t[3]; decompose_E(E, inward, x, t);                                     // :115-117 r1 = r
+    x[3] = 0; x[4] = 0; x[5] = inward ? 1.0 : -1.0;                                      // :118-119 t1 = (0,0,-1) / (0,0,1)
+    LMOptions o; o.max_num_iterations = 200; o.max_num_consecutive_invalid_steps = 10;   // :146-150
+    LMSummary sm;
+    if (g_lsq_r_only) { SampsonLSQ<3> P(R, sample, inward); sm = lm_minimize(P, o, x); }
+    else { SampsonLSQ<6> P(R, sample, inward); sm = lm_minimize(P, o, x); }
     g_lsq_calls++; g_lsq_iterations += sm.iterations; g_lsq_points += (long long)sample.size();
-    double Rm[9]; rm_so3exp(r, Rm); make_E(Rm, inward, E);
+    if (out_sm) *out_sm = sm;
+    if (out_x) std::memcpy(out_x, x, 48);
+    double Rm[9]; rm_so3exp(x, Rm); make_E(Rm, inward, E);                               // :156 t1 is discarded
 }
 
 typedef std::array<double, 9> EMat;      // row-major
@@ -429,6 +448,18 @@ extern "C" void oracle_make_spherical_essential_matrix(const double R_cm[9], int
 extern "C" void oracle_decompose_spherical_essential_matrix(const double E_cm[9], int32_t inward, double r[3], double t[3]) { double E[9]; cm_to_rm(E_cm, E); decompose_E(E, inward != 0, r, t); }
 extern "C" void oracle_sampson_least_squares(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, int32_t inward, double E_cm[9]) {
     Rays R{n, u, v}; std::vector<int> s(sample, sample + ns); double E[9]; cm_to_rm(E_cm, E); least_squares(R, inward != 0, s, E); rm_to_cm(E, E_cm);
+}
+// the same fit with its trace exposed: x_out = [r1; t1] at the end, stats = {iterations, termination, successful, unsuccessful},
+// costs = {initial, final}.  r_only != 0 runs the 3-parameter fit of rounds 1-2 (NOT the reference; the negative test of tests/).
+extern "C" void oracle_sampson_least_squares_ex(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, int32_t inward, int32_t r_only,
+                                                double E_cm[9], double x_out[6], int32_t stats[4], double costs[2]) {
+    Rays R{n, u, v}; std::vector<int> s(sample, sample + ns); double E[9]; cm_to_rm(E_cm, E);
+    LMSummary sm; g_lsq_r_only = r_only != 0;
+    least_squares(R, inward != 0, s, E, &sm, x_out);
+    g_lsq_r_only = false;
+    rm_to_cm(E, E_cm);
+    if (stats) { stats[0] = sm.iterations; stats[1] = sm.termination; stats[2] = sm.num_successful_steps; stats[3] = sm.num_unsuccessful_steps; }
+    if (costs) { costs[0] = sm.initial_cost; costs[1] = sm.final_cost; }
 }
 // per-pair logic of estimate_pairwise (examples/spherical_sfm_tools.cpp:314-318,378-419): options, EstimateModel, inlier mask, R
 extern "C" int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inward, double sq_thresh, uint32_t min_it, uint32_t max_it,

@@ -106,6 +106,10 @@ int oracle_spherical_solver_poly(int32_t n, const double* u, const double* v, in
 void oracle_make_spherical_essential_matrix(const double R[9], int32_t inward, double E[9]);
 void oracle_decompose_spherical_essential_matrix(const double E[9], int32_t inward, double r[3], double t[3]);
 void oracle_sampson_least_squares(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, int32_t inward, double E[9]);
+/* same, trace exposed: x_out = [r1; t1] (the reference leaves t1 FREE, src/spherical_estimator.cpp:140-144), stats = {iterations, termination,
+ * successful, unsuccessful steps}, costs = {initial, final}; r_only != 0: the 3-parameter fit of rounds 1-2 (negative test only) */
+void oracle_sampson_least_squares_ex(int32_t n, const double* u, const double* v, int32_t num_sample, const int32_t* sample, int32_t inward, int32_t r_only,
+                                     double E[9], double x_out[6], int32_t stats[4], double costs[2]);
 int oracle_ransac_pair(int32_t n, const double* u, const double* v, int32_t inward, double squared_inlier_threshold, uint32_t min_iterations,
                        uint32_t max_iterations, uint32_t seed, int32_t min_num_inliers, double E[9], double R[9], uint8_t* inlier_mask,
                        uint32_t* iterations, double* best_score);

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include "ransac_device.h"
+#include "sampson_lsq.h"
 
 namespace ssfm {
 
@@ -315,21 +316,25 @@ k_lomsac_trace(const int* __restrict__ pair_ptr, const double* __restrict__ gu, 
 
 // ---- deterministic probes of the pieces (tests/test_ransac_probes_gpu.py) -------------------------------------------------------
 // what: 0 = LeastSquares(list, E) -> E;  1 = Decompose(E) -> r (angle-axis) ;  2 = NonMinimalSolver(list) -> E (flag in out[9]);
-// one workgroup per task, rays of ONE pair in global memory.
+// 3 = LeastSquares through the one-wave variant; one workgroup per task, rays of ONE pair in global memory.  EST_OUT doubles per task.
+constexpr int EST_OUT = 20;
 __global__ void __launch_bounds__(LO_T)
 k_estimator_probe(int what, int n, const double* __restrict__ u, const double* __restrict__ v, const int* __restrict__ task_ptr,
-                  const int* __restrict__ lists, const double* __restrict__ Ein /* [tasks*9] row-major */, int inward, double* __restrict__ out /* [tasks*12] */) {
-    __shared__ double red[10 * (LO_T / 64)]; __shared__ double sh[64];
+                  const int* __restrict__ lists, const double* __restrict__ Ein /* [tasks*9] row-major */, int inward, double* __restrict__ out /* [tasks*EST_OUT] */) {
+    __shared__ double red[28 * (LO_T / 64)]; __shared__ double sh[64];
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = blockIdx.x, l0 = task_ptr[t], cnt = task_ptr[t + 1] - l0;
     int* list = reinterpret_cast<int*>(lds);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) list[i] = lists[l0 + i];
     __syncthreads();
     double E[9]; for (int k = 0; k < 9; k++) E[k] = Ein[9 * (size_t)t + k];
-    double* o = out + 12 * (size_t)t;
-    if (what == 0) {
-        block_sampson_lsq(list, cnt, u, v, inward != 0, E, red, sh);
-        if (threadIdx.x == 0) { for (int k = 0; k < 9; k++) o[k] = E[k]; o[9] = 1.0; }
+    double* o = out + EST_OUT * (size_t)t;
+    if (what == 0 || what == 3) {
+        // LeastSquares: 0 = the workgroup-cooperative fit, 3 = the one-wave fit k_lomsac_trace runs; o[10..19] = [r1; t1], iterations, status, costs
+        double tr[10];
+        if (what == 0) block_sampson_lsq(list, cnt, u, v, inward != 0, E, red, sh, tr);
+        else if (threadIdx.x < 64) wave_sampson_lsq(list, cnt, u, v, inward != 0, E, tr);
+        if (threadIdx.x == 0) { for (int k = 0; k < 9; k++) o[k] = E[k]; o[9] = 1.0; for (int k = 0; k < 10; k++) o[10 + k] = tr[k]; }
     } else if (what == 1) {
         if (threadIdx.x == 0) { double r[3]; decompose_E_dev(E, inward != 0, r); o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; so3exp(r, o + 3); }
     } else {
@@ -441,11 +446,11 @@ static int estimator_probe(ssfm_ctx* ctx, int what, int32_t n, const double* u, 
     int rc = SSFM_OK;
     auto body = [&]() -> int {
         SSFM_HIP_CHECK(ctx, upload(du, hu, st)); SSFM_HIP_CHECK(ctx, upload(dv, hv, st)); SSFM_HIP_CHECK(ctx, upload(dE, hE, st));
-        SSFM_HIP_CHECK(ctx, upload(dp, hp, st)); SSFM_HIP_CHECK(ctx, upload(dl, hl, st)); SSFM_HIP_CHECK(ctx, dout.alloc((size_t)12 * tasks));
+        SSFM_HIP_CHECK(ctx, upload(dp, hp, st)); SSFM_HIP_CHECK(ctx, upload(dl, hl, st)); SSFM_HIP_CHECK(ctx, dout.alloc((size_t)EST_OUT * tasks));
         const size_t lds = (size_t)maxc * 4 + 16;
         if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_estimator_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_estimator_probe, dim3(tasks), dim3(LO_T), lds, st, what, n, du.p, dv.p, dp.p, dl.p, dE.p, inward, dout.p);
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(out12, dout.p, (size_t)12 * tasks * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(out12, dout.p, (size_t)EST_OUT * tasks * sizeof(double), hipMemcpyDeviceToHost, st));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         return SSFM_OK;
     };
@@ -456,20 +461,35 @@ static int estimator_probe(ssfm_ctx* ctx, int what, int32_t n, const double* u, 
 
 extern "C" int ssfm_sampson_refine_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
                                          const int32_t* lists, int32_t inward, double* E_inout) {
-    std::vector<double> out((size_t)12 * std::max(tasks, 1));
+    std::vector<double> out((size_t)EST_OUT * std::max(tasks, 1));
     const int rc = estimator_probe(ctx, 0, n, u, v, tasks, task_ptr, lists, E_inout, inward, out.data());
     if (rc) return rc;
-    for (int t = 0; t < tasks; t++) rm_to_cm(&out[12 * (size_t)t], E_inout + 9 * (size_t)t);
+    for (int t = 0; t < tasks; t++) rm_to_cm(&out[EST_OUT * (size_t)t], E_inout + 9 * (size_t)t);
+    return SSFM_OK;
+}
+// the same fit with its trace: variant 0 = workgroup-cooperative, 1 = the one-wave form k_lomsac_trace runs.  trace: [tasks*10] =
+// [r1; t1] at the end (t1 is free in the reference's problem, src/spherical_estimator.cpp:140-144), LM iterations, status
+// (0 converged, 1 iteration limit, 2 invalid steps, 3 evaluation failure), initial cost, final cost
+extern "C" int ssfm_sampson_refine_probe_ex(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
+                                            const int32_t* lists, int32_t inward, int32_t variant, double* E_inout, double* trace) {
+    if (variant != 0 && variant != 1) return fail(ctx, SSFM_ERR_INVALID, "ssfm_sampson_refine_probe_ex: variant is 0 or 1");
+    std::vector<double> out((size_t)EST_OUT * std::max(tasks, 1));
+    const int rc = estimator_probe(ctx, variant ? 3 : 0, n, u, v, tasks, task_ptr, lists, E_inout, inward, out.data());
+    if (rc) return rc;
+    for (int t = 0; t < tasks; t++) {
+        rm_to_cm(&out[EST_OUT * (size_t)t], E_inout + 9 * (size_t)t);
+        if (trace) for (int k = 0; k < 10; k++) trace[10 * (size_t)t + k] = out[EST_OUT * (size_t)t + 10 + k];
+    }
     return SSFM_OK;
 }
 extern "C" int ssfm_decompose_probe(ssfm_ctx* ctx, int32_t tasks, const double* E, int32_t inward, double* r_out, double* R_out) {
     if (!E || tasks <= 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_decompose_probe: bad arguments");
-    std::vector<double> out((size_t)12 * tasks); std::vector<int> ptr(tasks + 1, 0), lists(1, 0);
+    std::vector<double> out((size_t)EST_OUT * tasks); std::vector<int> ptr(tasks + 1, 0), lists(1, 0);
     const double dummy[3] = {0, 0, 1};
     const int rc = estimator_probe(ctx, 1, 1, dummy, dummy, tasks, ptr.data(), lists.data(), E, inward, out.data());
     if (rc) return rc;
     for (int t = 0; t < tasks; t++) {
-        const double* o = &out[12 * (size_t)t];
+        const double* o = &out[EST_OUT * (size_t)t];
         if (r_out) { r_out[3 * t] = o[0]; r_out[3 * t + 1] = o[1]; r_out[3 * t + 2] = o[2]; }
         if (R_out) rm_to_cm(o + 3, R_out + 9 * (size_t)t);
     }
@@ -477,11 +497,11 @@ extern "C" int ssfm_decompose_probe(ssfm_ctx* ctx, int32_t tasks, const double* 
 }
 extern "C" int ssfm_nonminimal_probe(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t tasks, const int32_t* task_ptr,
                                      const int32_t* lists, double* E_out, int32_t* ok_out) {
-    std::vector<double> out((size_t)12 * std::max(tasks, 1));
+    std::vector<double> out((size_t)EST_OUT * std::max(tasks, 1));
     if (task_ptr) for (int t = 0; t < tasks; t++) { const int c = task_ptr[t + 1] - task_ptr[t]; if (c < 3 || c > 9) return fail(ctx, SSFM_ERR_INVALID, "ssfm_nonminimal_probe: samples hold 3..9 rays"); }
     const int rc = estimator_probe(ctx, 2, n, u, v, tasks, task_ptr, lists, nullptr, 0, out.data());
     if (rc) return rc;
-    for (int t = 0; t < tasks; t++) { if (E_out) rm_to_cm(&out[12 * (size_t)t], E_out + 9 * (size_t)t); if (ok_out) ok_out[t] = (int)out[12 * (size_t)t + 9]; }
+    for (int t = 0; t < tasks; t++) { if (E_out) rm_to_cm(&out[EST_OUT * (size_t)t], E_out + 9 * (size_t)t); if (ok_out) ok_out[t] = (int)out[EST_OUT * (size_t)t + 9]; }
     return SSFM_OK;
 }
 
@@ -582,7 +602,7 @@ extern "C" int ssfm_sampson_probe(ssfm_ctx* ctx, int32_t n, const double* u, con
 struct ssfm_estimator {
     ssfm_ctx* ctx = nullptr; int n = 0, poly = 0, inward = 0;
     DevBuf<double> u, v, E, out; DevBuf<int> idx, cnt;
-    double* h_d = nullptr; int* h_i = nullptr;          // pinned staging: [max(n, 48) doubles], [n + 4 ints]
+    double* h_d = nullptr; int* h_i = nullptr;          // pinned staging: [max(n, 48) doubles], [max(n, 9) + 4 ints] (a sample may repeat indices: up to 9 entries on a pair with n < 9)
 };
 extern "C" int ssfm_estimator_create(ssfm_ctx* ctx, int32_t n, const double* u, const double* v, int32_t use_poly_solver, int32_t inward, ssfm_estimator** out) {
     if (!ctx || n < 0 || (n > 0 && (!u || !v)) || !out) return fail(ctx, SSFM_ERR_INVALID, "ssfm_estimator_create: bad arguments");
@@ -591,9 +611,9 @@ extern "C" int ssfm_estimator_create(ssfm_ctx* ctx, int32_t n, const double* u, 
     auto body = [&]() -> int {
         std::vector<double> hu(u, u + (size_t)3 * n), hv(v, v + (size_t)3 * n); if (hu.empty()) { hu.assign(3, 0.0); hv.assign(3, 0.0); }
         SSFM_HIP_CHECK(ctx, upload(e->u, hu, ctx->stream)); SSFM_HIP_CHECK(ctx, upload(e->v, hv, ctx->stream));
-        SSFM_HIP_CHECK(ctx, e->E.alloc(36)); SSFM_HIP_CHECK(ctx, e->out.alloc(std::max(n, 48))); SSFM_HIP_CHECK(ctx, e->idx.alloc(n + 4)); SSFM_HIP_CHECK(ctx, e->cnt.alloc(4));
+        SSFM_HIP_CHECK(ctx, e->E.alloc(36)); SSFM_HIP_CHECK(ctx, e->out.alloc(std::max(n, 48))); SSFM_HIP_CHECK(ctx, e->idx.alloc(std::max(n, 9) + 4)); SSFM_HIP_CHECK(ctx, e->cnt.alloc(4));
         SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&e->h_d, (size_t)std::max(n, 48) * sizeof(double), hipHostMallocDefault));
-        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&e->h_i, (size_t)(n + 4) * sizeof(int), hipHostMallocDefault));
+        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&e->h_i, (size_t)(std::max(n, 9) + 4) * sizeof(int), hipHostMallocDefault));
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return SSFM_OK;
     };
@@ -645,14 +665,14 @@ static int est_task(ssfm_estimator* e, int what, const int32_t* sample, int32_t 
     const size_t lds = (size_t)std::max(m, 1) * 4 + 16;
     if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_estimator_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_estimator_probe, dim3(1), dim3(LO_T), lds, st, what, e->n, e->u.p, e->v.p, e->cnt.p, e->idx.p, e->E.p, e->inward, e->out.p);
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(e->h_d + 16, e->out.p, 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(e->h_d + 16, e->out.p, EST_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    for (int k = 0; k < 12; k++) out12[k] = e->h_d[16 + k];
+    for (int k = 0; k < EST_OUT; k++) out12[k] = e->h_d[16 + k];
     return SSFM_OK;
 }
 extern "C" int ssfm_estimator_non_minimal_solver(ssfm_estimator* e, const int32_t* sample, int32_t sample_size, double* E, int32_t* ok) {
     { const int rc = est_check_sample(e, sample, sample_size, 3, 9, "ssfm_estimator_non_minimal_solver"); if (rc) return rc; }
-    double o[12]; const int rc = est_task(e, 2, sample, sample_size, nullptr, o); if (rc) return rc;
+    double o[EST_OUT]; const int rc = est_task(e, 2, sample, sample_size, nullptr, o); if (rc) return rc;
     if (ok) *ok = (int)o[9];
     if (o[9] != 0.0) rm_to_cm(o, E);
     return SSFM_OK;
@@ -660,13 +680,13 @@ extern "C" int ssfm_estimator_non_minimal_solver(ssfm_estimator* e, const int32_
 extern "C" int ssfm_estimator_least_squares(ssfm_estimator* e, const int32_t* sample, int32_t sample_size, double* E) {
     { const int rc = est_check_sample(e, sample, sample_size, 0, e ? e->n : 0, "ssfm_estimator_least_squares"); if (rc) return rc; }
     if (!E) return fail(e->ctx, SSFM_ERR_INVALID, "ssfm_estimator_least_squares: E is null");
-    double o[12]; const int rc = est_task(e, 0, sample, sample_size, E, o); if (rc) return rc;
+    double o[EST_OUT]; const int rc = est_task(e, 0, sample, sample_size, E, o); if (rc) return rc;
     rm_to_cm(o, E);
     return SSFM_OK;
 }
 extern "C" int ssfm_estimator_decompose(ssfm_estimator* e, const double* E, double* R, double* t) {
     if (!e || !E) return fail(e ? e->ctx : nullptr, SSFM_ERR_INVALID, "ssfm_estimator_decompose: bad arguments");
-    const int32_t none = 0; double o[12]; const int rc = est_task(e, 1, &none, 0, E, o); if (rc) return rc;
+    const int32_t none = 0; double o[EST_OUT]; const int rc = est_task(e, 1, &none, 0, E, o); if (rc) return rc;
     if (R) rm_to_cm(o + 3, R);
     if (t) { const double s = e->inward ? -1.0 : 1.0; t[0] = s * o[3 + 2]; t[1] = s * o[3 + 5]; t[2] = s * (o[3 + 8] - 1.0); }   // src/spherical_utils.cpp:43-49: t = R.col(2) - e_z, negated if inward
     return SSFM_OK;

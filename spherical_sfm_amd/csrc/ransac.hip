@@ -19,6 +19,7 @@
 #include <atomic>
 #include <thread>
 #include "ransac_device.h"
+#include "sampson_lsq.h"
 
 namespace ssfm {
 
@@ -88,7 +89,7 @@ k_ransac_refine(const int* __restrict__ pair_ptr, const double* __restrict__ u, 
                 int min_num_inliers, int do_lsq, int* __restrict__ glists /* [total] scratch: the inlier list of every pair */,
                 double* __restrict__ bestE, double* __restrict__ bestScore, double* __restrict__ outR,
                 unsigned char* __restrict__ inlier_mask, int* __restrict__ num_inliers) {
-    __shared__ double red[10 * 4];
+    __shared__ double red[28 * 4];
     __shared__ double sh[64];
     __shared__ double bc;
     __shared__ int s_cnt[4];

@@ -438,299 +438,7 @@ __device__ double block_msac_score(const double* E, const double* pu, const doub
     return r;
 }
 
-// E(r) = [t]x R(r), t = -R(r) t0 + t0, t0 = (0, 0, tz) -- the essential matrix SampsonError builds from (r0 = 0, t0, r1 = r, t1 = t0)
-// (src/spherical_estimator.cpp:23-65) -- and, when dE != nullptr, its three partial derivatives dE[k] = dE / dr_k (row-major 3x3 each).
-// R is Ceres' AngleAxisToRotationMatrix (theta^2 > eps: Rodrigues, else I + [r]x), differentiated in closed form:
-//   R = c I + (1 - c) w w^T + s [w]x,  dw/dr_k = (e_k - w w_k) / theta,  dc/dr_k = -s w_k,  ds/dr_k = c w_k.
-// The same numbers the reference's Jets carry, without running every ray through the dual-number trigonometry.
-__device__ void sampson_E_and_derivatives(const double* r, double tz, double* E, double* dE /* [27] or null */) {
-    double R[9], Rk[3][9];
-    const double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-    if (t2 > DBL_EPSILON) {
-        const double th = sqrt(t2), w[3] = {r[0] / th, r[1] / th, r[2] / th};
-        const double c = cos(th), s = sin(th), omc = 1.0 - c;
-        R[0] = c + w[0] * w[0] * omc;        R[1] = w[0] * w[1] * omc - w[2] * s; R[2] = w[1] * s + w[0] * w[2] * omc;
-        R[3] = w[2] * s + w[0] * w[1] * omc; R[4] = c + w[1] * w[1] * omc;        R[5] = w[1] * w[2] * omc - w[0] * s;
-        R[6] = w[0] * w[2] * omc - w[1] * s; R[7] = w[0] * s + w[1] * w[2] * omc; R[8] = c + w[2] * w[2] * omc;
-        if (dE) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                double dw[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) dw[i] = (((i == k) ? 1.0 : 0.0) - w[i] * w[k]) / th;
-                const double dc = -s * w[k], ds = c * w[k];              // d cos / d r_k, d sin / d r_k;  d(1 - c) = -dc
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++)
-                        Rk[k][3 * i + j] = ((i == j) ? dc : 0.0) - dc * w[i] * w[j] + omc * (dw[i] * w[j] + w[i] * dw[j]);
-                // + d(s [w]x): [w]x = [0 -w2 w1; w2 0 -w0; -w1 w0 0]
-                Rk[k][1] += -(ds * w[2] + s * dw[2]); Rk[k][2] += ds * w[1] + s * dw[1];
-                Rk[k][3] += ds * w[2] + s * dw[2];    Rk[k][5] += -(ds * w[0] + s * dw[0]);
-                Rk[k][6] += -(ds * w[1] + s * dw[1]); Rk[k][7] += ds * w[0] + s * dw[0];
-            }
-        }
-    } else {
-        R[0] = 1; R[1] = -r[2]; R[2] = r[1]; R[3] = r[2]; R[4] = 1; R[5] = -r[0]; R[6] = -r[1]; R[7] = r[0]; R[8] = 1;
-        if (dE) {
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int i = 0; i < 9; i++) Rk[k][i] = 0.0;
-            Rk[0][5] = -1; Rk[0][7] = 1; Rk[1][2] = 1; Rk[1][6] = -1; Rk[2][1] = -1; Rk[2][3] = 1;
-        }
-    }
-    const double t[3] = {R[2] * (-tz), R[5] * (-tz), R[8] * (-tz) + tz};
-#pragma unroll
-    for (int j = 0; j < 3; j++) { E[j] = t[1] * R[6 + j] - t[2] * R[3 + j]; E[3 + j] = t[2] * R[j] - t[0] * R[6 + j]; E[6 + j] = t[0] * R[3 + j] - t[1] * R[j]; }
-    if (dE) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double* Q = Rk[k]; double* D = dE + 9 * k;
-            const double tk[3] = {Q[2] * (-tz), Q[5] * (-tz), Q[8] * (-tz)};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                D[j] = tk[1] * R[6 + j] - tk[2] * R[3 + j] + t[1] * Q[6 + j] - t[2] * Q[3 + j];
-                D[3 + j] = tk[2] * R[j] - tk[0] * R[6 + j] + t[2] * Q[j] - t[0] * Q[6 + j];
-                D[6 + j] = tk[0] * R[3 + j] - tk[1] * R[j] + t[0] * Q[3 + j] - t[1] * Q[j];
-            }
-        }
-    }
-}
-
-// SphericalEstimator::LeastSquares (src/spherical_estimator.cpp:110-157) on the rays list[0..cnt): decompose E -> r, Levenberg-
-// Marquardt on the Sampson residuals with only r free (Ceres 2.2 TrustRegionMinimizer rules as restated in oracle/lm.hpp:
-// Jacobi scaling from the iteration-0 Jacobian, 200 iterations, 10 consecutive invalid steps, default tolerances, DENSE_NORMAL_CHOLESKY
-// on the 3x3 system), E <- make_spherical_essential_matrix(so3exp(r)).  E: registers, identical in every thread, in/out.
-// The essential matrix of the current rotation and its three derivatives are the same for every ray: one thread evaluates them
-// (sampson_E_and_derivatives) and publishes 36 numbers through LDS; a ray then costs ~120 multiply-adds for its residual and gradient
-// instead of a pass through dual-number trigonometry.
-// red: LDS double[10 * blockDim/64]; sh: LDS double[64].
-__device__ void block_sampson_lsq(const int* list, int cnt, const double* pu, const double* pv, bool inward, double* E, double* red, double* sh) {
-    const double tz = inward ? 1.0 : -1.0;
-    double* sE = sh + 16; double* sdE = sh + 25;
-    if (threadIdx.x == 0) { double r[3]; decompose_E_dev(E, inward, r); sh[0] = r[0]; sh[1] = r[1]; sh[2] = r[2]; sampson_E_and_derivatives(r, tz, sE, sdE); }
-    __syncthreads();
-    double x[3] = {sh[0], sh[1], sh[2]};
-    double radius = 1e4, decrease = 2.0, scale[3] = {1, 1, 1}, x_cost = 0, x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    double A[6], g[3];
-    bool finite_ok = true;
-    // sums over the rays at the point whose E / dE are in LDS; every lane ends up with the same sums
-    auto linearize = [&]() {
-        double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // JtJ (00 01 02 11 12 22), Jtr (3), cost
-        for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
-            const int i = list[q];
-            const double u0 = pu[3 * i], u1 = pu[3 * i + 1], u2 = pu[3 * i + 2], v0 = pv[3 * i], v1 = pv[3 * i + 1], v2 = pv[3 * i + 2];
-            const double e0 = sE[0] * u0 + sE[1] * u1 + sE[2] * u2, e1 = sE[3] * u0 + sE[4] * u1 + sE[5] * u2, e2 = sE[6] * u0 + sE[7] * u1 + sE[8] * u2;
-            const double f0 = sE[0] * v0 + sE[3] * v1 + sE[6] * v2, f1 = sE[1] * v0 + sE[4] * v1 + sE[7] * v2;
-            const double d = e0 * v0 + e1 * v1 + e2 * v2, den = e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1;
-            const double res = (d * d) / den;
-            double j[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double* D = sdE + 9 * k;
-                const double a0 = D[0] * u0 + D[1] * u1 + D[2] * u2, a1 = D[3] * u0 + D[4] * u1 + D[5] * u2, a2 = D[6] * u0 + D[7] * u1 + D[8] * u2;
-                const double b0 = D[0] * v0 + D[3] * v1 + D[6] * v2, b1 = D[1] * v0 + D[4] * v1 + D[7] * v2;
-                const double dk = a0 * v0 + a1 * v1 + a2 * v2, denk = 2.0 * (e0 * a0 + e1 * a1 + f0 * b0 + f1 * b1);
-                j[k] = ((2.0 * d * dk - res * denk) / den) * scale[k];
-            }
-            acc[0] += j[0] * j[0]; acc[1] += j[0] * j[1]; acc[2] += j[0] * j[2]; acc[3] += j[1] * j[1]; acc[4] += j[1] * j[2]; acc[5] += j[2] * j[2];
-            acc[6] += j[0] * res; acc[7] += j[1] * res; acc[8] += j[2] * res; acc[9] += 0.5 * res * res;
-        }
-        block_sum<10>(acc, red);
-        if (threadIdx.x == 0) for (int k = 0; k < 10; k++) sh[k] = acc[k];
-        __syncthreads();
-        for (int k = 0; k < 6; k++) A[k] = sh[k];
-        g[0] = sh[6]; g[1] = sh[7]; g[2] = sh[8]; x_cost = sh[9];
-        __syncthreads();
-        finite_ok = isfinite(x_cost);
-    };
-    linearize();
-    if (finite_ok) {
-        // Jacobi scaling from the iteration-0 Jacobian
-        scale[0] = 1.0 / (1.0 + sqrt(A[0])); scale[1] = 1.0 / (1.0 + sqrt(A[3])); scale[2] = 1.0 / (1.0 + sqrt(A[5]));
-        A[0] *= scale[0] * scale[0]; A[1] *= scale[0] * scale[1]; A[2] *= scale[0] * scale[2]; A[3] *= scale[1] * scale[1]; A[4] *= scale[1] * scale[2]; A[5] *= scale[2] * scale[2];
-        g[0] *= scale[0]; g[1] *= scale[1]; g[2] *= scale[2];
-        int iteration = 0, invalid = 0; bool last_ok = true;
-        while (true) {
-            if (iteration >= 200) break;                                              // src/spherical_estimator.cpp:148
-            const double gmax = fmax(fabs(g[0] / scale[0]), fmax(fabs(g[1] / scale[1]), fabs(g[2] / scale[2])));
-            if (last_ok && gmax <= 1e-10) break;
-            if (radius <= 1e-32) break;
-            iteration++;
-            double Ad[6] = {A[0], A[1], A[2], A[3], A[4], A[5]};
-            Ad[0] += fmin(fmax(A[0], 1e-6), 1e32) / radius; Ad[3] += fmin(fmax(A[3], 1e-6), 1e32) / radius; Ad[5] += fmin(fmax(A[5], 1e-6), 1e32) / radius;
-            // Cholesky of the damped 3x3 system; a non-positive pivot is a failed linear solve (an invalid step)
-            const double l00 = sqrt(Ad[0]), l10 = Ad[1] / l00, l20 = Ad[2] / l00;
-            const double d1 = Ad[3] - l10 * l10, l11 = sqrt(d1), l21 = (Ad[4] - l20 * l10) / l11;
-            const double d2 = Ad[5] - l20 * l20 - l21 * l21, l22 = sqrt(d2);
-            const bool chol_ok = (Ad[0] > 0.0) && (d1 > 0.0) && (d2 > 0.0);
-            const double z0 = g[0] / l00, z1 = (g[1] - l10 * z0) / l11, z2 = (g[2] - l20 * z0 - l21 * z1) / l22;
-            const double y2 = z2 / l22, y1 = (z1 - l21 * y2) / l11, y0 = (z0 - l10 * y1 - l20 * y2) / l00;
-            const double st[3] = {-y0, -y1, -y2};
-            const double sAs = A[0] * st[0] * st[0] + A[3] * st[1] * st[1] + A[5] * st[2] * st[2] + 2 * (A[1] * st[0] * st[1] + A[2] * st[0] * st[2] + A[4] * st[1] * st[2]);
-            const double model = -((g[0] * st[0] + g[1] * st[1] + g[2] * st[2]) + 0.5 * sAs);   // -(Js)^T (r + Js/2)
-            if (!chol_ok || !(model > 0.0) || !isfinite(model)) {
-                if (++invalid >= 10) break;                                           // max_num_consecutive_invalid_steps, :149
-                radius /= decrease; decrease *= 2.0; last_ok = false; continue;
-            }
-            invalid = 0;
-            const double xc[3] = {x[0] + st[0] * scale[0], x[1] + st[1] * scale[1], x[2] + st[2] * scale[2]};
-            // candidate: its E (and, in case it is accepted, the derivatives) into LDS; the accepted point's copy stays in sh[52..60] for a rejected step
-            if (threadIdx.x == 0) { for (int k = 0; k < 9; k++) sh[52 + k] = sE[k]; sampson_E_and_derivatives(xc, tz, sE, nullptr); }
-            __syncthreads();
-            double c[1] = {0.0};
-            for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
-                const int i = list[q];
-                const double r = sampson_err(sE, pu + 3 * i, pv + 3 * i); c[0] += 0.5 * r * r;
-            }
-            block_sum<1>(c, red);
-            if (threadIdx.x == 0) sh[10] = c[0];
-            __syncthreads();
-            double cand = sh[10];
-            __syncthreads();
-            if (!isfinite(cand)) cand = 1.79769313486231570815e308;
-            const double step_norm = sqrt((xc[0] - x[0]) * (xc[0] - x[0]) + (xc[1] - x[1]) * (xc[1] - x[1]) + (xc[2] - x[2]) * (xc[2] - x[2]));
-            const double change = x_cost - cand;
-            const double rho = (cand >= 1.79769313486231570815e308) ? -1.79769313486231570815e308 : change / model;
-            const bool stop = (step_norm <= 1e-8 * (x_norm + 1e-8)) || (fabs(change) <= 1e-6 * x_cost);
-            if (!stop && rho > 1e-3) {
-                const double xp[3] = {x[0], x[1], x[2]};
-                x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
-                if (threadIdx.x == 0) sampson_E_and_derivatives(x, tz, sE, sdE);
-                __syncthreads();
-                linearize();                      // scale[] is applied inside: the sums come back Jacobi-scaled
-                if (!finite_ok) { x[0] = xp[0]; x[1] = xp[1]; x[2] = xp[2]; break; }      // evaluation failure: the last good x stands
-                x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-                radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3))); decrease = 2.0; last_ok = true;
-            } else {
-                // the derivatives in LDS still belong to x (only E was overwritten): restore E for the next candidate's bookkeeping
-                if (threadIdx.x == 0) for (int k = 0; k < 9; k++) sE[k] = sh[52 + k];
-                __syncthreads();
-                if (stop) break;
-                radius /= decrease; decrease *= 2.0; last_ok = false;
-            }
-        }
-    }
-    double Rm[9]; so3exp(x, Rm); make_E_dev(Rm, inward, E);
-}
-
-// The same minimisation on ONE wave, without a workgroup barrier and without LDS: every lane evaluates E(r) / dE itself (the same instructions
-// as one lane doing it for all), rays are dealt 64 at a time, the ten sums meet in one transposing wave reduction and are read back by
-// v_readlane.  The cooperative version spends a Levenberg-Marquardt iteration mostly in its ~10 workgroup barriers and in the single-lane
-// sections between them (21 rays on 128 threads); k_lomsac_trace calls this one on its first wave and hands E to the other wave through
-// LDS afterwards (profiles/r02_notes.md: local optimisation + final least squares were 0.4 of a pair's 1.2 us).  All 64 lanes must call it.
-__device__ __forceinline__ double wave_value_of(double v, int holder) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), holder), __builtin_amdgcn_readlane(__double2loint(v), holder));
-}
-template <int N>
-__device__ __forceinline__ void wave_allsum(double (&v)[N]) {      // every lane leaves with all N wave-wide sums
-    const double t = wave_transpose_sum(v);                        // sum i sits in the lane whose six bits reversed are i
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int holder = ((i & 1) << 5) | ((i & 2) << 3) | ((i & 4) << 1) | ((i & 8) >> 1) | ((i & 16) >> 3) | ((i & 32) >> 5);
-        v[i] = wave_value_of(t, holder);
-    }
-}
-__device__ void wave_sampson_lsq(const int* list, int cnt, const double* pu, const double* pv, bool inward, double* E) {
-    const double tz = inward ? 1.0 : -1.0;
-    const int lane = threadIdx.x & 63;
-    double sE[9], sdE[27], sEkeep[9];
-    double x[3]; decompose_E_dev(E, inward, x); sampson_E_and_derivatives(x, tz, sE, sdE);
-    double radius = 1e4, decrease = 2.0, scale[3] = {1, 1, 1}, x_cost = 0, x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    double A[6], g[3];
-    bool finite_ok = true;
-    // sums over the rays at the point whose E / dE are in LDS; every lane ends up with the same sums
-    auto linearize = [&]() {
-        double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // JtJ (00 01 02 11 12 22), Jtr (3), cost
-        for (int q = lane; q < cnt; q += 64) {
-            const int i = list[q];
-            const double u0 = pu[3 * i], u1 = pu[3 * i + 1], u2 = pu[3 * i + 2], v0 = pv[3 * i], v1 = pv[3 * i + 1], v2 = pv[3 * i + 2];
-            const double e0 = sE[0] * u0 + sE[1] * u1 + sE[2] * u2, e1 = sE[3] * u0 + sE[4] * u1 + sE[5] * u2, e2 = sE[6] * u0 + sE[7] * u1 + sE[8] * u2;
-            const double f0 = sE[0] * v0 + sE[3] * v1 + sE[6] * v2, f1 = sE[1] * v0 + sE[4] * v1 + sE[7] * v2;
-            const double d = e0 * v0 + e1 * v1 + e2 * v2, den = e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1;
-            const double res = (d * d) / den;
-            double j[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double* D = sdE + 9 * k;
-                const double a0 = D[0] * u0 + D[1] * u1 + D[2] * u2, a1 = D[3] * u0 + D[4] * u1 + D[5] * u2, a2 = D[6] * u0 + D[7] * u1 + D[8] * u2;
-                const double b0 = D[0] * v0 + D[3] * v1 + D[6] * v2, b1 = D[1] * v0 + D[4] * v1 + D[7] * v2;
-                const double dk = a0 * v0 + a1 * v1 + a2 * v2, denk = 2.0 * (e0 * a0 + e1 * a1 + f0 * b0 + f1 * b1);
-                j[k] = ((2.0 * d * dk - res * denk) / den) * scale[k];
-            }
-            acc[0] += j[0] * j[0]; acc[1] += j[0] * j[1]; acc[2] += j[0] * j[2]; acc[3] += j[1] * j[1]; acc[4] += j[1] * j[2]; acc[5] += j[2] * j[2];
-            acc[6] += j[0] * res; acc[7] += j[1] * res; acc[8] += j[2] * res; acc[9] += 0.5 * res * res;
-        }
-        wave_allsum<10>(acc);
-        for (int k = 0; k < 6; k++) A[k] = acc[k];
-        g[0] = acc[6]; g[1] = acc[7]; g[2] = acc[8]; x_cost = acc[9];
-        finite_ok = isfinite(x_cost);
-    };
-    linearize();
-    if (finite_ok) {
-        // Jacobi scaling from the iteration-0 Jacobian
-        scale[0] = 1.0 / (1.0 + sqrt(A[0])); scale[1] = 1.0 / (1.0 + sqrt(A[3])); scale[2] = 1.0 / (1.0 + sqrt(A[5]));
-        A[0] *= scale[0] * scale[0]; A[1] *= scale[0] * scale[1]; A[2] *= scale[0] * scale[2]; A[3] *= scale[1] * scale[1]; A[4] *= scale[1] * scale[2]; A[5] *= scale[2] * scale[2];
-        g[0] *= scale[0]; g[1] *= scale[1]; g[2] *= scale[2];
-        int iteration = 0, invalid = 0; bool last_ok = true;
-        while (true) {
-            if (iteration >= 200) break;                                              // src/spherical_estimator.cpp:148
-            const double gmax = fmax(fabs(g[0] / scale[0]), fmax(fabs(g[1] / scale[1]), fabs(g[2] / scale[2])));
-            if (last_ok && gmax <= 1e-10) break;
-            if (radius <= 1e-32) break;
-            iteration++;
-            double Ad[6] = {A[0], A[1], A[2], A[3], A[4], A[5]};
-            Ad[0] += fmin(fmax(A[0], 1e-6), 1e32) / radius; Ad[3] += fmin(fmax(A[3], 1e-6), 1e32) / radius; Ad[5] += fmin(fmax(A[5], 1e-6), 1e32) / radius;
-            // Cholesky of the damped 3x3 system; a non-positive pivot is a failed linear solve (an invalid step)
-            const double l00 = sqrt(Ad[0]), l10 = Ad[1] / l00, l20 = Ad[2] / l00;
-            const double d1 = Ad[3] - l10 * l10, l11 = sqrt(d1), l21 = (Ad[4] - l20 * l10) / l11;
-            const double d2 = Ad[5] - l20 * l20 - l21 * l21, l22 = sqrt(d2);
-            const bool chol_ok = (Ad[0] > 0.0) && (d1 > 0.0) && (d2 > 0.0);
-            const double z0 = g[0] / l00, z1 = (g[1] - l10 * z0) / l11, z2 = (g[2] - l20 * z0 - l21 * z1) / l22;
-            const double y2 = z2 / l22, y1 = (z1 - l21 * y2) / l11, y0 = (z0 - l10 * y1 - l20 * y2) / l00;
-            const double st[3] = {-y0, -y1, -y2};
-            const double sAs = A[0] * st[0] * st[0] + A[3] * st[1] * st[1] + A[5] * st[2] * st[2] + 2 * (A[1] * st[0] * st[1] + A[2] * st[0] * st[2] + A[4] * st[1] * st[2]);
-            const double model = -((g[0] * st[0] + g[1] * st[1] + g[2] * st[2]) + 0.5 * sAs);   // -(Js)^T (r + Js/2)
-            if (!chol_ok || !(model > 0.0) || !isfinite(model)) {
-                if (++invalid >= 10) break;                                           // max_num_consecutive_invalid_steps, :149
-                radius /= decrease; decrease *= 2.0; last_ok = false; continue;
-            }
-            invalid = 0;
-            const double xc[3] = {x[0] + st[0] * scale[0], x[1] + st[1] * scale[1], x[2] + st[2] * scale[2]};
-            // candidate: its E; the accepted point's copy is kept for a rejected step
-            for (int k = 0; k < 9; k++) sEkeep[k] = sE[k];
-            sampson_E_and_derivatives(xc, tz, sE, nullptr);
-            double c[1] = {0.0};
-            for (int q = lane; q < cnt; q += 64) {
-                const int i = list[q];
-                const double r = sampson_err(sE, pu + 3 * i, pv + 3 * i); c[0] += 0.5 * r * r;
-            }
-            double cand = wave_sum(c[0]);
-            if (!isfinite(cand)) cand = 1.79769313486231570815e308;
-            const double step_norm = sqrt((xc[0] - x[0]) * (xc[0] - x[0]) + (xc[1] - x[1]) * (xc[1] - x[1]) + (xc[2] - x[2]) * (xc[2] - x[2]));
-            const double change = x_cost - cand;
-            const double rho = (cand >= 1.79769313486231570815e308) ? -1.79769313486231570815e308 : change / model;
-            const bool stop = (step_norm <= 1e-8 * (x_norm + 1e-8)) || (fabs(change) <= 1e-6 * x_cost);
-            if (!stop && rho > 1e-3) {
-                const double xp[3] = {x[0], x[1], x[2]};
-                x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
-                sampson_E_and_derivatives(x, tz, sE, sdE);
-                linearize();                      // scale[] is applied inside: the sums come back Jacobi-scaled
-                if (!finite_ok) { x[0] = xp[0]; x[1] = xp[1]; x[2] = xp[2]; break; }      // evaluation failure: the last good x stands
-                x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-                radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3))); decrease = 2.0; last_ok = true;
-            } else {
-                // the derivatives still belong to x (only E was overwritten): restore E for the next candidate's bookkeeping
-                for (int k = 0; k < 9; k++) sE[k] = sEkeep[k];
-                if (stop) break;
-                radius /= decrease; decrease *= 2.0; last_ok = false;
-            }
-        }
-    }
-    double Rm[9]; so3exp(x, Rm); make_E_dev(Rm, inward, E);
-}
-
+// SphericalEstimator::LeastSquares lives in sampson_lsq.h (six free parameters [r1; t1], src/spherical_estimator.cpp:140-144).
 
 // ---- std::mt19937 + std::uniform_int_distribution<int> of libstdc++ (GCC >= 11), as RansacLib draws them
 // (include/RansacLib/sampling.h:46-135, utils.h:48-73).  State: 624 words in LDS, position in a register that every thread keeps.

@@ -99,6 +99,20 @@ def sampson_refine_probe(ctx, u, v, lists, Es, inward=False):
     return _unflat(E)
 
 
+def sampson_refine_probe_ex(ctx, u, v, lists, Es, inward=False, wave=False):
+    """The same fit with its trace.  -> (E (T,3,3), x (T,6) = [r1; t1], iterations (T,), status (T,), initial cost (T,), final cost (T,)).
+    wave=True runs the one-wave form the batched LO-MSAC kernel uses instead of the workgroup-cooperative one."""
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    ptr, flat = _csr(lists)
+    E = np.ascontiguousarray(np.transpose(np.asarray(Es, np.float64).reshape(-1, 3, 3), (0, 2, 1))).reshape(-1).copy()
+    tr = np.zeros(10 * len(lists))
+    _lib.check(_lib.lib().ssfm_sampson_refine_probe_ex(ctx._p, len(u), u.ctypes.data_as(c_double_p), v.ctypes.data_as(c_double_p), len(lists),
+                                                       ptr.ctypes.data_as(c_i32_p), flat.ctypes.data_as(c_i32_p), int(inward), int(wave),
+                                                       E.ctypes.data_as(c_double_p), tr.ctypes.data_as(c_double_p)), ctx._p)
+    tr = tr.reshape(-1, 10)
+    return _unflat(E), tr[:, :6].copy(), tr[:, 6].astype(int), tr[:, 7].astype(int), tr[:, 8].copy(), tr[:, 9].copy()
+
+
 def decompose_probe(ctx, Es, inward=False):
     """decompose_spherical_essential_matrix + so3exp on the device -> (r (T,3), R (T,3,3))"""
     E = np.ascontiguousarray(np.transpose(np.asarray(Es, np.float64).reshape(-1, 3, 3), (0, 2, 1))).reshape(-1).copy()

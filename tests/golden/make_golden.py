@@ -73,7 +73,18 @@ def ransac_case():
     dec = np.array([np.concatenate(O.decompose_spherical_essential_matrix(Ei, False)) for Ei in Em])
     thr = (2 / 600) ** 2
     o = O.ransac_pair(u, v, thr, min_num_inliers=20)
-    return dict(u=u, v=v, R=R, E=E, inlier_gt=inl, samples=samples, Es_action=Es_am, Es_poly=Es_poly, poly_imag=im_poly, sampson=samp, Rs=Rs, E_outward=Em,
+    # SphericalEstimator::LeastSquares with its six free parameters [r1; t1] (src/spherical_estimator.cpp:140-144 leaves t1 free):
+    # 8 fits on subsets of the true inliers from perturbed starts; x = [r1; t1] at the end, LM iterations
+    good = np.nonzero(inl)[0]
+    lsq_lists = np.full((8, 40), -1, np.int32); lsq_start = np.zeros((8, 3, 3)); lsq_E = np.zeros((8, 3, 3)); lsq_x = np.zeros((8, 6)); lsq_it = np.zeros(8, np.int32)
+    for k in range(8):
+        m = [21, 7, 3, 40][k % 4]
+        lst = rng.choice(good, m, replace=False).astype(np.int32); lsq_lists[k, :m] = lst
+        lsq_start[k] = O.make_spherical_essential_matrix(synth.so3exp(rng.normal(size=(1, 3)) * 0.02)[0] @ R, False)
+        f = O.sampson_least_squares_ex(u, v, lst, lsq_start[k])
+        lsq_E[k] = f["E"]; lsq_x[k] = f["x"]; lsq_it[k] = f["iterations"]
+    return dict(lsq_lists=lsq_lists, lsq_start=lsq_start, lsq_E=lsq_E, lsq_x=lsq_x, lsq_iterations=lsq_it,
+                u=u, v=v, R=R, E=E, inlier_gt=inl, samples=samples, Es_action=Es_am, Es_poly=Es_poly, poly_imag=im_poly, sampson=samp, Rs=Rs, E_outward=Em,
                 E_inward=Emi, decomposed=dec, thr=thr, ransac_E=o["E"], ransac_R=o["R"], ransac_inliers=o["inliers"], ransac_num_inliers=o["num_inliers"],
                 ransac_iterations=o["iterations"], ransac_score=o["score"])
 
@@ -86,7 +97,10 @@ def retri_case():
 
 
 if __name__ == "__main__":
+    import sys
     np.savez_compressed(os.path.join(HERE, "ransac.npz"), **ransac_case())
+    if "--only-ransac" in sys.argv:
+        sys.exit(0)
     np.savez_compressed(os.path.join(HERE, "retriangulate.npz"), **retri_case())
     np.savez_compressed(os.path.join(HERE, "so3.npz"), **so3_cases())
     for sph in (True, False):

@@ -158,3 +158,9 @@ def test_gpu_against_ransac_golden(gpu_ctx):
     out = ransac.estimate_pairs(gpu_ctx, [(u, v)], float(g["thr"]), min_num_inliers=20)
     assert (out["inliers"][0] == g["ransac_inliers"]).all() and rot_err(g["ransac_R"], out["R"][0]) < 1e-7
     assert out["iterations"][0] == int(g["ransac_iterations"]) and abs(out["scores"][0] - float(g["ransac_score"])) <= 1e-9 * float(g["ransac_score"])
+    # SphericalEstimator::LeastSquares, six free parameters [r1; t1]: both device forms against the committed fits
+    lists = [l[l >= 0] for l in g["lsq_lists"]]
+    for wave in (False, True):
+        E, x, it, status, c0, c1 = ransac.sampson_refine_probe_ex(gpu_ctx, u, v, lists, g["lsq_start"], wave=wave)
+        assert max(frob_err(a, b) for a, b in zip(E, g["lsq_E"])) <= 1e-9
+        assert np.abs(x[:, :3] - g["lsq_x"][:, :3]).max() <= 1e-9 and (it == g["lsq_iterations"]).all() and (status == 0).all()

@@ -66,11 +66,39 @@ def test_least_squares_probe_matches_oracle(gpu_ctx, oracle, inward):
             Rp = Rotation.from_rotvec(rng.normal(size=3) * 0.02).as_matrix() @ R
             starts.append(oracle.make_spherical_essential_matrix(Rp, inward))
     got = ransac.sampson_refine_probe(gpu_ctx, u, v, lists, starts, inward=inward)
-    worst = 0.0
-    for lst, e0, g in zip(lists, starts, got):
-        ref = oracle.sampson_least_squares(u, v, lst, e0, inward=inward)
-        worst = max(worst, frob_err(g, ref))
+    refs = [oracle.sampson_least_squares_ex(u, v, lst, e0, inward=inward) for lst, e0 in zip(lists, starts)]
+    worst = max(frob_err(g, r["E"]) for g, r in zip(got, refs))
     assert worst <= 1e-9, worst
+    # both device forms (workgroup-cooperative; the one-wave fit of the batched kernel) with their traces: the SIX parameters [r1; t1]
+    # (src/spherical_estimator.cpp:140-144 leaves t1 free), the same number of Levenberg-Marquardt iterations, the same costs
+    for wave in (False, True):
+        E, x, it, status, c0, c1 = ransac.sampson_refine_probe_ex(gpu_ctx, u, v, lists, starts, inward=inward, wave=wave)
+        assert max(frob_err(g, r["E"]) for g, r in zip(E, refs)) <= 1e-9
+        assert max(np.abs(xx[:3] - r["x"][:3]).max() for xx, r in zip(x, refs)) <= 1e-9
+        # t1 has a gauge direction (the scale of t) that only the damping holds: its component along t is rounding-sensitive, compare looser
+        assert max(np.abs(xx[3:] - r["x"][3:]).max() for xx, r in zip(x, refs)) <= 1e-6
+        assert [int(i) for i in it] == [r["iterations"] for r in refs] and (status == 0).all()
+        assert max(abs(a - r["initial_cost"]) / r["initial_cost"] for a, r in zip(c0, refs)) <= 1e-9
+        assert max(abs(a - r["final_cost"]) / r["final_cost"] for a, r in zip(c1, refs)) <= 1e-8
+        assert max(np.abs(xx[3:] - [0, 0, 1.0 if inward else -1.0]).max() for xx in x) > 1e-5       # t1 moved on the device too
+
+
+def test_least_squares_is_not_the_three_parameter_fit(gpu_ctx, oracle):
+    """The negative test: rounds 1-2 pinned t1 (SURVEY a12's sentence); the reference does not (src/spherical_estimator.cpp:140-144).
+    The device result must sit on the six-parameter minimum and AWAY from the three-parameter one by more than north_star's 1e-5."""
+    from spherical_sfm_amd import ransac
+    lists, starts, six, three = [], [], [], []
+    pairs = []
+    for seed in range(5):
+        u, v, R, E, _ = synth.make_relative_pose_problem(500, seed=seed, noise=1 / 1000, rotation_deg=10)
+        Rp = Rotation.from_rotvec(np.random.default_rng(seed).normal(size=3) * 0.01).as_matrix() @ R
+        E0 = oracle.make_spherical_essential_matrix(Rp)
+        s = np.arange(500, dtype=np.int32)
+        a = oracle.sampson_least_squares_ex(u, v, s, E0); b = oracle.sampson_least_squares_ex(u, v, s, E0, r_only=True)
+        _, x, it, status, c0, c1 = ransac.sampson_refine_probe_ex(gpu_ctx, u, v, [s], [E0], wave=bool(seed & 1))
+        d6 = np.linalg.norm(x[0, :3] - a["x"][:3]); d3 = np.linalg.norm(x[0, :3] - b["x"][:3])
+        assert d6 <= 1e-9 and d3 > 2e-5, (d6, d3)
+        assert it[0] == a["iterations"] and c1[0] < b["final_cost"]
 
 
 def test_decompose_probe_matches_oracle(gpu_ctx, oracle):
