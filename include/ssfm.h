@@ -311,12 +311,28 @@ int ssfm_focal_search(ssfm_ctx* ctx, int32_t n, int32_t num_edges, const int32_t
                       double* costs, int32_t* best_trial, double* rotations_best, double* rel_rotations_best);
 
 /* ---- SfM::Retriangulate (src/sfm.cpp:156-192) ------------------------------------------------------------------
- * Re-estimates EVERY point of the problem from its observations and the current cameras/focal: LO-MSAC over 2-view DLT
- * hypotheses (TriangulationEstimator, src/triangulation_estimator.cpp:46-127; squared inlier threshold 4 px^2, final
- * least squares on), one GPU lane per point.  p->points is overwritten; points with < 3 observations or < 3 inliers
- * become (0,0,0) exactly as in the reference (which removes them from later Optimize calls).  num_inliers_out: [num_points]
- * or NULL.  The *_fixed masks are ignored, like the reference does. */
+ * Re-estimates EVERY point of the problem from its observations and the current cameras/focal with the per-point
+ * ransac_lib::LocallyOptimizedMSAC<Point, ..., TriangulationEstimator> of the reference (src/triangulation_estimator.cpp:46-127,
+ * include/RansacLib/ransac.h:128-428; squared inlier threshold 4 px^2, final least squares on, every other option a LORansacOptions
+ * default), one GPU lane per point.  The default mode REPLAYS THE REFERENCE'S TRACE: both std::mt19937 streams run from seed 0 for
+ * every point, so the sampler's pair sequence (a function of the track length only) and the raw words of the local optimisation's
+ * stream are drawn once on the host with libstdc++'s generators, and the device walks RansacLib's control flow draw for draw -- same
+ * iteration counts, same local-optimisation runs, same inlier sets as a CPU build (tests/test_retriangulate_gpu.py compares with the
+ * oracle bit for bit).  p->points is overwritten; points with < 3 observations or < 3 inliers become (0,0,0) exactly as in the
+ * reference (which removes them from later Optimize calls).  num_inliers_out: [num_points] or NULL.  The *_fixed masks are ignored,
+ * like the reference does.  SSFM_RETRI_ENUMERATE=1 selects the enumerating kernel of rounds 1-2 (every observation pair once, no random
+ * stream: statistical agreement only, ~8x faster).
+ * ssfm_retriangulate_ex: the same with its trace -- stats_out [2*num_points] = RansacStatistics::num_iterations, number_lo_iterations
+ *   of every point's run; inlier_flags_out [num_observations] = 1 where the observation is in the final stats.inlier_indices of its
+ *   point (either may be NULL; trace mode only).
+ * ssfm_tri_probe: TriangulationEstimator's pieces, one lane per task, on point task_pt[t] with the observation subset
+ *   lists[task_ptr[t] .. task_ptr[t+1]) (positions in the point's observation list, cameras ascending); out [tasks*4]:
+ *   what 0 NonMinimalSolver (1..6 observations) -> X, 0;  what 1 LeastSquares from X_in[t] -> X, Levenberg-Marquardt iterations;
+ *   what 2 ScoreModel / GetInliers of X_in[t] -> MSAC score at 4, inliers at 4, inliers at 4 sqrt 2, error of observation 0. */
 int ssfm_retriangulate(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out);
+int ssfm_retriangulate_ex(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out);
+int ssfm_tri_probe(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t what, int32_t tasks, const int32_t* task_pt, const int32_t* task_ptr, const int32_t* lists,
+                   const double* X_in, double* out);
 
 /* ---- feature tracks: the integer part of build_sfm (examples/spherical_sfm_tools.cpp:862-950), host only ------
  * Keyframe k owns features [feat_ptr[k], feat_ptr[k+1]) of feat_xy ([total*2] pixels).  Match set s links keyframes

@@ -60,11 +60,18 @@ template <int N> inline bool operator>=(const Jet<N>& f, double s) { return f.a 
 template <int N> inline Jet<N> jsqrt(const Jet<N>& f) {
     Jet<N> h; h.a = std::sqrt(f.a); const double d = 0.5 / h.a;
     for (int i = 0; i < N; i++) h.v[i] = f.v[i] * d; return h; }
+// sin and cos of one angle.  Ceres' Jet cos() / sin() evaluate both functions of the same argument, and so does every caller here; GCC at
+// -O2 and above turns such a pair into ONE call of glibc's sincos(), whose sine is not always bit-identical to sin()'s (it differs in the last
+// bit for e.g. 0.83775804095727813).  The pair is requested explicitly so that the bits do not depend on what the optimiser happened to merge
+// (the device replay of SfM::Retriangulate takes the cameras' sin / cos from the same call, retriangulate.hip).
+inline void sincos_pair(double x, double* s, double* c) { ::sincos(x, s, c); }
 template <int N> inline Jet<N> jsin(const Jet<N>& f) {
-    Jet<N> h; h.a = std::sin(f.a); const double d = std::cos(f.a);
+    double sn, cs; sincos_pair(f.a, &sn, &cs);
+    Jet<N> h; h.a = sn; const double d = cs;
     for (int i = 0; i < N; i++) h.v[i] = f.v[i] * d; return h; }
 template <int N> inline Jet<N> jcos(const Jet<N>& f) {
-    Jet<N> h; h.a = std::cos(f.a); const double d = -std::sin(f.a);
+    double sn, cs; sincos_pair(f.a, &sn, &cs);
+    Jet<N> h; h.a = cs; const double d = -sn;
     for (int i = 0; i < N; i++) h.v[i] = f.v[i] * d; return h; }
 template <int N> inline Jet<N> jatan2(const Jet<N>& y, const Jet<N>& x) {
     // d atan2(y,x) = (x dy - y dx) / (x^2 + y^2)
@@ -73,8 +80,8 @@ template <int N> inline Jet<N> jatan2(const Jet<N>& y, const Jet<N>& x) {
 
 // scalar overloads so the same templated residual code runs on plain doubles
 inline double jsqrt(double x) { return std::sqrt(x); }
-inline double jsin(double x) { return std::sin(x); }
-inline double jcos(double x) { return std::cos(x); }
+inline double jsin(double x) { double sn, cs; sincos_pair(x, &sn, &cs); return sn; }
+inline double jcos(double x) { double sn, cs; sincos_pair(x, &sn, &cs); return cs; }
 inline double jatan2(double y, double x) { return std::atan2(y, x); }
 
 template <typename T> struct JetTraits { static double value(const T& x) { return x.a; } };

@@ -350,3 +350,31 @@ def retriangulate(prob, num_threads=16):
     nin = np.zeros(len(h.pts), np.int32)
     lib().oracle_retriangulate(C.byref(h.c), num_threads, _ip(nin))
     return h.pts, nin
+
+
+def retriangulate_ex(prob, num_threads=16):
+    """-> (points, num_inliers, iterations (Np,), local-optimisation runs (Np,), inlier flags (M,) per observation)"""
+    h = _Held(prob)
+    nin = np.zeros(len(h.pts), np.int32); st = np.zeros(2 * max(len(h.pts), 1), np.uint32); fl = np.zeros(max(len(h.oc), 1), np.uint8)
+    f = lib().oracle_retriangulate_ex
+    f.argtypes = [C.c_void_p, C.c_int32, c_i32_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]; f.restype = C.c_int
+    f(C.byref(h.c), num_threads, _ip(nin), st.ctypes.data_as(C.POINTER(C.c_uint32)), _up(fl))
+    st = st[:2 * len(h.pts)].reshape(-1, 2)
+    return h.pts, nin, st[:, 0].copy(), st[:, 1].copy(), fl[:len(h.oc)].astype(bool)
+
+
+def tri_probe(prob, what, task_pt, lists, X_in=None):
+    """TriangulationEstimator's pieces (triangulation_oracle.cpp: oracle_tri_probe) -> (tasks, 4)"""
+    h = _Held(prob)
+    task_pt = np.ascontiguousarray(task_pt, np.int32); T = len(task_pt)
+    ptr = np.zeros(T + 1, np.int32)
+    for i, l in enumerate(lists):
+        ptr[i + 1] = ptr[i] + len(l)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32).reshape(-1) for l in lists]) if ptr[-1] else np.zeros(1, np.int32), np.int32)
+    X = np.ascontiguousarray(X_in if X_in is not None else np.zeros((T, 3)), np.float64).reshape(-1)
+    out = np.zeros(4 * T)
+    f = lib().oracle_tri_probe
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, c_i32_p, c_i32_p, c_i32_p, c_double_p, c_double_p]; f.restype = C.c_int
+    rc = f(C.byref(h.c), what, T, _ip(task_pt), _ip(ptr), _ip(flat), _dp(X), _dp(out))
+    assert rc == 0, rc
+    return out.reshape(T, 4)

@@ -143,7 +143,8 @@ inline void so3exp(const double r[3], double R[9]) {   // src/so3.cpp:16-23
     double K[9] = {0, k[2], -k[1], -k[2], 0, k[0], k[1], -k[0], 0};   // column-major skew
     double KK[9];
     mat3_mul(K, K, KK);
-    const double s = std::sin(theta), omc = 1.0 - std::cos(theta);
+    double s, cs; sincos_pair(theta, &s, &cs);
+    const double omc = 1.0 - cs;
     for (int i = 0; i < 9; i++) R[i] += s * K[i] + omc * KK[i];
 }
 

@@ -126,6 +126,12 @@ void oracle_mt19937_draws(uint32_t seed, int32_t n, const int32_t* lo, const int
 /* SfM::Retriangulate (src/sfm.cpp:156-192): every point is re-estimated from its observations with the per-point LO-MSAC
  * of TriangulationEstimator; points with < 3 observations or < 3 inliers become (0,0,0).  num_inliers_out: [num_points] or NULL */
 int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out);
+/* same with its trace: stats_out [2*num_points] = RansacStatistics::num_iterations, number_lo_iterations; inlier_flags_out [num_observations]
+ * = membership in the final stats.inlier_indices (either may be NULL) */
+int oracle_retriangulate_ex(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out);
+/* TriangulationEstimator's pieces on chosen observation subsets (src/triangulation_estimator.cpp:46-127); see triangulation_oracle.cpp */
+int oracle_tri_probe(oracle_ba_problem* p, int32_t what, int32_t tasks, const int32_t* task_pt, const int32_t* task_ptr, const int32_t* lists,
+                     const double* X_in, double* out);
 
 #ifdef __cplusplus
 }

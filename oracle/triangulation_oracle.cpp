@@ -129,28 +129,46 @@ struct TriSolver {                                     // TriangulationEstimator
 }  // namespace oracle
 using namespace oracle;
 
-// points: in/out.  Every point index in [0, num_points) "exists"; observations of a point over the cameras, ascending.
-extern "C" int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out) {
+// observation lists of every point over the cameras, ascending; map semantics (last value of a repeated key), src/sfm.cpp:164-169
+static std::vector<std::vector<int64_t>> point_lists(const oracle_ba_problem* p) {
     const int Np = p->num_points; const int64_t M = p->num_observations;
     std::vector<std::vector<int64_t>> per_pt(Np);
     for (int64_t i = 0; i < M; i++) if (p->obs_pt[i] >= 0 && p->obs_pt[i] < Np) per_pt[p->obs_pt[i]].push_back(i);
+    for (auto& ids : per_pt) {
+        std::stable_sort(ids.begin(), ids.end(), [&](int64_t a, int64_t b) { return p->obs_cam[a] < p->obs_cam[b]; });
+        std::vector<int64_t> keep;
+        for (size_t k = 0; k < ids.size(); k++) if (!(k + 1 < ids.size() && p->obs_cam[ids[k + 1]] == p->obs_cam[ids[k]])) keep.push_back(ids[k]);
+        ids.swap(keep);
+    }
+    return per_pt;
+}
+static std::vector<TriObs> point_observations(const oracle_ba_problem* p, const std::vector<int64_t>& ids) {
+    std::vector<TriObs> obs;
+    for (int64_t id : ids) {
+        const int c = p->obs_cam[id];
+        TriObs o; std::memcpy(o.t, &p->cameras[(size_t)c * 6], 24); std::memcpy(o.r, &p->cameras[(size_t)c * 6 + 3], 24);
+        double Rc[9]; so3exp(o.r, Rc);                                                         // column-major; Pose::Pose, src/sfm_types.cpp:14-19
+        for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) o.P[4 * a + b] = Rc[a + 3 * b]; o.P[4 * a + 3] = o.t[a]; }
+        o.x[0] = p->obs_xy[2 * id]; o.x[1] = p->obs_xy[2 * id + 1]; o.focal = *p->focal;
+        obs.push_back(o);
+    }
+    return obs;
+}
+
+// points: in/out.  Every point index in [0, num_points) "exists"; observations of a point over the cameras, ascending.
+// Optional trace outputs: stats_out [2 * num_points] = RansacStatistics::num_iterations, number_lo_iterations of every point's run;
+// inlier_flags_out [num_observations] = 1 where the observation is in the final stats.inlier_indices of its point.
+extern "C" int oracle_retriangulate_ex(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out) {
+    const int Np = p->num_points; const int64_t M = p->num_observations;
+    const std::vector<std::vector<int64_t>> per_pt = point_lists(p);
+    if (inlier_flags_out) std::memset(inlier_flags_out, 0, (size_t)M);
     omp_set_num_threads(std::max(1, std::min(num_threads > 0 ? num_threads : 1, omp_get_num_procs())));
 #pragma omp parallel for schedule(dynamic, 64)
     for (int j = 0; j < Np; j++) {
-        auto& ids = per_pt[j];
-        std::stable_sort(ids.begin(), ids.end(), [&](int64_t a, int64_t b) { return p->obs_cam[a] < p->obs_cam[b]; });
-        std::vector<TriObs> obs;
-        for (size_t k = 0; k < ids.size(); k++) {
-            if (k + 1 < ids.size() && p->obs_cam[ids[k + 1]] == p->obs_cam[ids[k]]) continue;      // map semantics: last value of a key
-            const int c = p->obs_cam[ids[k]];
-            TriObs o; std::memcpy(o.t, &p->cameras[(size_t)c * 6], 24); std::memcpy(o.r, &p->cameras[(size_t)c * 6 + 3], 24);
-            double Rc[9]; so3exp(o.r, Rc);                                                         // column-major
-            for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) o.P[4 * a + b] = Rc[a + 3 * b]; o.P[4 * a + 3] = o.t[a]; }
-            o.x[0] = p->obs_xy[2 * ids[k]]; o.x[1] = p->obs_xy[2 * ids[k] + 1]; o.focal = *p->focal;
-            obs.push_back(o);
-        }
+        const std::vector<TriObs> obs = point_observations(p, per_pt[j]);
         double* X = &p->points[(size_t)j * 3]; X[0] = X[1] = X[2] = 0.0;                            // src/sfm.cpp:172
         if (num_inliers_out) num_inliers_out[j] = 0;
+        if (stats_out) { stats_out[2 * j] = 0; stats_out[2 * j + 1] = 0; }
         if (obs.size() < 3) continue;
         MSACOptions o; o.sq_thresh = 4.0; o.final_lsq = true;                                      // src/sfm.cpp:175-177
         TriSolver solver{obs};
@@ -158,8 +176,45 @@ extern "C" int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, i
         Pt Xm{}; MSACStats st;
         const int nin = R.estimate(&Xm, &st);
         if (num_inliers_out) num_inliers_out[j] = nin;
+        if (stats_out) { stats_out[2 * j] = st.iterations; stats_out[2 * j + 1] = (uint32_t)st.lo_count; }
+        if (inlier_flags_out) for (int k : st.inliers) inlier_flags_out[per_pt[j][k]] = 1;
         if (nin < 3) continue;                                                                     // src/sfm.cpp:186
         X[0] = Xm[0]; X[1] = Xm[1]; X[2] = Xm[2];
+    }
+    return 0;
+}
+extern "C" int oracle_retriangulate(oracle_ba_problem* p, int32_t num_threads, int32_t* num_inliers_out) {
+    return oracle_retriangulate_ex(p, num_threads, num_inliers_out, nullptr, nullptr);
+}
+
+// The estimator's pieces on chosen observation subsets (bit-for-bit parity tests of the device code).  Task t works on point
+// task_pt[t] with the sample lists[task_ptr[t] .. task_ptr[t+1]) = positions in that point's observation list (cameras ascending).
+// what 0: NonMinimalSolver(sample)           -> out[4t..] = X, 0
+// what 1: LeastSquares(sample, X_in[t])      -> out[4t..] = X, Levenberg-Marquardt iterations
+// what 2: ScoreModel / GetInliers(X_in[t])   -> out[4t..] = MSAC score at threshold 4, inliers at 4, inliers at 4 sqrt 2, error of observation 0
+extern "C" int oracle_tri_probe(oracle_ba_problem* p, int32_t what, int32_t tasks, const int32_t* task_pt, const int32_t* task_ptr, const int32_t* lists,
+                                const double* X_in, double* out) {
+    const std::vector<std::vector<int64_t>> per_pt = point_lists(p);
+    for (int t = 0; t < tasks; t++) {
+        const int j = task_pt[t];
+        if (j < 0 || j >= p->num_points) return -1;
+        const std::vector<TriObs> obs = point_observations(p, per_pt[j]);
+        std::vector<int> sample(lists + task_ptr[t], lists + task_ptr[t + 1]);
+        for (int k : sample) if (k < 0 || k >= (int)obs.size()) return -2;
+        TriSolver S{obs};
+        double* o = out + 4 * (size_t)t;
+        if (what == 0) { Pt X{}; S.NonMinimalSolver(sample, &X); o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; o[3] = 0; }
+        else if (what == 1) {
+            Pt X = {X_in[3 * t], X_in[3 * t + 1], X_in[3 * t + 2]};
+            TriLSQ P(obs, sample); LMOptions lo; lo.max_num_iterations = 200; lo.max_num_consecutive_invalid_steps = 10;
+            const LMSummary sm = lm_minimize(P, lo, X.data());
+            o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; o[3] = sm.iterations;
+        } else {
+            const Pt X = {X_in[3 * t], X_in[3 * t + 1], X_in[3 * t + 2]};
+            double sc = 0; int n1 = 0, n2 = 0;
+            for (int i = 0; i < (int)obs.size(); i++) { const double e = S.EvaluateModelOnPoint(X, i); sc += std::min(e, 4.0); n1 += e < 4.0; n2 += e < 4.0 * std::sqrt(2.0); }
+            o[0] = sc; o[1] = n1; o[2] = n2; o[3] = obs.empty() ? 0.0 : S.EvaluateModelOnPoint(X, 0);
+        }
     }
     return 0;
 }

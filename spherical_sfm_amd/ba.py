@@ -134,6 +134,31 @@ def retriangulate(ctx, prob):
     return b.pts, nin
 
 
+def retriangulate_ex(ctx, prob):
+    """The same with its trace -> (points, num_inliers, iterations (Np,), local-optimisation runs (Np,), inlier flags (M,) per observation)."""
+    b = _ProblemBuffers(prob)
+    nin = np.zeros(len(b.pts), np.int32); st = np.zeros(2 * max(len(b.pts), 1), np.uint32); fl = np.zeros(max(len(b.oc), 1), np.uint8)
+    _lib.check(_lib.lib().ssfm_retriangulate_ex(ctx._p, C.byref(b.c), nin.ctypes.data_as(c_i32_p), st.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                fl.ctypes.data_as(_lib.c_u8_p)), ctx._p)
+    st = st[:2 * len(b.pts)].reshape(-1, 2)
+    return b.pts, nin, st[:, 0].copy(), st[:, 1].copy(), fl[:len(b.oc)].astype(bool)
+
+
+def tri_probe(ctx, prob, what, task_pt, lists, X_in=None):
+    """TriangulationEstimator's pieces on the device (ssfm.h: ssfm_tri_probe) -> (tasks, 4)"""
+    b = _ProblemBuffers(prob)
+    task_pt = np.ascontiguousarray(task_pt, np.int32); T = len(task_pt)
+    ptr = np.zeros(T + 1, np.int32)
+    for i, l in enumerate(lists):
+        ptr[i + 1] = ptr[i] + len(l)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32).reshape(-1) for l in lists]) if ptr[-1] else np.zeros(1, np.int32), np.int32)
+    X = np.ascontiguousarray(X_in if X_in is not None else np.zeros((T, 3)), np.float64).reshape(-1)
+    out = np.zeros(4 * T)
+    _lib.check(_lib.lib().ssfm_tri_probe(ctx._p, C.byref(b.c), what, T, task_pt.ctypes.data_as(c_i32_p), ptr.ctypes.data_as(c_i32_p), flat.ctypes.data_as(c_i32_p),
+                                         X.ctypes.data_as(c_double_p), out.ctypes.data_as(c_double_p)), ctx._p)
+    return out.reshape(T, 4)
+
+
 class BundleAdjuster:
     def __init__(self, ctx, prob, options=None, **kw):
         self.ctx = ctx

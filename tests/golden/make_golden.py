@@ -2,7 +2,7 @@
 
 The reference holds no golden vectors for this path and cannot be built here, so these fixtures pin
 the ORACLE's behaviour (regression + cross-machine determinism) and give the HIP path fixed targets; they do not
-pin the reference.  Re-run:  python tests/golden/make_golden.py
+pin the reference.  Re-run:  python tests/golden/make_golden.py [--only=ransac,retriangulate,so3,ba,rotavg]
 """
 import os
 import sys
@@ -92,19 +92,25 @@ def ransac_case():
 def retri_case():
     p = synth.make_circle(60, 400, 6, rot_noise_deg=0.0, pixel_noise=0.4, seed=23)
     bad = synth.corrupt_observations(p, 0.1, seed=9)
-    X, nin = O.retriangulate(p, 4)
-    return dict(cameras=p.cameras, focal=p.focal, obs_xy=p.obs_xy, obs_cam=p.obs_cam, obs_pt=p.obs_pt, corrupted=bad, points=X, num_inliers=nin)
+    # the oracle's triangulation unit is compiled without fused multiply-adds (oracle/Makefile): the trace depends on last bits
+    X, nin, it, lo, fl = O.retriangulate_ex(p, 4)
+    return dict(cameras=p.cameras, focal=p.focal, obs_xy=p.obs_xy, obs_cam=p.obs_cam, obs_pt=p.obs_pt, corrupted=bad, points=X, num_inliers=nin,
+                iterations=it, lo_runs=lo, inlier_flags=fl)
 
 
 if __name__ == "__main__":
     import sys
-    np.savez_compressed(os.path.join(HERE, "ransac.npz"), **ransac_case())
-    if "--only-ransac" in sys.argv:
-        sys.exit(0)
-    np.savez_compressed(os.path.join(HERE, "retriangulate.npz"), **retri_case())
-    np.savez_compressed(os.path.join(HERE, "so3.npz"), **so3_cases())
-    for sph in (True, False):
-        for ff in (True, False):
-            np.savez_compressed(os.path.join(HERE, f"ba_s{int(sph)}_f{int(ff)}.npz"), **ba_case(sph, ff))
-    np.savez_compressed(os.path.join(HERE, "rotavg.npz"), **rot_case())
-    print("golden fixtures written to", HERE)
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    want = lambda name: not only or name in only[0]
+    if want("ransac"):
+        np.savez_compressed(os.path.join(HERE, "ransac.npz"), **ransac_case())
+    if want("retriangulate"):
+        np.savez_compressed(os.path.join(HERE, "retriangulate.npz"), **retri_case())
+    if want("so3"):
+        np.savez_compressed(os.path.join(HERE, "so3.npz"), **so3_cases())
+    if want("ba"):
+        for sph in (True, False):
+            for ff in (True, False):
+                np.savez_compressed(os.path.join(HERE, f"ba_s{int(sph)}_f{int(ff)}.npz"), **ba_case(sph, ff))
+    if want("rotavg"):
+        np.savez_compressed(os.path.join(HERE, "rotavg.npz"), **rot_case())

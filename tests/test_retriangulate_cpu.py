@@ -58,7 +58,11 @@ def test_retriangulate_golden(oracle):
     p = synth.BAProblem(cameras=g["cameras"], points=np.ones((Np, 3)), focal=float(g["focal"]), obs_xy=g["obs_xy"], obs_cam=g["obs_cam"], obs_pt=g["obs_pt"],
                         rot_fixed=np.zeros(len(g["cameras"]), np.uint8), trans_fixed=np.ones(len(g["cameras"]), np.uint8), pt_fixed=np.zeros(Np, np.uint8),
                         focal_fixed=True, gt_cameras=g["cameras"], gt_points=g["points"], gt_focal=0.0)
-    X, nin = oracle.retriangulate(p, 2)
-    assert np.array_equal(nin, g["num_inliers"]) and np.allclose(X, g["points"], rtol=1e-9, atol=1e-12)
+    X, nin, it, lo, fl = oracle.retriangulate_ex(p, 2)
+    # the triangulation unit of the oracle is compiled without fused multiply-adds, so its trace is a property of IEEE arithmetic, not of
+    # this machine's compiler: bit-identical points, the same RansacStatistics, the same inlier sets
+    assert np.array_equal(nin, g["num_inliers"]) and np.array_equal(X, g["points"])
+    assert np.array_equal(it, g["iterations"]) and np.array_equal(lo, g["lo_runs"]) and np.array_equal(fl, g["inlier_flags"])
+    assert (it >= 100).all() and (lo >= 1).all()                        # min_num_iterations_; LO at iteration 50 at the latest
     mask = np.zeros(Np, bool); mask[g["corrupted"]] = True
     assert (nin[mask] <= 5).all() and (nin[~mask] == 6).mean() > 0.99
