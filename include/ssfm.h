@@ -239,6 +239,14 @@ int ssfm_ransac_batch_indexed(ssfm_ctx* ctx, int32_t num_frames, const int32_t* 
                               const int32_t* match_idx0, const int32_t* match_idx1,
                               double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
                               int32_t* num_inliers, double* scores, uint32_t* stats);
+/* The indexed form over the ranks of the context's communicator (multi-GPU estimate_pairwise, BASELINE configs[3]): every rank passes the SAME full
+ * arguments, uploads the feature rays of all frames and the match lists of ITS pairs (r, r + nranks, ...), and the result table of
+ * ssfm_ransac_batch_sharded is all-reduced -- bit-identical to ssfm_ransac_batch_indexed on one GPU.  Without a communicator it is that call. */
+int ssfm_ransac_batch_indexed_sharded(ssfm_ctx* ctx, int32_t num_frames, const int32_t* feat_ptr, const double* feat_rays,
+                                      int32_t num_pairs, const int32_t* pair_frame0, const int32_t* pair_frame1, const int32_t* match_ptr,
+                                      const int32_t* match_idx0, const int32_t* match_idx1,
+                                      double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
+                                      int32_t* num_inliers, double* scores, uint32_t* stats);
 /* ---- the reference's estimator interface for ONE pair (rays resident on the device) ------------------------------------------------
  * One entry point per virtual of sphericalsfm::Estimator<Eigen::Matrix3d> / EssentialEstimator (include/sphericalsfm/estimator.h:7-29) as
  * SphericalEstimator implements them (include/sphericalsfm/spherical_estimator.h:8-35, src/spherical_estimator.cpp:67-164): what a host-side

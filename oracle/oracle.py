@@ -378,3 +378,28 @@ def tri_probe(prob, what, task_pt, lists, X_in=None):
     rc = f(C.byref(h.c), what, T, _ip(task_pt), _ip(ptr), _ip(flat), _dp(X), _dp(out))
     assert rc == 0, rc
     return out.reshape(T, 4)
+
+
+def lsq_log(fn):
+    """runs fn() with the call log on -> (fn's result, [dict(sample, E_in, E_out, x, iterations)] LeastSquares calls in order); the
+    NonMinimalSolver calls of the same run are left in lsq_log.nonminimal = [dict(sample, E_out, after_lsq_calls)]"""
+    L = lib()
+    L.oracle_lsq_log_get.argtypes = [C.c_int32, C.c_int32, c_i32_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int32)]; L.oracle_lsq_log_get.restype = C.c_int32
+    L.oracle_lsq_log_enable(1)
+    try:
+        res = fn()
+    finally:
+        n = L.oracle_lsq_log_count(); log = []
+        for i in range(n):
+            smp = np.zeros(4096, np.int32); Ei = np.zeros(9); Eo = np.zeros(9); x = np.zeros(6); it = C.c_int32(0)
+            ns = L.oracle_lsq_log_get(i, len(smp), _ip(smp), _dp(Ei), _dp(Eo), _dp(x), C.byref(it))
+            log.append(dict(sample=smp[:ns].copy(), E_in=_um(Ei), E_out=_um(Eo), x=x, iterations=it.value))
+        L.oracle_nonmin_log_get.argtypes = [C.c_int32, c_i32_p, c_double_p, C.POINTER(C.c_int32)]; L.oracle_nonmin_log_get.restype = C.c_int32
+        nm = []
+        for i in range(L.oracle_nonmin_log_count()):
+            smp = np.zeros(9, np.int32); Eo = np.zeros(9); after = C.c_int32(0)
+            ns = L.oracle_nonmin_log_get(i, _ip(smp), _dp(Eo), C.byref(after))
+            nm.append(dict(sample=smp[:ns].copy(), E_out=_um(Eo), after_lsq_calls=after.value))
+        lsq_log.nonminimal = nm
+        L.oracle_lsq_log_enable(0)
+    return res, log

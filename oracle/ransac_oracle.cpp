@@ -390,7 +390,13 @@ struct SampsonLSQ : LMProblem {
     void plus(const double* x, const double* d, double* o) override { for (int k = 0; k < NP; k++) o[k] = x[k] + d[k]; }
 };
 static bool g_lsq_r_only = false;          // negative test only: the 3-parameter fit of rounds 1-2
+// diagnostics (tests log WHERE a device trace leaves the oracle's): every LeastSquares call of a run, in order
+struct LsqRecord { std::vector<int> sample; double E_in[9], E_out[9], x[6]; int iterations, termination; };
+static bool g_lsq_log_on = false; static std::vector<LsqRecord> g_lsq_log;
+struct NonMinRecord { std::vector<int> sample; double E_out[9]; int ok; int after_lsq_calls; };      // NonMinimalSolver calls of the same run
+static std::vector<NonMinRecord> g_nonmin_log;
 static void least_squares(const Rays& R, bool inward, const std::vector<int>& sample, double* E, LMSummary* out_sm = nullptr, double* out_x = nullptr) {
+    LsqRecord rec; if (g_lsq_log_on) { rec.sample = sample; std::memcpy(rec.E_in, E, 72); }
     double x[6], t[3]; decompose_E(E, inward, x, t);                                     // :115-117 r1 = r
     x[3] = 0; x[4] = 0; x[5] = inward ? 1.0 : -1.0;                                      // :118-119 t1 = (0,0,-1) / (0,0,1)
     LMOptions o; o.max_num_iterations = 200; o.max_num_consecutive_invalid_steps = 10;   // :146-150
@@ -401,6 +407,7 @@ static void least_squares(const Rays& R, bool inward, const std::vector<int>& sa
     if (out_sm) *out_sm = sm;
     if (out_x) std::memcpy(out_x, x, 48);
     double Rm[9]; rm_so3exp(x, Rm); make_E(Rm, inward, E);                               // :156 t1 is discarded
+    if (g_lsq_log_on) { std::memcpy(rec.E_out, E, 72); std::memcpy(rec.x, x, 48); rec.iterations = sm.iterations; rec.termination = sm.termination; g_lsq_log.push_back(rec); }
 }
 
 typedef std::array<double, 9> EMat;      // row-major
@@ -418,7 +425,9 @@ struct SphericalSolver {                 // SphericalEstimator, include/spherica
         double buf[36]; if (solver_action_matrix(R, sample.data(), (int)sample.size(), buf) == 0) return 0;
         double bs = INFINITY; int bi = 0;
         for (int i = 0; i < 4; i++) { double sc = 0; for (int j : sample) sc += sampson(buf + 9 * i, R.u + 3 * j, R.v + 3 * j); if (sc < bs) { bs = sc; bi = i; } }
-        std::memcpy(E->data(), buf + 9 * bi, 72); return 1;
+        std::memcpy(E->data(), buf + 9 * bi, 72);
+        if (g_lsq_log_on) { NonMinRecord r; r.sample = sample; std::memcpy(r.E_out, E->data(), 72); r.ok = 1; r.after_lsq_calls = (int)g_lsq_log.size(); g_nonmin_log.push_back(r); }
+        return 1;
     }
     double EvaluateModelOnPoint(const EMat& E, int i) const { return sampson(E.data(), R.u + 3 * i, R.v + 3 * i); }
     void LeastSquares(const std::vector<int>& sample, EMat* E) const { least_squares(R, inward, sample, E->data()); }
@@ -530,6 +539,25 @@ extern "C" void oracle_mt19937_draws(uint32_t seed, int32_t n, const int32_t* lo
     std::mt19937 rng; rng.seed(seed);
     for (int i = 0; i < nraw; i++) raw[i] = (uint32_t)rng();
     for (int i = 0; i < n; i++) { std::uniform_int_distribution<int> d(lo[i], hi[i]); out[i] = d(rng); }
+}
+
+// LeastSquares call log (single-threaded use): enable != 0 clears and starts recording
+extern "C" void oracle_lsq_log_enable(int32_t enable) { g_lsq_log_on = enable != 0; if (enable) { g_lsq_log.clear(); g_nonmin_log.clear(); } }
+extern "C" int32_t oracle_nonmin_log_count() { return (int32_t)g_nonmin_log.size(); }
+extern "C" int32_t oracle_nonmin_log_get(int32_t i, int32_t* sample9, double E_out_cm[9], int32_t* after_lsq_calls) {
+    if (i < 0 || i >= (int)g_nonmin_log.size()) return -1;
+    const NonMinRecord& r = g_nonmin_log[i];
+    for (int k = 0; k < (int)r.sample.size() && k < 9; k++) sample9[k] = r.sample[k];
+    rm_to_cm(r.E_out, E_out_cm); *after_lsq_calls = r.after_lsq_calls;
+    return (int32_t)r.sample.size();
+}
+extern "C" int32_t oracle_lsq_log_count() { return (int32_t)g_lsq_log.size(); }
+extern "C" int32_t oracle_lsq_log_get(int32_t i, int32_t cap, int32_t* sample, double E_in_cm[9], double E_out_cm[9], double x[6], int32_t* iterations) {
+    if (i < 0 || i >= (int)g_lsq_log.size()) return -1;
+    const LsqRecord& r = g_lsq_log[i];
+    for (int k = 0; k < (int)r.sample.size() && k < cap; k++) sample[k] = r.sample[k];
+    rm_to_cm(r.E_in, E_in_cm); rm_to_cm(r.E_out, E_out_cm); std::memcpy(x, r.x, 48); *iterations = r.iterations;
+    return (int32_t)r.sample.size();
 }
 
 extern "C" void oracle_dk_histogram(int64_t* out201, int32_t reset) { for (int i = 0; i <= 200; i++) { out201[i] = g_dk_hist[i]; if (reset) g_dk_hist[i] = 0; } }

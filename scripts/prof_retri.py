@@ -2,7 +2,7 @@
 usage: python scripts/prof_retri.py [Nc Np K] [repeats]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spherical_sfm_amd import ba, synth
 Nc, Np, K = [int(a) for a in sys.argv[1:4]] if len(sys.argv) > 3 else (300, 100000, 6)
 rep = int(sys.argv[4]) if len(sys.argv) > 4 else 3

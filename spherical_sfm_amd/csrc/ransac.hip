@@ -247,9 +247,9 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
     int max_n = 0; for (int p = 0; p < num_pairs; p++) max_n = std::max(max_n, pair_ptr[p + 1] - pair_ptr[p]);
     const size_t lds_fixed = (size_t)6 * max_n * sizeof(double);
     if (!trace && lds_fixed > 150 * 1024) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch: more than 3200 correspondences in one pair (fixed-budget mode keeps the rays in LDS; use the reference-trace mode)");
-    const size_t SLAB_RAYS = getenv("SSFM_RANSAC_SLAB_RAYS") ? (size_t)atoll(getenv("SSFM_RANSAC_SLAB_RAYS")) : ((size_t)4 << 20);   // 4 M rays = 200 MB of u, v per slab
+    const size_t SLAB_RAYS = getenv("SSFM_RANSAC_SLAB_RAYS") ? (size_t)std::max(atoll(getenv("SSFM_RANSAC_SLAB_RAYS")), 1ll) : ((size_t)4 << 20);   // 4 M rays = 200 MB of u, v per slab
     const size_t stage_threads = getenv("SSFM_RANSAC_STAGE_THREADS") ? (size_t)std::max(1, atoi(getenv("SSFM_RANSAC_STAGE_THREADS"))) : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
-    const int SLAB_PAIRS = getenv("SSFM_RANSAC_SLAB_PAIRS") ? atoi(getenv("SSFM_RANSAC_SLAB_PAIRS")) : 65536;
+    const int SLAB_PAIRS = getenv("SSFM_RANSAC_SLAB_PAIRS") ? std::max(atoi(getenv("SSFM_RANSAC_SLAB_PAIRS")), 1) : 65536;   // a value <= 0 would never advance the slab loop
     // slab boundaries
     std::vector<int> slab(1, 0);
     for (int p = 0; p < num_pairs;) {
@@ -438,6 +438,55 @@ extern "C" int ssfm_ransac_batch(ssfm_ctx* ctx, int32_t num_pairs, const int32_t
     return ransac_batch_impl(ctx, num_pairs, pair_ptr, u, v, sq_thresh, O, nullptr, E_out, R_out, inlier_mask, num_inliers, scores, stats);
 }
 
+// Every rank enters with the results of ITS pairs (ids = their global indices, lptr = their local CSR) and leaves with all of them: one sum
+// all-reduce of a zero-filled table [E 9 | R 9 | score | num_inliers | iterations | LO runs] per pair + the inlier masks packed 32 per double
+// (exact: one rank contributes each word) + an error flag, so that a rank whose local batch failed does not leave the others waiting.
+static int sharded_exchange(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pair_ptr, const std::vector<int>& ids, const std::vector<int>& lptr, int local_rc,
+                            const std::vector<double>& lE, const std::vector<double>& lR, const std::vector<double>& lS, const std::vector<uint8_t>& lmask,
+                            const std::vector<int>& lnin, const std::vector<uint32_t>& lst, double* E_out, double* R_out, uint8_t* inlier_mask, int32_t* num_inliers,
+                            double* scores, uint32_t* stats) {
+    const int nl = (int)ids.size();
+    // result table; every mask word belongs to exactly one pair's rank only if words do not straddle pairs: pack per pair
+    std::vector<size_t> wptr(num_pairs + 1, 0);
+    for (int p = 0; p < num_pairs; p++) wptr[p + 1] = wptr[p] + (size_t)(pair_ptr[p + 1] - pair_ptr[p] + 31) / 32;
+    const size_t per = 22, n_tab = per * num_pairs + wptr[num_pairs] + 1;              // + 1: the error flag
+    std::vector<double> tab(n_tab, 0.0);
+    tab[n_tab - 1] = (local_rc != SSFM_OK) ? 1.0 : 0.0;
+    if (local_rc == SSFM_OK) for (int i = 0; i < nl; i++) {
+        const int p = ids[i]; double* t = &tab[per * (size_t)p];
+        std::memcpy(t, &lE[9 * (size_t)i], 9 * sizeof(double)); std::memcpy(t + 9, &lR[9 * (size_t)i], 9 * sizeof(double));
+        t[18] = lS[i]; t[19] = (double)lnin[i]; t[20] = (double)lst[2 * (size_t)i]; t[21] = (double)lst[2 * (size_t)i + 1];
+        double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+        const int n = lptr[i + 1] - lptr[i];
+        for (int k = 0; k < n; k += 32) { uint32_t bits = 0; for (int q = 0; q < 32 && k + q < n; q++) bits |= (uint32_t)(lmask[lptr[i] + k + q] != 0) << q; w[k / 32] = (double)bits; }
+    }
+    const std::string local_err = ctx->err;
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> dtab;
+    SSFM_HIP_CHECK(ctx, upload(dtab, tab, ctx->stream));
+    { const int rc = ctx_allreduce(ctx, dtab.p, n_tab, ncclSum); if (rc) { dtab.free(); return rc; } }
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(tab.data(), dtab.p, n_tab * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    dtab.free();
+    if (local_rc != SSFM_OK) return fail(ctx, local_rc, local_err);
+    if (tab[n_tab - 1] != 0.0) return fail(ctx, SSFM_ERR_COMM, "ssfm_ransac_batch_*_sharded: the local batch of another rank failed");
+    for (int p = 0; p < num_pairs; p++) {
+        const double* t = &tab[per * (size_t)p];
+        if (E_out) std::memcpy(E_out + 9 * (size_t)p, t, 9 * sizeof(double));
+        if (R_out) std::memcpy(R_out + 9 * (size_t)p, t + 9, 9 * sizeof(double));
+        if (scores) scores[p] = t[18];
+        if (num_inliers) num_inliers[p] = (int32_t)t[19];
+        if (stats) { stats[2 * (size_t)p] = (uint32_t)t[20]; stats[2 * (size_t)p + 1] = (uint32_t)t[21]; }
+        if (inlier_mask) {
+            const double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+            const int n = pair_ptr[p + 1] - pair_ptr[p];
+            for (int k = 0; k < n; k++) inlier_mask[pair_ptr[p] + k] = (uint8_t)(((uint32_t)w[k / 32] >> (k % 32)) & 1u);
+        }
+    }
+    return SSFM_OK;
+}
+
+
 // Multi-GPU estimate_pairwise (BASELINE configs[3]): image pairs are independent, so rank r of the context's
 // communicator takes pairs r, r + nranks, ... (round robin keeps neighbouring-frame pairs, which have the most correspondences,
 // spread over the ranks), runs them as one local batch with the random streams of their global indices, and one sum all-reduce
@@ -470,44 +519,46 @@ extern "C" int ssfm_ransac_batch_sharded(ssfm_ctx* ctx, int32_t num_pairs, const
     }
     int local_rc = SSFM_OK;
     if (nl > 0) local_rc = ransac_batch_impl(ctx, nl, lptr.data(), lu.data(), lv.data(), sq_thresh, O, ids.data(), lE.data(), lR.data(), lmask.data(), lnin.data(), lS.data(), lst.data());
-    // result table; every mask word belongs to exactly one pair's rank only if words do not straddle pairs: pack per pair
-    std::vector<size_t> wptr(num_pairs + 1, 0);
-    for (int p = 0; p < num_pairs; p++) wptr[p + 1] = wptr[p] + (size_t)(pair_ptr[p + 1] - pair_ptr[p] + 31) / 32;
-    const size_t per = 22, n_tab = per * num_pairs + wptr[num_pairs] + 1;              // + 1: the error flag
-    std::vector<double> tab(n_tab, 0.0);
-    tab[n_tab - 1] = (local_rc != SSFM_OK) ? 1.0 : 0.0;
-    if (local_rc == SSFM_OK) for (int i = 0; i < nl; i++) {
-        const int p = ids[i]; double* t = &tab[per * (size_t)p];
-        std::memcpy(t, &lE[9 * (size_t)i], 9 * sizeof(double)); std::memcpy(t + 9, &lR[9 * (size_t)i], 9 * sizeof(double));
-        t[18] = lS[i]; t[19] = (double)lnin[i]; t[20] = (double)lst[2 * (size_t)i]; t[21] = (double)lst[2 * (size_t)i + 1];
-        double* w = &tab[per * (size_t)num_pairs + wptr[p]];
-        const int n = lptr[i + 1] - lptr[i];
-        for (int k = 0; k < n; k += 32) { uint32_t bits = 0; for (int q = 0; q < 32 && k + q < n; q++) bits |= (uint32_t)(lmask[lptr[i] + k + q] != 0) << q; w[k / 32] = (double)bits; }
-    }
-    const std::string local_err = ctx->err;
-    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    DevBuf<double> dtab;
-    SSFM_HIP_CHECK(ctx, upload(dtab, tab, ctx->stream));
-    { const int rc = ctx_allreduce(ctx, dtab.p, n_tab, ncclSum); if (rc) { dtab.free(); return rc; } }
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(tab.data(), dtab.p, n_tab * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    dtab.free();
-    if (local_rc != SSFM_OK) return fail(ctx, local_rc, local_err);
-    if (tab[n_tab - 1] != 0.0) return fail(ctx, SSFM_ERR_COMM, "ssfm_ransac_batch_sharded: the local batch of another rank failed");
+    return sharded_exchange(ctx, num_pairs, pair_ptr, ids, lptr, local_rc, lE, lR, lS, lmask, lnin, lst, E_out, R_out, inlier_mask, num_inliers, scores, stats);
+}
+
+// The same for the indexed form (per-frame feature rays + per-pair match lists: what estimate_pairwise holds, and 6x less host-to-device traffic):
+// every rank uploads the feature rays of all frames (2000 frames x 1000 rays = 48 MB at BASELINE configs[3]) and the match lists of ITS pairs.
+extern "C" int ssfm_ransac_batch_indexed_sharded(ssfm_ctx* ctx, int32_t num_frames, const int32_t* feat_ptr, const double* feat_rays, int32_t num_pairs,
+                                                 const int32_t* pair_frame0, const int32_t* pair_frame1, const int32_t* match_ptr, const int32_t* match_idx0,
+                                                 const int32_t* match_idx1, double sq_thresh, const ssfm_ransac_options* opt, double* E_out, double* R_out,
+                                                 uint8_t* inlier_mask, int32_t* num_inliers, double* scores, uint32_t* stats) {
+    if (!ctx) return SSFM_ERR_INVALID;
+    const int nr = ctx->collective ? ctx->nranks : 1, rk = ctx->collective ? ctx->rank : 0;
+    if (nr == 1 && !ctx->collective)
+        return ssfm_ransac_batch_indexed(ctx, num_frames, feat_ptr, feat_rays, num_pairs, pair_frame0, pair_frame1, match_ptr, match_idx0, match_idx1, sq_thresh, opt, E_out, R_out,
+                                         inlier_mask, num_inliers, scores, stats);
+    if (num_frames <= 0 || !feat_ptr || !feat_rays || num_pairs <= 0 || !pair_frame0 || !pair_frame1 || !match_ptr || !match_idx0 || !match_idx1)
+        return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed_sharded: bad arguments");
+    ssfm_ransac_options O; if (opt) O = *opt; else ssfm_ransac_default_options(&O);
+    // the checks every rank must agree on (the global list)
+    for (int f = 0; f < num_frames; f++) if (feat_ptr[f + 1] < feat_ptr[f]) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed_sharded: feat_ptr must ascend");
     for (int p = 0; p < num_pairs; p++) {
-        const double* t = &tab[per * (size_t)p];
-        if (E_out) std::memcpy(E_out + 9 * (size_t)p, t, 9 * sizeof(double));
-        if (R_out) std::memcpy(R_out + 9 * (size_t)p, t + 9, 9 * sizeof(double));
-        if (scores) scores[p] = t[18];
-        if (num_inliers) num_inliers[p] = (int32_t)t[19];
-        if (stats) { stats[2 * (size_t)p] = (uint32_t)t[20]; stats[2 * (size_t)p + 1] = (uint32_t)t[21]; }
-        if (inlier_mask) {
-            const double* w = &tab[per * (size_t)num_pairs + wptr[p]];
-            const int n = pair_ptr[p + 1] - pair_ptr[p];
-            for (int k = 0; k < n; k++) inlier_mask[pair_ptr[p] + k] = (uint8_t)(((uint32_t)w[k / 32] >> (k % 32)) & 1u);
-        }
+        const int f0 = pair_frame0[p], f1 = pair_frame1[p], c = match_ptr[p + 1] - match_ptr[p];
+        if (f0 < 0 || f0 >= num_frames || f1 < 0 || f1 >= num_frames || c < 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed_sharded: frame index out of range or match_ptr not ascending");
+        if (O.mode == SSFM_RANSAC_FIXED_BUDGET && (size_t)6 * c * sizeof(double) > 150 * 1024) return fail(ctx, SSFM_ERR_INVALID, "ssfm_ransac_batch_indexed_sharded: more than 3200 correspondences in one pair (fixed-budget mode)");
     }
-    return SSFM_OK;
+    std::vector<int> ids, lptr(1, 0), lf0, lf1;
+    for (int p = rk; p < num_pairs; p += nr) { ids.push_back(p); lptr.push_back(lptr.back() + match_ptr[p + 1] - match_ptr[p]); lf0.push_back(pair_frame0[p]); lf1.push_back(pair_frame1[p]); }
+    const int nl = (int)ids.size(), ltotal = lptr.back();
+    std::vector<int> li0(std::max(ltotal, 1)), li1(std::max(ltotal, 1));
+    for (int i = 0; i < nl; i++) {
+        const size_t src = (size_t)match_ptr[ids[i]], cnt = (size_t)(lptr[i + 1] - lptr[i]);
+        if (cnt) { std::memcpy(&li0[lptr[i]], match_idx0 + src, cnt * sizeof(int)); std::memcpy(&li1[lptr[i]], match_idx1 + src, cnt * sizeof(int)); }
+    }
+    std::vector<double> lE((size_t)9 * nl), lR((size_t)9 * nl), lS(nl);
+    std::vector<uint8_t> lmask(std::max(ltotal, 1)); std::vector<int> lnin(nl); std::vector<uint32_t> lst((size_t)2 * nl);
+    int local_rc = SSFM_OK;
+    if (nl > 0) {
+        const RansacIndexed X{num_frames, feat_ptr, feat_rays, lf0.data(), lf1.data(), li0.data(), li1.data()};
+        local_rc = ransac_batch_impl(ctx, nl, lptr.data(), nullptr, nullptr, sq_thresh, O, ids.data(), lE.data(), lR.data(), lmask.data(), lnin.data(), lS.data(), lst.data(), &X);
+    }
+    return sharded_exchange(ctx, num_pairs, match_ptr, ids, lptr, local_rc, lE, lR, lS, lmask, lnin, lst, E_out, R_out, inlier_mask, num_inliers, scores, stats);
 }
 
 // parity probe: the minimal solver on given 3-point samples.  Es: [S*36] (4 column-major 3x3 per sample), counts: [S]

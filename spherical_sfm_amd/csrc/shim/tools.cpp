@@ -113,7 +113,7 @@ int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::ve
     O.min_num_inliers = min_num_inliers; O.inward = inward ? 1 : 0; O.final_least_squares = 1;                                 // :316-318
     const int P = (int)cand.size();
     std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(std::max<size_t>(1, m0.size())); std::vector<int32_t> nin(P);
-    if (ssfm_ransac_batch_indexed(ctx, nf, feat_ptr.data(), rays.data(), P, pf0.data(), pf1.data(), pair_ptr.data(), m0.data(), m1.data(), sq_thresh, &O, nullptr, R.data(),
+    if (ssfm_ransac_batch_indexed_sharded(ctx, nf, feat_ptr.data(), rays.data(), P, pf0.data(), pf1.data(), pair_ptr.data(), m0.data(), m1.data(), sq_thresh, &O, nullptr, R.data(),
                                   mask.data(), nin.data(), nullptr, nullptr) != SSFM_OK) {
         std::cout << "error: " << ssfm_last_error(ctx) << "\n"; std::exit(1);
     }

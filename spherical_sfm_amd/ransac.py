@@ -49,8 +49,9 @@ def estimate_flat(ctx, pair_ptr, U, V, squared_inlier_threshold, options=None, s
     return dict(E=_unflat(E), R=_unflat(R), mask=mask[:int(ptr[-1])], num_inliers=nin, scores=sc, iterations=st[0::2].copy(), lo_runs=st[1::2].copy())
 
 
-def estimate_indexed(ctx, feat_ptr, feat_rays, pair_frame0, pair_frame1, match_ptr, match_idx0, match_idx1, squared_inlier_threshold, options=None, **kw):
-    """ssfm_ransac_batch_indexed: per-frame feature rays (feat_rays[feat_ptr[f] + k]) and per-pair match lists instead of materialised ray pairs."""
+def estimate_indexed(ctx, feat_ptr, feat_rays, pair_frame0, pair_frame1, match_ptr, match_idx0, match_idx1, squared_inlier_threshold, options=None, sharded=False, **kw):
+    """ssfm_ransac_batch_indexed: per-frame feature rays (feat_rays[feat_ptr[f] + k]) and per-pair match lists instead of materialised ray pairs.
+    sharded=True: ssfm_ransac_batch_indexed_sharded (pairs round robin over the ranks of the context's communicator, every rank gets every result)."""
     fp = np.ascontiguousarray(feat_ptr, np.int32); fr = np.ascontiguousarray(feat_rays, np.float64)
     f0 = np.ascontiguousarray(pair_frame0, np.int32); f1 = np.ascontiguousarray(pair_frame1, np.int32)
     mp = np.ascontiguousarray(match_ptr, np.int32); m0 = np.ascontiguousarray(match_idx0, np.int32); m1 = np.ascontiguousarray(match_idx1, np.int32)
@@ -58,7 +59,8 @@ def estimate_indexed(ctx, feat_ptr, feat_rays, pair_frame0, pair_frame1, match_p
     P = len(mp) - 1
     E = np.zeros(9 * P); R = np.zeros(9 * P); mask = np.zeros(max(int(mp[-1]), 1), np.uint8); nin = np.zeros(P, np.int32); sc = np.zeros(P)
     st = np.zeros(2 * P, np.uint32)
-    _lib.check(_lib.lib().ssfm_ransac_batch_indexed(ctx._p, len(fp) - 1, fp.ctypes.data_as(c_i32_p), fr.ctypes.data_as(c_double_p), P,
+    fn = _lib.lib().ssfm_ransac_batch_indexed_sharded if sharded else _lib.lib().ssfm_ransac_batch_indexed
+    _lib.check(fn(ctx._p, len(fp) - 1, fp.ctypes.data_as(c_i32_p), fr.ctypes.data_as(c_double_p), P,
                                                    f0.ctypes.data_as(c_i32_p), f1.ctypes.data_as(c_i32_p), mp.ctypes.data_as(c_i32_p),
                                                    m0.ctypes.data_as(c_i32_p), m1.ctypes.data_as(c_i32_p), C.c_double(squared_inlier_threshold), C.byref(o),
                                                    E.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p), mask.ctypes.data_as(c_u8_p),

@@ -8,6 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -37,6 +38,16 @@ def main():
         o = ransac.estimate_pairs(ctx, pairs, (2 / 600) ** 2, sharded=True, min_num_inliers=12, num_hypotheses=256, mode=int(os.environ.get("RANSAC_MODE", "1")))
         np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=np.concatenate(o["inliers"]),
                  iterations=o["iterations"], lo_runs=o["lo_runs"])
+        if mode == "host":
+            dist.barrier(); dist.destroy_process_group()
+        return
+    if len(sys.argv) > 5 and sys.argv[5] == "ransac_indexed":
+        # ssfm_ransac_batch_indexed_sharded: per-frame feature rays + per-pair match lists, pairs round robin over the ranks
+        from spherical_sfm_amd import ransac
+        import _pairwise_frames
+        a = _pairwise_frames.indexed_problem()
+        o = ransac.estimate_indexed(ctx, *a, (2 / 600) ** 2, sharded=True, min_num_inliers=12)
+        np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=o["mask"], iterations=o["iterations"], lo_runs=o["lo_runs"])
         if mode == "host":
             dist.barrier(); dist.destroy_process_group()
         return

@@ -85,6 +85,23 @@ def test_sharded_pair_batch_is_bit_identical(gpu_ctx, tmp_path, mode, world, rmo
         assert np.array_equal(r["iterations"], ref["iterations"]) and np.array_equal(r["lo_runs"], ref["lo_runs"])
 
 
+@pytest.mark.parametrize("mode,world", [("host", 2), ("host", 3), ("rccl1", 1)])
+def test_sharded_indexed_pair_batch_is_bit_identical(gpu_ctx, tmp_path, mode, world):
+    """ssfm_ransac_batch_indexed_sharded (what the C++ estimate_pairwise calls): per-frame feature rays + match lists, pairs round robin over the ranks,
+    every rank ends with exactly the single-GPU ssfm_ransac_batch_indexed results."""
+    from spherical_sfm_amd import ransac
+    import _pairwise_frames
+    a = _pairwise_frames.indexed_problem()
+    ref = ransac.estimate_indexed(gpu_ctx, *a, (2 / 600) ** 2, min_num_inliers=12)
+    env = {"SSFM_COMM_SINGLE_RANK": "1"} if mode == "rccl1" else {}
+    res = _run(mode, world, str(tmp_path / "pi"), False, True, env, task="ransac_indexed")
+    assert (ref["num_inliers"] > 12).sum() >= 6
+    for r in res:
+        assert np.array_equal(r["E"], ref["E"]) and np.array_equal(r["R"], ref["R"]) and np.array_equal(r["scores"], ref["scores"])
+        assert np.array_equal(r["num_inliers"], ref["num_inliers"]) and np.array_equal(r["mask"], ref["mask"])
+        assert np.array_equal(r["iterations"], ref["iterations"]) and np.array_equal(r["lo_runs"], ref["lo_runs"])
+
+
 def test_weak_scaling_shape_two_ranks(gpu_ctx, tmp_path):
     """The problem shape of `bench.py --gpus 2` (weak scaling: 600 cameras = 8 twisted rings of 75), two ranks sharing GPU 0."""
     prob = synth.make_circle(600, 24000, 6, spherical=False, focal_fixed=True, seed=21)

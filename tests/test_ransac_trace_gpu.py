@@ -156,9 +156,10 @@ def test_trace_mode_reproduces_the_oracle_pair_by_pair(gpu_ctx, oracle):
         assert out["num_inliers"][k] == out["inliers"][k].sum()
         assert abs(out["scores"][k] - o["score"]) <= 1e-9 * o["score"] or not all(res[-1])
     res = np.array(res)
-    # identical sample trace, identical inlier flags, E / R to 1e-7: everywhere, up to one pair where a rounding-level difference of a
-    # score may pick the other of two near-equal models
-    assert res[:, 0].mean() >= 0.98 and res[:, 1].mean() >= 0.98 and res[:, 2].mean() >= 0.98, res.mean(axis=0)
+    # identical sample trace, identical inlier flags, E / R to 1e-9 on EVERY pair: with these options the only floating-point work between two
+    # decisions is a minimal solve + a score, or one 6-parameter least-squares fit, and each of those agrees with the oracle to ~1e-10
+    # (scripts/dbg_trace_mismatch.py: 0 differing pairs of 256 on MI355X); the kernel has no atomics, so this does not vary from run to run
+    assert res.all(), (res.mean(axis=0), np.nonzero(~res.all(1))[0])
     assert (out["iterations"] >= 100).all() and (out["lo_runs"] >= 1).all()
 
 
@@ -175,9 +176,24 @@ def test_trace_mode_with_local_optimization_steps(gpu_ctx, oracle, poly):
         res.append(_compare(out, k, o, u, v, oracle, tol=1e-8))
         assert rot_err(R, out["R"][k]) < 5e-3
     res = np.array(res)
-    # dozens of least-squares fits per pair, each stopped by Ceres' tolerances: a rounding-level difference can flip one stopping
-    # decision, after which that pair's models differ at the 1e-5 level (still the same inliers); allow a few such pairs
-    assert res[:, 0].mean() >= 0.9 and res[:, 1].mean() >= 0.85 and res[:, 2].mean() >= 0.85, res.mean(axis=0)
+    # Where a pair leaves the oracle's trace, find out WHY: replay the oracle's own call log on the device, call by call (same ray subset, same start
+    # model), and name the first call whose output differs.  Measured on MI355X (scripts/dbg_lsq_replay.py: 6528 LeastSquares calls): no
+    # Levenberg-Marquardt stopping rule ever flips -- every fit has the oracle's iteration count and agrees to ~1e-9.  What differs is
+    # NonMinimalSolver on an ill-conditioned 4..9-ray sample (the 6x6 elimination + companion roots amplify rounding to 1e-6 and more,
+    # test_nonminimal_solver_probe_matches_oracle); the next GetInliers then admits a different ray and the runs part ways.
+    for k in np.nonzero(~res.all(1))[0]:
+        u, v = probs[k][0], probs[k][1]
+        _, log = oracle.lsq_log(lambda: oracle.lomsac_pair(u, v, THR, num_lo_steps=10, num_lsq_iterations=4, final_least_squares=False, min_num_inliers=20, use_poly=poly))
+        nm = oracle.lsq_log.nonminimal
+        Eg, x, it, status, c0, c1 = ransac.sampson_refine_probe_ex(gpu_ctx, u, v, [l["sample"] for l in log], [l["E_in"] for l in log], wave=True)
+        lsq_bad = [i for i, l in enumerate(log) if frob_err(Eg[i], l["E_out"]) > 1e-8 or it[i] != l["iterations"]]
+        ok, En = ransac.nonminimal_probe(gpu_ctx, u, v, [m["sample"] for m in nm])
+        nm_err = np.array([frob_err(e, m["E_out"]) for e, m in zip(En, nm)])
+        print(f"pair {k}: {len(log)} LeastSquares calls, {len(lsq_bad)} differ (> 1e-8 or other iteration count); {len(nm)} NonMinimalSolver calls, "
+              f"errors max {nm_err.max():.2e}, > 1e-9: {(nm_err > 1e-9).sum()}")
+        assert not lsq_bad, (k, lsq_bad[:5])                        # never a flipped stopping rule
+        assert (nm_err > 1e-10).any()                               # the divergence starts in a non-minimal solve
+    assert res[:, 0].mean() >= 0.95 and res[:, 1].mean() >= 0.95 and res[:, 2].mean() >= 0.95, res.mean(axis=0)
 
 
 def test_fast_shuffle_is_the_same_stream(gpu_ctx):
@@ -280,3 +296,46 @@ def test_indexed_entry_point_equals_materialised_rays(gpu_ctx):
     bad = m0.copy(); bad[5] = 10 ** 6
     with pytest.raises(_lib.SsfmError):
         ransac.estimate_indexed(gpu_ctx, feat_ptr, rays, f0, f1, mp, bad, m1, thr)
+
+
+def test_configs3_full_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[3] at its full size on one GPU: the 1 999 000 image pairs of a 2000-frame exhaustive circle x 500 correspondences (SURVEY 8d:
+    30 % outliers, noise 1 px / f, threshold (2 px / f)^2, f = 1000) through ssfm_ransac_batch_indexed -- per-frame feature rays once, 8 bytes of match
+    indices per correspondence.  The pair list cycles through 2000 distinct relative-pose problems (frame k = problem k), which gives the
+    size-independent properties: every pair is accepted and its rotation sits within the noise of the generating one; equal inputs give
+    bit-equal outputs wherever they sit in the stream of slabs; 200 sampled pairs equal the oracle's run (same trace)."""
+    import time
+    from spherical_sfm_amd import ransac
+    F = 1000.0; thr = (2 / F) ** 2; NC = 500; POOL = 2000; TOTAL = 1999000; PER = 100000
+    probs = [synth.make_relative_pose_problem(NC, seed=1000 + k, noise=1 / F, outlier_frac=0.3, rotation_deg=1 + (k % 60)) for k in range(POOL)]
+    feat_ptr = (np.arange(POOL + 1, dtype=np.int64) * 2 * NC).astype(np.int32)
+    feat_rays = np.ascontiguousarray(np.concatenate([np.concatenate([p[0], p[1]]) for p in probs]))
+    ptr = (np.arange(PER + 1, dtype=np.int64) * NC).astype(np.int32)
+    m0 = np.tile(np.arange(NC, dtype=np.int32), PER); m1 = m0 + NC
+    first = None; done = 0; t0 = time.perf_counter(); accepted = 0
+    while done < TOTAL:
+        n = min(PER, TOTAL - done)
+        fr = ((done + np.arange(n)) % POOL).astype(np.int32)
+        o = ransac.estimate_indexed(gpu_ctx, feat_ptr, feat_rays, fr, fr, ptr[:n + 1], m0[:n * NC], m1[:n * NC], thr, min_num_inliers=20)
+        accepted += int((o["num_inliers"] > 20).sum())
+        if first is None:
+            first = {k: o[k][:POOL].copy() for k in ("E", "R", "num_inliers", "scores", "iterations", "lo_runs")}
+            first["mask"] = o["mask"][:POOL * NC].copy()
+        # determinism across the whole stream: pair p repeats problem p mod 2000 with the same random streams
+        for key in ("E", "R", "num_inliers", "scores", "iterations", "lo_runs"):
+            assert np.array_equal(o[key], first[key][fr]), (key, done)
+        if done == 0 or done + n == TOTAL:
+            assert np.array_equal(o["mask"].reshape(n, NC), first["mask"].reshape(POOL, NC)[fr])
+        done += n
+    dt = time.perf_counter() - t0
+    assert accepted == TOTAL
+    errs = np.array([rot_err(probs[k][2], first["R"][k]) for k in range(POOL)])
+    assert errs.max() < 5e-3 and np.median(errs) < 5e-4, (errs.max(), np.median(errs))
+    inl_gt = np.array([p[4] for p in probs])
+    agree = (first["mask"].reshape(POOL, NC).astype(bool) == inl_gt).mean()
+    assert agree > 0.95, agree             # the 2 px threshold at 1 px noise cuts the tail of the true inliers (0.966 measured)
+    for k in range(0, POOL, 10):                                   # 200 pairs against the oracle: same trace, same flags, same rotation
+        r = oracle.lomsac_pair(probs[k][0], probs[k][1], thr, min_num_inliers=20)
+        assert r["iterations"] == first["iterations"][k] and r["lo_runs"] == first["lo_runs"][k] and r["num_inliers"] == first["num_inliers"][k], k
+        assert np.array_equal(r["inliers"], first["mask"].reshape(POOL, NC)[k].astype(bool)) and rot_err(r["R"], first["R"][k]) <= 1e-9, k
+    print(f"configs[3]: {TOTAL} pairs in {dt:.2f} s ({TOTAL / dt:.3e} pairs/s incl. the checks)")
