@@ -18,6 +18,8 @@ LM iteration.  Default ("strong"): BASELINE.json's metric is THIS 300-camera pro
 fixed and is sharded N ways; the reduced solve is replicated (about half of an N = 1 iteration), which caps the speed-up
 near 2x -- that is what the line reports.  The same JSON line also carries `configs4_sharded`: the BASELINE
 configs[4] problem (4000 cameras / 1.5 M points / 12 M observations, the 8-GPU config) sharded over the same N ranks.
+For N > 1 the line also carries `pairwise_sharded`: BASELINE configs[3] (1 999 000 image pairs x 500 correspondences) over the same N ranks.
+At N = 1 `roofline_configs4` prices every data-parallel kernel at the configs[4] SIZE (12 M observations on this one GPU: SURVEY 8d's "real HBM test").
 `--scaling weak` (opt-in): the circle grows with the job instead -- N x 300 cameras / N x 100k points / N x 600k observations
 from the same generator rule (stride round(Nc/75), i.e. 4N rings of 75 cameras), every rank keeps 600k observations.
 """
@@ -40,6 +42,42 @@ def pair_kernel_flops(pairs):
     (reprojection + analytic 2x6 camera / 2x3 point blocks, ~150 flop each) and the DCxDC block update through the 2x2 core
     Jc_i^T (Jp_i Vs Jp_j^T) Jc_j (126 multiply-adds = 252 flop at DC = 6)."""
     return pairs * (2 * 150.0 + 252.0)
+
+
+PAIR_USEFUL_FLOP = 252.0       # the DCxDC block update through the 2x2 core: 126 multiply-adds at DC = 6 (DESIGN.md 4)
+PAIR_RELIN_FLOP = 2 * 150.0    # what the kernel spends on top: both observations of a pair are re-linearised (each observation K - 1 times per iteration)
+
+
+def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1):
+    """Per-kernel HBM fractions of the data-parallel kernels of one LM iteration from their hipEvent durations (SURVEY 8d algorithmic bytes, split per
+    pass as DESIGN.md 4 states them), and the pair kernel against the FP64 vector peak by USEFUL flops next to the modelled total."""
+    per = {
+        # lane per point: pixels 16 + camera ids 8 per observation; X 24 + Jacobi scales 24 read, record PS 96 + g_p 24 written per point
+        "k_point_lin": 24.0 * M + 168.0 * nP,
+        # diagonal blocks / J_c^T r: pixels + ids per observation, X + PS per point, diagonal S blocks + rhs written
+        "k_cam_sums2": 24.0 * M + 120.0 * nP + Nc * (dc * dc + dc) * 8.0,
+        "k_schur_pairs2": pair_kernel_bytes(M, nP, nnzb, Nc, dc),
+        # back substitution + candidate + both costs in one sweep: pixels + ids per observation; X, PS, g_p read, candidate X written per point
+        "k_point_backsub": 24.0 * M + 168.0 * nP,
+    }
+    out = {}
+    for k, b in per.items():
+        us = kern.get(k, {}).get("avg_us")
+        if us is None or not us == us:
+            continue
+        b = b / world
+        out[k] = {"avg_us": us, "launches_per_lm_iteration": kern[k]["launches"] / max(1, n_lm), "algorithmic_bytes_per_launch": b,
+                  "achieved_GBs": b / (us * 1e-6) / 1e9, "frac_hbm": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    us = kern.get("k_schur_pairs2", {}).get("avg_us")
+    if us is not None and us == us:
+        p = pairs / world
+        out["k_schur_pairs2"]["fp64_vector"] = {
+            "pairs_per_launch": p, "useful_flop_per_pair": PAIR_USEFUL_FLOP, "modelled_flop_per_pair": PAIR_USEFUL_FLOP + PAIR_RELIN_FLOP,
+            "useful_TFLOPs": p * PAIR_USEFUL_FLOP / (us * 1e-6) / 1e12, "useful_frac": p * PAIR_USEFUL_FLOP / (us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "modelled_TFLOPs": p * (PAIR_USEFUL_FLOP + PAIR_RELIN_FLOP) / (us * 1e-6) / 1e12,
+            "modelled_frac": p * (PAIR_USEFUL_FLOP + PAIR_RELIN_FLOP) / (us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "note": "flop counts are a hand model of the kernel's arithmetic (DESIGN.md 4), not a counter; durations are measured"}
+    return out
 
 
 def algorithmic_bytes(M, nP, nnzb, dc, focal_free):
@@ -118,6 +156,8 @@ def main():
                          "exercises the sharded path on a 1-GPU box; not a performance configuration)")
     ap.add_argument("--no-side-paths", action="store_true", help="skip the pairwise-RANSAC and rotation-averaging side measurements (N = 1)")
     ap.add_argument("--no-configs4", action="store_true", help="N > 1: skip the configs[4] problem sharded over the N ranks")
+    ap.add_argument("--no-pairwise", action="store_true", help="N > 1: skip BASELINE configs[3] (exhaustive pairwise RANSAC) sharded over the N ranks")
+    ap.add_argument("--pairwise-pairs", type=int, default=1999000, help="N > 1: image pairs of the pairwise_sharded leg (default: the 2000-frame exhaustive circle)")
     args = ap.parse_args()
 
     import numpy as np
@@ -228,6 +268,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.cameras} cams x {args.points} pts x {M} obs synthetic circle (BASELINE configs[1]" + (f" x {world}" if world > 1 and args.scaling == "weak" else "") + "), "
                                    f"{args.mode} BA, focal {'free' if args.focal_free else 'fixed'}, CauchyLoss(1.0), Ceres-default LM",
+                       "reduced_solver": "exact block-banded Cholesky in Cuthill-McKee order (direct, like the reference's SPARSE_SCHUR); the PCG of the metric's name is a "
+                                         f"refinement that did not run: {s.get('pcg_iterations_total', 0)} sweeps in the last step",
                        "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}", "comm": ("none" if world == 1 else ("host-staged gloo (test configuration)" if host_comm else "rccl"))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -236,9 +278,15 @@ def main():
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
             # HBM is not what bounds this kernel (the working set is cache resident and the traffic is 5 % of peak): its arithmetic against the FP64 vector peak
             "roofline_compute": {"bound": "fp64-vector", "kernel": dom, "pairs_per_launch": pairs / world, "flop_per_pair": pair_kernel_flops(1),
+                                 "flop_source": "modelled (hand count of the kernel's arithmetic: 2 re-linearisations x 150 + 252 for the block update), not a counter",
                                  "achieved": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
                                  "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None},
+                                 "frac": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None,
+                                 # by USEFUL work: each observation is re-linearised K - 1 times per iteration; only the 252-flop block update is work the algorithm asks for
+                                 "useful_flop_per_pair": PAIR_USEFUL_FLOP,
+                                 "useful_achieved": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
+                                 "useful_frac": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None},
+            "roofline_per_kernel": kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
             # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
             "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4, "source": f"committed profile {PMC_PROFILE} (SQ_INSTS_VALU), not measured in this run",
@@ -307,6 +355,22 @@ def main():
                 "workload": "4000 cams x 1500000 pts x 12000000 obs, general BA, focal fixed", "value": sb["num_residual_blocks"] * nb / tb, "unit": "obs/s",
                 "ms_per_solve": 1e3 * tb / 2, "lm_iterations": sb["num_linearizations"], "band_half_width": sb["band_half_width"],
                 "factorisation_workgroups": sb["band_segments"], "separators": sb["band_separators"]}
+            # "treat config 5 as the real HBM test" -- the working set (1.2 GB touched per iteration) does not fit the 256 MB Infinity Cache.
+            # One more solve with every launch bracketed by hipEvents on the solver's stream: per-kernel HBM fractions and the pair kernel by useful flops.
+            adj.set_profiling(True); adj.reset(); sq = adj.run(); kb = adj.kernel_times(); adj.set_profiling(False)
+            kernb = {k: {"launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / max(1, v["launches"])} for k, v in kb.items()}
+            Mb = int(sq["num_residual_blocks"]); nlb = sq["num_linearizations"]
+            kkb = np.bincount(big.obs_pt, minlength=1500000).astype(np.float64); kkb = kkb[kkb >= 3]
+            per_iter_b, _ = algorithmic_bytes(Mb, 1500000, sq["reduced_blocks"], sq["camera_dof"], False)
+            iter_ms_b = 1e3 * tb / max(1, nb)
+            gpu_ms = sum(v["total_ms"] for v in kb.values()) / max(1, nlb)
+            out["roofline_configs4"] = {
+                "workload": "BASELINE configs[4] SIZE on one GPU: 4000 cams x 1500000 pts x 12000000 obs (8 observations per point), general BA, focal fixed",
+                "lm_iteration": {"algorithmic_bytes": per_iter_b, "avg_ms_wall": iter_ms_b, "achieved_GBs": per_iter_b / (iter_ms_b * 1e-3) / 1e9,
+                                 "frac_hbm": per_iter_b / (iter_ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_iteration_profiled": gpu_ms},
+                "kernels": kernel_rooflines(kernb, Mb, 1500000, sq["reduced_blocks"], 4000, sq["camera_dof"], float((kkb * (kkb - 1) / 2).sum()), nlb),
+                "all_kernels_avg_us": {k: v["avg_us"] for k, v in kernb.items()},
+                "share_of_gpu_time": {k: v["total_ms"] / max(1e-12, sum(w["total_ms"] for w in kb.values())) for k, v in kb.items()}}
     if world > 1 and not args.no_configs4 and not spherical and not args.focal_free and args.cameras == 300 and args.scaling == "strong":
         # BASELINE configs[4] (the 8-GPU config): 4000 cameras / 1.5 M points / 12 M observations sharded over the N ranks of this job
         adj.close()
@@ -324,6 +388,30 @@ def main():
                 "n_gpus": world, "scaling": "strong", "value": sb["num_residual_blocks_global"] * nb / tb, "unit": "obs/s", "ms_per_solve": 1e3 * tb / 2,
                 "lm_iterations": sb["num_linearizations"], "observations_this_rank": sb["num_residual_blocks"], "band_half_width": sb["band_half_width"],
                 "factorisation_workgroups": sb["band_segments"], "separators": sb["band_separators"]}
+    if world > 1 and not args.no_pairwise:
+        # BASELINE configs[3] ("2000-frame circle, exhaustive pairwise spherical_estimator RANSAC batched across 4 x MI355X"): the 1 999 000 image
+        # pairs x 500 correspondences over the N ranks of this job through ssfm_ransac_batch_indexed_sharded -- every rank passes the same pair list,
+        # estimates pairs r, r + N, ... and one all-reduce per call of 100 000 pairs hands every rank every result (no other exchange).
+        from spherical_sfm_amd import ransac
+        Fp = 1000.0; NCp = 500; POOL = 2000; TOTAL = args.pairwise_pairs; PER = 100000
+        pool = [synth.make_relative_pose_problem(NCp, seed=1000 + k, noise=1 / Fp, outlier_frac=0.3, rotation_deg=1 + (k % 60)) for k in range(POOL)]
+        feat_ptr = (np.arange(POOL + 1, dtype=np.int64) * 2 * NCp).astype(np.int32)
+        feat_rays = np.ascontiguousarray(np.concatenate([np.concatenate([q[0], q[1]]) for q in pool]))
+        pptr = (np.arange(PER + 1, dtype=np.int64) * NCp).astype(np.int32); pm0 = np.tile(np.arange(NCp, dtype=np.int32), PER); pm1 = pm0 + NCp
+        def pw_call(first, n):
+            fr = ((first + np.arange(n)) % POOL).astype(np.int32)
+            return ransac.estimate_indexed(ctx, feat_ptr, feat_rays, fr, fr, pptr[:n + 1], pm0[:n * NCp], pm1[:n * NCp], (2 / Fp) ** 2, sharded=True, min_num_inliers=20)
+        pw_call(0, 2000 * world)                                                  # warm-up: module load, pinned staging buffers, the communicator
+        barrier(); tp = time.perf_counter(); done = 0; acc = 0
+        while done < TOTAL:
+            n = min(PER, TOTAL - done); o = pw_call(done, n); acc += int((o["num_inliers"] > 20).sum()); done += n
+        barrier(); tp = time.perf_counter() - tp
+        t = torch.tensor([tp], dtype=torch.float64, device="cpu" if host_comm else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); tp = float(t.item())
+        if rank == 0:
+            out["pairwise_sharded"] = {
+                "workload": f"BASELINE configs[3]: {TOTAL} image pairs x {NCp} correspondences (30 % outliers, 1 px noise at f = 1000), reference-trace LO-MSAC, "
+                            f"ssfm_ransac_batch_indexed_sharded: pairs round robin over the ranks, host buffers in, every result on every rank (one all-reduce per {PER} pairs)",
+                "n_gpus": world, "scaling": "strong", "value": TOTAL / tp, "unit": "pairs/s", "seconds": tp, "accepted_pairs": acc, "includes_pcie": True}
     if rank == 0:
         print(json.dumps(out))
     adj.close(); ctx.close()

@@ -81,7 +81,11 @@ typedef struct {
     int32_t loss_type;                         /* 0 trivial, 1 Cauchy, 2 SoftLOne; default 1 */
     double loss_scale;                         /* 1.0 */
     int32_t jacobi_scaling;                    /* 1 */
-    /* reduced-camera-system solver (the reference uses a direct sparse Cholesky; this build uses PCG) */
+    /* reduced-camera-system solver.  The reference solves it directly (SPARSE_SCHUR: sparse Cholesky, src/sfm.cpp:205) and so does this build by
+     * default: an exact block-banded Cholesky in Cuthill-McKee order (twisted / substructured for long components).  The PCG of
+     * north_star survives as a REFINEMENT that runs only when |rhs - S y| > pcg_tolerance |rhs| after the direct solve -- never observed, 0 sweeps in
+     * every measured solve -- and as the block-Jacobi comparison solver (preconditioner = 1).  The "pcg" in field names below is historical: they time
+     * and count the reduced solve, whichever solver ran. */
     int32_t pcg_max_iterations;                /* 1000 */
     double pcg_tolerance;                      /* |r| <= tol |b|, default 1e-10 (tracks a direct solve) */
     int32_t preconditioner;                    /* 0: block-banded Cholesky (exact on the Cuthill-McKee band) + PCG
@@ -101,7 +105,7 @@ typedef struct {
     int32_t num_points_used;
     int32_t camera_dof;           /* 3 = spherical (all translations fixed), 6 = general */
     double t_flatten_s, t_upload_s, t_solve_s, t_download_s;   /* host wall-clock */
-    double t_kernel_linearize_ms, t_kernel_schur_ms, t_kernel_pcg_ms, t_kernel_update_ms; /* hipEvent sums */
+    double t_kernel_linearize_ms, t_kernel_schur_ms, t_kernel_pcg_ms, t_kernel_update_ms; /* hipEvent sums; "pcg" = the reduced solve (banded Cholesky + back substitution) */
     int32_t reduced_blocks;       /* non-zero DCxDC blocks of the reduced camera system */
     int32_t band_half_width;      /* block half-bandwidth of S in the Cuthill-McKee order */
     int32_t band_segments;        /* workgroups of the reduced-system factorisation: connected components, long ones cut */
