@@ -467,8 +467,10 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
 // the back edge), loads are unconditional from clamped indices (padding lanes carry a zero weight), the point index rides in
 // the pair list (one dependent load less) and the Jacobi point scales are pre-folded into Vs.  Blocks are folded across the
 // wave at every slot change and added to S with global atomics (a few dozen per task).
-template <int DC>
-__global__ void __launch_bounds__(256, (DC == 3) ? 3 : 2)
+// OCC = waves per SIMD the register allocation is held to (EXPERIMENT, VERDICT r2 #6a: SSFM_PAIRS_OCC3=1 runs the 6-dof kernel at 3 waves per
+// SIMD, i.e. <= 168 VGPRs instead of 224; profiles/r03_notes.md has the measurement)
+template <int DC, int OCC = ((DC == 3) ? 3 : 2)>
+__global__ void __launch_bounds__(256, OCC)
 k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ row_ptr,
                const int* __restrict__ col_idx, const int* __restrict__ task_cam, const int* __restrict__ task_b0,

@@ -137,6 +137,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         }
         if (!F.chunk_cam.empty()) {
             const int ntasks = (int)F.chunk_cam.size();
+            static const bool occ3 = std::getenv("SSFM_PAIRS_OCC3") && std::atoi(std::getenv("SSFM_PAIRS_OCC3")) != 0;      // experiment (ba_kernels.h)
+            if (occ3 && DC == 6)
+                LAUNCH(h, KID_SCHUR_ROWS, (k_schur_pairs2<DC, 3>), (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
+                       h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
+            else
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
