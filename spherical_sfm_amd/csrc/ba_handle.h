@@ -98,6 +98,7 @@ struct ssfm_ba_handle {
     // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
     struct { bool on = false, residual_later = false; const double *cam = nullptr, *focal = nullptr; double *cam_c = nullptr, *focal_c = nullptr, *rot_c = nullptr; } tail;
     int pcg_prev_iters = 16;
+    bool external_tail = false;          // the caller runs its own focal arrow / residual check after the direct solve (rotavg_solver.hip: k_rot_step, k_rot_eval)
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -447,6 +448,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     }
     h->band_filled = false;
     { const int rc = direct(h->Yb.p); if (rc) return rc; }
+    if (h->external_tail) { *iters_out = 0; *ok_out = true; return SSFM_OK; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
     if (F.sym_lower && h->tail.on) {
         const int phi_parts = !F.focal_free ? -1 : (Nc > 1024 ? std::min(64, (n + 2047) / 2048) : 0);      // -1: focal fixed, the arrow is empty (pqpart: Nc doubles, only used by the PCG mat-vec)

@@ -132,7 +132,7 @@ k_rot_edges(int mode, int kind, int E, const int* __restrict__ e0, const int* __
 
 __global__ void __launch_bounds__(64)
 k_rot_cost(int kind, int E, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
-           const double* __restrict__ x, const double* __restrict__ fm, double* __restrict__ out) {
+           const double* __restrict__ x, const double* __restrict__ fm, double* __restrict__ out, double* __restrict__ part = nullptr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double c = 0.0;
     if (e < E) {
@@ -143,13 +143,257 @@ k_rot_cost(int kind, int E, const int* __restrict__ e0, const int* __restrict__ 
         c = 0.5 * rho0;
     }
     c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) { if (part) part[blockIdx.x] = c; else unsafeAtomicAdd(out, c); }     // part: one slot per workgroup, summed in order by the reader
+}
+
+enum { SC_GDELTA = 14, SC_DMAX = 15 };      // scalar slots of the line search of bounded problems (k_rot_update / k_rot_step)
+
+// ---- deterministic assembly (round 3): node-major gather instead of edge-major scatter ------------------------------------------------
+// k_rot_edges adds every edge's 3x3 blocks into S with global fp64 atomics, so the last bits of S -- and, near a tolerance, the iteration count of a
+// 2000-node solve -- varied from run to run.  Here ONE WAVE owns a node: lane l evaluates incident edge l of its node (each edge is evaluated by both of its
+// ends: the same instructions on the same inputs, hence bit-identical Jacobians and a bit-symmetric S), the diagonal block, J^T r, the focal border and
+// the column norms are summed over the wave by a butterfly (fixed order), every off-diagonal block is written by the lane of its edge (parallel edges:
+// the first lane of the run adds the run in lane order), and the three scalar sums go through per-node partials that the LAST wave to finish folds in
+// node order.  No atomics on data, no dependence on scheduling.  Adjacency: nadj_ptr / nadj_edge / nadj_side (0: the node is index0 of the edge, 1: index1,
+// 2: both) / nadj_slot (block slot of the neighbour in the node's row) / nadj_first (first entry of a run of parallel edges), sorted by (neighbour, edge).
+// ejac: [E * 24] robustified, Jacobi-scaled J0 (9) | J1 (9) | Jf (3) | r (3) of every edge, written by the edge pass (k_rot_edge_records) and read again by
+// the model-cost pass of k_rot_eval.
+constexpr int ROT_MAX_DEG = 64;
+// pass 1, lane per edge (full waves; one Dual<7> evaluation per edge -- a wave per node evaluating its incident edges itself ran every edge twice on
+// a quarter-full wave: 208 us per launch at 4000 nodes): the record of the edge and, per workgroup, the three scalar partial sums
+__global__ void __launch_bounds__(64)
+k_rot_edge_records(int kind, int E, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
+                   const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node, const double* __restrict__ sc_f,
+                   double* __restrict__ ejac, double* __restrict__ edge_part /* [gridDim.x * 3] */) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double p[3] = {0, 0, 0};
+    if (e < E) {
+        typedef Dual<7> D;
+        const int i0 = e0[e], i1 = e1[e];
+        D r0[3] = {D(x[3 * i0], 0), D(x[3 * i0 + 1], 1), D(x[3 * i0 + 2], 2)}, r1[3] = {D(x[3 * i1], 3), D(x[3 * i1 + 1], 4), D(x[3 * i1 + 2], 5)};
+        D f(fm[0], 6), res[3];
+        edge_residual<D>(kind, ec[e], scale, r0, r1, f, res);
+        double rho0, rho1; robust_loss(2, loss_a, res[0].a * res[0].a + res[1].a * res[1].a + res[2].a * res[2].a, rho0, rho1);
+        const double sr = sqrt(rho1), sf = sc_f[0];
+        double* q = ejac + (size_t)24 * e;
+        p[0] = 0.5 * rho0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double ra = sr * res[a].a, jf = sr * res[a].v[6] * sf;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { q[3 * a + k] = sr * res[a].v[k] * sc_node[3 * i0 + k]; q[9 + 3 * a + k] = sr * res[a].v[3 + k] * sc_node[3 * i1 + k]; }
+            q[18 + a] = jf; q[21 + a] = ra;
+            p[1] += jf * jf; p[2] += jf * ra;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = wave_sum(p[k]);
+    if ((threadIdx.x & 63) == 0) { double* w = edge_part + 3 * (size_t)blockIdx.x; w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; }
+}
+// pass 2, wave per node, lane per incident edge: gathers the records into the node's row of S, its J^T r, focal border and column norms; wave 0
+// folds the scalar partials of pass 1 in workgroup order
+__global__ void __launch_bounds__(64)
+k_rot_gather_nodes(int n_nodes, int n_edge_parts, const int* __restrict__ nadj_ptr, const int* __restrict__ nadj_edge, const unsigned char* __restrict__ nadj_side,
+                   const int* __restrict__ nadj_slot, const unsigned char* __restrict__ nadj_first, const double* __restrict__ ejac, const double* __restrict__ edge_part,
+                   const int* __restrict__ row_ptr, const int* __restrict__ diag_slot, double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag,
+                   double* __restrict__ Sfc, double* __restrict__ scal) {
+    __shared__ double tmp[64][9];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int a0 = nadj_ptr[i], deg = nadj_ptr[i + 1] - a0;
+    double v[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) v[k] = 0.0;
+    double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < deg) {
+        const int e = nadj_edge[a0 + lane], side = nadj_side[a0 + lane];
+        const double* q = ejac + (size_t)24 * e;
+        double Js[3][3], Jo[3][3], Jf[3], r[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double j0 = q[3 * a + k], j1 = q[9 + 3 * a + k];
+                Js[a][k] = (side == 0) ? j0 : ((side == 1) ? j1 : j0 + j1);         // a self-loop moves the node through both slots
+                Jo[a][k] = (side == 0) ? j1 : ((side == 1) ? j0 : 0.0);
+            }
+            Jf[a] = q[18 + a]; r[a] = q[21 + a];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                double d = 0.0, b = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { d += Js[a][u] * Js[a][w]; b += Js[a][u] * Jo[a][w]; }
+                v[3 * u + w] = d; B[3 * u + w] = b;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) { v[9 + u] += Js[a][u] * r[a]; v[12 + u] += Jf[a] * Js[a][u]; v[15 + u] += Js[a][u] * Js[a][u]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) tmp[lane][k] = B[k];
+    const double mine = wave_transpose_sum(v);             // sum k sits in the lane with wave_tr_index() == k
+    const int slot = wave_tr_index();
+    const int rb = row_ptr[i];
+    if (slot < 9) S_val[((size_t)rb + diag_slot[i]) * 9 + slot] = mine;
+    else if (slot < 12) rhs[3 * i + slot - 9] = mine;
+    else if (slot < 15) Sfc[3 * i + slot - 12] = mine;
+    else if (slot < 18) Udiag[3 * i + slot - 15] = mine;
+    __syncthreads();
+    if (lane < deg && nadj_first[a0 + lane] && nadj_side[a0 + lane] != 2) {
+        double acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc[k] = tmp[lane][k];
+        for (int m = lane + 1; m < deg && !nadj_first[a0 + m]; m++)
+#pragma unroll
+            for (int k = 0; k < 9; k++) acc[k] += tmp[m][k];
+        double* dst = S_val + ((size_t)rb + nadj_slot[a0 + lane]) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k] = acc[k];
+    }
+    // ---- wave 0 folds the scalar partials of the edge pass (complete before this launch started) in workgroup order
+    if (i != 0) return;
+    double c[3] = {0.0, 0.0, 0.0};
+    for (int k = lane; k < n_edge_parts; k += 64) { const double* q = edge_part + 3 * (size_t)k; c[0] += q[0]; c[1] += q[1]; c[2] += q[2]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = wave_sum(c[k]);
+    if (lane == 0) { scal[SC_COST] = c[0]; scal[SC_FJJ] = c[1]; scal[SC_FJR] = c[2]; }
+}
+
+// Focal arrow + step + candidate in one single-workgroup launch (was k_band_combine + k_rot_update): y = V - U phi from the two band solutions
+// (phi = (rho - S_fc . V) / (S_ff - S_fc . U)), step = -y, candidate = Plus(x, scale o step) with the box projection of the focal multiplier,
+// |x - candidate|^2, |candidate|^2, the projected-gradient max norm, g . delta and |delta|_inf (line search of bounded problems).
+__global__ void __launch_bounds__(1024)
+k_rot_step(int n_nodes, const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
+           const double* __restrict__ rho_ptr, const int* __restrict__ pos, const double* __restrict__ x, const double* __restrict__ fm,
+           const double* __restrict__ sc_node, const double* __restrict__ sc_f, const double* __restrict__ rhs_raw, double f_lo, double f_hi,
+           double* __restrict__ y, double* __restrict__ xc, double* __restrict__ fmc, double* __restrict__ step, double* __restrict__ scal) {
+    __shared__ double red[96];
+    __shared__ double sphi;
+    const int n = 3 * n_nodes;
+    double d2[2] = {0, 0};
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int c = t / 3, a = t - 3 * c; const int pi = pos[c] * 3 + a;
+        d2[0] += Sfc[t] * V[pi]; d2[1] += Sfc[t] * U[pi];
+    }
+    block_sum<2>(d2, red);
+    if (threadIdx.x == 0) sphi = (rho_ptr[0] - d2[0]) / (Sff[0] - d2[1]);
+    __syncthreads();
+    const double phi = sphi;
+    double acc[3] = {0, 0, 0}; double gmax = 0.0, dmax = 0.0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int c = t / 3, a = t - 3 * c; const int pi = pos[c] * 3 + a;
+        const double yi = V[pi] - U[pi] * phi; y[t] = yi;
+        const double s = sc_node[t]; double v = x[t];
+        const double st = -yi; step[t] = st;
+        if (s > 0.0) { const double d = st * s; v += d; acc[0] += d * d; acc[1] += v * v; gmax = fmax(gmax, fabs(rhs_raw[t] / s)); acc[2] += rhs_raw[t] * st; dmax = fmax(dmax, fabs(st * s)); }
+        xc[t] = v;
+    }
+    if (threadIdx.x == 0) {
+        y[n] = phi;
+        const double s = sc_f[0]; double v = fm[0]; const double st = -phi; step[n] = st;
+        if (s > 0.0) {
+            const double nv = fmin(fmax(v + st * s, f_lo), f_hi);
+            acc[0] += (nv - v) * (nv - v); acc[1] += nv * nv;
+            const double g = rhs_raw[n] / s;
+            gmax = fmax(gmax, fabs(v - fmin(fmax(v - g, f_lo), f_hi)));
+            acc[2] += rhs_raw[n] * st; dmax = fmax(dmax, fabs(st * s));
+            v = nv;
+        }
+        fmc[0] = v;
+    }
+    __syncthreads();
+    block_sum<3>(acc, red);
+    gmax = wave_max(gmax); dmax = wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) { red[48 + (threadIdx.x >> 6)] = gmax; red[64 + (threadIdx.x >> 6)] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = 0.0, d = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) { g = fmax(g, red[48 + w]); d = fmax(d, red[64 + w]); }
+        scal[SC_GMAX] = g;
+        scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; scal[SC_GDELTA] = acc[2]; scal[SC_DMAX] = d;
+    }
+}
+
+// Everything that is left of an iteration in one launch (was k_pcg_matvec + k_ref_residual + k_rot_edges(mode 1) + k_rot_cost): workgroups [0, ge) take
+// 64 edges each -- model cost change from the Jacobian records of the assembly, cost at the candidate --, workgroups [ge, ge + gn) take 64 nodes each --
+// their rows of S y for the residual check |rhs - S y| <= tol |rhs| of the direct solve.  Per-workgroup partial sums, folded in workgroup order by the
+// last workgroup to finish: [model, candidate cost, |r|^2, |rhs|^2, S_fc . y].
+__global__ void __launch_bounds__(64)
+k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
+           const double* __restrict__ ejac, const double* __restrict__ step, const double* __restrict__ xc, const double* __restrict__ fmc,
+           const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val, const double* __restrict__ Sfc,
+           const double* __restrict__ Sff, const double* __restrict__ rhs, const double* __restrict__ y, double tol2, double* __restrict__ resid /* [3n + 1] */,
+           double* __restrict__ wg_part /* [gridDim.x * 5] */, int* __restrict__ ticket, double* __restrict__ scal, double* __restrict__ pcg) {
+    __shared__ int s_last;
+    const int lane = threadIdx.x, wg = blockIdx.x;
+    double p[5] = {0, 0, 0, 0, 0};
+    if (wg < ge) {
+        const int e = wg * 64 + lane;
+        if (e < E) {
+            const int i0 = e0[e], i1 = e1[e];
+            const double* q = ejac + (size_t)24 * e;
+            const double sfv = step[3 * n_nodes];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double m = q[18 + a] * sfv;
+#pragma unroll
+                for (int k = 0; k < 3; k++) m += q[3 * a + k] * step[3 * i0 + k] + q[9 + 3 * a + k] * step[3 * i1 + k];
+                p[0] += m * (q[21 + a] + 0.5 * m);
+            }
+            const double r0[3] = {xc[3 * i0], xc[3 * i0 + 1], xc[3 * i0 + 2]}, r1[3] = {xc[3 * i1], xc[3 * i1 + 1], xc[3 * i1 + 2]};
+            double res[3]; edge_residual<double>(kind, ec[e], scale, r0, r1, fmc[0], res);
+            double rho0, rho1; robust_loss(2, loss_a, res[0] * res[0] + res[1] * res[1] + res[2] * res[2], rho0, rho1);
+            p[1] = 0.5 * rho0;
+        }
+    } else {
+        const int i = (wg - ge) * 64 + lane;
+        if (i < n_nodes) {
+            const int rb = row_ptr[i], nb = row_ptr[i + 1] - rb;
+            double qv[3] = {0, 0, 0};
+            for (int b = 0; b < nb; b++) {
+                const double* blk = S_val + ((size_t)rb + b) * 9; const double* yv = y + 3 * (size_t)col_idx[rb + b];
+#pragma unroll
+                for (int a = 0; a < 3; a++) qv[a] += blk[3 * a] * yv[0] + blk[3 * a + 1] * yv[1] + blk[3 * a + 2] * yv[2];
+            }
+            const double yf = y[3 * n_nodes];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double bi = rhs[3 * i + a], ri = bi - (qv[a] + Sfc[3 * i + a] * yf);
+                resid[3 * i + a] = ri; p[2] += ri * ri; p[3] += bi * bi; p[4] += Sfc[3 * i + a] * y[3 * i + a];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) p[k] = wave_sum(p[k]);
+    if (lane == 0) { double* w = wg_part + 5 * (size_t)wg; for (int k = 0; k < 5; k++) w[k] = p[k]; }
+    __threadfence();
+    if (lane == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double c[5] = {0, 0, 0, 0, 0};
+    for (int k = lane; k < (int)gridDim.x; k += 64) {
+        const volatile double* w = wg_part + 5 * (size_t)k;
+#pragma unroll
+        for (int j = 0; j < 5; j++) c[j] += w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) c[j] = wave_sum(c[j]);
+    if (lane == 0) {
+        const int n = 3 * n_nodes;
+        const double bf = rhs[n], rf = bf - (Sff[0] * y[n] + c[4]);          // the focal row of the bordered system
+        resid[n] = rf;
+        const double rr = c[2] + rf * rf, bn2 = c[3] + bf * bf;
+        scal[SC_MODEL] = c[0]; scal[SC_CAND_COST] = c[1];
+        pcg[PCG_RR] = rr; pcg[PCG_BN2] = bn2; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0; pcg[PCG_DONE] = (rr <= tol2 * bn2) ? 1.0 : 0.0;
+        *ticket = 0;
+    }
 }
 
 // candidate = Plus(x, alpha (scale o step)) with the box projection on the focal multiplier (Ceres ParameterBlock::Plus; alpha = 1 except
 // after a line search); also |x - candidate|^2, |candidate|^2, the projected-gradient max norm |x - Plus(x, -g)|_inf, and for the line
 // search of bounded problems g . delta (slot SC_GDELTA) and |delta|_inf (SC_DMAX) with delta = scale o step, g = the unscaled gradient
-enum { SC_GDELTA = 14, SC_DMAX = 15 };
 __global__ void __launch_bounds__(1024)
 k_rot_update(int n_nodes, const double* __restrict__ x, const double* __restrict__ fm, const double* __restrict__ sc_node,
              const double* __restrict__ sc_f, const double* __restrict__ y, const double* __restrict__ rhs_raw, double f_lo, double f_hi, double alpha,
@@ -267,24 +511,35 @@ extern "C" int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotation
     hipStream_t st = ctx->stream;
     RotGraph G; build_graph(n, rotations, E, index0, index1, rel_rotations, 1, false, G);   // PoseGraphError, src/uncalibrated_pose_graph.cpp:131
     DevBuf<double> x, fm, out; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
-    std::vector<double> one = {1.0}, zero = {0.0};
-    SSFM_HIP_CHECK(ctx, upload(x, G.x0, st)); SSFM_HIP_CHECK(ctx, upload(fm, one, st)); SSFM_HIP_CHECK(ctx, upload(out, zero, st));
-    SSFM_HIP_CHECK(ctx, upload(e0, G.e0, st)); SSFM_HIP_CHECK(ctx, upload(e1, G.e1, st)); SSFM_HIP_CHECK(ctx, upload(ec, G.ec, st));
-    hipLaunchKernelGGL(k_rot_cost, dim3((E + 63) / 64), dim3(64), 0, st, 1, E, e0.p, e1.p, ec.p, G.scale, 0.03, x.p, fm.p, out.p);
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(cost, out.p, sizeof(double), hipMemcpyDeviceToHost, st));
-    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    std::vector<double> one = {1.0}, part((size_t)(E + 63) / 64, 0.0);
+    int rc = SSFM_OK;
+    auto body = [&]() -> int {
+        SSFM_HIP_CHECK(ctx, upload(x, G.x0, st)); SSFM_HIP_CHECK(ctx, upload(fm, one, st)); SSFM_HIP_CHECK(ctx, out.alloc(part.size()));
+        SSFM_HIP_CHECK(ctx, upload(e0, G.e0, st)); SSFM_HIP_CHECK(ctx, upload(e1, G.e1, st)); SSFM_HIP_CHECK(ctx, upload(ec, G.ec, st));
+        // one partial sum per workgroup, added up in workgroup order on the host: the same bits on every call (no floating-point atomics)
+        hipLaunchKernelGGL(k_rot_cost, dim3((E + 63) / 64), dim3(64), 0, st, 1, E, e0.p, e1.p, ec.p, G.scale, 0.03, x.p, fm.p, (double*)nullptr, out.p);
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(part.data(), out.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        return SSFM_OK;
+    };
+    rc = body();
     x.free(); fm.free(); out.free(); e0.free(); e1.free(); ec.free();
+    if (rc) return rc;
+    double c = 0.0; for (double v : part) c += v;
+    *cost = c;
     return SSFM_OK;
 }
 
 // the buffers of one pose-graph solve; released on every exit path of rot_solve (after the stream has drained: the pool rule of ssfm_ctx.h)
 struct RotScratch {
     ssfm_ctx* ctx; ssfm_ba_handle H;
-    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out, m3, mf; DevBuf<int> e0, e1; DevBuf<EdgeConst> ec;
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out, m3, mf, ejac, node_part, wg_part; DevBuf<int> e0, e1, nadj_ptr, nadj_edge, nadj_slot, ticket; DevBuf<EdgeConst> ec;
+    DevBuf<unsigned char> nadj_side, nadj_first;
     explicit RotScratch(ssfm_ctx* c) : ctx(c) {}
     ~RotScratch() {
         (void)hipStreamSynchronize(ctx->stream);
         x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); ls_out.free(); m3.free(); mf.free(); e0.free(); e1.free(); ec.free();
+        ejac.free(); node_part.free(); wg_part.free(); nadj_ptr.free(); nadj_edge.free(); nadj_slot.free(); ticket.free(); nadj_side.free(); nadj_first.free();
         H.free_all();
     }
 };
@@ -347,6 +602,40 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     { const size_t Nb = (size_t)F.band_rows, DCB = (size_t)F.band_block, ny = (size_t)F.y_rows(3) * 3;
       ALV(h->band, Nb * (F.band + 1) * DCB * DCB); ALV(h->Linv, Nb * DCB * DCB); ALV(h->Yb, 2 * ny); ALV(h->Yr, 2 * ny); }
     { const int rc = sub_upload(h, 3); if (rc) return rc; }
+    // ---- node-major adjacency of the deterministic assembly (k_rot_edge_records + k_rot_gather_nodes): entries sorted by (neighbour, edge id)
+    static const bool node_major_on = !(std::getenv("SSFM_ROT_NODE_MAJOR") && std::atoi(std::getenv("SSFM_ROT_NODE_MAJOR")) == 0);
+    bool node_major = node_major_on && O.preconditioner == 0;
+    {
+        std::vector<int> deg(n, 0);
+        for (int e = 0; e < E; e++) { deg[index0[e]]++; if (index1[e] != index0[e]) deg[index1[e]]++; }
+        for (int i = 0; i < n; i++) if (deg[i] > ROT_MAX_DEG) node_major = false;          // a lane per incident edge: wider nodes take the scatter kernel
+    }
+    const int gnode = (n + 63) / 64;
+    if (node_major) {
+        struct Ent { int nb, e; unsigned char side; };
+        std::vector<std::vector<Ent>> adj(n);
+        for (int e = 0; e < E; e++) {
+            const int a = index0[e], b = index1[e];
+            if (a == b) adj[a].push_back(Ent{a, e, 2});
+            else { adj[a].push_back(Ent{b, e, 0}); adj[b].push_back(Ent{a, e, 1}); }
+        }
+        std::vector<int> nptr(n + 1, 0), nedge, nslot; std::vector<unsigned char> nside, nfirst;
+        for (int i = 0; i < n; i++) {
+            auto& v = adj[i];
+            std::sort(v.begin(), v.end(), [](const Ent& p, const Ent& q) { return p.nb != q.nb ? p.nb < q.nb : p.e < q.e; });
+            for (size_t k = 0; k < v.size(); k++) {
+                nedge.push_back(v[k].e); nside.push_back(v[k].side);
+                nslot.push_back((int)(std::lower_bound(F.col_idx.begin() + F.row_ptr[i], F.col_idx.begin() + F.row_ptr[i + 1], v[k].nb) - (F.col_idx.begin() + F.row_ptr[i])));
+                nfirst.push_back((k == 0 || v[k - 1].nb != v[k].nb) ? 1 : 0);
+            }
+            nptr[i + 1] = (int)nedge.size();
+        }
+        if (nedge.empty()) { nedge.push_back(0); nslot.push_back(0); nside.push_back(0); nfirst.push_back(0); }
+        std::vector<int> zero2(2, 0);
+        SSFM_HIP_CHECK(ctx, upload(RS.nadj_ptr, nptr, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_edge, nedge, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_slot, nslot, st));
+        SSFM_HIP_CHECK(ctx, upload(RS.nadj_side, nside, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_first, nfirst, st)); SSFM_HIP_CHECK(ctx, upload(RS.ticket, zero2, st));
+        ALV(RS.ejac, (size_t)24 * E); ALV(RS.node_part, (size_t)3 * ((E + 63) / 64)); ALV(RS.wg_part, (size_t)5 * ((E + 63) / 64 + gnode));
+    }
 #undef ALV
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
     const int ge = (E + 63) / 64, gn = (n + 63) / 64;
@@ -356,6 +645,11 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double* host_scal = poll ? h->host_pub : h->host_sp; double* host_pcg = poll ? h->host_pub + SC_TOTAL : h->host_sp + SC_NSLOT * SC_TOTAL;      // this solver only ever writes replica 0 of the scalar block
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
     auto assemble = [&](const double* s3, const double* sf) -> int {      // into the current zone, which is clean
+        if (node_major) {
+            hipLaunchKernelGGL(k_rot_edge_records, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, RS.ejac.p, RS.node_part.p);
+            hipLaunchKernelGGL(k_rot_gather_nodes, dim3(n), dim3(64), 0, st, n, ge, RS.nadj_ptr.p, RS.nadj_edge.p, RS.nadj_side.p, RS.nadj_slot.p, RS.nadj_first.p, RS.ejac.p, RS.node_part.p,
+                               h->row_ptr.p, h->diag_slot.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
+        } else
         hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
                            (const double*)nullptr, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
         return SSFM_OK;
@@ -395,7 +689,20 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         LAUNCH(h, KID_FINALIZE, k_finalize_S<3>, gn, 64, 0, h->row_ptr.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal,
                O.max_lm_diagonal, n, h->S_val, h->Minv.p, h->rhs, h->Sff.p, h->scal.p);
         int pcg_iters = 0; bool pcg_ok = false;
-        { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); if (rc) return rc; }
+        const bool fused_tail = node_major && O.preconditioner == 0;
+        h->external_tail = fused_tail;
+        { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); h->external_tail = false; if (rc) return rc; }
+        const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
+        const int nbr = (F.band_rows > 0 ? F.y_rows(3) : n) * 3;                   // stride of the right-hand-side columns in band order
+        auto tail_fused = [&]() -> int {                                          // focal arrow + step + candidate | model change + candidate cost + residual check | hand-over
+            hipLaunchKernelGGL(k_rot_step, dim3(1), dim3(1024), 0, st, n, h->Yb.p, h->Yb.p + nbr, h->Sfc, h->Sff.p, h->rhs + 3 * n, h->cam_pos.p, xx, fmx, sc3.p, scf.p, h->rhs, f_lo, f_hi,
+                               h->px.p, xcand, fmc, step.p, h->scal.p);
+            hipLaunchKernelGGL(k_rot_eval, dim3(ge + gnode), dim3(64), 0, st, kind, E, ge, n, e0.p, e1.p, ec.p, G.scale, la, RS.ejac.p, step.p, xcand, fmc, h->row_ptr.p, h->col_idx.p, h->S_val,
+                               h->Sfc, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p, RS.wg_part.p, RS.ticket.p + 1, h->scal.p, h->pcg.p);
+            if (poll) publish(h);
+            else SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+            return SSFM_OK;
+        };
         auto tail = [&]() -> int {
             hipLaunchKernelGGL(k_rot_update, dim3(1), dim3(1024), 0, st, n, xx, fmx, sc3.p, scf.p, h->px.p, h->rhs, f_lo, f_hi, 1.0, xcand, fmc, step.p, h->scal.p);
             hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 1, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, sc3.p, scf.p, h->row_ptr.p, h->col_idx.p, n,
@@ -410,7 +717,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             return SSFM_OK;
         };
-        { int rc = tail(); if (rc) return rc; }
+        { int rc = fused_tail ? tail_fused() : tail(); if (rc) return rc; }
         // the other zone (the previous iteration's) is cleared while the host waits and decides
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)(zi ^ 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
         { int rc = wait_tail(); if (rc) return rc; }
