@@ -156,7 +156,9 @@ inline void parallel_chunks(int64_t n, int T, Fn f) {
 }
 inline int planner_threads() {
     if (const char* e = std::getenv("SSFM_PLAN_THREADS")) return std::max(1, std::atoi(e));
-    return (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));        // measured on the MI355X host: 4 threads halve the plan, 16 add nothing
+    // 16 = the thread count the reference gives Ceres (src/sfm.cpp:209) and the CPU baseline uses.  Measured on the MI355X host (256 cores), 600k observations,
+    // first call on a structure: plan 3.1 / 2.0 / 1.35 / 1.15 ms with 4 / 8 / 16 / 32 threads; beyond 16 the observation upload on its own thread loses its overlap
+    return (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 }
 
 // Cuthill-McKee order of the camera graph given as block-CSR structure (folds a ring into a band of twice
@@ -369,7 +371,29 @@ inline void pair_fill_host(BAFlat& F, int NT, std::vector<int64_t>& slot_off) {
     });
 }
 
-inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F, bool host_pairs = true, int num_cus = 256) {
+// Host-side recycling of the per-observation arrays of a plan.  A first call on a structure allocates ~35 MB of vectors; fresh allocations of
+// that size are mmap'ed, and touching them for the first time costs a page fault per 4 KB (~1 ms of the "emit observations" stage at 600k
+// observations).  ssfm_ba_destroy hands the arrays of the dying handle to this stash and the next ba_flatten takes them back, already mapped.
+struct HostStash {
+    std::mutex m;
+    raw_vector<int> obs_cam, obs_pt, pt_ids; raw_vector<int64_t> obs_orig; raw_vector<double> obs_xy, pts0, mask_pt;
+};
+inline HostStash& host_stash() { static HostStash s; return s; }
+template <class V> inline void stash_swap_if_larger(V& mine, V& stashed) { if (mine.capacity() > stashed.capacity()) mine.swap(stashed); }
+inline void stash_take(BAFlat& F) {
+    HostStash& S = host_stash(); std::lock_guard<std::mutex> g(S.m);
+    F.obs_cam.swap(S.obs_cam); F.obs_pt.swap(S.obs_pt); F.pt_ids.swap(S.pt_ids); F.obs_orig.swap(S.obs_orig); F.obs_xy.swap(S.obs_xy); F.pts0.swap(S.pts0); F.mask_pt.swap(S.mask_pt);
+}
+inline void stash_give(BAFlat& F) {
+    HostStash& S = host_stash(); std::lock_guard<std::mutex> g(S.m);
+    stash_swap_if_larger(F.obs_cam, S.obs_cam); stash_swap_if_larger(F.obs_pt, S.obs_pt); stash_swap_if_larger(F.pt_ids, S.pt_ids); stash_swap_if_larger(F.obs_orig, S.obs_orig);
+    stash_swap_if_larger(F.obs_xy, S.obs_xy); stash_swap_if_larger(F.pts0, S.pts0); stash_swap_if_larger(F.mask_pt, S.mask_pt);
+}
+
+// after_emit (optional): called as soon as this rank's observations and points are laid out (F.obs_*, F.pt_start, F.pts0, F.mask_pt, F.pt_ids are final),
+// before the structure of S, the ordering and the task tables are planned -- ba_create_impl starts uploading them on a second host thread there.
+inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F, bool host_pairs = true, int num_cus = 256,
+                       const std::function<void(BAFlat&)>* after_emit = nullptr) {
     const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; const auto t = std::chrono::steady_clock::now();
@@ -378,36 +402,31 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     const int64_t M = P.num_observations;
     const int NT = planner_threads();
     F = BAFlat();
+    stash_take(F);
     F.Nc = Nc; F.focal_free = !P.focal_fixed;
     if (Nc == 0 || Np == 0 || M == 0) { F.nothing_to_do = true; return; }
-    // ---- order observations point-major / camera-ascending (skip the sort if they already are)
-    bool sorted = true;
-    {
-        std::vector<char> bad(NT, 0);
-        parallel_chunks(M - 1, M >= 200000 ? NT : 1, [&](int t, int64_t a, int64_t b) {
-            for (int64_t i = a + 1; i <= b; i++)
-                if (P.obs_pt[i] < P.obs_pt[i - 1] || (P.obs_pt[i] == P.obs_pt[i - 1] && P.obs_cam[i] <= P.obs_cam[i - 1])) { bad[t] = 1; break; }
-        });
-        for (char c : bad) if (c) sorted = false;
-    }
-    std::vector<int64_t> order;
-    if (!sorted) {
-        order.resize(M); std::iota(order.begin(), order.end(), (int64_t)0);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-            if (P.obs_pt[a] != P.obs_pt[b]) return P.obs_pt[a] < P.obs_pt[b];
-            return P.obs_cam[a] < P.obs_cam[b]; });
-    }
-    auto at = [&](int64_t i) { return sorted ? i : order[i]; };
+    // ---- order observations point-major / camera-ascending (skip the sort if they already are), and
     // ---- pass 1: which points are used (global), with their observation counts.  Chunks of the observation array, cut at point boundaries.
+    // The order check rides along with the first attempt at pass 1 (one sweep over the index arrays instead of two: 0.25 ms at 600k observations);
+    // an unsorted input is sorted and the pass repeated.
+    bool sorted = true;
+    std::vector<int64_t> order;
+    auto at = [&](int64_t i) { return sorted ? i : order[i]; };
     struct Seg { int pt; int64_t begin, end; int nobs; };
     std::vector<Seg> segs;
-    {
+    auto build_segments = [&](bool check_order) -> bool {
         const int TS = (M >= 200000) ? NT : 1;
         std::vector<std::vector<Seg>> part(TS);
+        std::vector<char> bad(TS, 0);
         parallel_chunks(M, TS, [&](int t, int64_t i0, int64_t i1) {
+            const int tt = (TS == 1) ? 0 : t;
+            if (check_order) {                                            // this chunk's entries against their predecessors (the first one against the previous chunk's last)
+                for (int64_t i = std::max<int64_t>(i0, 1); i < i1; i++)
+                    if (P.obs_pt[i] < P.obs_pt[i - 1] || (P.obs_pt[i] == P.obs_pt[i - 1] && P.obs_cam[i] <= P.obs_cam[i - 1])) { bad[tt] = 1; return; }
+            }
             // a chunk owns the points that START inside it
             while (i0 > 0 && i0 < M && P.obs_pt[at(i0)] == P.obs_pt[at(i0 - 1)]) i0++;
-            std::vector<Seg>& out = part[TS == 1 ? 0 : t]; out.reserve((size_t)((i1 - i0) / 4 + 16));
+            std::vector<Seg>& out = part[tt]; out.reserve((size_t)((i1 - i0) / 4 + 16));
             for (int64_t i = i0; i < i1;) {
                 const int p = P.obs_pt[at(i)];
                 int64_t e = i; int nobs = 0; int last_cam = -1;
@@ -418,14 +437,63 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 i = e;
             }
         });
+        for (char c : bad) if (c) return false;
         size_t tot = 0; for (auto& v : part) tot += v.size();
-        segs.reserve(tot);
+        segs.clear(); segs.reserve(tot);
         for (auto& v : part) segs.insert(segs.end(), v.begin(), v.end());
+        return true;
+    };
+    if (!build_segments(true)) {
+        sorted = false;
+        order.resize(M); std::iota(order.begin(), order.end(), (int64_t)0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            if (P.obs_pt[a] != P.obs_pt[b]) return P.obs_pt[a] < P.obs_pt[b];
+            return P.obs_cam[a] < P.obs_cam[b]; });
+        (void)build_segments(false);
     }
     lap("sorted check + segments");
     F.nP_global = (int)segs.size();
     for (const Seg& s : segs) F.M_global += s.nobs;
     if (segs.empty()) { F.nothing_to_do = true; return; }
+    // ---- this rank's contiguous share of the used points, balanced by observation count
+    size_t s0 = 0, s1 = segs.size();
+    if (nranks > 1) {
+        const int64_t lo = F.M_global * rank / nranks, hi = F.M_global * (rank + 1) / nranks;
+        int64_t acc = 0; s0 = s1 = segs.size(); bool have0 = false;
+        for (size_t k = 0; k < segs.size(); k++) {
+            if (!have0 && acc >= lo) { s0 = k; have0 = true; }
+            if (acc >= hi) { s1 = k; break; }
+            acc += segs[k].nobs;
+        }
+        if (!have0) s0 = segs.size();
+        if (rank == nranks - 1) s1 = segs.size();
+    }
+    // ---- pass 2: emit local observations
+    F.nP = (int)(s1 - s0);
+    {
+        int64_t mloc = 0; for (size_t k = s0; k < s1; k++) mloc += segs[k].nobs;
+        F.pt_ids.resize(F.nP); F.pt_start.resize((size_t)F.nP + 1); F.pts0.resize((size_t)F.nP * 3); F.mask_pt.resize((size_t)F.nP * 3);
+        F.obs_cam.resize(mloc); F.obs_pt.resize(mloc); F.obs_orig.resize(mloc); F.obs_xy.resize((size_t)mloc * 2);
+        F.pt_start[0] = 0;
+        for (size_t k = s0; k < s1; k++) F.pt_start[k - s0 + 1] = F.pt_start[k - s0] + segs[k].nobs;
+        parallel_chunks((int64_t)(s1 - s0), NT, [&](int, int64_t q0, int64_t q1) {
+            for (int64_t q = q0; q < q1; q++) {
+                const Seg& sg = segs[s0 + (size_t)q];
+                int64_t w = F.pt_start[q];
+                for (int64_t i = sg.begin; i < sg.end; i++) {
+                    const int64_t o = at(i); const int c = P.obs_cam[o];
+                    if (c < 0 || c >= Nc) continue;
+                    if (i + 1 < sg.end && P.obs_cam[at(i + 1)] == c) continue;     // keep the last duplicate
+                    F.obs_cam[w] = c; F.obs_pt[w] = (int)q; F.obs_orig[w] = o; F.obs_xy[2 * w] = P.obs_xy[2 * o]; F.obs_xy[2 * w + 1] = P.obs_xy[2 * o + 1]; w++;
+                }
+                const double m = (P.pt_fixed && P.pt_fixed[sg.pt]) ? 0.0 : 1.0;
+                for (int d = 0; d < 3; d++) { F.pts0[(size_t)q * 3 + d] = P.points[(size_t)sg.pt * 3 + d]; F.mask_pt[(size_t)q * 3 + d] = m; }
+                F.pt_ids[q] = sg.pt;
+            }
+        });
+    }
+    lap("emit observations");
+    if (after_emit) (*after_emit)(F);
     // ---- structure of S and camera activity come from ALL used points (identical on every rank)
     std::vector<char> cam_in(Nc, 0);
     if (Nc <= 1024) {
@@ -533,44 +601,6 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         if (!rf) for (int k = 0; k < 3; k++) F.mask_cam[c * 6 + 3 + k] = 1.0;
     }
     F.DC = all_t_fixed ? 3 : 6;
-    // ---- this rank's contiguous share of the used points, balanced by observation count
-    size_t s0 = 0, s1 = segs.size();
-    if (nranks > 1) {
-        const int64_t lo = F.M_global * rank / nranks, hi = F.M_global * (rank + 1) / nranks;
-        int64_t acc = 0; s0 = s1 = segs.size(); bool have0 = false;
-        for (size_t k = 0; k < segs.size(); k++) {
-            if (!have0 && acc >= lo) { s0 = k; have0 = true; }
-            if (acc >= hi) { s1 = k; break; }
-            acc += segs[k].nobs;
-        }
-        if (!have0) s0 = segs.size();
-        if (rank == nranks - 1) s1 = segs.size();
-    }
-    // ---- pass 2: emit local observations
-    F.nP = (int)(s1 - s0);
-    {
-        int64_t mloc = 0; for (size_t k = s0; k < s1; k++) mloc += segs[k].nobs;
-        F.pt_ids.resize(F.nP); F.pt_start.resize((size_t)F.nP + 1); F.pts0.resize((size_t)F.nP * 3); F.mask_pt.resize((size_t)F.nP * 3);
-        F.obs_cam.resize(mloc); F.obs_pt.resize(mloc); F.obs_orig.resize(mloc); F.obs_xy.resize((size_t)mloc * 2);
-        F.pt_start[0] = 0;
-        for (size_t k = s0; k < s1; k++) F.pt_start[k - s0 + 1] = F.pt_start[k - s0] + segs[k].nobs;
-        parallel_chunks((int64_t)(s1 - s0), NT, [&](int, int64_t q0, int64_t q1) {
-            for (int64_t q = q0; q < q1; q++) {
-                const Seg& sg = segs[s0 + (size_t)q];
-                int64_t w = F.pt_start[q];
-                for (int64_t i = sg.begin; i < sg.end; i++) {
-                    const int64_t o = at(i); const int c = P.obs_cam[o];
-                    if (c < 0 || c >= Nc) continue;
-                    if (i + 1 < sg.end && P.obs_cam[at(i + 1)] == c) continue;     // keep the last duplicate
-                    F.obs_cam[w] = c; F.obs_pt[w] = (int)q; F.obs_orig[w] = o; F.obs_xy[2 * w] = P.obs_xy[2 * o]; F.obs_xy[2 * w + 1] = P.obs_xy[2 * o + 1]; w++;
-                }
-                const double m = (P.pt_fixed && P.pt_fixed[sg.pt]) ? 0.0 : 1.0;
-                for (int d = 0; d < 3; d++) { F.pts0[(size_t)q * 3 + d] = P.points[(size_t)sg.pt * 3 + d]; F.mask_pt[(size_t)q * 3 + d] = m; }
-                F.pt_ids[q] = sg.pt;
-            }
-        });
-    }
-    lap("emit observations");
     F.M = (int64_t)F.obs_cam.size();
     F.cam_start.assign(Nc + 1, 0);
     for (int64_t j = 0; j < F.M; j++) F.cam_start[F.obs_cam[j] + 1]++;

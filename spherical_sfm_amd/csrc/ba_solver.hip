@@ -398,20 +398,37 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
     g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_s = 0.0; g_alloc_n = 0;
     const double t_create0 = wall_s();
-    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs, ctx->num_cus); h->t_flatten_s = wall_s() - tf; }
+    // The per-observation arrays are final long before the plan is (the structure of S, the ordering, the task tables follow): a second host thread
+    // uploads them on the context's stream while this one goes on planning -- the main thread does not touch the stream until it has joined the upload.
+    hipStream_t st = ctx->stream;
+    std::thread up_thread; int up_rc = SSFM_OK; double up_s = 0.0;
+    static const bool overlap_upload = !(std::getenv("SSFM_PLAN_OVERLAP") && std::atoi(std::getenv("SSFM_PLAN_OVERLAP")) == 0);
+    auto upload_obs = [&](BAFlat& Fm) -> int {
+        const double tu = wall_s();
+        SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        SSFM_HIP_CHECK(ctx, upload(h->obs_xy, Fm.obs_xy, st)); SSFM_HIP_CHECK(ctx, upload(h->obs_cam, Fm.obs_cam, st)); SSFM_HIP_CHECK(ctx, upload(h->obs_pt, Fm.obs_pt, st));
+        SSFM_HIP_CHECK(ctx, upload(h->pt_start, Fm.pt_start, st)); SSFM_HIP_CHECK(ctx, upload(h->pts_x, Fm.pts0, st)); SSFM_HIP_CHECK(ctx, upload(h->pts_init, Fm.pts0, st));
+        SSFM_HIP_CHECK(ctx, upload(h->mask_pt, Fm.mask_pt, st));
+        up_s = wall_s() - tu;
+        return SSFM_OK;
+    };
+    const std::function<void(BAFlat&)> after_emit = [&](BAFlat& Fm) { if (overlap_upload) up_thread = std::thread([&]() { up_rc = upload_obs(Fm); }); };
+    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs, ctx->num_cus, &after_emit); h->t_flatten_s = wall_s() - tf; }
     *out = h;
+    if (up_thread.joinable()) up_thread.join();
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
-    hipStream_t st = ctx->stream;
+    if (up_rc != SSFM_OK) return up_rc;
+    if (!overlap_upload) { const int rc = upload_obs(h->F); if (rc) return rc; }
+    if (g_alloc_timing) std::fprintf(stderr, "[create] observation upload %.2f ms (%s)\n", 1e3 * up_s, overlap_upload ? "on a second thread, under the rest of the plan" : "after the plan");
     const int Nc = F.Nc, nP = F.nP, DC = F.DC;
     std::vector<double> cams(p->cameras, p->cameras + (size_t)Nc * 6);
     h->focal_host = *p->focal;
     std::vector<double> f3 = {*p->focal, *p->focal, *p->focal};
     std::vector<double> maskf = {F.focal_free ? 1.0 : 0.0};
 #define UP(buf, vec) SSFM_HIP_CHECK(ctx, upload(h->buf, vec, st))
-    UP(cam_x, cams); UP(cam_init, cams); UP(pts_x, F.pts0); UP(pts_init, F.pts0); UP(focal3, f3);
-    UP(mask_cam, F.mask_cam); UP(mask_pt, F.mask_pt); UP(mask_f, maskf);
-    UP(obs_xy, F.obs_xy); UP(obs_cam, F.obs_cam); UP(obs_pt, F.obs_pt); UP(pt_start, F.pt_start);
+    UP(cam_x, cams); UP(cam_init, cams); UP(focal3, f3);
+    UP(mask_cam, F.mask_cam); UP(mask_f, maskf);
     UP(cam_start, F.cam_start);
     if (host_pairs) { UP(cam_obs, F.cam_obs); UP(cam_obs_pt, F.cam_obs_pt); }
     else if (F.M > 0) {                                               // camera-major lists on the device
@@ -575,6 +592,7 @@ extern "C" void ssfm_ba_destroy(ssfm_ba_handle* h) {
     // nothing of this handle may still be in flight when its buffers go back to the pool (asynchronous copies of ssfm_ba_reset, a
     // speculative launch); the device-wide wait does not touch the context, which the caller may already have destroyed
     (void)hipDeviceSynchronize();
+    stash_give(h->F);                  // the per-observation host arrays go to the next plan, already mapped (ba_flatten.h: HostStash)
     h->free_all();
     delete h;
 }
