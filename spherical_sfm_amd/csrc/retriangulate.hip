@@ -613,8 +613,8 @@ __device__ void tt_local_optimization(const TtPoint& c, const TtOpts& o, TtRng& 
     }
 }
 
-__global__ void __launch_bounds__(64)
-k_retriangulate_trace(const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
+__device__ __forceinline__ void
+retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                       const int* __restrict__ pt_start, int nP, const int* __restrict__ order /* lane -> point, or null */, TtOpts o,
                       const int* __restrict__ pt_slot, const unsigned short* __restrict__ samples /* [slot][TRI_MAX_IT][2] */,
                       const int* __restrict__ req_ptr, const unsigned* __restrict__ req_it /* NumRequiredIterations per (slot, inlier count) */,
@@ -646,6 +646,8 @@ k_retriangulate_trace(const double* __restrict__ ct, const double* __restrict__ 
             double X[3];
             tt_dlt<4>(c, sample, 2, 2, X);                                    // MinimalSolver: one model
             const double sc = tt_score(c, X, o.thr);
+            // (skipping ordered pairs that were drawn before -- their models and scores repeat bit for bit and cannot become a new best -- was measured:
+            //  23.4 -> 25.9 ms; the local optimisation's ~120 least-squares fits per point are 85 % of the work, the branch costs more than it saves)
             if (sc < best_min_score || it == o.lo_start) {                    // ransac.h:183-225
                 const bool best_min_model = sc < best_min_score;
                 if (best_min_model) { best_min_score = sc; best_min[0] = X[0]; best_min[1] = X[1]; best_min[2] = X[2]; tt_update(best_min_score, best_min, &best_score, best); }
@@ -680,6 +682,18 @@ k_retriangulate_trace(const double* __restrict__ ct, const double* __restrict__ 
     if (num_inliers) num_inliers[p] = nin;
     if (stats) { stats[2 * (size_t)p] = it; stats[2 * (size_t)p + 1] = (unsigned)lo_count; }
 }
+// The same body at three register budgets (waves per SIMD).  The compiler's free choice is 256 VGPRs + 38 AGPRs = one wave per SIMD; 100 000 points are
+// 1563 waves for 1024 SIMDs, i.e. two rounds with the second one half empty.  SSFM_RETRI_WAVES=1|2|3 selects (profiles/r03_notes.md has the measurement).
+#define SSFM_RETRI_ARGS                                                                                                                       \
+    const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,        \
+    const int* __restrict__ pt_start, int nP, const int* __restrict__ order, TtOpts o, const int* __restrict__ pt_slot,                          \
+    const unsigned short* __restrict__ samples, const int* __restrict__ req_ptr, const unsigned* __restrict__ req_it, const unsigned* __restrict__ W, \
+    int LW, int* __restrict__ lists, double* __restrict__ pts, int* __restrict__ num_inliers, unsigned* __restrict__ stats,                    \
+    unsigned char* __restrict__ flags, int* __restrict__ overflow
+#define SSFM_RETRI_PASS ct, focal, obs_xy, obs_cam, pt_start, nP, order, o, pt_slot, samples, req_ptr, req_it, W, LW, lists, pts, num_inliers, stats, flags, overflow
+__global__ void __launch_bounds__(64) k_retriangulate_trace(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_retriangulate_trace_w2(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_retriangulate_trace_w3(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
 
 // the estimator's pieces, one lane per task (bit-for-bit parity tests; mirrors oracle_tri_probe)
 __global__ void k_tri_probe(const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
@@ -852,9 +866,12 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
             SSFM_HIP_CHECK(ctx, upload(D.dW, W, st));
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(D.dovf.p, 0, sizeof(int), st));
             if (inlier_flags_out) SSFM_HIP_CHECK(ctx, hipMemsetAsync(D.dflags.p, 0, (size_t)std::max(total, 1), st));
-            if (Np > 0) hipLaunchKernelGGL(k_retriangulate_trace, dim3((Np + 63) / 64), dim3(64), 0, st, D.dct.p, D.df.p, reinterpret_cast<const double2*>(D.dxy.p), D.dcamidx.p, D.dps.p, Np,
-                                           D.dorder.p, o, D.dslot.p, D.dsamples.p, D.dreqptr.p, D.dreq.p, D.dW.p, (int)LW, D.dlists.p, D.dpts.p, D.dnin.p,
-                                           stats_out ? D.dstats.p : nullptr, inlier_flags_out ? D.dflags.p : nullptr, D.dovf.p);
+            const char* ew = getenv("SSFM_RETRI_WAVES"); const int waves = ew ? atoi(ew) : 2;        // measured: 32.8 / 23.4 / 25.1 ms at 1 / 2 / 3 waves per SIMD (100k points x 6)
+#define SSFM_RETRI_LAUNCH(K) hipLaunchKernelGGL(K, dim3((Np + 63) / 64), dim3(64), 0, st, D.dct.p, D.df.p, reinterpret_cast<const double2*>(D.dxy.p), D.dcamidx.p, D.dps.p, Np, \
+                                           D.dorder.p, o, D.dslot.p, D.dsamples.p, D.dreqptr.p, D.dreq.p, D.dW.p, (int)LW, D.dlists.p, D.dpts.p, D.dnin.p,                \
+                                           stats_out ? D.dstats.p : nullptr, inlier_flags_out ? D.dflags.p : nullptr, D.dovf.p)
+            if (Np > 0) { if (waves == 2) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w2); else if (waves == 3) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w3); else SSFM_RETRI_LAUNCH(k_retriangulate_trace); }
+#undef SSFM_RETRI_LAUNCH
             SSFM_HIP_CHECK(ctx, hipGetLastError());
             int ovf = 0;
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&ovf, D.dovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
