@@ -170,6 +170,7 @@ class BundleAdjuster:
             self._h = C.c_void_p()
             _lib.check(rc, ctx._p)
         import weakref
+        ctx._adjusters = [r for r in ctx._adjusters if r() is not None]      # drop the references of adjusters that are gone (the list only ever grew)
         ctx._adjusters.append(weakref.ref(self))
 
     def reset(self):

@@ -293,7 +293,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             // through flags in global memory.  Measured at config 2: 70.7 us for the fused launch against 2 x 35.2, 2.958 vs 2.919 ms per solve -- the fence + flag
             // hand-over costs what the launch boundary did (profiles/r02_notes.md)
             static const bool chol_fuse = std::getenv("SSFM_CHOL_FUSE") && std::atoi(std::getenv("SSFM_CHOL_FUSE")) != 0;
-            const bool fused = chol_fuse && B.ntwist > 0;
+            const bool fused = chol_fuse && B.ntwist > 0 && B.nseg + B.ntwist <= ctx->num_cus;      // waiting workgroups must all be resident (one per compute unit)
             if (fused) { h->sub_fz_seq++;
                 SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp, chol_map,
                                   h->sub_fz_await.p, h->sub_fz_signal.p, h->sub_fz_flags.p, h->sub_fz_seq); }
@@ -316,7 +316,10 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     if (stamp_state == 1) { (void)hipMalloc((void**)&d_stamps, 16 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(long long), st); stamp_state = 2; }
                     // chains of three or more separators are eliminated from both ends by two workgroups each (SSFM_CHAIN_TWIST=0: one workgroup, front to back)
                     static const bool chain_twist = !(std::getenv("SSFM_CHAIN_TWIST") && std::atoi(std::getenv("SSFM_CHAIN_TWIST")) == 0);
-                    const int tw = chain_twist ? 1 : 0;
+                    // The two workgroups of a chain wait for each other through flags in global memory: both must be RESIDENT.  A chain workgroup (1024 threads,
+                    // > 100 KB of LDS) owns a compute unit, so the two-sided form is only used while all 2 x nchain workgroups fit the device at once;
+                    // beyond that the one-sided kernel runs (nothing waits on anything in it).
+                    const int tw = (chain_twist && 2 * B.nchain <= ctx->num_cus) ? 1 : 0;
                     h->sub_seq++;
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq);

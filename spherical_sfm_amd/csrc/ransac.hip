@@ -446,20 +446,24 @@ static int sharded_exchange(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pai
                             const std::vector<int>& lnin, const std::vector<uint32_t>& lst, double* E_out, double* R_out, uint8_t* inlier_mask, int32_t* num_inliers,
                             double* scores, uint32_t* stats) {
     const int nl = (int)ids.size();
+    const int NT = planner_threads();          // packing / unpacking 500 mask bits per pair is host work of the same order as a rank's GPU time at 8 ranks: fork-join over the pairs
     // result table; every mask word belongs to exactly one pair's rank only if words do not straddle pairs: pack per pair
     std::vector<size_t> wptr(num_pairs + 1, 0);
     for (int p = 0; p < num_pairs; p++) wptr[p + 1] = wptr[p] + (size_t)(pair_ptr[p + 1] - pair_ptr[p] + 31) / 32;
     const size_t per = 22, n_tab = per * num_pairs + wptr[num_pairs] + 1;              // + 1: the error flag
-    std::vector<double> tab(n_tab, 0.0);
+    raw_vector<double> tab(n_tab);
+    parallel_chunks((int64_t)n_tab, NT, [&](int, int64_t a0, int64_t a1) { std::memset(tab.data() + a0, 0, (size_t)(a1 - a0) * sizeof(double)); });
     tab[n_tab - 1] = (local_rc != SSFM_OK) ? 1.0 : 0.0;
-    if (local_rc == SSFM_OK) for (int i = 0; i < nl; i++) {
-        const int p = ids[i]; double* t = &tab[per * (size_t)p];
-        std::memcpy(t, &lE[9 * (size_t)i], 9 * sizeof(double)); std::memcpy(t + 9, &lR[9 * (size_t)i], 9 * sizeof(double));
-        t[18] = lS[i]; t[19] = (double)lnin[i]; t[20] = (double)lst[2 * (size_t)i]; t[21] = (double)lst[2 * (size_t)i + 1];
-        double* w = &tab[per * (size_t)num_pairs + wptr[p]];
-        const int n = lptr[i + 1] - lptr[i];
-        for (int k = 0; k < n; k += 32) { uint32_t bits = 0; for (int q = 0; q < 32 && k + q < n; q++) bits |= (uint32_t)(lmask[lptr[i] + k + q] != 0) << q; w[k / 32] = (double)bits; }
-    }
+    if (local_rc == SSFM_OK) parallel_chunks(nl, NT, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            const int p = ids[i]; double* t = &tab[per * (size_t)p];
+            std::memcpy(t, &lE[9 * (size_t)i], 9 * sizeof(double)); std::memcpy(t + 9, &lR[9 * (size_t)i], 9 * sizeof(double));
+            t[18] = lS[i]; t[19] = (double)lnin[i]; t[20] = (double)lst[2 * (size_t)i]; t[21] = (double)lst[2 * (size_t)i + 1];
+            double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+            const int n = lptr[i + 1] - lptr[i];
+            for (int k = 0; k < n; k += 32) { uint32_t bits = 0; for (int q = 0; q < 32 && k + q < n; q++) bits |= (uint32_t)(lmask[lptr[i] + k + q] != 0) << q; w[k / 32] = (double)bits; }
+        }
+    });
     const std::string local_err = ctx->err;
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     DevBuf<double> dtab;
@@ -470,22 +474,23 @@ static int sharded_exchange(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pai
     dtab.free();
     if (local_rc != SSFM_OK) return fail(ctx, local_rc, local_err);
     if (tab[n_tab - 1] != 0.0) return fail(ctx, SSFM_ERR_COMM, "ssfm_ransac_batch_*_sharded: the local batch of another rank failed");
-    for (int p = 0; p < num_pairs; p++) {
-        const double* t = &tab[per * (size_t)p];
-        if (E_out) std::memcpy(E_out + 9 * (size_t)p, t, 9 * sizeof(double));
-        if (R_out) std::memcpy(R_out + 9 * (size_t)p, t + 9, 9 * sizeof(double));
-        if (scores) scores[p] = t[18];
-        if (num_inliers) num_inliers[p] = (int32_t)t[19];
-        if (stats) { stats[2 * (size_t)p] = (uint32_t)t[20]; stats[2 * (size_t)p + 1] = (uint32_t)t[21]; }
-        if (inlier_mask) {
-            const double* w = &tab[per * (size_t)num_pairs + wptr[p]];
-            const int n = pair_ptr[p + 1] - pair_ptr[p];
-            for (int k = 0; k < n; k++) inlier_mask[pair_ptr[p] + k] = (uint8_t)(((uint32_t)w[k / 32] >> (k % 32)) & 1u);
+    parallel_chunks(num_pairs, NT, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; p++) {
+            const double* t = &tab[per * (size_t)p];
+            if (E_out) std::memcpy(E_out + 9 * (size_t)p, t, 9 * sizeof(double));
+            if (R_out) std::memcpy(R_out + 9 * (size_t)p, t + 9, 9 * sizeof(double));
+            if (scores) scores[p] = t[18];
+            if (num_inliers) num_inliers[p] = (int32_t)t[19];
+            if (stats) { stats[2 * (size_t)p] = (uint32_t)t[20]; stats[2 * (size_t)p + 1] = (uint32_t)t[21]; }
+            if (inlier_mask) {
+                const double* w = &tab[per * (size_t)num_pairs + wptr[p]];
+                const int n = pair_ptr[p + 1] - pair_ptr[p]; uint8_t* m = inlier_mask + pair_ptr[p];
+                for (int k = 0; k < n; k += 32) { const uint32_t bits = (uint32_t)w[k / 32]; const int lim = std::min(32, n - k); for (int q = 0; q < lim; q++) m[k + q] = (uint8_t)((bits >> q) & 1u); }
+            }
         }
-    }
+    });
     return SSFM_OK;
 }
-
 
 // Multi-GPU estimate_pairwise (BASELINE configs[3]): image pairs are independent, so rank r of the context's
 // communicator takes pairs r, r + nranks, ... (round robin keeps neighbouring-frame pairs, which have the most correspondences,

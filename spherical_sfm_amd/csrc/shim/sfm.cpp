@@ -61,6 +61,11 @@ bool SfM::GetObservation(int camera, int point, Observation& o) {
     auto c = r->second.find(point); if (c == r->second.end()) return false;
     o = c->second; return true;
 }
+bool SfM::GetMeasurement(int i, int j, Pose& m) {                                            // same lookup as GetObservation (src/sfm.cpp:148-154) on the m x m map
+    auto r = measurements.find(i); if (r == measurements.end()) return false;
+    auto c = r->second.find(j); if (c == r->second.end()) return false;
+    m = c->second; return true;
+}
 void SfM::MergePoint(int point1, int point2) {                                                // src/sfm.cpp:129-141
     for (auto& row : observations) {
         if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;

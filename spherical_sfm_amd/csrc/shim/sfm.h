@@ -54,6 +54,7 @@ protected:
     std::map<int, Camera> cameras;
     std::map<int, Point> points;
     std::map<int, std::map<int, Observation>> observations;   // [camera][point]
+    std::map<int, std::map<int, Pose>> measurements;           // [camera][camera], include/sphericalsfm/sfm.h:27 (the reference never writes it either)
     std::map<int, std::string> paths;
     std::map<int, std::array<unsigned char, 3>> colors;        // BGR like cv::Vec3b (the reference's SparseVector<cv::Vec3b>)
     std::map<int, std::vector<float>> descriptors;             // SparseVector<cv::Mat>, one row of floats per point
@@ -88,6 +89,7 @@ public:
     int GetNumCameras() { return numCameras; }
     int GetNumPoints() { return numPoints; }
     bool GetObservation(int camera, int point, Observation& observation);
+    bool GetMeasurement(int i, int j, Pose& measurement);      // include/sphericalsfm/sfm.h:71 -- declared there and defined nowhere in the reference; here: lookup in `measurements`
 
     void Retriangulate();                         // src/sfm.cpp:156-192
     bool Optimize();                              // src/sfm.cpp:228-290: true iff CONVERGENCE; exit(1) on FAILURE
