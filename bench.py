@@ -156,6 +156,7 @@ def main():
                          "exercises the sharded path on a 1-GPU box; not a performance configuration)")
     ap.add_argument("--no-side-paths", action="store_true", help="skip the pairwise-RANSAC and rotation-averaging side measurements (N = 1)")
     ap.add_argument("--no-configs4", action="store_true", help="N > 1: skip the configs[4] problem sharded over the N ranks")
+    ap.add_argument("--no-collective-probe", action="store_true", help="N > 1: skip the timing probe that re-runs the sharded solve with its reductions switched off")
     ap.add_argument("--no-pairwise", action="store_true", help="N > 1: skip BASELINE configs[3] (exhaustive pairwise RANSAC) sharded over the N ranks")
     ap.add_argument("--pairwise-pairs", type=int, default=1999000, help="N > 1: image pairs of the pairwise_sharded leg (default: the 2000-frame exhaustive circle)")
     args = ap.parse_args()
@@ -371,6 +372,22 @@ def main():
                 "kernels": kernel_rooflines(kernb, Mb, 1500000, sq["reduced_blocks"], 4000, sq["camera_dof"], float((kkb * (kkb - 1) / 2).sum()), nlb),
                 "all_kernels_avg_us": {k: v["avg_us"] for k, v in kernb.items()},
                 "share_of_gpu_time": {k: v["total_ms"] / max(1e-12, sum(w["total_ms"] for w in kb.values())) for k, v in kb.items()}}
+    if world > 1 and not args.no_collective_probe:
+        # What do the collectives cost?  The same sharded solve with the reductions switched off (SSFM_TIMING_SKIP_ALLREDUCE: every rank iterates on its own
+        # shard, results meaningless, kernels and sizes unchanged); per LM iteration, rank 0's count.  Reported next to the real figure, never as `value`.
+        os.environ["SSFM_TIMING_SKIP_ALLREDUCE"] = "1"
+        adj.reset(); adj.run(); barrier()
+        tq = time.perf_counter(); nq = 0
+        for _ in range(max(2, args.steps // 2)):
+            adj.reset(); sq = adj.run(); nq += sq["num_linearizations"]
+        torch.cuda.synchronize(); tq = time.perf_counter() - tq
+        del os.environ["SSFM_TIMING_SKIP_ALLREDUCE"]
+        barrier()
+        if rank == 0:
+            with_ms = 1e3 * elapsed / max(1, n_lm); without_ms = 1e3 * tq / max(1, nq)
+            out["timing_without_collective"] = {"ms_per_lm_iteration": without_ms, "ms_per_lm_iteration_with_collectives": with_ms,
+                                                "collective_cost_ms_per_lm_iteration_estimate": with_ms - without_ms, "lm_iterations_timed_rank0": nq,
+                                                "note": "reductions skipped: every rank solved its own shard; a timing probe, its results are not a solution"}
     if world > 1 and not args.no_configs4 and not spherical and not args.focal_free and args.cameras == 300 and args.scaling == "strong":
         # BASELINE configs[4] (the 8-GPU config): 4000 cameras / 1.5 M points / 12 M observations sharded over the N ranks of this job
         adj.close()

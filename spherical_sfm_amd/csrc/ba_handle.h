@@ -169,6 +169,9 @@ static hipError_t upload(DevBuf<T>& b, const std::vector<T, A>& v, hipStream_t s
 
 static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     if (!h->ctx->collective) return SSFM_OK;
+    // TIMING EXPERIMENT ONLY (bench.py --gpus N, `timing_without_collective`): every rank solves its own shard without the reductions -- the results are
+    // meaningless, the kernels and their sizes are those of the sharded solve, so the difference to the real run prices the collectives
+    if (std::getenv("SSFM_TIMING_SKIP_ALLREDUCE")) return SSFM_OK;
     h->span_begin(KID_ALLREDUCE);
     const int rc = ctx_allreduce(h->ctx, buf, n, op);
     h->span_end();
