@@ -1211,6 +1211,57 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
     }
 }
 
+// LmGate: what the host knows when it queues the end of iteration k -- enough for the device to decide "step accepted, go on" (see k_publish below)
+struct LmGate {
+    int enabled, last_successful;
+    double radius, x_norm, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius;
+};
+__device__ __forceinline__ double coherent_load(const double* p) {          // straight from L2: the value another workgroup's atomics / stores left there
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)b);
+}
+// The end-of-iteration hand-over (fold of the scalar replicas, solver flags, the device's accept decision, sequence number into pinned host memory) as a
+// function any workgroup of >= 64 threads can run: k_publish is one launch of it, k_point_backsub's last workgroup runs it in place of that launch.
+__device__ __forceinline__ void publish_body(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
+                                             const LmGate& gate, double* __restrict__ spec, double* folded /* LDS [SC_TOTAL] */) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int k = w; k < SC_TOTAL; k += nw) {
+        const double v = coherent_load(scal + (size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k);
+        const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);
+        if (lane == 0) folded[k] = r;
+    }
+    __syncthreads();
+    if (w == 0) {
+        if (lane < SC_TOTAL) host_out[lane] = folded[lane];
+        else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = coherent_load(pcg + lane - SC_TOTAL);
+        if (spec && lane == 0) {
+            double go = 0.0, new_radius = gate.radius;
+            if (gate.enabled) {
+                int fail_word; { const double fw = coherent_load(pcg + PCG_TOTAL); __builtin_memcpy(&fail_word, &fw, sizeof(int)); }
+                const double x_cost = folded[SC_COST], gmax = folded[SC_GMAX], model = -folded[SC_MODEL], cand = folded[SC_CAND_COST];
+                bool ok = isfinite(x_cost) && !(gate.last_successful && gmax <= gate.gradient_tolerance);
+                ok = ok && fail_word == 0 && coherent_load(pcg + PCG_DONE) != 0.0 && isfinite(model) && model > 0.0 && isfinite(cand);
+                const double step_norm = sqrt(folded[SC_STEP2_PT] + folded[SC_STEP2_CAM]);
+                ok = ok && !(step_norm <= gate.parameter_tolerance * (gate.x_norm + gate.parameter_tolerance));
+                const double cost_change = x_cost - cand;
+                ok = ok && !(fabs(cost_change) <= gate.function_tolerance * x_cost);
+                const double rel = cost_change / model;
+                ok = ok && rel > gate.min_relative_decrease;
+                if (ok) {
+                    const double t = 2.0 * rel - 1.0;
+                    new_radius = fmin(gate.max_radius, gate.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                    ok = new_radius > gate.min_radius;
+                }
+                go = ok ? 1.0 : 0.0;
+            }
+            spec[0] = go; spec[1] = new_radius;
+            host_out[SC_TOTAL + PCG_TOTAL + 2] = go; host_out[SC_TOTAL + PCG_TOTAL + 3] = new_radius;
+        }
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SC_TOTAL + PCG_TOTAL + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
 //   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
 //   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
@@ -1225,9 +1276,14 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
                 // residual check of the reduced solve (what k_ref_residual does), by one extra workgroup behind the point workgroups when
                 // res_r is given: the single-workgroup launch leaves the critical path of the iteration
                 const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
-                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg) {
+                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg,
+                // fused hand-over (pub_host != nullptr): the workgroup that finishes LAST (a ticket) folds the scalars and publishes them, which
+                // takes the k_publish launch (4.7 us in a dependent stream) off the iteration
+                int* __restrict__ pub_ticket = nullptr, double* __restrict__ pub_host = nullptr, unsigned long long pub_seq = 0,
+                const LmGate pub_gate = LmGate(), double* __restrict__ pub_spec = nullptr) {
     __shared__ double red[4 * 4];
-    if (res_r && blockIdx.x == gridDim.x - 1) {
+    const bool residual_block = res_r && blockIdx.x == gridDim.x - 1;
+    if (residual_block) {
         __shared__ double sqf;
         const int n = Nc * DC;
         double a0[1] = {0.0};
@@ -1246,11 +1302,11 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             res_pcg[PCG_RR] = a2[0]; res_pcg[PCG_BN2] = a2[1]; res_pcg[PCG_ITERS] = 0.0; res_pcg[PCG_BREAKDOWN] = 0.0;
             res_pcg[PCG_DONE] = (a2[0] <= res_tol2 * a2[1]) ? 1.0 : 0.0;
         }
-        return;
+        if (!pub_host) return;
     }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
-    if (p < nP) {
+    if (!residual_block && p < nP) {
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC];
@@ -1319,7 +1375,19 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
     const double t = wave_transpose_sum(acc);
     const int slot = wave_tr_index();
     double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
-    if (slot < 4) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
+    if (slot < 4 && !residual_block) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
+    if (pub_host) {
+        __shared__ int s_last; __shared__ double folded[SC_TOTAL];
+        __threadfence();                                    // this workgroup's sums / flags are in L2 before its ticket is
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(pub_ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (threadIdx.x == 0) *pub_ticket = 0;
+            publish_body(scal, res_pcg, pub_host, pub_seq, pub_gate, pub_spec, folded);
+        }
+    }
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------
@@ -1362,48 +1430,11 @@ k_scal_fold(double* __restrict__ scal, double* __restrict__ packed, int rank) {
 // LmGate: what the host knows when it queues the end of iteration k -- enough for the device to decide "step accepted, go on" by the
 // rules of the host loop (ba_solver.hip) and to compute the next trust-region radius.  The decision only gates a speculative launch of
 // the next iteration's k_point_lin (queued before the host has seen the scalars); the host decides for itself and stays authoritative.
-struct LmGate {
-    int enabled, last_successful;
-    double radius, x_norm, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius;
-};
 static __global__ void __launch_bounds__(SC_TOTAL * 64)
 k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
           const LmGate gate, double* __restrict__ spec) {
     __shared__ double folded[SC_TOTAL];
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double v = scal[(size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k];
-    const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);
-    if (lane == 0) folded[k] = r;
-    __syncthreads();
-    if (k == 0) {
-        if (lane < SC_TOTAL) host_out[lane] = folded[lane];
-        else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = pcg[lane - SC_TOTAL];
-        if (spec && lane == 0) {
-            double go = 0.0, new_radius = gate.radius;
-            if (gate.enabled) {
-                int fail_word; { const double fw = pcg[PCG_TOTAL]; __builtin_memcpy(&fail_word, &fw, sizeof(int)); }
-                const double x_cost = folded[SC_COST], gmax = folded[SC_GMAX], model = -folded[SC_MODEL], cand = folded[SC_CAND_COST];
-                bool ok = isfinite(x_cost) && !(gate.last_successful && gmax <= gate.gradient_tolerance);
-                ok = ok && fail_word == 0 && pcg[PCG_DONE] != 0.0 && isfinite(model) && model > 0.0 && isfinite(cand);
-                const double step_norm = sqrt(folded[SC_STEP2_PT] + folded[SC_STEP2_CAM]);
-                ok = ok && !(step_norm <= gate.parameter_tolerance * (gate.x_norm + gate.parameter_tolerance));
-                const double cost_change = x_cost - cand;
-                ok = ok && !(fabs(cost_change) <= gate.function_tolerance * x_cost);
-                const double rel = cost_change / model;
-                ok = ok && rel > gate.min_relative_decrease;
-                if (ok) {
-                    const double t = 2.0 * rel - 1.0;
-                    new_radius = fmin(gate.max_radius, gate.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                    ok = new_radius > gate.min_radius;
-                }
-                go = ok ? 1.0 : 0.0;
-            }
-            spec[0] = go; spec[1] = new_radius;
-            host_out[SC_TOTAL + PCG_TOTAL + 2] = go; host_out[SC_TOTAL + PCG_TOTAL + 3] = new_radius;
-        }
-        __threadfence_system();
-        if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SC_TOTAL + PCG_TOTAL + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    publish_body(scal, pcg, host_out, seq, gate, spec, folded);
 }
 // after the all-reduce: sums back into replica 0, gradient max = max over the per-rank slots
 static __global__ void __launch_bounds__(64)

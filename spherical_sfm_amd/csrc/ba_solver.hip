@@ -103,6 +103,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
     const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
     bool lin_done = false, spec_launched = false;
+    // EXPERIMENT, off (SSFM_PUBLISH_FUSED=1): the end-of-iteration hand-over in the last workgroup of k_point_backsub (arrival ticket) instead of a k_publish
+    // launch.  Measured: k_point_backsub 22.8 -> 55.9 us at config 2 and 380 -> 1290 us at the configs[4] size -- every workgroup needs an agent-scope release
+    // fence (an L2 write-back on this multi-XCD part) + a same-address atomic before it may leave, which costs far more than the 4.7 us launch it saves.
+    static const bool fused_publish = std::getenv("SSFM_PUBLISH_FUSED") && std::atoi(std::getenv("SSFM_PUBLISH_FUSED")) != 0;
+    if (fused_publish && poll && !h->pub_ticket.p) {
+        SSFM_HIP_CHECK(ctx, h->pub_ticket.alloc(1)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pub_ticket.p, 0, sizeof(int), st));
+    }
     static const bool zone_clear_fused = !(std::getenv("SSFM_ZONE_CLEAR_FUSED") && std::atoi(std::getenv("SSFM_ZONE_CLEAR_FUSED")) == 0);
     // per-phase device times (summary.t_kernel_*_ms) cost five event records and four queries per iteration, the queries on the
     // host's critical path between two iterations: only with profiling on (ssfm_ba_set_profiling) or options.verbose
@@ -191,12 +198,31 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                 LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p, Nc <= 1024 ? 1 : 0);
                 if (Nc > 1024) LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_c, rot_c, Nc);
             }
+            bool published = false;
             if (nP > 0) {
                 const bool res = !with_cams && residual_later;      // first pass of the iteration: the residual check rides along
+                // hand-over fused into this launch (its last workgroup publishes): single rank, polling hand-over, first pass of the iteration
+                const bool fuse_pub = fused_publish && poll && !ctx->collective && res && h->pub_ticket.p;
+                if (fuse_pub) {
+                    LmGate g; std::memset(&g, 0, sizeof(g)); double* specp = nullptr;
+                    spec_launched = false;
+                    if (spec_on && !(h->profile || O.verbose) && iteration < O.max_num_iterations) {
+                        g.enabled = 1; g.last_successful = last_successful ? 1 : 0; g.radius = radius; g.x_norm = x_norm;
+                        g.function_tolerance = O.function_tolerance; g.gradient_tolerance = O.gradient_tolerance; g.parameter_tolerance = O.parameter_tolerance;
+                        g.min_relative_decrease = O.min_relative_decrease; g.max_radius = O.max_trust_region_radius; g.min_radius = O.min_trust_region_radius;
+                        specp = h->lmdev.p; spec_launched = true;
+                    }
+                    LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + 1, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                           h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                           h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, h->pr.p, h->pcg.p,
+                           h->pub_ticket.p, h->host_pub, ++ctx->pub_seq, g, specp);
+                    published = true;
+                } else
                 LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                        h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                        h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p);
             }
+            if (published) return SSFM_OK;
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
             if (poll) {
