@@ -144,6 +144,19 @@ def test_ragged_tracks_replay_the_oracle_trace(oracle):
     assert not Xg[keep_n == 2].any()
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_random_shapes_noise_levels_and_flipped_cameras(oracle, case):
+    """scripts/soak_retri_trace.py in small (60 cases / 94 563 points there: no difference at all, points bit-identical): heavy noise, up to 60 % of the
+    points with a gross outlier, ragged tracks, cameras turned around so that points fall behind them (DBL_MAX errors)."""
+    rng = np.random.default_rng(700 + case)
+    Nc = int(rng.choice([24, 60, 200])); K = min(int(rng.choice([3, 5, 8, 12, 20])), Nc // 4); Np = int(rng.integers(300, 1500))
+    prob = synth.make_circle(Nc, Np, K, rot_noise_deg=0.5, pixel_noise=float(rng.choice([0.2, 1.5, 4.0])), seed=int(rng.integers(1, 10 ** 6)), check_in_frame=False, xy_range=0.25)
+    synth.corrupt_observations(prob, float(rng.choice([0.1, 0.3, 0.6])), seed=case)
+    if case % 2 == 0:
+        cams = prob.cameras.copy(); cams[::7, 3:] += [0.0, np.pi, 0.0]; prob = dataclasses.replace(prob, cameras=cams)
+    _compare(prob, oracle)
+
+
 def test_full_size_config2(oracle):
     """BASELINE config 2 sizes: 300 cameras x 100k points x 600k observations -- 100 % identical inlier sets, points <= 1e-9."""
     prob = synth.make_circle(300, 100000, 6, rot_noise_deg=0.0, pixel_noise=0.5, seed=3)
