@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64)
 k_rot_gather_nodes(int n_nodes, int n_edge_parts, const int* __restrict__ nadj_ptr, const int* __restrict__ nadj_edge, const unsigned char* __restrict__ nadj_side,
                    const int* __restrict__ nadj_slot, const unsigned char* __restrict__ nadj_first, const double* __restrict__ ejac, const double* __restrict__ edge_part,
                    const int* __restrict__ row_ptr, const int* __restrict__ diag_slot, double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag,
-                   double* __restrict__ Sfc, double* __restrict__ scal) {
+                   double* __restrict__ Sfc, double* __restrict__ scal, double* __restrict__ pcg_fail /* the word behind the solver flags */) {
     __shared__ double tmp[64][9];
     const int i = blockIdx.x, lane = threadIdx.x;
     const int a0 = nadj_ptr[i], deg = nadj_ptr[i + 1] - a0;
@@ -252,8 +252,12 @@ k_rot_gather_nodes(int n_nodes, int n_edge_parts, const int* __restrict__ nadj_p
 #pragma unroll
         for (int k = 0; k < 9; k++) dst[k] = acc[k];
     }
-    // ---- wave 0 folds the scalar partials of the edge pass (complete before this launch started) in workgroup order
+    // ---- wave 0 folds the scalar partials of the edge pass (complete before this launch started) in workgroup order, and resets what the rest of the
+    // iteration accumulates into by atomic max / sets only on failure (the gradient-max slot of every scalar replica, the factorisation's fail word): with
+    // plain stores everywhere else the per-iteration memset of the zone is not needed
     if (i != 0) return;
+    scal[(size_t)lane * SC_TOTAL + SC_GMAX] = 0.0;
+    if (lane == 0) pcg_fail[0] = 0.0;
     double c[3] = {0.0, 0.0, 0.0};
     for (int k = lane; k < n_edge_parts; k += 64) { const double* q = edge_part + 3 * (size_t)k; c[0] += q[0]; c[1] += q[1]; c[2] += q[2]; }
 #pragma unroll
@@ -554,7 +558,10 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     std::memset(S, 0, sizeof(*S));
     ssfm_ba_options O; if (opt_in) O = *opt_in; else ssfm_rotavg_default_options(&O);
     const double t0 = wall_s();
+    const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; double t_last = t0;
+    auto lap = [&](const char* what) { if (!timing) return; const double t = wall_s(); std::fprintf(stderr, "[rot] %-34s %7.3f ms\n", what, 1e3 * (t - t_last)); t_last = t; };
     RotGraph G; build_graph(n, rotations, E, index0, index1, rel, kind, true, G);
+    lap("build_graph (so3ln, edge constants)");
     const bool with_f = kind == 2;
     const double f_lo = with_f ? min_focal / *focal_length : 0.0, f_hi = with_f ? max_focal / *focal_length : 0.0;   // :181-182
     // ---- reduced-system container (the BA handle's solver state with DC = 3)
@@ -575,6 +582,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         band_plan(n, 3, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy);
         for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     }
+    lap("S structure + band plan");
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
     // scale laid out 6 per node (slots 3..5) so that k_finalize_S<3> can be reused unchanged
     std::vector<double> mask6((size_t)6 * n, 0.0); for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) mask6[6 * i + 3 + k] = G.mask[3 * i + k];
@@ -648,7 +656,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         if (node_major) {
             hipLaunchKernelGGL(k_rot_edge_records, dim3(ge), dim3(64), 0, st, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, RS.ejac.p, RS.node_part.p);
             hipLaunchKernelGGL(k_rot_gather_nodes, dim3(n), dim3(64), 0, st, n, ge, RS.nadj_ptr.p, RS.nadj_edge.p, RS.nadj_side.p, RS.nadj_slot.p, RS.nadj_first.p, RS.ejac.p, RS.node_part.p,
-                               h->row_ptr.p, h->diag_slot.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
+                               h->row_ptr.p, h->diag_slot.p, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p, h->pcg.p + PCG_TOTAL);
         } else
         hipLaunchKernelGGL(k_rot_edges, dim3(ge), dim3(64), 0, st, 0, kind, E, e0.p, e1.p, ec.p, G.scale, la, xx, fmx, s3, sf, h->row_ptr.p, h->col_idx.p, n,
                            (const double*)nullptr, h->S_val, h->rhs, h->Udiag, h->Sfc, h->scal.p);
@@ -664,6 +672,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         hipLaunchKernelGGL(k_scale3to6, dim3((6 * n + 255) / 256), dim3(256), 0, st, sc3.p, n, sc6.p);
         SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
+    lap("allocations, uploads, Jacobi scaling");
     double x_norm = 0; { double s2 = with_f ? fm0 * fm0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
     int iteration = 0, num_invalid = 0; bool last_successful = true;
@@ -718,8 +727,9 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
             return SSFM_OK;
         };
         { int rc = fused_tail ? tail_fused() : tail(); if (rc) return rc; }
-        // the other zone (the previous iteration's) is cleared while the host waits and decides
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)(zi ^ 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
+        // the other zone (the previous iteration's) is cleared while the host waits and decides -- unless every kernel of the iteration stores instead of
+        // accumulating (node-major assembly + fused tail: k_rot_gather_nodes resets the two words that are not plainly stored)
+        if (!fused_tail) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + (size_t)(zi ^ 1) * h->zone_len, 0, h->zone_len * sizeof(double), st));
         { int rc = wait_tail(); if (rc) return rc; }
         if (O.preconditioner == 0) {
             int ff; std::memcpy(&ff, &host_pcg[PCG_TOTAL], sizeof(int));
@@ -793,6 +803,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         if (O.verbose) std::printf("[ssfm rot] iter %3d cost %.12e change %.3e |g| %.3e |step| %.3e rho %.3e radius %.3e %s\n", iteration, x_cost, cost_change,
                                    gmax, step_norm, rel, radius, last_successful ? "" : "(rejected)");
     }
+    lap("LM loop");
     S->iterations = iteration; S->final_cost = (minimum_cost == std::numeric_limits<double>::max()) ? x_cost : minimum_cost;
     S->reduced_blocks = (int32_t)nnzb; S->band_half_width = F.band;
     // ---- back to rotation matrices: every rotation is re-exponentiated (src/rotation_averaging.cpp:88)
@@ -802,6 +813,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < n; i++) { double R[9]; so3exp(&xf[3 * i], R); for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rotations[9 * i + a + 3 * b] = R[3 * a + b]; }
     if (with_f) *focal_length *= fmult;                                         // src/uncalibrated_pose_graph.cpp:200
+    lap("download + so3exp");
     S->t_solve_s = wall_s() - t0;                          // RotScratch releases the buffers
     return SSFM_OK;
 }
