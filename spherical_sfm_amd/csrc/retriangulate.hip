@@ -635,32 +635,50 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
         const unsigned* req = req_it + req_ptr[slot];
         double best_score = TRI_DMAX, best_min[3] = {0, 0, 0}, best_min_score = TRI_DMAX;
         unsigned max_it = TRI_MAX_IT;                                         // max(max_num_iterations_, min_num_iterations_)
-        for (it = 0; it < max_it; ++it) {
-            if (it == o.lo_start && best_min_score < TRI_DMAX) {              // ransac.h:162-176
-                ++lo_count;
-                tt_local_optimization(c, o, g, base, work, best, &best_score);
-                nin = tt_inliers(c, best, o.thr, listI);
-                max_it = req[nin];
-            }
-            int sample[2] = {smp[2 * it], smp[2 * it + 1]};
-            double X[3];
-            tt_dlt<4>(c, sample, 2, 2, X);                                    // MinimalSolver: one model
-            const double sc = tt_score(c, X, o.thr);
-            // (skipping ordered pairs that were drawn before -- their models and scores repeat bit for bit and cannot become a new best -- was measured:
-            //  23.4 -> 25.9 ms; the local optimisation's ~120 least-squares fits per point are 85 % of the work, the branch costs more than it saves)
-            if (sc < best_min_score || it == o.lo_start) {                    // ransac.h:183-225
-                const bool best_min_model = sc < best_min_score;
-                if (best_min_model) { best_min_score = sc; best_min[0] = X[0]; best_min[1] = X[1]; best_min[2] = X[2]; tt_update(best_min_score, best_min, &best_score, best); }
-                const bool run_lo = (it >= o.lo_start && best_min_score < TRI_DMAX);
-                if (!best_min_model && !run_lo) continue;
-                if (run_lo) {
-                    ++lo_count;
-                    double s2 = best_min_score;
-                    tt_local_optimization(c, o, g, base, work, best_min, &s2);
-                    tt_update(s2, best_min, &best_score, best);
+        // EstimateModel's loop (ransac.h:154-229) as a per-lane state machine.  A lane's sequence of operations is the reference's; what changes is WHEN
+        // the wave executes them: a local optimisation is ~100x an iteration, and lanes call it at different iterations (whenever their point finds a
+        // new best minimal model after iteration 50) -- run where the loop calls it, the wave executed up to 64 of them one after the other with one lane
+        // active each.  Here a lane that needs one PARKS (need != 0) while the others go on iterating; when every lane is parked or finished the parked
+        // ones run it together, then all resume.  Rounds = the largest number of local optimisations of any lane of the wave (2-4).
+        //   phase 0: top of iteration `it` (loop test, the lo_starting_iterations_ call of ransac.h:162-176)   phase 1: sample, solve, score, update
+        int phase = 0; bool done = false;
+        it = 0;
+        while (true) {
+            int need = 0;                                                     // 1: LocalOptimization(best_model) at lo_start; 2: LocalOptimization(best_minimal_model)
+            while (!done) {
+                if (phase == 0) {
+                    if (!(it < max_it)) { done = true; break; }
+                    if (it == o.lo_start && best_min_score < TRI_DMAX) { need = 1; break; }
+                    phase = 1;
                 }
+                int sample[2] = {smp[2 * it], smp[2 * it + 1]};
+                double X[3];
+                tt_dlt<4>(c, sample, 2, 2, X);                                // MinimalSolver: one model
+                const double sc = tt_score(c, X, o.thr);
+                if (sc < best_min_score || it == o.lo_start) {                // ransac.h:183-225
+                    const bool best_min_model = sc < best_min_score;
+                    if (best_min_model) { best_min_score = sc; best_min[0] = X[0]; best_min[1] = X[1]; best_min[2] = X[2]; tt_update(best_min_score, best_min, &best_score, best); }
+                    const bool run_lo = (it >= o.lo_start && best_min_score < TRI_DMAX);
+                    if (best_min_model || run_lo) {
+                        if (run_lo) { need = 2; break; }
+                        nin = tt_inliers(c, best, o.thr, listI);
+                        max_it = req[nin];
+                    }
+                }
+                ++it; phase = 0;
+            }
+            if (__ballot(need != 0) == 0ull) break;                           // every lane of the wave has finished its loop
+            if (need != 0) {                                                  // the parked lanes, together
+                double model[3], msc;
+                if (need == 1) { model[0] = best[0]; model[1] = best[1]; model[2] = best[2]; msc = best_score; }
+                else { model[0] = best_min[0]; model[1] = best_min[1]; model[2] = best_min[2]; msc = best_min_score; }
+                ++lo_count;
+                tt_local_optimization(c, o, g, base, work, model, &msc);
+                if (need == 1) { best[0] = model[0]; best[1] = model[1]; best[2] = model[2]; best_score = msc; phase = 1; }      // then the same iteration goes on with its sample
+                else { best_min[0] = model[0]; best_min[1] = model[1]; best_min[2] = model[2]; tt_update(msc, best_min, &best_score, best); }
                 nin = tt_inliers(c, best, o.thr, listI);
                 max_it = req[nin];
+                if (need == 2) { ++it; phase = 0; }
             }
         }
         if (it <= o.lo_start && best_score < TRI_DMAX) {                      // ransac.h:232-243 (never reached with min_num_iterations_ 100 > 50)
