@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <condition_variable>
 #include <functional>
@@ -93,7 +94,16 @@ struct BAFlat {
     int64_t pair_batches = 0;           // 64-entry batches of the pair lists (the lists themselves may live on the device only)
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
+    // Signature groups (round 3, k_schur_gram): runs of >= GRAM_MIN_RUN consecutive points observed by exactly the same K <= GRAM_KMAX cameras.  Their
+    // off-diagonal Schur blocks are formed as ONE Gram product per 64 points on the matrix cores, each observation linearised once, instead of lane-per-pair
+    // from the pair lists (which then skip these points: pt_grouped).  Task t = points [gr_pt0[t], gr_pt0[t] + gr_cnt[t]) (<= GRAM_PTS), cameras
+    // gr_cam[t * GRAM_KMAX ..] ascending, gr_slot[t * GRAM_NPAIR + a (a - 1) / 2 + b] (a > b) = block index of (camera a, camera b) in S, bit 30 set when
+    // the stored block is (row camera b, column camera a), i.e. the transpose.
+    std::vector<int> gr_pt0, gr_cnt, gr_K, gr_cam, gr_slot;
+    raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
+    int64_t gram_points = 0; int gram_kmax = 0;
 };
+constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_PTS = 64, GRAM_MIN_RUN = 32;
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
 // once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
@@ -303,6 +313,7 @@ inline void pair_counts_host(const BAFlat& F, int NT, std::vector<int>& slot_cnt
             for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
             for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
                 const int p = F.cam_obs_pt[q];
+                if (!F.pt_grouped.empty() && F.pt_grouped[p]) continue;                  // its blocks come from k_schur_gram
                 for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) { const int c2 = F.obs_cam[j2]; if (F.cam_pos[c2] < pc) slot_cnt[rb + slot_of[c2]]++; }   // diagonal blocks: k_cam_sums2
             }
             for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = -1;
@@ -360,6 +371,7 @@ inline void pair_fill_host(BAFlat& F, int NT, std::vector<int64_t>& slot_off) {
             for (int e = 0; e < nnb; e++) slot_of[F.col_idx[rb + e]] = e;
             for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q++) {
                 const int j = F.cam_obs[q], p = F.cam_obs_pt[q];
+                if (!F.pt_grouped.empty() && F.pt_grouped[p]) continue;
                 for (int j2 = F.pt_start[p]; j2 < F.pt_start[p + 1]; j2++) {
                     const int c2 = F.obs_cam[j2]; if (!(F.cam_pos[c2] < pc)) continue;
                     const int64_t w = slot_off[rb + slot_of[c2]]++;
@@ -630,6 +642,45 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     for (int c = 0; c < Nc; c++)
         for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += cs_run) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + cs_run, F.cam_start[c + 1])); }
     lap("camera-major lists");
+    // ---- signature groups for k_schur_gram (see BAFlat::gr_*): consecutive points with identical camera lists
+    {
+        static const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);
+        static const int gram_pts = std::getenv("SSFM_GRAM_PTS") ? std::max(16, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : GRAM_PTS;   // points per wave task
+        F.pt_grouped.resize((size_t)F.nP);
+        if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
+        if (gram_on && F.sym_lower) {
+            auto same = [&](int q0, int q1) {
+                const int k0 = F.pt_start[q0 + 1] - F.pt_start[q0]; if (F.pt_start[q1 + 1] - F.pt_start[q1] != k0) return false;
+                for (int k = 0; k < k0; k++) if (F.obs_cam[F.pt_start[q0] + k] != F.obs_cam[F.pt_start[q1] + k]) return false;
+                return true;
+            };
+            for (int q = 0; q < F.nP;) {
+                int e = q + 1; while (e < F.nP && same(q, e)) e++;
+                const int K = F.pt_start[q + 1] - F.pt_start[q];
+                if (e - q >= GRAM_MIN_RUN && K >= 2 && K <= GRAM_KMAX) {
+                    const int* cams = &F.obs_cam[F.pt_start[q]];
+                    int slots[GRAM_NPAIR]; for (int i = 0; i < GRAM_NPAIR; i++) slots[i] = -1;
+                    for (int a = 1; a < K; a++) for (int b = 0; b < a; b++) {
+                        const int ca = cams[a], cb = cams[b];
+                        const bool row_a = F.cam_pos[ca] > F.cam_pos[cb];           // the stored block sits in the row of the camera eliminated later
+                        const int row = row_a ? ca : cb, col = row_a ? cb : ca;
+                        const int sl = (int)(std::lower_bound(F.col_idx.begin() + F.row_ptr[row], F.col_idx.begin() + F.row_ptr[row + 1], col) - F.col_idx.begin());
+                        slots[a * (a - 1) / 2 + b] = sl | (row_a ? 0 : (1 << 30));
+                    }
+                    for (int t0 = q; t0 < e; t0 += gram_pts) {
+                        F.gr_pt0.push_back(t0); F.gr_cnt.push_back(std::min(gram_pts, e - t0)); F.gr_K.push_back(K);
+                        for (int k = 0; k < GRAM_KMAX; k++) F.gr_cam.push_back(k < K ? cams[k] : cams[0]);
+                        F.gr_slot.insert(F.gr_slot.end(), slots, slots + GRAM_NPAIR);
+                    }
+                    std::memset(F.pt_grouped.data() + q, 1, (size_t)(e - q));
+                    F.gram_points += e - q; F.gram_kmax = std::max(F.gram_kmax, K);
+                }
+                q = e;
+            }
+        }
+    }
+    if (timing) std::fprintf(stderr, "[plan] signature groups: %lld of %d points in %zu tasks\n", (long long)F.gram_points, F.nP, F.gr_pt0.size());
+    lap("signature groups");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     if (host_pairs) {
         std::vector<int> slot_cnt; pair_counts_host(F, NT, slot_cnt);

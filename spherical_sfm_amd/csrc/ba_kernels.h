@@ -568,6 +568,133 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
     if (cur >= 0) fold();
 }
 
+// ---- Schur complement of SIGNATURE GROUPS on the matrix cores (round 3) -----------------------------------------------------------------
+// A task = up to GRAM_PTS consecutive points observed by exactly the same K <= 8 cameras (BAFlat::gr_*).  With V^-1 = L L^T per point and the half
+// products Y_k = Jc_k^T Jp_k L (DC x 3) of its K observations stacked into a (DC K) x 3 matrix per point, the off-diagonal blocks of all K (K - 1) / 2
+// camera pairs are the blocks of ONE Gram matrix  G = sum_points Y Y^T  -- every observation is linearised ONCE (the pair kernel re-linearises it
+// K - 1 times) and the products run as v_mfma_f64_16x16x4_f64 tiles.  FP64 MFMA has the VALU's flop rate on gfx950; what it buys is issue slots:
+// one instruction per 1024 multiply-adds with its operands from LDS, against ~470 VALU instructions per 64 pairs.
+// One wave per task, sub-chunks of 16 points: lane (point = lane & 15, quarter = lane >> 4) linearises observations quarter, quarter + 4 of its point
+// (camera records staged in LDS once per task) and lays Y out in LDS as sY[row = DC k + d][3 point + c] (48 columns, leading dimension 52: the
+// fragment loads below touch every bank twice, the hardware minimum for 64 x 8 bytes); then the wave runs the tiles of the lower triangle over the
+// 12 k-steps, accumulating across sub-chunks; at the end every lane adds the entries it holds of blocks (a > b) to S with the Jacobi scales of both
+// cameras (the pair kernel's convention: unscaled Jc, scales at the fold).  Diagonal blocks (a = b) are k_cam_sums2's and are skipped.
+// Rows >= DC K of a tile hold whatever LDS holds: row i of Y only reaches row i and column i of G, and those entries are never emitted -- so nothing is
+// zeroed and the launch sizes LDS for the largest K of the problem (rows_alloc = DC Kmax rows + the camera records: 17 KB for K = 6, 9 waves per CU).
+// The points' records of the NEXT sub-chunk are loaded before the tiles of the current one run (the observations of a group are consecutive, K per point:
+// no dependent index load), so the matrix pipe covers the load latency; two waves per SIMD cover each other's linearisation.
+constexpr int GRAM_LD = 52, GRAM_SUB = 16, GRAM_CAMREC = 34;
+template <int DC>
+__global__ void __launch_bounds__(64)
+k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+             const double2* __restrict__ obs_xy, const int* __restrict__ pt_start, int ntasks, const int* __restrict__ gr_pt0, const int* __restrict__ gr_cnt,
+             const int* __restrict__ gr_K, const int* __restrict__ gr_cam, const int* __restrict__ gr_slot, const double* __restrict__ scale_cam,
+             const double* __restrict__ Vs, int loss, double la, int rows_alloc, double* __restrict__ S_val) {
+    constexpr int BB = DC * DC, ROWS = (DC == 6) ? 48 : 32, NT = ROWS / 16, off = (DC == 6) ? 0 : 3;
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) double sY[];          // [rows_alloc][GRAM_LD] | camera records [GRAM_KMAX][GRAM_CAMREC]
+    double* sCam = sY + rows_alloc * GRAM_LD;
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x));
+    if (task >= ntasks) return;
+    const int lane = threadIdx.x;
+    const int p0 = __builtin_amdgcn_readfirstlane(gr_pt0[task]), cnt = __builtin_amdgcn_readfirstlane(gr_cnt[task]), K = __builtin_amdgcn_readfirstlane(gr_K[task]);
+    const int j00 = __builtin_amdgcn_readfirstlane(pt_start[p0]);
+    const double f = focal[0];
+    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = gr_cam[task * GRAM_KMAX + k]; sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
+    v4d_ acc[NT * (NT + 1) / 2];
+#pragma unroll
+    for (int t = 0; t < NT * (NT + 1) / 2; t++) acc[t] = v4d_{0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, lk = lane >> 4;
+    const int k0 = min(lk, K - 1), k1 = min(lk + 4, K - 1);             // this lane's two observations (clamped: a lane without a second one repeats, and does not store)
+    // point record of a sub-chunk: X, the six entries of the scaled V^-1, the two observations
+    double X[3], V[6]; double2 o0, o1;
+#define GRAM_LOAD(s0_)                                                                                                            \
+    do {                                                                                                                          \
+        const int q_ = min((s0_) + li, cnt - 1);                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) X[k] = pts[3 * (size_t)(p0 + q_) + k];                                      \
+        _Pragma("unroll") for (int k = 0; k < 6; k++) V[k] = Vs[12 * (size_t)(p0 + q_) + k];                                      \
+        o0 = obs_xy[j00 + (size_t)q_ * K + k0]; o1 = obs_xy[j00 + (size_t)q_ * K + k1];                                           \
+    } while (0)
+    GRAM_LOAD(0);
+    for (int s0 = 0; s0 < cnt; s0 += GRAM_SUB) {
+        __syncthreads();                                                 // the tiles of the previous sub-chunk have read sY (first pass: sCam is written)
+        {
+            const bool valid = s0 + li < cnt;
+            // Cholesky factor of the scaled V^-1 (all zero for a fixed point or a lane past the end of the task: its columns of Y are zero)
+            double L00 = 0, L10 = 0, L20 = 0, L11 = 0, L21 = 0, L22 = 0;
+            if (valid && V[0] > 0.0) {
+                const double i0 = fast_rsqrt(V[0]);
+                L00 = V[0] * i0; L10 = V[1] * i0; L20 = V[2] * i0;
+                const double d1 = V[3] - L10 * L10;
+                if (d1 > 0.0) {
+                    const double i1 = fast_rsqrt(d1);
+                    L11 = d1 * i1; L21 = (V[4] - L20 * L10) * i1;
+                    const double d2 = V[5] - L20 * L20 - L21 * L21;
+                    if (d2 > 0.0) L22 = d2 * fast_rsqrt(d2);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = h ? k1 : k0;
+                const double2 o = h ? o1 : o0;
+                const double* rec = sCam + k * GRAM_CAMREC;
+                ObsLin Lk; lin_obs<DC == 6>(f, rec, rec + 6, X, o.x, o.y, loss, la, Lk);
+                double Jc[2][DC]; cam_block_raw<DC>(Lk, Jc);
+                double T[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    T[r][0] = Lk.Jp[r][0] * L00 + Lk.Jp[r][1] * L10 + Lk.Jp[r][2] * L20;
+                    T[r][1] = Lk.Jp[r][1] * L11 + Lk.Jp[r][2] * L21;
+                    T[r][2] = Lk.Jp[r][2] * L22;
+                }
+                if (h == 0 ? (lk < K) : (lk + 4 < K)) {
+                    double* dst = sY + (size_t)(DC * k) * GRAM_LD + 3 * li;
+#pragma unroll
+                    for (int d = 0; d < DC; d++)
+#pragma unroll
+                        for (int cc = 0; cc < 3; cc++) dst[d * GRAM_LD + cc] = Jc[0][d] * T[0][cc] + Jc[1][d] * T[1][cc];
+                }
+            }
+        }
+        if (s0 + GRAM_SUB < cnt) GRAM_LOAD(s0 + GRAM_SUB);              // in flight while the tiles run
+        __syncthreads();
+        // tiles of the lower triangle: G(ti, tj) += Y(ti rows) Y(tj rows)^T over the 48 columns of this sub-chunk, 4 per instruction
+#pragma unroll 4
+        for (int st = 0; st < 3 * GRAM_SUB / 4; st++) {
+            double fr[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) fr[t] = sY[(size_t)min(16 * t + li, rows_alloc - 1) * GRAM_LD + 4 * st + lk];
+            int tix = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+                for (int tj = 0; tj <= ti; tj++) { acc[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[tix], 0, 0, 0); tix++; }
+        }
+    }
+#undef GRAM_LOAD
+    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg
+    int tix = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+        for (int tj = 0; tj <= ti; tj++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int R = 16 * ti + lk + 4 * reg, C = 16 * tj + li;
+                const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
+                if (a < K && b < a) {
+                    const int sl = gr_slot[task * GRAM_NPAIR + a * (a - 1) / 2 + b];
+                    const int ca = gr_cam[task * GRAM_KMAX + a], cb = gr_cam[task * GRAM_KMAX + b];
+                    const double v = -acc[tix][reg] * scale_cam[6 * ca + off + da] * scale_cam[6 * cb + off + db];
+                    double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
+                    if (loss >= 0) unsafeAtomicAdd(&blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                    else blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)] = v;
+                }
+            }
+            tix++;
+        }
+}
+
 // EXPERIMENT (SSFM_PAIRS_Y_PROBE=1, not part of the solve): the pair pass if every observation carried a stored half product
 // Y_i = Jc_i^T Jp_i L (DC x 3, V^-1 = L L^T) -- a pair would be blk -= Y_i Y_j^T (DC*DC*3 multiply-adds) and two DC*3*8-byte reads instead of two
 // re-linearisations.  Same wave tasks, same slot folds and atomics as k_schur_pairs2, into a scratch copy of S; Y holds arbitrary data.
@@ -1019,7 +1146,8 @@ template <bool FILL>
 static __global__ void __launch_bounds__(256)
 k_pair_lists(int M, const int* __restrict__ cam_obs, const int* __restrict__ cam_obs_pt, const int* __restrict__ obs_cam,
              const int* __restrict__ pt_start, const int* __restrict__ elim_pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
-             unsigned int* __restrict__ slot_ctr, int* __restrict__ pair_j, int* __restrict__ pair_j2, int* __restrict__ pair_p) {
+             unsigned int* __restrict__ slot_ctr, int* __restrict__ pair_j, int* __restrict__ pair_j2, int* __restrict__ pair_p,
+             const unsigned char* __restrict__ pt_skip = nullptr /* points whose blocks come from k_schur_gram */) {
     __shared__ unsigned int cnt[PAIR_LISTS_SLOTS];
     __shared__ unsigned int base[FILL ? PAIR_LISTS_SLOTS : 1];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1028,7 +1156,8 @@ k_pair_lists(int M, const int* __restrict__ cam_obs, const int* __restrict__ cam
     const bool local = (s1 - s0) <= PAIR_LISTS_SLOTS;
     if (local) { for (int i = threadIdx.x; i < s1 - s0; i += blockDim.x) cnt[i] = 0u; __syncthreads(); }
     int j = 0, p = 0, c = 0, pc = 0, rb = 0, nnb = 0, ja = 0, jb = 0;
-    if (q < M) { j = cam_obs[q]; p = cam_obs_pt[q]; c = obs_cam[j]; pc = elim_pos[c]; rb = row_ptr[c]; nnb = row_ptr[c + 1] - rb; ja = pt_start[p]; jb = pt_start[p + 1]; }
+    if (q < M) { j = cam_obs[q]; p = cam_obs_pt[q]; c = obs_cam[j]; pc = elim_pos[c]; rb = row_ptr[c]; nnb = row_ptr[c + 1] - rb; ja = pt_start[p]; jb = pt_start[p + 1];
+                 if (pt_skip && pt_skip[p]) jb = ja; }
     for (int j2 = ja; j2 < jb; j2++) {
         const int c2 = obs_cam[j2];
         if (!(elim_pos[c2] < pc)) continue;

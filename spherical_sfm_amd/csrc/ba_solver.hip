@@ -152,6 +152,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
+        if (!F.gr_pt0.empty()) {                                   // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram)
+            const int ng = (int)F.gr_pt0.size();
+            static const bool gram_noatomic = std::getenv("SSFM_GRAM_NOATOMIC") != nullptr;      // TIMING EXPERIMENT ONLY (wrong sums): plain stores instead of atomics
+            const int rows_alloc = DC * F.gram_kmax;
+            LAUNCH(h, KID_SCHUR_GRAM, k_schur_gram<DC>, ng, 64, ((size_t)rows_alloc * GRAM_LD + GRAM_KMAX * GRAM_CAMREC) * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, h->pt_start.p, ng,
+                   h->gr_pt0.p, h->gr_cnt.p, h->gr_K.p, h->gr_cam.p, h->gr_slot.p, h->scale_cam.p, h->Vs.p, gram_noatomic ? -1 : loss, la, rows_alloc, h->S_val);
+        }
         if (y_probe && !F.chunk_cam.empty()) {                     // experiment only (ba_kernels.h: k_pairs_y_probe)
             const int ntasks = (int)F.chunk_cam.size();
             hipLaunchKernelGGL(k_pairs_y_probe<DC>, dim3((ntasks + 3) / 4), dim3(256), 0, st, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, ntasks,
@@ -472,6 +479,8 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
         SSFM_HIP_CHECK(ctx, e1); SSFM_HIP_CHECK(ctx, e2);
     }
     UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
+    if (!F.gr_pt0.empty()) { UP(gr_pt0, F.gr_pt0); UP(gr_cnt, F.gr_cnt); UP(gr_K, F.gr_K); UP(gr_cam, F.gr_cam); UP(gr_slot, F.gr_slot); }
+    UP(pt_grouped, F.pt_grouped);
 #undef UP
 #define AL(buf, count) SSFM_HIP_CHECK(ctx, h->buf.alloc(count))
     AL(cam_c, (size_t)Nc * 6); AL(pts_c, (size_t)nP * 3); AL(rot_x, (size_t)Nc * 27); AL(rot_c, (size_t)Nc * 27);
@@ -516,7 +525,7 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(ctr.p, 0, nnzb_s * sizeof(unsigned int), st));
             const int gq = (int)((Fm.M + 255) / 256);
             hipLaunchKernelGGL((k_pair_lists<false>), dim3(gq), dim3(256), 0, st, (int)Fm.M, h->cam_obs.p, h->cam_obs_pt.p, h->obs_cam.p, h->pt_start.p, elim.p, h->row_ptr.p,
-                               h->col_idx.p, ctr.p, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+                               h->col_idx.p, ctr.p, (int*)nullptr, (int*)nullptr, (int*)nullptr, (const unsigned char*)h->pt_grouped.p);
             std::vector<int> slot_cnt(nnzb_s);
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(slot_cnt.data(), ctr.p, nnzb_s * sizeof(int), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -529,7 +538,7 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_j.p, 0xFF, npair * sizeof(int), st)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_j2.p, 0xFF, npair * sizeof(int), st));
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pair_p.p, 0xFF, npair * sizeof(int), st));
             hipLaunchKernelGGL((k_pair_lists<true>), dim3(gq), dim3(256), 0, st, (int)Fm.M, h->cam_obs.p, h->cam_obs_pt.p, h->obs_cam.p, h->pt_start.p, elim.p, h->row_ptr.p,
-                               h->col_idx.p, ctr.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p);
+                               h->col_idx.p, ctr.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, (const unsigned char*)h->pt_grouped.p);
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));           // `start` and the temporaries go out of scope
             return SSFM_OK;
         };
