@@ -96,14 +96,16 @@ struct BAFlat {
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
     // Signature groups (round 3, k_schur_gram): runs of >= GRAM_MIN_RUN consecutive points observed by exactly the same K <= GRAM_KMAX cameras.  Their
     // off-diagonal Schur blocks are formed as ONE Gram product per 64 points on the matrix cores, each observation linearised once, instead of lane-per-pair
-    // from the pair lists (which then skip these points: pt_grouped).  Task t = points [gr_pt0[t], gr_pt0[t] + gr_cnt[t]) (<= GRAM_PTS), cameras
-    // gr_cam[t * GRAM_KMAX ..] ascending, gr_slot[t * GRAM_NPAIR + a (a - 1) / 2 + b] (a > b) = block index of (camera a, camera b) in S, bit 30 set when
-    // the stored block is (row camera b, column camera a), i.e. the transpose.
-    std::vector<int> gr_pt0, gr_cnt, gr_K, gr_cam, gr_slot;
+    // from the pair lists (which then skip these points: pt_grouped).  One record of GRAM_REC ints per task:
+    //   [0] first point  [1] points (<= the task length chosen below)  [2] K  [3] first observation (the K of every point follow each other)
+    //   [4..11] the cameras, ascending  [12..39] slot[a (a - 1) / 2 + b] (a > b) = block index of (camera a, camera b) in S, bit 30 set when
+    //   the stored block is (b, a), i.e. the transpose  [40..47] the diagonal block of every camera
+    // k_schur_gram also produces the camera-side sums (k_cam_sums2's) of these points: the cs_task lists only cover cameras that have other points
+    std::vector<int> gr_rec;
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
     int64_t gram_points = 0; int gram_kmax = 0;
 };
-constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_PTS = 64, GRAM_MIN_RUN = 32;
+constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32;
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
 // once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
@@ -639,13 +641,11 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             if (best < 0 || cost < best) { best = cost; cs_run = run; }
         }
     }
-    for (int c = 0; c < Nc; c++)
-        for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += cs_run) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + cs_run, F.cam_start[c + 1])); }
     lap("camera-major lists");
     // ---- signature groups for k_schur_gram (see BAFlat::gr_*): consecutive points with identical camera lists
     {
         static const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);
-        static const int gram_pts = std::getenv("SSFM_GRAM_PTS") ? std::max(16, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : GRAM_PTS;   // points per wave task
+        static const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(16, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;   // points per wave task (0: by size)
         F.pt_grouped.resize((size_t)F.nP);
         if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
         if (gram_on && F.sym_lower) {
@@ -654,32 +654,51 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 for (int k = 0; k < k0; k++) if (F.obs_cam[F.pt_start[q0] + k] != F.obs_cam[F.pt_start[q1] + k]) return false;
                 return true;
             };
+            std::vector<int> runs;                                   // (first point, end) of every run that qualifies
             for (int q = 0; q < F.nP;) {
                 int e = q + 1; while (e < F.nP && same(q, e)) e++;
                 const int K = F.pt_start[q + 1] - F.pt_start[q];
-                if (e - q >= GRAM_MIN_RUN && K >= 2 && K <= GRAM_KMAX) {
-                    const int* cams = &F.obs_cam[F.pt_start[q]];
-                    int slots[GRAM_NPAIR]; for (int i = 0; i < GRAM_NPAIR; i++) slots[i] = -1;
-                    for (int a = 1; a < K; a++) for (int b = 0; b < a; b++) {
-                        const int ca = cams[a], cb = cams[b];
-                        const bool row_a = F.cam_pos[ca] > F.cam_pos[cb];           // the stored block sits in the row of the camera eliminated later
-                        const int row = row_a ? ca : cb, col = row_a ? cb : ca;
-                        const int sl = (int)(std::lower_bound(F.col_idx.begin() + F.row_ptr[row], F.col_idx.begin() + F.row_ptr[row + 1], col) - F.col_idx.begin());
-                        slots[a * (a - 1) / 2 + b] = sl | (row_a ? 0 : (1 << 30));
-                    }
-                    for (int t0 = q; t0 < e; t0 += gram_pts) {
-                        F.gr_pt0.push_back(t0); F.gr_cnt.push_back(std::min(gram_pts, e - t0)); F.gr_K.push_back(K);
-                        for (int k = 0; k < GRAM_KMAX; k++) F.gr_cam.push_back(k < K ? cams[k] : cams[0]);
-                        F.gr_slot.insert(F.gr_slot.end(), slots, slots + GRAM_NPAIR);
-                    }
-                    std::memset(F.pt_grouped.data() + q, 1, (size_t)(e - q));
-                    F.gram_points += e - q; F.gram_kmax = std::max(F.gram_kmax, K);
-                }
+                if (e - q >= GRAM_MIN_RUN && K >= 2 && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_kmax = std::max(F.gram_kmax, K); }
                 q = e;
+            }
+            // points per wave task: a task pays ~5 us of start-up (index loads, camera records, the atomics of its blocks at the end) whatever its length, and
+            // the chip holds ~2300 of these waves at once: two rounds' worth of tasks when the problem is small, 192 points when it is large
+            // (measured: 100 000 points 64 -> 39.5 us, 128 -> 41, 192 -> 54; 1.5 M points 64 -> 560 us, 128 -> 453, 192 -> 434)
+            int gram_pts = gram_pts_env;
+            if (gram_pts <= 0) gram_pts = (int)std::min<int64_t>(192, std::max<int64_t>(64, (F.gram_points / 4608 + 15) / 16 * 16));
+            for (size_t r = 0; r < runs.size(); r += 2) {
+                const int q = runs[r], e = runs[r + 1], K = F.pt_start[q + 1] - F.pt_start[q];
+                const int* cams = &F.obs_cam[F.pt_start[q]];
+                int slots[GRAM_NPAIR]; for (int i = 0; i < GRAM_NPAIR; i++) slots[i] = 0;
+                for (int a = 1; a < K; a++) for (int b = 0; b < a; b++) {
+                    const int ca = cams[a], cb = cams[b];
+                    const bool row_a = F.cam_pos[ca] > F.cam_pos[cb];           // the stored block sits in the row of the camera eliminated later
+                    const int row = row_a ? ca : cb, col = row_a ? cb : ca;
+                    const int sl = (int)(std::lower_bound(F.col_idx.begin() + F.row_ptr[row], F.col_idx.begin() + F.row_ptr[row + 1], col) - F.col_idx.begin());
+                    slots[a * (a - 1) / 2 + b] = sl | (row_a ? 0 : (1 << 30));
+                }
+                for (int t0 = q; t0 < e; t0 += gram_pts) {
+                    const int head[4] = {t0, std::min(gram_pts, e - t0), K, F.pt_start[t0]};
+                    F.gr_rec.insert(F.gr_rec.end(), head, head + 4);
+                    for (int k = 0; k < GRAM_KMAX; k++) F.gr_rec.push_back(k < K ? cams[k] : cams[0]);
+                    F.gr_rec.insert(F.gr_rec.end(), slots, slots + GRAM_NPAIR);
+                    for (int k = 0; k < GRAM_KMAX; k++) { const int c = k < K ? cams[k] : cams[0]; F.gr_rec.push_back(F.row_ptr[c] + F.diag_slot[c]); }
+                }
+                std::memset(F.pt_grouped.data() + q, 1, (size_t)(e - q));
             }
         }
     }
-    if (timing) std::fprintf(stderr, "[plan] signature groups: %lld of %d points in %zu tasks\n", (long long)F.gram_points, F.nP, F.gr_pt0.size());
+    // wave tasks of k_cam_sums2: cameras all of whose points sit in signature groups have none (k_schur_gram has their sums); a camera with other points
+    // keeps its whole list, and the kernel gives the grouped points among them a zero weight
+    {
+        std::vector<int> loose(Nc, F.gram_points == 0 ? 1 : 0);
+        if (F.gram_points > 0 && F.gram_points < F.nP)
+            for (int q = 0; q < F.nP; q++) if (!F.pt_grouped[q]) for (int j = F.pt_start[q]; j < F.pt_start[q + 1]; j++) loose[F.obs_cam[j]] = 1;
+        for (int c = 0; c < Nc; c++)
+            if (loose[c])
+                for (int q = F.cam_start[c]; q < F.cam_start[c + 1]; q += cs_run) { F.cs_task_cam.push_back(c); F.cs_task_q0.push_back(q); F.cs_task_q1.push_back(std::min(q + cs_run, F.cam_start[c + 1])); }
+    }
+    if (timing) std::fprintf(stderr, "[plan] signature groups: %lld of %d points in %zu tasks\n", (long long)F.gram_points, F.nP, F.gr_rec.size() / GRAM_REC);
     lap("signature groups");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     if (host_pairs) {

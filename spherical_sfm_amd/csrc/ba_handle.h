@@ -97,7 +97,8 @@ struct ssfm_ba_handle {
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
     // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
     struct { bool on = false, residual_later = false; const double *cam = nullptr, *focal = nullptr; double *cam_c = nullptr, *focal_c = nullptr, *rot_c = nullptr; } tail;
-    DevBuf<int> gr_pt0, gr_cnt, gr_K, gr_cam, gr_slot; DevBuf<unsigned char> pt_grouped;     // signature groups of k_schur_gram (ba_flatten.h)
+    bool gram_attr_set = false;
+    DevBuf<int> gr_rec; DevBuf<unsigned char> pt_grouped;     // signature groups of k_schur_gram (ba_flatten.h)
     DevBuf<int> pub_ticket;              // arrival counter of the fused hand-over in k_point_backsub (zero between launches)
     int pcg_prev_iters = 16;
     bool external_tail = false;          // the caller runs its own focal arrow / residual check after the direct solve (rotavg_solver.hip: k_rot_step, k_rot_eval)
@@ -129,7 +130,7 @@ struct ssfm_ba_handle {
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free(); subC.free(); subTc.free(); sub_flags.free(); sub_fz_lo.free(); sub_fz_hi.free(); sub_fz_wend.free(); sub_fz_merge.free(); sub_fz_await.free(); sub_fz_signal.free(); sub_fz_flags.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
-        pub_ticket.free(); gr_pt0.free(); gr_cnt.free(); gr_K.free(); gr_cam.free(); gr_slot.free(); pt_grouped.free();
+        pub_ticket.free(); gr_rec.free(); pt_grouped.free();
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
         host_pub = nullptr;

@@ -384,7 +384,7 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
             const int* __restrict__ task_q1, int ntasks, const int* __restrict__ row_ptr, const int* __restrict__ diag_slot,
             const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ PS, int loss, double la,
             double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
-            double* __restrict__ gcraw) {
+            double* __restrict__ gcraw, const unsigned char* __restrict__ pt_skip) {
     constexpr int BB = DC * DC;
     constexpr int NU = DC * (DC + 1) / 2;
     constexpr int NSM = NU + 4 * DC;           // [S_cc (upper) | Jc^T r | -W g' | focal coupling | diag U]   (<= 64 for DC <= 6)
@@ -403,6 +403,7 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
         wgt_ = (q_ < q1) ? 1.0 : 0.0;                                                                                 \
         const int qc_ = min(q_, q1 - 1);                                                                              \
         const int j_ = cam_obs[qc_], p_ = cam_obs_pt[qc_];                                                            \
+        if (pt_skip && pt_skip[p_]) wgt_ = 0.0;                 /* a point of a signature group: k_schur_gram has its sums */ \
         _Pragma("unroll") for (int k = 0; k < 3; k++) X_[k] = pts[3 * (size_t)p_ + k];                                \
         _Pragma("unroll") for (int k = 0; k < 12; k++) P_[k] = PS[12 * (size_t)p_ + k];                               \
         o_ = obs_xy[j_];                                                                                              \
@@ -569,57 +570,114 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 }
 
 // ---- Schur complement of SIGNATURE GROUPS on the matrix cores (round 3) -----------------------------------------------------------------
-// A task = up to GRAM_PTS consecutive points observed by exactly the same K <= 8 cameras (BAFlat::gr_*).  With V^-1 = L L^T per point and the half
-// products Y_k = Jc_k^T Jp_k L (DC x 3) of its K observations stacked into a (DC K) x 3 matrix per point, the off-diagonal blocks of all K (K - 1) / 2
-// camera pairs are the blocks of ONE Gram matrix  G = sum_points Y Y^T  -- every observation is linearised ONCE (the pair kernel re-linearises it
-// K - 1 times) and the products run as v_mfma_f64_16x16x4_f64 tiles.  FP64 MFMA has the VALU's flop rate on gfx950; what it buys is issue slots:
-// one instruction per 1024 multiply-adds with its operands from LDS, against ~470 VALU instructions per 64 pairs.
-// One wave per task, sub-chunks of 16 points: lane (point = lane & 15, quarter = lane >> 4) linearises observations quarter, quarter + 4 of its point
-// (camera records staged in LDS once per task) and lays Y out in LDS as sY[row = DC k + d][3 point + c] (48 columns, leading dimension 52: the
-// fragment loads below touch every bank twice, the hardware minimum for 64 x 8 bytes); then the wave runs the tiles of the lower triangle over the
-// 12 k-steps, accumulating across sub-chunks; at the end every lane adds the entries it holds of blocks (a > b) to S with the Jacobi scales of both
-// cameras (the pair kernel's convention: unscaled Jc, scales at the fold).  Diagonal blocks (a = b) are k_cam_sums2's and are skipped.
+// A task = a run of consecutive points observed by exactly the same K <= 8 cameras (BAFlat::gr_rec).  With V^-1 = L L^T per point and the half
+// products Y_k = Jc_k^T Jp_k L (DC x 3) of its K observations stacked into a (DC K) x 3 matrix per point, the blocks of all K (K - 1) / 2 camera pairs AND
+// the Schur corrections of the K diagonal blocks are the blocks of ONE Gram matrix  G = sum_points Y Y^T  -- every observation is linearised ONCE (the
+// pair kernel re-linearises it K - 1 times, k_cam_sums2 once more) and the products run as v_mfma_f64_16x16x4_f64 tiles.  FP64 MFMA has the VALU's flop
+// rate on gfx950; what it buys is issue slots: one instruction per 1024 multiply-adds with its operands from LDS, against ~470 VALU instructions per 64 pairs.
+// One wave per task, sub-chunks of 8 points: lane (point = lane & 7, k = lane >> 3) linearises observation k of its point (camera records staged in LDS
+// once per task) and lays Y out in LDS as sY[row = DC k + d][3 point + c] (24 columns, leading dimension 28: the fragment loads touch every bank twice,
+// the hardware minimum for 64 x 8 bytes); then the wave runs the tiles of the lower triangle over the 6 k-steps, accumulating across sub-chunks.
+// While the matrix pipe works the lane also keeps the camera-side sums of ITS camera in registers (what k_cam_sums2 computes from a second
+// linearisation): Jc^T Jc, Jc^T r, Jc^T Jp V^-1 g, the focal coupling -- folded over the 8 lanes of a camera once per task.
+// At the end every lane adds the entries of G it holds to S with the Jacobi scales of both cameras (unscaled Jc inside, scales at the fold): blocks
+// (a > b) to their slot, blocks (a = a) to the diagonal block of camera a.
 // Rows >= DC K of a tile hold whatever LDS holds: row i of Y only reaches row i and column i of G, and those entries are never emitted -- so nothing is
-// zeroed and the launch sizes LDS for the largest K of the problem (rows_alloc = DC Kmax rows + the camera records: 17 KB for K = 6, 9 waves per CU).
+// zeroed and the launch sizes LDS for the largest K of the problem (DC Kmax rows + GRAM_TAIL: 13.4 KB at K = 8).
 // The points' records of the NEXT sub-chunk are loaded before the tiles of the current one run (the observations of a group are consecutive, K per point:
-// no dependent index load), so the matrix pipe covers the load latency; two waves per SIMD cover each other's linearisation.
-constexpr int GRAM_LD = 52, GRAM_SUB = 16, GRAM_CAMREC = 34;
+// no dependent index load), so the matrix pipe covers the load latency; the waves of a SIMD cover each other's linearisation.
+// History (profiles/r03_notes.md): 32-point sub-chunks on half the lanes 70.7 us at config 2; 16 points on all lanes 57; + prefetch, no zeroing 39.5;
+// emission from LDS instead of per-entry global index loads 35.3; 8-point sub-chunks (12 instead of 7 waves per CU) 380 -> 355 us at the configs[4] size.
+constexpr int GRAM_CAMREC = 34, GRAM_LD = 28, GRAM_SUB = 8, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
+// transposing reduction over the 8 lanes that differ in lane bits 0..2: N values per lane in, ceil(N / 8) out; out[j] of a lane is the 8-lane sum of
+// value 8 j + 4 (lane & 1) + 2 ((lane >> 1) & 1) + ((lane >> 2) & 1)
+template <int N, int MASK>
+struct OctTR {
+    static __device__ __forceinline__ void run(double (&v)[N], double* out) {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (threadIdx.x & MASK) != 0;
+        double w[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const double lo = v[2 * j], hi = (2 * j + 1 < N) ? v[2 * j + 1] : 0.0;
+            const double mine = up ? hi : lo, send = up ? lo : hi;
+            w[j] = mine + __shfl_xor(send, MASK, 64);
+        }
+        OctTR<H, MASK / 2>::run(w, out);
+    }
+};
+template <int N>
+struct OctTR<N, 0> { static __device__ __forceinline__ void run(double (&v)[N], double* out) {
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = v[j]; } };
+// W waves per workgroup, one task and one LDS slice each; the waves never talk to each other, so the two hand-overs per sub-chunk are wave-local
+// (LDS operations of one wave complete in order; the fences keep the compiler from moving them) instead of workgroup barriers.
+__device__ __forceinline__ void wave_lds_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// entry (r, i) of the unscaled 6-dof camera block that is zero by construction: d/dt = [a 0 -a x; 0 a -a y]
+template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i) { return DC == 6 && ((r == 0 && i == 1) || (r == 1 && i == 0)); }
 template <int DC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
-             const double2* __restrict__ obs_xy, const int* __restrict__ pt_start, int ntasks, const int* __restrict__ gr_pt0, const int* __restrict__ gr_cnt,
-             const int* __restrict__ gr_K, const int* __restrict__ gr_cam, const int* __restrict__ gr_slot, const double* __restrict__ scale_cam,
-             const double* __restrict__ Vs, int loss, double la, int rows_alloc, double* __restrict__ S_val) {
+             const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
+             const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, double* __restrict__ S_val, double* __restrict__ rhs,
+             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg) {
     constexpr int BB = DC * DC, ROWS = (DC == 6) ? 48 : 32, NT = ROWS / 16, off = (DC == 6) ? 0 : 3;
+    constexpr int NU = DC * (DC + 1) / 2, NS = NU + 3 * DC, NO = (NS + 7) / 8;          // camera-side sums: [Jc^T Jc (upper) | Jc^T r | -Jc^T Jp V^-1 g | Jc^T (J_f - Jp V^-1 w_f)]
     typedef double v4d_ __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) double sY[];          // [rows_alloc][GRAM_LD] | camera records [GRAM_KMAX][GRAM_CAMREC]
-    double* sCam = sY + rows_alloc * GRAM_LD;
-    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x));
+    const long long t_0 = dbg ? wall_clock64() : 0;
+    extern __shared__ __attribute__((aligned(16))) double sY[];          // per wave: [rows_alloc][GRAM_LD] | camera records [GRAM_KMAX][GRAM_CAMREC] | scales | slots | diagonal slots
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (task >= ntasks) return;
-    const int lane = threadIdx.x;
-    const int p0 = __builtin_amdgcn_readfirstlane(gr_pt0[task]), cnt = __builtin_amdgcn_readfirstlane(gr_cnt[task]), K = __builtin_amdgcn_readfirstlane(gr_K[task]);
-    const int j00 = __builtin_amdgcn_readfirstlane(pt_start[p0]);
+    const int lane = threadIdx.x & 63;
+    double* sYw = sY + (size_t)(threadIdx.x >> 6) * (rows_alloc * GRAM_LD + GRAM_TAIL);
+    double* sCam = sYw + rows_alloc * GRAM_LD;
+    double* sScale = sCam + GRAM_KMAX * GRAM_CAMREC;                     // [DC K] Jacobi scale of Gram row DC k + d
+    int* sSlot = (int*)(sScale + 48);                                    // [GRAM_NPAIR] pair slots, then [GRAM_KMAX] diagonal blocks
+    int* sDiag = sSlot + GRAM_NPAIR;
+    const int* rec = gr_rec + (size_t)task * GRAM_REC;                   // one record per task (ba_flatten.h): wave-uniform, scalar loads
+    const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
     const double f = focal[0];
-    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = gr_cam[task * GRAM_KMAX + k]; sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
+    // the eight camera ids ride in scalar registers (one s_load with the head of the record): the loads of the camera records below depend on the record
+    // alone, not on a second round trip for an id per lane
+    int cams[GRAM_KMAX];
+#pragma unroll
+    for (int k = 0; k < GRAM_KMAX; k++) cams[k] = __builtin_amdgcn_readfirstlane(rec[4 + k]);
+    auto cam_of = [&](int k) { int c = cams[0];
+#pragma unroll
+                               for (int q = 1; q < GRAM_KMAX; q++) c = (k == q) ? cams[q] : c;
+                               return c; };
+    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = cam_of(k); sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
+    if (lane < DC * K) { const int k = lane / DC; sScale[lane] = scale_cam[6 * cam_of(k) + off + lane - DC * k]; }
+    if (lane < GRAM_NPAIR + GRAM_KMAX) sSlot[lane] = rec[12 + lane];
     v4d_ acc[NT * (NT + 1) / 2];
 #pragma unroll
     for (int t = 0; t < NT * (NT + 1) / 2; t++) acc[t] = v4d_{0.0, 0.0, 0.0, 0.0};
-    const int li = lane & 15, lk = lane >> 4;
-    const int k0 = min(lk, K - 1), k1 = min(lk + 4, K - 1);             // this lane's two observations (clamped: a lane without a second one repeats, and does not store)
-    // point record of a sub-chunk: X, the six entries of the scaled V^-1, the two observations
-    double X[3], V[6]; double2 o0, o1;
+    double sm[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) sm[i] = 0.0;
+    const int li = lane & 15, lk = lane >> 4;                          // fragment / accumulator coordinates of the tiles
+    const int lp = lane & (GRAM_SUB - 1), lq = lane >> 3;               // linearisation: point of the sub-chunk, observation (= camera of the group) of this lane
+    const int kq = min(lq, K - 1);                                      // clamped: a lane whose camera does not exist repeats the last one, stores nothing and sums nothing
+    const double sf = scale_f[0];
+    // point record of a sub-chunk: X, the scaled V^-1 (6) with V^-1 g (3) and V^-1 w_f (3), this lane's observation
+    double X[3], V[12]; double2 ob;
 #define GRAM_LOAD(s0_)                                                                                                            \
     do {                                                                                                                          \
-        const int q_ = min((s0_) + li, cnt - 1);                                                                                  \
+        const int q_ = min((s0_) + lp, cnt - 1);                                                                                  \
         _Pragma("unroll") for (int k = 0; k < 3; k++) X[k] = pts[3 * (size_t)(p0 + q_) + k];                                      \
-        _Pragma("unroll") for (int k = 0; k < 6; k++) V[k] = Vs[12 * (size_t)(p0 + q_) + k];                                      \
-        o0 = obs_xy[j00 + (size_t)q_ * K + k0]; o1 = obs_xy[j00 + (size_t)q_ * K + k1];                                           \
+        _Pragma("unroll") for (int k = 0; k < 9; k++) V[k] = PS[12 * (size_t)(p0 + q_) + k];                                      \
+        if (focal_free) { _Pragma("unroll") for (int k = 9; k < 12; k++) V[k] = PS[12 * (size_t)(p0 + q_) + k]; }                 \
+        ob = obs_xy[j00 + (size_t)q_ * K + kq];                                                                                   \
     } while (0)
     GRAM_LOAD(0);
+    long long t_1 = 0, t_2 = 0;
     for (int s0 = 0; s0 < cnt; s0 += GRAM_SUB) {
-        __syncthreads();                                                 // the tiles of the previous sub-chunk have read sY (first pass: sCam is written)
+        wave_lds_handover();                                             // the tiles of the previous sub-chunk have read sY (first pass: sCam is written)
         {
-            const bool valid = s0 + li < cnt;
+            const bool valid = s0 + lp < cnt;
             // Cholesky factor of the scaled V^-1 (all zero for a fixed point or a lane past the end of the task: its columns of Y are zero)
             double L00 = 0, L10 = 0, L20 = 0, L11 = 0, L21 = 0, L22 = 0;
             if (valid && V[0] > 0.0) {
@@ -633,37 +691,63 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
                     if (d2 > 0.0) L22 = d2 * fast_rsqrt(d2);
                 }
             }
+            const double* crec = sCam + kq * GRAM_CAMREC;
+            ObsLin Lk; lin_obs<DC == 6>(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lk);
+            double Jc[2][DC]; cam_block_raw<DC>(Lk, Jc);
+            double T[2][3];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int k = h ? k1 : k0;
-                const double2 o = h ? o1 : o0;
-                const double* rec = sCam + k * GRAM_CAMREC;
-                ObsLin Lk; lin_obs<DC == 6>(f, rec, rec + 6, X, o.x, o.y, loss, la, Lk);
-                double Jc[2][DC]; cam_block_raw<DC>(Lk, Jc);
-                double T[2][3];
+            for (int r = 0; r < 2; r++) {
+                T[r][0] = Lk.Jp[r][0] * L00 + Lk.Jp[r][1] * L10 + Lk.Jp[r][2] * L20;
+                T[r][1] = Lk.Jp[r][1] * L11 + Lk.Jp[r][2] * L21;
+                T[r][2] = Lk.Jp[r][2] * L22;
+            }
+            if (lq < K) {
+                double* dst = sYw + (size_t)(DC * kq) * GRAM_LD + 3 * lp;
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    T[r][0] = Lk.Jp[r][0] * L00 + Lk.Jp[r][1] * L10 + Lk.Jp[r][2] * L20;
-                    T[r][1] = Lk.Jp[r][1] * L11 + Lk.Jp[r][2] * L21;
-                    T[r][2] = Lk.Jp[r][2] * L22;
-                }
-                if (h == 0 ? (lk < K) : (lk + 4 < K)) {
-                    double* dst = sY + (size_t)(DC * k) * GRAM_LD + 3 * li;
+                for (int d = 0; d < DC; d++)
 #pragma unroll
-                    for (int d = 0; d < DC; d++)
+                    for (int cc = 0; cc < 3; cc++) {
+                        double y = 0.0;
+                        if (!jc_zero<DC>(0, d)) y += Jc[0][d] * T[0][cc];
+                        if (!jc_zero<DC>(1, d)) y += Jc[1][d] * T[1][cc];
+                        dst[d * GRAM_LD + cc] = y;
+                    }
+                if (valid) {                                             // camera-side sums of camera kq (k_cam_sums2's, from the same linearisation)
+                    double yv[2], zv[2];
 #pragma unroll
-                        for (int cc = 0; cc < 3; cc++) dst[d * GRAM_LD + cc] = Jc[0][d] * T[0][cc] + Jc[1][d] * T[1][cc];
+                    for (int r = 0; r < 2; r++) {
+                        yv[r] = Lk.Jp[r][0] * V[6] + Lk.Jp[r][1] * V[7] + Lk.Jp[r][2] * V[8];
+                        zv[r] = focal_free ? Lk.Jf[r] * sf - (Lk.Jp[r][0] * V[9] + Lk.Jp[r][1] * V[10] + Lk.Jp[r][2] * V[11]) : 0.0;
+                    }
+                    int u = 0;
+#pragma unroll
+                    for (int a2 = 0; a2 < DC; a2++) {
+#pragma unroll
+                        for (int b2 = a2; b2 < DC; b2++) {
+                            if (!jc_zero<DC>(0, a2) && !jc_zero<DC>(0, b2)) sm[u] += Jc[0][a2] * Jc[0][b2];
+                            if (!jc_zero<DC>(1, a2) && !jc_zero<DC>(1, b2)) sm[u] += Jc[1][a2] * Jc[1][b2];
+                            u++;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+                            if (!jc_zero<DC>(r, a2)) {
+                                sm[NU + a2] += Jc[r][a2] * Lk.r[r];
+                                sm[NU + DC + a2] -= Jc[r][a2] * yv[r];
+                                if (focal_free) sm[NU + 2 * DC + a2] += Jc[r][a2] * zv[r];
+                            }
+                    }
                 }
             }
         }
+        if (dbg && s0 == 0) t_1 = wall_clock64();                       // first sub-chunk linearised
         if (s0 + GRAM_SUB < cnt) GRAM_LOAD(s0 + GRAM_SUB);              // in flight while the tiles run
-        __syncthreads();
-        // tiles of the lower triangle: G(ti, tj) += Y(ti rows) Y(tj rows)^T over the 48 columns of this sub-chunk, 4 per instruction
-#pragma unroll 4
+        wave_lds_handover();
+        // tiles of the lower triangle: G(ti, tj) += Y(ti rows) Y(tj rows)^T over the 24 columns of this sub-chunk, 4 per instruction
+#pragma unroll
         for (int st = 0; st < 3 * GRAM_SUB / 4; st++) {
             double fr[NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) fr[t] = sY[(size_t)min(16 * t + li, rows_alloc - 1) * GRAM_LD + 4 * st + lk];
+            for (int t = 0; t < NT; t++) fr[t] = sYw[(size_t)min(16 * t + li, rows_alloc - 1) * GRAM_LD + 4 * st + lk];
             int tix = 0;
 #pragma unroll
             for (int ti = 0; ti < NT; ti++)
@@ -672,7 +756,37 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
         }
     }
 #undef GRAM_LOAD
-    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg
+    if (dbg) t_2 = wall_clock64();
+    // camera-side sums: fold over the 8 point lanes of every camera; the lane that holds value i adds it where k_cam_sums2 would -- except Jc^T Jc, which goes
+    // to LDS (sU[k][DC x DC], over sY: the tiles are done) and rides with the Gram diagonal of its camera: one atomic per entry of a diagonal block, not two
+    wave_lds_handover();
+    double* sU = sYw;
+    {
+        double out[NO];
+        OctTR<NS, 4>::run(sm, out);
+        if (lq < K) {
+            const int c = cam_of(lq);
+            const double* sc = sScale + DC * lq;
+            const int i0 = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+#pragma unroll
+            for (int j = 0; j < NO; j++) {
+                const int i = 8 * j + i0;
+                const double v = out[j];
+                if (i < NU) {
+                    int a = 0, rem = i; while (rem >= DC - a) { rem -= DC - a; a++; }
+                    const int b = a + rem;
+                    const double w = v * sc[a] * sc[b];
+                    sU[lq * BB + a * DC + b] = w;
+                    if (b != a) sU[lq * BB + b * DC + a] = w; else unsafeAtomicAdd(&Udiag[c * DC + a], w);
+                } else if (i < NU + DC) { const int a = i - NU; unsafeAtomicAdd(&rhs[c * DC + a], v * sc[a]); unsafeAtomicAdd(&gcraw[c * DC + a], v * sc[a]); }
+                else if (i < NU + 2 * DC) { const int a = i - NU - DC; unsafeAtomicAdd(&rhs[c * DC + a], v * sc[a]); }
+                else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; unsafeAtomicAdd(&Sfc[c * DC + a], v * sc[a]); }
+            }
+        }
+    }
+    wave_lds_handover();
+    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg.  Everything the emission needs sits in LDS: no load
+    // between the last tile and the atomics (the first version fetched slot, cameras and scales per entry behind divergent branches: ~30 us per task)
     int tix = 0;
 #pragma unroll
     for (int ti = 0; ti < NT; ti++)
@@ -682,17 +796,23 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
             for (int reg = 0; reg < 4; reg++) {
                 const int R = 16 * ti + lk + 4 * reg, C = 16 * tj + li;
                 const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
-                if (a < K && b < a) {
-                    const int sl = gr_slot[task * GRAM_NPAIR + a * (a - 1) / 2 + b];
-                    const int ca = gr_cam[task * GRAM_KMAX + a], cb = gr_cam[task * GRAM_KMAX + b];
-                    const double v = -acc[tix][reg] * scale_cam[6 * ca + off + da] * scale_cam[6 * cb + off + db];
-                    double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
-                    if (loss >= 0) unsafeAtomicAdd(&blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
-                    else blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)] = v;
+                if (a < K && b <= a) {
+                    const double v = -acc[tix][reg] * sScale[R] * sScale[C];
+                    if (b < a) {
+                        const int sl = sSlot[a * (a - 1) / 2 + b];
+                        double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
+                        unsafeAtomicAdd(&blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                    } else {                                            // diagonal block of camera a: a diagonal tile holds both triangles, a tile below the diagonal only (da > db)
+                        double* blk = S_val + (size_t)sDiag[a] * BB;
+                        const double w = v + sU[a * BB + da * DC + db];
+                        unsafeAtomicAdd(&blk[da * DC + db], w);
+                        if (ti != tj) unsafeAtomicAdd(&blk[db * DC + da], w);
+                    }
                 }
             }
             tix++;
         }
+    if (dbg && lane == 0) { long long* d = dbg + 4 * (size_t)task; d[0] = t_0; d[1] = t_1; d[2] = t_2; d[3] = wall_clock64(); }   // SSFM_GRAM_STAMPS (timing study)
 }
 
 // EXPERIMENT (SSFM_PAIRS_Y_PROBE=1, not part of the solve): the pair pass if every observation carried a stored half product

@@ -140,7 +140,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             const int ntasks = (int)F.cs_task_cam.size();
             LAUNCH(h, KID_CAM_SUMS, k_cam_sums2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->cam_obs.p, h->cam_obs_pt.p, h->cs_task_cam.p,
                    h->cs_task_q0.p, h->cs_task_q1.p, ntasks, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, h->S_val, h->rhs,
-                   h->Udiag, h->Sfc, h->gcraw);
+                   h->Udiag, h->Sfc, h->gcraw, (const unsigned char*)(F.gram_points > 0 ? h->pt_grouped.p : nullptr));
         }
         if (!F.chunk_cam.empty()) {
             const int ntasks = (int)F.chunk_cam.size();
@@ -152,12 +152,27 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
-        if (!F.gr_pt0.empty()) {                                   // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram)
-            const int ng = (int)F.gr_pt0.size();
-            static const bool gram_noatomic = std::getenv("SSFM_GRAM_NOATOMIC") != nullptr;      // TIMING EXPERIMENT ONLY (wrong sums): plain stores instead of atomics
+        if (!F.gr_rec.empty()) {                                   // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram)
+            const int ng = (int)(F.gr_rec.size() / GRAM_REC);
             const int rows_alloc = DC * F.gram_kmax;
-            LAUNCH(h, KID_SCHUR_GRAM, k_schur_gram<DC>, ng, 64, ((size_t)rows_alloc * GRAM_LD + GRAM_KMAX * GRAM_CAMREC) * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, h->pt_start.p, ng,
-                   h->gr_pt0.p, h->gr_cnt.p, h->gr_K.p, h->gr_cam.p, h->gr_slot.p, h->scale_cam.p, h->Vs.p, gram_noatomic ? -1 : loss, la, rows_alloc, h->S_val);
+            static bool gram_stamps_done = std::getenv("SSFM_GRAM_STAMPS") == nullptr;      // timing study: per-task phase stamps of the first launch
+            long long* gram_dbg = nullptr;
+            if (!gram_stamps_done) (void)hipMalloc((void**)&gram_dbg, (size_t)4 * ng * sizeof(long long));
+            static const int gram_waves = std::getenv("SSFM_GRAM_WAVES") ? std::min(4, std::max(1, std::atoi(std::getenv("SSFM_GRAM_WAVES")))) : 1;   // waves (tasks) per workgroup: 1 measured best (2: +14 %, 4: +13 % at the configs[4] size)
+            const size_t gram_lds = (size_t)gram_waves * ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);
+            if (gram_lds > 48 * 1024 && !h->gram_attr_set) {
+                SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); h->gram_attr_set = true;
+            }
+            LAUNCH(h, KID_SCHUR_GRAM, k_schur_gram<DC>, (ng + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, h->scale_cam.p, h->scale_f.p,
+                   h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw, gram_dbg);
+            if (gram_dbg) {                                        // print the phase times of this launch (100 MHz clock) and stop stamping
+                std::vector<long long> st((size_t)4 * ng); (void)hipStreamSynchronize(h->ctx->stream); (void)hipMemcpy(st.data(), gram_dbg, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                long long tmin = st[0], tmax = 0; double a = 0, b = 0, c = 0;
+                for (int t = 0; t < ng; t++) { tmin = std::min(tmin, st[4 * t]); tmax = std::max(tmax, st[4 * t + 3]); a += st[4 * t + 1] - st[4 * t]; b += st[4 * t + 2] - st[4 * t + 1]; c += st[4 * t + 3] - st[4 * t + 2]; }
+                std::fprintf(stderr, "[gram] %d tasks, kernel span %.1f us; mean per task: start + first linearisation %.2f us, tiles + other sub-chunks %.2f us, emission %.2f us\n", ng, (tmax - tmin) * 0.01,
+                             a / ng * 0.01, b / ng * 0.01, c / ng * 0.01);
+                (void)hipFree(gram_dbg); gram_dbg = nullptr; gram_stamps_done = true;
+            }
         }
         if (y_probe && !F.chunk_cam.empty()) {                     // experiment only (ba_kernels.h: k_pairs_y_probe)
             const int ntasks = (int)F.chunk_cam.size();
@@ -479,7 +494,7 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
         SSFM_HIP_CHECK(ctx, e1); SSFM_HIP_CHECK(ctx, e2);
     }
     UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
-    if (!F.gr_pt0.empty()) { UP(gr_pt0, F.gr_pt0); UP(gr_cnt, F.gr_cnt); UP(gr_K, F.gr_K); UP(gr_cam, F.gr_cam); UP(gr_slot, F.gr_slot); }
+    if (!F.gr_rec.empty()) UP(gr_rec, F.gr_rec);
     UP(pt_grouped, F.pt_grouped);
 #undef UP
 #define AL(buf, count) SSFM_HIP_CHECK(ctx, h->buf.alloc(count))
