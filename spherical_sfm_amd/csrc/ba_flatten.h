@@ -644,8 +644,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     lap("camera-major lists");
     // ---- signature groups for k_schur_gram (see BAFlat::gr_*): consecutive points with identical camera lists
     {
-        static const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);
-        static const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(16, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;   // points per wave task (0: by size)
+        const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);                               // read per plan: tests switch it
+        const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;           // points per wave task (0: by size)
         F.pt_grouped.resize((size_t)F.nP);
         if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
         if (gram_on && F.sym_lower) {

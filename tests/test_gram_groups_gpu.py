@@ -1,0 +1,105 @@
+"""Signature groups (k_schur_gram, ba_kernels.h): points that share their camera list take the Gram/MFMA path, the others the pair lists and
+k_cam_sums2 -- and a problem usually has both.  Mixed problems against the oracle and against the same solve with grouping switched off."""
+import dataclasses
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def mixed_problem(seed, K, spherical, focal_fixed, loose_frac=0.3, per_cam=70):
+    """Runs of ~per_cam points per camera window (grouped), of which loose_frac lose one observation (their camera list becomes their own:
+    pair lists), a few constant points inside the groups, extra constant cameras, one camera seen only by grouped points."""
+    rng = np.random.default_rng(seed)
+    Nc = max(24, int(np.ceil((K - 1) * 360.0 / 45.0)) + 2) + int(rng.integers(0, 20))
+    Np = per_cam * Nc
+    p = synth.make_circle(Nc, Np, K, spherical=spherical, focal_fixed=focal_fixed, check_in_frame=False, seed=seed, xy_range=0.25)
+    keep = np.ones(len(p.obs_cam), bool)
+    if K > 2 and loose_frac > 0:
+        # loose points come in blocks, so that whole runs survive between them (a run needs >= 32 identical neighbours)
+        blocks = rng.random(Np // 16 + 1) < loose_frac
+        loose = np.nonzero(blocks[np.arange(Np) // 16])[0]
+        drop = loose * K + rng.integers(0, K, size=len(loose))          # observation j of point q sits at q K + j (make_circle is point-major)
+        keep[drop] = False
+    pt_fixed = p.pt_fixed.copy(); pt_fixed[rng.choice(Np, size=Np // 40 + 1, replace=False)] = 1
+    rot_fixed = p.rot_fixed.copy(); rot_fixed[rng.choice(Nc, size=2, replace=False)] = 1
+    trans_fixed = p.trans_fixed.copy()
+    if not spherical:
+        trans_fixed[rng.choice(Nc, size=3, replace=False)] = 1
+    return dataclasses.replace(p, obs_xy=p.obs_xy[keep], obs_cam=p.obs_cam[keep], obs_pt=p.obs_pt[keep], pt_fixed=pt_fixed, rot_fixed=rot_fixed,
+                               trans_fixed=trans_fixed)
+
+
+CASES = [(2, True, True), (3, False, True), (4, True, False), (5, False, False), (6, True, True), (6, False, True), (7, False, False), (8, True, False), (8, False, True)]
+
+
+@pytest.mark.parametrize("K,spherical,focal_fixed", CASES)
+def test_mixed_groups_match_oracle_and_ungrouped_solve(gpu_ctx, oracle, monkeypatch, K, spherical, focal_fixed):
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = mixed_problem(500 + K, K, spherical, focal_fixed)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] and abs(s["iterations"] - os_["iterations"]) <= 1 and s["pcg_iterations_total"] == 0
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-7 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    used = np.linalg.norm(opts, axis=1) > 0
+    assert (np.linalg.norm(pts[used] - opts[used], axis=1) / np.linalg.norm(opts[used], axis=1)).max() <= 1e-4
+    monkeypatch.setenv("SSFM_GRAM", "0")
+    c0, p0, f0, s0 = ba.optimize(gpu_ctx, p)
+    assert s0["iterations"] == s["iterations"] and rel_err(cams, c0) <= 1e-7 and rel_err(pts, p0) <= 1e-7 and abs(f - f0) <= 1e-9 * f0
+    assert abs(s0["final_cost"] - s["final_cost"]) <= 1e-10 * s["final_cost"]
+
+
+@pytest.mark.parametrize("loss", [0, 1, 2])
+def test_groups_with_every_loss(gpu_ctx, oracle, monkeypatch, loss):
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = mixed_problem(77, 6, False, False)
+    kw = dict(loss_type=loss, loss_scale=2.0)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p, **kw)
+    ocams, opts, of, os_ = oracle.ba_solve(p, **kw)
+    assert abs(s["iterations"] - os_["iterations"]) <= 1 and abs(s["final_cost"] - os_["final_cost"]) <= 1e-7 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5 and abs(f - of) <= 1e-5 * of
+
+
+def test_which_kernels_run(gpu_ctx, monkeypatch):
+    """All points grouped: neither the pair kernel nor k_cam_sums2 runs; mixed: all three; grouping off or K > 8: no Gram kernel."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+
+    def kernels(p):
+        adj = ba.BundleAdjuster(gpu_ctx, p); adj.set_profiling(True); adj.run()
+        kt = adj.kernel_times(); adj.close()
+        return {n for n in kt if kt[n]["launches"] > 0}
+
+    full = synth.make_circle(60, 60 * 70, 6, spherical=False, focal_fixed=True)
+    k = kernels(full)
+    assert "k_schur_gram" in k and "k_schur_pairs2" not in k and "k_cam_sums2" not in k
+    k = kernels(mixed_problem(9, 6, False, True))
+    assert {"k_schur_gram", "k_schur_pairs2", "k_cam_sums2"} <= k
+    monkeypatch.setenv("SSFM_GRAM", "0")
+    k = kernels(full)
+    assert "k_schur_gram" not in k and {"k_schur_pairs2", "k_cam_sums2"} <= k
+    monkeypatch.delenv("SSFM_GRAM")
+    wide = synth.make_circle(120, 120 * 40, 10, spherical=True, focal_fixed=True, check_in_frame=False, xy_range=0.2)
+    k = kernels(wide)
+    assert "k_schur_gram" not in k and "k_schur_pairs2" in k
+
+
+@pytest.mark.parametrize("pts_per_task", [8, 24, 40, 200])
+def test_task_length_does_not_change_the_answer(gpu_ctx, monkeypatch, pts_per_task):
+    """Tasks that end inside a sub-chunk of 8 points, single-sub-chunk tasks, tasks longer than a run."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = mixed_problem(31, 7, False, False, per_cam=45)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    monkeypatch.setenv("SSFM_GRAM_PTS", str(pts_per_task))
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
+    assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and rel_err(pts, p1) <= 1e-8 and abs(f - f1) <= 1e-10 * f
