@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r03f_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
+PMC_PROFILE = os.path.join("profiles", "r03g_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
 
 
 def pair_kernel_flops(pairs):
@@ -48,7 +48,7 @@ PAIR_USEFUL_FLOP = 252.0       # the DCxDC block update through the 2x2 core: 12
 PAIR_RELIN_FLOP = 2 * 150.0    # what the kernel spends on top: both observations of a pair are re-linearised (each observation K - 1 times per iteration)
 
 
-def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1):
+def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1, focal_free=False):
     """Per-kernel HBM fractions of the data-parallel kernels of one LM iteration from their hipEvent durations (SURVEY 8d algorithmic bytes, split per
     pass as DESIGN.md 4 states them), and the pair kernel against the FP64 vector peak by USEFUL flops next to the modelled total."""
     per = {
@@ -57,6 +57,7 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1):
         # diagonal blocks / J_c^T r: pixels + ids per observation, X + PS per point, diagonal S blocks + rhs written
         "k_cam_sums2": 24.0 * M + 120.0 * nP + Nc * (dc * dc + dc) * 8.0,
         "k_schur_pairs2": pair_kernel_bytes(M, nP, nnzb, Nc, dc),
+        "k_schur_gram": gram_kernel_bytes(M, nP, nnzb, Nc, dc, focal_free),
         # back substitution + candidate + both costs in one sweep: pixels + ids per observation; X, PS, g_p read, candidate X written per point
         "k_point_backsub": 24.0 * M + 168.0 * nP,
     }
@@ -77,7 +78,37 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1):
             "modelled_TFLOPs": p * (PAIR_USEFUL_FLOP + PAIR_RELIN_FLOP) / (us * 1e-6) / 1e12,
             "modelled_frac": p * (PAIR_USEFUL_FLOP + PAIR_RELIN_FLOP) / (us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
             "note": "flop counts are a hand model of the kernel's arithmetic (DESIGN.md 4), not a counter; durations are measured"}
+    us = kern.get("k_schur_gram", {}).get("avg_us")
+    if us is not None and us == us:
+        ex, useful = gram_kernel_flops(M / world, nP / world, pairs / world, dc)
+        out["k_schur_gram"]["fp64"] = {
+            "executed_TFLOPs": ex / (us * 1e-6) / 1e12, "executed_frac": ex / (us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "useful_TFLOPs": useful / (us * 1e-6) / 1e12, "useful_frac": useful / (us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "note": "FP64 matrix and vector instructions share one peak on gfx950 (78.6 TFLOP/s) and, measured, one pipe; flop counts are a hand model "
+                    "(DESIGN.md 4), durations are measured.  When some points are not grouped the pair kernel runs too and these figures overcount."}
     return out
+
+
+def gram_kernel_bytes(M, nP, nnzb, Nc, dc, focal_free):
+    """k_schur_gram (the Schur assembly of points that share their camera list: off-diagonal AND diagonal blocks, right-hand side, focal border):
+    every observation's pixel pair once (16 B; no index: the observations of a group are consecutive), every point's X + record PS once
+    (24 + 72 B, + 24 with a free focal), every block of S written once, the camera-side vectors (rhs, J_c^T r, diag U, focal border)."""
+    return 16.0 * M + (96.0 + (24.0 if focal_free else 0.0)) * nP + nnzb * dc * dc * 8.0 + Nc * 4 * dc * 8.0
+
+
+GRAM_TILE_FLOP = 2 * 16 * 16 * 4                # one v_mfma_f64_16x16x4_f64
+GRAM_OBS_VALU_FLOP = 150.0 + 102.0 + 132.0      # per observation, once: linearisation, half product Y = Jc^T (Jp L) (30 + 72), camera-side sums (Jc^T Jc 84 + two Jc^T v 48)
+
+
+def gram_kernel_flops(M, nP, pairs, dc):
+    """(executed, useful) FP64 flop of one k_schur_gram launch (hand model).  Executed: NT (NT + 1) / 2 tiles x 6 k-steps per 8 points on the
+    matrix pipe (6 tiles at DC = 6) + the VALU work per observation.  Useful: the same VALU work (every observation is linearised once now) + the
+    entries of the Gram matrix the algorithm asks for: Y_a Y_b^T per (observation, observation) pair (DC x DC x 3 multiply-adds) and the upper
+    triangle of Y_a Y_a^T per observation."""
+    tiles = 6 if dc == 6 else 3
+    executed = (nP / 8.0) * tiles * 6 * GRAM_TILE_FLOP + M * GRAM_OBS_VALU_FLOP
+    useful = pairs * dc * dc * 3 * 2 + M * (dc * (dc + 1) / 2) * 3 * 2 + M * GRAM_OBS_VALU_FLOP
+    return executed, useful
 
 
 def algorithmic_bytes(M, nP, nnzb, dc, focal_free):
@@ -250,11 +281,33 @@ def main():
         nnzb = s["reduced_blocks"]
         per_iter_bytes, schur_bytes = algorithmic_bytes(M, args.points, nnzb, dc, args.focal_free)
         kern = {k: {"launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / max(1, v["launches"])} for k, v in ktimes.items()}
-        dom = "k_schur_pairs2"            # largest data-parallel kernel; k_band_chol_v2 is longer but is a sequential dependency chain
+        # largest data-parallel kernel (k_band_chol_v2 is longer but is a sequential dependency chain): the Schur assembly -- k_schur_gram when the points
+        # share camera lists (they do in this workload: every point of a camera window has the same K cameras), k_schur_pairs2 (+ k_cam_sums2) otherwise
+        gram = kern.get("k_schur_gram", {}).get("launches", 0) > 0
+        dom = "k_schur_gram" if gram else "k_schur_pairs2"
         dom_us = kern.get(dom, {}).get("avg_us", float("nan"))
-        dom_bytes = pair_kernel_bytes(M, args.points, nnzb, args.cameras, dc) / world
+        dom_bytes = (gram_kernel_bytes(M, args.points, nnzb, args.cameras, dc, args.focal_free) if gram else pair_kernel_bytes(M, args.points, nnzb, args.cameras, dc)) / world
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us == dom_us else None
-        asm_us = dom_us + kern.get("k_cam_sums2", {}).get("avg_us", float("nan"))
+        asm_us = dom_us + (kern.get("k_cam_sums2", {}).get("avg_us", 0.0) if gram else kern.get("k_cam_sums2", {}).get("avg_us", float("nan")))
+        if gram:
+            ex_flop, useful_flop = gram_kernel_flops(M / world, args.points / world, pairs / world, dc)
+            rc = {"bound": "fp64 (matrix + vector instructions, one peak and one pipe on gfx950)", "kernel": dom, "pairs_per_launch": pairs / world, "observations_per_launch": M / world,
+                  "flop_source": "modelled (hand count, DESIGN.md 4): executed = 6 tiles x 6 k-steps x 2048 flop per 8 points on the matrix pipe + 384 flop per observation on the VALU; "
+                                 "useful = the Gram entries the algorithm asks for (DC x DC x 3 multiply-adds per pair, the upper triangle per observation) + the same VALU work",
+                  "achieved": (ex_flop / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": (ex_flop / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None,
+                  "useful_achieved": (useful_flop / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
+                  "useful_frac": (useful_flop / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None}
+        else:
+            rc = {"bound": "fp64-vector", "kernel": dom, "pairs_per_launch": pairs / world, "flop_per_pair": pair_kernel_flops(1),
+                  "flop_source": "modelled (hand count of the kernel's arithmetic: 2 re-linearisations x 150 + 252 for the block update), not a counter",
+                  "achieved": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
+                  "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None,
+                  # by USEFUL work: each observation is re-linearised K - 1 times per iteration; only the 252-flop block update is work the algorithm asks for
+                  "useful_flop_per_pair": PAIR_USEFUL_FLOP,
+                  "useful_achieved": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
+                  "useful_frac": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None}
         iter_ms = 1e3 * elapsed / max(1, n_lm)          # wall time of the timed loop per LM iteration (host round trips included)
         traffic = None; valu = None
         tp = os.path.join(ROOT, PMC_PROFILE)
@@ -277,22 +330,14 @@ def main():
                          "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
                                            "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
-            # HBM is not what bounds this kernel (the working set is cache resident and the traffic is 5 % of peak): its arithmetic against the FP64 vector peak
-            "roofline_compute": {"bound": "fp64-vector", "kernel": dom, "pairs_per_launch": pairs / world, "flop_per_pair": pair_kernel_flops(1),
-                                 "flop_source": "modelled (hand count of the kernel's arithmetic: 2 re-linearisations x 150 + 252 for the block update), not a counter",
-                                 "achieved": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
-                                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": (pair_kernel_flops(pairs / world) / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None,
-                                 # by USEFUL work: each observation is re-linearised K - 1 times per iteration; only the 252-flop block update is work the algorithm asks for
-                                 "useful_flop_per_pair": PAIR_USEFUL_FLOP,
-                                 "useful_achieved": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
-                                 "useful_frac": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None},
-            "roofline_per_kernel": kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world),
+            # HBM is not what bounds this kernel (the working set is cache resident): its arithmetic against the FP64 peak
+            "roofline_compute": rc,
+            "roofline_per_kernel": kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
             # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
             "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4, "source": f"committed profile {PMC_PROFILE} (SQ_INSTS_VALU), not measured in this run",
                            "frac": (valu / (256 * dom_us * 1e-6 * 2.4e9) if valu and dom_us == dom_us else None)},
-            "roofline_schur_assembly": {"bound": "hbm", "kernels": ["k_cam_sums2", dom], "algorithmic_bytes": schur_bytes / world,
+            "roofline_schur_assembly": {"bound": "hbm", "kernels": [dom] if gram else ["k_cam_sums2", dom], "algorithmic_bytes": schur_bytes / world,
                                         "avg_us": asm_us, "achieved": (schur_bytes / world) / (asm_us * 1e-6) / 1e9 if asm_us == asm_us else None,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": (schur_bytes / world) / (asm_us * 1e-6) / 1e9 / HBM_PEAK_GBS if asm_us == asm_us else None},

@@ -12,7 +12,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for i in (1, 2, 3):
+for i in (1, 2, 3, 4):
     f = os.path.join(ROOT, "gpurun_out", f"pmc{i}_{tag}", "ba_counter_collection.csv")
     if not os.path.exists(f):
         continue
