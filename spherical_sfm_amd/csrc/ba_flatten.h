@@ -103,9 +103,9 @@ struct BAFlat {
     // k_schur_gram also produces the camera-side sums (k_cam_sums2's) of these points: the cs_task lists only cover cameras that have other points
     std::vector<int> gr_rec;
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
-    int64_t gram_points = 0; int gram_kmax = 0;
+    int64_t gram_points = 0, gram_obs = 0; int gram_kmax = 0;
 };
-constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32;
+constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 4;
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
 // once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
@@ -645,6 +645,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     // ---- signature groups for k_schur_gram (see BAFlat::gr_*): consecutive points with identical camera lists
     {
         const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);                               // read per plan: tests switch it
+        const int kmin = std::getenv("SSFM_GRAM_KMIN") ? std::max(2, std::atoi(std::getenv("SSFM_GRAM_KMIN"))) : GRAM_KMIN;
         const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;           // points per wave task (0: by size)
         F.pt_grouped.resize((size_t)F.nP);
         if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
@@ -658,7 +659,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             for (int q = 0; q < F.nP;) {
                 int e = q + 1; while (e < F.nP && same(q, e)) e++;
                 const int K = F.pt_start[q + 1] - F.pt_start[q];
-                if (e - q >= GRAM_MIN_RUN && K >= 2 && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_kmax = std::max(F.gram_kmax, K); }
+                // (K = 2, 3: the pair lists are cheaper -- 1 or 3 pairs per point against a sub-chunk's fixed cost; measured cross-over between 3 and 4, scripts/prof_gram_k.py)
+                if (e - q >= GRAM_MIN_RUN && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; F.gram_kmax = std::max(F.gram_kmax, K); }
                 q = e;
             }
             // points per wave task: a task pays ~5 us of start-up (index loads, camera records, the atomics of its blocks at the end) whatever its length, and
@@ -666,7 +668,12 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             // (measured: 100 000 points 64 -> 39.5 us, 128 -> 41, 192 -> 54; 1.5 M points 64 -> 560 us, 128 -> 453, 192 -> 434)
             int gram_pts = gram_pts_env;
             if (gram_pts <= 0) gram_pts = (int)std::min<int64_t>(192, std::max<int64_t>(64, (F.gram_points / 4608 + 15) / 16 * 16));
-            for (size_t r = 0; r < runs.size(); r += 2) {
+            // tasks sorted by K (stable: point order within a K): k_schur_gram is launched once per tile count, over a contiguous range of tasks
+            std::vector<size_t> run_order(runs.size() / 2);
+            for (size_t r = 0; r < run_order.size(); r++) run_order[r] = 2 * r;
+            auto run_K = [&](size_t r) { return F.pt_start[runs[r] + 1] - F.pt_start[runs[r]]; };
+            std::stable_sort(run_order.begin(), run_order.end(), [&](size_t a, size_t b) { return run_K(a) < run_K(b); });
+            for (size_t r : run_order) {
                 const int q = runs[r], e = runs[r + 1], K = F.pt_start[q + 1] - F.pt_start[q];
                 const int* cams = &F.obs_cam[F.pt_start[q]];
                 int slots[GRAM_NPAIR]; for (int i = 0; i < GRAM_NPAIR; i++) slots[i] = 0;

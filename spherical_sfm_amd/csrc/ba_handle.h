@@ -21,13 +21,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub"};
 
 static bool g_alloc_timing = false; static double g_alloc_s = 0.0; static int g_alloc_n = 0;   // SSFM_PLAN_TIMING: time spent in hipMalloc
 template <typename T>
@@ -97,7 +97,6 @@ struct ssfm_ba_handle {
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
     // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
     struct { bool on = false, residual_later = false; const double *cam = nullptr, *focal = nullptr; double *cam_c = nullptr, *focal_c = nullptr, *rot_c = nullptr; } tail;
-    bool gram_attr_set = false;
     DevBuf<int> gr_rec; DevBuf<unsigned char> pt_grouped;     // signature groups of k_schur_gram (ba_flatten.h)
     DevBuf<int> pub_ticket;              // arrival counter of the fused hand-over in k_point_backsub (zero between launches)
     int pcg_prev_iters = 16;

@@ -617,18 +617,18 @@ __device__ __forceinline__ void wave_lds_handover() {
 }
 // entry (r, i) of the unscaled 6-dof camera block that is zero by construction: d/dt = [a 0 -a x; 0 a -a y]
 template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i) { return DC == 6 && ((r == 0 && i == 1) || (r == 1 && i == 0)); }
-template <int DC>
+template <int DC, int NT>
 __global__ void __launch_bounds__(256)
 k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
              const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
-             const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, double* __restrict__ S_val, double* __restrict__ rhs,
+             const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int task0, double* __restrict__ S_val, double* __restrict__ rhs,
              double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg) {
-    constexpr int BB = DC * DC, ROWS = (DC == 6) ? 48 : 32, NT = ROWS / 16, off = (DC == 6) ? 0 : 3;
+    constexpr int BB = DC * DC, off = (DC == 6) ? 0 : 3;                // NT = row tiles of 16 in use: the launch covers the tasks with 16 (NT - 1) < DC K <= 16 NT
     constexpr int NU = DC * (DC + 1) / 2, NS = NU + 3 * DC, NO = (NS + 7) / 8;          // camera-side sums: [Jc^T Jc (upper) | Jc^T r | -Jc^T Jp V^-1 g | Jc^T (J_f - Jp V^-1 w_f)]
     typedef double v4d_ __attribute__((ext_vector_type(4)));
     const long long t_0 = dbg ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) double sY[];          // per wave: [rows_alloc][GRAM_LD] | camera records [GRAM_KMAX][GRAM_CAMREC] | scales | slots | diagonal slots
-    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int task = task0 + __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));   // [task0, ntasks): this launch's tile class
     if (task >= ntasks) return;
     const int lane = threadIdx.x & 63;
     double* sYw = sY + (size_t)(threadIdx.x >> 6) * (rows_alloc * GRAM_LD + GRAM_TAIL);
@@ -743,6 +743,8 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
         if (s0 + GRAM_SUB < cnt) GRAM_LOAD(s0 + GRAM_SUB);              // in flight while the tiles run
         wave_lds_handover();
         // tiles of the lower triangle: G(ti, tj) += Y(ti rows) Y(tj rows)^T over the 24 columns of this sub-chunk, 4 per instruction
+        // (only the row tiles that hold cameras: the tasks are sorted by K and every tile count has its own launch -- DC K <= 16: one product per k-step,
+        // <= 32: three, else six.  Guards in one loop cost the full case 6 %; two or three loop variants in one kernel 35-40 %: the accumulators left their AGPRs)
 #pragma unroll
         for (int st = 0; st < 3 * GRAM_SUB / 4; st++) {
             double fr[NT];
@@ -1514,6 +1516,28 @@ __device__ __forceinline__ void publish_body(const double* __restrict__ scal, co
 // ---- K3b: back-substitution + model cost change + candidate points (one lane per point) ---------------
 //   y_p = V^-1 (g_p - sum_j Jp_j^T (Jc_j y_c + Jf_j y_f)),  step = -y,  delta = scale o step
 //   model = sum_j m_j (r_j + m_j / 2),  m_j = Jc_j step_c + Jf_j step_f + Jp_j step_p
+// residual check of the reduced solve (what k_ref_residual does) by ONE workgroup: r = b - [q | S_fc.y + S_ff y_f], |r|^2 <= tol^2 |b|^2 ?  red: LDS scratch [16]
+__device__ __forceinline__ void residual_check_body(int n, const double* __restrict__ y, const double* __restrict__ res_b, const double* __restrict__ res_q,
+                                                    const double* __restrict__ res_Sfc, const double* __restrict__ res_Sff, double res_tol2,
+                                                    double* __restrict__ res_r, double* __restrict__ res_pcg, double* red) {
+    __shared__ double sqf;
+    double a0[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a0[0] += res_Sfc[i] * y[i];
+    block_sum<1>(a0, red);
+    if (threadIdx.x == 0) sqf = res_Sff[0] * y[n] + a0[0];
+    __syncthreads();
+    double a2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        const double qi = (i < n) ? res_q[i] : sqf;
+        const double ri = res_b[i] - qi; res_r[i] = ri;
+        a2[0] += ri * ri; a2[1] += res_b[i] * res_b[i];
+    }
+    block_sum<2>(a2, red);
+    if (threadIdx.x == 0) {
+        res_pcg[PCG_RR] = a2[0]; res_pcg[PCG_BN2] = a2[1]; res_pcg[PCG_ITERS] = 0.0; res_pcg[PCG_BREAKDOWN] = 0.0;
+        res_pcg[PCG_DONE] = (a2[0] <= res_tol2 * a2[1]) ? 1.0 : 0.0;
+    }
+}
 template <int DC>
 __global__ void __launch_bounds__(256)
 k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
@@ -1526,6 +1550,7 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
                 // res_r is given: the single-workgroup launch leaves the critical path of the iteration
                 const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
                 const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg,
+                const unsigned char* __restrict__ pt_skip,          // points of signature groups: k_gram_backsub has them
                 // fused hand-over (pub_host != nullptr): the workgroup that finishes LAST (a ticket) folds the scalars and publishes them, which
                 // takes the k_publish launch (4.7 us in a dependent stream) off the iteration
                 int* __restrict__ pub_ticket = nullptr, double* __restrict__ pub_host = nullptr, unsigned long long pub_seq = 0,
@@ -1533,29 +1558,12 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
     __shared__ double red[4 * 4];
     const bool residual_block = res_r && blockIdx.x == gridDim.x - 1;
     if (residual_block) {
-        __shared__ double sqf;
-        const int n = Nc * DC;
-        double a0[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += blockDim.x) a0[0] += res_Sfc[i] * y[i];
-        block_sum<1>(a0, red);
-        if (threadIdx.x == 0) sqf = res_Sff[0] * y[n] + a0[0];
-        __syncthreads();
-        double a2[2] = {0.0, 0.0};
-        for (int i = threadIdx.x; i <= n; i += blockDim.x) {
-            const double qi = (i < n) ? res_q[i] : sqf;
-            const double ri = res_b[i] - qi; res_r[i] = ri;
-            a2[0] += ri * ri; a2[1] += res_b[i] * res_b[i];
-        }
-        block_sum<2>(a2, red);
-        if (threadIdx.x == 0) {
-            res_pcg[PCG_RR] = a2[0]; res_pcg[PCG_BN2] = a2[1]; res_pcg[PCG_ITERS] = 0.0; res_pcg[PCG_BREAKDOWN] = 0.0;
-            res_pcg[PCG_DONE] = (a2[0] <= res_tol2 * a2[1]) ? 1.0 : 0.0;
-        }
+        residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red);
         if (!pub_host) return;
     }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
-    if (!residual_block && p < nP) {
+    if (!residual_block && p < nP && !(pt_skip && pt_skip[p])) {
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC];
@@ -1637,6 +1645,123 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             publish_body(scal, res_pcg, pub_host, pub_seq, pub_gate, pub_spec, folded);
         }
     }
+}
+
+// ---- back substitution + candidate + both costs for the points of SIGNATURE GROUPS (round 3) -------------------------------------------------
+// What k_point_backsub does with a lane per point and one dependent camera-table gather per observation, in k_schur_gram's layout: wave task = a run of
+// points with the same K <= 8 cameras, sub-chunks of 8 points, lane = (point, observation).  The K camera records (current and candidate) and the cameras'
+// steps sit in LDS, every lane linearises ONE observation, the per-point sums (|a|^2, a.r, B^T B, B^T a: 11 doubles) are folded over the 8 observation
+// lanes of the point with three xor-shuffles, every lane of the point then knows the point's step and evaluates ITS observation at the candidate.
+// No dependent index load anywhere (the observations of a group are consecutive, K per point); the next sub-chunk's records are in flight during the arithmetic.
+constexpr int GBS_CAMC = 12, GBS_TAIL = GRAM_KMAX * (GRAM_CAMREC + GBS_CAMC + 6), GBS_WAVES = 4;
+template <int DC>
+__global__ void __launch_bounds__(256)
+k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+               const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam,
+               const double* __restrict__ scale_pt, const double* __restrict__ scale_f, const double* __restrict__ PS, const double* __restrict__ gp,
+               const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
+               const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
+               // residual check of the reduced solve by one extra workgroup behind the task workgroups when res_r is given (as in k_point_backsub)
+               const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
+               const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg) {
+    constexpr int off = (DC == 6) ? 0 : 3;
+    extern __shared__ __attribute__((aligned(16))) double sB[];          // per wave: camera records [K][34] | candidate [t | R] [K][12] | scaled camera steps [K][6]
+    if (res_r && blockIdx.x == gridDim.x - 1) { __shared__ double red[4 * 4]; residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red); return; }
+    const int nwg = res_r ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (one WORKGROUP per task with its four waves taking the sub-chunks in turn -- four times the waves -- was slower: 25.9 -> 33.4 us at config 2, 277 -> 353 us
+    // at the configs[4] size)
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, nwg) * (blockDim.x >> 6) + wave);
+    if (task >= ntasks) return;
+    double* sCam = sB + (size_t)wave * GBS_TAIL;
+    double* sCamC = sCam + GRAM_KMAX * GRAM_CAMREC;
+    double* sStep = sCamC + GRAM_KMAX * GBS_CAMC;
+    const int* rec = gr_rec + (size_t)task * GRAM_REC;
+    const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
+    int cams[GRAM_KMAX];
+#pragma unroll
+    for (int k = 0; k < GRAM_KMAX; k++) cams[k] = __builtin_amdgcn_readfirstlane(rec[4 + k]);
+    auto cam_of = [&](int k) { int c = cams[0];
+#pragma unroll
+                               for (int q = 1; q < GRAM_KMAX; q++) c = (k == q) ? cams[q] : c;
+                               return c; };
+    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = cam_of(k); sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
+    for (int e = lane; e < K * GBS_CAMC; e += 64) { const int k = e / GBS_CAMC, i = e - GBS_CAMC * k, c = cam_of(k); sCamC[e] = (i < 3) ? cam_c[6 * c + i] : rot_c[27 * c + i - 3]; }
+    if (lane < DC * K) { const int k = lane / DC, a = lane - DC * k, c = cam_of(k); sStep[6 * k + a] = scale_cam[6 * c + off + a] * y[c * DC + a]; }
+    const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC], fcand = focal_c[0];
+    const int lp = lane & (GRAM_SUB - 1), lq = lane >> 3;
+    const int kq = min(lq, K - 1);
+    double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
+    double X[3], sp[3], g3[3], Vi[6]; double2 ob;
+#define GBS_LOAD(s0_)                                                                                                             \
+    do {                                                                                                                          \
+        const size_t p_ = (size_t)(p0 + min((s0_) + lp, cnt - 1));                                                                \
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { X[k] = pts[3 * p_ + k]; sp[k] = scale_pt[3 * p_ + k]; g3[k] = gp[3 * p_ + k]; } \
+        _Pragma("unroll") for (int k = 0; k < 6; k++) Vi[k] = PS[12 * p_ + k];                                                     \
+        ob = obs_xy[j00 + (size_t)min((s0_) + lp, cnt - 1) * K + kq];                                                             \
+    } while (0)
+    constexpr int s_step = GRAM_SUB;
+    GBS_LOAD(0);
+    wave_lds_handover();
+    for (int s0 = 0; s0 < cnt; s0 += s_step) {
+        const bool valid = s0 + lp < cnt, act = valid && lq < K;
+        const double Xn[3] = {X[0], X[1], X[2]}, spn[3] = {sp[0], sp[1], sp[2]}, gn[3] = {g3[0], g3[1], g3[2]}, Vn[6] = {Vi[0], Vi[1], Vi[2], Vi[3], Vi[4], Vi[5]};
+        const double2 on = ob;
+        const size_t pn = (size_t)(p0 + min(s0 + lp, cnt - 1));
+        if (s0 + s_step < cnt) GBS_LOAD(s0 + s_step);
+        // this observation: a = camera / focal part of J s, B = Jp diag(s_p).  With M = a + B z (z = the point's step) the model cost change is
+        // -sum M.(r - M/2): only B^T a has to be known per POINT before z is (three values folded over the 8 observation lanes); M itself is per lane
+        double m0 = 0.0, m1 = 0.0, r0 = 0.0, r1 = 0.0, B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, Ba[3] = {0, 0, 0};
+        if (act) {
+            const double* crec = sCam + kq * GRAM_CAMREC;
+            ObsLin L; lin_obs<DC == 6>(f, crec, crec + 6, Xn, on.x, on.y, loss, la, L);
+            double Jc[2][DC]; cam_block_raw<DC>(L, Jc);
+            m0 = L.Jf[0] * sf * yf; m1 = L.Jf[1] * sf * yf; r0 = L.r[0]; r1 = L.r[1];
+#pragma unroll
+            for (int a = 0; a < DC; a++) {
+                const double ya = sStep[6 * kq + a];
+                if (!jc_zero<DC>(0, a)) m0 += Jc[0][a] * ya;
+                if (!jc_zero<DC>(1, a)) m1 += Jc[1][a] * ya;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { B0[k] = L.Jp[0][k] * spn[k]; B1[k] = L.Jp[1][k] * spn[k]; Ba[k] = B0[k] * m0 + B1[k] * m1; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { double v = Ba[i]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); Ba[i] = v; }
+        const double b[3] = {gn[0] - Ba[0], gn[1] - Ba[1], gn[2] - Ba[2]};
+        double yp[3] = {0.0, 0.0, 0.0};
+        if (spn[0] > 0.0) {
+            const double is[3] = {fast_rcp(spn[0]), fast_rcp(spn[1]), fast_rcp(spn[2])};
+            const double bs[3] = {b[0] * is[0], b[1] * is[1], b[2] * is[2]};
+            yp[0] = (Vn[0] * bs[0] + Vn[1] * bs[1] + Vn[2] * bs[2]) * is[0];
+            yp[1] = (Vn[1] * bs[0] + Vn[3] * bs[1] + Vn[4] * bs[2]) * is[1];
+            yp[2] = (Vn[2] * bs[0] + Vn[4] * bs[1] + Vn[5] * bs[2]) * is[2];
+        }
+        double Xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) Xc[k] = Xn[k] - yp[k] * spn[k];
+        if (act) {
+            const double M0 = m0 + B0[0] * yp[0] + B0[1] * yp[1] + B0[2] * yp[2], M1 = m1 + B1[0] * yp[0] + B1[1] * yp[1] + B1[2] * yp[2];
+            acc[0] += -(M0 * r0 + M1 * r1) + 0.5 * (M0 * M0 + M1 * M1);
+            const double* cc = sCamC + kq * GBS_CAMC;
+            acc[3] += obs_cost(fcand, cc, cc + 3, Xc, on.x, on.y, loss, la);
+        }
+        if (valid && lq == 0) {                                          // the point's candidate and step norms, once per point
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double d = -yp[k] * spn[k];
+                pts_c[3 * pn + k] = Xc[k];
+                if (spn[k] > 0.0) { acc[1] += d * d; acc[2] += Xc[k] * Xc[k]; }
+            }
+        }
+    }
+#undef GBS_LOAD
+    static_assert(SC_STEP2_PT == SC_MODEL + 1 && SC_XN2_PT == SC_MODEL + 2 && SC_CAND_COST == SC_MODEL + 3, "the four sums are consecutive scalars");
+    const double t = wave_transpose_sum(acc);
+    const int slot = wave_tr_index();
+    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + wave) & (SC_NSLOT - 1)) * SC_TOTAL;
+    if (slot < 4) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------

@@ -154,17 +154,28 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         }
         if (!F.gr_rec.empty()) {                                   // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram)
             const int ng = (int)(F.gr_rec.size() / GRAM_REC);
-            const int rows_alloc = DC * F.gram_kmax;
             static bool gram_stamps_done = std::getenv("SSFM_GRAM_STAMPS") == nullptr;      // timing study: per-task phase stamps of the first launch
             long long* gram_dbg = nullptr;
             if (!gram_stamps_done) (void)hipMalloc((void**)&gram_dbg, (size_t)4 * ng * sizeof(long long));
             static const int gram_waves = std::getenv("SSFM_GRAM_WAVES") ? std::min(4, std::max(1, std::atoi(std::getenv("SSFM_GRAM_WAVES")))) : 1;   // waves (tasks) per workgroup: 1 measured best (2: +14 %, 4: +13 % at the configs[4] size)
-            const size_t gram_lds = (size_t)gram_waves * ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);
-            if (gram_lds > 48 * 1024 && !h->gram_attr_set) {
-                SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); h->gram_attr_set = true;
-            }
-            LAUNCH(h, KID_SCHUR_GRAM, k_schur_gram<DC>, (ng + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, h->scale_cam.p, h->scale_f.p,
-                   h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw, gram_dbg);
+            // one launch per tile count (the tasks are sorted by K): DC K <= 16 -> 1 row tile, <= 32 -> 2, else 3
+            int cls_end[3] = {0, 0, 0};
+            for (int t = 0; t < ng; t++) { const int K = F.gr_rec[(size_t)t * GRAM_REC + 2]; const int nt = (DC * K + 15) / 16; for (int c = nt - 1; c < 3; c++) cls_end[c] = t + 1; }
+#define SSFM_GRAM_LAUNCH(NT_)                                                                                                                          \
+            do {                                                                                                                                       \
+                const int t0 = (NT_ == 1) ? 0 : cls_end[(NT_ >= 2) ? NT_ - 2 : 0], t1 = cls_end[NT_ - 1];                                             \
+                if (t1 > t0) {                                                                                                                         \
+                    const int rows_alloc = DC * F.gr_rec[(size_t)(t1 - 1) * GRAM_REC + 2];              /* the largest K of the class: its last task */ \
+                    const size_t gram_lds = (size_t)gram_waves * ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);                          \
+                    if (gram_lds > 48 * 1024)                                                                                                          \
+                        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
+                    LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, t1, h->gr_rec.p,  \
+                           h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw, gram_dbg);  \
+                }                                                                                                                                      \
+            } while (0)
+            SSFM_GRAM_LAUNCH(1); SSFM_GRAM_LAUNCH(2);
+            if (DC == 6) SSFM_GRAM_LAUNCH(3);
+#undef SSFM_GRAM_LAUNCH
             if (gram_dbg) {                                        // print the phase times of this launch (100 MHz clock) and stop stamping
                 std::vector<long long> st((size_t)4 * ng); (void)hipStreamSynchronize(h->ctx->stream); (void)hipMemcpy(st.data(), gram_dbg, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 long long tmin = st[0], tmax = 0; double a = 0, b = 0, c = 0;
@@ -236,13 +247,32 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     }
                     LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + 1, PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                            h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
-                           h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, h->pr.p, h->pcg.p,
+                           h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, h->pr.p, h->pcg.p, (const unsigned char*)nullptr,
                            h->pub_ticket.p, h->host_pub, ++ctx->pub_seq, g, specp);
                     published = true;
-                } else
-                LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
-                       h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
-                       h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p);
+                } else {
+                    // the points of signature groups take k_gram_backsub (lane = observation, camera records in LDS); k_point_backsub keeps the others and
+                    // the residual check's extra workgroup
+                    // Its time follows the POINTS (8 lanes per point whatever K), k_point_backsub's the observations: measured (scripts/prof_gram_backsub.py) 27.3 / 28.1 us
+                    // at K = 6 / 8 against 23.4 / 31.7 (100k points) and 271 / 278 against 284 / 379 (1.5 M points): on from 7 observations per point on average.
+                    // SSFM_GRAM_BACKSUB=0 / 1 forces it off / on.
+                    const char* e_gbs = std::getenv("SSFM_GRAM_BACKSUB");                        // read per launch: tests switch it
+                    const int gram_bs = e_gbs ? std::atoi(e_gbs) : -1;
+                    const bool grouped = !fused_publish && !F.gr_rec.empty() && (gram_bs < 0 ? F.gram_obs >= 7 * F.gram_points : gram_bs != 0);
+                    const bool all_grouped = grouped && F.gram_points == F.nP;               // then the residual check's workgroup rides with k_gram_backsub
+                    if (grouped) {
+                        const int ng = (int)(F.gr_rec.size() / GRAM_REC);
+                        const bool res_here = res && all_grouped;
+                        LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub<DC>, (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
+                               h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p);
+                    }
+                    if (!all_grouped)
+                        LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                               h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
+                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr));
+                }
             }
             if (published) return SSFM_OK;
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);

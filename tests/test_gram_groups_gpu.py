@@ -43,6 +43,8 @@ CASES = [(2, True, True), (3, False, True), (4, True, False), (5, False, False),
 def test_mixed_groups_match_oracle_and_ungrouped_solve(gpu_ctx, oracle, monkeypatch, K, spherical, focal_fixed):
     from spherical_sfm_amd import ba
     monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "2")                          # by default runs of 2 or 3 cameras stay with the pair lists (cheaper there)
+    monkeypatch.setenv("SSFM_GRAM_BACKSUB", "1" if K % 2 == 0 else "0")  # default: k_gram_backsub from 7 observations per point on average
     p = mixed_problem(500 + K, K, spherical, focal_fixed)
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
     ocams, opts, of, os_ = oracle.ba_solve(p)
@@ -82,8 +84,16 @@ def test_which_kernels_run(gpu_ctx, monkeypatch):
     full = synth.make_circle(60, 60 * 70, 6, spherical=False, focal_fixed=True)
     k = kernels(full)
     assert "k_schur_gram" in k and "k_schur_pairs2" not in k and "k_cam_sums2" not in k
+    assert "k_point_backsub" in k and "k_gram_backsub" not in k          # 6 observations per point: the lane-per-point back substitution
+    full8 = synth.make_circle(80, 80 * 70, 8, spherical=False, focal_fixed=True, check_in_frame=False, xy_range=0.25)
+    k = kernels(full8)
+    assert "k_gram_backsub" in k and "k_point_backsub" not in k          # 8 per point, every point grouped: the residual check rides with k_gram_backsub
+    k = kernels(mixed_problem(9, 8, False, True))
+    assert {"k_schur_gram", "k_schur_pairs2", "k_cam_sums2", "k_gram_backsub", "k_point_backsub"} <= k
     k = kernels(mixed_problem(9, 6, False, True))
     assert {"k_schur_gram", "k_schur_pairs2", "k_cam_sums2"} <= k
+    k = kernels(synth.make_circle(60, 60 * 70, 3, spherical=False, focal_fixed=True))
+    assert "k_schur_gram" not in k                                       # 3 cameras per point: the pair lists are cheaper
     monkeypatch.setenv("SSFM_GRAM", "0")
     k = kernels(full)
     assert "k_schur_gram" not in k and {"k_schur_pairs2", "k_cam_sums2"} <= k
@@ -99,6 +109,7 @@ def test_task_length_does_not_change_the_answer(gpu_ctx, monkeypatch, pts_per_ta
     from spherical_sfm_amd import ba
     monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
     p = mixed_problem(31, 7, False, False, per_cam=45)
+    monkeypatch.setenv("SSFM_GRAM_BACKSUB", "1")
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
     monkeypatch.setenv("SSFM_GRAM_PTS", str(pts_per_task))
     c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
