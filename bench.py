@@ -60,6 +60,8 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1, focal_free
         "k_schur_gram": gram_kernel_bytes(M, nP, nnzb, Nc, dc, focal_free),
         # back substitution + candidate + both costs in one sweep: pixels + ids per observation; X, PS, g_p read, candidate X written per point
         "k_point_backsub": 24.0 * M + 168.0 * nP,
+        # the same pass for grouped points (lane = observation): pixels only (the observations of a group are consecutive, no ids); X, scales, g_p, V^-1 read, candidate X written
+        "k_gram_backsub": 16.0 * M + 144.0 * nP,
     }
     out = {}
     for k, b in per.items():
