@@ -114,3 +114,45 @@ def test_task_length_does_not_change_the_answer(gpu_ctx, monkeypatch, pts_per_ta
     monkeypatch.setenv("SSFM_GRAM_PTS", str(pts_per_task))
     c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
     assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and rel_err(pts, p1) <= 1e-8 and abs(f - f1) <= 1e-10 * f
+
+
+def multi_k_problem(seed, spherical, focal_fixed, block=48):
+    """An 8-observation circle whose points keep only their first k cameras, k drawn per block of `block` consecutive points from 3..8: runs of every length class
+    (one, two and three 16-row tiles) in ONE problem, plus blocks shorter than a run (16 points: pair lists)."""
+    rng = np.random.default_rng(seed)
+    Nc = 60 + int(rng.integers(0, 30))
+    Np = 60 * Nc
+    p = synth.make_circle(Nc, Np, 8, spherical=spherical, focal_fixed=focal_fixed, check_in_frame=False, seed=seed, xy_range=0.25)
+    nb = Np // block + 1
+    kb = rng.integers(3, 9, size=nb)
+    short = rng.random(nb) < 0.15                                      # some blocks change k every 16 points: no run of 32
+    k_pt = kb[np.arange(Np) // block]
+    fine = rng.integers(3, 9, size=Np // 16 + 1)[np.arange(Np) // 16]
+    k_pt = np.where(short[np.arange(Np) // block], fine, k_pt)
+    j = np.arange(len(p.obs_cam)) % 8                                  # make_circle is point-major with 8 observations per point
+    keep = j < k_pt[p.obs_pt]
+    pt_fixed = p.pt_fixed.copy(); pt_fixed[rng.choice(Np, size=Np // 60, replace=False)] = 1
+    return dataclasses.replace(p, obs_xy=p.obs_xy[keep], obs_cam=p.obs_cam[keep], obs_pt=p.obs_pt[keep], pt_fixed=pt_fixed)
+
+
+@pytest.mark.parametrize("seed,spherical,focal_fixed,backsub", [(1, False, True, "1"), (2, True, False, "1"), (3, False, False, "0"), (4, True, True, "1"), (5, False, True, None)])
+def test_runs_of_every_tile_class_in_one_problem(gpu_ctx, oracle, monkeypatch, seed, spherical, focal_fixed, backsub):
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "3")
+    if backsub is not None:
+        monkeypatch.setenv("SSFM_GRAM_BACKSUB", backsub)
+    p = multi_k_problem(seed, spherical, focal_fixed)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] and abs(s["iterations"] - os_["iterations"]) <= 1 and s["pcg_iterations_total"] == 0
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-7 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    monkeypatch.setenv("SSFM_GRAM", "0")
+    c0, p0, f0, s0 = ba.optimize(gpu_ctx, p)
+    assert s0["iterations"] == s["iterations"] and rel_err(cams, c0) <= 1e-7 and rel_err(pts, p0) <= 1e-7 and abs(f - f0) <= 1e-9 * f0
+    monkeypatch.delenv("SSFM_GRAM")
+    # the launches really covered several tile classes
+    adj = ba.BundleAdjuster(gpu_ctx, p); adj.set_profiling(True); st = adj.run(); kt = adj.kernel_times(); adj.close()
+    assert kt["k_schur_gram"]["launches"] >= 2 * st["num_linearizations"]
+    assert kt["k_schur_pairs2"]["launches"] > 0
