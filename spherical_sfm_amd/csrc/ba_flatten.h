@@ -103,7 +103,7 @@ struct BAFlat {
     // k_schur_gram also produces the camera-side sums (k_cam_sums2's) of these points: the cs_task lists only cover cameras that have other points
     std::vector<int> gr_rec;
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
-    int64_t gram_points = 0, gram_obs = 0; int gram_kmax = 0;
+    int64_t gram_points = 0, gram_obs = 0;
 };
 constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 4;
 
@@ -660,7 +660,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 int e = q + 1; while (e < F.nP && same(q, e)) e++;
                 const int K = F.pt_start[q + 1] - F.pt_start[q];
                 // (K = 2, 3: the pair lists are cheaper -- 1 or 3 pairs per point against a sub-chunk's fixed cost; measured cross-over between 3 and 4, scripts/prof_gram_k.py)
-                if (e - q >= GRAM_MIN_RUN && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; F.gram_kmax = std::max(F.gram_kmax, K); }
+                if (e - q >= GRAM_MIN_RUN && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
                 q = e;
             }
             // points per wave task: a task pays ~5 us of start-up (index loads, camera records, the atomics of its blocks at the end) whatever its length, and

@@ -1655,7 +1655,7 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
 // No dependent index load anywhere (the observations of a group are consecutive, K per point); the next sub-chunk's records are in flight during the arithmetic.
 constexpr int GBS_CAMC = 12, GBS_TAIL = GRAM_KMAX * (GRAM_CAMREC + GBS_CAMC + 6), GBS_WAVES = 4;
 template <int DC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs + 64 B of scratch: 277 -> 254 us at the configs[4] size; 4 waves (128) spill: 532
 k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
                const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam,
                const double* __restrict__ scale_pt, const double* __restrict__ scale_f, const double* __restrict__ PS, const double* __restrict__ gp,
