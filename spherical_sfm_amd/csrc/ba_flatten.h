@@ -94,9 +94,10 @@ struct BAFlat {
     int64_t pair_batches = 0;           // 64-entry batches of the pair lists (the lists themselves may live on the device only)
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
-    // Signature groups (round 3, k_schur_gram): runs of >= GRAM_MIN_RUN consecutive points observed by exactly the same K <= GRAM_KMAX cameras.  Their
-    // off-diagonal Schur blocks are formed as ONE Gram product per 64 points on the matrix cores, each observation linearised once, instead of lane-per-pair
-    // from the pair lists (which then skip these points: pt_grouped).  One record of GRAM_REC ints per task:
+    // Signature groups (round 3, k_schur_gram / k_gram_backsub): runs of >= GRAM_MIN_RUN consecutive points observed by exactly the same K cameras,
+    // GRAM_KMIN <= K <= GRAM_KMAX.  Their Schur blocks (off-diagonal and diagonal) and camera-side sums are formed as ONE Gram product per wave task on the
+    // matrix cores, each observation linearised once, instead of lane-per-pair from the pair lists and k_cam_sums2 (which then skip these points: pt_grouped).
+    // Tasks are sorted by K (k_schur_gram is launched once per number of 16-row tiles in use).  One record of GRAM_REC ints per task:
     //   [0] first point  [1] points (<= the task length chosen below)  [2] K  [3] first observation (the K of every point follow each other)
     //   [4..11] the cameras, ascending  [12..39] slot[a (a - 1) / 2 + b] (a > b) = block index of (camera a, camera b) in S, bit 30 set when
     //   the stored block is (b, a), i.e. the transpose  [40..47] the diagonal block of every camera
@@ -642,7 +643,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         }
     }
     lap("camera-major lists");
-    // ---- signature groups for k_schur_gram (see BAFlat::gr_*): consecutive points with identical camera lists
+    // ---- signature groups for k_schur_gram / k_gram_backsub (see BAFlat::gr_rec): runs of consecutive points with identical camera lists
     {
         const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);                               // read per plan: tests switch it
         const int kmin = std::getenv("SSFM_GRAM_KMIN") ? std::max(2, std::atoi(std::getenv("SSFM_GRAM_KMIN"))) : GRAM_KMIN;

@@ -583,11 +583,13 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 // At the end every lane adds the entries of G it holds to S with the Jacobi scales of both cameras (unscaled Jc inside, scales at the fold): blocks
 // (a > b) to their slot, blocks (a = a) to the diagonal block of camera a.
 // Rows >= DC K of a tile hold whatever LDS holds: row i of Y only reaches row i and column i of G, and those entries are never emitted -- so nothing is
-// zeroed and the launch sizes LDS for the largest K of the problem (DC Kmax rows + GRAM_TAIL: 13.4 KB at K = 8).
+// zeroed and a launch sizes LDS for the largest K of its task range (DC Kmax rows + GRAM_TAIL: 13.4 KB at K = 8).  NT = 16-row tiles in use: the tasks
+// are sorted by K and every tile count has its own launch over a contiguous task range (DC K <= 16: one product per k-step, <= 32: three, else six).
 // The points' records of the NEXT sub-chunk are loaded before the tiles of the current one run (the observations of a group are consecutive, K per point:
 // no dependent index load), so the matrix pipe covers the load latency; the waves of a SIMD cover each other's linearisation.
 // History (profiles/r03_notes.md): 32-point sub-chunks on half the lanes 70.7 us at config 2; 16 points on all lanes 57; + prefetch, no zeroing 39.5;
-// emission from LDS instead of per-entry global index loads 35.3; 8-point sub-chunks (12 instead of 7 waves per CU) 380 -> 355 us at the configs[4] size.
+// emission from LDS instead of per-entry global index loads 35.3; 8-point sub-chunks (12 instead of 7 waves per CU) 380 -> 355 us at the configs[4] size;
+// with the camera-side sums (k_cam_sums2 no longer runs for these cameras) 48.7 us / 400 us against 39.5 + 20.5 / 931 + 414 for the pair path.
 constexpr int GRAM_CAMREC = 34, GRAM_LD = 28, GRAM_SUB = 8, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
 // transposing reduction over the 8 lanes that differ in lane bits 0..2: N values per lane in, ceil(N / 8) out; out[j] of a lane is the 8-lane sum of
 // value 8 j + 4 (lane & 1) + 2 ((lane >> 1) & 1) + ((lane >> 2) & 1)
