@@ -327,12 +327,23 @@ def main():
                        "reduced_solver": "exact block-banded Cholesky in Cuthill-McKee order (direct, like the reference's SPARSE_SCHUR); the PCG of the metric's name is a "
                                          f"refinement that did not run: {s.get('pcg_iterations_total', 0)} sweeps in the last step",
                        "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}", "comm": ("none" if world == 1 else ("host-staged gloo (test configuration)" if host_comm else "rccl"))},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
-                                           "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
-            # HBM is not what bounds this kernel (the working set is cache resident): its arithmetic against the FP64 peak
+            # The dominant kernel against the roof that bounds it.  k_schur_gram is a matrix-core kernel: ALGORITHMIC flop per launch (what the Schur assembly asks for
+            # whatever the implementation: per observation one linearisation 150 + the half product 102 + the camera-side sums 132 + the upper triangle of its
+            # diagonal Gram block 126; per observation pair the DC x DC x 3 multiply-adds of its off-diagonal block 216 -- DESIGN.md 4) / measured launch duration,
+            # against the dense FP64 MFMA peak (which on gfx950 is also the FP64 vector peak, and one pipe).  The pair kernel (ungrouped problems) stays on the HBM line.
+            "roofline": ({"bound": "mfma", "kernel": dom, "achieved": rc["useful_achieved"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rc["useful_frac"],
+                          "traffic": traffic, "dtype_peak": "FP64 dense MFMA 78.6 TFLOP/s = the FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz; a v_mfma_f64_16x16x4 issues every 64 cycles: measured, profiles/r03_notes.md)", "algorithmic_flop_per_launch": useful_flop,
+                          "executed_flop_per_launch": ex_flop, "executed_frac": rc["frac"], "avg_launch_us": dom_us,
+                          "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
+                                            "gfx950 x2 FETCH_SIZE correction applied; HBM bytes per launch) -- NOT measured in this run"} if gram else
+                         {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                          "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
+                                            "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
+                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us}),
+            # the same kernel on the HBM line (SURVEY 8d's figure of merit): algorithmic bytes per launch / duration
+            "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                             "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
             "roofline_compute": rc,
             "roofline_per_kernel": kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
