@@ -311,11 +311,11 @@ def main():
                   "useful_achieved": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
                   "useful_frac": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None}
         iter_ms = 1e3 * elapsed / max(1, n_lm)          # wall time of the timed loop per LM iteration (host round trips included)
-        traffic = None; valu = None
+        traffic = None; valu = None; mops = None
         tp = os.path.join(ROOT, PMC_PROFILE)
         if os.path.exists(tp):
             try:
-                pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom)
+                pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom); mops = pm.get("_mfma_mops_f64", {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -334,6 +334,8 @@ def main():
             "roofline": ({"bound": "mfma", "kernel": dom, "achieved": rc["useful_achieved"], "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rc["useful_frac"],
                           "traffic": traffic, "dtype_peak": "FP64 dense MFMA 78.6 TFLOP/s = the FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz; a v_mfma_f64_16x16x4 issues every 64 cycles: measured, profiles/r03_notes.md)", "algorithmic_flop_per_launch": useful_flop,
                           "executed_flop_per_launch": ex_flop, "executed_frac": rc["frac"], "avg_launch_us": dom_us,
+                          # cross-check of the model's matrix-pipe part against a counter: SQ_INSTS_VALU_MFMA_MOPS_F64 (512 flop per MOP) of the committed PMC profile
+                          "executed_mfma_flop_model": (args.points / world / 8.0) * (6 if dc == 6 else 3) * 6 * GRAM_TILE_FLOP, "executed_mfma_flop_pmc": (mops * 512.0) if mops else None,
                           "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
                                             "gfx950 x2 FETCH_SIZE correction applied; HBM bytes per launch) -- NOT measured in this run"} if gram else
                          {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
