@@ -494,13 +494,11 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&g)[16]) {
     const int lane = threadIdx.x & 63;
     bool ok = true;
-    double rs[16];                                           // 1 / L[c][c] = rsqrt(d_c): the substitution below divides by the diagonal with it (round 3: no second reciprocal per row)
 #pragma unroll
     for (int c = 0; c < 16; c++) {
         double d = lane_bcast(row[c], c);
         if (!(d > 0.0)) { ok = false; d = 1.0; }
-        rs[c] = fast_rsqrt(d);
-        const double l = row[c] * rs[c];                     // L[r][c] on lane r (meaningful for r >= c); replaces row[c]
+        const double l = row[c] * fast_rsqrt(d);             // L[r][c] on lane r (meaningful for r >= c); replaces row[c]
         row[c] = l;
 #pragma unroll
         for (int c2 = c + 1; c2 < 16; c2++) row[c2] -= l * lane_bcast(l, c2);
@@ -510,7 +508,7 @@ __device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&
         double acc = (lane == r) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < r; k++) acc -= lane_bcast(row[k], r) * g[k];
-        g[r] = acc * rs[r];
+        g[r] = acc * fast_rcp(lane_bcast(row[r], r));
     }
     return ok;
 }
