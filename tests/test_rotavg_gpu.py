@@ -114,7 +114,9 @@ def test_large_graphs_are_deterministic_and_match_the_oracle_iteration_count(gpu
             assert s["iterations"] == so["iterations"] and s["termination"] == so["termination"]
             # 50 iterations (the cap) on a ring of thousands of nodes end far from convergence, and the path there amplifies rounding: the oracle and
             # the device -- like any two summation orders -- part by ~1e-4 in the cost after the same 50 iterations and 33-35 accepted steps
-            assert abs(cost - co) <= 1e-3 * co and np.median(rot_angle(R, Ro)) <= 2e-2 and s["num_successful_steps"] == so["num_successful_steps"]
+            # (a rounding-level change anywhere in the solver moves one accept / reject decision along such a path: measured when the 16x16 diagonal routine divided
+            # by rsqrt(d) instead of 1 / (d rsqrt(d)) -- hence a band of two accepted steps, not equality)
+            assert abs(cost - co) <= 1e-3 * co and np.median(rot_angle(R, Ro)) <= 2e-2 and abs(s["num_successful_steps"] - so["num_successful_steps"]) <= 2
         else:
             assert np.array_equal(R, first[0]) and cost == first[1] and s["iterations"] == first[2] and s["num_successful_steps"] == first[3], rep
     c0 = rotavg.get_cost(gpu_ctx, Rgt, i0, i1, Rrel)
