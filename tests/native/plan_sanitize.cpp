@@ -25,6 +25,32 @@ static long check(const ssfm::BAFlat& F, int Nc) {
         for (int b = F.chunk_b0[t]; b < F.chunk_b1[t]; b++) { const int c = F.chunk_cam[t]; if (F.batch_slot[b] < 0 || F.batch_slot[b] >= F.row_ptr[c + 1] - F.row_ptr[c]) { std::printf("bad slot\n"); std::abort(); } }
     }
     for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] < 0 || F.col_idx[e] >= Nc) { std::printf("bad col\n"); std::abort(); }
+    // signature groups: every record of k_schur_gram / k_gram_backsub stays inside the arrays, covers exactly the flagged points, and is sorted by K
+    {
+        const size_t nnzb = F.col_idx.size(); int lastK = 0; long grouped = 0;
+        std::vector<char> seen((size_t)F.nP, 0);
+        for (size_t t = 0; t * ssfm::GRAM_REC < F.gr_rec.size(); t++) {
+            const int* r = &F.gr_rec[t * ssfm::GRAM_REC];
+            const int p0 = r[0], cnt = r[1], K = r[2], j0 = r[3];
+            if (p0 < 0 || cnt <= 0 || p0 + cnt > F.nP || K < 2 || K > ssfm::GRAM_KMAX || K < lastK || j0 != F.pt_start[p0]) { std::printf("bad group head\n"); std::abort(); }
+            lastK = K;
+            for (int q = p0; q < p0 + cnt; q++) {
+                if (!F.pt_grouped[q] || seen[q] || F.pt_start[q + 1] - F.pt_start[q] != K) { std::printf("bad group point\n"); std::abort(); }
+                seen[q] = 1; grouped++;
+                for (int k = 0; k < K; k++) if (F.obs_cam[F.pt_start[q] + k] != r[4 + k]) { std::printf("bad group camera\n"); std::abort(); }
+            }
+            for (int k = 0; k < ssfm::GRAM_KMAX; k++) { if (r[4 + k] < 0 || r[4 + k] >= Nc || r[40 + k] < 0 || (size_t)r[40 + k] >= nnzb) { std::printf("bad group camera / diagonal slot\n"); std::abort(); } }
+            for (int a = 1; a < K; a++) for (int b = 0; b < a; b++) {
+                const int sl = r[12 + a * (a - 1) / 2 + b] & 0x3fffffff; const bool tr = (r[12 + a * (a - 1) / 2 + b] >> 30) & 1;
+                const int row = tr ? r[4 + b] : r[4 + a], col = tr ? r[4 + a] : r[4 + b];
+                if ((size_t)sl >= nnzb || sl < F.row_ptr[row] || sl >= F.row_ptr[row + 1] || F.col_idx[sl] != col) { std::printf("bad group slot\n"); std::abort(); }
+            }
+            sum += p0 + cnt;
+        }
+        if (grouped != F.gram_points) { std::printf("group count\n"); std::abort(); }
+        for (int q = 0; q < F.nP; q++) if (!F.pt_grouped.empty() && (bool)F.pt_grouped[q] != (bool)seen[q]) { std::printf("flag without group\n"); std::abort(); }
+        for (size_t e = 0; e < F.pair_j.size(); e++) if (F.pair_p[e] >= 0 && F.pt_grouped[F.pair_p[e]]) { std::printf("grouped point in the pair lists\n"); std::abort(); }
+    }
     return sum;
 }
 
@@ -79,6 +105,32 @@ int main() {
             F1.nP_global != F4.nP_global || F1.M_global != F4.M_global || F1.max_row_blocks != F4.max_row_blocks) { std::printf("threaded plan differs at Nc=%d\n", Nc); std::abort(); }
         acc += check(F4, Nc);
     }
+    // signature groups: blocks of consecutive points that share their camera list (runs of 20..90 points, lists of 2..10 cameras, every now and then a loose point
+    // inside a run), host-built pair lists, 1..3 ranks, with and without the K >= 4 rule
+    for (int trial = 0; trial < 6; trial++) {
+        const int Nc = 40 + (int)(rng() % 200), Np = 6000; std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
+        std::vector<uint8_t> rf(Nc, 0), tf(Nc, trial % 2), pf(Np, 0);
+        for (auto& v : pts) v = (rng() % 100) / 10.0 + 0.5;
+        int left = 0, first = 0, len = 3;
+        for (int j = 0; j < Np; j++) {
+            if (left == 0) { left = 20 + (int)(rng() % 71); first = (int)(rng() % Nc); len = 2 + (int)(rng() % 9); }
+            left--;
+            int f2 = first, l2 = len; if (rng() % 41 == 0) { f2 = (int)(rng() % Nc); l2 = 3 + (int)(rng() % 4); }
+            std::vector<int> cs; for (int q = 0; q < l2; q++) cs.push_back((f2 + q) % Nc);
+            std::sort(cs.begin(), cs.end());
+            for (int c : cs) { oc.push_back(c); op.push_back(j); xy.push_back(1.0); xy.push_back(2.0); }
+        }
+        double focal = 800.0;
+        ssfm_ba_problem P;
+        P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
+        P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = 1;
+        if (trial % 3 == 2) setenv("SSFM_GRAM_KMIN", "2", 1); else unsetenv("SSFM_GRAM_KMIN");
+        if (trial == 4) setenv("SSFM_GRAM_PTS", "24", 1); else unsetenv("SSFM_GRAM_PTS");
+        long groups = 0;
+        for (int nr = 1; nr <= 3; nr++) for (int r = 0; r < nr; r++) { ssfm::BAFlat F; ssfm::ba_flatten(P, nr, r, F); acc += check(F, Nc); groups += (long)F.gr_rec.size(); }
+        if (groups == 0) { std::printf("no signature group found\n"); std::abort(); }
+    }
+    unsetenv("SSFM_GRAM_KMIN"); unsetenv("SSFM_GRAM_PTS");
     // tracks: random match sets incl. merges
     for (int trial = 0; trial < 20; trial++) {
         const int nk = 2 + rng() % 6; std::vector<int32_t> fp(nk + 1, 0); for (int k = 0; k < nk; k++) fp[k + 1] = fp[k] + 5 + rng() % 20;
