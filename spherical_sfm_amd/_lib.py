@@ -53,7 +53,8 @@ class BAPlanInfoC(C.Structure):
     _fields_ = [("camera_dof", C.c_int32), ("num_points_used", C.c_int32), ("num_points_used_global", C.c_int32),
                 ("reduced_blocks", C.c_int32), ("band_half_width", C.c_int32), ("max_row_blocks", C.c_int32),
                 ("num_observations_used", C.c_int64), ("num_observations_used_global", C.c_int64),
-                ("band_segments", C.c_int32), ("band_separators", C.c_int32)]
+                ("band_segments", C.c_int32), ("band_separators", C.c_int32),
+                ("num_points_grouped", C.c_int64), ("num_observations_grouped", C.c_int64), ("group_tasks", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

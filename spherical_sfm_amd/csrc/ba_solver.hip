@@ -452,6 +452,7 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
     { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.band_block, B);
       info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep + B.ntwist; }
+    info->num_points_grouped = F.gram_points; info->num_observations_grouped = F.gram_obs; info->group_tasks = (int32_t)(F.gr_rec.size() / GRAM_REC);
     if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];
     if (obs_used) for (int64_t j = 0; j < F.M; j++) obs_used[F.obs_orig[j]] = 1;
     if (cam_pos) for (int c = 0; c < F.Nc; c++) cam_pos[c] = F.cam_pos[c];

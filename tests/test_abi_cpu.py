@@ -153,6 +153,32 @@ def test_config2_plan():
     assert info["reduced_blocks"] == 300 * 6 and info["band_half_width"] <= 12
 
 
+def test_signature_groups_of_the_plan(monkeypatch):
+    """Runs of >= 32 consecutive points with the same 4..8 cameras are assembled as Gram products; the plan reports how many."""
+    import dataclasses
+    monkeypatch.delenv("SSFM_GRAM", raising=False); monkeypatch.delenv("SSFM_GRAM_KMIN", raising=False); monkeypatch.delenv("SSFM_GRAM_PTS", raising=False)
+    assert C.sizeof(_lib.BAPlanInfoC) == 72
+    p = synth.make_circle(300, 100000, 6, spherical=False)                 # config 2: every point of a camera window has the same six cameras
+    info = ba.plan(p)[0]
+    assert info["num_points_grouped"] == 100000 and info["num_observations_grouped"] == 600000
+    assert info["group_tasks"] == 1800                                      # 600 runs of 166..167 points in tasks of <= 64
+    parts = [ba.plan(p, 4, r)[0] for r in range(4)]                        # sharded: every rank groups its own points
+    assert sum(q["num_points_grouped"] for q in parts) >= 100000 - 4 * 4 * 32 and all(q["num_points_grouped"] <= q["num_points_used"] for q in parts)
+    # three cameras per point: cheaper through the pair lists; ten: more than a task holds; SSFM_GRAM=0: off
+    assert ba.plan(synth.make_circle(60, 4200, 3, spherical=False))[0]["num_points_grouped"] == 0
+    assert ba.plan(synth.make_circle(120, 4800, 10, spherical=True, check_in_frame=False, xy_range=0.2))[0]["num_points_grouped"] == 0
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "3")
+    assert ba.plan(synth.make_circle(60, 4200, 3, spherical=False))[0]["num_points_grouped"] == 4200
+    monkeypatch.delenv("SSFM_GRAM_KMIN")
+    # a loose point every 20 points: no run reaches 32
+    q = synth.make_circle(60, 4200, 6, spherical=False)
+    keep = ~((q.obs_pt % 20 == 0) & (np.arange(len(q.obs_pt)) % 6 == 5))
+    q2 = dataclasses.replace(q, obs_xy=q.obs_xy[keep], obs_cam=q.obs_cam[keep], obs_pt=q.obs_pt[keep])
+    assert ba.plan(q2)[0]["num_points_grouped"] == 0 and ba.plan(q)[0]["num_points_grouped"] == 4200
+    monkeypatch.setenv("SSFM_GRAM", "0")
+    assert ba.plan(p)[0]["num_points_grouped"] == 0
+
+
 def test_band_segment_plan_matches_reference_partition(monkeypatch):
     """The segment / separator tables of the substructured factorisation (csrc/band_sub.h) are host logic: ssfm_ba_plan reports
     their sizes; tests/_band_ref.py restates the partition rule."""
