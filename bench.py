@@ -107,8 +107,10 @@ def gram_kernel_flops(M, nP, pairs, dc):
     matrix pipe (6 tiles at DC = 6) + the VALU work per observation.  Useful: the same VALU work (every observation is linearised once now) + the
     entries of the Gram matrix the algorithm asks for: Y_a Y_b^T per (observation, observation) pair (DC x DC x 3 multiply-adds) and the upper
     triangle of Y_a Y_a^T per observation."""
-    tiles = 6 if dc == 6 else 3
-    executed = (nP / 8.0) * tiles * 6 * GRAM_TILE_FLOP + M * GRAM_OBS_VALU_FLOP
+    rows = dc * int(round(M / max(nP, 1)))              # Gram rows of a point with the average number of observations (the synthetic workloads have one K)
+    # 16x16 products per k-step: one, three or six by the number of 16-row tiles in use; six 6-dof cameras (36 rows) = three + three 4x4x4 instructions (4 blocks x 128 flop)
+    tile_flop = (1 if rows <= 16 else 3 if rows <= 32 else 6) * GRAM_TILE_FLOP if rows != 36 else 3 * GRAM_TILE_FLOP + 3 * 512
+    executed = (nP / 8.0) * 6 * tile_flop + M * GRAM_OBS_VALU_FLOP
     useful = pairs * dc * dc * 3 * 2 + M * (dc * (dc + 1) / 2) * 3 * 2 + M * GRAM_OBS_VALU_FLOP
     return executed, useful
 
@@ -294,7 +296,7 @@ def main():
         if gram:
             ex_flop, useful_flop = gram_kernel_flops(M / world, args.points / world, pairs / world, dc)
             rc = {"bound": "fp64 (matrix + vector instructions, one peak and one pipe on gfx950)", "kernel": dom, "pairs_per_launch": pairs / world, "observations_per_launch": M / world,
-                  "flop_source": "modelled (hand count, DESIGN.md 4): executed = 6 tiles x 6 k-steps x 2048 flop per 8 points on the matrix pipe + 384 flop per observation on the VALU; "
+                  "flop_source": "modelled (hand count, DESIGN.md 4): executed = the 16x16x4 products of the row tiles in use (+ three 4x4x4 instructions for the 4-row tail at 36 rows) x 6 k-steps per 8 points on the matrix pipe + 384 flop per observation on the VALU; "
                                  "useful = the Gram entries the algorithm asks for (DC x DC x 3 multiply-adds per pair, the upper triangle per observation) + the same VALU work",
                   "achieved": (ex_flop / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": (ex_flop / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None,
@@ -335,7 +337,7 @@ def main():
                           "traffic": traffic, "dtype_peak": "FP64 dense MFMA 78.6 TFLOP/s = the FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz; a v_mfma_f64_16x16x4 issues every 64 cycles: measured, profiles/r03_notes.md)", "algorithmic_flop_per_launch": useful_flop,
                           "executed_flop_per_launch": ex_flop, "executed_frac": rc["frac"], "avg_launch_us": dom_us,
                           # cross-check of the model's matrix-pipe part against a counter: SQ_INSTS_VALU_MFMA_MOPS_F64 (512 flop per MOP) of the committed PMC profile
-                          "executed_mfma_flop_model": (args.points / world / 8.0) * (6 if dc == 6 else 3) * 6 * GRAM_TILE_FLOP, "executed_mfma_flop_pmc": (mops * 512.0) if mops else None,
+                          "executed_mfma_flop_model": ex_flop - M / world * GRAM_OBS_VALU_FLOP, "executed_mfma_flop_pmc": (mops * 512.0) if mops else None,
                           "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
                                             "gfx950 x2 FETCH_SIZE correction applied; HBM bytes per launch) -- NOT measured in this run"} if gram else
                          {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
