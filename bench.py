@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r03i_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
+PMC_PROFILE = os.path.join("profiles", "r03j_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
 
 
 def pair_kernel_flops(pairs):
