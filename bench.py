@@ -108,8 +108,14 @@ def gram_kernel_flops(M, nP, pairs, dc):
     entries of the Gram matrix the algorithm asks for: Y_a Y_b^T per (observation, observation) pair (DC x DC x 3 multiply-adds) and the upper
     triangle of Y_a Y_a^T per observation."""
     rows = dc * int(round(M / max(nP, 1)))              # Gram rows of a point with the average number of observations (the synthetic workloads have one K)
-    # 16x16 products per k-step: one, three or six by the number of 16-row tiles in use; six 6-dof cameras (36 rows) = three + three 4x4x4 instructions (4 blocks x 128 flop)
-    tile_flop = (1 if rows <= 16 else 3 if rows <= 32 else 6) * GRAM_TILE_FLOP if rows != 36 else 3 * GRAM_TILE_FLOP + 3 * 512
+    # 16x16 products per k-step: one, three or six by the number of 16-row tiles in use; up to four rows beyond the last full tile (18 or 36 rows: six cameras)
+    # go through ceil(rows / 16) 4x4x4 instructions (4 blocks x 128 flop) instead of one more row of tiles
+    full, tail = rows // 16, rows % 16
+    if full >= 1 and 1 <= tail <= 4:
+        tile_flop = (full * (full + 1) // 2) * GRAM_TILE_FLOP + ((rows + 15) // 16) * 512
+    else:
+        nt = (rows + 15) // 16
+        tile_flop = (nt * (nt + 1) // 2) * GRAM_TILE_FLOP
     executed = (nP / 8.0) * 6 * tile_flop + M * GRAM_OBS_VALU_FLOP
     useful = pairs * dc * dc * 3 * 2 + M * (dc * (dc + 1) / 2) * 3 * 2 + M * GRAM_OBS_VALU_FLOP
     return executed, useful

@@ -619,7 +619,7 @@ __device__ __forceinline__ void wave_lds_handover() {
 }
 // entry (r, i) of the unscaled 6-dof camera block that is zero by construction: d/dt = [a 0 -a x; 0 a -a y]
 template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i) { return DC == 6 && ((r == 0 && i == 1) || (r == 1 && i == 0)); }
-template <int DC, int NT, bool T4 = false>
+template <int DC, int NT, int TI = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // <= 256 registers (vector + accumulation): at one wave per SIMD config 2's 1800 tasks need two rounds
 k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
              const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
@@ -657,11 +657,12 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
     v4d_ acc[NT * (NT + 1) / 2];
 #pragma unroll
     for (int t = 0; t < NT * (NT + 1) / 2; t++) acc[t] = v4d_{0.0, 0.0, 0.0, 0.0};
-    // T4: DC K = 16 NT + 4 (six 6-dof cameras: 36 rows).  The last four rows would cost NT + 1 more 16x16 products per k-step (64 cycles each) for 4 x 36 useful entries;
-    // they go through v_mfma_f64_4x4x4_4b_f64 instead (22 cycles, four 4x4 blocks per instruction): rows 32..35 against the nine column groups of four = three instructions.
-    // Block b of instruction u is column group g = 4 u + b; operands A_b[i][k] = Y[16 NT + i][k] on lane i + 4 b + 16 k, B_b[k][j] = Y[4 g + j][k] on lane j + 4 b + 16 k,
-    // result D_b[i][j] on lane j + 4 b + 16 i (profiles/r03_notes.md).
-    double tacc[3] = {0.0, 0.0, 0.0};
+    // TI > 0: 16 NT < DC K <= 16 NT + 4 (six cameras: 36 rows at 6 dof, 18 at 3).  The last rows would cost NT + 1 more 16x16 products per k-step (64 cycles each) for
+    // a handful of useful entries; they go through v_mfma_f64_4x4x4_4b_f64 instead (22 cycles, four 4x4 blocks per instruction): rows 16 NT .. + 3 against the
+    // ceil(DC K / 4) column groups of four = TI instructions.  Block b of instruction u is column group g = 4 u + b; operands A_b[i][k] = Y[16 NT + i][k] on lane
+    // i + 4 b + 16 k, B_b[k][j] = Y[4 g + j][k] on lane j + 4 b + 16 k, result D_b[i][j] on lane j + 4 b + 16 i (profiles/r03_notes.md).  Rows / columns >= DC K hold
+    // whatever LDS holds and only reach entries that are dropped.
+    double tacc[TI > 0 ? TI : 1] = {};
     double sm[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) sm[i] = 0.0;
@@ -763,21 +764,21 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
 #pragma unroll
                 for (int tj = 0; tj <= ti; tj++) { acc[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[tix], 0, 0, 0); tix++; }
         }
-        if constexpr (T4) {                                        // after the 16x16 products of all six k-steps: the two shapes do not mix well in one stream
-            double a4[3 * GRAM_SUB / 4], b4[3][3 * GRAM_SUB / 4];
+        if constexpr (TI > 0) {
+            double a4[3 * GRAM_SUB / 4], b4[TI][3 * GRAM_SUB / 4];
 #pragma unroll
             for (int st = 0; st < 3 * GRAM_SUB / 4; st++) {
-                a4[st] = sYw[(size_t)(16 * NT + (lane & 3)) * GRAM_LD + 4 * st + lk];
+                a4[st] = sYw[(size_t)min(16 * NT + (lane & 3), rows_alloc - 1) * GRAM_LD + 4 * st + lk];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int g = 4 * u + ((lane >> 2) & 3);                                   // column group of this lane's block; groups 9..11 do not exist (their results are dropped)
-                    b4[u][st] = sYw[(size_t)min(4 * g + (lane & 3), 16 * NT + 3) * GRAM_LD + 4 * st + lk];
+                for (int u = 0; u < TI; u++) {
+                    const int g = 4 * u + ((lane >> 2) & 3);                                   // column group of this lane's block
+                    b4[u][st] = sYw[(size_t)min(4 * g + (lane & 3), rows_alloc - 1) * GRAM_LD + 4 * st + lk];
                 }
             }
 #pragma unroll
             for (int st = 0; st < 3 * GRAM_SUB / 4; st++)
 #pragma unroll
-                for (int u = 0; u < 3; u++) tacc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[st], b4[u][st], tacc[u], 0, 0, 0);
+                for (int u = 0; u < TI; u++) tacc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[st], b4[u][st], tacc[u], 0, 0, 0);
         }
     }
 #undef GRAM_LOAD
@@ -837,14 +838,14 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
             }
             tix++;
         }
-    if constexpr (T4) {
-        // rows 16 NT .. + 3 (the last camera's parameters 2..5 at DC = 6) against every column: off-diagonal blocks to their slots, the camera's own block to its diagonal
-        // block -- with the mirrored entry where the column lies in the 16-row tiles (parameters 0, 1), whose rows never met these columns
+    if constexpr (TI > 0) {
+        // rows 16 NT .. + 3 against every column: off-diagonal blocks to their slots, a camera's own block to its diagonal block -- with the mirrored entry where
+        // the column lies in the 16-row tiles, whose rows never met these columns
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < TI; u++) {
             const int g = 4 * u + ((lane >> 2) & 3), R = 16 * NT + (lane >> 4), C = 4 * g + (lane & 3);
-            if (g <= (16 * NT) / 4) {
-                const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
+            const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
+            if (a < K && b <= a && C < DC * K) {
                 const double v = -tacc[u] * sScale[R] * sScale[C];
                 if (b < a) {
                     const int sl = sSlot[a * (a - 1) / 2 + b];

@@ -159,25 +159,25 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             if (!gram_stamps_done) (void)hipMalloc((void**)&gram_dbg, (size_t)4 * ng * sizeof(long long));
             static const bool gram_t4 = !(std::getenv("SSFM_GRAM_T4") && std::atoi(std::getenv("SSFM_GRAM_T4")) == 0);
             static const int gram_waves = std::getenv("SSFM_GRAM_WAVES") ? std::min(4, std::max(1, std::atoi(std::getenv("SSFM_GRAM_WAVES")))) : 1;   // waves (tasks) per workgroup: 1 measured best (2: +14 %, 4: +13 % at the configs[4] size)
-            // one launch per tile class (the tasks are sorted by K): DC K <= 16 -> 1 row tile of 16, <= 32 -> 2, DC K = 36 (six 6-dof cameras) -> 2 tiles + a 4-row tail
-            // through the 4x4x4 instruction, else 3
-            auto tile_class = [&](int K) { const int rows = DC * K; return rows <= 16 ? 0 : rows <= 32 ? 1 : (rows == 36 && gram_t4) ? 2 : 3; };
-            int cls_end[4] = {0, 0, 0, 0};
-            for (int t = 0; t < ng; t++) { const int c0 = tile_class(F.gr_rec[(size_t)t * GRAM_REC + 2]); for (int c = c0; c < 4; c++) cls_end[c] = t + 1; }
-#define SSFM_GRAM_LAUNCH(CLS_, NT_, T4_)                                                                                                               \
+            // one launch per tile class (the tasks are sorted by K, i.e. by rows = DC K): rows <= 16 -> 1 row tile of 16; 17..20 -> 1 tile + a tail of <= 4 rows through
+            // the 4x4x4 instruction; <= 32 -> 2 tiles; 33..36 -> 2 tiles + tail; else 3 tiles
+            auto tile_class = [&](int K) { const int rows = DC * K; return rows <= 16 ? 0 : (rows <= 20 && gram_t4) ? 1 : rows <= 32 ? 2 : (rows <= 36 && gram_t4) ? 3 : 4; };
+            int cls_end[5] = {0, 0, 0, 0, 0};
+            for (int t = 0; t < ng; t++) { const int c0 = tile_class(F.gr_rec[(size_t)t * GRAM_REC + 2]); for (int c = c0; c < 5; c++) cls_end[c] = t + 1; }
+#define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_)                                                                                                               \
             do {                                                                                                                                       \
                 const int t0 = (CLS_ == 0) ? 0 : cls_end[(CLS_ >= 1) ? CLS_ - 1 : 0], t1 = cls_end[CLS_];                                             \
                 if (t1 > t0) {                                                                                                                         \
                     const int rows_alloc = DC * F.gr_rec[(size_t)(t1 - 1) * GRAM_REC + 2];              /* the largest K of the class: its last task */ \
                     const size_t gram_lds = (size_t)gram_waves * ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);                          \
                     if (gram_lds > 48 * 1024)                                                                                                          \
-                        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_, T4_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
-                    LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_, T4_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, t1, h->gr_rec.p,  \
+                        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_, TI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
+                    LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_, TI_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, t1, h->gr_rec.p,  \
                            h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw, gram_dbg);  \
                 }                                                                                                                                      \
             } while (0)
-            SSFM_GRAM_LAUNCH(0, 1, false); SSFM_GRAM_LAUNCH(1, 2, false);
-            if (DC == 6) { SSFM_GRAM_LAUNCH(2, 2, true); SSFM_GRAM_LAUNCH(3, 3, false); }
+            SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
+            if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
 #undef SSFM_GRAM_LAUNCH
             if (gram_dbg) {                                        // print the phase times of this launch (100 MHz clock) and stop stamping
                 std::vector<long long> st((size_t)4 * ng); (void)hipStreamSynchronize(h->ctx->stream); (void)hipMemcpy(st.data(), gram_dbg, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
