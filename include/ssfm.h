@@ -131,7 +131,7 @@ typedef struct {
     int32_t camera_dof, num_points_used, num_points_used_global, reduced_blocks, band_half_width, max_row_blocks;
     int64_t num_observations_used, num_observations_used_global;
     int32_t band_segments, band_separators;   /* as in ssfm_ba_summary (SSFM_BAND_SEGMENTS=1 disables cutting, =P forces P per component) */
-    /* round 3: points of this rank whose Schur blocks are assembled as Gram products on the matrix cores (runs of >= 32 consecutive points with the same 4..8
+    /* round 3: points of this rank whose Schur blocks are assembled as Gram products on the matrix cores (runs of >= 32 consecutive points with the same 3..8
      * cameras; everything else goes through the sorted pair lists), their observations, and the wave tasks they are cut into */
     int64_t num_points_grouped, num_observations_grouped;
     int32_t group_tasks, reserved;

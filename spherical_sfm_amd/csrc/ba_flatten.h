@@ -95,7 +95,7 @@ struct BAFlat {
     // work chunks for the pair kernel: <= 16 consecutive batches of ONE camera each (balances rows of very different size)
     std::vector<int> chunk_cam, chunk_b0, chunk_b1;
     // Signature groups (round 3, k_schur_gram / k_gram_backsub): runs of >= GRAM_MIN_RUN consecutive points observed by exactly the same K cameras,
-    // GRAM_KMIN <= K <= GRAM_KMAX.  Their Schur blocks (off-diagonal and diagonal) and camera-side sums are formed as ONE Gram product per wave task on the
+    // GRAM_KMIN <= K <= GRAM_KMAX (3..8).  Their Schur blocks (off-diagonal and diagonal) and camera-side sums are formed as ONE Gram product per wave task on the
     // matrix cores, each observation linearised once, instead of lane-per-pair from the pair lists and k_cam_sums2 (which then skip these points: pt_grouped).
     // Tasks are sorted by K (k_schur_gram is launched once per number of 16-row tiles in use).  One record of GRAM_REC ints per task:
     //   [0] first point  [1] points (<= the task length chosen below)  [2] K  [3] first observation (the K of every point follow each other)
@@ -106,7 +106,7 @@ struct BAFlat {
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
     int64_t gram_points = 0, gram_obs = 0;
 };
-constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 4;
+constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3;
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
 // once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
@@ -660,7 +660,8 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             for (int q = 0; q < F.nP;) {
                 int e = q + 1; while (e < F.nP && same(q, e)) e++;
                 const int K = F.pt_start[q + 1] - F.pt_start[q];
-                // (K = 2, 3: the pair lists are cheaper -- 1 or 3 pairs per point against a sub-chunk's fixed cost; measured cross-over between 3 and 4, scripts/prof_gram_k.py)
+                // (every point the flatten rules keep has >= 3 observations.  K = 3 went through the pair lists until its 18 Gram rows ran as one 16-row tile + a 4x4x4
+                //  tail: 29.7 | 230 us against 31.7 | 246 us at 100k | 1.5 M points, scripts/prof_gram_k.py; SSFM_GRAM_KMIN raises the bound)
                 if (e - q >= GRAM_MIN_RUN && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
                 q = e;
             }

@@ -154,7 +154,7 @@ def test_config2_plan():
 
 
 def test_signature_groups_of_the_plan(monkeypatch):
-    """Runs of >= 32 consecutive points with the same 4..8 cameras are assembled as Gram products; the plan reports how many."""
+    """Runs of >= 32 consecutive points with the same 3..8 cameras are assembled as Gram products; the plan reports how many."""
     import dataclasses
     monkeypatch.delenv("SSFM_GRAM", raising=False); monkeypatch.delenv("SSFM_GRAM_KMIN", raising=False); monkeypatch.delenv("SSFM_GRAM_PTS", raising=False)
     assert C.sizeof(_lib.BAPlanInfoC) == 72
@@ -164,11 +164,11 @@ def test_signature_groups_of_the_plan(monkeypatch):
     assert info["group_tasks"] == 1800                                      # 600 runs of 166..167 points in tasks of <= 64
     parts = [ba.plan(p, 4, r)[0] for r in range(4)]                        # sharded: every rank groups its own points
     assert sum(q["num_points_grouped"] for q in parts) >= 100000 - 4 * 4 * 32 and all(q["num_points_grouped"] <= q["num_points_used"] for q in parts)
-    # three cameras per point: cheaper through the pair lists; ten: more than a task holds; SSFM_GRAM=0: off
-    assert ba.plan(synth.make_circle(60, 4200, 3, spherical=False))[0]["num_points_grouped"] == 0
+    # ten cameras per point: more than a task holds; SSFM_GRAM_KMIN: a lower bound on the camera list; SSFM_GRAM=0: off
     assert ba.plan(synth.make_circle(120, 4800, 10, spherical=True, check_in_frame=False, xy_range=0.2))[0]["num_points_grouped"] == 0
-    monkeypatch.setenv("SSFM_GRAM_KMIN", "3")
     assert ba.plan(synth.make_circle(60, 4200, 3, spherical=False))[0]["num_points_grouped"] == 4200
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "4")
+    assert ba.plan(synth.make_circle(60, 4200, 3, spherical=False))[0]["num_points_grouped"] == 0
     monkeypatch.delenv("SSFM_GRAM_KMIN")
     # a loose point every 20 points: no run reaches 32
     q = synth.make_circle(60, 4200, 6, spherical=False)

@@ -43,7 +43,7 @@ CASES = [(2, True, True), (3, False, True), (4, True, False), (5, False, False),
 def test_mixed_groups_match_oracle_and_ungrouped_solve(gpu_ctx, oracle, monkeypatch, K, spherical, focal_fixed):
     from spherical_sfm_amd import ba
     monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
-    monkeypatch.setenv("SSFM_GRAM_KMIN", "2")                          # by default runs of 2 or 3 cameras stay with the pair lists (cheaper there)
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "2")
     monkeypatch.setenv("SSFM_GRAM_BACKSUB", "1" if K % 2 == 0 else "0")  # default: k_gram_backsub from 7 observations per point on average
     p = mixed_problem(500 + K, K, spherical, focal_fixed)
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
@@ -92,8 +92,12 @@ def test_which_kernels_run(gpu_ctx, monkeypatch):
     assert {"k_schur_gram", "k_schur_pairs2", "k_cam_sums2", "k_gram_backsub", "k_point_backsub"} <= k
     k = kernels(mixed_problem(9, 6, False, True))
     assert {"k_schur_gram", "k_schur_pairs2", "k_cam_sums2"} <= k
+    monkeypatch.setenv("SSFM_GRAM_KMIN", "4")
     k = kernels(synth.make_circle(60, 60 * 70, 3, spherical=False, focal_fixed=True))
-    assert "k_schur_gram" not in k                                       # 3 cameras per point: the pair lists are cheaper
+    assert "k_schur_gram" not in k                                       # SSFM_GRAM_KMIN: shorter camera lists stay with the pair lists
+    monkeypatch.delenv("SSFM_GRAM_KMIN")
+    k = kernels(synth.make_circle(60, 60 * 70, 3, spherical=False, focal_fixed=True))
+    assert "k_schur_gram" in k and "k_schur_pairs2" not in k             # 18 Gram rows: one 16-row tile + the 4x4x4 tail
     monkeypatch.setenv("SSFM_GRAM", "0")
     k = kernels(full)
     assert "k_schur_gram" not in k and {"k_schur_pairs2", "k_cam_sums2"} <= k
