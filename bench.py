@@ -205,7 +205,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from spherical_sfm_amd import ba, synth
+    from spherical_sfm_amd import ba, synth, _lib
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
@@ -441,15 +441,15 @@ def main():
                 "all_kernels_avg_us": {k: v["avg_us"] for k, v in kernb.items()},
                 "share_of_gpu_time": {k: v["total_ms"] / max(1e-12, sum(w["total_ms"] for w in kb.values())) for k, v in kb.items()}}
     if world > 1 and not args.no_collective_probe:
-        # What do the collectives cost?  The same sharded solve with the reductions switched off (SSFM_TIMING_SKIP_ALLREDUCE: every rank iterates on its own
+        # What do the collectives cost?  The same sharded solve with the reductions switched off (ssfm_debug_timing_skip_collectives: every rank iterates on its own
         # shard, results meaningless, kernels and sizes unchanged); per LM iteration, rank 0's count.  Reported next to the real figure, never as `value`.
-        os.environ["SSFM_TIMING_SKIP_ALLREDUCE"] = "1"
+        _lib.lib().ssfm_debug_timing_skip_collectives(ctx._p, 1)
         adj.reset(); adj.run(); barrier()
         tq = time.perf_counter(); nq = 0
         for _ in range(max(2, args.steps // 2)):
             adj.reset(); sq = adj.run(); nq += sq["num_linearizations"]
         torch.cuda.synchronize(); tq = time.perf_counter() - tq
-        del os.environ["SSFM_TIMING_SKIP_ALLREDUCE"]
+        _lib.lib().ssfm_debug_timing_skip_collectives(ctx._p, 0)
         barrier()
         if rank == 0:
             with_ms = 1e3 * elapsed / max(1, n_lm); without_ms = 1e3 * tq / max(1, nq)

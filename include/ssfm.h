@@ -49,6 +49,10 @@ enum { SSFM_REDUCE_SUM = 0, SSFM_REDUCE_MAX = 1 };
 typedef int (*ssfm_host_allreduce_fn)(void* user, double* buf, uint64_t n, int32_t op);
 int ssfm_comm_init_host(ssfm_ctx* ctx, int32_t nranks, int32_t rank, ssfm_host_allreduce_fn fn, void* user);
 
+/* Timing probe of bench.py (`timing_without_collective`), not a product setting: while on, the bundle-adjustment reductions of this context return at once, so
+ * every rank iterates on its own shard (kernels and sizes of the sharded solve, results meaningless).  Warns on stderr when switched on. */
+int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on);
+
 /* ---- bundle adjustment: replaces the body of sphericalsfm::SfM::Optimize (src/sfm.cpp:228-290) --- */
 typedef struct {
     int32_t num_cameras;
@@ -341,7 +345,13 @@ int ssfm_focal_search(ssfm_ctx* ctx, int32_t n, int32_t num_edges, const int32_t
  * oracle bit for bit).  p->points is overwritten; points with < 3 observations or < 3 inliers become (0,0,0) exactly as in the
  * reference (which removes them from later Optimize calls).  num_inliers_out: [num_points] or NULL.  The *_fixed masks are ignored,
  * like the reference does.  SSFM_RETRI_ENUMERATE=1 selects the enumerating kernel of rounds 1-2 (every observation pair once, no random
- * stream: statistical agreement only, ~8x faster).
+ * stream: statistical agreement only, ~2.5x faster) as the default of the two forms without a mode argument; ssfm_retriangulate_mode
+ * takes the mode explicitly (SSFM_RETRI_MODE_TRACE / SSFM_RETRI_MODE_ENUMERATE).
+ * WHAT "THE REFERENCE'S TRACE" MEANS: bit-for-bit agreement is with this repository's CPU restatement (oracle/triangulation_oracle.cpp: one-sided
+ * Jacobi SVD for the DLT, a hand-written Levenberg-Marquardt with Ceres' rules), compiled without fused multiply-adds.  A real build of the reference
+ * computes the DLT with Eigen::JacobiSVD and the point refinement with Ceres; last bits decide every `score < best` branch and therefore every later
+ * draw, so against such a build the replay is the same ALGORITHM and random streams, statistically equivalent results (same inlier sets for all but
+ * marginal observations), not the same trace.  Parity of this row is "unpinned" like the rest of the oracle.
  * ssfm_retriangulate_ex: the same with its trace -- stats_out [2*num_points] = RansacStatistics::num_iterations, number_lo_iterations
  *   of every point's run; inlier_flags_out [num_observations] = 1 where the observation is in the final stats.inlier_indices of its
  *   point (either may be NULL; trace mode only).
@@ -349,7 +359,10 @@ int ssfm_focal_search(ssfm_ctx* ctx, int32_t n, int32_t num_edges, const int32_t
  *   lists[task_ptr[t] .. task_ptr[t+1]) (positions in the point's observation list, cameras ascending); out [tasks*4]:
  *   what 0 NonMinimalSolver (1..6 observations) -> X, 0;  what 1 LeastSquares from X_in[t] -> X, Levenberg-Marquardt iterations;
  *   what 2 ScoreModel / GetInliers of X_in[t] -> MSAC score at 4, inliers at 4, inliers at 4 sqrt 2, error of observation 0. */
+#define SSFM_RETRI_MODE_TRACE 0
+#define SSFM_RETRI_MODE_ENUMERATE 1
 int ssfm_retriangulate(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out);
+int ssfm_retriangulate_mode(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t mode, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out);
 int ssfm_retriangulate_ex(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out);
 int ssfm_tri_probe(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t what, int32_t tasks, const int32_t* task_pt, const int32_t* task_ptr, const int32_t* lists,
                    const double* X_in, double* out);

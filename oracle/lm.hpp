@@ -202,7 +202,8 @@ inline LMSummary lm_minimize(LMProblem& prob, const LMOptions& opt, double* para
             x = cand; x_norm = vec_norm(x);
             if (!prob.linearize(x.data(), &x_cost, grad.data())) { sum.termination = FAILURE; break; }
             gradient_norms(gmax);
-            radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+            { const double t = 2.0 * rel - 1.0;      // Ceres: pow(2 rho - 1, 3); here t*t*t on BOTH sides (oracle and device), because glibc's pow and the device's are not bit-identical
+              radius = radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t); }
             radius = std::fmin(opt.max_trust_region_radius, radius);
             decrease_factor = 2.0; reuse_diagonal = false;
             last_step_successful = true; sum.num_successful_steps++;

@@ -126,11 +126,18 @@ def band_solve_probe(ctx, dc, comp_ptr, band, Y, dump=False):
     return (Yc, d, Z, D, T) if dump else (Yc, d)
 
 
-def retriangulate(ctx, prob):
-    """SfM::Retriangulate (reference src/sfm.cpp:156-192) on the GPU -> (points (Np,3), num_inliers (Np,))."""
+RETRI_MODE_TRACE, RETRI_MODE_ENUMERATE = 0, 1
+
+
+def retriangulate(ctx, prob, mode=None):
+    """SfM::Retriangulate (reference src/sfm.cpp:156-192) on the GPU -> (points (Np,3), num_inliers (Np,)).
+    mode: None = the library default (trace replay), RETRI_MODE_TRACE or RETRI_MODE_ENUMERATE (ssfm.h: ssfm_retriangulate_mode)."""
     b = _ProblemBuffers(prob)
     nin = np.zeros(len(b.pts), np.int32)
-    _lib.check(_lib.lib().ssfm_retriangulate(ctx._p, C.byref(b.c), nin.ctypes.data_as(c_i32_p)), ctx._p)
+    if mode is None:
+        _lib.check(_lib.lib().ssfm_retriangulate(ctx._p, C.byref(b.c), nin.ctypes.data_as(c_i32_p)), ctx._p)
+    else:
+        _lib.check(_lib.lib().ssfm_retriangulate_mode(ctx._p, C.byref(b.c), int(mode), nin.ctypes.data_as(c_i32_p), None, None), ctx._p)
     return b.pts, nin
 
 

@@ -399,7 +399,18 @@ inline void stash_take(BAFlat& F) {
     HostStash& S = host_stash(); std::lock_guard<std::mutex> g(S.m);
     F.obs_cam.swap(S.obs_cam); F.obs_pt.swap(S.obs_pt); F.pt_ids.swap(S.pt_ids); F.obs_orig.swap(S.obs_orig); F.obs_xy.swap(S.obs_xy); F.pts0.swap(S.pts0); F.mask_pt.swap(S.mask_pt);
 }
+// Bounded: a plan whose per-observation arrays exceed HOST_STASH_MAX_BYTES (the 12 M-observation problems: ~700 MB) is not kept, and whatever is kept is
+// released by ssfm_ctx_destroy (host_stash_clear) -- the stash exists for the few-ms first calls of config-2-sized problems, not for the big ones.
+constexpr size_t HOST_STASH_MAX_BYTES = (size_t)96 << 20;
+inline void host_stash_clear() {
+    HostStash& S = host_stash(); std::lock_guard<std::mutex> g(S.m);
+    raw_vector<int>().swap(S.obs_cam); raw_vector<int>().swap(S.obs_pt); raw_vector<int>().swap(S.pt_ids); raw_vector<int64_t>().swap(S.obs_orig);
+    raw_vector<double>().swap(S.obs_xy); raw_vector<double>().swap(S.pts0); raw_vector<double>().swap(S.mask_pt);
+}
 inline void stash_give(BAFlat& F) {
+    const size_t bytes = (F.obs_cam.capacity() + F.obs_pt.capacity() + F.pt_ids.capacity()) * sizeof(int) + F.obs_orig.capacity() * sizeof(int64_t)
+                       + (F.obs_xy.capacity() + F.pts0.capacity() + F.mask_pt.capacity()) * sizeof(double);
+    if (bytes > HOST_STASH_MAX_BYTES) return;
     HostStash& S = host_stash(); std::lock_guard<std::mutex> g(S.m);
     stash_swap_if_larger(F.obs_cam, S.obs_cam); stash_swap_if_larger(F.obs_pt, S.obs_pt); stash_swap_if_larger(F.pt_ids, S.pt_ids); stash_swap_if_larger(F.obs_orig, S.obs_orig);
     stash_swap_if_larger(F.obs_xy, S.obs_xy); stash_swap_if_larger(F.pts0, S.pts0); stash_swap_if_larger(F.mask_pt, S.mask_pt);

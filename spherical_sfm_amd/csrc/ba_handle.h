@@ -29,7 +29,8 @@ static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_sch
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
                                               "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub"};
 
-static bool g_alloc_timing = false; static double g_alloc_s = 0.0; static int g_alloc_n = 0;   // SSFM_PLAN_TIMING: time spent in hipMalloc
+// SSFM_PLAN_TIMING: time spent in hipMalloc (atomic: the observation arrays are allocated by the upload thread of ba_create_impl while the main thread plans)
+static bool g_alloc_timing = false; static std::atomic<long long> g_alloc_ns{0}; static std::atomic<int> g_alloc_n{0};
 template <typename T>
 struct DevBuf {
     T* p = nullptr; size_t n = 0; size_t cap_bytes = 0; int dev = 0;
@@ -48,7 +49,7 @@ struct DevBuf {
                 if (e != hipSuccess) { p = nullptr; cap_bytes = 0; }
             }
         }
-        if (g_alloc_timing) { g_alloc_s += wall_s() - t0; g_alloc_n++; }
+        if (g_alloc_timing) { g_alloc_ns += (long long)(1e9 * (wall_s() - t0)); g_alloc_n++; }
         return e;
     }
     void free() {
@@ -172,9 +173,10 @@ static hipError_t upload(DevBuf<T>& b, const std::vector<T, A>& v, hipStream_t s
 
 static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     if (!h->ctx->collective) return SSFM_OK;
-    // TIMING EXPERIMENT ONLY (bench.py --gpus N, `timing_without_collective`): every rank solves its own shard without the reductions -- the results are
-    // meaningless, the kernels and their sizes are those of the sharded solve, so the difference to the real run prices the collectives
-    if (std::getenv("SSFM_TIMING_SKIP_ALLREDUCE")) return SSFM_OK;
+    // TIMING EXPERIMENT ONLY (bench.py --gpus N, `timing_without_collective`; switched on by ssfm_debug_timing_skip_collectives, which warns on stderr -- no
+    // environment variable can do this): every rank solves its own shard without the reductions -- the results are meaningless, the kernels and their sizes are
+    // those of the sharded solve, so the difference to the real run prices the collectives
+    if (h->ctx->timing_skip_collectives) return SSFM_OK;
     h->span_begin(KID_ALLREDUCE);
     const int rc = ctx_allreduce(h->ctx, buf, n, op);
     h->span_end();

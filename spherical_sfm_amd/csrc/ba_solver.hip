@@ -359,7 +359,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             x_norm = std::sqrt(host_scal[SC_XN2_PT] + host_scal[SC_XN2_CAM]);
             if (dev_go) { radius = dev_radius; lin_done = true; }     // the linearisation at the new x is already running with that radius
             else {
-                radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+                { const double t3 = 2.0 * rel - 1.0; radius = radius / std::fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }
                 radius = std::fmin(O.max_trust_region_radius, radius);
             }
             decrease_factor = 2.0; last_successful = true; S->num_successful_steps++;
@@ -443,10 +443,14 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
     return rc;
 }
 
+// ssfm_ctx_destroy releases the recycled host arrays of the planner (ba_flatten.h: HostStash)
+void ssfm_host_stash_clear() { host_stash_clear(); }
+
 extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba_plan_info* info, int32_t* point_ids,
                             uint8_t* obs_used, int32_t* cam_pos) {
     if (!p || !info || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, SSFM_ERR_INVALID, "ssfm_ba_plan: bad arguments");
     BAFlat F; ba_flatten(*p, nranks, rank, F, false);     // the pair lists are not part of what the plan reports
+    struct GiveBack { BAFlat& F; ~GiveBack() { stash_give(F); } } give_back{F};      // ba_flatten took the recycled host arrays: hand them on
     std::memset(info, 0, sizeof(*info));
     if (obs_used) std::memset(obs_used, 0, (size_t)p->num_observations);
     if (F.nothing_to_do) return SSFM_OK;
@@ -478,12 +482,13 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
     const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
-    g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_s = 0.0; g_alloc_n = 0;
+    g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_ns = 0; g_alloc_n = 0;
     const double t_create0 = wall_s();
     // The per-observation arrays are final long before the plan is (the structure of S, the ordering, the task tables follow): a second host thread
     // uploads them on the context's stream while this one goes on planning -- the main thread does not touch the stream until it has joined the upload.
     hipStream_t st = ctx->stream;
     std::thread up_thread; int up_rc = SSFM_OK; double up_s = 0.0;
+    struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } up_guard{up_thread};      // ba_flatten may throw (std::bad_alloc) after the thread started
     static const bool overlap_upload = !(std::getenv("SSFM_PLAN_OVERLAP") && std::atoi(std::getenv("SSFM_PLAN_OVERLAP")) == 0);
     auto upload_obs = [&](BAFlat& Fm) -> int {
         const double tu = wall_s();
@@ -495,7 +500,8 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
         return SSFM_OK;
     };
     const std::function<void(BAFlat&)> after_emit = [&](BAFlat& Fm) { if (overlap_upload) up_thread = std::thread([&]() { up_rc = upload_obs(Fm); }); };
-    { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs, ctx->num_cus, &after_emit); h->t_flatten_s = wall_s() - tf; }
+    try { const double tf = wall_s(); ba_flatten(*p, ctx->nranks, ctx->rank, h->F, host_pairs, ctx->num_cus, &after_emit); h->t_flatten_s = wall_s() - tf; }
+    catch (const std::exception& e) { if (up_thread.joinable()) up_thread.join(); *out = h; /* the caller tears it down */ return fail(ctx, SSFM_ERR_INVALID, (std::string("ssfm_ba_create: planning failed: ") + e.what()).c_str()); }
     *out = h;
     if (up_thread.joinable()) up_thread.join();
     const BAFlat& F = h->F;
@@ -601,7 +607,7 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p, 0, h->zone.n * sizeof(double), st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (g_alloc_timing) std::fprintf(stderr, "[create] total %.2f ms: host plan %.2f, %d hipMalloc %.2f ms, uploads + device lists %.2f ms\n", 1e3 * (wall_s() - t_create0),
-                                     1e3 * h->t_flatten_s, g_alloc_n, 1e3 * g_alloc_s, 1e3 * (wall_s() - t_create0 - h->t_flatten_s - g_alloc_s));
+                                     1e3 * h->t_flatten_s, g_alloc_n.load(), 1e-6 * g_alloc_ns.load(), 1e3 * (wall_s() - t_create0 - h->t_flatten_s - 1e-9 * g_alloc_ns.load()));
     return SSFM_OK;
 }
 

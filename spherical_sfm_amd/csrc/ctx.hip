@@ -32,11 +32,13 @@ extern "C" int ssfm_ctx_create(int32_t device, void* stream, ssfm_ctx** out) {
     return SSFM_OK;
 }
 
+void ssfm_host_stash_clear();
 extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->plan_cache && ctx->plan_cache_free) ctx->plan_cache_free(ctx->plan_cache);
     g_dev_pool.drain(ctx->device);                               // recycled device buffers of this device
+    ssfm_host_stash_clear();                                     // recycled host arrays of the planner (ba_solver.hip)
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->host_pub) (void)hipHostFree(ctx->host_pub);
@@ -73,5 +75,14 @@ extern "C" int ssfm_comm_init_host(ssfm_ctx* ctx, int32_t nranks, int32_t rank, 
     if (ctx->comm) return fail(ctx, SSFM_ERR_INVALID, "ssfm_comm_init_host: an RCCL communicator is already attached");
     ctx->host_allreduce = fn; ctx->host_allreduce_user = user;
     ctx->nranks = nranks; ctx->rank = rank; ctx->collective = true;
+    return SSFM_OK;
+}
+
+// bench.py's `timing_without_collective` probe (never a product setting): BA reductions of this context return at once while `on` is set
+extern "C" int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on) {
+    if (!ctx) return SSFM_ERR_INVALID;
+    if (on && !ctx->timing_skip_collectives)
+        std::fprintf(stderr, "[ssfm] WARNING: collectives of this context are SKIPPED (timing probe): multi-rank bundle adjustment results are meaningless until it is switched off\n");
+    ctx->timing_skip_collectives = on != 0;
     return SSFM_OK;
 }

@@ -137,7 +137,7 @@ __device__ void tri_lsq(const TriCtx& c, const unsigned long long* mask, double*
         if (rho > 1e-3) {
             x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2]; x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
             linearize(x);
-            radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3))); decrease = 2.0; last_ok = true;
+            { const double t3 = 2.0 * rho - 1.0; radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3)); } decrease = 2.0; last_ok = true;
         } else { radius /= decrease; decrease *= 2.0; last_ok = false; }
     }
     X[0] = x[0]; X[1] = x[1]; X[2] = x[2];
@@ -547,7 +547,7 @@ __device__ int tt_lsq(const TtPoint& c, const int* list, int cnt, double* X) {
             x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
             if (!sweep(x, true)) break;
             gmax = gradient_max();
-            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+            { const double t3 = 2.0 * rel - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }      // the cube by multiplication, like oracle/lm.hpp: IEEE on both sides
             radius = fmin(1e16, radius);
             decrease = 2.0; reuse_diagonal = false; last_ok = true;
             if (x_cost < minimum_cost) { minimum_cost = x_cost; best[0] = x[0]; best[1] = x[1]; best[2] = x[2]; }
@@ -811,6 +811,30 @@ static void tri_sample_sequence(int n, int iters, unsigned short* out /* [iters 
         out[2 * it] = (unsigned short)s[0]; out[2 * it + 1] = (unsigned short)s[1];
     }
 }
+// The device reduces the raw words of mt19937(0) the way libstdc++ >= 11 does (Lemire's multiply-shift with rejection, bits/uniform_int_dist.h), while the
+// sampler tables above come from whatever libstdc++ this library is linked against.  One check per process that the two are the same algorithm: a few
+// hundred draws over ranges of every size class against the host restatement of tt_uniform_int.
+static bool tri_libstdcxx_is_lemire() {
+    static const bool ok = [] {
+        std::mt19937 a; a.seed(0u); std::mt19937 w; w.seed(0u);
+        const int hi[] = {1, 2, 3, 5, 6, 13, 20, 63, 64, 999, 65534};
+        for (int rep = 0; rep < 40; rep++)
+            for (int h : hi) {
+                std::uniform_int_distribution<int> d(rep % (h + 1), h);
+                const int want = d(a), lo = rep % (h + 1);
+                const unsigned range = (unsigned)(h - lo) + 1u; int got;
+                while (true) {
+                    const unsigned long long prod = (unsigned long long)(unsigned)w() * (unsigned long long)range;
+                    const unsigned low = (unsigned)prod;
+                    if (low < range) { const unsigned thr = (0u - range) % range; if (low < thr) continue; }
+                    got = lo + (int)(unsigned)(prod >> 32); break;
+                }
+                if (got != want) return false;
+            }
+        return true;
+    }();
+    return ok;
+}
 // utils::NumRequiredIterations (utils.h:110-140) with the options of EstimateModel's calls (ransac.h:171-175)
 static unsigned tri_num_required_iterations(double ratio, double pmiss, int ssize, unsigned mn, unsigned mx) {
     if (ratio <= 0.0) return mx;
@@ -845,6 +869,8 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
     const int Np = p->num_points; const int64_t M = p->num_observations;
     TriDevice D; std::vector<int> pt_start; std::vector<int64_t> obs_index; int total = 0;
     TtOpts o; o.thr = 4.0; o.mult = std::sqrt(2.0); o.lo_steps = 10; o.lsq_it = 4; o.min_sample_mult = 7; o.non_min_mult = 3; o.min_it = 100u; o.lo_start = 50u;   // src/sfm.cpp:175-177 + ransac.h:47-88
+    if (!tri_libstdcxx_is_lemire())
+        return fail(ctx, SSFM_ERR_INVALID, "ssfm_retriangulate: this libstdc++'s uniform_int_distribution is not the multiply-shift reduction the device replays; use SSFM_RETRI_MODE_ENUMERATE");
     auto body = [&]() -> int {
         { const int rc = tri_upload_problem(ctx, st, p, D, pt_start, inlier_flags_out ? &obs_index : nullptr, &total); if (rc) return rc; }
         // one sampler sequence + one iteration-count table per distinct track length
@@ -912,15 +938,23 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
     return rc;
 }
 
-extern "C" int ssfm_retriangulate_ex(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out) {
+extern "C" int ssfm_retriangulate_mode(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t mode, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out) {
     if (!ctx || !p || !p->points || !p->cameras || !p->focal || p->num_points < 0 || p->num_cameras < 0 || p->num_observations < 0) return fail(ctx, SSFM_ERR_INVALID, "ssfm_retriangulate: bad arguments");
+    if (mode != SSFM_RETRI_MODE_TRACE && mode != SSFM_RETRI_MODE_ENUMERATE) return fail(ctx, SSFM_ERR_INVALID, "ssfm_retriangulate_mode: unknown mode");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const char* e = getenv("SSFM_RETRI_ENUMERATE");
-    if (e && atoi(e) != 0) {
+    if (mode == SSFM_RETRI_MODE_ENUMERATE) {
         if (stats_out || inlier_flags_out) return fail(ctx, SSFM_ERR_INVALID, "ssfm_retriangulate_ex: the enumerating mode has no trace to report");
         return retriangulate_enumerate(ctx, p, num_inliers_out);
     }
     return retriangulate_trace(ctx, p, num_inliers_out, stats_out, inlier_flags_out);
+}
+// default mode of the two-argument forms: the trace replay; SSFM_RETRI_ENUMERATE=1 (read once) turns the default into the enumerating kernel
+static int retri_default_mode() {
+    static const int m = [] { const char* e = getenv("SSFM_RETRI_ENUMERATE"); return (e && atoi(e) != 0) ? SSFM_RETRI_MODE_ENUMERATE : SSFM_RETRI_MODE_TRACE; }();
+    return m;
+}
+extern "C" int ssfm_retriangulate_ex(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out, uint32_t* stats_out, uint8_t* inlier_flags_out) {
+    return ssfm_retriangulate_mode(ctx, p, retri_default_mode(), num_inliers_out, stats_out, inlier_flags_out);
 }
 extern "C" int ssfm_retriangulate(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_inliers_out) { return ssfm_retriangulate_ex(ctx, p, num_inliers_out, nullptr, nullptr); }
 

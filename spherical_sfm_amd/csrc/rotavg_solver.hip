@@ -796,7 +796,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         if (rel > O.min_relative_decrease) {
             std::swap(xx, xcand); std::swap(fmx, fmc);
             x_norm = std::sqrt(cand_xn2);
-            radius = std::fmin(O.max_trust_region_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+            { const double t3 = 2.0 * rel - 1.0; radius = std::fmin(O.max_trust_region_radius, radius / std::fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3)); }
             decrease_factor = 2.0; last_successful = true; S->num_successful_steps++;
             x_cost = cand_cost; if (x_cost < minimum_cost) minimum_cost = x_cost;
         } else { radius /= decrease_factor; decrease_factor *= 2.0; last_successful = false; S->num_unsuccessful_steps++; }

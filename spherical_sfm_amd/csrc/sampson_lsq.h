@@ -293,7 +293,7 @@ __device__ void sampson_lsq6(const G& grp, const int* list, int cnt, const doubl
 #pragma unroll
                 for (int k = 0; k < LSQ_NP; k++) x_norm += x[k] * x[k];
                 x_norm = sqrt(x_norm);
-                radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3))); decrease = 2.0; last_ok = true;
+                { const double t3 = 2.0 * rho - 1.0; radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3)); } decrease = 2.0; last_ok = true;
             } else {
                 if (stop) break;
                 tables(x, false);                 // R, t back to the accepted point (dR never left it)

@@ -127,7 +127,7 @@ void SfM::Flatten(FlatProblem& F) {
 void SfM::Retriangulate() {
     if (numCameras == 0 || numPoints == 0) return;
     FlatProblem F; Flatten(F);
-    int rc = ssfm_retriangulate(ctx, &F.P, nullptr);
+    int rc = retriangulateMode < 0 ? ssfm_retriangulate(ctx, &F.P, nullptr) : ssfm_retriangulate_mode(ctx, &F.P, retriangulateMode, nullptr, nullptr, nullptr);
     if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(ctx) << "\n"; exit(1); }
     for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = F.pts[(size_t)kv.first * 3 + k];
 }

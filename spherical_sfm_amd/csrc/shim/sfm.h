@@ -92,6 +92,7 @@ public:
     bool GetMeasurement(int i, int j, Pose& measurement);      // include/sphericalsfm/sfm.h:71 -- declared there and defined nowhere in the reference; here: lookup in `measurements`
 
     void Retriangulate();                         // src/sfm.cpp:156-192
+    int retriangulateMode = -1;                   // -1: the library default (trace replay); SSFM_RETRI_MODE_TRACE / SSFM_RETRI_MODE_ENUMERATE (not in the reference)
     bool Optimize();                              // src/sfm.cpp:228-290: true iff CONVERGENCE; exit(1) on FAILURE
 
     void Apply(const Pose& pose);

@@ -113,6 +113,10 @@ int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::ve
     O.min_num_inliers = min_num_inliers; O.inward = inward ? 1 : 0; O.final_least_squares = 1;                                 // :316-318
     const int P = (int)cand.size();
     std::vector<double> R((size_t)9 * P); std::vector<uint8_t> mask(std::max<size_t>(1, m0.size())); std::vector<int32_t> nin(P);
+    // COLLECTIVE when the context carries a communicator (ssfm_comm_init / ssfm_comm_init_host): every rank of the job must make this call with the same
+    // keyframes and matches, or the ranks that did wait in the result all-reduce forever -- a rank-0-only pairwise stage needs a context of its own without a
+    // communicator.  Without one this is the plain single-GPU indexed batch.  (The result table is summed: a -0.0 entry of a rotation comes back as +0.0 on the
+    // ranks that did not compute it; every other bit equals the single-GPU result.)
     if (ssfm_ransac_batch_indexed_sharded(ctx, nf, feat_ptr.data(), rays.data(), P, pf0.data(), pf1.data(), pair_ptr.data(), m0.data(), m1.data(), sq_thresh, &O, nullptr, R.data(),
                                   mask.data(), nin.data(), nullptr, nullptr) != SSFM_OK) {
         std::cout << "error: " << ssfm_last_error(ctx) << "\n"; std::exit(1);

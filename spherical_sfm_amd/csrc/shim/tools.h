@@ -44,7 +44,8 @@ bool read_feature_tracks(const std::string& outputpath, std::vector<Keyframe>& k
 // estimate_pairwise (spherical_sfm_tools.cpp:309-431): every candidate pair (index0 < index1) with at least min_num_inliers matches goes
 // through the spherical 3-point LO-MSAC -- all pairs in ONE ssfm_ransac_batch launch instead of the OpenMP loop; pairs with more than
 // min_num_inliers inliers come back with their inlier matches and R = so3exp(decompose(E)).  Returns the number of loop closures
-// (accepted pairs that are not consecutive).
+// (accepted pairs that are not consecutive).  COLLECTIVE if ctx carries a communicator: every rank calls it with the same arguments (pairs are sharded, one all-reduce
+// returns all results everywhere); a context without a communicator runs all pairs locally.
 int estimate_pairwise(ssfm_ctx* ctx, const Intrinsics& intrinsics, const std::vector<Keyframe>& keyframes, const std::vector<ImageMatch>& image_matches,
                       double inlier_threshold, int min_num_inliers, bool inward, std::vector<ImageMatch>& image_matches_out);
 

@@ -15,6 +15,7 @@ struct ssfm_ctx {
     std::string err;
     ncclComm_t comm = nullptr;   // RCCL communicator (one rank per GPU), null for single-GPU
     int nranks = 1, rank = 0;
+    bool timing_skip_collectives = false;      // ssfm_debug_timing_skip_collectives (bench.py's timing probe): the BA reductions return at once -- results are NOT a solution
     bool collective = false;     // reductions go through RCCL or the host hook (nranks > 1, or a forced 1-rank communicator)
     ssfm_host_allreduce_fn host_allreduce = nullptr; void* host_allreduce_user = nullptr;   // alternative to RCCL
     double* host_stage = nullptr; size_t host_stage_n = 0;                                  // pinned staging for the hook
