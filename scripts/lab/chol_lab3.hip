@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
+#define CHOL3_STAMPS 1
 #include "ba_flatten.h"
 #include "band_kernels3.h"
 using namespace ssfm;
@@ -55,6 +56,7 @@ int run(int ncomp, int ncam, int b, int reps) {
     CK(hipMemcpy(dpairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcomp, comp_ptr.data(), comp_ptr.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dfail, 0, 4));
     hipStream_t st; CK(hipStreamCreate(&st));
+    { static long long* dst_ = nullptr; if (!dst_) { CK(hipMalloc(&dst_, 16 * 8 * 8)); CK(hipMemset(dst_, 0, 16 * 8 * 8)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_chol3_stamps), &dst_, sizeof(dst_))); } }
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     auto check = [&](const char* tag) {
         std::vector<double> X(Y.size()); CK(hipMemcpy(X.data(), dY, X.size() * 8, hipMemcpyDeviceToHost));
@@ -96,16 +98,22 @@ int run(int ncomp, int ncam, int b, int reps) {
         else if (tw <= 3 && (b + 1) * 36 + 12 <= 64 * 10) V3(3, 10);
         else if (tw <= 4 && (b + 1) * 36 + 12 <= 64 * 10) V3(4, 10);
 #undef V3
+        {   // stamps of one step (block 0, step 10) per role: 0 loop head | 1 after phase B | 2 after barrier A | 3 after the role's work | 4 after barrier B | 5 (role 0) before the factorisation
+            long long hs[16 * 8]; long long* dptr; CK(hipMemcpyFromSymbol(&dptr, HIP_SYMBOL(g_chol3_stamps), sizeof(dptr)));
+            CK(hipMemcpy(hs, dptr, sizeof(hs), hipMemcpyDeviceToHost));
+            const long long t0 = hs[0];
+            for (int r = 0; r < tw + 4; r++) printf("  role %d: phaseB %5lld  barA %5lld  work %5lld  barB %5lld   (head at %+lld%s)\n", r, hs[r * 8 + 1] - hs[r * 8 + 0], hs[r * 8 + 2] - hs[r * 8 + 1],
+                                                   hs[r * 8 + 3] - hs[r * 8 + 2], hs[r * 8 + 4] - hs[r * 8 + 3], hs[r * 8 + 0] - t0, r == 0 ? ", D update" : "");
+            printf("  role 0: D update %lld, factor+inverse %lld;  step %lld (s_memtime ticks: 100 MHz -> x cycles/tick)\n", hs[5] - hs[2], hs[3] - hs[5], hs[4] - hs[0]);
+        }
     }
     return 0;
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const int reps = 50;
     run<6>(4, 75, 10, reps);
-    run<6>(8, 32, 10, reps);
-    run<6>(4, 75, 12, reps);
     run<6>(4, 75, 14, reps);
-    run<6>(4, 12, 10, reps);
     return 0;
 }

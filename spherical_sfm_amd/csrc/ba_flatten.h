@@ -105,6 +105,7 @@ struct BAFlat {
     std::vector<int> gr_rec;
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
     int64_t gram_points = 0, gram_obs = 0;
+    bool gram_sorted = false;               // the local points were re-ordered by camera-list signature (ba_flatten: signature sort)
 };
 constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3;
 
@@ -438,7 +439,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     bool sorted = true;
     std::vector<int64_t> order;
     auto at = [&](int64_t i) { return sorted ? i : order[i]; };
-    struct Seg { int pt; int64_t begin, end; int nobs; };
+    struct Seg { int pt; int64_t begin, end; int nobs; int first_cam; uint64_t sig; };      // sig: hash of the (deduplicated) camera list, for the signature sort below
     std::vector<Seg> segs;
     auto build_segments = [&](bool check_order) -> bool {
         const int TS = (M >= 200000) ? NT : 1;
@@ -455,11 +456,13 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             std::vector<Seg>& out = part[tt]; out.reserve((size_t)((i1 - i0) / 4 + 16));
             for (int64_t i = i0; i < i1;) {
                 const int p = P.obs_pt[at(i)];
-                int64_t e = i; int nobs = 0; int last_cam = -1;
-                while (e < M && P.obs_pt[at(e)] == p) { const int c = P.obs_cam[at(e)]; if (c != last_cam && c >= 0 && c < Nc) { nobs++; last_cam = c; } e++; }
+                int64_t e = i; int nobs = 0; int last_cam = -1, first_cam = -1; uint64_t sig = 0x9E3779B97F4A7C15ull;
+                while (e < M && P.obs_pt[at(e)] == p) { const int c = P.obs_cam[at(e)];
+                    if (c != last_cam && c >= 0 && c < Nc) { nobs++; last_cam = c; if (first_cam < 0) first_cam = c; sig = (sig ^ (uint64_t)(c + 1)) * 0xFF51AFD7ED558CCDull; sig ^= sig >> 29; }
+                    e++; }
                 bool valid = p >= 0 && p < Np && nobs >= 3;
                 if (valid) { const double* X = &P.points[(size_t)p * 3]; valid = (X[0] * X[0] + X[1] * X[1] + X[2] * X[2]) != 0.0; }
-                if (valid) out.push_back({p, i, e, nobs});
+                if (valid) out.push_back({p, i, e, nobs, first_cam, sig});
                 i = e;
             }
         });
@@ -493,6 +496,41 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         }
         if (!have0) s0 = segs.size();
         if (rank == nranks - 1) s1 = segs.size();
+    }
+    // ---- signature sort (round 4).  k_schur_gram takes runs of CONSECUTIVE local points with the same camera list; the order of the local points is the planner's
+    // own (pt_ids maps back), so when the caller's order leaves points of equal signature apart -- build_sfm issues point ids in match order
+    // (examples/spherical_sfm_tools.cpp:862-955): tracks that start in the same frame get neighbouring ids whatever their length -- this rank's points are
+    // re-ordered by (first camera, track length, camera-list hash), stable in the caller's order: equal lists become adjacent and neighbours in the order still
+    // share cameras (the XCD-contiguous task order relies on that).  Counting sort by first camera, then every bucket on its own planner thread: ~0.3 ms at 100k
+    // points.  Skipped when the caller's order already groups >= 90 % of the points that could be grouped (the synthetic circles: 100 %).  SSFM_GRAM_SORT=0 / 1 forces it.
+    {
+        const char* e_gs = std::getenv("SSFM_GRAM_SORT");
+        const int force = e_gs ? std::atoi(e_gs) : -1;
+        bool do_sort = force == 1;
+        if (force < 0 && s1 - s0 >= 2 * (size_t)GRAM_MIN_RUN) {
+            int64_t could = 0, adjacent = 0;
+            for (size_t k = s0; k < s1;) {
+                size_t e = k + 1; while (e < s1 && segs[e].sig == segs[k].sig && segs[e].nobs == segs[k].nobs) e++;
+                if (segs[k].nobs <= GRAM_KMAX) { could += (int64_t)(e - k); if (e - k >= (size_t)GRAM_MIN_RUN) adjacent += (int64_t)(e - k); }
+                k = e;
+            }
+            do_sort = could > 0 && adjacent * 10 < could * 9;
+        }
+        if (do_sort) {
+            std::vector<int> bucket_ptr(Nc + 1, 0);
+            for (size_t k = s0; k < s1; k++) bucket_ptr[segs[k].first_cam + 1]++;
+            for (int c = 0; c < Nc; c++) bucket_ptr[c + 1] += bucket_ptr[c];
+            std::vector<Seg> tmp(s1 - s0);
+            { std::vector<int> fill(bucket_ptr.begin(), bucket_ptr.end() - 1); for (size_t k = s0; k < s1; k++) tmp[fill[segs[k].first_cam]++] = segs[k]; }
+            parallel_chunks(Nc, NT, [&](int, int64_t c0, int64_t c1) {
+                for (int c = (int)c0; c < (int)c1; c++)
+                    std::stable_sort(tmp.begin() + bucket_ptr[c], tmp.begin() + bucket_ptr[c + 1],
+                                     [](const Seg& a, const Seg& b2) { return a.nobs != b2.nobs ? a.nobs < b2.nobs : a.sig < b2.sig; });
+            });
+            std::copy(tmp.begin(), tmp.end(), segs.begin() + s0);
+            F.gram_sorted = true;
+        }
+        lap("signature sort");
     }
     // ---- pass 2: emit local observations
     F.nP = (int)(s1 - s0);
@@ -658,6 +696,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     {
         const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);                               // read per plan: tests switch it
         const int kmin = std::getenv("SSFM_GRAM_KMIN") ? std::max(2, std::atoi(std::getenv("SSFM_GRAM_KMIN"))) : GRAM_KMIN;
+        const int min_run = std::getenv("SSFM_GRAM_MIN_RUN") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_MIN_RUN"))) : GRAM_MIN_RUN;       // shortest run that becomes a wave task
         const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;           // points per wave task (0: by size)
         F.pt_grouped.resize((size_t)F.nP);
         if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
@@ -673,7 +712,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 const int K = F.pt_start[q + 1] - F.pt_start[q];
                 // (every point the flatten rules keep has >= 3 observations.  K = 3 went through the pair lists until its 18 Gram rows ran as one 16-row tile + a 4x4x4
                 //  tail: 29.7 | 230 us against 31.7 | 246 us at 100k | 1.5 M points, scripts/prof_gram_k.py; SSFM_GRAM_KMIN raises the bound)
-                if (e - q >= GRAM_MIN_RUN && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
+                if (e - q >= min_run && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
                 q = e;
             }
             // points per wave task: a task pays ~5 us of start-up (index loads, camera records, the atomics of its blocks at the end) whatever its length, and

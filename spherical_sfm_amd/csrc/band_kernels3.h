@@ -62,6 +62,13 @@ inline int chol3_trailing_waves(int b) { return ((b + 1) * b + 63) / 64; }
 //   Y     [NR][N*6]     in/out: right-hand sides -> L^-1 Y
 // Same tables and meaning as k_band_chol_v2: pivots [piv_lo, piv_hi), window to win_hi, merge_from, await2 / signal / flags.
 // TW trailing waves (64 TW >= (b+1) b), PRE loader registers per lane (64 PRE >= (b+1) 36 + 6 NR).  blockDim.x = 64 (TW + 4).
+#ifdef CHOL3_STAMPS
+__device__ long long* g_chol3_stamps;
+#define CHOL3_STAMPJ(jv_, slot_) do { if (blockIdx.x == 0 && (jv_) == r0 + 10 && lane == 0) g_chol3_stamps[role * 8 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHOL3_STAMPJ(jv_, slot_) do { } while (0)
+#endif
+#define CHOL3_STAMP(slot_) CHOL3_STAMPJ(j, slot_)
 template <int NR, int TW, int PRE>
 __global__ void __launch_bounds__(64 * (TW + 4))
 k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y,
@@ -194,8 +201,11 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
+            CHOL3_STAMP(0);
             phaseB(jm, nb);
+            CHOL3_STAMP(1);
             lds_barrier();
+            CHOL3_STAMP(2);
             if (j + 1 < r1) {
                 int s1 = jm + 1; if (s1 >= R) s1 -= R;
                 const int lr = min(lane, 5);
@@ -216,20 +226,26 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 #pragma unroll
                     for (int c = 0; c < 6; c++) row[c] = 0.0;
                 }
+                CHOL3_STAMP(5);
                 if (!wave_ldl_inverse6(row, g) && lane == 0) *fail_flag = 1;
                 if (lane < 6) {
 #pragma unroll
                     for (int c = 0; c < 6; c += 2) *reinterpret_cast<c3_d2*>(sG + lane * 6 + c) = c3_d2{g[c], g[c + 1]};
                 }
             }
+            CHOL3_STAMP(3);
             lds_barrier();
+            CHOL3_STAMP(4);
         }
     } else if (is_tr) {
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
+            CHOL3_STAMP(0);
             phaseB(jm, nb);
+            CHOL3_STAMP(1);
             lds_barrier();
+            CHOL3_STAMP(2);
             int rel = rho - jm; if (rel < 0) rel += R;
             const int kr = rel - d;
             const bool live = valid && kr >= 1 && j + rel < re;
@@ -268,15 +284,20 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                         for (int c = 0; c < 6; c += 2) *reinterpret_cast<c3_d2*>(dst + a * 6 + c) = c3_d2{acc[a][c], acc[a][c + 1]};
                 }
             }
+            CHOL3_STAMP(3);
             lds_barrier();
+            CHOL3_STAMP(4);
         }
     } else if (role == TW + 1) {
         // ---- the other diagonal blocks of the window (lower triangle computed, both halves written) + right-hand sides
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
+            CHOL3_STAMP(0);
             phaseB(jm, nb);
+            CHOL3_STAMP(1);
             lds_barrier();
+            CHOL3_STAMP(2);
             const int k0 = (j + 1 < r1) ? 1 : 0;             // block (j+1, j+1) belongs to the look-ahead wave while it is a pivot
             for (int q = lane; q < (nb - k0) * 21; q += 64) {
                 const int kk = q / 21, tr = q - kk * 21, k = kk + k0;
@@ -301,19 +322,26 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                     for (int m = 0; m < DC; m++) v += Lk_[m] * sYj[r * DC + m];
                     sYr[(size_t)sk * NR * DC + r * DC + a] -= v; }
             }
+            CHOL3_STAMP(3);
             lds_barrier();
+            CHOL3_STAMP(4);
         }
     } else if (role == TW + 2) {
         // ---- writer: panel, y_j and G to global memory (stores only, never waited on)
         int jm = jm0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
+            CHOL3_STAMP(0);
             phaseB(jm, nb);
             if (lane < BB) Ginv[(size_t)j * BB + lane] = sG[lane];      // before the look-ahead wave replaces it
+            CHOL3_STAMP(1);
             lds_barrier();
+            CHOL3_STAMP(2);
             for (int e = lane; e < nb * BB; e += 64) { const int k = e / BB, rc = e - k * BB; band[((size_t)(j + 1 + k) * R + (k + 1)) * BB + rc] = sP[k * PS + rc]; }
             if (lane < NR * DC) Y[(size_t)(lane / DC) * n + (size_t)j * DC + (lane % DC)] = sYj[lane];
+            CHOL3_STAMP(3);
             lds_barrier();
+            CHOL3_STAMP(4);
         }
     } else {
         // ---- loader: the image of row j + 1 + R goes to the staging buffer during step j (its lanes take it during step j + 1);
@@ -332,8 +360,11 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 #define CHOL3_STEP(pre_, j_)                                                                                          \
         do {                                                                                                          \
             const int nb = min(b, re - 1 - (j_));                                                                     \
+            CHOL3_STAMPJ((j_), 0);                                                                                           \
             phaseB(jm, nb);                                                                                           \
+            CHOL3_STAMPJ((j_), 1);                                                                                           \
             lds_barrier();                                                                                            \
+            CHOL3_STAMPJ((j_), 2);                                                                                           \
             if ((j_) + R < re) {                                                                                      \
                 const double* img = sStage + (size_t)((j_) & 1) * RWP;                                                \
                 if (lane < BB) sDg[(size_t)jm * BB + lane] = img[lane];                                               \
@@ -342,7 +373,9 @@ k_band_chol_v3(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             double* nxt = sStage + (size_t)(((j_) + 1) & 1) * RWP;                                                    \
             _Pragma("unroll") for (int u = 0; u < PRE; u++) { const int e = lane + u * 64; if (e < RWP) nxt[e] = pre_[u]; } \
             CHOL3_ISSUE(pre_, (j_) + R + 3);                                                                          \
+            CHOL3_STAMPJ((j_), 3);                                                                                           \
             lds_barrier();                                                                                            \
+            CHOL3_STAMPJ((j_), 4);                                                                                           \
             jm = (jm + 1 == R) ? 0 : jm + 1;                                                                          \
         } while (0)
         CHOL3_ISSUE(preA, r0 + R + 1);

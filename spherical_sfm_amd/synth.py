@@ -102,6 +102,58 @@ def make_circle(num_cameras=60, num_points=20000, obs_per_point=6, *, spherical=
                      gt_focal=float(focal))
 
 
+def make_ragged_circle(num_cameras=300, num_observations=600000, min_len=3, max_len=14, *, spherical=False, focal_fixed=True,
+                       seed=4321, focal=1000.0, pixel_noise=0.5, rot_noise_deg=0.5, point_noise=0.01, focal_init_factor=1.1, shuffle_within_frame=True):
+    """Video-like tracks on the outward circle: a point is seen by `L` CONSECUTIVE cameras f0 .. f0+L-1 (mod Nc), L uniform in [min_len, max_len], f0 uniform --
+    ragged track lengths, and point ids issued the way build_sfm issues them (examples/spherical_sfm_tools.cpp:862-955: a track gets its id when its first
+    match is met, so ids ascend with the first frame and tracks of different length that start in the same frame are interleaved).  About
+    `num_observations` observations in total (the last track is cut so that M is exact when possible)."""
+    Nc = int(num_cameras)
+    rng = np.random.default_rng(seed)
+    mean_len = 0.5 * (min_len + max_len)
+    Np = int(np.ceil(num_observations / mean_len * 1.02)) + 8
+    L = rng.integers(min_len, max_len + 1, size=Np)
+    keep = np.searchsorted(np.cumsum(L), num_observations, side='left') + 1
+    L = L[:keep]; Np = len(L)
+    over = int(L.sum() - num_observations)
+    if over > 0 and L[-1] - over >= 3: L[-1] -= over
+    f0 = np.sort(rng.integers(0, Nc, size=Np))                    # ids ascend with the first frame
+    if shuffle_within_frame:                                      # ... and lengths are interleaved inside a frame
+        L = L[np.lexsort((rng.random(Np), f0))]
+    ang = 2 * np.pi * np.arange(Nc) / Nc
+    r_gt = np.stack([np.zeros(Nc), ang, np.zeros(Nc)], axis=1)
+    r_gt[:, 1] = np.where(r_gt[:, 1] > np.pi, r_gt[:, 1] - 2 * np.pi, r_gt[:, 1])
+    t_gt = np.tile(np.array([0.0, 0.0, -1.0]), (Nc, 1))
+    R = so3exp(r_gt)
+    # anchor = the middle camera of the window; narrow image window so that every projection of the (at most 14-frame, 16.8 degree) span stays in the frame
+    mid = (f0 + L // 2) % Nc
+    xy = rng.uniform(-0.30, 0.30, size=(Np, 2))
+    depth = rng.uniform(4.0, 8.0, size=Np)
+    pc = np.concatenate([xy, np.ones((Np, 1))], axis=1) * depth[:, None]
+    X = np.einsum('nji,nj->ni', R[mid], pc - t_gt[mid])
+    pt = np.repeat(np.arange(Np, dtype=np.int64), L)
+    k = np.arange(int(L.sum()), dtype=np.int64) - np.repeat(np.cumsum(L) - L, L)
+    cam = (f0[pt] + k) % Nc
+    # point-major, cameras ascending (std::map order)
+    order = np.lexsort((cam, pt)); pt = pt[order]; cam = cam[order]
+    Xc = np.einsum('nij,nj->ni', R[cam], X[pt]) + t_gt[cam]
+    assert (Xc[:, 2] > 0.5).all(), "generator: a point fell behind a camera"
+    proj = focal * Xc[:, :2] / Xc[:, 2:3]
+    assert (np.abs(proj[:, 0]) < 960).all() and (np.abs(proj[:, 1]) < 540).all(), "projection outside 1920x1080"
+    obs = proj + rng.normal(0.0, pixel_noise, size=proj.shape)
+    cams0 = np.concatenate([t_gt, r_gt], axis=1).copy()
+    noise_r = rng.normal(0.0, np.deg2rad(rot_noise_deg), size=(Nc, 3)); noise_r[0] = 0
+    cams0[:, 3:] += noise_r
+    pts0 = X * (1.0 + rng.normal(0.0, point_noise, size=(Np, 1)))
+    rot_fixed = np.zeros(Nc, np.uint8); rot_fixed[0] = 1
+    trans_fixed = np.ones(Nc, np.uint8) if spherical else np.zeros(Nc, np.uint8)
+    trans_fixed[0] = 1
+    return BAProblem(cameras=cams0, points=pts0, focal=float(focal if focal_fixed else focal * focal_init_factor),
+                     obs_xy=np.ascontiguousarray(obs), obs_cam=np.ascontiguousarray(cam.astype(np.int32)), obs_pt=np.ascontiguousarray(pt.astype(np.int32)),
+                     rot_fixed=rot_fixed, trans_fixed=trans_fixed, pt_fixed=np.zeros(Np, np.uint8), focal_fixed=bool(focal_fixed),
+                     gt_cameras=np.concatenate([t_gt, r_gt], axis=1), gt_points=X, gt_focal=float(focal))
+
+
 def make_rotation_graph(num_cameras=300, max_offset=8, *, seed=1234, noise_deg=0.2, outlier_frac=0.02):
     """Pose graph of SURVEY.md 8d: edges (i, i+d mod Nc), d=1..max_offset, R_rel = R_j R_i^T with noise,
     a fraction of gross outliers.  Returns (R_init (Nc,3,3), index0, index1, R_rel (E,3,3), R_gt)."""
