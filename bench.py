@@ -32,7 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy bandwidth of the box is MEASURED in every run (hbm_copy_GBs, ssfm_debug_copy_bandwidth)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
 PMC_PROFILE = os.path.join("profiles", "r03j_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
 
@@ -89,6 +89,14 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1, focal_free
             "note": "FP64 matrix and vector instructions share one peak on gfx950 (78.6 TFLOP/s) and, measured, one pipe; flop counts are a hand model "
                     "(DESIGN.md 4), durations are measured.  When some points are not grouped the pair kernel runs too and these figures overcount."}
     return out
+
+
+def with_copy_fraction(per_kernel, copy_gbs):
+    """adds frac_of_measured_copy (achieved / the device copy bandwidth measured in the same run) next to frac_hbm (achieved / nominal 8 TB/s)"""
+    for v in per_kernel.values():
+        if copy_gbs and v.get("achieved_GBs") is not None:
+            v["frac_of_measured_copy"] = v["achieved_GBs"] / copy_gbs
+    return per_kernel
 
 
 def gram_kernel_bytes(M, nP, nnzb, Nc, dc, focal_free):
@@ -174,6 +182,42 @@ def side_paths(ctx):
     res["rotation_averaging"] = {"workload": f"optimize_rotations, 300 cameras, {len(i0)} edges, SoftLOne(0.03)", "value": 1e3 * dt, "unit": "ms per call", "higher_is_better": False,
                                  "iterations": sg.get("iterations"), "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the same graph"},
                                  "parity_vs_oracle": {"max_rotation_error_rad": err, "iterations_cpu": sc.get("iterations")}}
+    # ---- the drivers' whole stage sequence at BASELINE configs[2] size (500 frames / 170 000 points / 1.02 M observations, shared focal free, -generalba):
+    # Optimize -> Retriangulate -> Optimize -> unfix t -> Optimize -> Normalize -> Retriangulate -> Optimize -> Normalize (examples/run_spherical_sfm_uncalib.cpp:176-222)
+    # through the C++ mirror (spherical_sfm_amd/demo_circle = shim/demo_circle.cpp, its own process and context), wall per stage as the driver sees it (flatten +
+    # upload + kernels + download), and every stage replayed on the CPU port from the state the GPU left before it (oracle/pipeline_chain.py): time + parity.
+    # Retriangulate and the retriangulate-only figures below answer VERDICT r3 #9 (it dominates the sequence).
+    exe = os.path.join(ROOT, "spherical_sfm_amd", "demo_circle")
+    if os.path.exists(exe):
+        import subprocess
+        import tempfile
+        from oracle import pipeline_chain as PC
+        with tempfile.TemporaryDirectory() as td:
+            dump = os.path.join(td, "dump.bin")
+            t = time.perf_counter()
+            pr = subprocess.run([exe, "170000", dump, "500", "6", "7", "1", "0"], capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t
+            if pr.returncode == 0:
+                ms = [float(x) for x in [l for l in pr.stdout.splitlines() if l.startswith("STAGE_MS")][0].split()[1:]]
+                d = PC.read_dump(dump)
+                names = {0: "Optimize", 1: "Retriangulate", 2: "Normalize", 3: "unfix translations"}
+                stages = []; general = False
+                for k, st in enumerate(d["stages"]):
+                    if st["kind"] == PC.UNFIX:
+                        general = True; continue
+                    t = time.perf_counter(); want, info = PC.run_stage(O, d, d["states"][k], st["kind"], general, False); tcpu = time.perf_counter() - t
+                    diff = PC.compare_states(d["states"][k + 1], want)
+                    stages.append({"stage": names[st["kind"]] + (" (general)" if general and st["kind"] == 0 else " (spherical)" if st["kind"] == 0 else ""),
+                                   "gpu_ms": ms[k], "cpu_port_ms": 1e3 * tcpu, "lm_iterations": st["iterations"] if st["kind"] == 0 else None,
+                                   "iterations_cpu": info.get("iterations") if st["kind"] == 0 else None,
+                                   "max_rel_camera": diff["cam"], "max_rel_point": diff["pt_max"], "rel_focal": diff["focal"], "zero_set_difference": diff["zero_diff"]})
+                res["pipeline_configs2"] = {
+                    "workload": "BASELINE configs[2] size: 500 cameras x 170 000 points x 1 020 000 observations, K = 6, stride 7, shared focal free, spherical then general BA "
+                                "(demo_circle through the sphericalsfm::SfM mirror; the image / matching front end is out of scope)",
+                    "stages": stages, "gpu_ms_total": sum(x["gpu_ms"] for x in stages), "cpu_port_ms_total": sum(x["cpu_port_ms"] for x in stages),
+                    "cpu_cores": 16, "process_wall_s": wall,
+                    "note": "gpu_ms = host wall of the shim call (map flatten + plan + upload + kernels + download); cpu_port_ms = the oracle on the same input state, 16 threads; "
+                            "both exclude building the synthetic scene"}
     return res
 
 
@@ -281,6 +325,17 @@ def main():
     phase = {k: sp[k] for k in phase}; n_lm_prof = sp["num_linearizations"]     # per-phase device times are only recorded with profiling on
     cams_gpu, pts_gpu, f_gpu = [np.copy(a) if hasattr(a, "copy") else a for a in adj.download()]
 
+    # measured device copy bandwidth (the HBM fractions are quoted against it AND against the nominal 8 TB/s): 512 MB float4 copy, beyond the Infinity Cache
+    copy_gbs = None
+    if rank == 0:
+        import ctypes as _C
+        g = _C.c_double(0.0)
+        if _lib.lib().ssfm_debug_copy_bandwidth(ctx._p, 512 << 20, 10, _C.byref(g)) == 0 and g.value > 0:
+            copy_gbs = float(g.value)
+
+    def vs_copy(gbs):
+        return (gbs / copy_gbs) if (gbs is not None and copy_gbs) else None
+
     out = None
     if rank == 0:
         dc = s["camera_dof"]
@@ -352,10 +407,12 @@ def main():
                                             "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
                           "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us}),
             # the same kernel on the HBM line (SURVEY 8d's figure of merit): algorithmic bytes per launch / duration
+            "hbm_copy_GBs": copy_gbs,       # measured in this run: float4 device copy of 512 MB (read + write bytes per second)
             "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                             "frac_of_measured_copy": vs_copy(achieved),
                              "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
             "roofline_compute": rc,
-            "roofline_per_kernel": kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free),
+            "roofline_per_kernel": with_copy_fraction(kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free), copy_gbs),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
             # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
             "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4, "source": f"committed profile {PMC_PROFILE} (SQ_INSTS_VALU), not measured in this run",
@@ -370,7 +427,8 @@ def main():
             "roofline_lm_iteration": {"bound": "hbm", "algorithmic_bytes": per_iter_bytes, "avg_ms": iter_ms,
                                       "achieved": per_iter_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else None,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": per_iter_bytes / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else None},
+                                      "frac": per_iter_bytes / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else None,
+                                      "frac_of_measured_copy": vs_copy(per_iter_bytes / (iter_ms * 1e-3) / 1e9) if iter_ms > 0 else None},
             "kernels": kern,
             "phases_ms_per_lm_iteration_profiled_step": {k: v / max(1, n_lm_prof) for k, v in phase.items()},
         }
@@ -436,8 +494,9 @@ def main():
             out["roofline_configs4"] = {
                 "workload": "BASELINE configs[4] SIZE on one GPU: 4000 cams x 1500000 pts x 12000000 obs (8 observations per point), general BA, focal fixed",
                 "lm_iteration": {"algorithmic_bytes": per_iter_b, "avg_ms_wall": iter_ms_b, "achieved_GBs": per_iter_b / (iter_ms_b * 1e-3) / 1e9,
-                                 "frac_hbm": per_iter_b / (iter_ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_iteration_profiled": gpu_ms},
-                "kernels": kernel_rooflines(kernb, Mb, 1500000, sq["reduced_blocks"], 4000, sq["camera_dof"], float((kkb * (kkb - 1) / 2).sum()), nlb),
+                                 "frac_hbm": per_iter_b / (iter_ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": vs_copy(per_iter_b / (iter_ms_b * 1e-3) / 1e9),
+                                 "kernel_ms_per_iteration_profiled": gpu_ms},
+                "kernels": with_copy_fraction(kernel_rooflines(kernb, Mb, 1500000, sq["reduced_blocks"], 4000, sq["camera_dof"], float((kkb * (kkb - 1) / 2).sum()), nlb), copy_gbs),
                 "all_kernels_avg_us": {k: v["avg_us"] for k, v in kernb.items()},
                 "share_of_gpu_time": {k: v["total_ms"] / max(1e-12, sum(w["total_ms"] for w in kb.values())) for k, v in kb.items()}}
     if world > 1 and not args.no_collective_probe:

@@ -53,6 +53,10 @@ int ssfm_comm_init_host(ssfm_ctx* ctx, int32_t nranks, int32_t rank, ssfm_host_a
  * every rank iterates on its own shard (kernels and sizes of the sharded solve, results meaningless).  Warns on stderr when switched on. */
 int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on);
 
+/* Measured device copy bandwidth ("denominator = measured device copy bandwidth on the box, nominal also quoted"): `reps` launches of a float4
+ * grid-stride copy of `bytes` bytes (>= 256 MB: beyond the Infinity Cache); GBs_out = bytes read + bytes written per second, in GB/s.  bench.py reports it. */
+int ssfm_debug_copy_bandwidth(ssfm_ctx* ctx, uint64_t bytes, int32_t reps, double* GBs_out);
+
 /* ---- bundle adjustment: replaces the body of sphericalsfm::SfM::Optimize (src/sfm.cpp:228-290) --- */
 typedef struct {
     int32_t num_cameras;

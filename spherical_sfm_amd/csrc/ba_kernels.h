@@ -21,6 +21,8 @@
 
 namespace ssfm {
 
+static __global__ void k_profile_pad() {}      // absorbs the dispatch latency of an idle queue in front of a profiled launch (ba_solver.hip)
+
 // slots of the per-iteration scalar block (device doubles)
 enum {
     SC_COST = 0,      // 1/2 sum rho at x                       (sharded by point)

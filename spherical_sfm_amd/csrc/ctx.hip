@@ -86,3 +86,33 @@ extern "C" int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on) {
     ctx->timing_skip_collectives = on != 0;
     return SSFM_OK;
 }
+
+// ---- measured device copy bandwidth: the denominator SURVEY.md 8d asks for next to the nominal 8 TB/s ----
+// grid-stride copy of 16-byte words (float4), `bytes` read + `bytes` written per launch; GBs_out = (2 x bytes) / average launch time over `reps` launches
+// (hipEvents on the context's stream, after two warm-up launches).  The buffers are larger than the 256 MB Infinity Cache when bytes >= 256 MB.
+static __global__ void __launch_bounds__(256) k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+extern "C" int ssfm_debug_copy_bandwidth(ssfm_ctx* ctx, uint64_t bytes, int32_t reps, double* GBs_out) {
+    if (!ctx || !GBs_out || bytes < 4096 || reps < 1) return fail(ctx, SSFM_ERR_INVALID, "ssfm_debug_copy_bandwidth: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n16 = bytes / 16; float4 *a = nullptr, *b = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        SSFM_HIP_CHECK(ctx, hipMalloc((void**)&a, n16 * 16)); SSFM_HIP_CHECK(ctx, hipMalloc((void**)&b, n16 * 16));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(a, 1, n16 * 16, ctx->stream)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(b, 0, n16 * 16, ctx->stream));
+        SSFM_HIP_CHECK(ctx, hipEventCreate(&e0)); SSFM_HIP_CHECK(ctx, hipEventCreate(&e1));
+        const int grid = ctx->num_cus * 16;
+        for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+        SSFM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+        SSFM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); SSFM_HIP_CHECK(ctx, hipGetLastError());
+        float ms = 0; SSFM_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *GBs_out = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+        return SSFM_OK;
+    };
+    const int rc = body();
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a); if (b) (void)hipFree(b);
+    return rc;
+}

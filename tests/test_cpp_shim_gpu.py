@@ -3,7 +3,6 @@ AddCamera/AddPoint/AddObservation -> Optimize() (spherical) -> Retriangulate() -
 Optimize() -> Normalize() -> Retriangulate() -> Optimize() -> Normalize().
 The problem the C++ side built is dumped and replayed through the oracle: parity of the whole drop-in path."""
 import os
-import struct
 import subprocess
 
 import numpy as np
@@ -31,35 +30,22 @@ def test_cpp_shim_call_sequence_matches_oracle(oracle, tmp_path):
     assert float(r["cost1b"]) <= float(r["cost1"]) * (1 + 1e-6) and float(r["cost3"]) <= float(r["cost2"]) * (1 + 1e-6)
     assert abs(float(r["focal1"]) - 1000.0) < 2.0 and abs(float(r["focal2"]) - 1000.0) < 2.0
     assert abs(float(r["mean_radius"]) - 1.0) < 1e-12                       # Normalize(), src/sfm.cpp:549-559
-    # ---- replay the first Optimize() through the oracle
-    b = open(dump, "rb").read()
-    Nc, Np, K = struct.unpack_from("3i", b, 0); off = 12
-    M = Np * K
-    rec = np.frombuffer(b, dtype=np.dtype([("c", "<i4"), ("p", "<i4"), ("x", "<f8"), ("y", "<f8")]), count=M, offset=off); off += M * 24
-    def state(o):
-        cams = np.frombuffer(b, "<f8", Nc * 6, o).reshape(Nc, 6); o += Nc * 48
-        pts = np.frombuffer(b, "<f8", Np * 3, o).reshape(Np, 3); o += Np * 24
-        f = np.frombuffer(b, "<f8", 1, o)[0]; o += 8
-        return cams.copy(), pts.copy(), float(f), o
-    c0, p0, f0, off = state(off)
-    c1, p1, f1, off = state(off)
-    c2, p2, f2, off = state(off)                                            # after the first Retriangulate()
-    tf = np.ones(Nc, np.uint8); rf = np.zeros(Nc, np.uint8); rf[0] = 1
-    prob = synth.BAProblem(cameras=c0, points=p0, focal=f0, obs_xy=np.stack([rec["x"], rec["y"]], 1), obs_cam=rec["c"].astype(np.int32),
-                           obs_pt=rec["p"].astype(np.int32), rot_fixed=rf, trans_fixed=tf, pt_fixed=np.zeros(Np, np.uint8), focal_fixed=False,
-                           gt_cameras=c0, gt_points=p0, gt_focal=0.0)
-    oc, op, of, os_ = oracle.ba_solve(prob)
-    assert os_["iterations"] == int(r["it1"])
+    # ---- replay the first Optimize() and the Retriangulate() behind it through the oracle (every stage at config size: tests/test_pipeline_gpu.py)
+    from oracle import pipeline_chain as PC
+    d = PC.read_dump(dump)
+    (c1, p1, f1), (c2, p2, f2) = d["states"][1], d["states"][2]
+    (oc, op, of), info = PC.run_stage(oracle, d, d["states"][0], PC.OPT, False, False)
+    assert info["iterations"] == int(r["it1"]) == d["stages"][0]["iterations"]
     assert np.abs(c1 - oc).max() / np.abs(oc).max() <= 1e-5
     assert (np.linalg.norm(p1 - op, axis=1) / np.linalg.norm(op, axis=1)).max() <= 1e-5
-    assert abs(f1 - of) <= 1e-5 * of and abs(float(r["cost1"]) - os_["final_cost"]) <= 1e-8 * os_["final_cost"]
-    # ---- and the Retriangulate() that followed (src/sfm.cpp:156-192): same cameras, points re-estimated
+    assert abs(f1 - of) <= 1e-5 * of and abs(float(r["cost1"]) - info["cost"]) <= 1e-8 * info["cost"]
+    # Retriangulate (src/sfm.cpp:156-192): same cameras, points re-estimated -- the device replays the oracle's trace on identical inputs: the same points are
+    # zeroed and the others agree to 1e-9
     assert np.array_equal(c2, c1) and f2 == f1
-    prob1 = synth.BAProblem(cameras=c1, points=p1, focal=f1, obs_xy=prob.obs_xy, obs_cam=prob.obs_cam, obs_pt=prob.obs_pt, rot_fixed=rf, trans_fixed=tf,
-                            pt_fixed=prob.pt_fixed, focal_fixed=False, gt_cameras=c1, gt_points=p1, gt_focal=0.0)
-    Xo, nin = oracle.retriangulate(prob1)
-    rel = np.linalg.norm(p2 - Xo, axis=1) / np.linalg.norm(Xo, axis=1)
-    assert np.quantile(rel, 0.99) <= 1e-4 and np.median(rel) <= 1e-5
+    (_, Xo, _), _ = PC.run_stage(oracle, d, d["states"][1], PC.RETRI, False, False)
+    assert np.array_equal(~Xo.any(1), ~p2.any(1))
+    nz = Xo.any(1)
+    assert (np.linalg.norm(p2 - Xo, axis=1)[nz] / np.linalg.norm(Xo[nz], axis=1)).max() <= 1e-9
 
 
 def test_cpp_focal_search_wrapper(tmp_path):
