@@ -80,7 +80,7 @@ int run(int ncomp, int ncam, int b, int reps) {
         printf("%-24s chol %.1f us   back %.1f us   (per step %.2f / %.2f us)\n", tag, tc / reps * 1e3, tb / reps * 1e3, tc / reps * 1e3 / ncam, tb / reps * 1e3 / ncam);
         check(tag);
     };
-    for (int nw : {9}) {
+    for (int nw : {9, 10}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
         bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(nw, nw - 2 - CHOL2_LOADERS, nw - 2 - CHOL2_LOADERS)); },
               [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);

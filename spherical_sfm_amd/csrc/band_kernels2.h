@@ -207,6 +207,12 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     const int lw = wave - 1 - ntw;                          // loader index, valid when 0 <= lw < CHOL2_LOADERS
     // ---- phase B, shared by every role: panel X_k = A_k G^T and y_j = G y_j into LDS
     const int li = lane & 15, lk = lane >> 4;
+    // round 4: when every panel entry has a thread of its own (b BB <= threads: always in the shapes ba_handle.h launches) the entry's coordinates are the same in
+    // every step -- two integer divisions and the address arithmetic leave the step loop (a step is ~10 ticks per instruction on every wave: profiles/r04_notes.md)
+    const bool pb_own = b * BB <= nt;
+    const int pb_k = tid / BB, pb_rc = tid - pb_k * BB, pb_a = pb_rc / DC, pb_c = pb_rc - pb_a * DC;
+    const int pb_offA = (pb_k + 1) * BB + pb_a * DC;
+    const double* pb_G = sG + pb_c * DC;
     auto phaseB = [&](int j, int jm, int nb) {
         if constexpr ((MF & 1) != 0) {
             // panel X = A G^T, 16 window rows per wave: X(i, c) = sum_m A(i, m) G(c, m); tile rows 16 wave .. + 15, columns c = li < 6
@@ -224,6 +230,15 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) { const int row = 16 * wave + lk + 4 * q; if (row < nrow && li < DC) sP[row * DC + li] = acc[q]; }
+            }
+        } else if (pb_own) {
+            if (pb_k < nb) {
+                int sl = jm + 1 + pb_k; if (sl >= R) sl -= R;
+                const double* A = sWin + (size_t)sl * RW + pb_offA;
+                double x = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) x += A[m] * pb_G[m];
+                sP[tid] = x;
             }
         } else
         for (int e = tid; e < nb * BB; e += nt) {
@@ -361,12 +376,36 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                 }
                 lds_barrier();
             }
-        } else
+        } else {
+        // round 4: with one block task per lane (the shapes ba_handle.h launches) the lane's task is the same in every step: its pair (an LDS round trip on the
+        // dependent path of the phase), tile coordinates and operand offsets are fixed before the loop
+        const int own_t = ct + TPB, own_pr = min(own_t / TPB, b * (b + 1) / 2 - 1), own_sub = own_t - (own_t / TPB) * TPB;
+        const int own_pk = sPairs[own_pr], own_ir = own_pk & 0xffff, own_kr = own_pk >> 16;
+        const int own_a0 = (own_sub / TP) * TR, own_c0 = (own_sub - (own_sub / TP) * TP) * TR;
+        const double* own_Li = sP + (size_t)(own_ir - 1) * BB + own_a0 * DC;
+        const double* own_Lk = sP + (size_t)(own_kr - 1) * BB + own_c0 * DC;
+        const int own_dst = (own_ir - own_kr) * BB + own_a0 * DC + own_c0;
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
             lds_barrier();
             const int work = (nb * (nb + 1) / 2) * TPB;
+            auto block_task_own = [&]() {
+                double la[TR][DC], lk[TR][DC];
+#pragma unroll
+                for (int u = 0; u < TR; u++)
+#pragma unroll
+                    for (int m = 0; m < DC; m++) { la[u][m] = own_Li[u * DC + m]; lk[u][m] = own_Lk[u * DC + m]; }
+                int si = jm + own_ir; if (si >= R) si -= R;
+                double* dst = sWin + (size_t)si * RW + own_dst;
+#pragma unroll
+                for (int u = 0; u < TR; u++)
+#pragma unroll
+                    for (int w = 0; w < TR; w++) { double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
+                        dst[u * DC + w] -= v; }
+            };
             auto block_task = [&](int t) {
                 const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
                 const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
@@ -401,12 +440,13 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             // the block tasks AND right-hand-side tasks ran both bodies: 2.2k cycles against 1.5k for its neighbours, and the step waits for it)
             const int nblk = work - TPB, nrhs = nb * DC, wbk = (nblk + 63) & ~63;
             if (wbk + nrhs <= cw) {
-                if (ct < nblk) block_task(ct + TPB);
+                if (ct < nblk) block_task_own();
                 else if (ct >= wbk && ct - wbk < nrhs) rhs_task(ct - wbk);
             } else {
                 for (int t = ct + TPB; t < work + nrhs; t += cw) { if (t < work) block_task(t); else rhs_task(t - work); }
             }
             lds_barrier();
+        }
         }
     } else if (!is_writer) {
         // ---- loaders: together they bring in the row that enters the window (RW + NR*DC doubles), two steps ahead, in

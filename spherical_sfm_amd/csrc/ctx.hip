@@ -91,7 +91,13 @@ extern "C" int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on) {
 // grid-stride copy of 16-byte words (float4), `bytes` read + `bytes` written per launch; GBs_out = (2 x bytes) / average launch time over `reps` launches
 // (hipEvents on the context's stream, after two warm-up launches).  The buffers are larger than the 256 MB Infinity Cache when bytes >= 256 MB.
 static __global__ void __launch_bounds__(256) k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per lane before the first store
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 extern "C" int ssfm_debug_copy_bandwidth(ssfm_ctx* ctx, uint64_t bytes, int32_t reps, double* GBs_out) {
     if (!ctx || !GBs_out || bytes < 4096 || reps < 1) return fail(ctx, SSFM_ERR_INVALID, "ssfm_debug_copy_bandwidth: bad arguments");

@@ -45,17 +45,17 @@ ssfm_ctx* SfM::GetContext() {
 }
 
 int SfM::AddCamera(const Pose& pose, const std::string& path) {                               // src/sfm.cpp:99-111
-    nextCamera++; numCameras++;
+    nextCamera++; numCameras++; obs_cache.stale = true;
     cameras[nextCamera] = Camera{pose.t.v[0], pose.t.v[1], pose.t.v[2], pose.r.v[0], pose.r.v[1], pose.r.v[2]};
     paths[nextCamera] = path; rotationFixed[nextCamera] = false; translationFixed[nextCamera] = false;
     return nextCamera;
 }
-int SfM::AddPoint(const Point& X) { numPoints++; points[nextPoint] = X; pointFixed[nextPoint] = false; return nextPoint++; }   // src/sfm.cpp:113-127
+int SfM::AddPoint(const Point& X) { numPoints++; obs_cache.stale = true; points[nextPoint] = X; pointFixed[nextPoint] = false; return nextPoint++; }   // src/sfm.cpp:113-127
 int SfM::AddPoint(const Point& X, const std::array<unsigned char, 3>& color_bgr) { const int p = AddPoint(X); colors[p] = color_bgr; return p; }
 int SfM::AddPoint(const Point& X, const std::vector<float>& descriptor, const std::array<unsigned char, 3>& color_bgr) { const int p = AddPoint(X, color_bgr); descriptors[p] = descriptor; return p; }
 std::vector<float> SfM::GetDescriptor(int point) { auto it = descriptors.find(point); return it == descriptors.end() ? std::vector<float>() : it->second; }
 std::array<unsigned char, 3> SfM::GetColor(int point) { auto it = colors.find(point); return it == colors.end() ? std::array<unsigned char, 3>{0, 0, 0} : it->second; }
-void SfM::AddObservation(int camera, int point, const Observation& o) { observations[camera][point] = o; }                 // src/sfm.cpp:143-146
+void SfM::AddObservation(int camera, int point, const Observation& o) { observations[camera][point] = o; obs_cache.stale = true; }                 // src/sfm.cpp:143-146
 bool SfM::GetObservation(int camera, int point, Observation& o) {
     auto r = observations.find(camera); if (r == observations.end()) return false;
     auto c = r->second.find(point); if (c == r->second.end()) return false;
@@ -67,6 +67,7 @@ bool SfM::GetMeasurement(int i, int j, Pose& m) {                               
     m = c->second; return true;
 }
 void SfM::MergePoint(int point1, int point2) {                                                // src/sfm.cpp:129-141
+    obs_cache.stale = true;
     for (auto& row : observations) {
         if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;
         auto it = row.second.find(point2);
@@ -75,10 +76,12 @@ void SfM::MergePoint(int point1, int point2) {                                  
     RemovePoint(point2);
 }
 void SfM::RemovePoint(int point) {                                                            // src/sfm.cpp:435-444
+    obs_cache.stale = true;
     for (auto& row : observations) if (row.first >= 0 && row.first < numCameras) row.second.erase(point);
     points.erase(point); colors.erase(point); descriptors.erase(point);
 }
 void SfM::RemoveCamera(int camera) {                                                          // src/sfm.cpp:446-461
+    obs_cache.stale = true;
     cameras.erase(camera); observations.erase(camera);
     for (int j = 0; j < numPoints; j++) {
         bool seen = false;
@@ -90,35 +93,57 @@ Pose SfM::GetPose(int camera) {
     auto it = cameras.find(camera); if (it == cameras.end()) return Pose();
     const Camera& c = it->second; return Pose(Vec3(c[0], c[1], c[2]), Vec3(c[3], c[4], c[5]));
 }
-void SfM::SetPose(int camera, const Pose& p) { cameras[camera] = Camera{p.t.v[0], p.t.v[1], p.t.v[2], p.r.v[0], p.r.v[1], p.r.v[2]}; }
+void SfM::SetPose(int camera, const Pose& p) {
+    auto it = cameras.find(camera); const Camera c{p.t.v[0], p.t.v[1], p.t.v[2], p.r.v[0], p.r.v[1], p.r.v[2]};
+    if (it == cameras.end()) { obs_cache.stale = true; cameras[camera] = c; } else it->second = c;      // a NEW key changes which observations count
+}
 Point SfM::GetPoint(int point) { auto it = points.find(point); return it == points.end() ? Point(0, 0, 0) : it->second; }
-void SfM::SetPoint(int point, const Point& X) { points[point] = X; }
+void SfM::SetPoint(int point, const Point& X) { auto it = points.find(point); if (it == points.end()) { obs_cache.stale = true; points[point] = X; } else it->second = X; }
 
 // dense index spaces [0,numCameras) x [0,numPoints) as the reference's loops use them; absent entries stay absent
 void SfM::Flatten(FlatProblem& F) {
     F.cam.assign((size_t)numCameras * 6, 0.0); F.pts.assign((size_t)numPoints * 3, 0.0);
     F.rf.assign(numCameras, 1); F.tf.assign(numCameras, 1); F.pf.assign(numPoints, 0);
-    F.xy.clear(); F.oc.clear(); F.op.clear();
+    std::vector<char> cam_ok(numCameras, 0), pt_ok(numPoints, 0);                             // dense existence masks: one map walk instead of a lookup per observation
     for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) {
         for (int k = 0; k < 6; k++) F.cam[(size_t)kv.first * 6 + k] = kv.second[k];
-        F.rf[kv.first] = rotationFixed[kv.first]; F.tf[kv.first] = translationFixed[kv.first];
+        cam_ok[kv.first] = 1;
     }
+    for (auto& kv : rotationFixed) if (kv.first >= 0 && kv.first < numCameras && cam_ok[kv.first]) F.rf[kv.first] = kv.second;
+    for (auto& kv : translationFixed) if (kv.first >= 0 && kv.first < numCameras && cam_ok[kv.first]) F.tf[kv.first] = kv.second;
+    for (int c = 0; c < numCameras; c++) if (cam_ok[c]) { if (!rotationFixed.count(c)) F.rf[c] = 0; if (!translationFixed.count(c)) F.tf[c] = 0; }   // (operator[] of the flags: absent = false)
     for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) {
         for (int k = 0; k < 3; k++) F.pts[(size_t)kv.first * 3 + k] = kv.second.v[k];
-        F.pf[kv.first] = pointFixed[kv.first];
+        pt_ok[kv.first] = 1;
     }
-    for (auto& row : observations) {
-        if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;   // src/sfm.cpp:249 / :167
-        for (auto& kv : row.second) {
-            if (kv.first < 0 || kv.first >= numPoints || !points.count(kv.first)) continue;     // src/sfm.cpp:242 / :161
-            F.xy.push_back(kv.second.x); F.xy.push_back(kv.second.y); F.oc.push_back(row.first); F.op.push_back(kv.first);
+    for (auto& kv : pointFixed) if (kv.first >= 0 && kv.first < numPoints && pt_ok[kv.first]) F.pf[kv.first] = kv.second;
+    ObsCache& C = obs_cache;
+    if (C.stale) {
+        // counting sort by point over the camera-major maps: rows come in ascending camera order and every row in ascending point order, so the observations of a
+        // point land in ascending camera order -- exactly the order the reference's build loop visits them in (src/sfm.cpp:240-263)
+        std::vector<int64_t> start((size_t)numPoints + 1, 0);
+        for (auto& row : observations) {
+            if (row.first < 0 || row.first >= numCameras || !cam_ok[row.first]) continue;      // src/sfm.cpp:249 / :167
+            for (auto& kv : row.second) if (kv.first >= 0 && kv.first < numPoints && pt_ok[kv.first]) start[(size_t)kv.first + 1]++;   // src/sfm.cpp:242 / :161
         }
+        for (int j = 0; j < numPoints; j++) start[(size_t)j + 1] += start[j];
+        const size_t M = (size_t)start[numPoints];
+        C.xy.resize(2 * M); C.oc.resize(M); C.op.resize(M);
+        for (auto& row : observations) {
+            if (row.first < 0 || row.first >= numCameras || !cam_ok[row.first]) continue;
+            for (auto& kv : row.second) {
+                if (kv.first < 0 || kv.first >= numPoints || !pt_ok[kv.first]) continue;
+                const size_t w = (size_t)start[kv.first]++;
+                C.xy[2 * w] = kv.second.x; C.xy[2 * w + 1] = kv.second.y; C.oc[w] = row.first; C.op[w] = kv.first;
+            }
+        }
+        C.stale = false;
     }
     GetContext();
     ssfm_ba_problem& P = F.P;
-    P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)F.oc.size();
+    P.num_cameras = numCameras; P.num_points = numPoints; P.num_observations = (int64_t)C.oc.size();
     P.cameras = F.cam.data(); P.points = F.pts.data(); P.focal = &intrinsics.focal;
-    P.obs_xy = F.xy.data(); P.obs_cam = F.oc.data(); P.obs_pt = F.op.data();
+    P.obs_xy = C.xy.data(); P.obs_cam = C.oc.data(); P.obs_pt = C.op.data();
     P.rot_fixed = F.rf.data(); P.trans_fixed = F.tf.data(); P.pt_fixed = F.pf.data(); P.focal_fixed = focalFixed ? 1 : 0;
 }
 
@@ -154,19 +179,17 @@ bool SfM::Optimize() {
 void SfM::Apply(const Pose& pose) {                                                           // src/sfm.cpp:341-362
     Pose inv = pose.inverse();
     for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); c.postMultiply(inv); SetPose(i, c); }
-    for (int j = 0; j < numPoints; j++) {
-        if (!points.count(j)) continue;
-        Point X = GetPoint(j); if (X.norm() == 0) continue;
-        SetPoint(j, pose.apply(X));
+    // (the reference probes j = 0 .. numPoints-1 with exists(): the same points in the same order as walking the map)
+    for (auto& kv : points) {
+        if (kv.first < 0 || kv.first >= numPoints || kv.second.norm() == 0) continue;
+        kv.second = pose.apply(kv.second);
     }
 }
 void SfM::Apply(double scale) {                                                               // src/sfm.cpp:364-382
     for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); for (int k = 0; k < 3; k++) c.t.v[k] *= scale; SetPose(i, c); }
-    for (int j = 0; j < numPoints; j++) {
-        if (!points.count(j)) continue;
-        Point X = GetPoint(j); if (X.norm() == 0) continue;
-        for (int k = 0; k < 3; k++) X.v[k] *= scale;
-        SetPoint(j, X);
+    for (auto& kv : points) {
+        if (kv.first < 0 || kv.first >= numPoints || kv.second.norm() == 0) continue;
+        for (int k = 0; k < 3; k++) kv.second.v[k] *= scale;
     }
 }
 void SfM::Unapply(const Pose& pose) {                                                         // src/sfm.cpp:384-402
@@ -298,6 +321,7 @@ void SfM::WriteCalib(const std::string& path) {                                 
 // src/sfm.cpp:297-339 -- the removals of a point do not depend on each other, so instead of probing every (point, camera) key this counts
 // the observations of all points in one sweep over the sparse rows and tests them in a second one.
 void SfM::FilterObservations(double thresh) {
+    obs_cache.stale = true;
     std::vector<int> seen(numPoints, 0);
     auto usable_row = [&](int cam) { return cam >= 0 && cam < numCameras && cameras.count(cam) != 0; };
     for (const auto& row : observations)

@@ -64,8 +64,12 @@ protected:
     ssfm_ctx* ctx;                        // created on first Optimize()
     ssfm_ba_summary last_summary;
     struct FlatProblem {                  // the flat arrays the C ABI takes + the struct pointing at them
-        std::vector<double> cam, pts, xy; std::vector<int32_t> oc, op; std::vector<uint8_t> rf, tf, pf; ssfm_ba_problem P;
+        std::vector<double> cam, pts; std::vector<uint8_t> rf, tf, pf; ssfm_ba_problem P;
     };
+    // The observation arrays of the flat problem, point-major / cameras ascending (what ssfm_ba_solve plans fastest: no sort), kept between calls: the drivers call
+    // Optimize / Retriangulate up to six times on one observation set, and walking a million std::map nodes per call cost more than the solve itself
+    // (bench.py side_paths.pipeline_configs2).  Any call that changes which cameras, points or observations exist marks them stale.
+    struct ObsCache { std::vector<double> xy; std::vector<int32_t> oc, op; bool stale = true; } obs_cache;
     void Flatten(FlatProblem& F);
 public:
     explicit SfM(const Intrinsics& _intrinsics);

@@ -1,6 +1,7 @@
 """Worker for tests/test_multirank_gpu.py: one rank of a point-sharded bundle adjustment.
 mode 'host': N ranks share GPU 0, reductions go through the host all-reduce hook (gloo).
-mode 'rccl1': one rank with a forced 1-rank RCCL communicator (SSFM_COMM_SINGLE_RANK=1) - exercises ncclAllReduce on the solver stream."""
+mode 'rccl1': one rank with a forced 1-rank RCCL communicator (SSFM_COMM_SINGLE_RANK=1) - exercises ncclAllReduce on the solver stream.
+mode 'rccl': N ranks on N GPUs with a real N-rank RCCL communicator (needs >= N visible GPUs: the tests skip otherwise)."""
 import os
 import sys
 
@@ -19,8 +20,8 @@ def main():
         prob = synth.make_circle(600, 24000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
     else:
         prob = synth.make_circle(60, 6000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
-    ctx = ba.Context(0)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    ctx = ba.Context(rank if mode == "rccl" else 0)         # 'rccl': one GPU per rank, the real multi-GPU layout
     if mode == "host":
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,6 +31,13 @@ def main():
         ctx.comm_init_host(world, rank, hook)
     elif mode == "rccl1":
         ctx.comm_init(ba.Context.unique_id(), 1, 0)
+    elif mode == "rccl":
+        # N ranks on N GPUs, reductions by ncclAllReduce over xGMI: the id travels through gloo like bench.py's does through torch.distributed
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [ba.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], world, rank)
     if len(sys.argv) > 5 and sys.argv[5] == "ransac":
         # ssfm_ransac_batch_sharded: every rank passes the same ragged pair list (one pair below the minimal sample size)
         from spherical_sfm_amd import ransac
@@ -38,7 +46,7 @@ def main():
         o = ransac.estimate_pairs(ctx, pairs, (2 / 600) ** 2, sharded=True, min_num_inliers=12, num_hypotheses=256, mode=int(os.environ.get("RANSAC_MODE", "1")))
         np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=np.concatenate(o["inliers"]),
                  iterations=o["iterations"], lo_runs=o["lo_runs"])
-        if mode == "host":
+        if mode in ("host", "rccl"):
             dist.barrier(); dist.destroy_process_group()
         return
     if len(sys.argv) > 5 and sys.argv[5] == "ransac_indexed":
@@ -48,13 +56,13 @@ def main():
         a = _pairwise_frames.indexed_problem()
         o = ransac.estimate_indexed(ctx, *a, (2 / 600) ** 2, sharded=True, min_num_inliers=12)
         np.savez(out + f".{rank}.npz", E=o["E"], R=o["R"], num_inliers=o["num_inliers"], scores=o["scores"], mask=o["mask"], iterations=o["iterations"], lo_runs=o["lo_runs"])
-        if mode == "host":
+        if mode in ("host", "rccl"):
             dist.barrier(); dist.destroy_process_group()
         return
     cams, pts, focal, summ = ba.optimize(ctx, prob)
     np.savez(out + f".{rank}.npz", cams=cams, pts=pts, focal=focal, iterations=summ["iterations"], final_cost=summ["final_cost"],
              initial_cost=summ["initial_cost"], termination=summ["termination"])
-    if mode == "host":
+    if mode in ("host", "rccl"):
         dist.barrier(); dist.destroy_process_group()
 
 
