@@ -151,7 +151,7 @@ def side_paths(ctx):
         correspondences, 30 % outliers -- host buffers in, results out (PCIe inclusive);
       * optimize_rotations (src/rotation_averaging.cpp:52-103) on the 300-camera graph of SURVEY 8d."""
     import numpy as np
-    from spherical_sfm_amd import synth, ransac, rotavg
+    from spherical_sfm_amd import ba, synth, ransac, rotavg
     from oracle import oracle as O
     res = {}
     F = 1000.0; THR = (2 / F) ** 2; NC = 500; POOL = 256; P = 16384
@@ -182,6 +182,37 @@ def side_paths(ctx):
     res["rotation_averaging"] = {"workload": f"optimize_rotations, 300 cameras, {len(i0)} edges, SoftLOne(0.03)", "value": 1e3 * dt, "unit": "ms per call", "higher_is_better": False,
                                  "iterations": sg.get("iterations"), "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the same graph"},
                                  "parity_vs_oracle": {"max_rotation_error_rad": err, "iterations_cpu": sc.get("iterations")}}
+    # ---- irregular structure: 300 cameras, 600k observations, RAGGED tracks of 3..14 (and 3..8) consecutive frames, point ids in build_sfm's
+    # order (examples/spherical_sfm_tools.cpp:862-955; synth.make_ragged_circle).  Reports what the same LM loop does when the synthetic circle's regularity is gone:
+    # grouped fraction (planner: signature sort + cost model), obs/s, where the time goes, parity and the CPU port beside it.
+    res["ba_irregular"] = {}
+    for max_len in (14, 8):
+        prob = synth.make_ragged_circle(300, 600000, 3, max_len)
+        info, _, _, _ = ba.plan(prob)
+        adj = ba.BundleAdjuster(ctx, prob)
+        adj.reset(); adj.run()
+        t = time.perf_counter(); n = 0
+        for _ in range(3):
+            adj.reset(); sa = adj.run(); n += sa["num_linearizations"]
+        dt = time.perf_counter() - t
+        adj.set_profiling(True); adj.reset(); sp_ = adj.run(); kt = adj.kernel_times(); adj.set_profiling(False)
+        cg, pg, _ = [np.copy(a) if hasattr(a, "copy") else a for a in adj.download()]
+        adj.close()
+        t = time.perf_counter(); oc, op, of, os_ = O.ba_solve(prob); tcpu = time.perf_counter() - t
+        tot = sum(v["total_ms"] for v in kt.values()) or 1.0
+        res["ba_irregular"][f"tracks_3_to_{max_len}"] = {
+            "workload": f"300 cameras x {len(prob.points)} points x {len(prob.obs_cam)} observations, tracks of 3..{max_len} consecutive frames, general BA, focal fixed",
+            "value": len(prob.obs_cam) * n / dt, "unit": "obs/s", "ms_per_lm_iteration": 1e3 * dt / n, "lm_iterations": sa["iterations"],
+            "grouped_fraction_of_observations": info["num_observations_grouped"] / max(1, info["num_observations_used"]),
+            "band_half_width": info["band_half_width"], "band_segments": info["band_segments"], "band_separators": info["band_separators"],
+            "share_of_gpu_time": {k: v["total_ms"] / tot for k, v in kt.items() if v["launches"]},
+            "avg_us": {k: 1e3 * v["total_ms"] / v["launches"] for k, v in kt.items() if v["launches"]},
+            "cpu_baseline": {"value": os_["num_residual_blocks"] * os_["num_linear_solves"] / (os_["t_total_s"] - os_["t_flatten_s"]), "unit": "obs/s", "cores": os_["threads_used"], "kind": "port",
+                             "sample": "the same problem, one solve", "wall_s": tcpu},
+            "parity_vs_oracle": {"max_rel_camera": float(np.abs(cg - oc).max() / np.abs(oc).max()),
+                                 "max_rel_point": float((np.linalg.norm(pg - op, axis=1) / np.linalg.norm(op, axis=1)).max()), "iterations_cpu": os_["iterations"]},
+            "note": "one connected ring of 300 cameras: the reduced system's band is 2 x (longest track - 1) wide; beyond half-width 21 the LDS-resident factorisation does not "
+                    "fit and the global-memory kernel runs (DESIGN.md 4 / 7)"}
     # ---- the drivers' whole stage sequence at BASELINE configs[2] size (500 frames / 170 000 points / 1.02 M observations, shared focal free, -generalba):
     # Optimize -> Retriangulate -> Optimize -> unfix t -> Optimize -> Normalize -> Retriangulate -> Optimize -> Normalize (examples/run_spherical_sfm_uncalib.cpp:176-222)
     # through the C++ mirror (spherical_sfm_amd/demo_circle = shim/demo_circle.cpp, its own process and context), wall per stage as the driver sees it (flatten +

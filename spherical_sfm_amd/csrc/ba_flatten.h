@@ -715,6 +715,30 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 if (e - q >= min_run && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
                 q = e;
             }
+            // Round 4: do the groups pay?  k_schur_gram is launched once per tile class (rows = DC K: {3}, {4, 5}, {6}, {7, 8} at 6 dof), and a launch of a few hundred
+            // wave tasks costs its ~24 us latency floor whatever it holds: 300 cameras / 600k observations with tracks of 3..8 frames, sorted into 1800 signatures
+            // of ~60 points, took 4 x 25 us through the groups against 44 + 21 us through the pair lists (scripts/prof_irregular.py, profiles/r04_notes.md).
+            // Estimated launch times from the measurements of rounds 3-4 (us): a class max(24, 0.45e-3 points K / 6); pair lists max(36, 22e-6 pairs) + camera sums
+            // max(20, 34.5e-6 observations).  The groups are kept when their estimate (+ the pair path for what stays loose) is below the pair path for everything.
+            // SSFM_GRAM_MODEL=0 keeps every group that qualifies.
+            if (!(std::getenv("SSFM_GRAM_MODEL") && std::atoi(std::getenv("SSFM_GRAM_MODEL")) == 0) && !runs.empty()) {
+                double cls_pts[4 * 2 * 8] = {0}; double all_pairs = 0, loose_pairs = 0;
+                for (int q = 0; q < F.nP; q++) { const double k = F.pt_start[q + 1] - F.pt_start[q]; all_pairs += 0.5 * k * (k - 1); }
+                double grouped_pairs = 0;
+                for (size_t r = 0; r < runs.size(); r += 2) {
+                    const int K = F.pt_start[runs[r] + 1] - F.pt_start[runs[r]], rows = F.DC * K, nt_full = rows / 16, tail = rows - 16 * nt_full;
+                    const int cls = (tail > 0 && tail <= 4 && nt_full >= 1) ? 8 + nt_full : (rows + 15) / 16;      // tile class = launch (ba_solver.hip)
+                    cls_pts[cls] += (double)(runs[r + 1] - runs[r]) * K / 6.0;
+                    grouped_pairs += 0.5 * K * (K - 1) * (runs[r + 1] - runs[r]);
+                }
+                loose_pairs = all_pairs - grouped_pairs;
+                double est_gram = 0; for (double v : cls_pts) if (v > 0) est_gram += std::max(24.0, 0.45e-3 * v);
+                const double obs_all = (double)F.pt_start[F.nP];
+                const double est_loose = loose_pairs > 0 ? std::max(36.0, 22e-6 * loose_pairs) + std::max(20.0, 34.5e-6 * obs_all) : 0.0;
+                const double est_pairs_only = std::max(36.0, 22e-6 * all_pairs) + std::max(20.0, 34.5e-6 * obs_all);
+                if (timing) std::fprintf(stderr, "[plan] group model: groups %.0f us + loose %.0f us against pair lists only %.0f us\n", est_gram, est_loose, est_pairs_only);
+                if (est_gram + est_loose > est_pairs_only) { runs.clear(); F.gram_points = 0; F.gram_obs = 0; }
+            }
             // points per wave task: a task pays ~5 us of start-up (index loads, camera records, the atomics of its blocks at the end) whatever its length, and
             // the chip holds ~2300 of these waves at once: two rounds' worth of tasks when the problem is small, 192 points when it is large
             // (measured: 100 000 points 64 -> 39.5 us, 128 -> 41, 192 -> 54; 1.5 M points 64 -> 560 us, 128 -> 453, 192 -> 434)

@@ -90,15 +90,18 @@ extern "C" int ssfm_debug_timing_skip_collectives(ssfm_ctx* ctx, int32_t on) {
 // ---- measured device copy bandwidth: the denominator SURVEY.md 8d asks for next to the nominal 8 TB/s ----
 // grid-stride copy of 16-byte words (float4), `bytes` read + `bytes` written per launch; GBs_out = (2 x bytes) / average launch time over `reps` launches
 // (hipEvents on the context's stream, after two warm-up launches).  The buffers are larger than the 256 MB Infinity Cache when bytes >= 256 MB.
+template <int INFLIGHT>
 static __global__ void __launch_bounds__(256) k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per lane before the first store
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
+    if (INFLIGHT == 4)
+        for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads in flight per lane before the first store
+            const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
+// best of a few launch shapes (blocks per CU x loads in flight) and of the runtime's own device-to-device copy: the figure is a property of the box, not of one shape
 extern "C" int ssfm_debug_copy_bandwidth(ssfm_ctx* ctx, uint64_t bytes, int32_t reps, double* GBs_out) {
     if (!ctx || !GBs_out || bytes < 4096 || reps < 1) return fail(ctx, SSFM_ERR_INVALID, "ssfm_debug_copy_bandwidth: bad arguments");
     SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -107,14 +110,23 @@ extern "C" int ssfm_debug_copy_bandwidth(ssfm_ctx* ctx, uint64_t bytes, int32_t 
         SSFM_HIP_CHECK(ctx, hipMalloc((void**)&a, n16 * 16)); SSFM_HIP_CHECK(ctx, hipMalloc((void**)&b, n16 * 16));
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(a, 1, n16 * 16, ctx->stream)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(b, 0, n16 * 16, ctx->stream));
         SSFM_HIP_CHECK(ctx, hipEventCreate(&e0)); SSFM_HIP_CHECK(ctx, hipEventCreate(&e1));
-        const int grid = ctx->num_cus * 16;
-        for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
-        SSFM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
-        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
-        SSFM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); SSFM_HIP_CHECK(ctx, hipGetLastError());
-        float ms = 0; SSFM_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
-        *GBs_out = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+        double best = 0.0;
+        for (int shape = 0; shape < 9; shape++) {
+            const int per_cu[4] = {8, 16, 32, 64}; const int grid = ctx->num_cus * per_cu[shape % 4]; const bool four = shape >= 4 && shape < 8;
+            auto go = [&]() {
+                if (shape == 8) (void)hipMemcpyAsync(b, a, n16 * 16, hipMemcpyDeviceToDevice, ctx->stream);
+                else if (four) hipLaunchKernelGGL(k_copy16<4>, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+                else hipLaunchKernelGGL(k_copy16<1>, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+            };
+            go();
+            SSFM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+            for (int r = 0; r < reps; r++) go();
+            SSFM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+            SSFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); SSFM_HIP_CHECK(ctx, hipGetLastError());
+            float ms = 0; SSFM_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+            best = std::max(best, 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9);
+        }
+        *GBs_out = best;
         return SSFM_OK;
     };
     const int rc = body();

@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
         }
     }
     dump_state();
+    sfm.GetContext();                                                                         // library / HIP start-up is not a stage of the pipeline
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto optimize = [&]() { const double t0 = now(); const bool ok = sfm.Optimize(); stage(0, sfm.LastSummary().iterations, ok, sfm.LastSummary().final_cost, now() - t0); return ok; };
     auto retriangulate = [&]() { const double t0 = now(); sfm.Retriangulate(); stage(1, 0, true, 0.0, now() - t0); };
