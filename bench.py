@@ -182,6 +182,27 @@ def side_paths(ctx):
     res["rotation_averaging"] = {"workload": f"optimize_rotations, 300 cameras, {len(i0)} edges, SoftLOne(0.03)", "value": 1e3 * dt, "unit": "ms per call", "higher_is_better": False,
                                  "iterations": sg.get("iterations"), "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the same graph"},
                                  "parity_vs_oracle": {"max_rotation_error_rad": err, "iterations_cpu": sc.get("iterations")}}
+    # ---- SfM::Retriangulate (src/sfm.cpp:156-192) on its own: the trace-replay kernel at the config-2 size, the oracle on 16 threads beside it.  The kernel is one lane
+    # per point and latency bound (1563 waves for 1024 SIMDs); its VALU-issue fraction comes from a committed PMC pass like the headline kernel's.
+    pr = synth.make_circle(300, 100000, 6, rot_noise_deg=0.0, pixel_noise=0.5)
+    ba.retriangulate(ctx, pr)
+    t = time.perf_counter(); Xg, ning = ba.retriangulate(ctx, pr); dt = time.perf_counter() - t
+    t = time.perf_counter(); Xe, _ = ba.retriangulate(ctx, pr, mode=ba.RETRI_MODE_ENUMERATE); dte = time.perf_counter() - t
+    t = time.perf_counter(); Xo, nino = O.retriangulate(pr, 16); tc = time.perf_counter() - t
+    nz = Xo.any(1)
+    pmc_r = {}
+    try:
+        pmc_r = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_retriangulate.json")))
+    except Exception:
+        pass
+    res["retriangulate"] = {
+        "workload": "300 cameras x 100 000 points x 6 observations, per-point LO-MSAC of the reference replayed draw for draw (ssfm_retriangulate, trace mode)",
+        "value": 1e3 * dt, "unit": "ms per call (host buffers in, points out)", "higher_is_better": False, "points_per_s": 100000 / dt,
+        "enumerate_mode_ms": 1e3 * dte,
+        "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 16, "kind": "port", "sample": "the same 100 000 points"},
+        "parity_vs_oracle": {"identical_zero_sets": bool(np.array_equal(nz, Xg.any(1))), "identical_inlier_counts": bool(np.array_equal(ning, nino)),
+                             "max_rel_point": float((np.linalg.norm(Xg - Xo, axis=1)[nz] / np.linalg.norm(Xo[nz], axis=1)).max())},
+        "valu_issue": pmc_r or {"note": "no committed PMC pass found (profiles/r04_pmc_retriangulate.json)"}}
     # ---- irregular structure: 300 cameras, 600k observations, RAGGED tracks of 3..14 (and 3..8) consecutive frames, point ids in build_sfm's
     # order (examples/spherical_sfm_tools.cpp:862-955; synth.make_ragged_circle).  Reports what the same LM loop does when the synthetic circle's regularity is gone:
     # grouped fraction (planner: signature sort + cost model), obs/s, where the time goes, parity and the CPU port beside it.

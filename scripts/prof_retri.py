@@ -1,4 +1,4 @@
-"""Retriangulate at config-2 size under rocprofv3 / plain timing: trace mode (default) and the enumerating kernel (SSFM_RETRI_ENUMERATE=1).
+"""Retriangulate at config-2 size under rocprofv3 / plain timing: trace mode (default) and the enumerating kernel (ssfm_retriangulate_mode).
 usage: python scripts/prof_retri.py [Nc Np K] [repeats]"""
 import os, sys, time
 import numpy as np
@@ -10,12 +10,11 @@ prob = synth.make_circle(Nc, Np, K, rot_noise_deg=0.0, pixel_noise=0.5, seed=3)
 synth.corrupt_observations(prob, 0.1, seed=5)
 ctx = ba.Context(0)
 for mode in ("trace", "enumerate"):
-    if mode == "enumerate":
-        os.environ["SSFM_RETRI_ENUMERATE"] = "1"
-    ba.retriangulate(ctx, prob)
+    m = ba.RETRI_MODE_ENUMERATE if mode == "enumerate" else ba.RETRI_MODE_TRACE
+    ba.retriangulate(ctx, prob, mode=m)
     ts = []
     for _ in range(rep):
-        t0 = time.perf_counter(); X, n = ba.retriangulate(ctx, prob); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); X, n = ba.retriangulate(ctx, prob, mode=m); ts.append(time.perf_counter() - t0)
     print(f"{mode}: {Np} points x {K} observations: {min(ts) * 1e3:.1f} ms end to end (host lists + upload + kernel + download), nonzero {X.any(1).sum()}")
 if os.environ.get("CHECK", "1") != "0":
     from oracle import oracle as O

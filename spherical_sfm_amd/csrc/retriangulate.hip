@@ -910,7 +910,11 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
             SSFM_HIP_CHECK(ctx, upload(D.dW, W, st));
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(D.dovf.p, 0, sizeof(int), st));
             if (inlier_flags_out) SSFM_HIP_CHECK(ctx, hipMemsetAsync(D.dflags.p, 0, (size_t)std::max(total, 1), st));
-            const char* ew = getenv("SSFM_RETRI_WAVES"); const int waves = ew ? atoi(ew) : 2;        // measured: 32.8 / 23.4 / 25.1 ms at 1 / 2 / 3 waves per SIMD (100k points x 6)
+            // register budget in waves per SIMD.  Measured at 100k points x 6 (1563 waves, one round either way): 32.8 / 23.4 / 25.1 ms at 1 / 2 / 3.  Two waves per
+            // SIMD hold 8 x CUs = 2048 waves at once; a problem with more (BASELINE configs[2]: 170k points = 2657 waves) would run a second, mostly empty round at
+            // two, but still fits one round at three (3072) -- and at sizes of many rounds three has the higher throughput (122 against 88 waves per ms).
+            const char* ew = getenv("SSFM_RETRI_WAVES");
+            const int waves = ew ? atoi(ew) : (((Np + 63) / 64 <= 8 * ctx->num_cus) ? 2 : 3);
 #define SSFM_RETRI_LAUNCH(K) hipLaunchKernelGGL(K, dim3((Np + 63) / 64), dim3(64), 0, st, D.dct.p, D.df.p, reinterpret_cast<const double2*>(D.dxy.p), D.dcamidx.p, D.dps.p, Np, \
                                            D.dorder.p, o, D.dslot.p, D.dsamples.p, D.dreqptr.p, D.dreq.p, D.dW.p, (int)LW, D.dlists.p, D.dpts.p, D.dnin.p,                \
                                            stats_out ? D.dstats.p : nullptr, inlier_flags_out ? D.dflags.p : nullptr, D.dovf.p)

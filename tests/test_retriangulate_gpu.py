@@ -6,7 +6,7 @@ from libstdc++'s generators on the host, the device walks RansacLib's control fl
 times and starts a local optimisation whenever a score is lower than the best by ANY margin, so the replay only works if the minimal solver and the
 scoring round every operation like the CPU: both sides are compiled without fused multiply-adds and sum in one documented order, and these tests
 compare the pieces for EQUALITY (==), then the whole run: identical iteration counts, local-optimisation runs, inlier sets, points <= 1e-9.
-The enumerating kernel of rounds 1-2 (SSFM_RETRI_ENUMERATE=1) keeps its statistical comparison at the end of the file."""
+The enumerating kernel of rounds 1-2 (ssfm_retriangulate_mode, SSFM_RETRI_MODE_ENUMERATE) keeps its statistical comparison at the end of the file."""
 import dataclasses
 
 import numpy as np
@@ -191,13 +191,15 @@ def test_small_random_stream_table_is_extended(oracle, gpu_ctx, monkeypatch):
     assert np.array_equal(X0, X1) and np.array_equal(n0, n1)
 
 
-def test_enumerating_mode_agrees_statistically(oracle, gpu_ctx, monkeypatch):
-    """SSFM_RETRI_ENUMERATE=1: the kernel of rounds 1-2 (every pair once, no random stream)"""
+def test_enumerating_mode_agrees_statistically(oracle, gpu_ctx):
+    """ssfm_retriangulate_mode(SSFM_RETRI_MODE_ENUMERATE): the kernel of rounds 1-2 (every pair once, no random stream) -- a different result from the trace
+    replay (asserted: otherwise this test would be running the wrong kernel), statistically the same reconstruction"""
     prob = synth.make_circle(60, 2000, 6, rot_noise_deg=0.0, pixel_noise=0.5, seed=3)
     synth.corrupt_observations(prob, 0.1, seed=5)
     Xo, no = oracle.retriangulate(prob, 16)
-    monkeypatch.setenv("SSFM_RETRI_ENUMERATE", "1")
-    Xg, ng = ba.retriangulate(gpu_ctx, prob)
+    Xg, ng = ba.retriangulate(gpu_ctx, prob, mode=ba.RETRI_MODE_ENUMERATE)
+    Xt, _ = ba.retriangulate(gpu_ctx, prob, mode=ba.RETRI_MODE_TRACE)
+    assert not np.array_equal(Xg, Xt) and np.array_equal(Xt, ba.retriangulate(gpu_ctx, prob)[0])          # the default is the trace replay
     zg, zo = ~Xg.any(1), ~Xo.any(1)
     assert (zg != zo).mean() <= 1e-3 and (ng == no).mean() >= 0.99
     both = ~zg & ~zo & (ng == no)
