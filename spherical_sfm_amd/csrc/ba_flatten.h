@@ -508,12 +508,18 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         const int force = e_gs ? std::atoi(e_gs) : -1;
         bool do_sort = force == 1;
         if (force < 0 && s1 - s0 >= 2 * (size_t)GRAM_MIN_RUN) {
-            int64_t could = 0, adjacent = 0;
-            for (size_t k = s0; k < s1;) {
-                size_t e = k + 1; while (e < s1 && segs[e].sig == segs[k].sig && segs[e].nobs == segs[k].nobs) e++;
-                if (segs[k].nobs <= GRAM_KMAX) { could += (int64_t)(e - k); if (e - k >= (size_t)GRAM_MIN_RUN) adjacent += (int64_t)(e - k); }
-                k = e;
-            }
+            // (a heuristic: every planner thread looks at its own chunk, a run that crosses a chunk border counts as two)
+            std::vector<int64_t> could_t(NT, 0), adj_t(NT, 0);
+            parallel_chunks((int64_t)(s1 - s0), NT, [&](int t, int64_t q0, int64_t q1) {
+                int64_t could = 0, adjacent = 0;
+                for (size_t k = s0 + (size_t)q0, end = s0 + (size_t)q1; k < end;) {
+                    size_t e = k + 1; while (e < end && segs[e].sig == segs[k].sig && segs[e].nobs == segs[k].nobs) e++;
+                    if (segs[k].nobs <= GRAM_KMAX) { could += (int64_t)(e - k); if (e - k >= (size_t)GRAM_MIN_RUN) adjacent += (int64_t)(e - k); }
+                    k = e;
+                }
+                could_t[t] += could; adj_t[t] += adjacent;
+            });
+            int64_t could = 0, adjacent = 0; for (int t = 0; t < NT; t++) { could += could_t[t]; adjacent += adj_t[t]; }
             do_sort = could > 0 && adjacent * 10 < could * 9;
         }
         if (do_sort) {
@@ -527,8 +533,15 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                     std::stable_sort(tmp.begin() + bucket_ptr[c], tmp.begin() + bucket_ptr[c + 1],
                                      [](const Seg& a, const Seg& b2) { return a.nobs != b2.nobs ? a.nobs < b2.nobs : a.sig < b2.sig; });
             });
-            std::copy(tmp.begin(), tmp.end(), segs.begin() + s0);
-            F.gram_sorted = true;
+            // adopt the new order only if it does produce groups: at least half of the points that could be grouped now sit in runs of GRAM_MIN_RUN (signatures
+            // with fewer members than that gain nothing from being adjacent, and the caller's order is kept)
+            int64_t could = 0, adjacent = 0;
+            for (size_t k = 0; k < tmp.size();) {
+                size_t e = k + 1; while (e < tmp.size() && tmp[e].sig == tmp[k].sig && tmp[e].nobs == tmp[k].nobs) e++;
+                if (tmp[k].nobs <= GRAM_KMAX) { could += (int64_t)(e - k); if (e - k >= (size_t)GRAM_MIN_RUN) adjacent += (int64_t)(e - k); }
+                k = e;
+            }
+            if (force == 1 || adjacent * 2 >= could) { std::copy(tmp.begin(), tmp.end(), segs.begin() + s0); F.gram_sorted = true; }
         }
         lap("signature sort");
     }
@@ -707,13 +720,26 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 return true;
             };
             std::vector<int> runs;                                   // (first point, end) of every run that qualifies
-            for (int q = 0; q < F.nP;) {
-                int e = q + 1; while (e < F.nP && same(q, e)) e++;
-                const int K = F.pt_start[q + 1] - F.pt_start[q];
-                // (every point the flatten rules keep has >= 3 observations.  K = 3 went through the pair lists until its 18 Gram rows ran as one 16-row tile + a 4x4x4
-                //  tail: 29.7 | 230 us against 31.7 | 246 us at 100k | 1.5 M points, scripts/prof_gram_k.py; SSFM_GRAM_KMIN raises the bound)
-                if (e - q >= min_run && K >= kmin && K <= GRAM_KMAX) { runs.push_back(q); runs.push_back(e); F.gram_points += e - q; F.gram_obs += (int64_t)(e - q) * K; }
-                q = e;
+            // every planner thread owns the runs that START in its chunk of the points (it walks back to no one: a chunk begins at the first point that differs from
+            // its predecessor) and follows its last run across the chunk's end; the per-thread lists are concatenated in order
+            {
+                const int TR = (F.nP >= 20000) ? NT : 1;
+                std::vector<std::vector<int>> runs_t(TR);
+                parallel_chunks(F.nP, TR, [&](int t, int64_t q0, int64_t q1) {
+                    std::vector<int>& out = runs_t[TR == 1 ? 0 : t];
+                    int q = (int)q0;
+                    while (q > 0 && q < (int)q1 && same(q - 1, q)) q++;        // the run that reaches into this chunk belongs to the previous one
+                    while (q < (int)q1) {
+                        int e = q + 1; while (e < F.nP && same(q, e)) e++;
+                        const int K = F.pt_start[q + 1] - F.pt_start[q];
+                        // (every point the flatten rules keep has >= 3 observations.  K = 3 went through the pair lists until its 18 Gram rows ran as one 16-row tile + a 4x4x4
+                        //  tail: 29.7 | 230 us against 31.7 | 246 us at 100k | 1.5 M points, scripts/prof_gram_k.py; SSFM_GRAM_KMIN raises the bound)
+                        if (e - q >= min_run && K >= kmin && K <= GRAM_KMAX) { out.push_back(q); out.push_back(e); }
+                        q = e;
+                    }
+                });
+                for (auto& v : runs_t) runs.insert(runs.end(), v.begin(), v.end());
+                for (size_t r = 0; r < runs.size(); r += 2) { const int K = F.pt_start[runs[r] + 1] - F.pt_start[runs[r]]; F.gram_points += runs[r + 1] - runs[r]; F.gram_obs += (int64_t)(runs[r + 1] - runs[r]) * K; }
             }
             // Round 4: do the groups pay?  k_schur_gram is launched once per tile class (rows = DC K: {3}, {4, 5}, {6}, {7, 8} at 6 dof), and a launch of a few hundred
             // wave tasks costs its ~24 us latency floor whatever it holds: 300 cameras / 600k observations with tracks of 3..8 frames, sorted into 1800 signatures
@@ -723,7 +749,9 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             // SSFM_GRAM_MODEL=0 keeps every group that qualifies.
             if (!(std::getenv("SSFM_GRAM_MODEL") && std::atoi(std::getenv("SSFM_GRAM_MODEL")) == 0) && !runs.empty()) {
                 double cls_pts[4 * 2 * 8] = {0}; double all_pairs = 0, loose_pairs = 0;
-                for (int q = 0; q < F.nP; q++) { const double k = F.pt_start[q + 1] - F.pt_start[q]; all_pairs += 0.5 * k * (k - 1); }
+                { std::vector<double> part(NT, 0.0);
+                  parallel_chunks(F.nP, NT, [&](int t, int64_t q0, int64_t q1) { double a = 0; for (int64_t q = q0; q < q1; q++) { const double k = F.pt_start[q + 1] - F.pt_start[q]; a += 0.5 * k * (k - 1); } part[t] += a; });
+                  for (double v : part) all_pairs += v; }
                 double grouped_pairs = 0;
                 for (size_t r = 0; r < runs.size(); r += 2) {
                     const int K = F.pt_start[runs[r] + 1] - F.pt_start[runs[r]], rows = F.DC * K, nt_full = rows / 16, tail = rows - 16 * nt_full;

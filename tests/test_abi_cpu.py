@@ -230,3 +230,27 @@ def test_planner_pool_survives_fork():
         os._exit(0 if ok else 1)
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+
+
+def test_signature_sort_groups_scattered_tracks(monkeypatch):
+    """Round 4: points whose camera lists are equal but whose ids are apart (build_sfm issues ids in match order: tracks of different length that start in the same
+    frame are interleaved, examples/spherical_sfm_tools.cpp:862-955) are made adjacent by the planner's signature sort, so they can share wave tasks of k_schur_gram;
+    the cost model then decides whether the groups are used."""
+    from spherical_sfm_amd import ba, synth
+    prob = synth.make_ragged_circle(100, 200000, 3, 8, seed=9)
+    monkeypatch.setenv("SSFM_GRAM_MODEL", "0")
+    monkeypatch.setenv("SSFM_GRAM_SORT", "0")
+    d0, ids0, used0, _ = ba.plan(prob)
+    monkeypatch.delenv("SSFM_GRAM_SORT")
+    d1, ids1, used1, _ = ba.plan(prob)
+    assert d0["num_points_grouped"] == 0 and (np.diff(ids0) > 0).all()                   # interleaved lengths: no run of 32 equal lists in the caller's order
+    assert d1["num_points_grouped"] >= 0.95 * d1["num_points_used"]                      # 100 start frames x 6 lengths = 600 signatures of ~60 points
+    assert np.array_equal(np.sort(ids1), ids0) and np.array_equal(used0, used1)          # a permutation of the same points, the same observations
+    assert d1["band_half_width"] == d0["band_half_width"] and d1["reduced_blocks"] == d0["reduced_blocks"]
+    monkeypatch.delenv("SSFM_GRAM_MODEL")
+    d2, ids2, _, _ = ba.plan(prob)
+    assert d2["num_points_grouped"] in (0, d1["num_points_grouped"])                     # the model keeps all groups or none
+    # signatures with fewer members than a wave task wants: the caller's order stays
+    small = synth.make_ragged_circle(150, 12000, 3, 14, seed=9)
+    d3, ids3, _, _ = ba.plan(small)
+    assert (np.diff(ids3) > 0).all() and d3["num_points_grouped"] == 0
