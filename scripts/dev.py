@@ -1,0 +1,26 @@
+"""Developer probes, one entry point:  python scripts/dev.py <name> [args...]   (runs scripts/dev/<name>.py; GPU box unless noted)
+
+timing
+  ba              config-2 bundle adjustment in the four modes (spherical / general x focal fixed / free): ms per solve + parity vs the oracle
+  warm            repeated ssfm_ba_solve on one structure (plan cache hit)
+  cold            first call on a structure: plan / upload / solve / download (SSFM_PLAN_TIMING=1 prints the planner's stages)
+  e2e             end-to-end Optimize() per call
+  plan            host planner only (no GPU)
+  scale           BASELINE configs[4] size (4000 cameras / 1.5 M points / 12 M observations) on one GPU; CHECK=0 skips the oracle
+  rotavg, rot_time, rot_large, rot_cut   pose-graph solves: config-2 size, timing loop, 2000 / 4000 nodes, forced segment counts
+parity / debugging
+  hard            BA starts that make the LM reject steps
+  sub [dc b rows P]   the band solver probe against numpy, stage by stage
+  ransac, trace, trace_mismatch, lsq_replay   pairwise LO-MSAC: batch vs oracle, where a reference-trace run leaves the oracle's
+  retri, tri_bits Retriangulate vs the oracle; which bits of DLT / score / least squares differ
+"""
+import os
+import runpy
+import sys
+
+if __name__ == "__main__":
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev")
+    if len(sys.argv) < 2 or not os.path.exists(os.path.join(here, sys.argv[1] + ".py")):
+        print(__doc__); print("available:", " ".join(sorted(f[:-3] for f in os.listdir(here) if f.endswith(".py")))); sys.exit(1)
+    name = sys.argv[1]; sys.argv = [os.path.join(here, name + ".py")] + sys.argv[2:]
+    runpy.run_path(sys.argv[0], run_name="__main__")

@@ -1,6 +1,6 @@
 """Developer probe (GPU box): config-2 BA in the four modes, timings + parity vs the oracle."""
 import sys, time, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from spherical_sfm_amd import synth, ba
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """End-to-end Optimize() timing on the GPU box: ssfm_ba_solve = flatten + upload + LM + download, per call."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch  # noqa
 from spherical_sfm_amd import ba, synth

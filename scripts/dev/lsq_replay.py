@@ -2,7 +2,7 @@
 subset): where does the device fit leave the oracle's, and which Levenberg-Marquardt rule flipped?"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spherical_sfm_amd import ba, synth, ransac
 from oracle import oracle as O
 THR = (2 / 600) ** 2

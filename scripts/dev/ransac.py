@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from scipy.spatial.transform import Rotation
 from spherical_sfm_amd import synth, ba, ransac

@@ -1,7 +1,7 @@
 """Timing of the pose-graph solves at the config-2 size (300 cameras, edges i -> i+1..8): GPU vs oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from spherical_sfm_amd import ba, rotavg, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Scale probe (GPU box): BASELINE configs[4]-sized BA (4000 cams / 1.5M pts / 12M obs) on ONE GPU + oracle parity."""
 import sys, os, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from spherical_sfm_amd import synth, ba
 from oracle import oracle as O

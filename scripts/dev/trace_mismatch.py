@@ -1,7 +1,7 @@
 """debug: which pairs of the reference-trace LO-MSAC differ from the oracle, and where (tests/test_ransac_trace_gpu.py thresholds)"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scipy.spatial.transform import Rotation
 from spherical_sfm_amd import ba, synth, ransac
 from oracle import oracle as O

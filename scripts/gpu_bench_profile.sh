@@ -12,5 +12,5 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-scale-probe > $OUT/pmc3_${TAG}.log 2>&1
 ls $OUT/pmc1_${TAG} $OUT/pmc2_${TAG} | head; tail -3 $OUT/pmc1_${TAG}.log
 # configs[4]-size probe under the kernel trace (substructured factorisation)
-CHECK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dbg_scale.py > $OUT/prof_scale_${TAG}.log 2>&1
+CHECK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dev/scale.py > $OUT/prof_scale_${TAG}.log 2>&1
 head -24 $(find $OUT/prof_scale_${TAG} -name "*kernel_stats.csv" | head -1)

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
 python bench.py --steps 10 --warmup 2 --focal-free > gpurun_out/bench_${TAG}_focalfree.json 2>> gpurun_out/bench_${TAG}.err
 python bench.py --steps 10 --warmup 2 --mode spherical > gpurun_out/bench_${TAG}_spherical.json 2>> gpurun_out/bench_${TAG}.err
-python scripts/dbg_scale.py > gpurun_out/scale_${TAG}.txt 2>&1
+python scripts/dev/scale.py > gpurun_out/scale_${TAG}.txt 2>&1
 for f in gpurun_out/bench_${TAG}.json gpurun_out/bench_${TAG}_focalfree.json gpurun_out/bench_${TAG}_spherical.json; do
 python - "$f" <<'PY'
 import sys, json

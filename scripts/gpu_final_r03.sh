@@ -16,7 +16,7 @@ if [ "$STAGE" = "pmc" ]; then
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc4_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-scale-probe > $OUT/pmc4_${TAG}.log 2>&1
   F=$(first_csv $OUT/pmc4_${TAG} "*counter_collection.csv"); [ -n "$F" ] && cp "$F" $OUT/pmc4_${TAG}/ba_counter_collection.csv 2>/dev/null; tail -3 $OUT/pmc4_${TAG}.log
   for i in 1 2 3; do F=$(first_csv $OUT/pmc${i}_${TAG} "*counter_collection.csv"); [ -n "$F" ] && cp "$F" $OUT/pmc${i}_${TAG}/ba_counter_collection.csv 2>/dev/null; ls $OUT/pmc${i}_${TAG} | head -3; done
-  CHECK=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dbg_scale.py > $OUT/prof_scale_${TAG}.log 2>&1
+  CHECK=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dev/scale.py > $OUT/prof_scale_${TAG}.log 2>&1
   F=$(first_csv $OUT/prof_scale_${TAG} "*kernel_stats.csv"); [ -n "$F" ] && { cp "$F" $OUT/${TAG}_scale_rocprofv3_kernel_stats.csv; head -16 "$F" | cut -c1-140; }
 else
   timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err; tail -c 600 $OUT/bench_${TAG}.json; tail -2 $OUT/bench_${TAG}.err

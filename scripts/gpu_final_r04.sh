@@ -17,7 +17,7 @@ if [ "$STAGE" = "pmc" ]; then
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3_${TAG} -o ba -- $B --steps 1 --warmup 0 > $OUT/pmc3_${TAG}.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc4_${TAG} -o ba -- $B --steps 1 --warmup 0 > $OUT/pmc4_${TAG}.log 2>&1
   for i in 1 2 3 4; do F=$(first_csv $OUT/pmc${i}_${TAG} "*counter_collection.csv"); [ -n "$F" ] && cp "$F" $OUT/pmc${i}_${TAG}/ba_counter_collection.csv 2>/dev/null; ls $OUT/pmc${i}_${TAG} | head -2; done
-  CHECK=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dbg_scale.py > $OUT/prof_scale_${TAG}.log 2>&1
+  CHECK=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scale_${TAG} -o ba -- python3 $GRAFT_REPO_ROOT/scripts/dev/scale.py > $OUT/prof_scale_${TAG}.log 2>&1
   F=$(first_csv $OUT/prof_scale_${TAG} "*kernel_stats.csv"); [ -n "$F" ] && { cp "$F" $OUT/${TAG}_scale_rocprofv3_kernel_stats.csv; head -14 "$F" | cut -c1-150; }
   # Retriangulate (trace replay, 100k points x 6): kernel stats + the VALU / wait counters
   CHECK=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_retri_${TAG} -o retri -- python3 $GRAFT_REPO_ROOT/scripts/prof_retri.py 300 100000 6 1 > $OUT/prof_retri_${TAG}.log 2>&1

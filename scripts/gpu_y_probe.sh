@@ -8,7 +8,7 @@ import csv
 for r in csv.DictReader(open('$OUT/yprobe_$mode/ba_kernel_stats.csv')):
     if 'pairs' in r['Name']: print('$mode', r['Name'].split('(')[0], 'avg us', float(r['AverageNs'])/1e3)"
 done
-SSFM_PAIRS_Y_PROBE=1 CHECK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/yprobe_scale -o ba -- python3 scripts/dbg_scale.py > $OUT/yprobe_scale.log 2>&1
+SSFM_PAIRS_Y_PROBE=1 CHECK=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/yprobe_scale -o ba -- python3 scripts/dev/scale.py > $OUT/yprobe_scale.log 2>&1
 python3 -c "
 import csv
 for r in csv.DictReader(open('$OUT/yprobe_scale/ba_kernel_stats.csv')):

@@ -158,7 +158,7 @@ def test_trace_mode_reproduces_the_oracle_pair_by_pair(gpu_ctx, oracle):
     res = np.array(res)
     # identical sample trace, identical inlier flags, E / R to 1e-9 on EVERY pair: with these options the only floating-point work between two
     # decisions is a minimal solve + a score, or one 6-parameter least-squares fit, and each of those agrees with the oracle to ~1e-10
-    # (scripts/dbg_trace_mismatch.py: 0 differing pairs of 256 on MI355X); the kernel has no atomics, so this does not vary from run to run
+    # (scripts/dev/trace_mismatch.py: 0 differing pairs of 256 on MI355X); the kernel has no atomics, so this does not vary from run to run
     assert res.all(), (res.mean(axis=0), np.nonzero(~res.all(1))[0])
     assert (out["iterations"] >= 100).all() and (out["lo_runs"] >= 1).all()
 
@@ -177,7 +177,7 @@ def test_trace_mode_with_local_optimization_steps(gpu_ctx, oracle, poly):
         assert rot_err(R, out["R"][k]) < 5e-3
     res = np.array(res)
     # Where a pair leaves the oracle's trace, find out WHY: replay the oracle's own call log on the device, call by call (same ray subset, same start
-    # model), and name the first call whose output differs.  Measured on MI355X (scripts/dbg_lsq_replay.py: 6528 LeastSquares calls): no
+    # model), and name the first call whose output differs.  Measured on MI355X (scripts/dev/lsq_replay.py: 6528 LeastSquares calls): no
     # Levenberg-Marquardt stopping rule ever flips -- every fit has the oracle's iteration count and agrees to ~1e-9.  What differs is
     # NonMinimalSolver on an ill-conditioned 4..9-ray sample (the 6x6 elimination + companion roots amplify rounding to 1e-6 and more,
     # test_nonminimal_solver_probe_matches_oracle); the next GetInliers then admits a different ray and the runs part ways.
