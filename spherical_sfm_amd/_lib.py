@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssfm_hip.so")
+LIB_PATH = os.environ.get("SSFM_LIB_PATH") or os.path.join(_HERE, "libssfm_hip.so")      # SSFM_LIB_PATH: a variant build of the same library (kernel experiments, scripts/gpu_gram_ld.sh)
 _LIB = None
 
 c_double_p = C.POINTER(C.c_double)

@@ -592,7 +592,10 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 // History (profiles/r03_notes.md): 32-point sub-chunks on half the lanes 70.7 us at config 2; 16 points on all lanes 57; + prefetch, no zeroing 39.5;
 // emission from LDS instead of per-entry global index loads 35.3; 8-point sub-chunks (12 instead of 7 waves per CU) 380 -> 355 us at the configs[4] size;
 // with the camera-side sums (k_cam_sums2 no longer runs for these cameras) 48.7 us / 400 us against 39.5 + 20.5 / 931 + 414 for the pair path.
-constexpr int GRAM_CAMREC = 34, GRAM_LD = 28, GRAM_SUB = 8, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
+#ifndef SSFM_GRAM_LD
+#define SSFM_GRAM_LD 28      // row stride of the half products in LDS, doubles (swept in round 4: scripts/gpu_gram_ld.sh, profiles/r04_notes.md)
+#endif
+constexpr int GRAM_CAMREC = 34, GRAM_LD = SSFM_GRAM_LD, GRAM_SUB = 8, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
 // transposing reduction over the 8 lanes that differ in lane bits 0..2: N values per lane in, ceil(N / 8) out; out[j] of a lane is the 8-lane sum of
 // value 8 j + 4 (lane & 1) + 2 ((lane >> 1) & 1) + ((lane >> 2) & 1)
 template <int N, int MASK>
