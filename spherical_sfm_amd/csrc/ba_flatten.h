@@ -107,7 +107,7 @@ struct BAFlat {
     int64_t gram_points = 0, gram_obs = 0;
     bool gram_sorted = false;               // the local points were re-ordered by camera-list signature (ba_flatten: signature sort)
 };
-constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3;
+constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3, GRAM_SUB_PTS = 8;      // GRAM_SUB_PTS = GRAM_SUB of ba_kernels.h (points per sub-chunk)
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
 // once the prefix sums are known.  The T - 1 helpers are persistent (a pool parked on a condition variable): spawning seven std::threads per
@@ -771,7 +771,16 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             // the chip holds ~2300 of these waves at once: two rounds' worth of tasks when the problem is small, 192 points when it is large
             // (measured: 100 000 points 64 -> 39.5 us, 128 -> 41, 192 -> 54; 1.5 M points 64 -> 560 us, 128 -> 453, 192 -> 434)
             int gram_pts = gram_pts_env;
-            if (gram_pts <= 0) gram_pts = (int)std::min<int64_t>(192, std::max<int64_t>(64, (F.gram_points / 4608 + 15) / 16 * 16));
+            if (gram_pts <= 0) {
+                gram_pts = (int)std::min<int64_t>(192, std::max<int64_t>(64, (F.gram_points / 4608 + 15) / 16 * 16));
+                // round 4: a small problem runs fastest with ONE wave per SIMD -- the shortest task length (64..192) that leaves at most 4 x CUs tasks, runs cut in equal
+                // parts.  Config 2 (300 runs of 333 points): 3 x 112 = 900 tasks 43.9 us; 6 x 56 = 1800 tasks (two waves on three of four SIMDs) 48.2; the
+                // 5 x 64 + 13 of round 3 46.1; 2 x 168 = 600 tasks 49.6 (scripts/prof_gram_ld.py with SSFM_GRAM_PTS, profiles/r04_notes.md)
+                for (int g = 64; g <= 192; g += 8) {
+                    int64_t tasks = 0; for (size_t r = 0; r < runs.size(); r += 2) tasks += (runs[r + 1] - runs[r] + g - 1) / g;
+                    if (tasks <= 4 * (int64_t)num_cus) { gram_pts = g; break; }
+                }
+            }
             // tasks sorted by K (stable: point order within a K): k_schur_gram is launched once per tile count, over a contiguous range of tasks
             std::vector<size_t> run_order(runs.size() / 2);
             for (size_t r = 0; r < run_order.size(); r++) run_order[r] = 2 * r;
@@ -788,8 +797,11 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                     const int sl = (int)(std::lower_bound(F.col_idx.begin() + F.row_ptr[row], F.col_idx.begin() + F.row_ptr[row + 1], col) - F.col_idx.begin());
                     slots[a * (a - 1) / 2 + b] = sl | (row_a ? 0 : (1 << 30));
                 }
-                for (int t0 = q; t0 < e; t0 += gram_pts) {
-                    const int head[4] = {t0, std::min(gram_pts, e - t0), K, F.pt_start[t0]};
+                // a run is cut into EQUAL tasks (whole sub-chunks of 8 points) instead of full tasks + a short remainder: config 2's runs of 333 points were
+                // 5 x 64 + 13 -- a sixth task that pays the full start-up and emission for two sub-chunks; now 5 x 56 + 53
+                const int parts = (e - q + gram_pts - 1) / gram_pts, per = (((e - q + parts - 1) / parts) + GRAM_SUB_PTS - 1) / GRAM_SUB_PTS * GRAM_SUB_PTS;
+                for (int t0 = q; t0 < e; t0 += per) {
+                    const int head[4] = {t0, std::min(per, e - t0), K, F.pt_start[t0]};
                     F.gr_rec.insert(F.gr_rec.end(), head, head + 4);
                     for (int k = 0; k < GRAM_KMAX; k++) F.gr_rec.push_back(k < K ? cams[k] : cams[0]);
                     F.gr_rec.insert(F.gr_rec.end(), slots, slots + GRAM_NPAIR);

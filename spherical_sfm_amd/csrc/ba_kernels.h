@@ -595,7 +595,7 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 #ifndef SSFM_GRAM_LD
 #define SSFM_GRAM_LD 28      // row stride of the half products in LDS, doubles (swept in round 4: scripts/gpu_gram_ld.sh, profiles/r04_notes.md)
 #endif
-constexpr int GRAM_CAMREC = 34, GRAM_LD = SSFM_GRAM_LD, GRAM_SUB = 8, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
+constexpr int GRAM_CAMREC = 34, GRAM_LD = SSFM_GRAM_LD, GRAM_SUB = GRAM_SUB_PTS, GRAM_TAIL = GRAM_KMAX * GRAM_CAMREC + 48 + GRAM_NPAIR / 2 + GRAM_KMAX / 2;
 // transposing reduction over the 8 lanes that differ in lane bits 0..2: N values per lane in, ceil(N / 8) out; out[j] of a lane is the 8-lane sum of
 // value 8 j + 4 (lane & 1) + 2 ((lane >> 1) & 1) + ((lane >> 2) & 1)
 template <int N, int MASK>
