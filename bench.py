@@ -34,7 +34,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy bandwidth of the box is MEASURED in every run (hbm_copy_GBs, ssfm_debug_copy_bandwidth)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r03j_pmc_traffic.json")   # committed rocprofv3 --pmc summary the traffic / VALU figures are read from
+PMC_PROFILE = os.path.join("profiles", "r04f_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r04.sh + collect_final_r04.py) the traffic / VALU figures are read from
+if not os.path.exists(os.path.join(ROOT, PMC_PROFILE)):
+    PMC_PROFILE = os.path.join("profiles", "r03j_pmc_traffic.json")
+ROCPROF_STATS = os.path.join("profiles", "r04f_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
+
+
+def rocprof_avg_us():
+    """{kernel name without template arguments: average launch duration in us} from the committed rocprofv3 summary (None if it is not there)"""
+    import csv
+    import re
+    path = os.path.join(ROOT, ROCPROF_STATS)
+    if not os.path.exists(path):
+        return None
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        name = re.sub(r"^void ", "", r["Name"]).split("(")[0].replace("ssfm::", "")
+        name = re.sub(r"<.*>", "", name)
+        c, t = int(r["Calls"]), float(r["TotalDurationNs"])
+        a = acc.setdefault(name, [0, 0.0]); a[0] += c; a[1] += t
+    return {k: v[1] / v[0] / 1e3 for k, v in acc.items() if v[0]}
+
 
 
 def pair_kernel_flops(pairs):
@@ -91,11 +111,17 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1, focal_free
     return out
 
 
-def with_copy_fraction(per_kernel, copy_gbs):
-    """adds frac_of_measured_copy (achieved / the device copy bandwidth measured in the same run) next to frac_hbm (achieved / nominal 8 TB/s)"""
-    for v in per_kernel.values():
+def with_copy_fraction(per_kernel, copy_gbs, rocprof=None):
+    """adds frac_of_measured_copy (achieved / the device copy bandwidth measured in the same run) next to frac_hbm (achieved / nominal 8 TB/s), and -- when the committed
+    rocprofv3 summary of this command is there -- the same fractions from ITS average launch durations (the event brackets of this run include a few us of dispatch
+    hand-over per launch: VERDICT r3 #12)"""
+    for k, v in per_kernel.items():
         if copy_gbs and v.get("achieved_GBs") is not None:
             v["frac_of_measured_copy"] = v["achieved_GBs"] / copy_gbs
+        us = (rocprof or {}).get(k)
+        if us:
+            g = v["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9
+            v["rocprof"] = {"avg_us": us, "achieved_GBs": g, "frac_hbm": g / HBM_PEAK_GBS, "frac_of_measured_copy": (g / copy_gbs) if copy_gbs else None, "source": ROCPROF_STATS}
     return per_kernel
 
 
@@ -464,7 +490,8 @@ def main():
                              "frac_of_measured_copy": vs_copy(achieved),
                              "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
             "roofline_compute": rc,
-            "roofline_per_kernel": with_copy_fraction(kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free), copy_gbs),
+            "roofline_per_kernel": with_copy_fraction(kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free), copy_gbs,
+                                                      rocprof_avg_us() if (world == 1 and not spherical and not args.focal_free and args.cameras == 300 and args.points == 100000) else None),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
             # committed profile) against what 256 CUs x 4 SIMDs can issue in the measured launch time (one wave64 VALU op per SIMD per 4 cycles)
             "valu_issue": {"kernel": dom, "wave_instructions_per_launch": valu, "clock_ghz": 2.4, "source": f"committed profile {PMC_PROFILE} (SQ_INSTS_VALU), not measured in this run",
