@@ -10,6 +10,7 @@
 #define CHOL3_STAMPS 1
 #include "ba_flatten.h"
 #include "band_kernels3.h"
+#include "band_kernels2p.h"
 using namespace ssfm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -66,7 +67,7 @@ int run(int ncomp, int ncam, int b, int reps) {
         return num / den;
     };
     const size_t lds_new = ((size_t)(b + 1) * W * BB + (size_t)b * BB + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * 8 + ((size_t)b * (b + 1) / 2 + 2) * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
+    if (lds_new <= 160 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
     printf("DC=%d ncomp=%d ncam=%d b=%d  lds %zu\n", DC, ncomp, ncam, b, lds_new);
     auto bench = [&](const char* tag, auto chol, auto back) {
         float tc = 0, tb = 0;
@@ -80,14 +81,32 @@ int run(int ncomp, int ncam, int b, int reps) {
         printf("%-24s chol %.1f us   back %.1f us   (per step %.2f / %.2f us)\n", tag, tc / reps * 1e3, tb / reps * 1e3, tc / reps * 1e3 / ncam, tb / reps * 1e3 / ncam);
         check(tag);
     };
-    for (int nw : {9, 10}) {
+    const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
+    auto back_any = [&] { if (b * DC > 128) hipLaunchKernelGGL((k_band_back_lds<DC, 2>), dim3(ncomp), dim3(256), lds_sub2, st, dband, dG, dY, dcomp, N, b);
+                          else if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                          else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
+    if constexpr (DC == 6) {
+        const size_t lds2p = chol2p_lds_bytes(b, NR);
+        if (lds2p <= 160 * 1024) {
+            const int nblk = (b * (b + 1) / 2) * 4 - 4 + b * DC;
+            printf("v2p: lds %zu B, tasks %d\n", lds2p, nblk);
+#define V2P(NT_, NPB_, PRE_, NW_) do { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, NT_, NPB_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p)); \
+            bench("v2p <" #NT_ "," #NPB_ "," #PRE_ "> " #NW_ " waves", [&] { hipLaunchKernelGGL((k_band_chol_v2p<2, NT_, NPB_, PRE_>), dim3(ncomp), dim3(64 * NW_), lds2p, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail); }, back_any); } while (0)
+            if (b <= 14) { V2P(1, 1, 5, 12); V2P(2, 1, 5, 9); }
+            else if (b <= 26) { V2P(3, 1, 8, 16); V2P(2, 1, 8, 16); }
+            else V2P(3, 2, 9, 16);
+#undef V2P
+        }
+    }
+    if (lds_new <= 160 * 1024)
+    for (int nw : {9}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
         bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(nw, nw - 2 - CHOL2_LOADERS, nw - 2 - CHOL2_LOADERS)); },
               [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
                     else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); });
     }
 
-    if constexpr (DC == 6) {
+    if constexpr (DC == 6) if (b <= 14) {
         const size_t lds3 = chol3_lds_doubles(b, NR) * 8;
         auto back = [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
                           else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
@@ -115,5 +134,9 @@ int main(int argc, char** argv) {
     const int reps = 50;
     run<6>(4, 75, 10, reps);
     run<6>(4, 75, 14, reps);
+    run<6>(1, 300, 14, 20);
+    run<6>(1, 300, 22, 20);
+    run<6>(1, 300, 26, 20);
+    run<6>(2, 150, 30, 20);
     return 0;
 }

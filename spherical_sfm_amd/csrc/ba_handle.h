@@ -12,6 +12,7 @@
 #include "ba_flatten.h"
 #include "ba_kernels.h"
 #include "band_kernels2.h"
+#include "band_kernels2p.h"
 #include "band_sub.h"
 #include "ssfm_ctx.h"
 
@@ -370,8 +371,30 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
             }
         } else {
-            LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, Y, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
+            // Round 4: bands too wide for the square window ring (6x6 blocks, half-width 22..30) keep an LDS-resident factorisation through the PACKED window of
+            // band_kernels2p.h (the live triangle only: 109 KB at half-width 26) and the workgroup back substitution; whole components (the planner does not twist or
+            // cut bands this wide).  One connected ring of 300 cameras at half-width 26: 4.0 + 1.1 us per block row against 6.2 + 1.9 for the global-memory pair below
+            // (scripts/lab/chol_lab3.hip, profiles/r04_notes.md).  SSFM_BAND_PACKED=0 keeps the global-memory kernels.
+            const bool packed_on = !(std::getenv("SSFM_BAND_PACKED") && std::atoi(std::getenv("SSFM_BAND_PACKED")) == 0);
+            bool done = false;
+            if constexpr (DC == 6) {
+                const size_t lds2p = chol2p_lds_bytes(b, 2);
+                const int tasks2p = (b * (b + 1) / 2) * 4 - 4 + b * DC;
+                if (packed_on && b >= 1 && lds2p <= 160 * 1024 && tasks2p <= 3 * 12 * 64 && b * BB <= 2 * 1024 && (b + 1) * BB + 2 * DC <= 9 * 128 && b * DC <= 256) {
+#define SSFM_LAUNCH_2P(NPB_, PRE_)                                                                                                                                        \
+                    do { SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, 3, NPB_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p)); \
+                         LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2p<2, 3, NPB_, PRE_>), ncomp, 1024, lds2p, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1,        \
+                                h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL)); } while (0)
+                    if (b * BB <= 1024 && (b + 1) * BB + 2 * DC <= 8 * 128) SSFM_LAUNCH_2P(1, 8); else SSFM_LAUNCH_2P(2, 9);      // one panel entry per thread up to half-width 27
+#undef SSFM_LAUNCH_2P
+                    LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
+                    done = true;
+                }
+            }
+            if (!done) {
+                LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, Y, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+                LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
+            }
         }
         return SSFM_OK;
 #undef SSFM_LAUNCH_CHOL2

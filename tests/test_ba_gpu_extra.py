@@ -28,10 +28,13 @@ def test_both_preconditioners_reach_the_oracle_answer(gpu_ctx, oracle, precond, 
         assert s["pcg_iterations_total"] <= 2 * s["num_linearizations"]      # the banded factor is exact: refinement is rare
 
 
-@pytest.mark.parametrize("K,Nc", [(12, 90), (6, 45)])
-def test_wide_band_ring(gpu_ctx, oracle, K, Nc):
-    """One connected ring with long tracks: exercises the global-memory factorisation path (window > LDS) for K=12."""
+@pytest.mark.parametrize("K,Nc,packed", [(12, 90, "1"), (12, 90, "0"), (14, 120, "1"), (16, 90, "1"), (16, 90, "0"), (6, 45, "1")])
+def test_wide_band_ring(gpu_ctx, oracle, monkeypatch, K, Nc, packed):
+    """One connected ring with long tracks: the band (2 (K - 1) blocks) is too wide for the square LDS window ring.  Half-width 22 / 26 / 30 take the packed-window
+    factorisation of round 4 (band_kernels2p.h) + the workgroup back substitution; SSFM_BAND_PACKED=0 the global-memory pair they replace."""
     from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    monkeypatch.setenv("SSFM_BAND_PACKED", packed)
     p = synth.make_circle(Nc, 900, K, spherical=False, focal_fixed=True, check_in_frame=False, xy_range=0.2)
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
     ocams, opts, of, os_ = oracle.ba_solve(p)
