@@ -80,8 +80,8 @@ int run(int ncomp, int ncam, int b, int reps) {
     for (int nw : {6, 8, 9, 10, 12}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
         bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(nw, nw - 2 - CHOL2_LOADERS, nw - 2 - CHOL2_LOADERS)); },
-              [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
-                    else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); });
+              [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, 2>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                    else hipLaunchKernelGGL((k_band_back_v2<DC, 1>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); });
     }
     return 0;
 }

@@ -67,7 +67,7 @@ int run(int ncomp, int ncam, int b, int reps) {
         return num / den;
     };
     const size_t lds_new = ((size_t)(b + 1) * W * BB + (size_t)b * BB + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * 8 + ((size_t)b * (b + 1) / 2 + 2) * 4;
-    if (lds_new <= 160 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
+    if (lds_new <= 140 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
     printf("DC=%d ncomp=%d ncam=%d b=%d  lds %zu\n", DC, ncomp, ncam, b, lds_new);
     auto bench = [&](const char* tag, auto chol, auto back) {
         float tc = 0, tb = 0;
@@ -82,9 +82,10 @@ int run(int ncomp, int ncam, int b, int reps) {
         check(tag);
     };
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
-    auto back_any = [&] { if (b * DC > 128) hipLaunchKernelGGL((k_band_back_lds<DC, 2>), dim3(ncomp), dim3(256), lds_sub2, st, dband, dG, dY, dcomp, N, b);
-                          else if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
-                          else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
+    auto back_any = [&] { if (b * DC > 192) hipLaunchKernelGGL((k_band_back_lds<DC, 2>), dim3(ncomp), dim3(256), lds_sub2, st, dband, dG, dY, dcomp, N, b);
+                          else if (b * DC > 128) hipLaunchKernelGGL((k_band_back_v2<DC, 3>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                          else if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, 2>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                          else hipLaunchKernelGGL((k_band_back_v2<DC, 1>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
     if constexpr (DC == 6) {
         const size_t lds2p = chol2p_lds_bytes(b, NR);
         if (lds2p <= 160 * 1024) {
@@ -98,18 +99,18 @@ int run(int ncomp, int ncam, int b, int reps) {
 #undef V2P
         }
     }
-    if (lds_new <= 160 * 1024)
+    if (lds_new <= 140 * 1024)      // (the product's limit for the square window ring)
     for (int nw : {9}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
         bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(nw, nw - 2 - CHOL2_LOADERS, nw - 2 - CHOL2_LOADERS)); },
-              [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
-                    else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); });
+              [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, 2>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                    else hipLaunchKernelGGL((k_band_back_v2<DC, 1>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); });
     }
 
     if constexpr (DC == 6) if (b <= 14) {
         const size_t lds3 = chol3_lds_doubles(b, NR) * 8;
-        auto back = [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
-                          else hipLaunchKernelGGL((k_band_back_v2<DC, false>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
+        auto back = [&] { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, 2>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b);
+                          else hipLaunchKernelGGL((k_band_back_v2<DC, 1>), dim3(ncomp, NR), dim3(64), 0, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b); };
         const int tw = chol3_trailing_waves(b);
         printf("v3: lds %zu B, trailing waves %d\n", lds3, tw);
 #define V3(TW_, PRE_) bench("v3 <" #TW_ "," #PRE_ ">", [&] { hipLaunchKernelGGL((k_band_chol_v3<2, TW_, PRE_>), dim3(ncomp), dim3(64 * (TW_ + 4)), lds3, st, dband, dG, dY, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail); }, back)

@@ -229,6 +229,10 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
 //   out: pos = elimination order (seg_0 | seg_1 reversed | sep), band_row / band_row2 / band_rows, comp_ptr in band rows
 // A component is twisted when both segments are longer than the band (n >= 3 b + 2) and it is not long enough to be cut into
 // several segments (band_sub.h, SUB_MIN_ROWS); the kernels involved need the LDS-resident factorisation (b <= 20).
+// Half-widths above 20 (6x6 blocks) need the packed-window factorisation (band_kernels2p.h, ba_handle.h: band_wide_packed): with it on (default) components are
+// twisted up to half-width 30, with SSFM_BAND_PACKED=0 up to 20 as before (the global-memory kernels that then serve wide bands know no twisted layout).
+inline bool band_packed_enabled() { const char* e = std::getenv("SSFM_BAND_PACKED"); return !(e && std::atoi(e) == 0); }
+inline int band_wide_max() { return band_packed_enabled() ? 30 : 20; }
 constexpr int BAND_CUT_MIN_ROWS = 512;            // below: twisted (two workgroups, no spike); from here on: cut into a chain of segments (band_sub.h)
 inline void band_twist_plan(int Nc, int b, std::vector<int>& pos, std::vector<int>& comp_ptr, std::vector<int>& band_row,
                             std::vector<int>& band_row2, std::vector<char>& comp_twist, int& band_rows, int max_b = 20) {
@@ -270,7 +274,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
     const bool merge = dc == 3 && !(env && env[0] == '0');
     if (!merge) {
         band_block = dc;
-        band_twist_plan(Nc, band, pos, comp_ptr, band_row, band_row2, comp_twist, band_rows, dc == 3 ? 40 : 20);
+        band_twist_plan(Nc, band, pos, comp_ptr, band_row, band_row2, comp_twist, band_rows, dc == 3 ? 40 : band_wide_max());
         return;
     }
     // ---- super nodes = pairs of consecutive Cuthill-McKee positions inside a component
@@ -291,7 +295,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
     bs = std::max(bs, 1);
     std::vector<int> spos(ns), srow, srow2;
     for (int i = 0; i < ns; i++) spos[i] = i;
-    band_twist_plan(ns, bs, spos, sup_ptr, srow, srow2, comp_twist, band_rows, 20);
+    band_twist_plan(ns, bs, spos, sup_ptr, srow, srow2, comp_twist, band_rows, band_wide_max());
     // cameras: elimination key 2 * spos + parity, compressed to a permutation
     std::vector<int> key(Nc), order(Nc);
     for (int c = 0; c < Nc; c++) { key[c] = 2 * spos[sup[c]] + par[c]; order[c] = c; }

@@ -154,10 +154,11 @@ namespace ssfm {
                    (h)->Sfc, vec, (h)->F.Nc, (h)->pcg.p, (h)->pq.p, (h)->pqpart.p);                                         \
     } while (0)
 
-// back substitution: the narrow variant when every task fits one lane set (b * DC <= 64)
+// back substitution: one, two or three task sets per lane (b * DC <= 64 / 128 / 192)
 #define BACK_V2_LAUNCH(grid, ...)                                                                                          \
-    do { if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, true>), grid, dim3(64), 0, st, __VA_ARGS__);             \
-         else hipLaunchKernelGGL((k_band_back_v2<DC, false>), grid, dim3(64), 0, st, __VA_ARGS__); } while (0)
+    do { if (b * DC > 128) hipLaunchKernelGGL((k_band_back_v2<DC, 3>), grid, dim3(64), 0, st, __VA_ARGS__);               \
+         else if (b * DC > 64) hipLaunchKernelGGL((k_band_back_v2<DC, 2>), grid, dim3(64), 0, st, __VA_ARGS__);            \
+         else hipLaunchKernelGGL((k_band_back_v2<DC, 1>), grid, dim3(64), 0, st, __VA_ARGS__); } while (0)
 #define LAUNCH(h, kid, kernel, grid, block, shmem, ...)                                   \
     do {                                                                                  \
         (h)->span_begin(kid);                                                             \
@@ -255,6 +256,16 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     return SSFM_OK;
 }
 
+// Round 4: bands too wide for the square window ring (6x6 blocks, half-width 21..30) keep an LDS-resident factorisation through the PACKED window of
+// band_kernels2p.h (the live triangle only: 109 KB at half-width 26) and the single-wave back substitution with three task sets per lane; twisted components
+// included (the planner twists up to half-width 30 when this path is on, ba_flatten.h: band_wide_max).  One connected ring of 300 cameras at half-width 26: 4.0 us
+// per block row against 6.2 for the global-memory kernel (scripts/lab/chol_lab3.hip, profiles/r04_notes.md).  SSFM_BAND_PACKED=0 keeps the global-memory kernels.
+static bool band_wide_packed(int DC, int b, bool use_lds) {
+    if (use_lds || DC != 6 || b < 1 || !band_packed_enabled()) return false;
+    const int tasks2p = (b * (b + 1) / 2) * 4 - 4 + b * DC;
+    return chol2p_lds_bytes(b, 2) <= 160 * 1024 && tasks2p <= 3 * 12 * 64 && b * 36 <= 2 * 1024 && (b + 1) * 36 + 2 * DC <= 9 * 128 && b * DC <= 192;
+}
+
 // Factor the band in h->band (block-band Cholesky in Cuthill-McKee order) and solve for the two right-hand-side columns of Y
 // (band order), in place.  Long components go through the substructured path (band_sub.h) when the plan holds one.
 template <int DC>
@@ -267,7 +278,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
     // LDS-resident factorisation (band_kernels2.h): window ring + panel + right-hand-side rows + scratch + pair table
     const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
     const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
-    const bool back_v2 = use_lds && b * DC <= 128;          // single-wave back substitution carries two tasks per lane at most
+    const bool wide2p = band_wide_packed(DC, b, use_lds);
+    const bool back_v2 = (use_lds && b * DC <= 128) || wide2p;          // single-wave back substitution: up to two task sets per lane with the square window, three with the packed one
+    const size_t lds2p = wide2p ? chol2p_lds_bytes(b, 2) : 0;
     // wave roles of k_band_chol_v2: 1 look-ahead + trailing-update waves (one block task per lane) + loaders + 1 writer
     // (block tasks and right-hand-side tasks on waves of their own when seven waves allow it: see the trailing role of the kernel)
     const int tpb_ = (DC % 3 == 0) ? (DC / 3) * (DC / 3) : DC * DC, blk_tasks = (b * (b + 1) / 2) * tpb_ - tpb_, rhs_tasks = b * DC;
@@ -286,10 +299,18 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
 #define SSFM_LAUNCH_CHOL2_V(V_, grid_, ...)                                                                                                 \
     do { if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win)); \
          LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2, V_>), grid_, chol_threads, lds_win, __VA_ARGS__); } while (0)
+    // the packed-window kernel takes the same tables (no wave map: its roles sit in wave order)
+#define SSFM_LAUNCH_2P(NPB_, PRE_, grid_, lo_, hi_, wend_, merge_)                                                                                            \
+    do { if constexpr (DC == 6) {                                                                                                                            \
+         SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, 3, NPB_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p)); \
+         LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2p<2, 3, NPB_, PRE_>), grid_, 1024, lds2p, h->band.p, h->Linv.p, Y, h->band_pairs.p, lo_, hi_, wend_, merge_, Nc, b,        \
+                reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL)); } } while (0)
+#define SSFM_LAUNCH_CHOL2P(grid_, lo_, hi_, wend_, merge_)                                                                                                   \
+    do { if (b * BB <= 1024 && (b + 1) * BB + 2 * DC <= 8 * 128) SSFM_LAUNCH_2P(1, 8, grid_, lo_, hi_, wend_, merge_); else SSFM_LAUNCH_2P(2, 9, grid_, lo_, hi_, wend_, merge_); } while (0)
 #define SSFM_LAUNCH_CHOL2(grid_, ...)                                                                                                       \
     do { if (mf == 3) SSFM_LAUNCH_CHOL2_V(MFB, grid_, __VA_ARGS__); else if (mf == 2) SSFM_LAUNCH_CHOL2_V(MFT, grid_, __VA_ARGS__);          \
          else if (mf == 1) SSFM_LAUNCH_CHOL2_V(MFP, grid_, __VA_ARGS__); else SSFM_LAUNCH_CHOL2_V(0, grid_, __VA_ARGS__); } while (0)
-        if (h->sub.enabled && use_lds && back_v2) {
+        if (h->sub.enabled && (use_lds || wide2p) && back_v2) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
             const BandSub& B = h->sub;
             const int Q = b * DC;
@@ -302,10 +323,11 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             // through flags in global memory.  Measured at config 2: 70.7 us for the fused launch against 2 x 35.2, 2.958 vs 2.919 ms per solve -- the fence + flag
             // hand-over costs what the launch boundary did (profiles/r02_notes.md)
             static const bool chol_fuse = std::getenv("SSFM_CHOL_FUSE") && std::atoi(std::getenv("SSFM_CHOL_FUSE")) != 0;
-            const bool fused = chol_fuse && B.ntwist > 0 && B.nseg + B.ntwist <= ctx->num_cus;      // waiting workgroups must all be resident (one per compute unit)
+            const bool fused = chol_fuse && !wide2p && B.ntwist > 0 && B.nseg + B.ntwist <= ctx->num_cus;      // waiting workgroups must all be resident (one per compute unit)
             if (fused) { h->sub_fz_seq++;
                 SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp, chol_map,
                                   h->sub_fz_await.p, h->sub_fz_signal.p, h->sub_fz_flags.p, h->sub_fz_seq); }
+            else if (wide2p) SSFM_LAUNCH_CHOL2P(B.nseg, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr);       // (no cut components at these widths: twisted halves only)
             else SSFM_LAUNCH_CHOL2(B.nseg, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, (const int*)nullptr, Nc, b, failp, chol_map);
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
@@ -345,7 +367,8 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
-                if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map);
+                if (wide2p) SSFM_LAUNCH_CHOL2P(B.ntwist, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p);
+                else if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map);
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
@@ -361,7 +384,12 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             return SSFM_OK;
         }
         // LDS-resident path: the (b+1)^2-block window and the substitution rings fit the CU; one workgroup per component
-        if (use_lds) {
+        if (wide2p) {
+            SSFM_LAUNCH_CHOL2P(ncomp, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr);
+            h->span_begin(KID_BAND_BACK);
+            BACK_V2_LAUNCH(dim3(ncomp, 2), h->band.p, h->Linv.p, Y, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b);
+            h->span_end();
+        } else if (use_lds) {
             SSFM_LAUNCH_CHOL2(ncomp, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1, h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL), chol_map);
             if (back_v2) {
                 h->span_begin(KID_BAND_BACK);
@@ -371,34 +399,14 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
             }
         } else {
-            // Round 4: bands too wide for the square window ring (6x6 blocks, half-width 22..30) keep an LDS-resident factorisation through the PACKED window of
-            // band_kernels2p.h (the live triangle only: 109 KB at half-width 26) and the workgroup back substitution; whole components (the planner does not twist or
-            // cut bands this wide).  One connected ring of 300 cameras at half-width 26: 4.0 + 1.1 us per block row against 6.2 + 1.9 for the global-memory pair below
-            // (scripts/lab/chol_lab3.hip, profiles/r04_notes.md).  SSFM_BAND_PACKED=0 keeps the global-memory kernels.
-            const bool packed_on = !(std::getenv("SSFM_BAND_PACKED") && std::atoi(std::getenv("SSFM_BAND_PACKED")) == 0);
-            bool done = false;
-            if constexpr (DC == 6) {
-                const size_t lds2p = chol2p_lds_bytes(b, 2);
-                const int tasks2p = (b * (b + 1) / 2) * 4 - 4 + b * DC;
-                if (packed_on && b >= 1 && lds2p <= 160 * 1024 && tasks2p <= 3 * 12 * 64 && b * BB <= 2 * 1024 && (b + 1) * BB + 2 * DC <= 9 * 128 && b * DC <= 256) {
-#define SSFM_LAUNCH_2P(NPB_, PRE_)                                                                                                                                        \
-                    do { SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, 3, NPB_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p)); \
-                         LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2p<2, 3, NPB_, PRE_>), ncomp, 1024, lds2p, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->comp_ptr.p, h->comp_ptr.p + 1,        \
-                                h->comp_ptr.p + 1, (const int*)nullptr, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL)); } while (0)
-                    if (b * BB <= 1024 && (b + 1) * BB + 2 * DC <= 8 * 128) SSFM_LAUNCH_2P(1, 8); else SSFM_LAUNCH_2P(2, 9);      // one panel entry per thread up to half-width 27
-#undef SSFM_LAUNCH_2P
-                    LAUNCH(h, KID_BAND_BACK, (k_band_back_lds<DC, 2>), ncomp, 256, lds_sub2, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nc, b);
-                    done = true;
-                }
-            }
-            if (!done) {
-                LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, Y, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
-                LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
-            }
+            LAUNCH(h, KID_BAND_CHOL, (k_band_chol<DC, 2>), 1, 1024, lds_chol, h->band.p, h->Linv.p, Y, h->band_pairs.p, Nc, b, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+            LAUNCH(h, KID_BAND_BACK, (k_band_back<DC, 2>), 1, 256, lds_sub2, h->band.p, h->Linv.p, Y, Nc, b);
         }
         return SSFM_OK;
 #undef SSFM_LAUNCH_CHOL2
 #undef SSFM_LAUNCH_CHOL2_V
+#undef SSFM_LAUNCH_CHOL2P
+#undef SSFM_LAUNCH_2P
     }
 
 // Second solve with the factor of band_direct (PCG refinement): forward + back substitution of the first column of Y with the stored
@@ -413,9 +421,10 @@ static int band_resolve(ssfm_ba_handle* h, double* Y, bool* needs_refactor) {
     const int ncomp = (int)F.comp_ptr.size() - 1;
     const size_t lds_win = ((size_t)(b + 1) * (b + 1) * BB + (size_t)b * BB + (size_t)(b + 1) * 2 * DC + 2 * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
     const bool use_lds = lds_win <= 140 * 1024 && b >= 1;
-    const bool back_v2 = use_lds && b * DC <= 128;
+    const bool wide2p = band_wide_packed(DC, b, use_lds);
+    const bool back_v2 = (use_lds && b * DC <= 128) || wide2p;
     const size_t lds_sub1 = (size_t)(2 * (size_t)b * DC + DC) * sizeof(double);
-    *needs_refactor = h->sub.enabled && use_lds && back_v2;
+    *needs_refactor = h->sub.enabled && (use_lds || wide2p) && back_v2;
     if (*needs_refactor) return SSFM_OK;
     if (use_lds) {
         LAUNCH(h, KID_BAND_FWD, (k_band_fwd_lds<DC, 1>), ncomp, 256, lds_sub1, h->band.p, h->Linv.p, Y, h->comp_ptr.p, Nb, b);

@@ -523,11 +523,12 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 }
 
 // Back substitution Y <- L^-T Y.  grid (components, NR), ONE wave per block.  Task t = (d-1)*DC + a (d = 1..b) owns the pending
-// sum of row j-(d-1), component a; lanes carry tasks t = lane and t = lane + 64 (b*DC <= 128).  The factor streams from
+// sum of row j-(d-1), component a; a lane carries tasks t = lane + 64 s, s < NS (b*DC <= 64 NS).  The factor streams from
 // global memory BACK_PD steps ahead (a step is shorter than one memory latency), loads unconditional from clamped addresses.
 constexpr int BACK_PD = 4;
-// WIDE: b * DC > 64, a lane carries two tasks (lane and lane + 64); narrow bands (half-width <= 10 at 6-dof blocks) skip the second set altogether
-template <int DC, bool WIDE>
+// NS task sets per lane: 1 for b * DC <= 64 (half-width <= 10 at 6-dof blocks: the second set of loads / sums is compiled out), 2 up to 128, 3 up to 192
+// (round 4: half-widths 22..30, the packed-window factorisation of band_kernels2p.h, twisted components included)
+template <int DC, int NS>
 __global__ void __launch_bounds__(64)
 k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
                const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b) {
@@ -541,15 +542,17 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
     const int gf = given_from ? given_from[blockIdx.x] : -1;
     double* y = Y + (size_t)blockIdx.y * n;
     const int T = b * DC;
-    const int t0 = min(lane, T - 1), t1 = min(lane + 64, T - 1);            // clamped: lanes without a task recompute a valid one and are masked
-    const int d0 = t0 / DC + 1, a0 = t0 - (d0 - 1) * DC, d1 = t1 / DC + 1, a1 = t1 - (d1 - 1) * DC;
-    const bool has0 = lane < T, has1 = lane + 64 < T;
+    int dd[NS], off[NS]; bool has[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int t = min(lane + 64 * s, T - 1);                    // clamped: lanes without a task recompute a valid one and are masked
+        dd[s] = t / DC + 1; off[s] = dd[s] * BB + (t - (dd[s] - 1) * DC); has[s] = lane + 64 * s < T;
+    }
     const int lc = min(lane, DC - 1);
-    struct Stage { double col0[DC], col1[DC], li[DC], yv; };
+    struct Stage { double col[NS][DC], li[DC], yv; };
     Stage st[BACK_PD];
     // the row is wave-uniform: a scalar base per row and a 32-bit lane offset per stream (the per-lane 64-bit products of a flat index cost
     // ~16 vector instructions per step of a kernel whose step is bound by the instructions ONE wave can issue)
-    const int o0 = d0 * BB + a0, o1 = d1 * BB + a1;
     const size_t row_stride = (size_t)W * BB;
     auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
         const int jc = max(j, r0);
@@ -557,8 +560,8 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
         const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
 #pragma unroll
         for (int m = 0; m < DC; m++) {
-            s.col0[m] = rowp[o0 + m * DC];
-            if (WIDE) s.col1[m] = rowp[o1 + m * DC];
+#pragma unroll
+            for (int q = 0; q < NS; q++) s.col[q][m] = rowp[off[q] + m * DC];
             s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
         }
         const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
@@ -566,36 +569,52 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
     };
 #pragma unroll
     for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
-    double acc0 = 0.0, acc1 = 0.0;         // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
+    double acc[NS];                        // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
+#pragma unroll
+    for (int q = 0; q < NS; q++) acc[q] = 0.0;
     for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
 #pragma unroll
         for (int u = 0; u < BACK_PD; u++) {
             const int j = jb - u;
             if (j < r0) break;
-            double c0[DC], c1[DC], cl[DC]; const double cy = st[u].yv;
-            const bool v0 = has0 && j - d0 >= r0, v1 = has1 && j - d1 >= r0;       // rows above the component do not exist: their terms are dropped below
+            double c[NS][DC], cl[DC]; const double cy = st[u].yv;
+            bool v[NS];
 #pragma unroll
-            for (int m = 0; m < DC; m++) { c0[m] = st[u].col0[m]; c1[m] = WIDE ? st[u].col1[m] : 0.0; cl[m] = st[u].li[m]; }
+            for (int q = 0; q < NS; q++) v[q] = has[q] && j - dd[q] >= r0;       // rows above the component do not exist: their terms are dropped below
+#pragma unroll
+            for (int m = 0; m < DC; m++) {
+#pragma unroll
+                for (int q = 0; q < NS; q++) c[q][m] = st[u].col[q][m];
+                cl[m] = st[u].li[m];
+            }
             fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
-            // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc0
-            const double z = cy - acc0;                             // lanes 0..DC-1
+            // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc[0]
+            const double z = cy - acc[0];                           // lanes 0..DC-1
             // the shift does not depend on x_j: issue it before the dependent chain
-            const double sh0 = lane_shift_down(acc0, DC), sh1 = WIDE ? lane_shift_down(acc1, DC) : 0.0;
-            double sft0 = (lane + DC < 64) ? sh0 : sh1;             // lanes near the top of set 0 take from the bottom of set 1
-            if (!(lane + DC < T)) sft0 = 0.0;
-            double sft1 = (lane + DC < 64) ? sh1 : 0.0;
-            if (!(lane + 64 + DC < T)) sft1 = 0.0;
+            double sh[NS], sft[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) sh[q] = lane_shift_down(acc[q], DC);
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const double next = (q + 1 < NS) ? sh[q + 1 < NS ? q + 1 : q] : 0.0;       // lanes near the top of a set take from the bottom of the next one
+                sft[q] = (lane + DC < 64) ? sh[q] : next;
+                if (!(lane + 64 * q + DC < T)) sft[q] = 0.0;
+            }
             double x = 0.0;
 #pragma unroll
             for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
             if (j >= r1) x = cy;                                               // given
             else if (lane < DC) y[(size_t)j * DC + lane] = x;
-            double s0 = 0.0, s1 = 0.0;
+            double sm[NS];
 #pragma unroll
-            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m); s0 += c0[m] * xm; if (WIDE) s1 += c1[m] * xm; }
-            s0 = v0 ? s0 : 0.0; s1 = v1 ? s1 : 0.0;                            // (one select per sum instead of one per loaded entry)
+            for (int q = 0; q < NS; q++) sm[q] = 0.0;
+#pragma unroll
+            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m);
+#pragma unroll
+                for (int q = 0; q < NS; q++) sm[q] += c[q][m] * xm; }
             // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
-            acc0 = sft0 + s0; if (WIDE) acc1 = sft1 + s1;
+#pragma unroll
+            for (int q = 0; q < NS; q++) acc[q] = sft[q] + (v[q] ? sm[q] : 0.0);      // (one select per sum instead of one per loaded entry)
         }
     }
 }

@@ -161,7 +161,7 @@ def test_signature_groups_of_the_plan(monkeypatch):
     p = synth.make_circle(300, 100000, 6, spherical=False)                 # config 2: every point of a camera window has the same six cameras
     info = ba.plan(p)[0]
     assert info["num_points_grouped"] == 100000 and info["num_observations_grouped"] == 600000
-    assert info["group_tasks"] == 1800                                      # 600 runs of 166..167 points in tasks of <= 64
+    assert info["group_tasks"] == 900                                       # 300 runs of 333..334 points, each cut in 3 equal tasks (round 4: at most 4 x CUs tasks, one wave per SIMD)
     parts = [ba.plan(p, 4, r)[0] for r in range(4)]                        # sharded: every rank groups its own points
     assert sum(q["num_points_grouped"] for q in parts) >= 100000 - 4 * 4 * 32 and all(q["num_points_grouped"] <= q["num_points_used"] for q in parts)
     # ten cameras per point: more than a task holds; SSFM_GRAM_KMIN: a lower bound on the camera list; SSFM_GRAM=0: off
