@@ -21,6 +21,24 @@ def test_band_solver_matches_dense_solve(gpu_ctx, monkeypatch, dc, b, rows, P):
     assert np.abs(X - xr).max() <= 1e-12 * np.abs(xr).max()
 
 
+@pytest.mark.parametrize("b,rows", [(21, [70, 95]), (22, [60, 23, 101]), (26, [120]), (26, [27, 26, 9]), (30, [64, 31, 150])])
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_wide_band_packed_window_matches_dense_solve(gpu_ctx, monkeypatch, b, rows, packed):
+    """Half-widths beyond the square LDS window ring (6x6 blocks, 21..30): the packed-window factorisation of round 4 (band_kernels2p.h) + the back substitution with
+    three task sets per lane, components longer and shorter than the window; SSFM_BAND_PACKED=0: the global-memory kernels they replace."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_BAND_PACKED", packed)
+    monkeypatch.setenv("SSFM_BAND_SEGMENTS", "1")
+    band, A, cp, rhs = R.random_band_system(rows, b, 6, seed=600 + b)
+    X, info = ba.band_solve_probe(gpu_ctx, 6, cp, band, rhs)
+    assert info["failed"] == 0
+    xr = np.linalg.solve(A, rhs.T).T
+    assert np.abs(X - xr).max() <= 1e-12 * np.abs(xr).max()
+    if packed == "1":
+        band[rows[0] // 2, 0] -= np.eye(6) * 1e4               # a non-positive pivot raises the flag on this path too
+        assert ba.band_solve_probe(gpu_ctx, 6, cp, band, rhs)[1]["failed"] == 1
+
+
 @pytest.mark.parametrize("dc,b,rows,P", [(6, 5, [130], 4), (6, 5, [160, 171], 5), (6, 14, [420], 6), (3, 9, [300, 310], 7), (6, 7, [330], 10), (6, 3, [64], 4)])
 def test_two_sided_separator_chain(gpu_ctx, monkeypatch, dc, b, rows, P):
     """Chains of three or more separators are eliminated from both ends by two workgroups that meet at the middle separator (band_sub.h 4b):
