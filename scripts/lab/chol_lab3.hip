@@ -93,10 +93,14 @@ int run(int ncomp, int ncam, int b, int reps) {
             printf("v2p: lds %zu B, tasks %d\n", lds2p, nblk);
 #define V2P(NT_, NPB_, PRE_, NW_) do { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, NT_, NPB_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p)); \
             bench("v2p <" #NT_ "," #NPB_ "," #PRE_ "> " #NW_ " waves", [&] { hipLaunchKernelGGL((k_band_chol_v2p<2, NT_, NPB_, PRE_>), dim3(ncomp), dim3(64 * NW_), lds2p, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail); }, back_any); } while (0)
+#define V2P6(NPB_, PRE_, NW_) do { const size_t l6 = chol2p_lds_bytes(b, NR, true); if (l6 <= 160 * 1024) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2p<2, 1, NPB_, PRE_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6)); \
+            bench("v2p 6x6 <1," #NPB_ "," #PRE_ "> " #NW_ " waves", [&] { hipLaunchKernelGGL((k_band_chol_v2p<2, 1, NPB_, PRE_, true>), dim3(ncomp), dim3(64 * NW_), l6, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail); }, back_any); } } while (0)
+            if (b <= 14) { V2P6(1, 5, 8); V2P6(1, 5, 12); } else if (b <= 26) { V2P6(2, 8, 12); } else V2P6(2, 9, 12);
             if (b <= 14) { V2P(1, 1, 5, 12); V2P(2, 1, 5, 9); }
             else if (b <= 26) { V2P(3, 1, 8, 16); V2P(2, 1, 8, 16); }
             else V2P(3, 2, 9, 16);
 #undef V2P
+#undef V2P6
         }
     }
     if (lds_new <= 140 * 1024)      // (the product's limit for the square window ring)
@@ -133,11 +137,10 @@ int run(int ncomp, int ncam, int b, int reps) {
 int main(int argc, char** argv) {
     setvbuf(stdout, NULL, _IONBF, 0);
     const int reps = 50;
-    run<6>(4, 75, 10, reps);
-    run<6>(4, 75, 14, reps);
     run<6>(1, 300, 14, 20);
     run<6>(1, 300, 22, 20);
     run<6>(1, 300, 26, 20);
+    run<6>(1, 300, 28, 20);
     run<6>(2, 150, 30, 20);
     return 0;
 }

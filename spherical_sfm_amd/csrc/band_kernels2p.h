@@ -21,16 +21,18 @@ namespace ssfm {
 
 __device__ __host__ __forceinline__ int win2p_base(int d, int b) { return d * (b + 1) - d * (d - 1) / 2; }
 __device__ __forceinline__ int win2p_slot(int i, int d, int b) { return win2p_base(d, b) + i % (b + 1 - d); }
-inline size_t chol2p_lds_bytes(int b, int NR) {
+inline size_t chol2p_lds_bytes(int b, int NR, bool t6 = false) {
     constexpr int DC = 6, BB = 36;
-    return ((size_t)(b + 1) * (b + 2) / 2 * BB + (size_t)b * BB + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
+    return ((size_t)(b + 1) * (b + 2) / 2 * BB + (size_t)b * BB * (t6 ? 2 : 1) + (size_t)(b + 1) * NR * DC + NR * DC + 2 * BB) * sizeof(double) + ((size_t)b * (b + 1) / 2 + 2) * sizeof(int);
 }
 
 //   band / Ginv / Y / pairs / piv_lo / piv_hi / win_hi / merge_from / await2 / signal / flags: exactly as k_band_chol_v2.
 // blockDim.x = 64 * (1 + ntw + 2 + 1), ntw trailing waves with NTASK * 64 * ntw >= 4 (b (b+1) / 2 - 1) + 6 b; NPB * blockDim.x >= 36 b;
 // PRE * 128 >= 36 (b+1) + 6 NR.
-template <int NR, int NTASK, int NPB, int PRE>
-__global__ void __launch_bounds__(1024)
+// T6: the trailing update on 6x6 tiles, one block per lane (operands as ds_read_b128 from a transposed copy of the panel, the block read and written once as 18 + 18
+// ds_*_b128): 404 KB of LDS traffic per step at half-width 26 against 606 KB for the 3x3 tiles, and one task per lane instead of three.
+template <int NR, int NTASK, int NPB, int PRE, bool T6 = false>
+__global__ void __launch_bounds__(T6 ? 768 : 1024)      // T6: twelve waves (eight trailing x 64 lanes >= blocks + right-hand sides up to half-width 29) leave 168 VGPRs for the 36 accumulators
 k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                 const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
                 const int* __restrict__ merge_from, int N, int b, int* __restrict__ fail_flag,
@@ -44,7 +46,8 @@ k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __
     double* sYj = sYr + (size_t)R * NR * DC;                // [NR][DC]   final y_j
     double* sG = sYj + NR * DC;                             // [BB]       inverse factor of the current diagonal block
     double* sD = sG + BB;                                   // [BB]       scratch: updated next diagonal block
-    int* sPairs = reinterpret_cast<int*>(sD + BB);
+    double* sPT = sD + BB;                                  // [b][BB]    T6: the panel transposed, X_k[m][a] at m*6 + a
+    int* sPairs = reinterpret_cast<int*>(sPT + (T6 ? (size_t)b * BB : 0));
     const int n = N * DC, nt = blockDim.x, lane = threadIdx.x & 63, nw = nt >> 6, tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ntw = nw - 2 - LOADERS;
@@ -125,6 +128,7 @@ k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __
 #pragma unroll
                 for (int m = 0; m < DC; m++) x += A[m] * Gc[m];
                 sP[tid + u * nt] = x;
+                if (T6) sPT[pbk[u] * BB + (pbc[u] / DC) * DC + pbo[u] / DC] = x;       // X_k[a][c] -> [k][c][a]
             }
             pbcnt[u] = (pbcnt[u] + 1 == pbm[u]) ? 0 : pbcnt[u] + 1;
         }
@@ -180,7 +184,7 @@ k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __
     } else if (wave <= ntw) {
         // ---- trailing update + right-hand sides: NTASK fixed tasks per lane.  Task t < nblk: 3x3 tile (pair, row part, column part) of block (j+ir, j+kr);
         // nblk <= t < nblk + b DC: right-hand-side row
-        constexpr int TR = 3, TP = 2, TPB = 4;
+        constexpr int TR = 3, TP = 2, TPB = T6 ? 1 : 4;
         const int cw = ntw * 64, ct = tid - 64, npair = b * (b + 1) / 2, nblk = npair * TPB - TPB;
         int kind[NTASK], t_ir[NTASK], t_kr[NTASK], offi[NTASK], offk[NTASK], offd[NTASK], tm[NTASK], tcnt[NTASK];
 #pragma unroll
@@ -188,7 +192,7 @@ k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __
             const int t = ct + u * cw;
             kind[u] = (t < nblk) ? 0 : (t < nblk + b * DC) ? 1 : 2;
             if (kind[u] == 0) {
-                const int tt = t + TPB, pr = tt / TPB, sub = tt - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
+                const int tt = t + TPB, pr = tt / TPB, sub = tt - pr * TPB, a0 = T6 ? 0 : (sub / TP) * TR, c0 = T6 ? 0 : (sub - (sub / TP) * TP) * TR;
                 const int pk = sPairs[pr], ir = pk & 0xffff, kr = pk >> 16, d = ir - kr;
                 t_ir[u] = ir; t_kr[u] = kr; offi[u] = (ir - 1) * BB + a0 * DC; offk[u] = (kr - 1) * BB + c0 * DC;
                 offd[u] = win2p_base(d, b) * BB + a0 * DC + c0; tm[u] = b + 1 - d; tcnt[u] = (r0 + ir) % tm[u];
@@ -204,7 +208,35 @@ k_band_chol_v2p(double* __restrict__ band, double* __restrict__ Ginv, double* __
             lds_barrier();
 #pragma unroll
             for (int u = 0; u < NTASK; u++) {
-                if (kind[u] == 0) {
+                if (T6 && kind[u] == 0) {
+                    if (t_ir[u] <= nb) {
+                        typedef double d2_ __attribute__((ext_vector_type(2)));
+                        double* dst = sWin + (size_t)tcnt[u] * BB + offd[u];
+                        const double* pi = sPT + offi[u];
+                        const double* pk = sPT + offk[u];
+                        double acc[6][6];
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int c = 0; c < 6; c += 2) { const d2_ v = *reinterpret_cast<const d2_*>(dst + a * 6 + c); acc[a][c] = v.x; acc[a][c + 1] = v.y; }
+#pragma unroll
+                        for (int m = 0; m < 6; m++) {
+                            double la[6], lk[6];
+#pragma unroll
+                            for (int q = 0; q < 6; q += 2) { const d2_ v = *reinterpret_cast<const d2_*>(pi + m * 6 + q); la[q] = v.x; la[q + 1] = v.y;
+                                                             const d2_ w = *reinterpret_cast<const d2_*>(pk + m * 6 + q); lk[q] = w.x; lk[q + 1] = w.y; }
+#pragma unroll
+                            for (int a = 0; a < 6; a++)
+#pragma unroll
+                                for (int c = 0; c < 6; c++) acc[a][c] -= la[a] * lk[c];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int c = 0; c < 6; c += 2) *reinterpret_cast<d2_*>(dst + a * 6 + c) = d2_{acc[a][c], acc[a][c + 1]};
+                    }
+                    tcnt[u] = (tcnt[u] + 1 == tm[u]) ? 0 : tcnt[u] + 1;
+                } else if (kind[u] == 0) {
                     if (t_ir[u] <= nb) {
                         const double* Li_ = sP + offi[u];
                         const double* Lk_ = sP + offk[u];
