@@ -107,6 +107,7 @@ int main() {
     }
     // signature groups: blocks of consecutive points that share their camera list (runs of 20..90 points, lists of 2..10 cameras, every now and then a loose point
     // inside a run), host-built pair lists, 1..3 ranks, with and without the K >= 4 rule
+    setenv("SSFM_GRAM_MODEL", "0", 1);                   // keep every group that qualifies: the planner's cost model (round 4) would leave these small mixed problems to the pair lists
     for (int trial = 0; trial < 6; trial++) {
         const int Nc = 40 + (int)(rng() % 200), Np = 6000; std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
         std::vector<uint8_t> rf(Nc, 0), tf(Nc, trial % 2), pf(Np, 0);
@@ -150,6 +151,32 @@ int main() {
                           ocam.data(), opt.data(), oxy.data());
         acc += npts + nobs;
     }
+    // signature sort (round 4): camera lists interleaved point by point -- no run in the caller's order, runs of 300 after the planner's re-ordering; 1..3 ranks, both
+    // with the cost model off (groups kept) and on
+    for (int trial = 0; trial < 4; trial++) {
+        const int Nc = 30 + (int)(rng() % 50), Np = 1200, NS = 4; std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
+        std::vector<uint8_t> rf(Nc, 0), tf(Nc, 0), pf(Np, 0);
+        for (auto& v : pts) v = (rng() % 100) / 10.0 + 0.5;
+        int first[NS], len[NS]; for (int q = 0; q < NS; q++) { first[q] = (int)(rng() % Nc); len[q] = 3 + (int)(rng() % 6); }
+        for (int j = 0; j < Np; j++) {
+            const int q = j % NS; std::vector<int> cs; for (int k = 0; k < len[q]; k++) cs.push_back((first[q] + k) % Nc);
+            std::sort(cs.begin(), cs.end());
+            for (int c : cs) { oc.push_back(c); op.push_back(j); xy.push_back(1.0); xy.push_back(2.0); }
+        }
+        double focal = 800.0;
+        ssfm_ba_problem P;
+        P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
+        P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = 1;
+        if (trial % 2) unsetenv("SSFM_GRAM_MODEL"); else setenv("SSFM_GRAM_MODEL", "0", 1);
+        long grouped = 0;
+        for (int nr = 1; nr <= 3; nr++) for (int r = 0; r < nr; r++) {
+            ssfm::BAFlat F; ssfm::ba_flatten(P, nr, r, F); acc += check(F, Nc); grouped += F.gram_points;
+            if (!F.gram_sorted) { std::printf("signature sort did not run\n"); std::abort(); }
+            std::vector<char> seen(Np, 0); for (int q = 0; q < F.nP; q++) { if (F.pt_ids[q] < 0 || F.pt_ids[q] >= Np || seen[F.pt_ids[q]]) { std::printf("sorted ids are not a permutation\n"); std::abort(); } seen[F.pt_ids[q]] = 1; }
+        }
+        if (trial % 2 == 0 && grouped < 3 * (Np - NS * 32 * 3)) { std::printf("sorted problem not grouped: %ld\n", grouped); std::abort(); }
+    }
+    unsetenv("SSFM_GRAM_MODEL");
     std::printf("SANITIZE_OK %ld\n", acc);
     return 0;
 }
