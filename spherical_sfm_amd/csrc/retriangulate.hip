@@ -746,13 +746,27 @@ using namespace ssfm;
 // repeated (camera, point) key (std::map semantics, src/sfm.cpp:164-169).  obs_index[k] = position of compacted observation k in the caller's arrays.
 static void tri_point_lists(const ssfm_ba_problem* p, std::vector<int>& pt_start, std::vector<int>& ocam, std::vector<double>& oxy, std::vector<int64_t>* obs_index) {
     const int Nc = p->num_cameras, Np = p->num_points; const int64_t M = p->num_observations;
-    std::vector<int64_t> order(M);
-    for (int64_t i = 0; i < M; i++) order[i] = i;
     bool sorted = true;
     for (int64_t i = 1; i < M && sorted; i++) if (p->obs_pt[i] < p->obs_pt[i - 1] || (p->obs_pt[i] == p->obs_pt[i - 1] && p->obs_cam[i] <= p->obs_cam[i - 1])) sorted = false;
+    pt_start.assign(Np + 1, 0); ocam.clear(); oxy.clear();
+    if (obs_index) obs_index->clear();
+    if (sorted) {
+        // point-major, cameras strictly ascending (what the SfM mirror hands over): no duplicates, no permutation -- one pass of plain copies
+        bool in_range = true;
+        for (int64_t i = 0; i < M && in_range; i++) in_range = p->obs_cam[i] >= 0 && p->obs_cam[i] < Nc && p->obs_pt[i] >= 0 && p->obs_pt[i] < Np;
+        if (in_range) {
+            ocam.assign(p->obs_cam, p->obs_cam + M); oxy.assign(p->obs_xy, p->obs_xy + 2 * M);
+            for (int64_t i = 0; i < M; i++) pt_start[p->obs_pt[i] + 1]++;
+            for (int j = 0; j < Np; j++) pt_start[j + 1] += pt_start[j];
+            if (obs_index) { obs_index->resize(M); for (int64_t i = 0; i < M; i++) (*obs_index)[i] = i; }
+            return;
+        }
+    }
+    std::vector<int64_t> order(M);
+    for (int64_t i = 0; i < M; i++) order[i] = i;
     if (!sorted) std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return p->obs_pt[a] != p->obs_pt[b] ? p->obs_pt[a] < p->obs_pt[b] : p->obs_cam[a] < p->obs_cam[b]; });
-    pt_start.assign(Np + 1, 0); ocam.clear(); oxy.clear(); ocam.reserve(M); oxy.reserve(2 * M);
-    if (obs_index) { obs_index->clear(); obs_index->reserve(M); }
+    ocam.reserve(M); oxy.reserve(2 * M);
+    if (obs_index) obs_index->reserve(M);
     int64_t i = 0;
     for (int j = 0; j < Np; j++) {
         while (i < M && p->obs_pt[order[i]] < j) i++;
