@@ -748,7 +748,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
             // Round 4: do the groups pay?  k_schur_gram is launched once per tile class (rows = DC K: {3}, {4, 5}, {6}, {7, 8} at 6 dof), and a launch of a few hundred
             // wave tasks costs its ~24 us latency floor whatever it holds: 300 cameras / 600k observations with tracks of 3..8 frames, sorted into 1800 signatures
             // of ~60 points, took 4 x 25 us through the groups against 44 + 21 us through the pair lists (scripts/prof_irregular.py, profiles/r04_notes.md).
-            // Estimated launch times from the measurements of rounds 3-4 (us): a class max(24, 0.45e-3 points K / 6); pair lists max(36, 22e-6 pairs) + camera sums
+            // Estimated launch times from the measurements of rounds 3-4 (us): a class max(24, 0.45e-3 points K / 6) (0.27e-3 beyond 300k points); pair lists max(36, 22e-6 pairs) + camera sums
             // max(20, 34.5e-6 observations).  The groups are kept when their estimate (+ the pair path for what stays loose) is below the pair path for everything.
             // SSFM_GRAM_MODEL=0 keeps every group that qualifies.
             if (!(std::getenv("SSFM_GRAM_MODEL") && std::atoi(std::getenv("SSFM_GRAM_MODEL")) == 0) && !runs.empty()) {
@@ -764,7 +764,9 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                     grouped_pairs += 0.5 * K * (K - 1) * (runs[r + 1] - runs[r]);
                 }
                 loose_pairs = all_pairs - grouped_pairs;
-                double est_gram = 0; for (double v : cls_pts) if (v > 0) est_gram += std::max(24.0, 0.45e-3 * v);
+                // per point: 0.45 ns in the latency-bound regime of one round of tasks (config 2: 100k points, 45 us), 0.27 ns once a class fills the chip for several
+                // rounds (configs[4] size: 1.5 M points of 8 cameras, 391 us)
+                double est_gram = 0; for (double v : cls_pts) if (v > 0) est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v);
                 const double obs_all = (double)F.pt_start[F.nP];
                 const double est_loose = loose_pairs > 0 ? std::max(36.0, 22e-6 * loose_pairs) + std::max(20.0, 34.5e-6 * obs_all) : 0.0;
                 const double est_pairs_only = std::max(36.0, 22e-6 * all_pairs) + std::max(20.0, 34.5e-6 * obs_all);
