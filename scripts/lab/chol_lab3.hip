@@ -103,6 +103,10 @@ int run(int ncomp, int ncam, int b, int reps) {
 #undef V2P6
         }
     }
+    if (lds_new <= 140 * 1024 && b * BB <= BB + 9 * 64 - 64) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
+        bench("v2 early look-ahead (9 waves)", [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2, 4>), dim3(ncomp), dim3(9 * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(9, 9 - 2 - CHOL2_LOADERS, 9 - 2 - CHOL2_LOADERS)); }, back_any);
+    }
     if (lds_new <= 140 * 1024)      // (the product's limit for the square window ring)
     for (int nw : {9}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);
@@ -137,7 +141,10 @@ int run(int ncomp, int ncam, int b, int reps) {
 int main(int argc, char** argv) {
     setvbuf(stdout, NULL, _IONBF, 0);
     const int reps = 50;
-    run<6>(1, 300, 14, 20);
+    run<6>(4, 75, 10, reps);
+    run<6>(8, 32, 10, reps);
+    run<6>(4, 75, 12, reps);
+    run<6>(4, 75, 14, reps);
     run<6>(1, 300, 22, 20);
     run<6>(1, 300, 26, 20);
     run<6>(1, 300, 28, 20);

@@ -314,8 +314,13 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL)); } } while (0)
 #define SSFM_LAUNCH_CHOL2P(grid_, lo_, hi_, wend_, merge_)                                                                                                   \
     do { if (t6) SSFM_LAUNCH_2P6(grid_, lo_, hi_, wend_, merge_); else if (b * BB <= 1024 && (b + 1) * BB + 2 * DC <= 8 * 128) SSFM_LAUNCH_2P(1, 8, grid_, lo_, hi_, wend_, merge_); else SSFM_LAUNCH_2P(2, 9, grid_, lo_, hi_, wend_, merge_); } while (0)
+    // early look-ahead (band_kernels2.h, MF bit 2; experiment, off): the look-ahead wave computes X_1 and the update of the next diagonal block before barrier A.  Measured
+    // in the lab (scripts/lab/chol_lab3.hip, same run): 89.8 against 79.9 us for 4 x 75 rows at half-width 10, 106.2 / 98.3 at 12, 124.9 / 123.2 at 14 -- once the pivot test
+    // left the factorisation's chain the step is bound by the trailing waves, and the longer stretch in front of barrier A only delays them.  SSFM_BAND_EARLY=1 selects it.
+    static const bool early_on = std::getenv("SSFM_BAND_EARLY") && std::atoi(std::getenv("SSFM_BAND_EARLY")) != 0;
+    const bool early = early_on && mf == 0 && b * BB <= BB + chol_threads - 64;
 #define SSFM_LAUNCH_CHOL2(grid_, ...)                                                                                                       \
-    do { if (mf == 3) SSFM_LAUNCH_CHOL2_V(MFB, grid_, __VA_ARGS__); else if (mf == 2) SSFM_LAUNCH_CHOL2_V(MFT, grid_, __VA_ARGS__);          \
+    do { if (early) SSFM_LAUNCH_CHOL2_V(4, grid_, __VA_ARGS__); else if (mf == 3) SSFM_LAUNCH_CHOL2_V(MFB, grid_, __VA_ARGS__); else if (mf == 2) SSFM_LAUNCH_CHOL2_V(MFT, grid_, __VA_ARGS__);          \
          else if (mf == 1) SSFM_LAUNCH_CHOL2_V(MFP, grid_, __VA_ARGS__); else SSFM_LAUNCH_CHOL2_V(0, grid_, __VA_ARGS__); } while (0)
         if (h->sub.enabled && (use_lds || wide2p) && back_v2) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)

@@ -122,6 +122,13 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
     y = y * (1.5 - h * y * y);
     return y;
 }
+// The same to full precision with ONE third-order step: v_rsq_f64 is good to 5e-8 (scripts/lab/rsq_lab.hip), e = 1 - d y^2, y (1 + e/2 + 3 e^2 / 8) leaves an
+// error of order e^3 = 1e-22.  Five dependent instructions instead of seven: for the factor-and-invert chain of the band kernels, where instructions are time.
+__device__ __forceinline__ double fast_rsqrt3(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
 // sqrt(rho'(s)) of robust_loss (ssfm_math.h): Cauchy 1/sqrt(1 + s/a^2) is ONE reciprocal square root
 __device__ __forceinline__ double loss_sqrt_weight(int type, double a, double s) {
     if (type == 1) return fast_rsqrt(1.0 + s * fast_rcp(a * a));

@@ -35,8 +35,11 @@ __device__ __forceinline__ bool wave_chol_inverse(double (&row)[DC], double (&g)
 #pragma unroll
     for (int c = 0; c < DC; c++) {
         double d = lane_bcast(row[c], c);
-        if (!(d > 0.0)) { ok = false; d = 1.0; }
-        rs[c] = fast_rsqrt(d);
+        // round 4: the pivot test no longer feeds the chain (it used to replace a bad pivot by 1.0: two selects in front of every reciprocal square root); a
+        // non-positive or NaN pivot makes the factor NaN / inf, the caller raises the failure flag and the LM loop discards the step, as before
+        ok = ok && (d > 0.0);
+        rs[c] = fast_rsqrt(d);                           // (a third-order single step, fast_rsqrt3, saves two instructions per column and measured 0.4 %: not worth a change of rounding --
+                                                         //  the 2000-node pose graph of tests/test_rotavg_gpu.py sits on a chaotic path where that moves an accept / reject decision)
         const double l = row[c] * rs[c];                 // L[r][c] on lane r (meaningful for r >= c)
         L[c] = l;
 #pragma unroll
@@ -105,7 +108,7 @@ inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_
 // read-modify-write.  Against the 3x3 register tiles of the VALU version (54 LDS operations per 54 multiply-adds and lane, scattered over
 // the panel: the phase was LDS-conflict bound at ~80 B/clk) a tile is 8 conflict-free operand reads + 4 read-modify-writes per 1536
 // multiply-adds.  SSFM_BAND_MFMA=0 selects the VALU version.
-template <int DC, int NR, int MF = 0>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update
+template <int DC, int NR, int MF = 0>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
@@ -209,8 +212,13 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     const int li = lane & 15, lk = lane >> 4;
     // round 4: when every panel entry has a thread of its own (b BB <= threads: always in the shapes ba_handle.h launches) the entry's coordinates are the same in
     // every step -- two integer divisions and the address arithmetic leave the step loop (a step is ~10 ticks per instruction on every wave: profiles/r04_notes.md)
-    const bool pb_own = b * BB <= nt;
-    const int pb_k = tid / BB, pb_rc = tid - pb_k * BB, pb_a = pb_rc / DC, pb_c = pb_rc - pb_a * DC;
+    // MF bit 2 (round 4, "early look-ahead"): the look-ahead wave keeps block 0 of the panel (X_1, 36 entries) for itself and has it -- and with it the update of the
+    // next diagonal block -- done BEFORE barrier A, while the other waves compute the rest of the panel; its part after the barrier is the factorisation alone.
+    // Needs one panel entry per thread with the look-ahead wave's 28 other lanes left out: b BB <= 36 + threads - 64.
+    constexpr bool EARLY = (MF & 4) != 0;
+    const bool pb_own = EARLY ? true : (b * BB <= nt);
+    const int pb_e = EARLY ? ((wave == 0) ? (lane < BB ? lane : b * BB) : BB + tid - 64) : tid;
+    const int pb_k = pb_e / BB, pb_rc = pb_e - pb_k * BB, pb_a = pb_rc / DC, pb_c = pb_rc - pb_a * DC;
     const int pb_offA = (pb_k + 1) * BB + pb_a * DC;
     const double* pb_G = sG + pb_c * DC;
     auto phaseB = [&](int j, int jm, int nb) {
@@ -238,7 +246,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                 double x = 0.0;
 #pragma unroll
                 for (int m = 0; m < DC; m++) x += A[m] * pb_G[m];
-                sP[tid] = x;
+                sP[pb_e] = x;
             }
         } else
         for (int e = tid; e < nb * BB; e += nt) {
@@ -266,6 +274,39 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     if (wave == 0) {
         // ---- look-ahead: next diagonal block, its factor and inverse.  No global memory traffic.
         int jm = jm0;
+        if constexpr (EARLY) {
+            for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
+                const int nb = min(b, re - 1 - j);
+                phaseB(j, jm, nb);                                                   // this wave's share: X_1 = A(j+1, j) G_j^T -> block 0 of the panel
+                double row[DC], g[DC];
+                if (nb >= 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-local: X_1 is in LDS
+                    int s1 = jm + 1; if (s1 >= R) s1 -= R;
+                    double* dblk = sWin + (size_t)s1 * RW;                          // block (j+1, j+1): final since the trailing update of step j-1
+                    double* dout = (j + 1 < r1) ? sD : dblk;                        // last pivot of a segment: the first separator row takes the update in place
+#pragma unroll
+                    for (int e = lane; e < BB; e += 64) {
+                        const int a = e / DC, c = e - a * DC;
+                        double v = dblk[e];
+#pragma unroll
+                        for (int m = 0; m < DC; m++) v -= sP[a * DC + m] * sP[c * DC + m];
+                        dout[e] = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < DC; c++) row[c] = (lane < DC) ? sD[lane * DC + c] : ((lane == c) ? 1.0 : 0.0);
+                }
+                lds_barrier();
+                if (j + 1 < r1) {
+                    if (!wave_chol_inverse<DC>(row, g) && lane == 0) *fail_flag = 1;
+                    if (lane < DC) {
+#pragma unroll
+                        for (int r = 0; r < DC; r++) sG[r * DC + lane] = g[r];
+                    }
+                }
+                lds_barrier();
+            }
+        } else
         for (int j = r0; j < r1; j++, jm = (jm + 1 == R) ? 0 : jm + 1) {
             const int nb = min(b, re - 1 - j);
             phaseB(j, jm, nb);
