@@ -107,6 +107,14 @@ int run(int ncomp, int ncam, int b, int reps) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
         bench("v2 early look-ahead (9 waves)", [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2, 4>), dim3(ncomp), dim3(9 * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(9, 9 - 2 - CHOL2_LOADERS, 9 - 2 - CHOL2_LOADERS)); }, back_any);
     }
+    if (lds_new <= 140 * 1024) {     // 3x2 tiles: six tasks per block
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
+        const int blk6 = (b * (b + 1) / 2) * 6 - 6, w6 = (blk6 + 63) / 64 + 1;
+        for (int nw : {4 + w6, 4 + w6 + 1}) if (nw <= 16) {
+            char tag[64]; snprintf(tag, 64, "v2 3x2 tiles (%d waves)", nw);
+            bench(tag, [&] { hipLaunchKernelGGL((k_band_chol_v2<DC, 2, 0, 2>), dim3(ncomp), dim3(nw * 64), lds_new, st, dband, dG, dY, dpairs, dcomp, dcomp + 1, dcomp + 1, (const int*)nullptr, N, b, dfail, chol_wave_map(0, 0, 0)); }, back_any);
+        }
+    }
     if (lds_new <= 140 * 1024)      // (the product's limit for the square window ring)
     for (int nw : {9}) {
         char tag[64]; snprintf(tag, 64, "v2 (%d waves)", nw);

@@ -108,7 +108,7 @@ inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_
 // read-modify-write.  Against the 3x3 register tiles of the VALU version (54 LDS operations per 54 multiply-adds and lane, scattered over
 // the panel: the phase was LDS-conflict bound at ~80 B/clk) a tile is 8 conflict-free operand reads + 4 read-modify-writes per 1536
 // multiply-adds.  SSFM_BAND_MFMA=0 selects the VALU version.
-template <int DC, int NR, int MF = 0>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead
+template <int DC, int NR, int MF = 0, int TCW = 3>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead; TCW: columns of a trailing tile (3: 3x3 tiles, 2: 3x2)
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
@@ -349,7 +349,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     } else if (wave <= ntw) {
         // ---- trailing update of the window + right-hand sides (LDS only)
         // block tasks: (pair, row part, column part) -> TR x TR outputs in registers; pair 0 = (1,1) belongs to wave 0
-        constexpr int TR = (DC % 3 == 0) ? 3 : 1, TP = DC / TR, TPB = TP * TP;
+        constexpr int TR = (DC % 3 == 0) ? 3 : 1, TC = (DC % 3 == 0) ? TCW : 1, TP = DC / TC, TPB = (DC / TR) * TP;      // TP column parts, DC / TR row parts per block
         const int cw = ntw * 64, ct = tid - 64;
         int jm = jm0;
         if constexpr ((MF & 2) != 0) {
@@ -422,7 +422,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         // dependent path of the phase), tile coordinates and operand offsets are fixed before the loop
         const int own_t = ct + TPB, own_pr = min(own_t / TPB, b * (b + 1) / 2 - 1), own_sub = own_t - (own_t / TPB) * TPB;
         const int own_pk = sPairs[own_pr], own_ir = own_pk & 0xffff, own_kr = own_pk >> 16;
-        const int own_a0 = (own_sub / TP) * TR, own_c0 = (own_sub - (own_sub / TP) * TP) * TR;
+        const int own_a0 = (own_sub / TP) * TR, own_c0 = (own_sub - (own_sub / TP) * TP) * TC;
         const double* own_Li = sP + (size_t)(own_ir - 1) * BB + own_a0 * DC;
         const double* own_Lk = sP + (size_t)(own_kr - 1) * BB + own_c0 * DC;
         const int own_dst = (own_ir - own_kr) * BB + own_a0 * DC + own_c0;
@@ -432,37 +432,43 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
             lds_barrier();
             const int work = (nb * (nb + 1) / 2) * TPB;
             auto block_task_own = [&]() {
-                double la[TR][DC], lk[TR][DC];
+                double la[TR][DC], lk[TC][DC];
 #pragma unroll
-                for (int u = 0; u < TR; u++)
+                for (int m = 0; m < DC; m++) {
 #pragma unroll
-                    for (int m = 0; m < DC; m++) { la[u][m] = own_Li[u * DC + m]; lk[u][m] = own_Lk[u * DC + m]; }
+                    for (int u = 0; u < TR; u++) la[u][m] = own_Li[u * DC + m];
+#pragma unroll
+                    for (int u = 0; u < TC; u++) lk[u][m] = own_Lk[u * DC + m];
+                }
                 int si = jm + own_ir; if (si >= R) si -= R;
                 double* dst = sWin + (size_t)si * RW + own_dst;
 #pragma unroll
                 for (int u = 0; u < TR; u++)
 #pragma unroll
-                    for (int w = 0; w < TR; w++) { double v = 0.0;
+                    for (int w = 0; w < TC; w++) { double v = 0.0;
 #pragma unroll
                         for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
                         dst[u * DC + w] -= v; }
             };
             auto block_task = [&](int t) {
-                const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TR;
+                const int pr = t / TPB, sub = t - pr * TPB, a0 = (sub / TP) * TR, c0 = (sub - (sub / TP) * TP) * TC;
                 const int pk = sPairs[pr]; const int ir = pk & 0xffff, kr = pk >> 16;
                 const double* Li_ = sP + (size_t)(ir - 1) * BB + a0 * DC;
                 const double* Lk_ = sP + (size_t)(kr - 1) * BB + c0 * DC;
-                double la[TR][DC], lk[TR][DC];
+                double la[TR][DC], lk[TC][DC];
 #pragma unroll
-                for (int u = 0; u < TR; u++)
+                for (int m = 0; m < DC; m++) {
 #pragma unroll
-                    for (int m = 0; m < DC; m++) { la[u][m] = Li_[u * DC + m]; lk[u][m] = Lk_[u * DC + m]; }
+                    for (int u = 0; u < TR; u++) la[u][m] = Li_[u * DC + m];
+#pragma unroll
+                    for (int u = 0; u < TC; u++) lk[u][m] = Lk_[u * DC + m];
+                }
                 int si = jm + ir; if (si >= R) si -= R;
                 double* dst = sWin + (size_t)si * RW + (size_t)(ir - kr) * BB + a0 * DC + c0;
 #pragma unroll
                 for (int u = 0; u < TR; u++)
 #pragma unroll
-                    for (int w = 0; w < TR; w++) { double v = 0.0;
+                    for (int w = 0; w < TC; w++) { double v = 0.0;
 #pragma unroll
                         for (int m = 0; m < DC; m++) v += la[u][m] * lk[w][m];
                         dst[u * DC + w] -= v; }
