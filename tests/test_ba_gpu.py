@@ -158,3 +158,20 @@ def test_config3_size_shared_focal_free_parity(gpu_ctx, oracle, spherical):
     assert s["camera_dof"] == (3 if spherical else 6)
     assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
     assert abs(f - p.gt_focal) <= 2e-3 * p.gt_focal                     # 1.1 x f at the start, recovered
+
+
+@pytest.mark.parametrize("max_len,spherical,focal_fixed", [(14, False, True), (8, False, False), (14, True, False), (11, False, True)])
+def test_ragged_tracks_full_size_parity(gpu_ctx, oracle, max_len, spherical, focal_fixed):
+    """Round 4: the irregular structure of a real sequence at the metric's size -- 300 cameras, 600k observations, tracks of 3..max_len consecutive frames, point ids in
+    build_sfm's order (synth.make_ragged_circle).  One connected ring: half-width 2 (max_len - 1) -- 26 / 20 through the packed LDS window with twisted halves
+    (band_kernels2p.h), 14 through the square one --, points through the pair lists (the planner's cost model) after the signature sort's look at them."""
+    from spherical_sfm_amd import ba
+    p = synth.make_ragged_circle(300, 600000, 3, max_len, spherical=spherical, focal_fixed=focal_fixed)
+    info = ba.plan(p)[0]
+    assert info["band_half_width"] == 2 * (max_len - 1) // (2 if spherical else 1) or spherical      # (3-dof cameras are merged in pairs: half the block rows)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["num_residual_blocks"] == os_["num_residual_blocks"] == 600000
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-9 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
