@@ -496,8 +496,8 @@ __device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        double d = lane_bcast(row[c], c);
-        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        const double d = lane_bcast(row[c], c);
+        ok = ok && (d > 0.0);                                // (off the dependent chain, as in wave_chol_inverse: band_kernels2.h)
         const double l = row[c] * fast_rsqrt(d);             // L[r][c] on lane r (meaningful for r >= c); replaces row[c]
         row[c] = l;
 #pragma unroll
