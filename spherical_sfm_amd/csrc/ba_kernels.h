@@ -228,12 +228,28 @@ static __global__ void k_cam_rot(const double* __restrict__ cam, double* __restr
     for (int i = 0; i < 9; i++) { rot[c * 27 + i] = R[i]; rot[c * 27 + 9 + i] = Rd[i]; rot[c * 27 + 18 + i] = M[i]; }
 }
 
+// the first launch of a solve: rotation tables + the clears the iteration-0 sums need (two hipMemsetAsync launches less per solve)
+static __global__ void k_cam_rot0(const double* __restrict__ cam, double* __restrict__ rot, int Nc, double* __restrict__ z0, int n0, double* __restrict__ z1, int n1) {
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n0; i += blockDim.x) z0[i] = 0.0;
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) z1[i] = 0.0;
+    }
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nc) return;
+    double aa[3] = {cam[c * 6 + 3], cam[c * 6 + 4], cam[c * 6 + 5]};
+    double R[9], Rd[9], M[9];
+    angle_axis_derivative_aid(aa, R, Rd, M);
+    for (int i = 0; i < 9; i++) { rot[c * 27 + i] = R[i]; rot[c * 27 + 9 + i] = Rd[i]; rot[c * 27 + 18 + i] = M[i]; }
+}
+
 // ---- one-time: squared column norms of the unscaled robustified Jacobian (Jacobi scaling, iteration 0)
+// (each kernel also writes the Jacobi scale of the columns it owns: mask * 1/(1 + sqrt(norm^2)), problem_impl.cc / trust_region_minimizer.cc of Ceres 2.2)
 // points + focal: one lane per point;  cameras: one workgroup per camera over its observation list (no atomics)
 static __global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                           const int* __restrict__ pt_start, int nP, int loss, double la,
-                          double* __restrict__ diag_pt, double* __restrict__ diag_f) {
+                          double* __restrict__ diag_pt, double* __restrict__ diag_f,
+                          const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi) {
     __shared__ double red[8];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double df[1] = {0.0};
@@ -247,7 +263,7 @@ static __global__ void k_colnorm(const double* __restrict__ cam, const double* _
             for (int k = 0; k < 3; k++) dp[k] += L.Jp[0][k] * L.Jp[0][k] + L.Jp[1][k] * L.Jp[1][k];
             df[0] += L.Jf[0] * L.Jf[0] + L.Jf[1] * L.Jf[1];
         }
-        for (int k = 0; k < 3; k++) diag_pt[3 * p + k] = dp[k];
+        for (int k = 0; k < 3; k++) { diag_pt[3 * p + k] = dp[k]; scale_pt[3 * p + k] = mask_pt[3 * p + k] * (jacobi ? 1.0 / (1.0 + sqrt(dp[k])) : 1.0); }
     }
     block_sum<1>(df, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(diag_f, df[0]);
@@ -255,7 +271,8 @@ static __global__ void k_colnorm(const double* __restrict__ cam, const double* _
 static __global__ void __launch_bounds__(256)
 k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
               const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
-              const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam) {
+              const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam,
+              const double* __restrict__ mask_cam, double* __restrict__ scale_cam, int jacobi) {   // scale_cam == nullptr: the norms still need a sum over ranks
     __shared__ double red[6 * 4];
     const int c = blockIdx.x;
     double d[6] = {0, 0, 0, 0, 0, 0};
@@ -268,7 +285,10 @@ k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, co
         for (int k = 0; k < 3; k++) { d[k] += L.Jt[0][k] * L.Jt[0][k] + L.Jt[1][k] * L.Jt[1][k]; d[3 + k] += L.Jr[0][k] * L.Jr[0][k] + L.Jr[1][k] * L.Jr[1][k]; }
     }
     block_sum<6>(d, red);
-    if (threadIdx.x == 0) for (int k = 0; k < 6; k++) diag_cam[c * 6 + k] = d[k];
+    if (threadIdx.x == 0) for (int k = 0; k < 6; k++) {
+        diag_cam[c * 6 + k] = d[k];
+        if (scale_cam) scale_cam[c * 6 + k] = mask_cam[c * 6 + k] * (jacobi ? 1.0 / (1.0 + sqrt(d[k])) : 1.0);
+    }
 }
 static __global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1885,6 +1905,42 @@ static __global__ void k_sqnorm_masked(const double* __restrict__ v, const doubl
     double acc[1] = {(i < n && mask[i] > 0.0) ? v[i] * v[i] : 0.0};
     block_sum<1>(acc, red);
     if (threadIdx.x == 0 && acc[0] != 0.0) unsafeAtomicAdd(out, acc[0]);
+}
+
+// the last launch of iteration 0, one instead of up to six: |x|^2 of the free point and camera(+focal) entries, the focal scale and -- when the camera
+// column norms were summed over ranks first -- the camera scales.  Workgroups [0, gpt) take the points, the rest the cameras.
+static __global__ void k_startup_tail(const double* __restrict__ pts, const double* __restrict__ mask_pt, int n_pt, int gpt,
+                                      const double* __restrict__ cam, const double* __restrict__ mask_cam, int n_cam,
+                                      const double* __restrict__ focal, const double* __restrict__ mask_f,
+                                      const double* __restrict__ diag_cam, double* __restrict__ scale_cam,     // scale_cam == nullptr: already written
+                                      const double* __restrict__ diag_f, double* __restrict__ scale_f, int jacobi, // scale_f == nullptr: scales kept from an earlier solve
+                                      double* __restrict__ out_pt, double* __restrict__ out_cam) {
+    __shared__ double red[4];
+    const bool is_pt = (int)blockIdx.x < gpt;
+    const int i = (is_pt ? blockIdx.x : blockIdx.x - gpt) * blockDim.x + threadIdx.x;
+    double acc[1] = {0.0};
+    if (is_pt) { if (i < n_pt && mask_pt[i] > 0.0) acc[0] = pts[i] * pts[i]; }
+    else {
+        if (i < n_cam) {
+            if (mask_cam[i] > 0.0) acc[0] = cam[i] * cam[i];
+            if (scale_cam) scale_cam[i] = mask_cam[i] * (jacobi ? 1.0 / (1.0 + sqrt(diag_cam[i])) : 1.0);
+        }
+        if ((int)blockIdx.x == gpt && threadIdx.x == 0) {
+            if (mask_f[0] > 0.0) acc[0] += focal[0] * focal[0];
+            if (scale_f) scale_f[0] = mask_f[0] * (jacobi ? 1.0 / (1.0 + sqrt(diag_f[0])) : 1.0);
+        }
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0 && acc[0] != 0.0) unsafeAtomicAdd(is_pt ? out_pt : out_cam, acc[0]);
+}
+
+// the state [cameras | points | focal] from one set of buffers into another in ONE launch (three copy launches before): reset and the end of a solve
+static __global__ void k_copy_state(double* __restrict__ dc, const double* __restrict__ sc, int nc, double* __restrict__ dp, const double* __restrict__ sp, int np,
+                                    double* __restrict__ df, const double* __restrict__ sf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dp[i] = sp[i];
+    else if (i - np < nc) dc[i - np] = sc[i - np];
+    if (i == 0 && df) df[0] = sf[0];
 }
 
 // ---- parity probe: per-observation residual + 2x10 Jacobian (focal | t | r | X), robustified, unscaled

@@ -63,26 +63,26 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     };
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     h->set_zone(0);
-    LAUNCH(h, KID_CAM_ROT, k_cam_rot, gp_cam, 64, 0, cam_x, rot_x, Nc);
-    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->scal.p, 0, SC_TOTAL * sizeof(double), st));
-    if (!h->scale_ready) {
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->diag_f.p, 0, sizeof(double), st));
+    // four launches: [rotation tables + clears] [point column norms + scales] [camera column norms + scales] [|x|^2 + focal scale]
+    const bool make_scale = !h->scale_ready;
+    LAUNCH(h, KID_CAM_ROT, k_cam_rot0, gp_cam, 64, 0, cam_x, rot_x, Nc, h->scal.p, (int)SC_TOTAL, h->diag_f.p, make_scale ? 1 : 0);
+    if (make_scale) {
         if (nP > 0) hipLaunchKernelGGL(k_colnorm, dim3(gp_pts), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP,
-                                       loss, la, h->diag_pt.p, h->diag_f.p);
+                                       loss, la, h->diag_pt.p, h->diag_f.p, h->mask_pt.p, h->scale_pt.p, O.jacobi_scaling);
         hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
-                           loss, la, h->diag_cam.p);
+                           loss, la, h->diag_cam.p, h->mask_cam.p, ctx->collective ? (double*)nullptr : h->scale_cam.p, O.jacobi_scaling);
         if (ctx->collective) {   // camera / focal column norms are sums over every rank's observations
             int rc = allreduce(h, h->diag_cam.p, (size_t)Nc * 6, ncclSum); if (rc) return rc;
             rc = allreduce(h, h->diag_f.p, 1, ncclSum); if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_make_scale, dim3((Nc * 6 + 255) / 256), dim3(256), 0, st, h->diag_cam.p, h->mask_cam.p, h->scale_cam.p, Nc * 6, O.jacobi_scaling);
-        if (nP > 0) hipLaunchKernelGGL(k_make_scale, dim3((nP * 3 + 255) / 256), dim3(256), 0, st, h->diag_pt.p, h->mask_pt.p, h->scale_pt.p, nP * 3, O.jacobi_scaling);
-        hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->diag_f.p, h->mask_f.p, h->scale_f.p, 1, O.jacobi_scaling);
         h->scale_ready = true;
     }
-    if (nP > 0) hipLaunchKernelGGL(k_sqnorm_masked, dim3((nP * 3 + 255) / 256), dim3(256), 0, st, pts_x, h->mask_pt.p, nP * 3, h->scal.p + SC_X0N2_PT);
-    hipLaunchKernelGGL(k_sqnorm_masked, dim3((Nc * 6 + 255) / 256), dim3(256), 0, st, cam_x, h->mask_cam.p, Nc * 6, h->scal.p + SC_X0N2_CAM);
-    hipLaunchKernelGGL(k_sqnorm_masked, dim3(1), dim3(64), 0, st, fx, h->mask_f.p, 1, h->scal.p + SC_X0N2_CAM);
+    {
+        const int gpt = nP > 0 ? (nP * 3 + 255) / 256 : 0, gcm = (Nc * 6 + 255) / 256;
+        hipLaunchKernelGGL(k_startup_tail, dim3(gpt + gcm), dim3(256), 0, st, pts_x, h->mask_pt.p, nP * 3, gpt, cam_x, h->mask_cam.p, Nc * 6, fx, h->mask_f.p,
+                           h->diag_cam.p, (make_scale && ctx->collective) ? h->scale_cam.p : (double*)nullptr, h->diag_f.p, make_scale ? h->scale_f.p : (double*)nullptr,
+                           O.jacobi_scaling, h->scal.p + SC_X0N2_PT, h->scal.p + SC_X0N2_CAM);
+    }
     { int rc = allreduce(h, h->scal.p + SC_X0N2_PT, 1, ncclSum); if (rc) return rc; }
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -376,11 +376,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                         x_cost, cost_change, gmax, step_norm, rel, radius, pcg_iters, last_successful ? "" : "(rejected)");
     }
     // make the x buffers of the handle hold the final state
-    if (cam_x != h->cam_x.p) {
-        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->cam_x.p, cam_x, (size_t)Nc * 6 * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->pts_x.p, pts_x, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (cam_x != h->cam_x.p || fx != h->focal3.p) {
+        const int nc = cam_x != h->cam_x.p ? Nc * 6 : 0, np = cam_x != h->cam_x.p ? nP * 3 : 0;
+        hipLaunchKernelGGL(k_copy_state, dim3((nc + np + 255) / 256 + 1), dim3(256), 0, st, h->cam_x.p, cam_x, nc, h->pts_x.p, pts_x, np,
+                           fx != h->focal3.p ? h->focal3.p : (double*)nullptr, fx);
     }
-    if (fx != h->focal3.p) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->focal3.p, fx, sizeof(double), hipMemcpyDeviceToDevice, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     probe_Y.free(); probe_S.free();
     S->iterations = iteration;
@@ -618,9 +618,10 @@ extern "C" int ssfm_ba_reset(ssfm_ba_handle* h) {
     if (!h) return SSFM_ERR_INVALID;
     if (h->F.nothing_to_do) return SSFM_OK;
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->cam_x.p, h->cam_init.p, h->cam_init.n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (h->F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->pts_x.p, h->pts_init.p, h->pts_init.n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(h->focal3.p, h->focal3.p + 2, sizeof(double), hipMemcpyDeviceToDevice, st));
+    const int nc = (int)h->cam_init.n, np = h->F.nP > 0 ? (int)h->pts_init.n : 0;
+    hipLaunchKernelGGL(k_copy_state, dim3((nc + np + 255) / 256 + 1), dim3(256), 0, st, h->cam_x.p, h->cam_init.p, nc, h->pts_x.p, h->pts_init.p, np,
+                       h->focal3.p, h->focal3.p + 2);
+    SSFM_HIP_CHECK(ctx, hipGetLastError());
     h->scale_ready = false;
     return SSFM_OK;
 }
