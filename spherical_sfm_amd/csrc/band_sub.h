@@ -513,7 +513,40 @@ __device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&
     return ok;
 }
 
-template <int DC, int NR>
+// The same factor-and-invert with the eliminations on the matrix cores (round 4).  The lane-per-row routine above is ~1150 dependent instructions of ONE wave
+// (two v_readlane + one FMA per updated entry) = 11k cycles, 41-43 % of a separator step.  Here the block lives in the ACCUMULATOR layout of
+// v_mfma_f64_16x16x4 (lane (li, lk) = (l & 15, l >> 4) holds S[lk + 4 q][li], q = 0..3) and column c is eliminated by ONE instruction: the operand
+// layouts are A(i, k) on lane (i, k) and B(k, j) on lane (j, k), so the lanes with lk == c % 4 already hold S[c][li] = S[li][c] in register c / 4 -- the pivot
+// column is an operand WITHOUT any cross-lane move (k-slice c % 4 carries it, the other three slices are zero).  Square-root free: S -= (a / d) a^T.  The same
+// multipliers applied to W (starts as I; row c of W sits on the same lanes, same register) leave W = L~^-1 of S = L~ D L~^T, so the inverse needs no
+// substitution pass: G = (L~ D^1/2)^-1 = D^-1/2 W.  Per column: two v_readlane (the pivot), one reciprocal, two selects, one multiply, two matrix
+// instructions.  Returns G in the accumulator layout (g[q] = G[lk + 4 q][li], zero above the diagonal); false if a pivot is not positive.
+__device__ __forceinline__ bool wave_ldl_inverse16_mfma(v4d_t& S, v4d_t& G) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    v4d_t W;
+#pragma unroll
+    for (int q = 0; q < 4; q++) W[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
+    double dmine[4] = {1.0, 1.0, 1.0, 1.0};                 // pivots of the rows this lane holds (lk + 4 q)
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const double d = lane_bcast(S[c >> 2], c + 16 * (c & 3));          // S[c][c]: lane (li = c, lk = c % 4), register c / 4
+        ok = ok && (d > 0.0);
+        if (lk == (c & 3)) dmine[c >> 2] = d;
+        if (c == 15) break;
+        const bool src = lk == (c & 3);
+        const double a = (src && li > c) ? S[c >> 2] : 0.0;               // a_i = S[i][c], rows below the pivot
+        const double w = src ? W[c >> 2] : 0.0;                           // row c of W (columns <= c are the only non-zeros)
+        const double m = -a * fast_rcp(d);
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(m, a, S, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(m, w, W, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) G[q] = W[q] * fast_rsqrt(dmine[q]);
+    return ok;
+}
+
+template <int DC, int NR, bool CHAIN_DIAG_MFMA = true>
 __global__ void __launch_bounds__(1024)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
@@ -654,13 +687,22 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             if (J == 0) STAMP(5);
             if (J == 1) STAMP(9);
             if (wave == 0) {
-                double row[16], g[16];
+                if (CHAIN_DIAG_MFMA) {                                      // eliminations on the matrix cores: 3.7k cycles against 10.9k (scripts/lab/ldl16_lab.hip)
+                    v4d_t Sd, Gd;
 #pragma unroll
-                for (int c = 0; c < 16; c++) row[c] = (li < nJ && c < nJ && lane < 16) ? sL[PK(c0 + max(li, c), c0 + min(li, c))] : ((lane == c) ? 1.0 : 0.0);
-                if (!wave_chol_inverse16(row, g) && lane == 0) *fail_flag = 1;
-                if (lane < nJ) {
+                    for (int q = 0; q < 4; q++) { const int r = lk + 4 * q; Sd[q] = (r < nJ && li < nJ) ? sL[PK(c0 + max(r, li), c0 + min(r, li))] : ((r == li) ? 1.0 : 0.0); }
+                    if (!wave_ldl_inverse16_mfma(Sd, Gd) && lane == 0) *fail_flag = 1;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) if (r >= lane && r < nJ) sL[PK(c0 + r, c0 + lane)] = g[r];
+                    for (int q = 0; q < 4; q++) { const int r = lk + 4 * q; if (r >= li && r < nJ) sL[PK(c0 + r, c0 + li)] = Gd[q]; }
+                } else {
+                    double row[16], g[16];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) row[c] = (li < nJ && c < nJ && lane < 16) ? sL[PK(c0 + max(li, c), c0 + min(li, c))] : ((lane == c) ? 1.0 : 0.0);
+                    if (!wave_chol_inverse16(row, g) && lane == 0) *fail_flag = 1;
+                    if (lane < nJ) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) if (r >= lane && r < nJ) sL[PK(c0 + r, c0 + lane)] = g[r];
+                    }
                 }
             }
             __syncthreads();
