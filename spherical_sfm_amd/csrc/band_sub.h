@@ -546,7 +546,7 @@ __device__ __forceinline__ bool wave_ldl_inverse16_mfma(v4d_t& S, v4d_t& G) {
     return ok;
 }
 
-template <int DC, int NR, bool CHAIN_DIAG_MFMA = true>
+template <int DC, int NR, bool CHAIN_DIAG_MFMA = true, bool CHAIN_PREFETCH = true>
 __global__ void __launch_bounds__(1024)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
@@ -590,41 +590,51 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
         STAMP(0);
         for (int e = tid; e < NR * Q; e += nt) sT[e] = virt ? 0.0 : tt[(size_t)s * NR * Q + e];
         if (j > 0) {
-            if (side == 0) { if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx]; }
-            else {                                                  // E' = E_{s+1}^T: rows = this separator, columns = the one behind it (s + 1)
-                const int pn = sep_lo[s + 1];
-                if (rowt) for (int r = ty; r < Q; r += 8) sF[tx * Q + r] = Z[(size_t)r * n + (size_t)pn * DC + tx];
+            if (!CHAIN_PREFETCH) {                                  // (else: the waves that idle during the previous separator's diagonal blocks brought E in, below)
+                if (side == 0) { if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx]; }
+                else {                                              // E' = E_{s+1}^T: rows = this separator, columns = the one behind it (s + 1)
+                    const int pn = sep_lo[s + 1];
+                    if (rowt) for (int r = ty; r < Q; r += 8) sF[tx * Q + r] = Z[(size_t)r * n + (size_t)pn * DC + tx];
+                }
             }
             __syncthreads();
             STAMP(1);
-            // ---- F = E Lc^-T: wave I = row tile I, block columns in order, no barrier
+            // ---- F = E Lc^-T: wave I = row tile I, block columns in order, no barrier.
+            // Round 4: the tile is accumulated TRANSPOSED (T^T = E^T - Lc(J, K) F(I, K)^T: the two operands of the round-2 product swapped), because the accumulator
+            // layout of T^T (lane (li, lk), register q = T[r0 + li][c0 + lk + 4 q]) IS the A-operand layout of the product T G_J^T that follows (k-slice q): T never goes
+            // through LDS (it did: four read-modify-writes, a fence and four reads per block column on the dependent chain), and E(I, J), G_J and the operands of
+            // K = 0 are all in flight before the first product.  24.4k -> see profiles/r04_notes.md cycles at Q = 84.
             if (wave < TQ) {
                 const int I = wave, r0 = TB * I;
                 for (int J = 0; J < TQ; J++) {
                     const int c0 = TB * J;
-                    v4d_t acc = {0.0, 0.0, 0.0, 0.0};
-                    for (int K = 0; K < J; K++) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            const int kc = TB * K + 4 * kk + lk;                   // < c0 <= Q - 1: always a real column
-                            acc = MFMA64(sF[kc * Q + r0 + li], sL[PK(c0 + li, kc)], acc);
-                        }
-                    }
-                    // T = E(I, J) - acc, in place (accumulator layout: rows lk + 4 q, column li)
+                    v4d_t Tt; double gop[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int row = r0 + lk + 4 * q, col = c0 + li;
-                        if (row < Q && col < Q) sF[col * Q + row] -= acc[q];
+                        const int k = lk + 4 * q, col = c0 + k;
+                        Tt[q] = (col < Q) ? sF[col * Q + r0 + li] : 0.0;                                            // E(I, J)^T
+                        gop[q] = (k <= li && c0 + li < Q) ? sL[PK(c0 + li, col)] : 0.0;                            // G_J[li][k]
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    {
+                        double fa[4], fl[4];
+                        const double* Lrow = sL + PK(c0 + li, 0);
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) { const int kc = 4 * kk + lk; fa[kk] = sF[kc * Q + r0 + li]; fl[kk] = -Lrow[kc]; }   // (J == 0: read, not used)
+                        for (int K = 0; K < J; K++) {
+                            double ca[4], cl[4];
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) { ca[kk] = fa[kk]; cl[kk] = fl[kk]; }
+                            if (K + 1 < J) {
+#pragma unroll
+                                for (int kk = 0; kk < 4; kk++) { const int kc = TB * (K + 1) + 4 * kk + lk; fa[kk] = sF[kc * Q + r0 + li]; fl[kk] = -Lrow[kc]; }     // kc < c0 <= Q - 1: always a real column
+                            }
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) Tt = MFMA64(cl[kk], ca[kk], Tt);                         // (Lc(J, K) F(I, K)^T)[i][j] lands at lane (j, .), register i: transposed
+                        }
+                    }
                     v4d_t f = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int k = 4 * kk + lk, kc = c0 + k;
-                        const double a = (kc < Q) ? sF[kc * Q + r0 + li] : 0.0;                                   // T(r0 + li, kc)
-                        const double g = (k <= li && c0 + li < Q) ? sL[PK(c0 + li, kc)] : 0.0;                    // G_J[li][k]
-                        f = MFMA64(a, g, f);
-                    }
+                    for (int kk = 0; kk < 4; kk++) f = MFMA64(Tt[kk], gop[kk], f);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int row = r0 + lk + 4 * q, col = c0 + li;
@@ -643,8 +653,8 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             }
             for (int e = tid; e < Q * Q; e += nt) Fbuf[fslot * Q * Q + e] = sF[e];
         }
-        // ---- D_j into the packed triangle (previous factor is dead: it went to Lbuf)
-        __syncthreads();
+        // ---- D_j into the packed triangle (the previous factor is dead: it went to Lbuf, and its last reader -- the F solve -- is behind a barrier): in the same
+        // phase as the t update and the store of F, no barrier between them
         STAMP(3);
         if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp];
         __syncthreads();
@@ -656,7 +666,15 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 int I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++;
                 const int J = t - I * (I + 1) / 2, r0 = TB * I, c0 = TB * J;
                 v4d_t acc = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = 0; k0 < Q; k0 += 4) {
+                int k0 = 0;
+                for (; k0 + 16 <= Q; k0 += 16) {                    // four k-steps per trip: the eight operand reads first, then the four products
+                    double a4[4], b4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int kc = k0 + 4 * u + lk; a4[u] = sF[kc * Q + r0 + li]; b4[u] = sF[kc * Q + c0 + li]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc = MFMA64(a4[u], b4[u], acc);
+                }
+                for (; k0 < Q; k0 += 4) {
                     const int kc = k0 + lk; const bool in = kc < Q; const int kcc = in ? kc : Q - 1;
                     const double a = in ? sF[kcc * Q + r0 + li] : 0.0, bb = in ? sF[kcc * Q + c0 + li] : 0.0;
                     acc = MFMA64(a, bb, acc);
@@ -704,6 +722,32 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                         for (int r = 0; r < 16; r++) if (r >= lane && r < nJ) sL[PK(c0 + r, c0 + lane)] = g[r];
                     }
                 }
+            } else if (CHAIN_PREFETCH) {
+                // the other fifteen waves have nothing to do until the diagonal block is there.
+                // (1) t(rows below block J - 1) -= L(rows, block J - 1) w_{J-1}: it was the long pole of the trailing phase (one thread per row, sixteen dependent terms, on
+                // waves that also had a tile); here four lanes share a row (four terms each, two xor-shuffles) and the block column J's w is only needed behind the next barrier
+                if (J > 0) {
+                    const int t2 = tid - 64, quad = t2 >> 2, part = t2 & 3, nrow = Q - c0, cp = c0 - TB;
+                    for (int task = quad; task < NR * nrow; task += 240) {
+                        const int r = (task >= nrow) ? task / nrow : 0, row = c0 + task - r * nrow;
+                        const double* Pr = sL + PK(row, cp + 4 * part); const double* wv = sT + r * Q + cp + 4 * part;
+                        double v = Pr[0] * wv[0] + Pr[1] * wv[1] + Pr[2] * wv[2] + Pr[3] * wv[3];
+                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+                        if (part == 0) sT[r * Q + row] -= v;
+                    }
+                }
+                // (2) slice J (columns == J mod TQ) of the NEXT separator's coupling block E into sF, which is dead from the rank-Q update of this separator to the
+                // F solve of the next (10 of 116 k cycles per step)
+                const int t2 = tid - 64, tx2 = t2 & 127, ty2 = t2 >> 7;                       // 7 full groups of 128 rows
+                if (j + 1 < npos && t2 < 896 && tx2 < Q) {
+                    if (side == 0) {
+                        const size_t pnx = (size_t)sep_lo[s + 1] * DC;
+                        for (int c = J + TQ * ty2; c < Q; c += TQ * 7) sF[c * Q + tx2] = Z[(size_t)c * n + pnx + tx2];
+                    } else {
+                        const size_t pnx = (size_t)sep_lo[s] * DC;                              // the next step's s is s - 1: the separator behind it is this one
+                        for (int r = J + TQ * ty2; r < Q; r += TQ * 7) sF[tx2 * Q + r] = Z[(size_t)r * n + pnx + tx2];
+                    }
+                }
             }
             __syncthreads();
             if (J == 0) STAMP(6);
@@ -749,7 +793,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                         if (row < Q && col <= row) sL[PK(row, col)] -= u[q];
                     }
                 }
-                if (rowt && tx >= c0 + TB && ty >= 8 - NR) {                // t(rows below) -= L(rows, block) w block   (threads of the last waves)
+                if (!CHAIN_PREFETCH && rowt && tx >= c0 + TB && ty >= 8 - NR) {    // t(rows below) -= L(rows, block) w block   (threads of the last waves)
                     const int r = ty - (8 - NR);
                     double v = sT[r * Q + tx];
                     const double* Pr = sL + PK(tx, c0);
