@@ -326,7 +326,11 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
             const BandSub& B = h->sub;
             const int Q = b * DC;
-            const size_t lds_chain = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
+            // a second packed triangle when it fits (Q <= 96): the chain kernel then brings the next separator's D in while it factors this one (band_sub.h: pingpong)
+            static const bool chain_pp_on = !(std::getenv("SSFM_CHAIN_PINGPONG") && std::atoi(std::getenv("SSFM_CHAIN_PINGPONG")) == 0);
+            const size_t lds_chain1 = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
+            const int chain_pp = (chain_pp_on && lds_chain1 + (size_t)Q * (Q + 1) / 2 * sizeof(double) <= 160 * 1024) ? 1 : 0;
+            const size_t lds_chain = lds_chain1 + (chain_pp ? (size_t)Q * (Q + 1) / 2 * sizeof(double) : 0);
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
@@ -369,7 +373,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     h->sub_seq++;
                     if (chain_diag_mfma)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
-                           tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq);
+                           tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
                     else
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, false, false>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq);

@@ -551,13 +551,17 @@ __global__ void __launch_bounds__(1024)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
                      double* __restrict__ Y, int* __restrict__ fail_flag, long long* __restrict__ stamps /* null, or [16] phase stamps of chain 0, separator 1 */,
-                     int twist, int nsep_total, double* __restrict__ Cbuf, double* __restrict__ Tcbuf, int* __restrict__ flags, int seq) {
+                     int twist, int nsep_total, double* __restrict__ Cbuf, double* __restrict__ Tcbuf, int* __restrict__ flags, int seq, int pingpong = 0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TB = 16;
 #define STAMP(k_) do { if (stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = blockDim.x, NP = Q * (Q + 1) / 2, TQ = (Q + TB - 1) / TB;
+    // pingpong (the host sets it when a second triangle fits the LDS, Q <= 96): two triangles take turns -- the factor of separator j - 1 (read by the F solve of
+    // separator j) in one, D_j in the other, and D_{j+1} is brought into the first while separator j is factored: the load of D leaves the dependent chain
+    const bool pp = CHAIN_PREFETCH && pingpong != 0;
     double* sL = lds;                  // [NP]   packed lower triangle, row-major; the 16x16 diagonal blocks hold G_J = L_JJ^-1
-    double* sF = sL + NP;              // [Q][Q] column-major: F(i, c) at c*Q + i
+    double* sLp = pp ? lds + NP : lds; // the triangle of the previous separator's factor (the same one without pingpong)
+    double* sF = lds + (pp ? 2 : 1) * NP;   // [Q][Q] column-major: F(i, c) at c*Q + i
     double* sT = sF + (size_t)Q * Q;   // [NR][Q]
     double* sW = sT + NR * Q;          // [NR][Q]
     // Two-sided elimination of a chain (twist): workgroup 2c takes the separators from the front up to and including the middle one,
@@ -613,11 +617,11 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                     for (int q = 0; q < 4; q++) {
                         const int k = lk + 4 * q, col = c0 + k;
                         Tt[q] = (col < Q) ? sF[col * Q + r0 + li] : 0.0;                                            // E(I, J)^T
-                        gop[q] = (k <= li && c0 + li < Q) ? sL[PK(c0 + li, col)] : 0.0;                            // G_J[li][k]
+                        gop[q] = (k <= li && c0 + li < Q) ? sLp[PK(c0 + li, col)] : 0.0;                           // G_J[li][k]
                     }
                     {
                         double fa[4], fl[4];
-                        const double* Lrow = sL + PK(c0 + li, 0);
+                        const double* Lrow = sLp + PK(c0 + li, 0);
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) { const int kc = 4 * kk + lk; fa[kk] = sF[kc * Q + r0 + li]; fl[kk] = -Lrow[kc]; }   // (J == 0: read, not used)
                         for (int K = 0; K < J; K++) {
@@ -646,7 +650,16 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             __syncthreads();
             STAMP(2);
             // ---- t_j -= F w_{j-1};  F to global for the backward pass
-            if (rowt && ty < NR) {
+            if (CHAIN_PREFETCH) {                                   // four lanes per (row, right-hand side): Q / 4 terms each and two xor-shuffles (one thread per row: Q dependent terms)
+                const int quad = tid >> 2, part = tid & 3;
+                for (int task = quad; task < NR * Q; task += 256) {
+                    const int r = (task >= Q) ? task / Q : 0, row = task - r * Q;
+                    double acc = 0.0;
+                    for (int c = part; c < Q; c += 4) acc += sF[c * Q + row] * sW[r * Q + c];
+                    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+                    if (part == 0) sT[r * Q + row] -= acc;
+                }
+            } else if (rowt && ty < NR) {
                 double acc = 0.0;
                 for (int c = 0; c < Q; c++) acc += sF[c * Q + tx] * sW[ty * Q + c];
                 sT[ty * Q + tx] -= acc;
@@ -656,7 +669,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
         // ---- D_j into the packed triangle (the previous factor is dead: it went to Lbuf, and its last reader -- the F solve -- is behind a barrier): in the same
         // phase as the t update and the store of F, no barrier between them
         STAMP(3);
-        if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp];
+        if (!(pp && j > 0)) { if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp]; }    // (else: prefetched during the previous separator)
         __syncthreads();
         STAMP(4);
         if (j > 0) {
@@ -747,6 +760,11 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                         const size_t pnx = (size_t)sep_lo[s] * DC;                              // the next step's s is s - 1: the separator behind it is this one
                         for (int r = J + TQ * ty2; r < Q; r += TQ * 7) sF[tx2 * Q + r] = Z[(size_t)r * n + pnx + tx2];
                     }
+                    if (pp) {                                                                   // (3) the same slice of the next separator's D into the other triangle
+                        const bool vnext = side == 1 && j + 1 == npos - 1;
+                        const double* Dn = Dd + (size_t)((side == 0) ? s + 1 : s - 1) * Q * Q + (size_t)tx2 * Q;
+                        for (int cp = J + TQ * ty2; cp <= tx2; cp += TQ * 7) sLp[PK(tx2, cp)] = vnext ? 0.0 : Dn[cp];
+                    }
                 }
             }
             __syncthreads();
@@ -809,6 +827,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
         for (int e = tid; e < NR * Q; e += nt) { const double wv = sT[e]; sW[e] = wv; wbuf[(size_t)s * NR * Q + e] = wv; }
         __syncthreads();
         STAMP(10);
+        if (pp && j + 1 < npos) { double* t_ = sL; sL = sLp; sLp = t_; }    // the next separator's D is in the other triangle; this factor becomes "the previous one"
     }
 #undef STAMP
     // ---- backward
