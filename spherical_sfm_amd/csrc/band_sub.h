@@ -612,7 +612,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 const int I = wave, r0 = TB * I;
                 for (int J = 0; J < TQ; J++) {
                     const int c0 = TB * J;
-                    v4d_t Tt; double gop[4];
+                    v4d_t Tt, Tt1 = {0.0, 0.0, 0.0, 0.0}; double gop[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int k = lk + 4 * q, col = c0 + k;
@@ -632,10 +632,12 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
 #pragma unroll
                                 for (int kk = 0; kk < 4; kk++) { const int kc = TB * (K + 1) + 4 * kk + lk; fa[kk] = sF[kc * Q + r0 + li]; fl[kk] = -Lrow[kc]; }     // kc < c0 <= Q - 1: always a real column
                             }
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) Tt = MFMA64(cl[kk], ca[kk], Tt);                         // (Lc(J, K) F(I, K)^T)[i][j] lands at lane (j, .), register i: transposed
+                            // (Lc(J, K) F(I, K)^T)[i][j] lands at lane (j, .), register i: transposed
+                            Tt = MFMA64(cl[0], ca[0], Tt); Tt1 = MFMA64(cl[1], ca[1], Tt1); Tt = MFMA64(cl[2], ca[2], Tt); Tt1 = MFMA64(cl[3], ca[3], Tt1);
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) Tt[q] += Tt1[q];
                     v4d_t f = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) f = MFMA64(Tt[kk], gop[kk], f);
@@ -678,15 +680,16 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             for (int t = wave; t < ntile; t += nw) {
                 int I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++;
                 const int J = t - I * (I + 1) / 2, r0 = TB * I, c0 = TB * J;
-                v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+                v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};      // two accumulators (no measurable difference: the phase is bound by the matrix pipe of the busiest SIMD, 6 of 21 tiles, and by 6.2 cycles per ds_read_b64 -- scripts/lab/syrk_lab.hip: 8.7k MFMA only, 5.4k reads only, 10.9k together at Q = 84)
                 int k0 = 0;
                 for (; k0 + 16 <= Q; k0 += 16) {                    // four k-steps per trip: the eight operand reads first, then the four products
                     double a4[4], b4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) { const int kc = k0 + 4 * u + lk; a4[u] = sF[kc * Q + r0 + li]; b4[u] = sF[kc * Q + c0 + li]; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) acc = MFMA64(a4[u], b4[u], acc);
+                    acc = MFMA64(a4[0], b4[0], acc); acc1 = MFMA64(a4[1], b4[1], acc1); acc = MFMA64(a4[2], b4[2], acc); acc1 = MFMA64(a4[3], b4[3], acc1);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] += acc1[q];
                 for (; k0 < Q; k0 += 4) {
                     const int kc = k0 + lk; const bool in = kc < Q; const int kcc = in ? kc : Q - 1;
                     const double a = in ? sF[kcc * Q + r0 + li] : 0.0, bb = in ? sF[kcc * Q + c0 + li] : 0.0;
@@ -737,10 +740,27 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 }
             } else if (CHAIN_PREFETCH) {
                 // the other fifteen waves have nothing to do until the diagonal block is there.
+                // (2) slice J (columns == J mod TQ) of the NEXT separator's coupling block E into sF, which is dead from the rank-Q update of this separator to the
+                // F solve of the next (10 of 116 k cycles per step), and (3) with two triangles the same slice of its D: the global loads are issued FIRST, the
+                // right-hand-side update (1) runs under their latency, the LDS stores come last
+                const int t2 = tid - 64, tx2 = t2 & 127, ty2 = t2 >> 7;                       // 7 full groups of 128 rows
+                const bool pre = j + 1 < npos && t2 < 896 && tx2 < Q;
+                const bool vnext = side == 1 && j + 1 == npos - 1;
+                double ev[3] = {0.0, 0.0, 0.0}, dv[3] = {0.0, 0.0, 0.0};                     // <= ceil(16 / 7) columns of a slice per thread (Q <= 114: a slice has <= 16 columns)
+                if (pre) {
+                    const size_t pnx = (size_t)sep_lo[side == 0 ? s + 1 : s] * DC;             // back side: the next step's s is s - 1 and the separator behind it is this one
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int c = J + TQ * (ty2 + 7 * u); if (c < Q) ev[u] = Z[(size_t)c * n + pnx + tx2]; }
+                    if (pp && !vnext) {
+                        const double* Dn = Dd + (size_t)((side == 0) ? s + 1 : s - 1) * Q * Q + (size_t)tx2 * Q;
+#pragma unroll
+                        for (int u = 0; u < 3; u++) { const int cp = J + TQ * (ty2 + 7 * u); if (cp <= tx2) dv[u] = Dn[cp]; }
+                    }
+                }
                 // (1) t(rows below block J - 1) -= L(rows, block J - 1) w_{J-1}: it was the long pole of the trailing phase (one thread per row, sixteen dependent terms, on
                 // waves that also had a tile); here four lanes share a row (four terms each, two xor-shuffles) and the block column J's w is only needed behind the next barrier
                 if (J > 0) {
-                    const int t2 = tid - 64, quad = t2 >> 2, part = t2 & 3, nrow = Q - c0, cp = c0 - TB;
+                    const int quad = t2 >> 2, part = t2 & 3, nrow = Q - c0, cp = c0 - TB;
                     for (int task = quad; task < NR * nrow; task += 240) {
                         const int r = (task >= nrow) ? task / nrow : 0, row = c0 + task - r * nrow;
                         const double* Pr = sL + PK(row, cp + 4 * part); const double* wv = sT + r * Q + cp + 4 * part;
@@ -749,21 +769,12 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                         if (part == 0) sT[r * Q + row] -= v;
                     }
                 }
-                // (2) slice J (columns == J mod TQ) of the NEXT separator's coupling block E into sF, which is dead from the rank-Q update of this separator to the
-                // F solve of the next (10 of 116 k cycles per step)
-                const int t2 = tid - 64, tx2 = t2 & 127, ty2 = t2 >> 7;                       // 7 full groups of 128 rows
-                if (j + 1 < npos && t2 < 896 && tx2 < Q) {
-                    if (side == 0) {
-                        const size_t pnx = (size_t)sep_lo[s + 1] * DC;
-                        for (int c = J + TQ * ty2; c < Q; c += TQ * 7) sF[c * Q + tx2] = Z[(size_t)c * n + pnx + tx2];
-                    } else {
-                        const size_t pnx = (size_t)sep_lo[s] * DC;                              // the next step's s is s - 1: the separator behind it is this one
-                        for (int r = J + TQ * ty2; r < Q; r += TQ * 7) sF[tx2 * Q + r] = Z[(size_t)r * n + pnx + tx2];
-                    }
-                    if (pp) {                                                                   // (3) the same slice of the next separator's D into the other triangle
-                        const bool vnext = side == 1 && j + 1 == npos - 1;
-                        const double* Dn = Dd + (size_t)((side == 0) ? s + 1 : s - 1) * Q * Q + (size_t)tx2 * Q;
-                        for (int cp = J + TQ * ty2; cp <= tx2; cp += TQ * 7) sLp[PK(tx2, cp)] = vnext ? 0.0 : Dn[cp];
+                if (pre) {
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const int c = J + TQ * (ty2 + 7 * u);
+                        if (c < Q) { if (side == 0) sF[c * Q + tx2] = ev[u]; else sF[tx2 * Q + c] = ev[u]; }
+                        if (pp && c <= tx2) sLp[PK(tx2, c)] = dv[u];
                     }
                 }
             }
