@@ -355,11 +355,20 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_end();
                 const int ntl = (Q + SUB_TS - 1) / SUB_TS;
                 const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
+                // separator blocks on the matrix cores, operands straight from global memory, no atomics and no clears (band_sub.h 3b); SSFM_ASM_MFMA=0: the VALU kernel of round 1
+                static const bool asm_mfma = !(std::getenv("SSFM_ASM_MFMA") && std::atoi(std::getenv("SSFM_ASM_MFMA")) == 0);
+                if (asm_mfma) {
+                    const int tq = (Q + 15) / 16;
+                    h->span_begin(KID_SUB_ASM);
+                    hipLaunchKernelGGL((k_sub_sep_assemble_mfma<DC, 2>), dim3(B.nsep * (tq * (tq + 1) / 2 + tq)), dim3(64 * ASM_NW), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
+                    h->span_end();
+                } else {
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subD.p, 0, h->subD.n * sizeof(double), st));
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subT.p, 0, h->subT.n * sizeof(double), st));
                 h->span_begin(KID_SUB_ASM);
                 hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
                 h->span_end();
+                }
                 if (chain_mfma) {
                     // SSFM_CHAIN_STAMPS=1: s_memtime stamps of the phases of one separator, printed once (profiles/*_notes.md)
                     static long long* d_stamps = nullptr; static int stamp_state = std::getenv("SSFM_CHAIN_STAMPS") ? 1 : 0;

@@ -1917,12 +1917,12 @@ static __global__ void k_startup_tail(const double* __restrict__ pts, const doub
                                       double* __restrict__ out_pt, double* __restrict__ out_cam) {
     __shared__ double red[4];
     const bool is_pt = (int)blockIdx.x < gpt;
-    const int i = (is_pt ? blockIdx.x : blockIdx.x - gpt) * blockDim.x + threadIdx.x;
+    const int i0 = (is_pt ? blockIdx.x : blockIdx.x - gpt) * blockDim.x + threadIdx.x, stride = (is_pt ? gpt : (int)gridDim.x - gpt) * blockDim.x;
     double acc[1] = {0.0};
-    if (is_pt) { if (i < n_pt && mask_pt[i] > 0.0) acc[0] = pts[i] * pts[i]; }
+    if (is_pt) { for (int i = i0; i < n_pt; i += stride) if (mask_pt[i] > 0.0) acc[0] += pts[i] * pts[i]; }
     else {
-        if (i < n_cam) {
-            if (mask_cam[i] > 0.0) acc[0] = cam[i] * cam[i];
+        for (int i = i0; i < n_cam; i += stride) {
+            if (mask_cam[i] > 0.0) acc[0] += cam[i] * cam[i];
             if (scale_cam) scale_cam[i] = mask_cam[i] * (jacobi ? 1.0 / (1.0 + sqrt(diag_cam[i])) : 1.0);
         }
         if ((int)blockIdx.x == gpt && threadIdx.x == 0) {

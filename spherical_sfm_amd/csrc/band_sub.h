@@ -254,6 +254,105 @@ k_sub_sep_assemble(const double* __restrict__ band, const double* __restrict__ Z
     }
 }
 
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+// ---- 3b. the same on the matrix cores (round 4) ---------------------------------------------------------------------------------------
+// D_s = inner - Z^T Z is a rank-K update with K = the rows of the segment behind the separator (~1200 at the configs[4] size): 16x16 output tiles of
+// v_mfma_f64_16x16x4 with the operands STRAIGHT FROM GLOBAL MEMORY -- Z is [Q][n] with the segment rows contiguous, lane (li, lk) loads Z[r0 + li][k0 + 4 lk .. + 3]
+// (32 bytes; the sixteen lanes of a k-slice group cover 16 rows x 128 contiguous bytes per trip) and feeds one value to each of four products (any partition of the
+// k index over the products is a valid one as long as both operands use the same).  One workgroup per (separator, lower tile or row group of the right-hand sides), its
+// sixteen waves split K and fold their accumulators through LDS in wave order: no atomics, no zeroing of Dd / tt beforehand, and the result does not depend on
+// the order in which workgroups finish (the VALU kernel above added K chunks with atomics).  80 -> see profiles/r04_notes.md us at the configs[4] size.
+constexpr int ASM_NW = 8;                          // waves per workgroup = K chunks of a tile
+template <int DC, int NR>
+__global__ void __launch_bounds__(64 * ASM_NW)
+k_sub_sep_assemble_mfma(const double* __restrict__ band, const double* __restrict__ Z, const double* __restrict__ Y, const int* __restrict__ sep_lo,
+                        const int* __restrict__ sep_rseg, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int N, int b,
+                        double* __restrict__ Dd, double* __restrict__ tt) {
+    constexpr int BB = DC * DC, TB = 16;
+    __shared__ double red[ASM_NW - 1][64][4];
+    const int W = b + 1, n = N * DC, Q = b * DC, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int TQ = (Q + TB - 1) / TB, ntile = TQ * (TQ + 1) / 2;
+    // 1-D grid, separator-major task list, each XCD a contiguous eighth of it: the 21 tiles of a separator re-read its Z rows (0.8 MB) from that XCD's L2
+    // instead of from the Infinity Cache once per XCD (116 MB of operand reads at the configs[4] size: 28 us at ~4 TB/s before)
+    const int lin = xcd_contiguous_block(blockIdx.x, gridDim.x), ntask = ntile + TQ;
+    const int s = lin / ntask, ty = lin - s * ntask, p0 = sep_lo[s], rs = sep_rseg[s];
+    const int ka = seg_lo[rs] * DC, kb = seg_hi[rs] * DC;
+    const int kq = (((kb - ka + ASM_NW - 1) / ASM_NW + 15) / 16) * 16;       // K per wave, a multiple of 16
+    const int k0w = ka + wave * kq, k1w = min(kb, k0w + kq);
+    const bool is_rhs = ty >= ntile;
+    int I = 0, J = 0;
+    if (!is_rhs) { const int t = ty; while ((I + 1) * (I + 2) / 2 <= t) I++; J = t - I * (I + 1) / 2; } else I = ty - ntile;
+    const int r0 = TB * I, c0 = TB * J;
+    const double* za = Z + (size_t)min(r0 + li, Q - 1) * n;                  // (rows beyond Q only feed outputs that are not stored)
+    const double* zb = Z + (size_t)min(c0 + li, Q - 1) * n;
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!is_rhs) {
+        v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+        const bool diag = I == J;
+        auto load4 = [&](const double* zp, int k, double (&v)[4]) {
+            if (k + 4 <= k1w) { const double2 v01 = *reinterpret_cast<const double2*>(zp + k), v23 = *reinterpret_cast<const double2*>(zp + k + 2); v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y; }
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (k + u < k1w) ? zp[k + u] : 0.0;
+            }
+        };
+        constexpr int DEPTH = 5;                                             // trips of 16 k whose loads are in flight together (a trip is one global round trip otherwise)
+        for (int k0 = k0w; k0 < k1w; k0 += 16 * DEPTH) {
+            double a[DEPTH][4], bb[DEPTH][4];
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                const int k = k0 + 16 * d + 4 * lk;
+                if (k0 + 16 * d < k1w) { load4(za, k, a[d]); if (!diag) load4(zb, k, bb[d]); }
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                if (k0 + 16 * d < k1w) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][u], diag ? a[d][u] : bb[d][u], acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc4[q] = acc[q];
+    } else {
+        // right-hand sides: t(q) = y_sep(q) - sum_k Z[q][k] y(k) for the 16 rows of group I; lane (li, lk) sums its k-slices, folded over lk below
+        for (int k0 = k0w; k0 < k1w; k0 += 16) {
+            const int k = k0 + 4 * lk;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (k + u < k1w) {
+                const double z = za[k + u];
+#pragma unroll
+                for (int r = 0; r < NR; r++) acc4[r] += z * Y[(size_t)r * n + k + u];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) { double v = acc4[r]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); acc4[r] = v; }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) red[wave - 1][lane][q] = acc4[q];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 0; w < ASM_NW - 1; w++)                                     // in wave order: the same bits whatever the schedule
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc4[q] += red[w][lane][q];
+    if (!is_rhs) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = r0 + lk + 4 * q, col = c0 + li;
+            if (row < Q && col <= row) {
+                const int r = row / DC, a = row - r * DC, r2 = col / DC, a2 = col - r2 * DC;
+                Dd[((size_t)s * Q + row) * Q + col] = band[((size_t)(p0 + r) * W + (r - r2)) * BB + a * DC + a2] - acc4[q];
+            }
+        }
+    } else if (lk == 0 && r0 + li < Q) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) tt[((size_t)s * NR + r) * Q + r0 + li] = Y[(size_t)r * n + (size_t)p0 * DC + r0 + li] - acc4[r];
+    }
+}
+
 // ---- 4. block-tridiagonal chain over the separators of one component -----------------------------------------------------------
 //   forward, j = 0..ns-1:  F_j = E_j Lc_{j-1}^-T,  D_j -= F_j F_j^T,  t_j -= F_j w_{j-1},  Lc_j = chol(D_j),  w_j = Lc_j^-1 t_j
 //   backward:              x_j = Lc_j^-T (w_j - F_{j+1}^T x_{j+1})          -> Y rows of the separator
@@ -488,7 +587,6 @@ k_sub_sep_chain(const double* __restrict__ Z, const double* __restrict__ Dd, con
 // outputs and are left as they are (they stay inside the LDS allocation), the K index is masked where it can run past Q.  The diagonal
 // blocks of the packed triangle hold G_J (16x16) here, so the substitutions work on 16-blocks too.  Same arguments and buffers as
 // k_sub_sep_chain (SSFM_CHAIN_MFMA=0 selects that one).
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 // lane r < 16 enters with row r of an SPD 16x16 block; on exit lane c holds column c of G = L^-1 (g[r] = G[r][c], zero above the diagonal)
 __device__ __forceinline__ bool wave_chol_inverse16(double (&row)[16], double (&g)[16]) {
