@@ -1616,7 +1616,10 @@ __device__ __forceinline__ void residual_check_body(int n, const double* __restr
         res_pcg[PCG_DONE] = (a2[0] <= res_tol2 * a2[1]) ? 1.0 : 0.0;
     }
 }
-template <int DC>
+// LPP = lanes per point (round 4 experiment, 1 in use): with 2, the pair splits the point's observations (interleaved), folds the eleven per-point sums with one quad-permute
+// each and both lanes know the point's step -- half the dependent camera gathers per lane and twice the waves.  Slower at config 2 (25.2 against 23.2 us): the kernel is not
+// bound by the length of a lane's chain of round trips (see also the unroll experiments below)
+template <int DC, int LPP = 1>
 __global__ void __launch_bounds__(256)
 k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                 const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
@@ -1639,14 +1642,14 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red);
         if (!pub_host) return;
     }
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x, p = gt / LPP, hl = gt - p * LPP;                 // hl: this lane's share of the point's observations
     double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
     if (!residual_block && p < nP && !(pt_skip && pt_skip[p])) {
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
         const double sp[3] = {scale_pt[3 * p], scale_pt[3 * p + 1], scale_pt[3 * p + 2]};
         const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC];
         const double g3[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
-        double b[3] = {g3[0], g3[1], g3[2]};
+        double b[3] = {0.0, 0.0, 0.0};
         const int j0 = pt_start[p], j1 = pt_start[p + 1];
         // ONE sweep over the observations: with M_j = a_j + B_j z  (a_j = camera/focal part of J s, B_j = Jp_j diag(s_p), z = point step)
         // the model cost change  -sum M_j.(r_j - M_j/2)  expands into sums that do not depend on z -- sum a.a, sum a.r, B^T a, B^T B --
@@ -1657,10 +1660,11 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
         // kernel is not bound by the length of a lane's chain of round trips.)
         // the camera index and pixel of observation j+1 are fetched while observation j is processed: one dependent round trip
         // per observation (its camera tables) instead of two
-        int c_nx = obs_cam[j0]; double2 o_nx = obs_xy[j0];
-        for (int j = j0; j < j1; j++) {
+        const int jf = min(j0 + hl, j1 - 1);
+        int c_nx = obs_cam[jf]; double2 o_nx = obs_xy[jf];
+        for (int j = j0 + hl; j < j1; j += LPP) {
             const int c = c_nx; const double2 o = o_nx;
-            { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
+            { const int jn = min(j + LPP, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
             ObsLin L; lin_obs<DC == 6>(f, cam + 6 * c, rot + 27 * c, X, o.x, o.y, loss, la, L);
             double Jc[2][DC]; cam_block<DC>(L, scale_cam + 6 * c, Jc);
             double m0 = L.Jf[0] * sf * yf, m1 = L.Jf[1] * sf * yf;
@@ -1673,6 +1677,15 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
 #pragma unroll
             for (int k = 0; k < 3; k++) b[k] -= B0[k] * m0 + B1[k] * m1;
         }
+        if (LPP == 2) {                                     // fold the pair: both lanes continue with the point's sums
+            Saa += __shfl_xor(Saa, 1, 64); Sar += __shfl_xor(Sar, 1, 64);
+#pragma unroll
+            for (int k = 0; k < 6; k++) Vr[k] += __shfl_xor(Vr[k], 1, 64);
+#pragma unroll
+            for (int k = 0; k < 3; k++) b[k] += __shfl_xor(b[k], 1, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) b[k] += g3[k];
         // V^-1 b from the record of the Schur kernels, PS_V = diag(s) V^-1 diag(s):  V^-1 b = s^-1 o (PS_V (s^-1 o b))
         const double* Vi = Vs + 12 * (size_t)p;
         double yp[3] = {0.0, 0.0, 0.0};
@@ -1687,21 +1700,21 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
             const double zg = yp[0] * g3[0] + yp[1] * g3[1] + yp[2] * g3[2];
             const double zBa = yp[0] * (g3[0] - b[0]) + yp[1] * (g3[1] - b[1]) + yp[2] * (g3[2] - b[2]);       // z . sum B^T a
             const double zVz = Vr[0] * yp[0] * yp[0] + Vr[3] * yp[1] * yp[1] + Vr[5] * yp[2] * yp[2] + 2.0 * (Vr[1] * yp[0] * yp[1] + Vr[2] * yp[0] * yp[2] + Vr[4] * yp[1] * yp[2]);
-            acc[0] = -(Sar + zg) + 0.5 * (Saa + 2.0 * zBa + zVz);
+            if (hl == 0) acc[0] = -(Sar + zg) + 0.5 * (Saa + 2.0 * zBa + zVz);
         }
         double Xc[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const double d = -yp[k] * sp[k]; const double v = X[k] + d;
-            pts_c[3 * p + k] = v; Xc[k] = v;
-            if (sp[k] > 0.0) { acc[1] += d * d; acc[2] += v * v; }
+            Xc[k] = v;
+            if (hl == 0) { pts_c[3 * p + k] = v; if (sp[k] > 0.0) { acc[1] += d * d; acc[2] += v * v; } }
         }
         // robustified cost at the candidate (cameras, focal, this point): what a separate k_point_cost launch did
         const double fcand = focal_c[0];
-        c_nx = obs_cam[j0]; o_nx = obs_xy[j0];
-        for (int j = j0; j < j1; j++) {
+        c_nx = obs_cam[jf]; o_nx = obs_xy[jf];
+        for (int j = j0 + hl; j < j1; j += LPP) {
             const int c = c_nx; const double2 o = o_nx;
-            { const int jn = min(j + 1, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
+            { const int jn = min(j + LPP, j1 - 1); c_nx = obs_cam[jn]; o_nx = obs_xy[jn]; }
             acc[3] += obs_cost(fcand, cam_c + 6 * c, rot_c + 27 * c, Xc, o.x, o.y, loss, la);
         }
     }

@@ -274,7 +274,15 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p);
                     }
-                    if (!all_grouped)
+                    // EXPERIMENT, off (SSFM_BACKSUB_LPP=2): two lanes per point -- half the dependent camera gathers per lane, twice the waves.  Measured at config 2
+                    // (scripts/lab/ab_lpp.sh, hipEvent averages): 25.1-25.3 us against 23.0-23.5 with one lane per point; 2.557 against 2.538-2.552 ms per solve
+                    static const int bs_lpp = std::getenv("SSFM_BACKSUB_LPP") ? std::atoi(std::getenv("SSFM_BACKSUB_LPP")) : 1;
+                    if (!all_grouped && bs_lpp == 2)
+                        LAUNCH(h, KID_BACKSUB, (k_point_backsub<DC, 2>), (2 * nP + PTB - 1) / PTB + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
+                               h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
+                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr));
+                    else if (!all_grouped)
                         LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
