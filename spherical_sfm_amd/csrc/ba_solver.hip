@@ -78,8 +78,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         h->scale_ready = true;
     }
     {
-        // (at most 1024 + 64 workgroups: each ends in one atomic on the same two scalars -- 17.6k of them at 1.5 M points took 217 us)
-        const int gpt = nP > 0 ? std::min(1024, (nP * 3 + 255) / 256) : 0, gcm = std::min(64, (Nc * 6 + 255) / 256);
+        // (at most 256 + 16 workgroups: each ends in one atomic on the same two scalars, ~12 ns apiece -- 17.6k of them at 1.5 M points took 217 us, 1032 at config 2 15 us)
+        const int gpt = nP > 0 ? std::min(256, (nP * 3 + 255) / 256) : 0, gcm = std::min(16, (Nc * 6 + 255) / 256);
         hipLaunchKernelGGL(k_startup_tail, dim3(gpt + gcm), dim3(256), 0, st, pts_x, h->mask_pt.p, nP * 3, gpt, cam_x, h->mask_cam.p, Nc * 6, fx, h->mask_f.p,
                            h->diag_cam.p, (make_scale && ctx->collective) ? h->scale_cam.p : (double*)nullptr, h->diag_f.p, make_scale ? h->scale_f.p : (double*)nullptr,
                            O.jacobi_scaling, h->scal.p + SC_X0N2_PT, h->scal.p + SC_X0N2_CAM);
