@@ -710,7 +710,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 const int I = wave, r0 = TB * I;
                 for (int J = 0; J < TQ; J++) {
                     const int c0 = TB * J;
-                    v4d_t Tt, Tt1 = {0.0, 0.0, 0.0, 0.0}; double gop[4];
+                    v4d_t Tt; double gop[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int k = lk + 4 * q, col = c0 + k;
@@ -731,11 +731,10 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                                 for (int kk = 0; kk < 4; kk++) { const int kc = TB * (K + 1) + 4 * kk + lk; fa[kk] = sF[kc * Q + r0 + li]; fl[kk] = -Lrow[kc]; }     // kc < c0 <= Q - 1: always a real column
                             }
                             // (Lc(J, K) F(I, K)^T)[i][j] lands at lane (j, .), register i: transposed
-                            Tt = MFMA64(cl[0], ca[0], Tt); Tt1 = MFMA64(cl[1], ca[1], Tt1); Tt = MFMA64(cl[2], ca[2], Tt); Tt1 = MFMA64(cl[3], ca[3], Tt1);
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) Tt = MFMA64(cl[kk], ca[kk], Tt);
                         }
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) Tt[q] += Tt1[q];
                     v4d_t f = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) f = MFMA64(Tt[kk], gop[kk], f);
@@ -778,16 +777,15 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             for (int t = wave; t < ntile; t += nw) {
                 int I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++;
                 const int J = t - I * (I + 1) / 2, r0 = TB * I, c0 = TB * J;
-                v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};      // two accumulators (no measurable difference: the phase is bound by the matrix pipe of the busiest SIMD, 6 of 21 tiles, and by 6.2 cycles per ds_read_b64 -- scripts/lab/syrk_lab.hip: 8.7k MFMA only, 5.4k reads only, 10.9k together at Q = 84)
+                v4d_t acc = {0.0, 0.0, 0.0, 0.0};      // (a second accumulator for alternate products changes nothing: the phase is bound by the matrix pipe of the busiest SIMD, 6 of 21 tiles, and by 6.2 cycles per ds_read_b64 -- scripts/lab/syrk_lab.hip: 8.7k MFMA only, 5.4k reads only, 10.9k together at Q = 84)
                 int k0 = 0;
                 for (; k0 + 16 <= Q; k0 += 16) {                    // four k-steps per trip: the eight operand reads first, then the four products
                     double a4[4], b4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) { const int kc = k0 + 4 * u + lk; a4[u] = sF[kc * Q + r0 + li]; b4[u] = sF[kc * Q + c0 + li]; }
-                    acc = MFMA64(a4[0], b4[0], acc); acc1 = MFMA64(a4[1], b4[1], acc1); acc = MFMA64(a4[2], b4[2], acc); acc1 = MFMA64(a4[3], b4[3], acc1);
-                }
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] += acc1[q];
+                    for (int u = 0; u < 4; u++) acc = MFMA64(a4[u], b4[u], acc);
+                }
                 for (; k0 < Q; k0 += 4) {
                     const int kc = k0 + lk; const bool in = kc < Q; const int kcc = in ? kc : Q - 1;
                     const double a = in ? sF[kcc * Q + r0 + li] : 0.0, bb = in ? sF[kcc * Q + c0 + li] : 0.0;
