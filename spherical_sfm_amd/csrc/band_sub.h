@@ -644,16 +644,17 @@ __device__ __forceinline__ bool wave_ldl_inverse16_mfma(v4d_t& S, v4d_t& G) {
     return ok;
 }
 
-template <int DC, int NR, bool CHAIN_DIAG_MFMA = true, bool CHAIN_PREFETCH = true>
-__global__ void __launch_bounds__(1024)
+// NTHR = 1024 or 512 threads: at 1024 the kernel sits on the 128-register limit of four waves per SIMD (35 scratch accesses); 512 threads have 256 registers each
+template <int DC, int NR, bool CHAIN_DIAG_MFMA = true, bool CHAIN_PREFETCH = true, int NTHR = 1024>
+__global__ void __launch_bounds__(NTHR)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
                      double* __restrict__ Y, int* __restrict__ fail_flag, long long* __restrict__ stamps /* null, or [16] phase stamps of chain 0, separator 1 */,
                      int twist, int nsep_total, double* __restrict__ Cbuf, double* __restrict__ Tcbuf, int* __restrict__ flags, int seq, int pingpong = 0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int TB = 16;
+    constexpr int TB = 16, NTY = NTHR / 128, PFG = (NTHR - 64) / 128, PFN = (16 + PFG - 1) / PFG;     // row groups of 128 threads; groups / values per thread of the prefetching waves
 #define STAMP(k_) do { if (stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = blockDim.x, NP = Q * (Q + 1) / 2, TQ = (Q + TB - 1) / TB;
+    const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = NTHR, NP = Q * (Q + 1) / 2, TQ = (Q + TB - 1) / TB;
     // pingpong (the host sets it when a second triangle fits the LDS, Q <= 96): two triangles take turns -- the factor of separator j - 1 (read by the F solve of
     // separator j) in one, D_j in the other, and D_{j+1} is brought into the first while separator j is factored: the load of D leaves the dependent chain
     const bool pp = CHAIN_PREFETCH && pingpong != 0;
@@ -693,10 +694,10 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
         for (int e = tid; e < NR * Q; e += nt) sT[e] = virt ? 0.0 : tt[(size_t)s * NR * Q + e];
         if (j > 0) {
             if (!CHAIN_PREFETCH) {                                  // (else: the waves that idle during the previous separator's diagonal blocks brought E in, below)
-                if (side == 0) { if (rowt) for (int c = ty; c < Q; c += 8) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx]; }
+                if (side == 0) { if (rowt) for (int c = ty; c < Q; c += NTY) sF[c * Q + tx] = Z[(size_t)c * n + (size_t)p0 * DC + tx]; }
                 else {                                              // E' = E_{s+1}^T: rows = this separator, columns = the one behind it (s + 1)
                     const int pn = sep_lo[s + 1];
-                    if (rowt) for (int r = ty; r < Q; r += 8) sF[tx * Q + r] = Z[(size_t)r * n + (size_t)pn * DC + tx];
+                    if (rowt) for (int r = ty; r < Q; r += NTY) sF[tx * Q + r] = Z[(size_t)r * n + (size_t)pn * DC + tx];
                 }
             }
             __syncthreads();
@@ -751,7 +752,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
             // ---- t_j -= F w_{j-1};  F to global for the backward pass
             if (CHAIN_PREFETCH) {                                   // four lanes per (row, right-hand side): Q / 4 terms each and two xor-shuffles (one thread per row: Q dependent terms)
                 const int quad = tid >> 2, part = tid & 3;
-                for (int task = quad; task < NR * Q; task += 256) {
+                for (int task = quad; task < NR * Q; task += NTHR / 4) {
                     const int r = (task >= Q) ? task / Q : 0, row = task - r * Q;
                     double acc = 0.0;
                     for (int c = part; c < Q; c += 4) acc += sF[c * Q + row] * sW[r * Q + c];
@@ -768,7 +769,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
         // ---- D_j into the packed triangle (the previous factor is dead: it went to Lbuf, and its last reader -- the F solve -- is behind a barrier): in the same
         // phase as the t update and the store of F, no barrier between them
         STAMP(3);
-        if (!(pp && j > 0)) { if (rowt) for (int cp = ty; cp <= tx; cp += 8) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp]; }    // (else: prefetched during the previous separator)
+        if (!(pp && j > 0)) { if (rowt) for (int cp = ty; cp <= tx; cp += NTY) sL[PK(tx, cp)] = virt ? 0.0 : Dd[((size_t)s * Q + tx) * Q + cp]; }    // (else: prefetched during the previous separator)
         __syncthreads();
         STAMP(4);
         if (j > 0) {
@@ -839,25 +840,27 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 // (2) slice J (columns == J mod TQ) of the NEXT separator's coupling block E into sF, which is dead from the rank-Q update of this separator to the
                 // F solve of the next (10 of 116 k cycles per step), and (3) with two triangles the same slice of its D: the global loads are issued FIRST, the
                 // right-hand-side update (1) runs under their latency, the LDS stores come last
-                const int t2 = tid - 64, tx2 = t2 & 127, ty2 = t2 >> 7;                       // 7 full groups of 128 rows
-                const bool pre = j + 1 < npos && t2 < 896 && tx2 < Q;
+                const int t2 = tid - 64, tx2 = t2 & 127, ty2 = t2 >> 7;                       // PFG full groups of 128 rows
+                const bool pre = j + 1 < npos && t2 < 128 * PFG && tx2 < Q;
                 const bool vnext = side == 1 && j + 1 == npos - 1;
-                double ev[3] = {0.0, 0.0, 0.0}, dv[3] = {0.0, 0.0, 0.0};                     // <= ceil(16 / 7) columns of a slice per thread (Q <= 114: a slice has <= 16 columns)
+                double ev[PFN], dv[PFN];
+#pragma unroll
+                for (int u = 0; u < PFN; u++) { ev[u] = 0.0; dv[u] = 0.0; }                     // <= ceil(16 / 7) columns of a slice per thread (Q <= 114: a slice has <= 16 columns)
                 if (pre) {
                     const size_t pnx = (size_t)sep_lo[side == 0 ? s + 1 : s] * DC;             // back side: the next step's s is s - 1 and the separator behind it is this one
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int c = J + TQ * (ty2 + 7 * u); if (c < Q) ev[u] = Z[(size_t)c * n + pnx + tx2]; }
+                    for (int u = 0; u < PFN; u++) { const int c = J + TQ * (ty2 + PFG * u); if (c < Q) ev[u] = Z[(size_t)c * n + pnx + tx2]; }
                     if (pp && !vnext) {
                         const double* Dn = Dd + (size_t)((side == 0) ? s + 1 : s - 1) * Q * Q + (size_t)tx2 * Q;
 #pragma unroll
-                        for (int u = 0; u < 3; u++) { const int cp = J + TQ * (ty2 + 7 * u); if (cp <= tx2) dv[u] = Dn[cp]; }
+                        for (int u = 0; u < PFN; u++) { const int cp = J + TQ * (ty2 + PFG * u); if (cp <= tx2) dv[u] = Dn[cp]; }
                     }
                 }
                 // (1) t(rows below block J - 1) -= L(rows, block J - 1) w_{J-1}: it was the long pole of the trailing phase (one thread per row, sixteen dependent terms, on
                 // waves that also had a tile); here four lanes share a row (four terms each, two xor-shuffles) and the block column J's w is only needed behind the next barrier
                 if (J > 0) {
                     const int quad = t2 >> 2, part = t2 & 3, nrow = Q - c0, cp = c0 - TB;
-                    for (int task = quad; task < NR * nrow; task += 240) {
+                    for (int task = quad; task < NR * nrow; task += (NTHR - 64) / 4) {
                         const int r = (task >= nrow) ? task / nrow : 0, row = c0 + task - r * nrow;
                         const double* Pr = sL + PK(row, cp + 4 * part); const double* wv = sT + r * Q + cp + 4 * part;
                         double v = Pr[0] * wv[0] + Pr[1] * wv[1] + Pr[2] * wv[2] + Pr[3] * wv[3];
@@ -867,8 +870,8 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                 }
                 if (pre) {
 #pragma unroll
-                    for (int u = 0; u < 3; u++) {
-                        const int c = J + TQ * (ty2 + 7 * u);
+                    for (int u = 0; u < PFN; u++) {
+                        const int c = J + TQ * (ty2 + PFG * u);
                         if (c < Q) { if (side == 0) sF[c * Q + tx2] = ev[u]; else sF[tx2 * Q + c] = ev[u]; }
                         if (pp && c <= tx2) sLp[PK(tx2, c)] = dv[u];
                     }
@@ -918,8 +921,8 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                         if (row < Q && col <= row) sL[PK(row, col)] -= u[q];
                     }
                 }
-                if (!CHAIN_PREFETCH && rowt && tx >= c0 + TB && ty >= 8 - NR) {    // t(rows below) -= L(rows, block) w block   (threads of the last waves)
-                    const int r = ty - (8 - NR);
+                if (!CHAIN_PREFETCH && rowt && tx >= c0 + TB && ty >= NTY - NR) {    // t(rows below) -= L(rows, block) w block   (threads of the last waves)
+                    const int r = ty - (NTY - NR);
                     double v = sT[r * Q + tx];
                     const double* Pr = sL + PK(tx, c0);
 #pragma unroll
