@@ -83,3 +83,23 @@ def test_indefinite_band_raises_the_flag(gpu_ctx, monkeypatch):
     segs, seps = R.segment_table(cp, 4, 2)
     band[seps[0][0] + 1, 0] -= np.eye(6) * 1e3             # a pivot inside the separator chain
     assert ba.band_solve_probe(gpu_ctx, 6, cp, band, rhs)[1]["failed"] == 1
+
+
+@pytest.mark.parametrize("env", [{"SSFM_ASM_MFMA": "0"}, {"SSFM_CHAIN_DIAG_MFMA": "0"}, {"SSFM_CHAIN_PINGPONG": "0"}, {"SSFM_CHAIN_THREADS": "512"}, {"SSFM_CHAIN_MFMA": "0"}])
+def test_substructured_solver_variants_agree_with_the_dense_solve(env):
+    """The kernels the round-4 ones replaced stay selectable (VALU separator blocks with atomics, lane-per-row 16x16 factor-and-invert without prefetch, one
+    triangle in LDS, eight waves, the VALU chain of round 1): each in its own process (the switches are read once), against numpy's dense solve --
+    half-width 14 (84-row separators, two triangles fit) and 19 (114 rows: the LDS is full), two-sided chains."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import _band_ref as R; from spherical_sfm_amd import ba; ctx = ba.Context(0)\n"
+            "for (b, rows, P) in ((14, [420], 6), (19, [300, 307], 4), (5, [160, 171], 5)):\n"
+            "    import os; os.environ['SSFM_BAND_SEGMENTS'] = str(P)\n"
+            "    band, A, cp, rhs = R.random_band_system(rows, b, 6, seed=31 + b)\n"
+            "    X, info = ba.band_solve_probe(ctx, 6, cp, band, rhs)\n"
+            "    xr = np.linalg.solve(A, rhs.T).T\n"
+            "    assert info['failed'] == 0 and info['separators'] == (P - 1) * len(rows), info\n"
+            "    err = np.abs(X - xr).max() / np.abs(xr).max(); assert err <= 1e-12, (b, err)\n"
+            "print('VARIANT_OK')\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
