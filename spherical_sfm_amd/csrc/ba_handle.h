@@ -85,7 +85,7 @@ struct ssfm_ba_handle {
     DevBuf<double> Vs, gp, redbuf, Minv, Sff, px, pr, pz, pp, pq, pqpart, scal, pcg;
     DevBuf<double> band, Linv, Yb, Yr; DevBuf<int> cam_pos, band_pairs, band_fail, comp_ptr;
     // substructured factorisation of long components (band_sub.h); disabled => segments == components
-    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given;
+    BandSub sub; DevBuf<int> sub_seg_lo, sub_seg_hi, sub_seg_wend, sub_left, sub_sep_lo, sub_sep_rseg, sub_chain_ptr, sub_tw_lo, sub_tw_hi, sub_tw_copy, sub_seg_given, sub_seg_mode;
     DevBuf<unsigned char> pair_dummy;    // merged 3-dof pairs: 1 = the partner slot of this camera is empty
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
     DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags, sub_fz_lo, sub_fz_hi, sub_fz_wend, sub_fz_merge, sub_fz_await, sub_fz_signal, sub_fz_flags; int sub_seq = 0, sub_fz_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
@@ -127,7 +127,7 @@ struct ssfm_ba_handle {
         diag_cam.free(); diag_pt.free(); diag_f.free(); obs_xy.free(); obs_cam.free(); obs_pt.free(); pt_start.free();
         cam_start.free(); cam_obs.free(); row_ptr.free(); col_idx.free(); diag_slot.free(); Vs.free(); gp.free();
         lmdev.free(); band.free(); Linv.free(); Yb.free(); Yr.free(); cam_pos.free(); band_pairs.free(); band_fail.free(); comp_ptr.free();
-        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); cam_pos2.free(); pair_dummy.free();
+        sub_seg_lo.free(); sub_seg_hi.free(); sub_seg_wend.free(); sub_left.free(); sub_sep_lo.free(); sub_sep_rseg.free(); sub_chain_ptr.free(); sub_tw_lo.free(); sub_tw_hi.free(); sub_tw_copy.free(); sub_seg_given.free(); sub_seg_mode.free(); cam_pos2.free(); pair_dummy.free();
         subZ.free(); subD.free(); subT.free(); subF.free(); subL.free(); subW.free(); subC.free(); subTc.free(); sub_flags.free(); sub_fz_lo.free(); sub_fz_hi.free(); sub_fz_wend.free(); sub_fz_merge.free(); sub_fz_await.free(); sub_fz_signal.free(); sub_fz_flags.free();
         trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
@@ -239,6 +239,11 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     if (!h->sub.enabled) return SSFM_OK;
     const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
     SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_given, B.seg_given, st));
+    {   // back substitution mode of a segment: 0, or 1 / 2 for the two halves of a twisted component (band_kernels2.h: k_band_back_v2 solves the separator itself)
+        std::vector<int> mode(B.seg_twist.size());
+        for (size_t i = 0; i < mode.size(); i++) mode[i] = B.seg_twist[i] >= 0 ? 1 + (B.seg_twist[i] & 1) : 0;
+        SSFM_HIP_CHECK(ctx, upload(h->sub_seg_mode, mode, st));
+    }
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_lo, B.seg_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_hi, B.seg_hi, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_seg_wend, B.seg_wend, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_left, B.left_segs, st));
     SSFM_HIP_CHECK(ctx, upload(h->sub_sep_lo, B.sep_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_sep_rseg, B.sep_rseg, st));
@@ -400,15 +405,21 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 }
                 else LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
             }
+            // EXPERIMENT, off (SSFM_BACK_FUSE=1): the separator of a twisted component back-substituted by the two segment waves themselves (k_band_back_v2's modes 1 / 2) instead
+            // of by a launch of its own.  Measured at config 2 (scripts/lab/ab_backfuse.sh): one launch of 23.2-23.8 us against two of 12.1-12.6 (event brackets), 2.545-2.555 against
+            // 2.530-2.546 ms per solve -- the second wave's redundant separator sweep and a second pipeline fill cost what the launch gap did
+            static const bool back_fuse = std::getenv("SSFM_BACK_FUSE") && std::atoi(std::getenv("SSFM_BACK_FUSE")) != 0;
             if (B.ntwist > 0) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
                 if (wide2p) SSFM_LAUNCH_CHOL2P(B.ntwist, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p);
                 else if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map);
+                if (!back_fuse) {
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();
+                }
             }
             if (B.nleft > 0) {
                 h->span_begin(KID_SUB_APPLY);
@@ -416,7 +427,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_end();
             }
             h->span_begin(KID_BAND_BACK);
-            BACK_V2_LAUNCH(dim3(B.nseg, 2), h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_seg_given.p, Nc, b);
+            BACK_V2_LAUNCH(dim3(B.nseg, 2), h->band.p, h->Linv.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_seg_given.p, Nc, b, (const int*)(back_fuse ? h->sub_seg_mode.p : nullptr));
             h->span_end();
             return SSFM_OK;
         }

@@ -12,6 +12,7 @@
 // row sum takes its L(j,i)^T x_j term at once, the sums shift by one block row per step through ds_bpermute, and no barrier
 // is needed at all.
 #pragma once
+#include <type_traits>
 #include "band_kernels.h"
 
 namespace ssfm {
@@ -575,18 +576,23 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
 constexpr int BACK_PD = 4;
 // NS task sets per lane: 1 for b * DC <= 64 (half-width <= 10 at 6-dof blocks: the second set of loads / sums is compiled out), 2 up to 128, 3 up to 192
 // (round 4: half-widths 22..30, the packed-window factorisation of band_kernels2p.h, twisted components included)
+// tw_mode (round 4, twisted components: seg_0 | sep | seg_1 reversed | copy of sep): the separator's own back substitution used to be a launch of its own in front of
+// this one (b steps + a launch gap in a dependent stream).  Mode 1 (seg_0): the rows [r1, re) ARE the separator and are solved here, the sweep simply starts at its last
+// row.  Mode 2 (seg_1): the wave first solves the separator proper (rows gf .. gf+b-1, an isolated component) into LDS -- the same arithmetic as mode 1's, redundantly --
+// and takes its given rows from there.  Mode 0 / nullptr: as before.
 template <int DC, int NS>
 __global__ void __launch_bounds__(64)
 k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
-               const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b) {
+               const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b,
+               const int* __restrict__ tw_mode = nullptr) {
     constexpr int BB = DC * DC;
+    __shared__ double xs[32 * DC];                                     // mode 2: the separator's solution (b <= 30 rows)
     const int W = b + 1, n = N * DC, lane = threadIdx.x;
     // rows [r1, re) (the separator behind a segment, band_sub.h) already hold their solution: they only feed the pending sums
     // given_from (reversed segment of a twisted component): its given rows are a reversed copy of the separator at rows gf..gf+b-1,
     // row j of the copy = row gf + (re-1-j) of the separator proper, where the solution is
-    const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
-    if (r0 >= r1) return;
-    const int gf = given_from ? given_from[blockIdx.x] : -1;
+    const int mode = tw_mode ? tw_mode[blockIdx.x] : 0;
+    if (piv_lo[blockIdx.x] >= piv_hi[blockIdx.x]) return;
     double* y = Y + (size_t)blockIdx.y * n;
     const int T = b * DC;
     int dd[NS], off[NS]; bool has[NS];
@@ -597,73 +603,85 @@ k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv,
     }
     const int lc = min(lane, DC - 1);
     struct Stage { double col[NS][DC], li[DC], yv; };
-    Stage st[BACK_PD];
     // the row is wave-uniform: a scalar base per row and a 32-bit lane offset per stream (the per-lane 64-bit products of a flat index cost
     // ~16 vector instructions per step of a kernel whose step is bound by the instructions ONE wave can issue)
     const size_t row_stride = (size_t)W * BB;
-    auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
-        const int jc = max(j, r0);
-        const double* __restrict__ rowp = band + (size_t)jc * row_stride;
-        const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
-#pragma unroll
-        for (int m = 0; m < DC; m++) {
-#pragma unroll
-            for (int q = 0; q < NS; q++) s.col[q][m] = rowp[off[q] + m * DC];
-            s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
-        }
-        const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
-        s.yv = y[(size_t)jy * DC + lc];
-    };
-#pragma unroll
-    for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
-    double acc[NS];                        // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
-#pragma unroll
-    for (int q = 0; q < NS; q++) acc[q] = 0.0;
-    for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
-#pragma unroll
-        for (int u = 0; u < BACK_PD; u++) {
-            const int j = jb - u;
-            if (j < r0) break;
-            double c[NS][DC], cl[DC]; const double cy = st[u].yv;
-            bool v[NS];
-#pragma unroll
-            for (int q = 0; q < NS; q++) v[q] = has[q] && j - dd[q] >= r0;       // rows above the component do not exist: their terms are dropped below
+    // one sweep from row re-1 down to r0: rows >= r1 are given (from Y, from the reversed copy at gf, or -- from_lds -- from xs), the others are solved and go to Y (to_lds: to xs)
+    auto sweep = [&](const int r0, const int r1, const int re, const int gf, auto TO_LDS, auto FROM_LDS) {      // (compile-time flags: a step is bound by its instruction count)
+        constexpr bool to_lds = decltype(TO_LDS)::value, from_lds = decltype(FROM_LDS)::value;
+        Stage st[BACK_PD];
+        auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
+            const int jc = max(j, r0);
+            const double* __restrict__ rowp = band + (size_t)jc * row_stride;
+            const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
 #pragma unroll
             for (int m = 0; m < DC; m++) {
 #pragma unroll
-                for (int q = 0; q < NS; q++) c[q][m] = st[u].col[q][m];
-                cl[m] = st[u].li[m];
+                for (int q = 0; q < NS; q++) s.col[q][m] = rowp[off[q] + m * DC];
+                s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
             }
-            fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
-            // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc[0]
-            const double z = cy - acc[0];                           // lanes 0..DC-1
-            // the shift does not depend on x_j: issue it before the dependent chain
-            double sh[NS], sft[NS];
+            const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
+            s.yv = (from_lds && jc >= r1) ? xs[(jy - gf) * DC + lc] : y[(size_t)jy * DC + lc];
+        };
 #pragma unroll
-            for (int q = 0; q < NS; q++) sh[q] = lane_shift_down(acc[q], DC);
+        for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
+        double acc[NS];                        // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
 #pragma unroll
-            for (int q = 0; q < NS; q++) {
-                const double next = (q + 1 < NS) ? sh[q + 1 < NS ? q + 1 : q] : 0.0;       // lanes near the top of a set take from the bottom of the next one
-                sft[q] = (lane + DC < 64) ? sh[q] : next;
-                if (!(lane + 64 * q + DC < T)) sft[q] = 0.0;
+        for (int q = 0; q < NS; q++) acc[q] = 0.0;
+        for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
+#pragma unroll
+            for (int u = 0; u < BACK_PD; u++) {
+                const int j = jb - u;
+                if (j < r0) break;
+                double c[NS][DC], cl[DC]; const double cy = st[u].yv;
+                bool v[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) v[q] = has[q] && j - dd[q] >= r0;       // rows above the component do not exist: their terms are dropped below
+#pragma unroll
+                for (int m = 0; m < DC; m++) {
+#pragma unroll
+                    for (int q = 0; q < NS; q++) c[q][m] = st[u].col[q][m];
+                    cl[m] = st[u].li[m];
+                }
+                fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
+                // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc[0]
+                const double z = cy - acc[0];                           // lanes 0..DC-1
+                // the shift does not depend on x_j: issue it before the dependent chain
+                double sh[NS], sft[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) sh[q] = lane_shift_down(acc[q], DC);
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    const double next = (q + 1 < NS) ? sh[q + 1 < NS ? q + 1 : q] : 0.0;       // lanes near the top of a set take from the bottom of the next one
+                    sft[q] = (lane + DC < 64) ? sh[q] : next;
+                    if (!(lane + 64 * q + DC < T)) sft[q] = 0.0;
+                }
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
+                if (j >= r1) x = cy;                                               // given
+                else if (lane < DC) { if (to_lds) xs[(j - r0) * DC + lane] = x; else y[(size_t)j * DC + lane] = x; }
+                double sm[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) sm[q] = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m);
+#pragma unroll
+                    for (int q = 0; q < NS; q++) sm[q] += c[q][m] * xm; }
+                // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
+#pragma unroll
+                for (int q = 0; q < NS; q++) acc[q] = sft[q] + (v[q] ? sm[q] : 0.0);      // (one select per sum instead of one per loaded entry)
             }
-            double x = 0.0;
-#pragma unroll
-            for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
-            if (j >= r1) x = cy;                                               // given
-            else if (lane < DC) y[(size_t)j * DC + lane] = x;
-            double sm[NS];
-#pragma unroll
-            for (int q = 0; q < NS; q++) sm[q] = 0.0;
-#pragma unroll
-            for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m);
-#pragma unroll
-                for (int q = 0; q < NS; q++) sm[q] += c[q][m] * xm; }
-            // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
-#pragma unroll
-            for (int q = 0; q < NS; q++) acc[q] = sft[q] + (v[q] ? sm[q] : 0.0);      // (one select per sum instead of one per loaded entry)
         }
-    }
+    };
+    const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
+    const int gf = given_from ? given_from[blockIdx.x] : -1;
+    constexpr std::false_type F_{}; constexpr std::true_type T_{};
+    if (mode == 2) {
+        sweep(gf, gf + b, gf + b, -1, T_, F_);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sweep(r0, r1, re, gf, F_, T_);
+    } else sweep(r0, mode == 1 ? re : r1, re, mode == 1 ? -1 : gf, F_, F_);
 }
 
 }  // namespace ssfm
