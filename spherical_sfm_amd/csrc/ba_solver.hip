@@ -658,13 +658,18 @@ extern "C" int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p) {
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
-    std::vector<double> cams((size_t)F.Nc * 6), pts((size_t)F.nP * 3); double f = 0;
-    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(cams.data(), h->cam_x.p, cams.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), h->pts_x.p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    // through the handle's pinned staging buffer when it has one (a reused plan: upload_state allocated it) -- a fresh 2.4 MB std::vector is page faults + a staged pageable copy
+    const size_t n_cam = (size_t)F.Nc * 6, n_pt = (size_t)F.nP * 3;
+    std::vector<double> tmp;
+    double* stage = (h->host_stage && h->host_stage_n >= n_cam + n_pt + 1) ? h->host_stage : nullptr;
+    if (!stage) { tmp.resize(n_cam + n_pt + 1); stage = tmp.data(); }
+    double* cams = stage; double* pts = stage + n_cam; double& f = stage[n_cam + n_pt];
+    SSFM_HIP_CHECK(ctx, hipMemcpyAsync(cams, h->cam_x.p, n_cam * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (F.nP > 0) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(pts, h->pts_x.p, n_pt * sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&f, h->focal3.p, sizeof(double), hipMemcpyDeviceToHost, st));
     SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     // only parameters that were free are written back (constant blocks are bit-identical anyway)
-    for (size_t i = 0; i < cams.size(); i++) if (F.mask_cam[i] > 0.0) p->cameras[i] = cams[i];
+    for (size_t i = 0; i < n_cam; i++) if (F.mask_cam[i] > 0.0) p->cameras[i] = cams[i];
     for (int q = 0; q < F.nP; q++) if (F.mask_pt[(size_t)q * 3] > 0.0) for (int d = 0; d < 3; d++) p->points[(size_t)F.pt_ids[q] * 3 + d] = pts[(size_t)q * 3 + d];
     if (F.focal_free) *p->focal = f;
     if (ctx->collective && ctx->nranks > 1) {
