@@ -340,6 +340,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, true, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+            if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, true, true, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
             // the 16x16 diagonal blocks of the chain are factored and inverted on the matrix cores (band_sub.h: wave_ldl_inverse16_mfma); SSFM_CHAIN_DIAG_MFMA=0: lane per row (round 2)
             static const bool chain_diag_mfma = !(std::getenv("SSFM_CHAIN_DIAG_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_DIAG_MFMA")) == 0);
             static const bool chain_mfma = !(std::getenv("SSFM_CHAIN_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_MFMA")) == 0);     // matrix-core separator chain (band_sub.h 4b)
@@ -389,6 +390,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     static const int chain_threads = std::getenv("SSFM_CHAIN_THREADS") ? std::atoi(std::getenv("SSFM_CHAIN_THREADS")) : 1024;    // 512: eight waves with 256 registers each (band_sub.h)
                     if (chain_diag_mfma && chain_threads == 512)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, true, true, 512>), B.nchain * (tw ? 2 : 1), 512, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
+                           tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
+                    else if (chain_diag_mfma && d_stamps)
+                    LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, true, true, 1024, true>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
                     else if (chain_diag_mfma)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,

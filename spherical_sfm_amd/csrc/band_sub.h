@@ -645,7 +645,7 @@ __device__ __forceinline__ bool wave_ldl_inverse16_mfma(v4d_t& S, v4d_t& G) {
 }
 
 // NTHR = 1024 or 512 threads: at 1024 the kernel sits on the 128-register limit of four waves per SIMD (35 scratch accesses); 512 threads have 256 registers each
-template <int DC, int NR, bool CHAIN_DIAG_MFMA = true, bool CHAIN_PREFETCH = true, int NTHR = 1024>
+template <int DC, int NR, bool CHAIN_DIAG_MFMA = true, bool CHAIN_PREFETCH = true, int NTHR = 1024, bool CHAIN_STAMPED = false>
 __global__ void __launch_bounds__(NTHR)
 k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt, const int* __restrict__ chain_ptr,
                      const int* __restrict__ sep_lo, int N, int b, double* __restrict__ Fbuf, double* __restrict__ Lbuf, double* __restrict__ wbuf,
@@ -653,7 +653,7 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
                      int twist, int nsep_total, double* __restrict__ Cbuf, double* __restrict__ Tcbuf, int* __restrict__ flags, int seq, int pingpong = 0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TB = 16, NTY = NTHR / 128, PFG = (NTHR - 64) / 128, PFN = (16 + PFG - 1) / PFG;     // row groups of 128 threads; groups / values per thread of the prefetching waves
-#define STAMP(k_) do { if (stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(k_) do { if (CHAIN_STAMPED && stamps && blockIdx.x == 0 && j == 1 && tid == 0) stamps[k_] = (long long)__builtin_amdgcn_s_memtime(); } while (0)   /* compiled out of the product build: the kernel is at its register limit */
     const int Q = b * DC, n = N * DC, tid = threadIdx.x, nt = NTHR, NP = Q * (Q + 1) / 2, TQ = (Q + TB - 1) / TB;
     // pingpong (the host sets it when a second triangle fits the LDS, Q <= 96): two triangles take turns -- the factor of separator j - 1 (read by the F solve of
     // separator j) in one, D_j in the other, and D_{j+1} is brought into the first while separator j is factored: the load of D leaves the dependent chain
