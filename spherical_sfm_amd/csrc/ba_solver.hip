@@ -658,10 +658,19 @@ extern "C" int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p) {
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
-    // through the handle's pinned staging buffer when it has one (a reused plan: upload_state allocated it) -- a fresh 2.4 MB std::vector is page faults + a staged pageable copy
+    // through a pinned staging buffer (the handle's when a plan is reused, else the context's) -- a fresh 2.4 MB std::vector is page faults + a staged pageable copy
     const size_t n_cam = (size_t)F.Nc * 6, n_pt = (size_t)F.nP * 3;
     std::vector<double> tmp;
     double* stage = (h->host_stage && h->host_stage_n >= n_cam + n_pt + 1) ? h->host_stage : nullptr;
+    if (!stage) {                                                   // first call on a structure: the context's own buffer (grow-only, outlives the handles)
+        if (ctx->dl_stage_n < n_cam + n_pt + 1) {
+            if (ctx->dl_stage) (void)hipHostFree(ctx->dl_stage);
+            ctx->dl_stage = nullptr; ctx->dl_stage_n = 0;
+            const size_t want = (n_cam + n_pt + 1) + (n_cam + n_pt + 1) / 4;
+            if (hipHostMalloc((void**)&ctx->dl_stage, want * sizeof(double), hipHostMallocDefault) == hipSuccess) ctx->dl_stage_n = want; else { ctx->dl_stage = nullptr; (void)hipGetLastError(); }
+        }
+        stage = ctx->dl_stage;
+    }
     if (!stage) { tmp.resize(n_cam + n_pt + 1); stage = tmp.data(); }
     double* cams = stage; double* pts = stage + n_cam; double& f = stage[n_cam + n_pt];
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(cams, h->cam_x.p, n_cam * sizeof(double), hipMemcpyDeviceToHost, st));

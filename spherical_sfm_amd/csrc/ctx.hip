@@ -41,6 +41,7 @@ extern "C" void ssfm_ctx_destroy(ssfm_ctx* ctx) {
     ssfm_host_stash_clear();                                     // recycled host arrays of the planner (ba_solver.hip)
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->dl_stage) (void)hipHostFree(ctx->dl_stage);
     if (ctx->host_pub) (void)hipHostFree(ctx->host_pub);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
