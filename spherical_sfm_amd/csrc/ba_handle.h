@@ -94,7 +94,6 @@ struct ssfm_ba_handle {
     double focal_host = 0, t_flatten_s = 0;
     double* host_sp = nullptr;           // pinned read-back buffer of the LM loop
     double* host_pub = nullptr;          // = ctx->host_pub once publish_alloc ran (k_publish target, coherent pinned memory)
-    double* host_stage = nullptr; size_t host_stage_n = 0;   // pinned staging of the parameter upload when a plan is reused
     bool scale_ready = false;
     bool band_filled = false;            // set by k_finalize_gather for the next solve_reduced call
     // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
@@ -135,7 +134,6 @@ struct ssfm_ba_handle {
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
         host_pub = nullptr;
-        if (host_stage) { (void)hipHostFree(host_stage); host_stage = nullptr; host_stage_n = 0; }
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         for (auto& e : phase_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }

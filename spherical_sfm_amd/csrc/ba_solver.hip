@@ -658,11 +658,11 @@ extern "C" int ssfm_ba_download(ssfm_ba_handle* h, ssfm_ba_problem* p) {
     const BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
-    // through a pinned staging buffer (the handle's when a plan is reused, else the context's) -- a fresh 2.4 MB std::vector is page faults + a staged pageable copy
+    // through the context's pinned staging buffer -- a fresh 2.4 MB std::vector is page faults + a staged pageable copy
     const size_t n_cam = (size_t)F.Nc * 6, n_pt = (size_t)F.nP * 3;
     std::vector<double> tmp;
-    double* stage = (h->host_stage && h->host_stage_n >= n_cam + n_pt + 1) ? h->host_stage : nullptr;
-    if (!stage) {                                                   // first call on a structure: the context's own buffer (grow-only, outlives the handles)
+    double* stage = nullptr;
+    {                                                               // the context's pinned staging buffer (grow-only, outlives the handles; shared with upload_state)
         if (ctx->dl_stage_n < n_cam + n_pt + 1) {
             if (ctx->dl_stage) (void)hipHostFree(ctx->dl_stage);
             ctx->dl_stage = nullptr; ctx->dl_stage_n = 0;
@@ -822,17 +822,19 @@ void structure_hash(const ssfm_ba_problem* p, uint64_t& a, uint64_t& b) {
 int upload_state(ssfm_ba_handle* h, const ssfm_ba_problem* p) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; BAFlat& F = h->F;
     if (F.nothing_to_do) return SSFM_OK;
-    // gather points / pixels in the plan's order straight into a pinned staging buffer (allocated on the first reuse of a plan), on the
-    // planner's threads; then three asynchronous copies
+    // gather points / pixels in the plan's order straight into a pinned staging buffer, on the planner's threads; then three asynchronous copies
     const double t_up0 = wall_s();
     const size_t n_pts = (size_t)F.nP * 3, n_xy = (size_t)F.M * 2;
-    if (!h->host_stage || h->host_stage_n < n_pts + n_xy) {
-        if (h->host_stage) (void)hipHostFree(h->host_stage);
-        h->host_stage = nullptr; h->host_stage_n = 0;
-        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&h->host_stage, std::max<size_t>(n_pts + n_xy, 1) * sizeof(double), hipHostMallocDefault));
-        h->host_stage_n = n_pts + n_xy;
+    // the staging buffer belongs to the CONTEXT (grow-only; one stream, solves one after the other): a hipHostMalloc per handle on its first reuse cost 5 ms at 1 M
+    // observations (26 MB) -- two of the four Optimize stages of the drivers' sequence paid it
+    if (ctx->dl_stage_n < n_pts + n_xy + 1) {
+        if (ctx->dl_stage) (void)hipHostFree(ctx->dl_stage);
+        ctx->dl_stage = nullptr; ctx->dl_stage_n = 0;
+        const size_t want = (n_pts + n_xy + 1) + (n_pts + n_xy + 1) / 4;
+        SSFM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->dl_stage, want * sizeof(double), hipHostMallocDefault));
+        ctx->dl_stage_n = want;
     }
-    double* sp = h->host_stage; double* sx = h->host_stage + n_pts;
+    double* sp = ctx->dl_stage; double* sx = ctx->dl_stage + n_pts;
     const int NT = planner_threads();
     parallel_chunks(F.M, NT, [&](int t, int64_t lo, int64_t hi) {      // one fork-join: every thread takes its share of the pixels and of the points
         for (int64_t j = lo; j < hi; j++) { const int64_t o = F.obs_orig[j]; sx[2 * j] = p->obs_xy[2 * o]; sx[2 * j + 1] = p->obs_xy[2 * o + 1]; }

@@ -19,7 +19,7 @@ struct ssfm_ctx {
     bool collective = false;     // reductions go through RCCL or the host hook (nranks > 1, or a forced 1-rank communicator)
     ssfm_host_allreduce_fn host_allreduce = nullptr; void* host_allreduce_user = nullptr;   // alternative to RCCL
     double* host_stage = nullptr; size_t host_stage_n = 0;                                  // pinned staging for the hook
-    double* dl_stage = nullptr; size_t dl_stage_n = 0;                                      // pinned staging of ssfm_ba_download (grow-only: outlives the handles)
+    double* dl_stage = nullptr; size_t dl_stage_n = 0;                                      // pinned staging of upload_state / ssfm_ba_download (grow-only: outlives the handles)
     int num_cus = 256;
     // one-entry plan cache of ssfm_ba_solve (ba_solver.hip): the resident handle of the last problem structure
     void* plan_cache = nullptr; void (*plan_cache_free)(void*) = nullptr;
