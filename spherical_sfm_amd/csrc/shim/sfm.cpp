@@ -112,11 +112,11 @@ void SfM::Flatten(FlatProblem& F) {
     for (auto& kv : rotationFixed) if (kv.first >= 0 && kv.first < numCameras && cam_ok[kv.first]) F.rf[kv.first] = kv.second;
     for (auto& kv : translationFixed) if (kv.first >= 0 && kv.first < numCameras && cam_ok[kv.first]) F.tf[kv.first] = kv.second;
     for (int c = 0; c < numCameras; c++) if (cam_ok[c]) { if (!rotationFixed.count(c)) F.rf[c] = 0; if (!translationFixed.count(c)) F.tf[c] = 0; }   // (operator[] of the flags: absent = false)
-    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) {
+    for (auto&& kv : points) if (kv.first >= 0 && kv.first < numPoints) {
         for (int k = 0; k < 3; k++) F.pts[(size_t)kv.first * 3 + k] = kv.second.v[k];
         pt_ok[kv.first] = 1;
     }
-    for (auto& kv : pointFixed) if (kv.first >= 0 && kv.first < numPoints && pt_ok[kv.first]) F.pf[kv.first] = kv.second;
+    for (auto&& kv : pointFixed) if (kv.first >= 0 && kv.first < numPoints && pt_ok[kv.first]) F.pf[kv.first] = kv.second;
     ObsCache& C = obs_cache;
     if (C.stale) {
         // counting sort by point over the camera-major maps: rows come in ascending camera order and every row in ascending point order, so the observations of a
@@ -154,7 +154,7 @@ void SfM::Retriangulate() {
     FlatProblem F; Flatten(F);
     int rc = retriangulateMode < 0 ? ssfm_retriangulate(ctx, &F.P, nullptr) : ssfm_retriangulate_mode(ctx, &F.P, retriangulateMode, nullptr, nullptr, nullptr);
     if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(ctx) << "\n"; exit(1); }
-    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = F.pts[(size_t)kv.first * 3 + k];
+    for (auto&& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = F.pts[(size_t)kv.first * 3 + k];
 }
 
 bool SfM::Optimize() {
@@ -172,7 +172,7 @@ bool SfM::Optimize() {
                 last_summary.initial_cost, last_summary.final_cost, last_summary.termination, last_summary.t_solve_s);
     if (last_summary.termination == SSFM_FAILURE) { std::cout << "error: ceres failed.\n"; exit(1); }             // src/sfm.cpp:278-282
     for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) for (int k = 0; k < 6; k++) kv.second[k] = cam[(size_t)kv.first * 6 + k];
-    for (auto& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = pts[(size_t)kv.first * 3 + k];
+    for (auto&& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = pts[(size_t)kv.first * 3 + k];
     return last_summary.termination == SSFM_CONVERGENCE;                                      // src/sfm.cpp:289
 }
 
@@ -180,14 +180,14 @@ void SfM::Apply(const Pose& pose) {                                             
     Pose inv = pose.inverse();
     for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); c.postMultiply(inv); SetPose(i, c); }
     // (the reference probes j = 0 .. numPoints-1 with exists(): the same points in the same order as walking the map)
-    for (auto& kv : points) {
+    for (auto&& kv : points) {
         if (kv.first < 0 || kv.first >= numPoints || kv.second.norm() == 0) continue;
         kv.second = pose.apply(kv.second);
     }
 }
 void SfM::Apply(double scale) {                                                               // src/sfm.cpp:364-382
     for (int i = 0; i < numCameras; i++) { Pose c = GetPose(i); for (int k = 0; k < 3; k++) c.t.v[k] *= scale; SetPose(i, c); }
-    for (auto& kv : points) {
+    for (auto&& kv : points) {
         if (kv.first < 0 || kv.first >= numPoints || kv.second.norm() == 0) continue;
         for (int k = 0; k < 3; k++) kv.second.v[k] *= scale;
     }

@@ -10,6 +10,9 @@
 // src/sfm.cpp:240-263) and hands caller-owned buffers to ssfm_ba_solve.
 #pragma once
 #include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -48,18 +51,62 @@ struct Intrinsics {                       // sfm_types.h:31-47
     Intrinsics(double _focal, double _centerx, double _centery) : focal(_focal), centerx(_centerx), centery(_centery) {}
 };
 
+// The slice of std::map<int, T>'s interface the mirror uses -- operator[], find / end, count, erase, iteration in ascending key order with .first / .second -- over
+// DENSE storage: point ids are small non-negative integers issued in order (AddPoint), and at 170 000 points every walk over a std::map (Flatten, the write-back after
+// Optimize / Retriangulate, Apply: ten per driver run) cost ~5 ms of pointer chasing against 0.1 ms over a vector (the reference's SparseVector is a std::map too:
+// sparse.hpp:9-59; what callers see -- which ids exist, in which order they are visited -- is the same).
+template <class T> class IndexedMap {
+    std::vector<T> val; std::vector<char> has; size_t n = 0;
+    static void check(int k) { if (k < 0) { std::fprintf(stderr, "IndexedMap: negative id %d\n", k); std::abort(); } }
+public:
+    struct Ref { const int first; T& second; };
+    struct CRef { const int first; const T& second; };
+    template <class M, class R> class Iter {
+        M* m; int i;
+        void skip() { while (i < (int)m->has.size() && !m->has[i]) i++; }
+        struct Arrow { R r; R* operator->() { return &r; } };
+    public:
+        Iter(M* m_, int i_) : m(m_), i(i_) { skip(); }
+        R operator*() const { return R{i, m->val[i]}; }
+        Arrow operator->() const { return Arrow{R{i, m->val[i]}}; }
+        Iter& operator++() { i++; skip(); return *this; }
+        bool operator==(const Iter& o) const { return i == o.i; }
+        bool operator!=(const Iter& o) const { return i != o.i; }
+    };
+    using iterator = Iter<IndexedMap, Ref>; using const_iterator = Iter<const IndexedMap, CRef>;
+    friend iterator; friend const_iterator;
+    iterator begin() { return iterator(this, 0); }
+    iterator end() { return iterator(this, (int)has.size()); }
+    const_iterator begin() const { return const_iterator(this, 0); }
+    const_iterator end() const { return const_iterator(this, (int)has.size()); }
+    iterator find(int k) { return (k >= 0 && k < (int)has.size() && has[k]) ? iterator(this, k) : end(); }
+    const_iterator find(int k) const { return (k >= 0 && k < (int)has.size() && has[k]) ? const_iterator(this, k) : end(); }
+    size_t count(int k) const { return (k >= 0 && k < (int)has.size() && has[k]) ? 1 : 0; }
+    T& operator[](int k) {
+        check(k);
+        if (k >= (int)has.size()) { const size_t want = std::max<size_t>((size_t)k + 1, has.size() + has.size() / 2); val.resize(want); has.resize(want, 0); }
+        if (!has[k]) { has[k] = 1; val[k] = T(); n++; }
+        return val[k];
+    }
+    size_t erase(int k) { if (!count(k)) return 0; has[k] = 0; val[k] = T(); n--; return 1; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { val.clear(); has.clear(); n = 0; }
+};
+
 class SfM {
 protected:
     Intrinsics intrinsics;
     std::map<int, Camera> cameras;
-    std::map<int, Point> points;
+    IndexedMap<Point> points;
     std::map<int, std::map<int, Observation>> observations;   // [camera][point]
     std::map<int, std::map<int, Pose>> measurements;           // [camera][camera], include/sphericalsfm/sfm.h:27 (the reference never writes it either)
     std::map<int, std::string> paths;
     std::map<int, std::array<unsigned char, 3>> colors;        // BGR like cv::Vec3b (the reference's SparseVector<cv::Vec3b>)
     std::map<int, std::vector<float>> descriptors;             // SparseVector<cv::Mat>, one row of floats per point
     bool focalFixed;
-    std::map<int, bool> rotationFixed, translationFixed, pointFixed;
+    std::map<int, bool> rotationFixed, translationFixed;
+    IndexedMap<char> pointFixed;
     int numCameras, numPoints, nextCamera, nextPoint;
     ssfm_ctx* ctx;                        // created on first Optimize()
     ssfm_ba_summary last_summary;
