@@ -71,7 +71,7 @@ void SfM::MergePoint(int point1, int point2) {                                  
     for (auto& row : observations) {
         if (row.first < 0 || row.first >= numCameras || !cameras.count(row.first)) continue;
         auto it = row.second.find(point2);
-        if (it != row.second.end()) row.second[point1] = it->second;
+        if (it != row.second.end()) { const Observation o = it->second; row.second[point1] = o; }    // (a copy first: the insert may move the row's storage)
     }
     RemovePoint(point2);
 }

@@ -94,12 +94,40 @@ public:
     void clear() { val.clear(); has.clear(); n = 0; }
 };
 
+// One row of the observation table (the points a camera sees): the same slice of std::map<int, T>'s interface over a SORTED VECTOR of (id, value) pairs.  A row is written in
+// ascending point order by every caller in the tree (build_sfm, the drivers: push_back), anything else is a binary search + insert.  The first Flatten of a run walks all rows
+// twice: 2 x 1.02 M std::map nodes took ~60 ms at configs[2] size, the vectors ~5.
+template <class T> class FlatMap {
+    std::vector<std::pair<int, T>> v;
+    struct KeyLess { bool operator()(const std::pair<int, T>& a, int k) const { return a.first < k; } };
+public:
+    using iterator = typename std::vector<std::pair<int, T>>::iterator;
+    using const_iterator = typename std::vector<std::pair<int, T>>::const_iterator;
+    iterator begin() { return v.begin(); }
+    iterator end() { return v.end(); }
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    iterator find(int k) { auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
+    const_iterator find(int k) const { auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
+    size_t count(int k) const { return find(k) != v.end() ? 1 : 0; }
+    T& operator[](int k) {
+        if (v.empty() || v.back().first < k) { v.emplace_back(k, T()); return v.back().second; }
+        auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess());
+        if (it != v.end() && it->first == k) return it->second;
+        return v.insert(it, std::make_pair(k, T()))->second;
+    }
+    size_t erase(int k) { auto it = find(k); if (it == v.end()) return 0; v.erase(it); return 1; }
+    iterator erase(iterator it) { return v.erase(it); }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+};
+
 class SfM {
 protected:
     Intrinsics intrinsics;
     std::map<int, Camera> cameras;
     IndexedMap<Point> points;
-    std::map<int, std::map<int, Observation>> observations;   // [camera][point]
+    std::map<int, FlatMap<Observation>> observations;          // [camera][point]: rows as sorted vectors (FlatMap above)
     std::map<int, std::map<int, Pose>> measurements;           // [camera][camera], include/sphericalsfm/sfm.h:27 (the reference never writes it either)
     std::map<int, std::string> paths;
     std::map<int, std::array<unsigned char, 3>> colors;        // BGR like cv::Vec3b (the reference's SparseVector<cv::Vec3b>)
