@@ -22,3 +22,17 @@ def test_planner_and_tracks_under_sanitizers(tmp_path, flags, env):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
     assert run.returncode == 0 and "SANITIZE_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
     assert "runtime error" not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr
+
+
+def test_mirror_containers_under_sanitizers(tmp_path):
+    """IndexedMap / FlatMap (csrc/shim/sfm.h) -- the dense point table and the sorted-vector observation rows behind the std::map interface of the SfM mirror --
+    against std::map on random operation sequences, ASan + UBSan."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_maps_sanitize")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", os.path.join(ROOT, "tests", "native", "shim_maps_sanitize.cpp"), "-o", exe],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "SHIM_MAPS_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
+    assert "runtime error" not in run.stderr
