@@ -95,31 +95,45 @@ public:
 };
 
 // One row of the observation table (the points a camera sees): the same slice of std::map<int, T>'s interface over a SORTED VECTOR of (id, value) pairs.  A row is written in
-// ascending point order by every caller in the tree (build_sfm, the drivers: push_back), anything else is a binary search + insert.  The first Flatten of a run walks all rows
+// ascending point order by the synthetic drivers (push_back); anything else goes through a small merge buffer (below).  The first Flatten of a run walks all rows
 // twice: 2 x 1.02 M std::map nodes took ~60 ms at configs[2] size, the vectors ~5.
 template <class T> class FlatMap {
-    std::vector<std::pair<int, T>> v;
+    // Out-of-order inserts (build_sfm hands a keyframe's observations over in feature order, i.e. in random track order) wait in a small unsorted buffer and are merged
+    // in when it holds 64 of them: a random insert into a 2000-entry row costs a search + 1/64 of a merge instead of moving half the row.
+    mutable std::vector<std::pair<int, T>> v;          // sorted by id, unique
+    mutable std::vector<std::pair<int, T>> pend;       // ids not in v, unique, unsorted
     struct KeyLess { bool operator()(const std::pair<int, T>& a, int k) const { return a.first < k; } };
+    void flush() const {
+        if (pend.empty()) return;
+        std::sort(pend.begin(), pend.end(), [](const std::pair<int, T>& a, const std::pair<int, T>& b) { return a.first < b.first; });
+        const size_t mid = v.size();
+        v.insert(v.end(), pend.begin(), pend.end());
+        std::inplace_merge(v.begin(), v.begin() + (std::ptrdiff_t)mid, v.end(), [](const std::pair<int, T>& a, const std::pair<int, T>& b) { return a.first < b.first; });
+        pend.clear();
+    }
 public:
     using iterator = typename std::vector<std::pair<int, T>>::iterator;
     using const_iterator = typename std::vector<std::pair<int, T>>::const_iterator;
-    iterator begin() { return v.begin(); }
-    iterator end() { return v.end(); }
-    const_iterator begin() const { return v.begin(); }
-    const_iterator end() const { return v.end(); }
-    iterator find(int k) { auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
-    const_iterator find(int k) const { auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
-    size_t count(int k) const { return find(k) != v.end() ? 1 : 0; }
+    iterator begin() { flush(); return v.begin(); }
+    iterator end() { flush(); return v.end(); }
+    const_iterator begin() const { flush(); return v.begin(); }
+    const_iterator end() const { flush(); return v.end(); }
+    iterator find(int k) { flush(); auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
+    const_iterator find(int k) const { flush(); auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? it : v.end(); }
+    size_t count(int k) const { flush(); auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess()); return (it != v.end() && it->first == k) ? 1 : 0; }
     T& operator[](int k) {
-        if (v.empty() || v.back().first < k) { v.emplace_back(k, T()); return v.back().second; }
+        if (pend.empty() && (v.empty() || v.back().first < k)) { v.emplace_back(k, T()); return v.back().second; }      // ids in ascending order: the common case
         auto it = std::lower_bound(v.begin(), v.end(), k, KeyLess());
         if (it != v.end() && it->first == k) return it->second;
-        return v.insert(it, std::make_pair(k, T()))->second;
+        for (auto& e : pend) if (e.first == k) return e.second;
+        pend.emplace_back(k, T());
+        if (pend.size() > 64) { flush(); return std::lower_bound(v.begin(), v.end(), k, KeyLess())->second; }
+        return pend.back().second;
     }
     size_t erase(int k) { auto it = find(k); if (it == v.end()) return 0; v.erase(it); return 1; }
-    iterator erase(iterator it) { return v.erase(it); }
-    size_t size() const { return v.size(); }
-    bool empty() const { return v.empty(); }
+    iterator erase(iterator it) { return v.erase(it); }          // (it comes from begin() / find(): the buffer is merged)
+    size_t size() const { return v.size() + pend.size(); }
+    bool empty() const { return v.empty() && pend.empty(); }
 };
 
 class SfM {

@@ -31,6 +31,7 @@ template <class M> static long run(const char* what, unsigned seed, bool ascendi
     return sum;
 }
 int main() {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);
     long s = 0;
     for (unsigned seed = 1; seed <= 6; seed++) { s += run<IndexedMap<double>>("IndexedMap", seed, seed & 1); s += run<FlatMap<double>>("FlatMap", 100 + seed, seed & 1); }
     // erase through an iterator while walking a row (FilterObservations)
