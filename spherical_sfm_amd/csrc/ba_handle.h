@@ -547,7 +547,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     if (F.sym_lower && h->tail.on) {
         const int phi_parts = !F.focal_free ? -1 : (Nc > 1024 ? std::min(64, (n + 2047) / 2048) : 0);      // -1: focal fixed, the arrow is empty (pqpart: Nc doubles, only used by the PCG mat-vec)
         if (phi_parts > 0) LAUNCH(h, KID_BAND_COMBINE, k_arrow_phi<DC>, phi_parts, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->cam_pos.p, Nc, h->pqpart.p);
-        LAUNCH(h, KID_PCG_MATVEC, k_arrow_update<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
+        LAUNCH(h, KID_PCG_MATVEC, k_arrow_update<DC>, (Nc + 3) / 4, 512, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
                h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p, h->tail.cam, h->tail.focal, h->scale_cam.p, h->scale_f.p,
                h->tail.cam_c, h->tail.focal_c, h->tail.rot_c, h->scal.p, h->pqpart.p, phi_parts);
     } else if (F.sym_lower) {

@@ -1440,8 +1440,10 @@ k_arrow_phi(const double* __restrict__ V, const double* __restrict__ U, const do
 // ---- K3a': k_arrow_matvec and k_cam_update in one launch (the usual tail of an LM iteration): every wave owns one camera -- its row of
 // q = S x for the residual check, its part of the step x, its candidate parameters and their rotation tables; the two camera norms
 // go to the replicated scalar slots by one atomic pair per workgroup.  Saves a single-workgroup launch (7 us) per iteration.
+// Round 4: TWO waves per camera (512 threads, four cameras per workgroup) -- the row of q = S x (four dependent gathers) on one, the candidate parameters and their rotation
+// tables (a serial sincos chain on one lane) on the other: the kernel's time is the longer of the two instead of their sum (9.3 -> see profiles/r04_notes.md us at config 2).
 template <int DC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
                const double* __restrict__ rho_ptr, const int* __restrict__ pos, const int* __restrict__ row_ptr, const int* __restrict__ col_idx,
                const int* __restrict__ trans_ptr, const int* __restrict__ trans_blk, const int* __restrict__ trans_row,
@@ -1449,14 +1451,14 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
                const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
                const double* __restrict__ scale_f, double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c,
                double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts) {
-    __shared__ double red[2 * 4];
+    __shared__ double red[2 * 8];
     __shared__ double part[4][64];
     __shared__ double part2[4][2];
     __shared__ double sphi;
     constexpr int BB = DC * DC;
     constexpr int LW = (64 / DC) * DC;
     constexpr int off = (DC == 6) ? 0 : 3;
-    const int n = Nc * DC, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = Nc * DC, w = (threadIdx.x >> 6) & 3, role = threadIdx.x >> 8, lane = threadIdx.x & 63;      // role 0: the matvec row, role 1: candidate + rotation tables
     double phi;
     if (phi_parts < 0) phi = 0.0;                                   // focal fixed: S_fc = 0, S_ff = 1, rho = 0 -- no block-wide dot products, no barrier
     else if (phi_parts > 0) {                                       // large camera sets: the dot products come from k_arrow_phi
@@ -1472,8 +1474,8 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
         phi = sphi;
     }
     const int c = blockIdx.x * 4 + w;
-    if (lane < 2) part2[w][lane] = 0.0;
-    if (c < Nc) {
+    if (lane < 2 && role == 1) part2[w][lane] = 0.0;
+    if (c < Nc && role == 0) {
         const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tb = trans_ptr[c], nt = trans_ptr[c + 1] - tb;
         double s = 0.0;
         if (lane < LW) {
@@ -1497,6 +1499,8 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
             }
         }
         part[w][lane] = s;
+    }
+    if (c < Nc && role == 1) {
         // candidate camera: lanes 0..5 hold its six parameters
         double v = 0.0, d2 = 0.0, v2 = 0.0;
         if (lane < 6) {
@@ -1520,7 +1524,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
         }
     }
     __syncthreads();
-    if (c < Nc && lane < DC) {
+    if (c < Nc && lane < DC && role == 0) {
         double s = 0.0;
         for (int l = lane; l < LW; l += DC) s += part[w][l];
         q[c * DC + lane] = s + Sfc[c * DC + lane] * phi;
