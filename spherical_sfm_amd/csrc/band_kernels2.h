@@ -109,7 +109,92 @@ inline CholWaveMap chol_wave_map(int nw, int ntw, int heavy_tw) {      // heavy_
 // read-modify-write.  Against the 3x3 register tiles of the VALU version (54 LDS operations per 54 multiply-adds and lane, scattered over
 // the panel: the phase was LDS-conflict bound at ~80 B/clk) a tile is 8 conflict-free operand reads + 4 read-modify-writes per 1536
 // multiply-adds.  SSFM_BAND_MFMA=0 selects the VALU version.
-template <int DC, int NR, int MF = 0, int TCW = 3>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead; TCW: columns of a trailing tile (3: 3x3 tiles, 2: 3x2)
+constexpr int BACK_PD = 4;
+// One sweep of the back substitution from row re-1 down to r0 by ONE wave: rows >= r1 are given (from y, from the reversed copy at gf, or -- FROM_LDS -- from xs), the others are solved
+// and go to y (TO_LDS: to xs).  Shared by k_band_back_v2 and by the epilogue of k_band_chol_v2 that solves a small component in the launch that factored it.
+template <int DC, int NS, bool to_lds, bool from_lds>
+__device__ __forceinline__ void band_back_sweep(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ y, double* xs,
+                                                const int r0, const int r1, const int re, const int gf, const int b, const int lane) {
+    constexpr int BB = DC * DC;
+    const int W = b + 1, T = b * DC;
+    int dd[NS], off[NS]; bool has[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int t = min(lane + 64 * s, T - 1);                    // clamped: lanes without a task recompute a valid one and are masked
+        dd[s] = t / DC + 1; off[s] = dd[s] * BB + (t - (dd[s] - 1) * DC); has[s] = lane + 64 * s < T;
+    }
+    const int lc = min(lane, DC - 1);
+    struct Stage { double col[NS][DC], li[DC], yv; };
+    // the row is wave-uniform: a scalar base per row and a 32-bit lane offset per stream (the per-lane 64-bit products of a flat index cost
+    // ~16 vector instructions per step of a kernel whose step is bound by the instructions ONE wave can issue)
+    const size_t row_stride = (size_t)W * BB;
+        Stage st[BACK_PD];
+        auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
+            const int jc = max(j, r0);
+            const double* __restrict__ rowp = band + (size_t)jc * row_stride;
+            const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
+#pragma unroll
+            for (int m = 0; m < DC; m++) {
+#pragma unroll
+                for (int q = 0; q < NS; q++) s.col[q][m] = rowp[off[q] + m * DC];
+                s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
+            }
+            const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
+            s.yv = (from_lds && jc >= r1) ? xs[(jy - gf) * DC + lc] : y[(size_t)jy * DC + lc];
+        };
+#pragma unroll
+        for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
+        double acc[NS];                        // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
+#pragma unroll
+        for (int q = 0; q < NS; q++) acc[q] = 0.0;
+        for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
+#pragma unroll
+            for (int u = 0; u < BACK_PD; u++) {
+                const int j = jb - u;
+                if (j < r0) break;
+                double c[NS][DC], cl[DC]; const double cy = st[u].yv;
+                bool v[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) v[q] = has[q] && j - dd[q] >= r0;       // rows above the component do not exist: their terms are dropped below
+#pragma unroll
+                for (int m = 0; m < DC; m++) {
+#pragma unroll
+                    for (int q = 0; q < NS; q++) c[q][m] = st[u].col[q][m];
+                    cl[m] = st[u].li[m];
+                }
+                fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
+                // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc[0]
+                const double z = cy - acc[0];                           // lanes 0..DC-1
+                // the shift does not depend on x_j: issue it before the dependent chain
+                double sh[NS], sft[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) sh[q] = lane_shift_down(acc[q], DC);
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    const double next = (q + 1 < NS) ? sh[q + 1 < NS ? q + 1 : q] : 0.0;       // lanes near the top of a set take from the bottom of the next one
+                    sft[q] = (lane + DC < 64) ? sh[q] : next;
+                    if (!(lane + 64 * q + DC < T)) sft[q] = 0.0;
+                }
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
+                if (j >= r1) x = cy;                                               // given
+                else if (lane < DC) { if (to_lds) xs[(j - r0) * DC + lane] = x; else y[(size_t)j * DC + lane] = x; }
+                double sm[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) sm[q] = 0.0;
+#pragma unroll
+                for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m);
+#pragma unroll
+                    for (int q = 0; q < NS; q++) sm[q] += c[q][m] * xm; }
+                // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
+#pragma unroll
+                for (int q = 0; q < NS; q++) acc[q] = sft[q] + (v[q] ? sm[q] : 0.0);      // (one select per sum instead of one per loaded entry)
+            }
+        }
+}
+
+template <int DC, int NR, int MF = 0, int TCW = 3, bool SOLVE = false>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead; TCW: columns of a trailing tile (3: 3x3 tiles, 2: 3x2); SOLVE: the instantiation with the back-substitution epilogue (its own kernel: the epilogue's registers cost the step loop 30 -> 41 us when every launch carried it)
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
@@ -117,7 +202,10 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                const CholWaveMap wmap,                 // role of every physical wave (chol_wave_map; identity = roles in wave order)
                // fused launch of segments and the separators that wait for them (ba_handle.h band_direct): per workgroup the first of two flags to await
                // before its window is loaded (-1: none) and the flag to raise when its rows are in global memory (-1: none); flags hold launch numbers
-               const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0) {
+               const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0,
+               // solve_small (round 4): the component is a whole one of at most b + 1 rows with b DC <= 64 (the separator of a twisted component): its back substitution runs
+               // here, behind the factorisation, instead of in a launch of its own (ten steps + a launch gap + a pipeline fill in a dependent stream at config 2)
+               int solve_small = 0) {
     constexpr int BB = DC * DC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int R = b + 1, W = b + 1, RW = W * BB;
@@ -568,12 +656,19 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
         __threadfence(); __syncthreads();
         if (tid == 0) __hip_atomic_store(flags + sig, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (SOLVE) if (solve_small && re == r1 && b * DC <= 64) {
+        // the factor, its inverse diagonal blocks and the forward-substituted right-hand sides went to global memory through the writer wave: visible to the rest of the
+        // WORKGROUP is enough (same compute unit, same L1: a workgroup-scope fence is a wait, an agent-scope one writes the L2 back on this multi-XCD part -- 22 us here),
+        // then one wave per right-hand side sweeps backwards
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int pw = (int)(threadIdx.x >> 6);
+        if (pw < NR) band_back_sweep<DC, 1, false, false>(band, Ginv, Y + (size_t)pw * n, nullptr, r0, r1, r1, -1, b, lane);
+    }
 }
 
 // Back substitution Y <- L^-T Y.  grid (components, NR), ONE wave per block.  Task t = (d-1)*DC + a (d = 1..b) owns the pending
 // sum of row j-(d-1), component a; a lane carries tasks t = lane + 64 s, s < NS (b*DC <= 64 NS).  The factor streams from
 // global memory BACK_PD steps ahead (a step is shorter than one memory latency), loads unconditional from clamped addresses.
-constexpr int BACK_PD = 4;
 // NS task sets per lane: 1 for b * DC <= 64 (half-width <= 10 at 6-dof blocks: the second set of loads / sums is compiled out), 2 up to 128, 3 up to 192
 // (round 4: half-widths 22..30, the packed-window factorisation of band_kernels2p.h, twisted components included)
 // tw_mode (round 4, twisted components: seg_0 | sep | seg_1 reversed | copy of sep): the separator's own back substitution used to be a launch of its own in front of
@@ -585,103 +680,21 @@ __global__ void __launch_bounds__(64)
 k_band_back_v2(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ piv_lo,
                const int* __restrict__ piv_hi, const int* __restrict__ win_hi, const int* __restrict__ given_from, int N, int b,
                const int* __restrict__ tw_mode = nullptr) {
-    constexpr int BB = DC * DC;
     __shared__ double xs[32 * DC];                                     // mode 2: the separator's solution (b <= 30 rows)
-    const int W = b + 1, n = N * DC, lane = threadIdx.x;
+    const int n = N * DC, lane = threadIdx.x;
     // rows [r1, re) (the separator behind a segment, band_sub.h) already hold their solution: they only feed the pending sums
     // given_from (reversed segment of a twisted component): its given rows are a reversed copy of the separator at rows gf..gf+b-1,
     // row j of the copy = row gf + (re-1-j) of the separator proper, where the solution is
     const int mode = tw_mode ? tw_mode[blockIdx.x] : 0;
     if (piv_lo[blockIdx.x] >= piv_hi[blockIdx.x]) return;
     double* y = Y + (size_t)blockIdx.y * n;
-    const int T = b * DC;
-    int dd[NS], off[NS]; bool has[NS];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int t = min(lane + 64 * s, T - 1);                    // clamped: lanes without a task recompute a valid one and are masked
-        dd[s] = t / DC + 1; off[s] = dd[s] * BB + (t - (dd[s] - 1) * DC); has[s] = lane + 64 * s < T;
-    }
-    const int lc = min(lane, DC - 1);
-    struct Stage { double col[NS][DC], li[DC], yv; };
-    // the row is wave-uniform: a scalar base per row and a 32-bit lane offset per stream (the per-lane 64-bit products of a flat index cost
-    // ~16 vector instructions per step of a kernel whose step is bound by the instructions ONE wave can issue)
-    const size_t row_stride = (size_t)W * BB;
-    // one sweep from row re-1 down to r0: rows >= r1 are given (from Y, from the reversed copy at gf, or -- from_lds -- from xs), the others are solved and go to Y (to_lds: to xs)
-    auto sweep = [&](const int r0, const int r1, const int re, const int gf, auto TO_LDS, auto FROM_LDS) {      // (compile-time flags: a step is bound by its instruction count)
-        constexpr bool to_lds = decltype(TO_LDS)::value, from_lds = decltype(FROM_LDS)::value;
-        Stage st[BACK_PD];
-        auto fetch = [&](int j, Stage& s) {    // column a of block (j, j-d) for this lane's tasks; column `lane` of G_j; y_j
-            const int jc = max(j, r0);
-            const double* __restrict__ rowp = band + (size_t)jc * row_stride;
-            const double* __restrict__ gpt = Ginv + (size_t)jc * BB;
-#pragma unroll
-            for (int m = 0; m < DC; m++) {
-#pragma unroll
-                for (int q = 0; q < NS; q++) s.col[q][m] = rowp[off[q] + m * DC];
-                s.li[m] = gpt[m * DC + lc];                                   // G[m][lane], zero for m < lane
-            }
-            const int jy = (gf >= 0 && jc >= r1) ? gf + (re - 1 - jc) : jc;
-            s.yv = (from_lds && jc >= r1) ? xs[(jy - gf) * DC + lc] : y[(size_t)jy * DC + lc];
-        };
-#pragma unroll
-        for (int u = 0; u < BACK_PD; u++) fetch(re - 1 - u, st[u]);
-        double acc[NS];                        // pending sums: task (d, a) = sum over processed k of (L(k, i)^T x_k)[a], i = j-(d-1)
-#pragma unroll
-        for (int q = 0; q < NS; q++) acc[q] = 0.0;
-        for (int jb = re - 1; jb >= r0; jb -= BACK_PD) {
-#pragma unroll
-            for (int u = 0; u < BACK_PD; u++) {
-                const int j = jb - u;
-                if (j < r0) break;
-                double c[NS][DC], cl[DC]; const double cy = st[u].yv;
-                bool v[NS];
-#pragma unroll
-                for (int q = 0; q < NS; q++) v[q] = has[q] && j - dd[q] >= r0;       // rows above the component do not exist: their terms are dropped below
-#pragma unroll
-                for (int m = 0; m < DC; m++) {
-#pragma unroll
-                    for (int q = 0; q < NS; q++) c[q][m] = st[u].col[q][m];
-                    cl[m] = st[u].li[m];
-                }
-                fetch(j - BACK_PD, st[u]);                              // in flight for the next BACK_PD steps
-                // task d owns the pending sum of row j-(d-1): the sum of row j sits in lanes 0..DC-1 of acc[0]
-                const double z = cy - acc[0];                           // lanes 0..DC-1
-                // the shift does not depend on x_j: issue it before the dependent chain
-                double sh[NS], sft[NS];
-#pragma unroll
-                for (int q = 0; q < NS; q++) sh[q] = lane_shift_down(acc[q], DC);
-#pragma unroll
-                for (int q = 0; q < NS; q++) {
-                    const double next = (q + 1 < NS) ? sh[q + 1 < NS ? q + 1 : q] : 0.0;       // lanes near the top of a set take from the bottom of the next one
-                    sft[q] = (lane + DC < 64) ? sh[q] : next;
-                    if (!(lane + 64 * q + DC < T)) sft[q] = 0.0;
-                }
-                double x = 0.0;
-#pragma unroll
-                for (int k = 0; k < DC; k++) x += cl[k] * lane_bcast(z, k);        // x_j[lane] = sum_k G[k][lane] z[k]
-                if (j >= r1) x = cy;                                               // given
-                else if (lane < DC) { if (to_lds) xs[(j - r0) * DC + lane] = x; else y[(size_t)j * DC + lane] = x; }
-                double sm[NS];
-#pragma unroll
-                for (int q = 0; q < NS; q++) sm[q] = 0.0;
-#pragma unroll
-                for (int m = 0; m < DC; m++) { const double xm = lane_bcast(x, m);
-#pragma unroll
-                    for (int q = 0; q < NS; q++) sm[q] += c[q][m] * xm; }
-                // next step: task d owns row (j-1)-(d-1) = j-d, i.e. what task d+1 owned, plus this step's term for row j-d
-#pragma unroll
-                for (int q = 0; q < NS; q++) acc[q] = sft[q] + (v[q] ? sm[q] : 0.0);      // (one select per sum instead of one per loaded entry)
-            }
-        }
-    };
     const int r0 = piv_lo[blockIdx.x], r1 = piv_hi[blockIdx.x], re = win_hi[blockIdx.x];
     const int gf = given_from ? given_from[blockIdx.x] : -1;
-    constexpr std::false_type F_{}; constexpr std::true_type T_{};
     if (mode == 2) {
-        sweep(gf, gf + b, gf + b, -1, T_, F_);
+        band_back_sweep<DC, NS, true, false>(band, Ginv, y, xs, gf, gf + b, gf + b, -1, b, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        sweep(r0, r1, re, gf, F_, T_);
-    } else sweep(r0, mode == 1 ? re : r1, re, mode == 1 ? -1 : gf, F_, F_);
+        band_back_sweep<DC, NS, false, true>(band, Ginv, y, xs, r0, r1, re, gf, b, lane);
+    } else band_back_sweep<DC, NS, false, false>(band, Ginv, y, xs, r0, mode == 1 ? re : r1, re, mode == 1 ? -1 : gf, b, lane);
 }
 
 }  // namespace ssfm
