@@ -415,17 +415,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution
                 // reads that solution through seg_given
-                // the separator's back substitution in the launch that factors it (k_band_chol_v2's solve_small; SSFM_SEP_SOLVE=0: its own launch as in rounds 2-4)
-                static const bool sep_solve_on = !(std::getenv("SSFM_SEP_SOLVE") && std::atoi(std::getenv("SSFM_SEP_SOLVE")) == 0);
-                const bool sep_solve = sep_solve_on && !wide2p && !fused && !back_fuse && b * DC <= 64 && mf == 0 && !early;
                 if (wide2p) SSFM_LAUNCH_CHOL2P(B.ntwist, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p);
-                else if (!fused && sep_solve && mf == 0 && !early) {
-                    if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, 0, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-                    LAUNCH(h, KID_BAND_CHOL, (k_band_chol_v2<DC, 2, 0, 3, true>), B.ntwist, chol_threads, lds_win, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map,
-                           (const int*)nullptr, (const int*)nullptr, (int*)nullptr, 0, 1);
-                }
                 else if (!fused) SSFM_LAUNCH_CHOL2(B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, h->sub_tw_copy.p, Nc, b, failp, chol_map);
-                if (!back_fuse && !sep_solve) {
+                if (!back_fuse) {
                 h->span_begin(KID_BAND_BACK);
                 BACK_V2_LAUNCH(dim3(B.ntwist, 2), h->band.p, h->Linv.p, Y, h->sub_tw_lo.p, h->sub_tw_hi.p, h->sub_tw_hi.p, (const int*)nullptr, Nc, b);
                 h->span_end();

@@ -194,7 +194,7 @@ __device__ __forceinline__ void band_back_sweep(const double* __restrict__ band,
         }
 }
 
-template <int DC, int NR, int MF = 0, int TCW = 3, bool SOLVE = false>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead; TCW: columns of a trailing tile (3: 3x3 tiles, 2: 3x2); SOLVE: the instantiation with the back-substitution epilogue (its own kernel: the epilogue's registers cost the step loop 30 -> 41 us when every launch carried it)
+template <int DC, int NR, int MF = 0, int TCW = 3>      // MF bit 0: matrix-core panel, bit 1: matrix-core trailing update, bit 2 (alone): early look-ahead; TCW: columns of a trailing tile (3: 3x3 tiles, 2: 3x2)
 __global__ void __launch_bounds__(768)
 k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __restrict__ Y, const int* __restrict__ pairs,
                const int* __restrict__ piv_lo, const int* __restrict__ piv_hi, const int* __restrict__ win_hi,
@@ -202,10 +202,7 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
                const CholWaveMap wmap,                 // role of every physical wave (chol_wave_map; identity = roles in wave order)
                // fused launch of segments and the separators that wait for them (ba_handle.h band_direct): per workgroup the first of two flags to await
                // before its window is loaded (-1: none) and the flag to raise when its rows are in global memory (-1: none); flags hold launch numbers
-               const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0,
-               // solve_small (round 4): the component is a whole one of at most b + 1 rows with b DC <= 64 (the separator of a twisted component): its back substitution runs
-               // here, behind the factorisation, instead of in a launch of its own (ten steps + a launch gap + a pipeline fill in a dependent stream at config 2)
-               int solve_small = 0) {
+               const int* __restrict__ await2 = nullptr, const int* __restrict__ signal = nullptr, int* __restrict__ flags = nullptr, int seq = 0) {
     constexpr int BB = DC * DC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int R = b + 1, W = b + 1, RW = W * BB;
@@ -655,14 +652,6 @@ k_band_chol_v2(double* __restrict__ band, double* __restrict__ Ginv, double* __r
     if (sig >= 0) {                                        // this segment's share of its separator is in global memory
         __threadfence(); __syncthreads();
         if (tid == 0) __hip_atomic_store(flags + sig, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if constexpr (SOLVE) if (solve_small && re == r1 && b * DC <= 64) {
-        // the factor, its inverse diagonal blocks and the forward-substituted right-hand sides went to global memory through the writer wave: visible to the rest of the
-        // WORKGROUP is enough (same compute unit, same L1: a workgroup-scope fence is a wait, an agent-scope one writes the L2 back on this multi-XCD part -- 22 us here),
-        // then one wave per right-hand side sweeps backwards
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int pw = (int)(threadIdx.x >> 6);
-        if (pw < NR) band_back_sweep<DC, 1, false, false>(band, Ginv, Y + (size_t)pw * n, nullptr, r0, r1, r1, -1, b, lane);
     }
 }
 
