@@ -1450,7 +1450,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
                const double* __restrict__ S_val, int Nc, double* __restrict__ x, double* __restrict__ q,
                const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
                const double* __restrict__ scale_f, double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c,
-               double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts) {
+               double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts, const int* __restrict__ col_pos, const int* __restrict__ trans_pos) {
     __shared__ double red[2 * 8];
     __shared__ double part[4][64];
     __shared__ double part2[4][2];
@@ -1482,8 +1482,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
             const int a = lane % DC;
             for (int idx = lane; idx < (nnb + nt) * DC; idx += LW) {
                 const int b = idx / DC;
-                const int col = (b < nnb) ? col_idx[rb + b] : trans_row[tb + (b - nnb)];
-                const int pc = pos[col] * DC;
+                const int pc = ((b < nnb) ? col_pos[rb + b] : trans_pos[tb + (b - nnb)]) * DC;      // (= pos[col_idx[..]] / pos[trans_row[..]], precomputed: one dependent gather less)
                 double xv[DC];
 #pragma unroll
                 for (int k = 0; k < DC; k++) xv[k] = V[pc + k] - U[pc + k] * phi;

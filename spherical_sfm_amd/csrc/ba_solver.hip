@@ -579,6 +579,14 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
     SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st));
+    {   // band row of every stored block's column camera (and of every transposed block's): k_arrow_update reads it instead of col_idx -> pos, one dependent gather less
+        std::vector<int> cp(F.col_idx.size()), tp(F.trans_row.size());
+        for (size_t e = 0; e < cp.size(); e++) cp[e] = F.band_row[F.col_idx[e]];
+        for (size_t e = 0; e < tp.size(); e++) tp[e] = F.band_row[F.trans_row[e]];
+        if (cp.empty()) cp.push_back(0);
+        if (tp.empty()) tp.push_back(0);
+        SSFM_HIP_CHECK(ctx, upload(h->col_pos, cp, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_pos, tp, st));
+    }
     if (host_pairs) {
         SSFM_HIP_CHECK(ctx, upload(h->pair_j, F.pair_j, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_j2, F.pair_j2, st)); SSFM_HIP_CHECK(ctx, upload(h->pair_p, F.pair_p, st));
     } else if (F.M > 0) {
