@@ -29,22 +29,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // MERGE (DC = 3): two consecutive camera rows share one 6x6 block row R = i >> 1 (upper / lower half u = i & 1); the camera owns its
 // three scalar rows of every block of R, except that the off-diagonal 3x3 parts of the DIAGONAL block both belong to the lower
 // camera (it mirrors its (1,0) part into (0,1)); an even camera without partner (pair_dummy) also owns the partner's rows: identity.
+// first half: the camera's band row(s) cleared (no barrier inside)
 template <int DC, bool MERGE>
-__device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
-                                               const int* __restrict__ pos, int i, int i2, int c, int b, bool dummy, double* __restrict__ band) {
+__device__ __forceinline__ void band_rows_zero(int i, int i2, int b, bool dummy, double* __restrict__ band) {
     constexpr int BB = DC * DC;
-    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tid = threadIdx.x, W = b + 1;
+    const int tid = threadIdx.x, W = b + 1;
     if (!MERGE) {
         double* row = band + (size_t)i * W * BB;
         double* row2 = band + (size_t)max(i2, 0) * W * BB;
         for (int e = tid; e < W * BB; e += blockDim.x) { row[e] = 0.0; if (i2 >= 0) row2[e] = 0.0; }
-        __syncthreads();
-        for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
-            const int s = rb + idx / BB, e = idx % BB;
-            const int k = pos[col_idx[s]];
-            if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e]; }
-            else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
-        }
     } else {
         constexpr int BM = 4 * BB, D2 = 2 * DC;                    // 6x6 blocks of 3x3 parts
         const int R = i >> 1, u = i & 1, R2 = max(i2, 0) >> 1, u2 = max(i2, 0) & 1;
@@ -61,16 +54,44 @@ __device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, 
             if (u == 1) row[r * D2 + DC + col] = 0.0;
             if (i2 >= 0 && u2 == 1) row2[r * D2 + DC + col] = 0.0;
         }
-        __syncthreads();
+    }
+}
+// second half (behind a barrier): the blocks of S's row c scattered into the band row(s).  col_pos (optional) = pos[col_idx[.]] precomputed: one dependent gather less
+template <int DC, bool MERGE>
+__device__ __forceinline__ void band_rows_scatter(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+                                                  const int* __restrict__ pos, int i, int i2, int c, int b, double* __restrict__ band, const int* __restrict__ col_pos = nullptr) {
+    constexpr int BB = DC * DC;
+    const int rb = row_ptr[c], nnb = row_ptr[c + 1] - rb, tid = threadIdx.x, W = b + 1;
+    if (!MERGE) {
+        double* row = band + (size_t)i * W * BB;
+        double* row2 = band + (size_t)max(i2, 0) * W * BB;
+        for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
+            const int s = rb + idx / BB, e = idx % BB;
+            const int k = col_pos ? col_pos[s] : pos[col_idx[s]];
+            if (k <= i) { if (i - k <= b) row[(size_t)(i - k) * BB + e] = S_val[(size_t)s * BB + e]; }
+            else if (i2 > k && i2 - k <= b) row2[(size_t)(i2 - k) * BB + e] = S_val[(size_t)s * BB + e];
+        }
+    } else {
+        constexpr int BM = 4 * BB, D2 = 2 * DC;
+        const int R = i >> 1, u = i & 1, R2 = max(i2, 0) >> 1, u2 = max(i2, 0) & 1;
+        double* row = band + (size_t)R * W * BM;
+        double* row2 = band + (size_t)R2 * W * BM;
         for (int idx = tid; idx < nnb * BB; idx += blockDim.x) {
             const int s = rb + idx / BB, e = idx % BB, a = e / DC, a2 = e - a * DC;
-            const int k = pos[col_idx[s]], C = k >> 1, v = k & 1;
+            const int k = col_pos ? col_pos[s] : pos[col_idx[s]], C = k >> 1, v = k & 1;
             const double val = S_val[(size_t)s * BB + e];
             if (C < R) { if (R - C <= b) row[(size_t)(R - C) * BM + (u * DC + a) * D2 + v * DC + a2] = val; }
             else if (C == R) { if (v <= u) { row[(u * DC + a) * D2 + v * DC + a2] = val; if (v < u) row[(v * DC + a2) * D2 + u * DC + a] = val; } }
             else if (i2 >= 0 && R2 > C && R2 - C <= b) row2[(size_t)(R2 - C) * BM + (u2 * DC + a) * D2 + v * DC + a2] = val;
         }
     }
+}
+template <int DC, bool MERGE>
+__device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
+                                               const int* __restrict__ pos, int i, int i2, int c, int b, bool dummy, double* __restrict__ band) {
+    band_rows_zero<DC, MERGE>(i, i2, b, dummy, band);
+    __syncthreads();
+    band_rows_scatter<DC, MERGE>(row_ptr, col_idx, S_val, pos, i, i2, c, b, band);
 }
 
 // S (block-CSR, camera order) -> band storage (permuted)
@@ -93,7 +114,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
                   const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs,
                   const double* __restrict__ Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal,
-                  double2* __restrict__ clear = nullptr, size_t clear_len2 = 0) {
+                  double2* __restrict__ clear = nullptr, size_t clear_len2 = 0, const int* __restrict__ col_pos = nullptr) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
     // the accumulation zone of the NEXT iteration (nothing has read it since the iteration before this one ended) is cleared here, a slice
@@ -103,6 +124,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
         for (size_t e = lo + tid; e < hi; e += blockDim.x) clear[e] = make_double2(0.0, 0.0);
     }
     const int i = pos[c], i2 = pos2[c], rb = row_ptr[c];     // pos / pos2: band rows in camera units (second row: twisted separators)
+    band_rows_zero<DC, MERGE>(i, i2, b, MERGE && pair_dummy[c], band);      // (round 4: in front of the damping, ONE barrier for both; the scatter reads precomputed column rows)
     double gmax = 0.0;
     if (tid < DC) {
         double* blk = S_val + ((size_t)rb + diag_slot[c]) * BB;
@@ -116,7 +138,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
     }
     if (tid < 64) { gmax = wave_max(gmax); if (tid == 0 && gmax > 0.0) atomic_max_nonneg(&scal[(size_t)(c & (SC_NSLOT - 1)) * SC_TOTAL + SC_GMAX], gmax); }
     __syncthreads();                                               // damped diagonal block visible to the whole workgroup
-    band_rows_fill<DC, MERGE>(row_ptr, col_idx, S_val, pos, i, i2, c, b, MERGE && pair_dummy[c], band);
+    band_rows_scatter<DC, MERGE>(row_ptr, col_idx, S_val, pos, i, i2, c, b, band, col_pos);
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;
         const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;
