@@ -531,11 +531,19 @@ def main():
             out["speedup_vs_cpu_lm_loop"] = value / cpu_obs_s
             # end to end, what a drop-in SfM::Optimize() call costs: ssfm_ba_solve = host planning + allocation/H2D + LM + D2H,
             # against the CPU port's flatten + solve (the reference additionally probes Np x Nc map entries, src/sfm.cpp:240-263)
-            def e2e_call():
-                _, _, _, se = ba.optimize(ctx, prob)
+            def e2e_call(p_=None):
+                _, _, _, se = ba.optimize(ctx, prob if p_ is None else p_)
                 return {"gpu_s": se["t_flatten_s"] + se["t_upload_s"] + se["t_solve_s"] + se["t_download_s"], "gpu_plan_s": se["t_flatten_s"],
                         "gpu_alloc_upload_s": se["t_upload_s"], "gpu_solve_s": se["t_solve_s"], "gpu_download_s": se["t_download_s"]}
-            e2e = e2e_call()                                        # cold: plans, allocates, uploads the index lists
+            # cold = first call on a structure (plans, allocates, uploads the index lists): best of three such calls -- the problem itself and two copies with one
+            # point held fixed (a different structure hash, the same work); a single sample right behind the 16-thread CPU baseline read 7 ... 17 ms
+            import dataclasses
+            colds = [e2e_call()]
+            for k_ in (5, 6):
+                pf_ = prob.pt_fixed.copy(); pf_[k_] = 1
+                colds.append(e2e_call(dataclasses.replace(prob, pt_fixed=pf_)))
+            e2e = min(colds, key=lambda d: d["gpu_s"]); e2e["cold_samples_s"] = [c_["gpu_s"] for c_ in colds]
+            e2e_call()                                              # back on the original structure (cold once more), then:
             warm = min((e2e_call() for _ in range(3)), key=lambda d: d["gpu_s"])   # same structure again (the drivers' pattern): plan cache hit
             e2e["warm"] = warm
             e2e["cpu_s"] = best["t_total_s"]; e2e["speedup"] = best["t_total_s"] / e2e["gpu_s"]
