@@ -2,6 +2,7 @@
 #include "sfm.h"
 #include <algorithm>
 #include <initializer_list>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -160,11 +161,15 @@ void SfM::Retriangulate() {
 bool SfM::Optimize() {
     if (numCameras == 0 || numPoints == 0) return false;                                      // src/sfm.cpp:230
     std::cout << "\tBuilding BA problem...\n";
+    const bool timing = std::getenv("SSFM_PLAN_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     FlatProblem F; Flatten(F);
+    const auto t_1 = std::chrono::steady_clock::now();
     ssfm_ba_problem& P = F.P; std::vector<double>&cam = F.cam, &pts = F.pts;
     ssfm_ba_options O; ssfm_ba_default_options(&O);                                            // src/sfm.cpp:194-212
     O.verbose = 1;                                                                            // minimizer_progress_to_stdout
     int rc = ssfm_ba_solve(ctx, &P, &O, &last_summary);
+    const auto t_2 = std::chrono::steady_clock::now();
     if (rc != SSFM_OK) { std::cout << "error: " << ssfm_last_error(ctx) << "\n"; exit(1); }
     if (last_summary.termination == SSFM_NOTHING_TO_DO) { std::cout << "didn't add any cameras\n"; return false; }   // src/sfm.cpp:265-268
     std::cout << "Running optimizer...\n\t" << 2 * last_summary.num_residual_blocks << " residuals\n";
@@ -173,6 +178,8 @@ bool SfM::Optimize() {
     if (last_summary.termination == SSFM_FAILURE) { std::cout << "error: ceres failed.\n"; exit(1); }             // src/sfm.cpp:278-282
     for (auto& kv : cameras) if (kv.first >= 0 && kv.first < numCameras) for (int k = 0; k < 6; k++) kv.second[k] = cam[(size_t)kv.first * 6 + k];
     for (auto&& kv : points) if (kv.first >= 0 && kv.first < numPoints) for (int k = 0; k < 3; k++) kv.second.v[k] = pts[(size_t)kv.first * 3 + k];
+    if (timing) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                  std::fprintf(stderr, "[mirror] Optimize: flatten %.2f ms, ssfm_ba_solve %.2f ms, write-back %.2f ms\n", ms(t_0, t_1), ms(t_1, t_2), ms(t_2, std::chrono::steady_clock::now())); }
     return last_summary.termination == SSFM_CONVERGENCE;                                      // src/sfm.cpp:289
 }
 
