@@ -51,6 +51,63 @@ def build(force=False):
     return so
 
 
+class _Missing:
+    """stands for a symbol the loaded library does not export: takes the signature assignments, refuses the call"""
+    def __init__(self, name):
+        object.__setattr__(self, "_name", name)
+
+    def __setattr__(self, k, v):
+        pass
+
+    def __call__(self, *a):
+        raise AttributeError("oracle library has no symbol " + self._name)
+
+
+class _Lenient:
+    """CDLL view for oracle/_ref/libssfm_ref.so, which holds the RANSAC / triangulation part only"""
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+
+    def __getattr__(self, n):
+        try:
+            return getattr(self._L, n)
+        except AttributeError:
+            return _Missing(n)
+
+
+def reference_lib_path():
+    """oracle/_ref/libssfm_ref.so (`make -C oracle ref`, build container only): the estimators of this oracle driven by the REFERENCE'S OWN
+    include/RansacLib template (lomsac_reference.hpp) + its SolveQuartic (ref_quartic_wrap.cpp); None when it has not been built"""
+    so = os.path.join(_HERE, "_ref", "libssfm_ref.so")
+    return so if os.path.exists(so) else None
+
+
+_REF_LIB = None
+
+
+class reference_ransaclib:
+    """with oracle.reference_ransaclib(): ...   every RANSAC / Retriangulate wrapper of this module runs on oracle/_ref/libssfm_ref.so"""
+    def __enter__(self):
+        global _LIB, _REF_LIB
+        if _REF_LIB is None:
+            so = reference_lib_path()
+            if so is None:
+                raise FileNotFoundError("oracle/_ref/libssfm_ref.so: run `make -C oracle ref` where /root/reference exists")
+            _REF_LIB = _Lenient(C.CDLL(so))
+            _declare(_REF_LIB)
+            _REF_LIB.oracle_lomsac_is_reference.restype = C.c_int32
+            assert _REF_LIB.oracle_lomsac_is_reference() == 1
+        lib()
+        self._saved = _LIB
+        _LIB = _REF_LIB
+        return _REF_LIB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._saved
+        return False
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -58,6 +115,13 @@ def lib():
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
+        _declare(L)
+        _LIB = L
+    return _LIB
+
+
+def _declare(L):
+    if True:
         L.oracle_ba_default_options.argtypes = [C.POINTER(LMOptionsC)]
         L.oracle_ba_solve.argtypes = [C.POINTER(BAProblemC), C.POINTER(LMOptionsC), C.POINTER(SummaryC)]
         L.oracle_ba_solve.restype = C.c_int
@@ -98,8 +162,8 @@ def lib():
         L.oracle_nonminimal_solver.argtypes = [C.c_int32, c_double_p, c_double_p, C.c_int32, c_i32_p, c_double_p]; L.oracle_nonminimal_solver.restype = C.c_int
         L.oracle_mt19937_draws.argtypes = [C.c_uint32, C.c_int32, c_i32_p, c_i32_p, c_i32_p, C.c_int32, C.POINTER(C.c_uint32)]; L.oracle_mt19937_draws.restype = None
         L.oracle_retriangulate.argtypes = [C.POINTER(BAProblemC), C.c_int32, c_i32_p]; L.oracle_retriangulate.restype = C.c_int
-        _LIB = L
-    return _LIB
+        L.oracle_solver_from_basis.argtypes = [c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]; L.oracle_solver_from_basis.restype = C.c_int
+        L.oracle_solve_quartic.argtypes = [C.c_double] * 5 + [c_double_p]; L.oracle_solve_quartic.restype = None
 
 
 def _dp(a):
@@ -319,6 +383,22 @@ def lomsac_pair(u, v, sq_thresh, inward=False, use_poly=False, min_iterations=10
                                  num_lo_steps, num_lsq_iterations, threshold_multiplier, min_sample_multiplicator, non_min_sample_multiplier,
                                  lo_starting_iterations, int(final_least_squares), min_num_inliers, _dp(E), _dp(R), _up(mask), st, C.byref(sc))
     return dict(E=_um(E), R=_um(R), inliers=mask[:len(u)].astype(bool), num_inliers=n, iterations=st[0], lo_runs=st[1], score=sc.value)
+
+
+def solver_from_basis(B, variant):
+    """both minimal solvers behind their nullspace basis B (6x3): -> dict(C (6,10) as the reference lays it out, Es (4,3,3), imag (4,), abcde (5,))
+    variant 0: spherical_solver_action_matrix (src/spherical_solvers.cpp:127-308), 1: spherical_solver_polynomial (:339-654)"""
+    B = np.ascontiguousarray(B, np.float64).reshape(6, 3)
+    Cm = np.zeros(60); Es = np.zeros(36); im = np.zeros(4); ab = np.zeros(5)
+    k = lib().oracle_solver_from_basis(_dp(B), int(variant), _dp(Cm), _dp(Es), _dp(im), _dp(ab))
+    return dict(n=k, C=Cm.reshape(6, 10), Es=np.stack([_um(Es[9 * i:9 * i + 9]) for i in range(4)]), imag=im, abcde=ab)
+
+
+def solve_quartic(a, b, c, d, e):
+    """SolveQuartic (src/spherical_solvers.cpp:15-69) as restated -> 4 complex roots in the reference's order"""
+    out = np.zeros(8)
+    lib().oracle_solve_quartic(a, b, c, d, e, _dp(out))
+    return out[0::2] + 1j * out[1::2]
 
 
 def nonminimal_solver(u, v, sample):

@@ -28,7 +28,13 @@
 #include <vector>
 #include <array>
 #include "lm.hpp"
+#ifdef SSFM_ORACLE_REAL_RANSACLIB      // oracle/_ref build: the reference's own include/RansacLib drives the same estimators (lomsac_reference.hpp)
+#include "lomsac_reference.hpp"
+#define ORACLE_LOMSAC LoMsacReference
+#else
 #include "lomsac.hpp"
+#define ORACLE_LOMSAC LoMsac
+#endif
 #include "rotation.hpp"
 #include "ssfm_oracle.h"
 
@@ -160,6 +166,17 @@ static void eig4(const double M[16], cd lam[4]) {
 // nullspace basis B (6x3) and the six cubic constraints -T01, T20, T00, T21, T12, T22 of T = 2 E E^T E - tr(E E^T) E over the
 // monomials [x^3, x^2y, xy^2, y^3, x^2z, xyz, y^2z, xz^2, yz^2, z^3]  (identified symbolically from the generated code; the
 // polynomial variant holds the same rows times 1/2 in a different monomial order).
+// the six cubic constraints from a GIVEN nullspace basis (everything of src/spherical_solvers.cpp:127-277 / 339-621 is a function of B alone)
+static void constraints_from_B(const double B[6][3], Cub rows[6]) {
+    Lin p[6]; for (int k = 0; k < 6; k++) for (int j = 0; j < 3; j++) p[k].c[j] = B[k][j];
+    Lin zero = {{0, 0, 0}}, np0 = {{-p[0].c[0], -p[0].c[1], -p[0].c[2]}};
+    const Lin* Em[3][3] = {{&p[0], &p[1], &p[2]}, {&p[1], &np0, &p[3]}, {&p[4], &p[5], &zero}};
+    Quad EEt[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Quad q = mul(*Em[i][0], *Em[j][0]); q = add(q, mul(*Em[i][1], *Em[j][1])); q = add(q, mul(*Em[i][2], *Em[j][2])); EEt[i][j] = q; }
+    Quad tr = add(add(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    auto T = [&](int i, int j, double s) { Cub c; for (double& x : c.c) x = 0; for (int k = 0; k < 3; k++) acc(c, EEt[i][k], *Em[k][j], 2.0 * s); acc(c, tr, *Em[i][j], -s); return c; };
+    rows[0] = T(0, 1, -1.0); rows[1] = T(2, 0, 1.0); rows[2] = T(0, 0, 1.0); rows[3] = T(2, 1, 1.0); rows[4] = T(1, 2, 1.0); rows[5] = T(2, 2, 1.0);
+}
 static bool solver_front(const Rays& R, const int* sample, int N, double B[6][3], Cub rows[6]) {
     if (N < 3) return false;
     std::vector<double> At((size_t)6 * N);
@@ -170,14 +187,7 @@ static bool solver_front(const Rays& R, const int* sample, int N, double B[6][3]
     }
     double Q[36]; qr_colpiv_Q(At, N, Q);
     for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) B[i][j] = Q[i * 6 + 3 + j];
-    Lin p[6]; for (int k = 0; k < 6; k++) for (int j = 0; j < 3; j++) p[k].c[j] = B[k][j];
-    Lin zero = {{0, 0, 0}}, np0 = {{-p[0].c[0], -p[0].c[1], -p[0].c[2]}};
-    const Lin* Em[3][3] = {{&p[0], &p[1], &p[2]}, {&p[1], &np0, &p[3]}, {&p[4], &p[5], &zero}};
-    Quad EEt[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Quad q = mul(*Em[i][0], *Em[j][0]); q = add(q, mul(*Em[i][1], *Em[j][1])); q = add(q, mul(*Em[i][2], *Em[j][2])); EEt[i][j] = q; }
-    Quad tr = add(add(EEt[0][0], EEt[1][1]), EEt[2][2]);
-    auto T = [&](int i, int j, double s) { Cub c; for (double& x : c.c) x = 0; for (int k = 0; k < 3; k++) acc(c, EEt[i][k], *Em[k][j], 2.0 * s); acc(c, tr, *Em[i][j], -s); return c; };
-    rows[0] = T(0, 1, -1.0); rows[1] = T(2, 0, 1.0); rows[2] = T(0, 0, 1.0); rows[3] = T(2, 1, 1.0); rows[4] = T(1, 2, 1.0); rows[5] = T(2, 2, 1.0);
+    constraints_from_B(B, rows);
     return true;
 }
 static void essential_from_b(const double B[6][3], const double b[3], double* E) {      // src/spherical_solvers.cpp:296-305 / 645-654
@@ -188,9 +198,13 @@ static void essential_from_b(const double B[6][3], const double b[3], double* E)
 }
 
 // src/spherical_solvers.cpp:102-311.  sample: indices into rays.  Es: 4 x 9 row-major.  Returns number of models.
+static int action_matrix_back(const double B[6][3], const Cub rows[6], double Es[36]);
 static int solver_action_matrix(const Rays& R, const int* sample, int N, double Es[36]) {
     double B[6][3]; Cub rows[6];
     if (!solver_front(R, sample, N, B, rows)) return 0;
+    return action_matrix_back(B, rows, Es);
+}
+static int action_matrix_back(const double B[6][3], const Cub rows[6], double Es[36]) {
     double C1[36], C2[24];
     for (int r = 0; r < 6; r++) { for (int k = 0; k < 6; k++) C1[r * 6 + k] = rows[r].c[k]; for (int k = 0; k < 4; k++) C2[r * 4 + k] = rows[r].c[6 + k]; }
     if (!lu_solve6(C1, C2)) return 0;
@@ -239,15 +253,21 @@ static void solve_quartic(double a, double b, double c, double d, double e, cd r
 // src/spherical_solvers.cpp:313-660: same constraints (times 1/2), monomials [x^3 x^2y xy^2 x^2z xyz xz^2 | y^3 y^2z yz^2 z^3];
 // rows 4, 5 of G = C[:, :6]^-1 C[:, 6:] give xy and x as cubics in y (z = 1) => quartic in y; the REAL PARTS of all four roots
 // are used (SolveQuarticReals without tolerance, :629-631).  imag_out (optional): imaginary parts, for the tests.
+static const int kPolyPerm[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};
+static int polynomial_back(const double B[6][3], const Cub rows[6], double Es[36], double* imag_out, double* abcde_out);
 static int solver_polynomial(const Rays& R, const int* sample, int N, double Es[36], double* imag_out = nullptr) {
     double B[6][3]; Cub rows[6];
     if (!solver_front(R, sample, N, B, rows)) return 0;
-    static const int perm[10] = {0, 1, 2, 4, 5, 7, 3, 6, 8, 9};
+    return polynomial_back(B, rows, Es, imag_out, nullptr);
+}
+static int polynomial_back(const double B[6][3], const Cub rows[6], double Es[36], double* imag_out, double* abcde_out) {
+    const int* perm = kPolyPerm;
     double C1[36], C2[24];
     for (int r = 0; r < 6; r++) { for (int k = 0; k < 6; k++) C1[r * 6 + k] = 0.5 * rows[r].c[perm[k]]; for (int k = 0; k < 4; k++) C2[r * 4 + k] = 0.5 * rows[r].c[perm[6 + k]]; }
     if (!lu_solve6(C1, C2)) return 0;
     const double* G4 = C2 + 16; const double* G5 = C2 + 20;
     const double a = -G5[0], b = G4[0] - G5[1], c = G4[1] - G5[2], d = G4[2] - G5[3], e = G4[3];
+    if (abcde_out) { abcde_out[0] = a; abcde_out[1] = b; abcde_out[2] = c; abcde_out[3] = d; abcde_out[4] = e; }
     cd roots[4]; solve_quartic(a, b, c, d, e, roots);
     for (int s = 0; s < 4; s++) {
         const double y = roots[s].real(), y2 = y * y, y3 = y2 * y;
@@ -477,7 +497,7 @@ extern "C" int oracle_ransac_pair(int32_t n, const double* u, const double* v, i
     Rays R{n, u, v};
     MSACOptions o; o.sq_thresh = sq_thresh; o.num_lo_steps = 0; o.num_lsq_it = 0; o.final_lsq = true; o.min_it = min_it; o.max_it = max_it; o.seed = seed;
     SphericalSolver solver{R, inward != 0};
-    LoMsac<SphericalSolver, EMat> M(solver, o);
+    ORACLE_LOMSAC<SphericalSolver, EMat> M(solver, o);
     EMat Em{}; MSACStats st;
     M.estimate(&Em, &st);
     double E[9]; std::memcpy(E, Em.data(), 72);
@@ -511,7 +531,7 @@ extern "C" int oracle_lomsac_pair(int32_t n, const double* u, const double* v, i
             return k;
         }
     } solver(R, inward != 0, use_poly != 0);
-    LoMsac<PolySolver, EMat> M(solver, o);
+    ORACLE_LOMSAC<PolySolver, EMat> M(solver, o);
     EMat Em{}; MSACStats st;
     M.estimate(&Em, &st);
     double E[9]; std::memcpy(E, Em.data(), 72);
@@ -525,6 +545,30 @@ extern "C" int oracle_lomsac_pair(int32_t n, const double* u, const double* v, i
     if (have && nin > min_num_inliers) { double r[3], t[3]; decompose_E(E, inward != 0, r, t); rm_so3exp(r, Rm); }
     rm_to_cm(Rm, R_cm);
     return nin;
+}
+// Reference-pin hooks (tests/test_reference_pins_cpu.py).  B: 6x3 row-major nullspace basis; variant 0 = action matrix
+// (C as src/spherical_solvers.cpp:272-277 lays it out), 1 = polynomial (:339-621: rows halved, its monomial order);
+// C_out 6x10 row-major; Es_out 4x9 COLUMN-major like every 3x3 of this API; abcde_out (variant 1): the quartic of :623-627.
+extern "C" int oracle_solver_from_basis(const double B_rm[18], int32_t variant, double C_out[60], double Es_out[36], double imag_out[4], double abcde_out[5]) {
+    double B[6][3]; for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) B[i][j] = B_rm[3 * i + j];
+    Cub rows[6]; constraints_from_B(B, rows);
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 10; k++) C_out[r * 10 + k] = variant ? 0.5 * rows[r].c[kPolyPerm[k]] : rows[r].c[k];
+    double Es[36]; for (double& x : Es) x = 0;
+    const int k = variant ? polynomial_back(B, rows, Es, imag_out, abcde_out) : action_matrix_back(B, rows, Es);
+    for (int s = 0; s < 4; s++) rm_to_cm(Es + 9 * s, Es_out + 9 * s);
+    return k;
+}
+extern "C" void oracle_solve_quartic(double a, double b, double c, double d, double e, double re_im[8]) {      // src/spherical_solvers.cpp:15-69
+    cd roots[4]; solve_quartic(a, b, c, d, e, roots);
+    for (int i = 0; i < 4; i++) { re_im[2 * i] = roots[i].real(); re_im[2 * i + 1] = roots[i].imag(); }
+}
+// which LO-MSAC this library was built around: 0 = the restatement (lomsac.hpp), 1 = the reference's include/RansacLib (oracle/_ref only)
+extern "C" int32_t oracle_lomsac_is_reference(void) {
+#ifdef SSFM_ORACLE_REAL_RANSACLIB
+    return 1;
+#else
+    return 0;
+#endif
 }
 // SphericalEstimator::NonMinimalSolver (src/spherical_estimator.cpp:86-108)
 extern "C" int oracle_nonminimal_solver(int32_t n, const double* u, const double* v, int32_t ns, const int32_t* sample, double E_cm[9]) {

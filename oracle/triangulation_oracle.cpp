@@ -14,7 +14,13 @@
 #include <cstring>
 #include <vector>
 #include "lm.hpp"
+#ifdef SSFM_ORACLE_REAL_RANSACLIB      // oracle/_ref build: the reference's own include/RansacLib drives the same estimator (lomsac_reference.hpp)
+#include "lomsac_reference.hpp"
+#define ORACLE_LOMSAC LoMsacReference
+#else
 #include "lomsac.hpp"
+#define ORACLE_LOMSAC LoMsac
+#endif
 #include "rotation.hpp"
 #include "ssfm_oracle.h"
 
@@ -172,7 +178,7 @@ extern "C" int oracle_retriangulate_ex(oracle_ba_problem* p, int32_t num_threads
         if (obs.size() < 3) continue;
         MSACOptions o; o.sq_thresh = 4.0; o.final_lsq = true;                                      // src/sfm.cpp:175-177
         TriSolver solver{obs};
-        LoMsac<TriSolver, Pt> R(solver, o);
+        ORACLE_LOMSAC<TriSolver, Pt> R(solver, o);
         Pt Xm{}; MSACStats st;
         const int nin = R.estimate(&Xm, &st);
         if (num_inliers_out) num_inliers_out[j] = nin;

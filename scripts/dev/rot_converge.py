@@ -1,0 +1,21 @@
+"""Converged-minimum comparison of the large pose graphs (VERDICT r4 #1b): both sides with the iteration cap lifted and tight tolerances.
+usage: python scripts/dev/rot_converge.py [n ...]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from scipy.spatial.transform import Rotation
+from oracle import oracle as O
+from spherical_sfm_amd import ba, rotavg, synth
+
+ctx = ba.Context(0)
+tol = dict(function_tolerance=float(os.environ.get("FT", 1e-16)), gradient_tolerance=1e-16, parameter_tolerance=float(os.environ.get("PT", 1e-16)))
+cap = int(os.environ.get("CAP", 8000))
+for n in [int(a) for a in sys.argv[1:]] or [2000, 4000]:
+    R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(n, 8)
+    t = time.time(); R, c, s = rotavg.optimize_rotations(ctx, R0, i0, i1, Rrel, max_num_iterations=cap, **tol); tg = time.time() - t
+    O.pose_graph_test_options(cap, tol["function_tolerance"], tol["gradient_tolerance"], tol["parameter_tolerance"])
+    t = time.time(); Ro, co, so = O.optimize_rotations(R0.copy(), i0, i1, Rrel); to = time.time() - t
+    O.pose_graph_test_options(0)
+    ang = np.linalg.norm(Rotation.from_matrix(np.einsum('nij,nkj->nik', R, Ro)).as_rotvec(), axis=1)
+    print(f"n={n} gpu: it {s['iterations']} term {s['termination']} cost {c!r} {tg:.1f}s | oracle: it {so['iterations']} term {so['termination']} cost {co!r} {to:.1f}s | "
+          f"dcost/cost {abs(c - co) / co:.2e} max angle {ang.max():.2e} rad", flush=True)

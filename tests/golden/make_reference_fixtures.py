@@ -1,0 +1,256 @@
+"""Fixtures that come from the REFERENCE ITSELF (run in the build container, where /root/reference exists):
+
+    python tests/golden/make_reference_fixtures.py        # builds oracle/_ref first (make -C oracle ref)
+
+Nothing of the reference's text is written: the outputs are numbers.
+
+ref_quartic.npz     SolveQuartic / SolveQuarticReals (src/spherical_solvers.cpp:14-98) COMPILED AS THEY STAND (oracle/ref_quartic_wrap.cpp)
+                    on coefficient sets incl. near-double roots, complex pairs, the |U.real| < 1e-8 branch (:44-49) and quartics of the
+                    polynomial solver itself.
+ref_solver_C.npz    the generated coefficient arithmetic of both minimal solvers, EVALUATED from the reference's own scalar lines
+                    (src/spherical_solvers.cpp:127-277 `t2..t145` + `C << ...`, :338-619 `t2..` + `C(i,j) = ...`; read at run time,
+                    `B(i,j)` -> array element, plain IEEE doubles in the written order -- no Eigen stand-in is compiled) for nullspace
+                    bases B of random 3-ray samples; then the rest of each solver with numpy in place of Eigen's LU / EigenSolver
+                    (:279-308, :623-654) and the compiled SolveQuartic: the candidate essential matrices.
+ref_ransaclib.npz   traces of the reference's OWN include/RansacLib/{ransac,sampling,utils}.h (compiled as they stand, lomsac_reference.hpp)
+                    driving the oracle's estimators: RansacStatistics, inlier sets and models for image pairs under many option sets
+                    (row a13) and for the per-point runs of SfM::Retriangulate (row N1).
+
+What this pins: oracle/ransac_oracle.cpp's quartic, constraint matrices and both solvers' back ends; oracle/lomsac.hpp (control flow, both
+random streams, iteration rule).  What it cannot pin: anything that runs through Ceres or Eigen in the reference (LM, LU pivot order,
+EigenSolver's eigenvector scaling, colPivHouseholderQr's basis) -- see DESIGN.md section 2.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SSFM_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O                      # noqa: E402
+from spherical_sfm_amd import synth                 # noqa: E402
+
+
+# ---- the compiled reference quartic ---------------------------------------------------------------------------------------------
+def ref_lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    L = C.CDLL(O.reference_lib_path())
+    dp = C.POINTER(C.c_double)
+    L.ref_solve_quartic.argtypes = [C.c_double] * 5 + [dp]; L.ref_solve_quartic.restype = C.c_int32
+    L.ref_solve_quartic_reals.argtypes = [C.c_double] * 5 + [dp]; L.ref_solve_quartic_reals.restype = C.c_int32
+    L.ref_solve_quartic_reals_tol.argtypes = [C.c_double] * 6 + [dp]; L.ref_solve_quartic_reals_tol.restype = C.c_int32
+    return L
+
+
+def ref_quartic(L, coef):
+    out = np.zeros(8)
+    n = L.ref_solve_quartic(*[float(x) for x in coef], out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert n == 4
+    return out[0::2] + 1j * out[1::2]
+
+
+def quartic_cases(rng):
+    cases = []
+    for _ in range(120):                                                       # generic
+        cases.append(rng.normal(size=5) * 10.0 ** rng.integers(-2, 3))
+    for k in range(40):                                                        # from roots: near-double / double / all real / complex pairs
+        r = rng.normal(size=4) * 2
+        if k % 4 == 0: r[1] = r[0] + 10.0 ** -rng.integers(3, 12)
+        if k % 4 == 1: r[1] = r[0]
+        lead = rng.uniform(0.5, 2) * rng.choice([-1, 1])
+        if k % 4 == 2:
+            z = complex(rng.normal(), abs(rng.normal()) * 10.0 ** -rng.integers(0, 9))
+            p = np.poly([z, z.conjugate(), r[2], r[3]]).real
+        else:
+            p = np.poly(r)
+        cases.append(lead * p)
+    for k in range(24):                                                        # P = 0, Q > 0: R = 0, |U.real| < 1e-8 branch (:44-46)
+        al = -rng.uniform(1, 4); be = rng.uniform(-1, 1) * np.sqrt(-8 * al ** 3 / 27) * 0.9
+        ga = -al * al / 12.0
+        if k % 3 == 1: ga *= 1 + 1e-13
+        if k % 3 == 2: ga *= 1 - 1e-15
+        s = rng.uniform(-1, 1) if k % 2 else 0.0                               # shift x -> x - s brings b != 0 back
+        p = np.poly1d([1, 0, al, be, ga])(np.poly1d([1, -s]))
+        cases.append(np.asarray(p.coeffs, float) * rng.uniform(0.5, 3))
+    for k in range(16):                                                        # biquadratic (beta = 0: 0/0 or x/0 inside, kept as the reference returns it)
+        cases.append(np.array([rng.uniform(0.5, 2), 0.0, rng.normal(), 0.0, rng.normal()]))
+    return np.array(cases)
+
+
+# ---- the reference's generated scalar code, evaluated ------------------------------------------------------------------------------
+def _statements(variant):
+    """the generated block of solver `variant` as a list of statements: from its first `const double t2 = ...` to the line in front of
+    `Eigen::Matrix<double,6,4> G(...)` (action matrix: src/spherical_solvers.cpp:127-277, polynomial: :338-619)"""
+    with open(os.path.join(REF, "src", "spherical_solvers.cpp")) as f:
+        lines = f.read().split("\n")
+    head = ["int spherical_solver_action_matrix(", "int spherical_solver_polynomial("][variant]
+    start = next(i for i, l in enumerate(lines) if head in l)
+    lo = next(i for i in range(start, len(lines)) if re.match(r"\s*const double\s+t2\s*=", lines[i]))
+    hi = next(i for i in range(lo, len(lines)) if "Eigen::Matrix<double,6,4> G(" in lines[i])
+    assert (lo + 1, hi) == [(127, 278), (338, 620)][variant], (lo + 1, hi)         # the cited line ranges (1-based, hi exclusive)
+    text = " ".join(lines[lo:hi])
+    text = re.sub(r"B\((\d),(\d)\)", r"B[\1][\2]", text)
+    return [s.strip() for s in text.split(";") if s.strip()]
+
+
+def eval_reference_C(B, variant):
+    """C (6x10) exactly as the reference's generated lines compute it from B (6x3).  variant 0: :127-277, 1: :338-619"""
+    env = {"B": [[float(B[i, j]) for j in range(3)] for i in range(6)]}
+    Cm = np.full((6, 10), np.nan)
+    stmts = _statements(variant)
+    seen_C = False
+    for s in stmts:
+        if s.startswith("Eigen::Matrix<double,6,10> C"):
+            s = s[len("Eigen::Matrix<double,6,10> C"):].strip()
+            if not s: continue
+        m = re.match(r"const double\s+(t\d+)\s*=\s*(.*)$", s)
+        if m:
+            env[m.group(1)] = eval(m.group(2), {"__builtins__": {}}, env)
+            continue
+        if s.startswith("C <<"):
+            exprs = s[4:].split(",")
+            assert len(exprs) == 60, len(exprs)
+            Cm[:] = np.array([eval(e, {"__builtins__": {}}, env) for e in exprs]).reshape(6, 10)      # Eigen's comma initialiser fills row by row
+            seen_C = True
+            continue
+        m = re.match(r"C\((\d),(\d)\)\s*=\s*(.*)$", s)
+        if m:
+            Cm[int(m.group(1)), int(m.group(2))] = eval(m.group(3), {"__builtins__": {}}, env)
+            seen_C = True
+            continue
+        raise ValueError("unexpected statement in the generated block: " + s[:80])
+    assert seen_C and np.isfinite(Cm).all()
+    return Cm
+
+
+def essential_from_b(B, b):                                                     # src/spherical_solvers.cpp:296-305 / 645-654
+    p = B @ b
+    E = np.array([[p[0], p[1], p[2]], [p[1], -p[0], p[3]], [p[4], p[5], 0.0]])
+    return E / np.linalg.norm(E)
+
+
+def reference_action_matrix_Es(B, Cm):                                          # :279-308 with numpy's LU / eig in place of Eigen's
+    G = np.linalg.solve(Cm[:, :6], Cm[:, 6:])
+    M = np.zeros((4, 4)); M[0] = -G[2]; M[1] = -G[4]; M[2] = -G[5]; M[3, 1] = 1
+    lam, V = np.linalg.eig(M)
+    Es, real = [], []
+    for i in range(4):
+        vi = V[:, i] / V[3, i]                                                  # the scale of an eigenvector is the solver's own; E is normalised anyway
+        Es.append(essential_from_b(B, np.array([vi[1].real, vi[2].real, 1.0])))
+        real.append(abs(lam[i].imag) <= 1e-9 * max(1.0, abs(lam[i])))
+    return np.array(Es), np.array(real), lam
+
+
+def reference_polynomial_Es(L, B, Cm):                                          # :623-654 with the compiled SolveQuartic
+    G = np.linalg.solve(Cm[:, :6], Cm[:, 6:])
+    abcde = np.array([-G[5, 0], G[4, 0] - G[5, 1], G[4, 1] - G[5, 2], G[4, 2] - G[5, 3], G[4, 3]])
+    roots = ref_quartic(L, abcde)
+    Es = []
+    for r in roots:
+        y = r.real
+        x = -G[5, 0] * y ** 3 - G[5, 1] * y ** 2 - G[5, 2] * y - G[5, 3]
+        Es.append(essential_from_b(B, np.array([x, y, 1.0])))
+    return np.array(Es), roots, abcde
+
+
+def nullspace_basis(u, v):
+    A = np.stack([u[:, 0] * v[:, 0] - u[:, 1] * v[:, 1], u[:, 0] * v[:, 1] + u[:, 1] * v[:, 0], u[:, 2] * v[:, 0], u[:, 2] * v[:, 1],
+                  u[:, 0] * v[:, 2], u[:, 1] * v[:, 2]], 1)                      # :119
+    return np.linalg.svd(A)[2][3:].T.copy()                                     # any orthonormal basis of the nullspace; the candidate E's do not depend on it
+
+
+# ---- RansacLib traces ---------------------------------------------------------------------------------------------------------------
+PAIR_CASES = [  # (correspondences, outlier fraction, noise, rotation, kwargs of oracle.lomsac_pair)
+    (500, 0.30, 1 / 600, 12, dict()),                                                           # estimate_pairwise's options (tools.cpp:314-318)
+    (500, 0.30, 1 / 600, 25, dict(num_lo_steps=10, num_lsq_iterations=4)),                      # RansacLib's LO defaults
+    (200, 0.50, 1 / 600, 8, dict(num_lo_steps=10, num_lsq_iterations=4, final_least_squares=False)),
+    (120, 0.10, 0.0, 30, dict(num_lo_steps=3, num_lsq_iterations=2, lo_starting_iterations=10)),
+    (60, 0.60, 2 / 600, 5, dict(num_lo_steps=10, num_lsq_iterations=4, max_iterations=400)),
+    (9, 0.0, 1 / 600, 15, dict(num_lo_steps=10, num_lsq_iterations=4)),
+    (5, 0.0, 0.0, 15, dict(num_lo_steps=10, num_lsq_iterations=4)),                             # n / (n - 3) > e: the sampler's shuffle branch (sampling.h:66-75)
+    (4, 0.0, 0.0, 20, dict(num_lo_steps=2, num_lsq_iterations=2)),
+    (3, 0.0, 0.0, 20, dict()),                                                                  # sample_size == num_data (sampling.h:103)
+    (2, 0.0, 0.0, 20, dict()),                                                                  # fewer data than a sample: returns 0 (ransac.h:137-141)
+    (300, 0.30, 1 / 600, 18, dict(use_poly=True)),
+    (300, 0.30, 1 / 600, 18, dict(use_poly=True, num_lo_steps=10, num_lsq_iterations=4)),
+    (400, 0.80, 1 / 600, 10, dict(num_lo_steps=10, num_lsq_iterations=4, success_probability=0.99)),
+    (1000, 0.40, 1 / 600, 40, dict(num_lo_steps=10, num_lsq_iterations=4, min_sample_multiplicator=3, non_min_sample_multiplier=5, threshold_multiplier=2.0)),
+    (250, 0.95, 1 / 600, 10, dict(num_lo_steps=10, num_lsq_iterations=4, max_iterations=300)),  # hardly any consensus: the iteration cap ends it
+    (500, 0.30, 1 / 600, 12, dict(inward=True, num_lo_steps=10, num_lsq_iterations=4)),
+]
+SEEDS = (0, 1, 12345)
+
+
+def pair_traces():
+    thr = (2 / 600) ** 2
+    rec = dict(ptr=[0], u=[], v=[], case=[], seed=[], iterations=[], lo_runs=[], num_inliers=[], score=[], E=[], R=[], mask=[])
+    with O.reference_ransaclib():
+        for ci, (n, of, noise, rot, kw) in enumerate(PAIR_CASES):
+            for seed in SEEDS:
+                u, v, *_ = synth.make_relative_pose_problem(n, seed=1000 + 17 * ci + seed % 7, noise=noise, outlier_frac=of, rotation_deg=rot, inward=kw.get("inward", False))
+                r = O.lomsac_pair(u, v, thr, seed=seed, **kw)
+                rec["ptr"].append(rec["ptr"][-1] + n); rec["u"].append(u); rec["v"].append(v); rec["case"].append(ci); rec["seed"].append(seed)
+                rec["iterations"].append(r["iterations"]); rec["lo_runs"].append(r["lo_runs"]); rec["num_inliers"].append(r["num_inliers"])
+                rec["score"].append(r["score"]); rec["E"].append(r["E"]); rec["R"].append(r["R"]); rec["mask"].append(r["inliers"])
+    return dict(pair_ptr=np.array(rec["ptr"], np.int64), pair_u=np.concatenate(rec["u"]), pair_v=np.concatenate(rec["v"]), pair_case=np.array(rec["case"], np.int32),
+                pair_seed=np.array(rec["seed"], np.uint32), pair_iterations=np.array(rec["iterations"], np.uint32), pair_lo_runs=np.array(rec["lo_runs"], np.uint32),
+                pair_num_inliers=np.array(rec["num_inliers"], np.int32), pair_score=np.array(rec["score"]), pair_E=np.array(rec["E"]), pair_R=np.array(rec["R"]),
+                pair_mask=np.concatenate(rec["mask"]))
+
+
+def retriangulate_problem():
+    """small circle + ragged tracks of 2..9 observations, a tenth of the pixels corrupted (the problem itself is rebuilt by the test from this recipe)"""
+    p = synth.make_ragged_circle(120, 3000, 2, 9, seed=21, pixel_noise=0.5)
+    synth.corrupt_observations(p, frac=0.1, seed=3)
+    return p
+
+
+def retriangulate_trace():
+    p = retriangulate_problem()
+    with O.reference_ransaclib():
+        pts, nin, it, lo, fl = O.retriangulate_ex(p, num_threads=8)
+    return dict(tri_points=pts, tri_num_inliers=nin, tri_iterations=it, tri_lo_runs=lo, tri_flags=fl)
+
+
+def main():
+    rng = np.random.default_rng(20261003)
+    L = ref_lib()
+    # 1. quartic
+    coef = quartic_cases(rng)
+    roots = np.array([ref_quartic(L, c) for c in coef])
+    reals = np.zeros((len(coef), 4)); reals_tol = np.full((len(coef), 4), np.nan); n_tol = np.zeros(len(coef), np.int32)
+    for i, c in enumerate(coef):
+        assert L.ref_solve_quartic_reals(*[float(x) for x in c], reals[i].ctypes.data_as(C.POINTER(C.c_double))) == 4
+        buf = np.zeros(4)
+        n_tol[i] = L.ref_solve_quartic_reals_tol(*[float(x) for x in c], 1e-9, buf.ctypes.data_as(C.POINTER(C.c_double)))
+        reals_tol[i, :n_tol[i]] = buf[:n_tol[i]]
+    # 2. generated coefficient code + solver back ends
+    S = 96
+    us, vs, Bs, Ca, Cp, Ea, Ea_real, lam, Ep, proots, abcde = ([] for _ in range(11))
+    for k in range(S):
+        u, v, *_ = synth.make_relative_pose_problem(3, seed=500 + k, noise=(0.0 if k % 3 == 0 else 1 / 600), rotation_deg=3 + k % 50, inward=bool(k % 5 == 4))
+        B = nullspace_basis(u, v)
+        c0 = eval_reference_C(B, 0); c1 = eval_reference_C(B, 1)
+        e0, re0, l0 = reference_action_matrix_Es(B, c0)
+        e1, r1, ab = reference_polynomial_Es(L, B, c1)
+        us.append(u); vs.append(v); Bs.append(B); Ca.append(c0); Cp.append(c1); Ea.append(e0); Ea_real.append(re0); lam.append(l0); Ep.append(e1); proots.append(r1); abcde.append(ab)
+    quart2 = np.array(abcde)                                                    # the solver's own quartics go through the compiled SolveQuartic too
+    coef = np.concatenate([coef, quart2]); roots = np.concatenate([roots, np.array(proots)])
+    np.savez_compressed(os.path.join(HERE, "ref_quartic.npz"), coef=coef, roots=roots, reals=reals, reals_tol=reals_tol, n_tol=n_tol)
+    np.savez_compressed(os.path.join(HERE, "ref_solver_C.npz"), u=np.array(us), v=np.array(vs), B=np.array(Bs), C_action=np.array(Ca), C_poly=np.array(Cp),
+                        E_action=np.array(Ea), E_action_is_real=np.array(Ea_real), lam_action=np.array(lam), E_poly=np.array(Ep), roots_poly=np.array(proots),
+                        abcde=np.array(abcde))
+    # 3. RansacLib
+    d = pair_traces(); d.update(retriangulate_trace())
+    np.savez_compressed(os.path.join(HERE, "ref_ransaclib.npz"), **d)
+    print("quartic cases", len(coef), "| solver samples", S, "| pair traces", len(d["pair_seed"]), "| retriangulated points", len(d["tri_points"]))
+
+
+if __name__ == "__main__":
+    main()
