@@ -291,7 +291,9 @@ k_sub_sep_assemble_mfma(const double* __restrict__ band, const double* __restric
         v4d_t acc = {0.0, 0.0, 0.0, 0.0};
         const bool diag = I == J;
         auto load4 = [&](const double* zp, int k, double (&v)[4]) {
-            if (k + 4 <= k1w) { const double2 v01 = *reinterpret_cast<const double2*>(zp + k), v23 = *reinterpret_cast<const double2*>(zp + k + 2); v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y; }
+            // 16-byte loads need an even element offset: rows start at multiples of n = N DC and k at multiples of DC (+ 4 lk), so DC = 6 is always
+            // aligned; the unmerged 3-dof band (ssfm_band_solve_probe with dc = 3, odd N or an odd segment start) is not and takes the scalar loads
+            if (k + 4 <= k1w && (DC % 2 == 0 || ((reinterpret_cast<uintptr_t>(zp + k) & 15) == 0))) { const double2 v01 = *reinterpret_cast<const double2*>(zp + k), v23 = *reinterpret_cast<const double2*>(zp + k + 2); v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y; }
             else {
 #pragma unroll
                 for (int u = 0; u < 4; u++) v[u] = (k + u < k1w) ? zp[k + u] : 0.0;

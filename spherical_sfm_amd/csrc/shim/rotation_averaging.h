@@ -13,4 +13,26 @@ struct RelativeRotation {
 
 double optimize_rotations(std::vector<Mat3>& rotations, const std::vector<RelativeRotation>& relative_rotations);
 
+#ifdef SSFM_WITH_EIGEN      // the reference's own signature (rotation_averaging.h:9-16); not compiled in this image (no Eigen), see sfm.h
+inline Mat3 mat3_from_eigen(const Eigen::Matrix3d& M) { Mat3 m; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) m[i + 3 * j] = M(i, j); return m; }
+inline Eigen::Matrix3d mat3_to_eigen(const Mat3& m) { Eigen::Matrix3d M; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) M(i, j) = m[i + 3 * j]; return M; }
+struct RelativeRotationEigen {
+    int index0, index1;
+    Eigen::Matrix3d R;
+    RelativeRotationEigen(const int _index0, const int _index1, const Eigen::Matrix3d& _R) : index0(_index0), index1(_index1), R(_R) {}
+};
+inline std::vector<RelativeRotation> relative_rotations_from_eigen(const std::vector<RelativeRotationEigen>& in) {
+    std::vector<RelativeRotation> out; out.reserve(in.size());
+    for (const auto& e : in) out.emplace_back(e.index0, e.index1, mat3_from_eigen(e.R));
+    return out;
+}
+inline double optimize_rotations(std::vector<Eigen::Matrix3d>& rotations, const std::vector<RelativeRotationEigen>& relative_rotations) {
+    std::vector<Mat3> R; R.reserve(rotations.size());
+    for (const auto& M : rotations) R.push_back(mat3_from_eigen(M));
+    const double cost = optimize_rotations(R, relative_rotations_from_eigen(relative_rotations));
+    for (size_t i = 0; i < R.size(); i++) rotations[i] = mat3_to_eigen(R[i]);
+    return cost;
+}
+#endif
+
 }  // namespace sphericalsfm

@@ -17,6 +17,13 @@
 #include <string>
 #include <vector>
 #include "../../../include/ssfm.h"
+// SSFM_WITH_EIGEN (SURVEY 8b "Build constraint"; reference include/sphericalsfm/sfm.h:4-13, sfm_types.h:3-29): a maintainer who HAS Eigen defines it and the
+// PODs below convert to and from the Eigen types of the reference's signatures implicitly -- sfm.AddPoint(Eigen::Vector3d(...)), Eigen::Vector3d X = sfm.GetPoint(j),
+// Pose(Eigen::Vector3d t, Eigen::Vector3d r), pose.P() -- so a caller written against the reference's headers compiles against these.  Eigen is not in this
+// image: this block is written from Eigen's documented interface and has NOT been compiled here (INTEGRATION.md says so too).
+#ifdef SSFM_WITH_EIGEN
+#include <Eigen/Core>
+#endif
 
 namespace sphericalsfm {
 
@@ -24,6 +31,10 @@ struct Vec3 {
     double v[3];
     Vec3() : v{0, 0, 0} {}
     Vec3(double x, double y, double z) : v{x, y, z} {}
+#ifdef SSFM_WITH_EIGEN
+    Vec3(const Eigen::Vector3d& e) : v{e(0), e(1), e(2)} {}
+    operator Eigen::Vector3d() const { return Eigen::Vector3d(v[0], v[1], v[2]); }
+#endif
     double& operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
     double& operator[](int i) { return v[i]; }
@@ -32,13 +43,25 @@ struct Vec3 {
 };
 typedef Vec3 Point;                       // include/sphericalsfm/sfm_types.h:8
 typedef std::array<double, 6> Camera;     // [t;r], sfm_types.h:9
-struct Observation { double x, y; Observation() : x(0), y(0) {} Observation(double _x, double _y) : x(_x), y(_y) {} };
+struct Observation {
+    double x, y;
+    Observation() : x(0), y(0) {}
+    Observation(double _x, double _y) : x(_x), y(_y) {}
+#ifdef SSFM_WITH_EIGEN                    // typedef Eigen::Vector2d Observation, sfm_types.h:12
+    Observation(const Eigen::Vector2d& e) : x(e(0)), y(e(1)) {}
+    operator Eigen::Vector2d() const { return Eigen::Vector2d(x, y); }
+    double operator()(int i) const { return i == 0 ? x : y; }
+#endif
+};
 
 struct Pose {                             // sfm_types.h:14-29 / src/sfm_types.cpp
     Vec3 t, r;
     double R[9];                          // row-major rotation so3exp(r) (the 3x3 block of the reference's P)
     Pose();
     Pose(const Vec3& _t, const Vec3& _r);
+#ifdef SSFM_WITH_EIGEN                    // the reference's member `Eigen::Matrix4d P` (sfm_types.h:18) as a function: [R t; 0 0 0 1]
+    Eigen::Matrix4d P() const { Eigen::Matrix4d M = Eigen::Matrix4d::Identity(); for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M(i, j) = R[3 * i + j]; M(i, 3) = t(i); } return M; }
+#endif
     Pose inverse() const;
     void postMultiply(const Pose& pose);
     Point apply(const Point& point) const;
@@ -97,6 +120,12 @@ public:
 // One row of the observation table (the points a camera sees): the same slice of std::map<int, T>'s interface over a SORTED VECTOR of (id, value) pairs.  A row is written in
 // ascending point order by the synthetic drivers (push_back); anything else goes through a small merge buffer (below).  The first Flatten of a run walks all rows
 // twice: 2 x 1.02 M std::map nodes took ~60 ms at configs[2] size, the vectors ~5.
+//
+// WHERE THESE TWO CONTAINERS PROMISE LESS THAN std::map (the reference's sparse.hpp): (1) a reference returned by operator[] is valid only until the NEXT insert
+// into the same container (IndexedMap grows its vectors, FlatMap merges its buffer) -- copy the value before inserting, as MergePoint does; std::map references
+// stay valid for the node's life.  (2) const access is NOT safe for concurrent readers: FlatMap's begin / end / find / count merge the pending buffer first
+// (`mutable`), so two threads reading one row at once race unless the row was frozen before -- call freeze() on every row (SfM::FreezeObservations) ahead of a
+// parallel read-only phase; after it the const accessors touch nothing until the next insert.  The mirror itself is single-threaded, like the reference's SfM.
 template <class T> class FlatMap {
     // Out-of-order inserts (build_sfm hands a keyframe's observations over in feature order, i.e. in random track order) wait in a small unsorted buffer and are merged
     // in when it holds 64 of them: a random insert into a 2000-entry row costs a search + 1/64 of a merge instead of moving half the row.
@@ -132,6 +161,8 @@ public:
     }
     size_t erase(int k) { auto it = find(k); if (it == v.end()) return 0; v.erase(it); return 1; }
     iterator erase(iterator it) { return v.erase(it); }          // (it comes from begin() / find(): the buffer is merged)
+    void freeze() { flush(); }                                   // merge the pending inserts now: const access is then read-only (see the note above)
+    bool frozen() const { return pend.empty(); }
     size_t size() const { return v.size() + pend.size(); }
     bool empty() const { return v.empty() && pend.empty(); }
 };
@@ -207,6 +238,7 @@ public:
     void WriteCOLMAP(const std::string& sparse_dir, int width, int height);          // src/sfm.cpp:573-647
     void WriteCalib(const std::string& path);                                        // run_spherical_sfm_uncalib.cpp:225-228
     void FilterObservations(double thresh);                                          // src/sfm.cpp:297-339
+    void FreezeObservations() { for (auto& row : observations) row.second.freeze(); }   // before a parallel read-only phase over this object (see FlatMap)
     const ssfm_ba_summary& LastSummary() const { return last_summary; }
     ssfm_ctx* GetContext();                       // the library context of this object (created on first use); for the tools around it
 };

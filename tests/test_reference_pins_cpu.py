@@ -215,3 +215,24 @@ def test_live_quartic_sweep(oracle):
     for _ in range(3000):
         c = rng.normal(size=5) * 10.0 ** rng.integers(-3, 4, size=5)
         assert np.array_equal(oracle.solve_quartic(*c), m.ref_quartic(L, c), equal_nan=True), c
+
+
+# ---- the product's host-side LO-MSAC driver (csrc/shim/lo_msac.h) against the reference's header -------------------------------------------
+def test_host_driver_reproduces_the_reference_ransaclib_on_a_toy_estimator(tmp_path):
+    """tests/native/lomsac_driver_trace.cpp is written against RansacLib's interface only; compiled against the shim's lo_msac.h it must print, bit for
+    bit (%a), what the same source printed when compiled against the reference's include/RansacLib/ransac.h (tests/golden/ref_ransaclib_line.txt:
+    11 option sets x 3 seeds of 2-D line fitting: iterations, LO runs, inlier sets, scores, models).  Where /root/reference exists the reference build
+    is repeated and compared as well."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "native", "lomsac_driver_trace.cpp")
+    gold = open(os.path.join(GOLD, "ref_ransaclib_line.txt")).read()
+    assert gold.count("\n") == 33
+    builds = [("shim", ["-I" + os.path.join(root, "spherical_sfm_amd", "csrc", "shim")])]
+    if os.path.isdir("/root/reference/include/RansacLib"):
+        builds.append(("reference", ["-DSSFM_TRACE_REFERENCE_HEADER", "-I/root/reference/include"]))
+    for name, flags in builds:
+        exe = str(tmp_path / ("trace_" + name))
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off"] + flags + [src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+        assert out == gold, name
