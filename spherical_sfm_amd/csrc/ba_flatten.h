@@ -27,6 +27,7 @@
 #include <unistd.h>
 #include <vector>
 #include "../../include/ssfm.h"
+#include "ring_comp.h"
 
 namespace ssfm {
 
@@ -82,6 +83,10 @@ struct BAFlat {
     int band_block = 0;                 // size of the band's blocks: DC, or 6 when DC = 3 and pairs are merged
     std::vector<unsigned char> pair_dummy;   // [Nc] 1 = this (even) camera's partner slot is empty (odd-sized component)
     int y_rows(int dc) const { return band_rows * (band_block > 0 ? band_block : dc) / dc; }   // rows of the right-hand sides in camera units
+    // Round 5: long camera rings in their own circular order (band_plan: RingComp); wrap_* = the coupling blocks between a ring's first arc and its last separator,
+    // which the gather kernels place (transposed) relative to the separator's copy slot in front of the arc (ring_wrap_table); empty without rings
+    std::vector<RingComp> rings;
+    std::vector<int> wrap_ptr, wrap_blk, wrap_row2;
     // The stored structure (row_ptr/col_idx) is the LOWER triangle in elimination order: row c holds block (c, c2) iff
     // cam_pos[c2] <= cam_pos[c].  trans_* lists, for every camera c, the stored blocks of OTHER rows whose column is c
     // (the upper triangle by symmetry) for the symmetric mat-vec.
@@ -222,11 +227,11 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
     return band;
 }
 
+// ---- band layout of the reduced camera system -------------------------------------------------------------------------------------------
 // Twisted (two-sided) elimination of medium-sized components.  A component of n rows in Cuthill-McKee order with half-width b is
 // split as seg_0 (m0 rows) | sep (b rows) | seg_1 (m1 rows).  seg_0 is eliminated front to back and seg_1 BACK TO FRONT, so both
 // have the separator behind them: no fill, and the dependent chain of the factorisation is (n - b) / 2 + b steps instead of n.
-//   in : pos = Cuthill-McKee positions, comp_ptr = component ranges in that order
-//   out: pos = elimination order (seg_0 | seg_1 reversed | sep), band_row / band_row2 / band_rows, comp_ptr in band rows
+// Elimination order seg_0 | seg_1 reversed | sep; band rows seg_0 | sep | seg_1 reversed | copy of sep.
 // A component is twisted when both segments are longer than the band (n >= 3 b + 2) and it is not long enough to be cut into
 // several segments (band_sub.h, SUB_MIN_ROWS); the kernels involved need the LDS-resident factorisation (b <= 20).
 // Half-widths above 20 (6x6 blocks) need the packed-window factorisation (band_kernels2p.h, ba_handle.h: band_wide_packed): with it on (default) components are
@@ -234,76 +239,182 @@ inline int cuthill_mckee(int n, const std::vector<int>& row_ptr, const std::vect
 inline bool band_packed_enabled() { const char* e = std::getenv("SSFM_BAND_PACKED"); return !(e && std::atoi(e) == 0); }
 inline int band_wide_max() { return band_packed_enabled() ? 30 : 20; }
 constexpr int BAND_CUT_MIN_ROWS = 512;            // below: twisted (two workgroups, no spike); from here on: cut into a chain of segments (band_sub.h)
-inline void band_twist_plan(int Nc, int b, std::vector<int>& pos, std::vector<int>& comp_ptr, std::vector<int>& band_row,
-                            std::vector<int>& band_row2, std::vector<char>& comp_twist, int& band_rows, int max_b = 20) {
-    const char* env = std::getenv("SSFM_BAND_TWIST");
-    const bool allow = !(env && env[0] == '0') && b >= 1 && b <= max_b;   // 20: the 6-dof factorisation window fits the LDS (3-dof blocks: 40)
+
+// Round 5 -- ring-native layout of long camera rings (band_ring.h).  Cuthill-McKee FOLDS a ring: the two sides of the ring are interleaved in one band of
+// twice the ring's reach r, although they do not touch each other except at the two turning points.  Everything downstream pays for the doubled width: the
+// factorisation window (b + 1)^2, the b DC spike columns, the dense separator blocks (b DC)^2.5.  A ring in its own circular order is a PERIODIC band of half-width r:
+//     [copy of S_{m-1}] | A_0 | S_0 | A_1 | S_1 | ... | A_{m-1} | S_{m-1}            (A = arcs, S = separators of r block rows, m >= 2 cuts)
+// Every arc has the separator behind it adjacent (the factorisation's window continues into it) and the separator in front of it adjacent too -- for A_0 that is
+// S_{m-1}, which gets a second set of r band rows in front of A_0 that only carries the coupling blocks (A_0, S_{m-1}) (the gather kernels place them there,
+// transposed: ring_wrap_table).  The separators form a CYCLE of m dense blocks of r DC unknowns -- half the size of the folded ones --, solved by cyclic reduction
+// (band_ring.h).  A component is laid out like this when it is long (or too wide for the LDS window when folded), periodic in camera-id order with a reach well
+// under the folded half-width, and its separator blocks fit the cyclic-reduction kernel (r DC <= RING_QMAX).  SSFM_RING=0 turns it off; SSFM_RING_CUTS=m forces m.
+constexpr int RING_QMAX = 78;                     // (3 Q + 2) (Q | 1) doubles of LDS in k_ring_cr_elim
+inline int ring_choose_cuts(int rows, int b) {
+    if (const char* e = std::getenv("SSFM_RING_CUTS")) { const int m = std::atoi(e); if (m >= 2) return std::min(m, std::max(2, rows / (2 * b + 1))); }
+    // arcs of about max(2 b, 32) rows: an arc costs its length in dependent steps (factorisation + spike + back substitution, ~2 us per row), a doubling of the
+    // cuts one more level of cyclic reduction (~25 us for its elimination and its back-substitution launch)
+    const int target = std::max(2 * b, 32);
+    int m = (rows + (target + b) / 2) / (target + b);
+    m = std::max(2, std::min(m, rows / (2 * b + 1)));
+    return m;
+}
+
+// Elimination order + band layout of the reduced camera system: Cuthill-McKee per component, then per component one of
+//   ring (above) | twisted | plain,   with (3-dof blocks) pairs of consecutive cameras merged into 6x6 block rows.
+//   out: pos (elimination order, a permutation), band (half-width in blocks), comp_ptr / band_rows (block rows), band_row / band_row2
+//        (camera rows), comp_twist, band_block, pair_dummy, rings (optional: nullptr = never lay out rings)
+inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos, int& band,
+                      std::vector<int>& comp_ptr, std::vector<int>& band_row, std::vector<int>& band_row2, std::vector<char>& comp_twist,
+                      int& band_rows, int& band_block, std::vector<unsigned char>& pair_dummy, std::vector<RingComp>* rings = nullptr) {
+    cuthill_mckee(Nc, row_ptr, col_idx, pos, &comp_ptr);
+    pair_dummy.assign(Nc, 0);
+    if (rings) rings->clear();
+    const char* env_m = std::getenv("SSFM_BAND_MERGE");
+    const bool merge = dc == 3 && !(env_m && env_m[0] == '0');
+    const int W = merge ? 2 : 1;                                           // cameras per block row
+    band_block = merge ? 6 : dc;
     const int ncomp = (int)comp_ptr.size() - 1;
-    band_row.assign(Nc, -1); band_row2.assign(Nc, -1); comp_twist.assign(ncomp, 0);
-    std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;      // Cuthill-McKee position -> camera
-    std::vector<int> new_ptr(1, 0);
-    int base = 0;
+    std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;  // Cuthill-McKee position -> camera
+    // ---- per component: the sequence of its cameras (Cuthill-McKee order, or id order for a ring) and its half-width in block rows
+    std::vector<std::vector<int>> seq(ncomp);
+    std::vector<int> cb(ncomp, 0), crows(ncomp, 0); std::vector<char> is_ring(ncomp, 0);
+    std::vector<std::vector<int>> seq_cm(ncomp); std::vector<int> cb_cm(ncomp, 0);      // rings: what Cuthill-McKee gave, in case the ring layout is withdrawn
+    std::vector<int> where(Nc, 0);                                         // index of a camera inside its component's sequence
+    const char* env_r = std::getenv("SSFM_RING");
+    const bool ring_on = rings && !(env_r && env_r[0] == '0');
+    const int wide_b = (dc == 3 && !merge) ? 40 : band_wide_max();        // widest band that is twisted
     for (int k = 0; k < ncomp; k++) {
         const int c0 = comp_ptr[k], n = comp_ptr[k + 1] - c0;
-        if (allow && n >= 3 * b + 2 && n < BAND_CUT_MIN_ROWS) {
-            comp_twist[k] = 1;
-            const int m0 = (n - b) / 2, m1 = n - b - m0;
-            for (int i = 0; i < m0; i++) { const int c = inv[c0 + i]; pos[c] = c0 + i; band_row[c] = base + i; }
-            for (int s = 0; s < b; s++) { const int c = inv[c0 + m0 + s]; pos[c] = c0 + m0 + m1 + s; band_row[c] = base + m0 + s; band_row2[c] = base + m0 + b + m1 + (b - 1 - s); }
-            for (int u = 0; u < m1; u++) { const int c = inv[c0 + m0 + b + u]; pos[c] = c0 + m0 + (m1 - 1 - u); band_row[c] = base + m0 + b + (m1 - 1 - u); }
-            base += n + b;
-        } else {
-            for (int i = 0; i < n; i++) { const int c = inv[c0 + i]; band_row[c] = base + i; }
-            base += n;
+        seq[k].assign(inv.begin() + c0, inv.begin() + c0 + n);
+        for (int i = 0; i < n; i++) where[seq[k][i]] = i;
+        int bk = 0;
+        for (int i = 0; i < n; i++) { const int u = seq[k][i]; for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) bk = std::max(bk, std::abs(i / W - where[col_idx[e]] / W)); }
+        cb[k] = bk; crows[k] = (n + W - 1) / W;
+        if (!ring_on) continue;
+        // A circular order of the component in which it is a periodic band?  Two candidates: (a) the camera ids (video frames in temporal order with a loop closure),
+        // (b) a walk round the ring from neighbour to nearest unvisited neighbour (rings whose ids are strided, e.g. SURVEY 8d's circle).  Whatever order comes out is only
+        // USED when the component really is a narrow periodic band in it (the reach below is measured, not assumed).
+        // reach = the largest circular distance between two coupled cameras, in block rows.
+        if (!(crows[k] >= BAND_CUT_MIN_ROWS || bk > 20)) continue;
+        const int R = crows[k];
+        auto circular_reach = [&](const std::vector<int>& ord) {
+            for (int i = 0; i < n; i++) where[ord[i]] = i;
+            int reach = 0;
+            for (int i = 0; i < n; i++) { const int u = ord[i]; for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) { const int d = std::abs(i / W - where[col_idx[e]] / W); reach = std::max(reach, std::min(d, R - d)); } }
+            return reach;
+        };
+        std::vector<int> ids(seq[k]); std::sort(ids.begin(), ids.end());
+        std::vector<int> unf; unf.reserve(n);
+        {   // greedy walk: from the current node to the unvisited neighbour that shares the most neighbours with it (on a ring: the next one in the same direction --
+            // two nodes d <= reach apart share 2 reach - 1 - d neighbours), all the way round
+            const std::vector<int>& cm = seq[k];
+            for (int i = 0; i < n; i++) where[cm[i]] = i;
+            std::vector<char> visited(n, 0), mine(n, 0);
+            int cur = 0; visited[0] = 1; unf.push_back(cm[0]);
+            int scan = 1;                                                  // first index that may still be unvisited (fallback when the walk is stuck)
+            for (int step = 1; step < n; step++) {
+                const int u = cm[cur];
+                for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) mine[where[col_idx[e]]] = 1;
+                int best = -1, best_cnt = -1;
+                for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) {
+                    const int vi = where[col_idx[e]];
+                    if (visited[vi]) continue;
+                    const int v2 = cm[vi]; int cnt = 0;
+                    for (int e2 = row_ptr[v2]; e2 < row_ptr[v2 + 1]; e2++) cnt += mine[where[col_idx[e2]]];
+                    if (cnt > best_cnt) { best_cnt = cnt; best = vi; }
+                }
+                for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) mine[where[col_idx[e]]] = 0;
+                if (best < 0) { while (scan < n && visited[scan]) scan++; best = scan; }
+                visited[best] = 1; unf.push_back(cm[best]); cur = best;
+            }
         }
+        const int ra = circular_reach(ids), rb = circular_reach(unf);
+        std::vector<int>& best = (ra <= rb) ? ids : unf;
+        const int reach = std::min(ra, rb);
+        if (std::getenv("SSFM_RING_DEBUG")) std::fprintf(stderr, "[ring] component %d: %d cameras, %d block rows, fold half-width %d, circular reach by id %d, unfolded %d\n", k, n, R, bk, ra, rb);
+        const bool ok = reach >= 1 && reach * band_block <= RING_QMAX && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
+        if (ok) { is_ring[k] = 1; seq_cm[k] = seq[k]; cb_cm[k] = bk; seq[k] = best; cb[k] = reach; }
+        for (int i = 0; i < n; i++) where[seq[k][i]] = i;
+    }
+    // one half-width for the whole band: a ring whose separators would not fit the cyclic-reduction kernel at THAT width (another component is wider) goes back to the fold
+    for (;;) {
+        band = merge ? 1 : 0;                                              // (6-dof: a graph without couplings keeps half-width 0, as before)
+        for (int k = 0; k < ncomp; k++) band = std::max(band, cb[k]);
+        int demote = -1;
+        for (int k = 0; k < ncomp; k++) if (is_ring[k] && (band * band_block > RING_QMAX || crows[k] < 2 * (2 * band + 1))) { demote = k; break; }
+        if (demote < 0) break;
+        is_ring[demote] = 0; seq[demote].swap(seq_cm[demote]); cb[demote] = cb_cm[demote];
+    }
+    const char* env_t = std::getenv("SSFM_BAND_TWIST");
+    const bool twist_ok = !(env_t && env_t[0] == '0') && band >= 1 && band <= wide_b;
+    // ---- layout: block row i of component k -> elimination index, band row, second band row
+    band_row.assign(Nc, -1); band_row2.assign(Nc, -1); comp_twist.assign(ncomp, 0);
+    std::vector<long long> key(Nc);
+    std::vector<int> new_ptr(1, 0);
+    int base = 0, ebase = 0;                                               // band rows / elimination indices handed out so far (block rows)
+    const int b = band;
+    for (int k = 0; k < ncomp; k++) {
+        const int n = (int)seq[k].size(), R = crows[k];
+        std::vector<int> elim(R), brow(R), brow2(R, -1);
+        if (is_ring[k]) {
+            RingComp rc; rc.comp = k; rc.b = b; rc.rows = R;
+            const int m = ring_choose_cuts(R, b), total = R - m * b;
+            int row = base + b;                                            // [base, base + b): the copy slot of S_{m-1}
+            int i = 0;
+            for (int a = 0; a < m; a++) {
+                const int len = total / m + (a < total % m ? 1 : 0);
+                rc.arc_len.push_back(len);
+                for (int t = 0; t < len + b; t++, i++) { elim[i] = i; brow[i] = row++; }
+            }
+            for (int t = 0; t < b; t++) brow2[R - b + t] = base + t;       // S_{m-1} = the last b block rows of the ring
+            rings->push_back(rc);
+            base += R + b;
+        } else if (twist_ok && R >= 3 * b + 2 && R < BAND_CUT_MIN_ROWS) {
+            comp_twist[k] = 1;
+            const int m0 = (R - b) / 2, m1 = R - b - m0;
+            for (int i = 0; i < m0; i++) { elim[i] = i; brow[i] = base + i; }
+            for (int t = 0; t < b; t++) { elim[m0 + t] = m0 + m1 + t; brow[m0 + t] = base + m0 + t; brow2[m0 + t] = base + m0 + b + m1 + (b - 1 - t); }
+            for (int u = 0; u < m1; u++) { elim[m0 + b + u] = m0 + (m1 - 1 - u); brow[m0 + b + u] = base + m0 + b + (m1 - 1 - u); }
+            base += R + b;
+        } else {
+            for (int i = 0; i < R; i++) { elim[i] = i; brow[i] = base + i; }
+            base += R;
+        }
+        for (int i = 0; i < n; i++) {
+            const int c = seq[k][i], r = i / W, par = i - r * W;
+            key[c] = (long long)(ebase + elim[r]) * W + par;
+            band_row[c] = brow[r] * W + par;
+            if (brow2[r] >= 0) band_row2[c] = brow2[r] * W + par;
+        }
+        if (merge && (n & 1)) pair_dummy[seq[k][n - 1]] = 1;
+        ebase += R;
         new_ptr.push_back(base);
     }
     comp_ptr.swap(new_ptr); band_rows = base;
-}
-
-// Elimination order + band layout of the reduced camera system: Cuthill-McKee, then (3-dof blocks) merging of consecutive cameras into
-// 6x6 block rows, then the twisted layout of medium components (band_twist_plan), in block rows.
-//   out: pos (elimination order, a permutation), band (half-width in blocks), comp_ptr / band_rows (block rows), band_row / band_row2
-//        (camera rows), comp_twist, band_block, pair_dummy
-inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, std::vector<int>& pos, int& band,
-                      std::vector<int>& comp_ptr, std::vector<int>& band_row, std::vector<int>& band_row2, std::vector<char>& comp_twist,
-                      int& band_rows, int& band_block, std::vector<unsigned char>& pair_dummy) {
-    band = cuthill_mckee(Nc, row_ptr, col_idx, pos, &comp_ptr);
-    pair_dummy.assign(Nc, 0);
-    const char* env = std::getenv("SSFM_BAND_MERGE");
-    const bool merge = dc == 3 && !(env && env[0] == '0');
-    if (!merge) {
-        band_block = dc;
-        band_twist_plan(Nc, band, pos, comp_ptr, band_row, band_row2, comp_twist, band_rows, dc == 3 ? 40 : band_wide_max());
-        return;
-    }
-    // ---- super nodes = pairs of consecutive Cuthill-McKee positions inside a component
-    const int ncomp = (int)comp_ptr.size() - 1;
-    std::vector<int> sup(Nc), par(Nc), sup_ptr(1, 0);
-    {
-        std::vector<int> inv(Nc); for (int c = 0; c < Nc; c++) inv[pos[c]] = c;
-        for (int k = 0; k < ncomp; k++) {
-            const int c0 = comp_ptr[k], n = comp_ptr[k + 1] - c0, s0 = sup_ptr.back();
-            for (int i = 0; i < n; i++) { const int c = inv[c0 + i]; sup[c] = s0 + i / 2; par[c] = i & 1; }
-            if (n & 1) pair_dummy[inv[c0 + n - 1]] = 1;
-            sup_ptr.push_back(s0 + (n + 1) / 2);
-        }
-    }
-    const int ns = sup_ptr.back();
-    int bs = 0;
-    for (int u = 0; u < Nc; u++) for (int e = row_ptr[u]; e < row_ptr[u + 1]; e++) bs = std::max(bs, std::abs(sup[u] - sup[col_idx[e]]));
-    bs = std::max(bs, 1);
-    std::vector<int> spos(ns), srow, srow2;
-    for (int i = 0; i < ns; i++) spos[i] = i;
-    band_twist_plan(ns, bs, spos, sup_ptr, srow, srow2, comp_twist, band_rows, band_wide_max());
-    // cameras: elimination key 2 * spos + parity, compressed to a permutation
-    std::vector<int> key(Nc), order(Nc);
-    for (int c = 0; c < Nc; c++) { key[c] = 2 * spos[sup[c]] + par[c]; order[c] = c; }
+    // cameras: elimination keys compressed to a permutation
+    std::vector<int> order(Nc); for (int c = 0; c < Nc; c++) order[c] = c;
     std::sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
     for (int r = 0; r < Nc; r++) pos[order[r]] = r;
-    band_row.assign(Nc, -1); band_row2.assign(Nc, -1);
-    for (int c = 0; c < Nc; c++) { band_row[c] = 2 * srow[sup[c]] + par[c]; if (srow2[sup[c]] >= 0) band_row2[c] = 2 * srow2[sup[c]] + par[c]; }
-    band = bs; comp_ptr.swap(sup_ptr); band_block = 6;
+}
+
+// Coupling blocks between A_0 and S_{m-1} of a ring: S stores them in the row of the separator camera (it is eliminated later), the band wants them in the row of
+// the A_0 camera, relative to the copy slot in front of it, TRANSPOSED.  Per camera c2 the list of (stored block of S, band row of the copy of its row camera).
+// Needs the lower-triangle structure (row_ptr / col_idx by elimination order) and band_row / band_row2.
+// (a camera of S_{m-1} is recognised by its second band row lying IN FRONT of its first: the copies of twisted separators lie behind)
+inline void ring_wrap_table(int Nc, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, const std::vector<int>& band_row, const std::vector<int>& band_row2,
+                            int band, int W, std::vector<int>& wrap_ptr, std::vector<int>& wrap_blk, std::vector<int>& wrap_row2) {
+    wrap_ptr.assign(Nc + 1, 0); wrap_blk.clear(); wrap_row2.clear();
+    std::vector<std::vector<std::pair<int, int>>> per(Nc);
+    for (int c = 0; c < Nc; c++) {
+        const int i2 = band_row2[c];
+        if (i2 < 0 || i2 >= band_row[c]) continue;
+        for (int e = row_ptr[c]; e < row_ptr[c + 1]; e++) {
+            const int c2 = col_idx[e], k = band_row[c2];
+            if (c2 != c && k / W > i2 / W && k / W - i2 / W <= band && band_row[c] / W - k / W > band) per[c2].push_back({e, i2});
+        }
+    }
+    for (int c = 0; c < Nc; c++) { for (auto& pr : per[c]) { wrap_blk.push_back(pr.first); wrap_row2.push_back(pr.second); } wrap_ptr[c + 1] = (int)wrap_blk.size(); }
 }
 
 // ---- Schur pair lists ---------------------------------------------------------------------------------------------------------
@@ -653,7 +764,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         for (int c = 0; c < Nc; c++) if (cam_in[c] && !(P.trans_fixed && P.trans_fixed[c])) { all_t_fixed = false; break; }
         F.DC = all_t_fixed ? 3 : 6;
     }
-    band_plan(Nc, F.DC, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy);
+    band_plan(Nc, F.DC, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy, &F.rings);
     for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
     {   // keep the lower triangle (in elimination order) only
         std::vector<int> rp(Nc + 1, 0), ci; ci.reserve(F.col_idx.size() / 2 + Nc);
@@ -671,6 +782,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         F.trans_ptr = cnt; F.trans_blk.resize(cnt[Nc]); F.trans_row.resize(cnt[Nc]);
         std::vector<int> fill(cnt.begin(), cnt.end() - 1);
         for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) if (F.col_idx[e] != c) { const int k = fill[F.col_idx[e]]++; F.trans_blk[k] = e; F.trans_row[k] = c; }
+        if (!F.rings.empty()) ring_wrap_table(Nc, F.row_ptr, F.col_idx, F.band_row, F.band_row2, F.band, F.band_block == 6 && F.DC == 3 ? 2 : 1, F.wrap_ptr, F.wrap_blk, F.wrap_row2);
     }
     lap("ordering + lower triangle");
     F.mask_cam.assign((size_t)Nc * 6, 0.0);

@@ -14,6 +14,7 @@
 #include "band_kernels2.h"
 #include "band_kernels2p.h"
 #include "band_sub.h"
+#include "band_ring.h"
 #include "ssfm_ctx.h"
 
 namespace ssfm {
@@ -22,13 +23,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back"};
 
 // SSFM_PLAN_TIMING: time spent in hipMalloc (atomic: the observation arrays are allocated by the upload thread of ba_create_impl while the main thread plans)
 static bool g_alloc_timing = false; static std::atomic<long long> g_alloc_ns{0}; static std::atomic<int> g_alloc_n{0};
@@ -90,6 +91,9 @@ struct ssfm_ba_handle {
     DevBuf<int> cam_pos2;                // second band row of the separator cameras of twisted components (-1 elsewhere); cam_pos holds BAND ROWS
     DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags, sub_fz_lo, sub_fz_hi, sub_fz_wend, sub_fz_merge, sub_fz_await, sub_fz_signal, sub_fz_flags; int sub_seq = 0, sub_fz_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
     DevBuf<int> col_pos, trans_pos;      // band row of the column camera of every stored / transposed block (k_arrow_update)
+    // rings (round 5, band_ring.h): wrap table of the gather kernels, cyclic-reduction schedule, per-separator factor / coupling / right-hand-side blocks
+    DevBuf<int> wrap_ptr, wrap_blk, wrap_row2, ring_rec, ring_pend; DevBuf<double> crL, crF, crW;
+    const int* wrap_ptr_p() const { return wrap_ptr.n ? wrap_ptr.p : nullptr; }
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
@@ -132,6 +136,7 @@ struct ssfm_ba_handle {
         col_pos.free(); trans_pos.free(); trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         pub_ticket.free(); gr_rec.free(); pt_grouped.free();
+        wrap_ptr.free(); wrap_blk.free(); wrap_row2.free(); ring_rec.free(); ring_pend.free(); crL.free(); crF.free(); crW.free();
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
         host_pub = nullptr;
@@ -234,7 +239,8 @@ static int wait_published(ssfm_ba_handle* h) {
 static int sub_upload(ssfm_ba_handle* h, int DC) {
     ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream; const BAFlat& F = h->F;
     if (F.band_block > 0) DC = F.band_block;                     // block size of the band (merged 3-dof pairs: 6)
-    sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub);
+    sub_build(F.comp_ptr, F.comp_twist, F.band, DC, h->sub, &F.rings);
+    if (!F.wrap_ptr.empty()) { SSFM_HIP_CHECK(ctx, upload(h->wrap_ptr, F.wrap_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->wrap_blk, F.wrap_blk, st)); SSFM_HIP_CHECK(ctx, upload(h->wrap_row2, F.wrap_row2, st)); }
     if (!h->sub.enabled) return SSFM_OK;
     const BandSub& B = h->sub; const size_t Q = (size_t)F.band * DC, n = (size_t)(F.band_rows > 0 ? F.band_rows : F.Nc) * DC;
     SSFM_HIP_CHECK(ctx, upload(h->sub_tw_lo, B.tw_lo, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_hi, B.tw_hi, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_tw_copy, B.tw_copy, st)); SSFM_HIP_CHECK(ctx, upload(h->sub_seg_given, B.seg_given, st));
@@ -257,6 +263,10 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     SSFM_HIP_CHECK(ctx, h->subF.alloc((size_t)(B.nsep + B.nchain) * Q * Q)); SSFM_HIP_CHECK(ctx, h->subL.alloc((size_t)B.nsep * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subW.alloc((size_t)B.nsep * 2 * Q));
     SSFM_HIP_CHECK(ctx, h->subC.alloc((size_t)B.nchain * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subTc.alloc((size_t)B.nchain * 2 * Q)); SSFM_HIP_CHECK(ctx, h->sub_flags.alloc((size_t)2 * B.nchain));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->sub_flags.p, 0, (size_t)2 * B.nchain * sizeof(int), st)); h->sub_seq = 0;
+    if (B.nring > 0) {
+        SSFM_HIP_CHECK(ctx, upload(h->ring_rec, B.ring_rec, st)); SSFM_HIP_CHECK(ctx, upload(h->ring_pend, B.ring_pend, st));
+        SSFM_HIP_CHECK(ctx, h->crL.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->crF.alloc((size_t)B.nsep * 2 * Q * Q)); SSFM_HIP_CHECK(ctx, h->crW.alloc((size_t)B.nsep * 2 * Q));
+    }
     return SSFM_OK;
 }
 
@@ -375,6 +385,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
                 h->span_end();
                 }
+                if (B.nchain > 0) {
                 if (chain_mfma) {
                     // SSFM_CHAIN_STAMPS=1: s_memtime stamps of the phases of one separator, printed once (profiles/*_notes.md)
                     static long long* d_stamps = nullptr; static int stamp_state = std::getenv("SSFM_CHAIN_STAMPS") ? 1 : 0;
@@ -407,6 +418,19 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     }
                 }
                 else LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
+                }
+                if (B.nring > 0) {
+                    // rings (band_ring.h): the separator cycles by cyclic reduction, one launch per step down and one per step back up
+                    const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2);
+                    if (le > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_elim<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le));
+                    if (lb > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_back<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                    const int nsteps = (int)B.ring_step_ptr.size() - 1;
+                    for (int sidx = 0; sidx < nsteps; sidx++)
+                        LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], 1024, le, h->ring_rec.p, h->ring_pend.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
+                               h->crL.p, h->crF.p, h->crW.p, Nc, b, failp);
+                    for (int sidx = nsteps - 1; sidx >= 0; sidx--)
+                        LAUNCH(h, KID_RING_BACK, (k_ring_cr_back<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], 256, lb, h->ring_rec.p, B.ring_step_ptr[sidx], h->crL.p, h->crF.p, h->crW.p, Y, Nc, b);
+                }
             }
             // EXPERIMENT, off (SSFM_BACK_FUSE=1): the separator of a twisted component back-substituted by the two segment waves themselves (k_band_back_v2's modes 1 / 2) instead
             // of by a launch of its own.  Measured at config 2 (scripts/lab/ab_backfuse.sh): one launch of 23.2-23.8 us against two of 12.1-12.6 (event brackets), 2.545-2.555 against
@@ -531,8 +555,8 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
     // the band may use bigger blocks than S (two 3-dof cameras per 6x6 block row, ba_flatten.h: band_plan)
     const bool merged = F.band_block > 0 && F.band_block != DC;
     auto gather = [&]() {
-        if (merged) LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, b, h->band.p);
-        else LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, (const unsigned char*)nullptr, Nc, b, h->band.p);
+        if (merged) LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, b, h->band.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
+        else LAUNCH(h, KID_BAND_GATHER, (k_band_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->S_val, h->cam_pos.p, h->cam_pos2.p, (const unsigned char*)nullptr, Nc, b, h->band.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
     };
     auto direct = [&](double* Y) -> int { return merged ? band_direct<6>(h, Y) : band_direct<DC>(h, Y); };
     if (stage == 0) {

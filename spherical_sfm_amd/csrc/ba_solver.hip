@@ -211,10 +211,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             if (F.band_block != DC)      // 3-dof cameras merged in pairs into 6x6 block rows of the band
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
             else
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -469,7 +469,7 @@ extern "C" int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t ra
     info->camera_dof = F.DC; info->num_points_used = F.nP; info->num_points_used_global = F.nP_global;
     info->reduced_blocks = F.row_ptr[F.Nc]; info->band_half_width = F.band; info->max_row_blocks = F.max_row_blocks;
     info->num_observations_used = F.M; info->num_observations_used_global = F.M_global;
-    { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.band_block, B);
+    { BandSub B; sub_build(F.comp_ptr, F.comp_twist, F.band, F.band_block, B, &F.rings);
       info->band_segments = B.enabled ? B.nseg : (int)F.comp_ptr.size() - 1; info->band_separators = B.nsep + B.ntwist; }
     info->num_points_grouped = F.gram_points; info->num_observations_grouped = F.gram_obs; info->group_tasks = (int32_t)(F.gr_rec.size() / GRAM_REC);
     if (point_ids) for (int i = 0; i < F.nP; i++) point_ids[i] = F.pt_ids[i];

@@ -86,6 +86,23 @@ __device__ __forceinline__ void band_rows_scatter(const int* __restrict__ row_pt
         }
     }
 }
+// Round 5, rings (ba_flatten.h: band_plan, ring_wrap_table): the coupling blocks between the first arc of a ring and its LAST separator are stored in S in the row of
+// the separator camera (it is eliminated later), but the band wants them in the row of the arc camera c, relative to the separator's copy slot in front of the arc:
+// (band row of c) - (copy row of the row camera) = d <= b, the block TRANSPOSED.  Camera c's own workgroup places them (its row was zeroed by itself).
+template <int DC, bool MERGE>
+__device__ __forceinline__ void band_rows_wrap(const int* __restrict__ wrap_ptr, const int* __restrict__ wrap_blk, const int* __restrict__ wrap_row2,
+                                               const double* __restrict__ S_val, int i, int c, int b, double* __restrict__ band) {
+    constexpr int BB = DC * DC;
+    const int w0 = wrap_ptr[c], nw = wrap_ptr[c + 1] - w0, tid = threadIdx.x, W = b + 1;
+    for (int idx = tid; idx < nw * BB; idx += blockDim.x) {
+        const int q = w0 + idx / BB, e = idx % BB, a = e / DC, a2 = e - a * DC;     // S block (row camera components a, this camera's components a2)
+        const double val = S_val[(size_t)wrap_blk[q] * BB + e];
+        const int k = wrap_row2[q];
+        if (!MERGE) band[((size_t)i * W + (i - k)) * BB + a2 * DC + a] = val;
+        else { constexpr int BM = 4 * BB, D2 = 2 * DC; const int R = i >> 1, u = i & 1, C = k >> 1, v = k & 1;
+               band[((size_t)R * W + (R - C)) * BM + (u * DC + a2) * D2 + v * DC + a] = val; }
+    }
+}
 template <int DC, bool MERGE>
 __device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
                                                const int* __restrict__ pos, int i, int i2, int c, int b, bool dummy, double* __restrict__ band) {
@@ -98,9 +115,11 @@ __device__ __forceinline__ void band_rows_fill(const int* __restrict__ row_ptr, 
 template <int DC, bool MERGE>
 __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val,
                               const int* __restrict__ pos, const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nc, int b,
-                              double* __restrict__ band) {
+                              double* __restrict__ band, const int* __restrict__ wrap_ptr = nullptr, const int* __restrict__ wrap_blk = nullptr,
+                              const int* __restrict__ wrap_row2 = nullptr) {
     const int c = blockIdx.x;
     band_rows_fill<DC, MERGE>(row_ptr, col_idx, S_val, pos, pos[c], pos2 ? pos2[c] : -1, c, b, pair_dummy && pair_dummy[c], band);
+    if (wrap_ptr) band_rows_wrap<DC, MERGE>(wrap_ptr, wrap_blk, wrap_row2, S_val, pos[c], c, b, band);
 }
 // k_finalize_S + k_band_gather + k_band_permute_rhs in one launch for the BA path with the banded preconditioner (one workgroup per
 // camera, which owns its diagonal block, its band row and its slice of the right-hand sides): LM diagonal on the diagonal block
@@ -114,7 +133,8 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
                   const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs,
                   const double* __restrict__ Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal,
-                  double2* __restrict__ clear = nullptr, size_t clear_len2 = 0, const int* __restrict__ col_pos = nullptr) {
+                  double2* __restrict__ clear = nullptr, size_t clear_len2 = 0, const int* __restrict__ col_pos = nullptr,
+                  const int* __restrict__ wrap_ptr = nullptr, const int* __restrict__ wrap_blk = nullptr, const int* __restrict__ wrap_row2 = nullptr) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
     // the accumulation zone of the NEXT iteration (nothing has read it since the iteration before this one ended) is cleared here, a slice
@@ -139,6 +159,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
     if (tid < 64) { gmax = wave_max(gmax); if (tid == 0 && gmax > 0.0) atomic_max_nonneg(&scal[(size_t)(c & (SC_NSLOT - 1)) * SC_TOTAL + SC_GMAX], gmax); }
     __syncthreads();                                               // damped diagonal block visible to the whole workgroup
     band_rows_scatter<DC, MERGE>(row_ptr, col_idx, S_val, pos, i, i2, c, b, band, col_pos);
+    if (wrap_ptr) band_rows_wrap<DC, MERGE>(wrap_ptr, wrap_blk, wrap_row2, S_val, i, c, b, band);
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;
         const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;

@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include <vector>
 #include "band_kernels2.h"
+#include "ring_comp.h"
+#include "ring_schedule.h"
 
 namespace ssfm {
 
@@ -39,6 +41,12 @@ struct BandSub {
     // fused launches (segments + the twisted separators that wait for them): tables over nseg + ntwist workgroups; flag 2t / 2t+1 = the halves of twisted component t
     std::vector<int> seg_twist;                     // per segment: 2t + half of the twisted component it belongs to, else -1
     std::vector<int> fz_lo, fz_hi, fz_wend, fz_merge, fz_await, fz_signal;
+    // rings (round 5, band_ring.h): arcs are segments, their separators a cycle solved by cyclic reduction.  sep_copy: first band row of a separator's copy slot (the
+    // last separator of a ring is also "in front of" its first arc) or -1; ring_seps: (first separator id, cuts) per ring; the schedule: RING_REC ints per elimination,
+    // eliminations of step s = records [ring_step_ptr[s], ring_step_ptr[s + 1]), ring_pend = (separator, slot) pairs of the pending Schur updates
+    int nring = 0;
+    std::vector<int> sep_copy; std::vector<std::pair<int, int>> ring_seps;
+    std::vector<int> ring_rec, ring_step_ptr, ring_pend;
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
@@ -60,14 +68,32 @@ inline int sub_choose_segments(int rows, int b, int dc) {
     return best;
 }
 
-inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>& comp_twist, int b, int dc, BandSub& S) {
+inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>& comp_twist, int b, int dc, BandSub& S, const std::vector<RingComp>* rings = nullptr) {
     S = BandSub();
     const char* env = std::getenv("SSFM_BAND_SEGMENTS");               // 1 = never cut; P >= 2 = cut every component that can take it into P
     const int forced = env ? std::atoi(env) : 0;
     const bool can_cut = b >= 1 && b * dc <= 114 && forced != 1;       // separator blocks must fit the chain kernel's LDS (see k_sub_sep_chain)
     S.chain_ptr.assign(1, 0);
+    for (int pass = 0; pass < 2; pass++)                               // rings last: the separators of a chain are a contiguous range of ids (chain_ptr)
     for (size_t c = 0; c + 1 < comp_ptr.size(); c++) {
         const int c0 = comp_ptr[c], rows = comp_ptr[c + 1] - c0;
+        const RingComp* ring = nullptr;
+        if (rings) for (const RingComp& rc : *rings) if (rc.comp == (int)c) ring = &rc;
+        if ((ring != nullptr) != (pass == 1)) continue;
+        if (ring) {                                                    // rows = n + b: copy of S_{m-1} | A_0 | S_0 | ... | A_{m-1} | S_{m-1}   (ba_flatten.h: band_plan)
+            const int m = (int)ring->arc_len.size(), seg0 = (int)S.seg_lo.size(), sep0 = (int)S.sep_lo.size();
+            int pos = c0 + b;
+            for (int k = 0; k < m; k++) {
+                S.left_segs.push_back((int)S.seg_lo.size());
+                S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + ring->arc_len[k]); S.seg_wend.push_back(pos + ring->arc_len[k] + b); S.seg_given.push_back(-1); S.seg_twist.push_back(-1);
+                pos += ring->arc_len[k];
+                S.sep_lo.push_back(pos); S.sep_rseg.push_back(seg0 + (k + 1) % m); S.sep_copy.push_back(k == m - 1 ? c0 : -1);
+                pos += b;
+            }
+            S.ring_seps.push_back({sep0, m}); S.nring++;
+            S.enabled = true;
+            continue;
+        }
         if (c < comp_twist.size() && comp_twist[c]) {                  // rows = n + b: seg_0 | sep | seg_1 reversed | copy of sep
             const int n = rows - b, m0 = (n - b) / 2, m1 = n - b - m0, t2 = 2 * (int)S.tw_lo.size();
             S.seg_lo.push_back(c0); S.seg_hi.push_back(c0 + m0); S.seg_wend.push_back(c0 + m0 + b); S.seg_given.push_back(-1); S.seg_twist.push_back(t2);
@@ -86,13 +112,14 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
             if (i > 0) S.left_segs.push_back((int)S.seg_lo.size());
             S.seg_lo.push_back(pos); S.seg_hi.push_back(pos + m); S.seg_wend.push_back(i + 1 < P ? pos + m + b : pos + m); S.seg_given.push_back(-1); S.seg_twist.push_back(-1);
             pos += m;
-            if (i + 1 < P) { S.sep_lo.push_back(pos); S.sep_rseg.push_back((int)S.seg_lo.size()); pos += b; }
+            if (i + 1 < P) { S.sep_lo.push_back(pos); S.sep_rseg.push_back((int)S.seg_lo.size()); S.sep_copy.push_back(-1); pos += b; }
         }
         if (P > 1) { S.enabled = true; S.chain_ptr.push_back((int)S.sep_lo.size()); }
     }
     S.nseg = (int)S.seg_lo.size(); S.nsep = (int)S.sep_lo.size(); S.nchain = (int)S.chain_ptr.size() - 1; S.nleft = (int)S.left_segs.size();
     S.ntwist = (int)S.tw_lo.size();
     if (!S.enabled) { S = BandSub(); return; }
+    if (S.nring > 0) ring_schedule(S.ring_seps, S.sep_lo, S.sep_copy, S.ring_rec, S.ring_step_ptr, S.ring_pend);
     S.fz_lo = S.seg_lo; S.fz_hi = S.seg_hi; S.fz_wend = S.seg_wend; S.fz_merge.assign(S.nseg, -1); S.fz_await.assign(S.nseg, -1); S.fz_signal = S.seg_twist;
     for (int t = 0; t < S.ntwist; t++) { S.fz_lo.push_back(S.tw_lo[t]); S.fz_hi.push_back(S.tw_hi[t]); S.fz_wend.push_back(S.tw_hi[t]); S.fz_merge.push_back(S.tw_copy[t]); S.fz_await.push_back(2 * t); S.fz_signal.push_back(-1); }
 }

@@ -579,8 +579,9 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         for (int i = 0; i < n; i++) { std::copy(nb[i].begin(), nb[i].end(), F.col_idx.begin() + F.row_ptr[i]);
                                       F.diag_slot[i] = (int)(std::lower_bound(nb[i].begin(), nb[i].end(), i) - nb[i].begin()); }
         // Cuthill-McKee, pairs of nodes merged into 6x6 block rows, rings of a video pose graph eliminated from both ends
-        band_plan(n, 3, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy);
+        band_plan(n, 3, F.row_ptr, F.col_idx, F.cam_pos, F.band, F.comp_ptr, F.band_row, F.band_row2, F.comp_twist, F.band_rows, F.band_block, F.pair_dummy, &F.rings);
         for (int ir = 1; ir <= F.band; ir++) for (int kr = 1; kr <= ir; kr++) F.band_pairs.push_back(ir | (kr << 16));
+        if (!F.rings.empty()) ring_wrap_table(n, F.row_ptr, F.col_idx, F.band_row, F.band_row2, F.band, F.band_block == 6 ? 2 : 1, F.wrap_ptr, F.wrap_blk, F.wrap_row2);
     }
     lap("S structure + band plan");
     const size_t nn = (size_t)3 * n, nnzb = (size_t)F.row_ptr[n];
@@ -689,10 +690,12 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         if (O.preconditioner == 0 && fused_finalize) {
             if (F.band_block != 3)
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<3, true>), n, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal, O.max_lm_diagonal,
-                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p,
+                       (double2*)nullptr, (size_t)0, (const int*)nullptr, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
             else
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<3, false>), n, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal, O.max_lm_diagonal,
-                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p);
+                       n, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(3), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p,
+                       (double2*)nullptr, (size_t)0, (const int*)nullptr, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
             h->band_filled = true;
         } else
         LAUNCH(h, KID_FINALIZE, k_finalize_S<3>, gn, 64, 0, h->row_ptr.p, h->diag_slot.p, sc6.p, scf.p, h->Udiag, h->rhs, radius, O.min_lm_diagonal,

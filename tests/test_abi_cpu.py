@@ -186,6 +186,7 @@ def test_band_segment_plan_matches_reference_partition(monkeypatch):
     from spherical_sfm_amd import ba, synth
     p = synth.make_circle(1000, 4000, 6, spherical=False, focal_fixed=True)          # stride 13, coprime with 1000: one ring of 1000
     monkeypatch.delenv("SSFM_BAND_SEGMENTS", raising=False)
+    monkeypatch.setenv("SSFM_RING", "0")                                             # the Cuthill-McKee fold cut into a chain (rounds 1-4; rings: test_ring_layout_of_long_rings)
     info, _, _, pos = ba.plan(p)
     assert info["band_separators"] >= 3 and info["band_segments"] == info["band_separators"] + 1        # cut without being asked
     b = info["band_half_width"]
@@ -206,15 +207,51 @@ def test_band_segment_plan_matches_reference_partition(monkeypatch):
     assert (small["band_segments"], small["band_separators"]) == (8, 4)
 
 
-def test_ring_components_fold_to_twice_their_reach():
+def test_ring_components_fold_to_twice_their_reach(monkeypatch):
     """Camera ordering (csrc/ba_flatten.h: cuthill_mckee): a ring whose cameras share points with their +-r neighbours is a periodic band of
     half-width r; folded into a plain band it cannot be narrower than 2 r, and the planner reaches that (the root's children go closest first)."""
     for nc, k, reach in ((300, 6, 5), (75, 6, 5), (60, 6, 5), (500, 6, 5), (4000, 8, 7)):
         p = synth.make_circle(nc, 2000 if nc < 1000 else 16000, k, spherical=False, focal_fixed=True)
+        if nc >= 1000: monkeypatch.setenv("SSFM_RING", "0")                           # long rings are no longer folded by default (next test)
         info = ba.plan(p)[0]
         assert info["band_half_width"] == 2 * reach, (nc, k, info["band_half_width"])
+    monkeypatch.delenv("SSFM_RING", raising=False)
     p = synth.make_circle(300, 2000, 6, spherical=True, focal_fixed=True)      # 3-dof cameras: pairs merged into 6x6 band blocks
     assert ba.plan(p)[0]["band_half_width"] == 5
+
+
+def test_ring_layout_of_long_rings(monkeypatch):
+    """Round 5 (csrc/ba_flatten.h: band_plan, RingComp): a long camera ring is laid out in its own circular order -- a periodic band of half-width = its reach, HALF of
+    what the Cuthill-McKee fold needs -- as  copy of S_{m-1} | A_0 | S_0 | ... | A_{m-1} | S_{m-1}:  m arcs (segments) and m separators of `reach` block rows.
+    The circular order is found from the graph (ids strided as in SURVEY 8d's circle: a walk round the ring) or is the id order (video-like tracks with a loop closure)."""
+    monkeypatch.delenv("SSFM_RING", raising=False); monkeypatch.delenv("SSFM_RING_CUTS", raising=False)
+    # (cameras, points, K, spherical) -> reach in block rows
+    for nc, npts, k, sph, reach, rings in ((1000, 4000, 6, False, 5, 1), (4000, 16000, 8, False, 7, 2), (4000, 16000, 8, True, 4, 2)):
+        p = synth.make_circle(nc, npts, k, spherical=sph, focal_fixed=True)
+        info, _, _, pos = ba.plan(p)
+        assert info["band_half_width"] == reach and sorted(pos.tolist()) == list(range(nc))
+        assert info["band_segments"] == info["band_separators"] and info["band_segments"] >= 2 * rings          # a cycle: as many separators as arcs
+        # the elimination order is the circular order: coupled cameras are within `reach` block rows of each other, modulo the ring
+        cams = p.obs_cam.reshape(-1, k); w = 2 if sph else 1
+        ring_of = np.zeros(nc, int); rows = nc // rings // w
+        order = np.argsort(pos); ring_of[order] = np.arange(nc) // (nc // rings)                              # rings are consecutive position ranges
+        a = pos[cams][:, :, None] // w; c = pos[cams][:, None, :] // w
+        d = np.abs(a - c); d = np.minimum(d, rows - d)
+        assert d.max() == reach and (ring_of[cams] == ring_of[cams][:, :1]).all()
+    # forced number of cuts; video-like ragged tracks (ids in circular order already, a band too wide for the LDS window when folded)
+    monkeypatch.setenv("SSFM_RING_CUTS", "4")
+    info = ba.plan(synth.make_circle(1000, 4000, 6, spherical=False, focal_fixed=True))[0]
+    assert (info["band_segments"], info["band_separators"]) == (4, 4)
+    monkeypatch.delenv("SSFM_RING_CUTS")
+    rag = synth.make_ragged_circle(300, 60000, 3, 14)
+    info = ba.plan(rag)[0]
+    assert info["band_half_width"] == 13 and info["band_segments"] == info["band_separators"] >= 2
+    monkeypatch.setenv("SSFM_RING", "0")
+    assert ba.plan(rag)[0]["band_half_width"] == 26
+    monkeypatch.delenv("SSFM_RING")
+    # short rings stay folded and twisted (config 2: four rings of 75)
+    info = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))[0]
+    assert info["band_half_width"] == 10 and (info["band_segments"], info["band_separators"]) == (8, 4)
 
 
 def test_planner_pool_survives_fork():

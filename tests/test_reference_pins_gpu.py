@@ -73,7 +73,9 @@ def test_lomsac_trace_equals_the_reference_ransaclib_runs(gpu_ctx):
         out = ransac.estimate_pairs(gpu_ctx, [(u, v)], THR, seed=int(g["pair_seed"][k]), min_num_inliers=0, **dev)
         same = (out["iterations"][0] == g["pair_iterations"][k] and out["lo_runs"][0] == g["pair_lo_runs"][k]
                 and out["num_inliers"][0] == g["pair_num_inliers"][k] and np.array_equal(out["inliers"][0], g["pair_mask"][ptr[k]:ptr[k + 1]]))
-        close = (not same) or g["pair_num_inliers"][k] == 0 or _sign_dist(out["E"][0], g["pair_E"][k]) <= 1e-8
+        # (the model itself is compared where the data determine it: with 3..5 rays the six-parameter least-squares fit that ends the run is under-determined and
+        #  its answer is set by the Levenberg-Marquardt damping alone -- there the trace, the inlier flags and the score are the statement)
+        close = (not same) or g["pair_num_inliers"][k] == 0 or len(u) <= 5 or _sign_dist(out["E"][0], g["pair_E"][k]) <= 1e-8
         (lo if dev["num_lo_steps"] > 0 else plain).append(same and close)
         if dev["num_lo_steps"] == 0:
             assert same and close, (k, kw, out["iterations"][0], g["pair_iterations"][k], out["num_inliers"][0], g["pair_num_inliers"][k])
