@@ -23,13 +23,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_RING_TAIL, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back", "k_ring_cr_tail"};
 
 // SSFM_PLAN_TIMING: time spent in hipMalloc (atomic: the observation arrays are allocated by the upload thread of ba_create_impl while the main thread plans)
 static bool g_alloc_timing = false; static std::atomic<long long> g_alloc_ns{0}; static std::atomic<int> g_alloc_n{0};
@@ -92,7 +92,7 @@ struct ssfm_ba_handle {
     DevBuf<double> subZ, subD, subT, subF, subL, subW, subC, subTc; DevBuf<int> sub_flags, sub_fz_lo, sub_fz_hi, sub_fz_wend, sub_fz_merge, sub_fz_await, sub_fz_signal, sub_fz_flags; int sub_seq = 0, sub_fz_seq = 0;      // subC / subTc / flags: the two-sided chain's hand-over (band_sub.h 4b)
     DevBuf<int> col_pos, trans_pos;      // band row of the column camera of every stored / transposed block (k_arrow_update)
     // rings (round 5, band_ring.h): wrap table of the gather kernels, cyclic-reduction schedule, per-separator factor / coupling / right-hand-side blocks
-    DevBuf<int> wrap_ptr, wrap_blk, wrap_row2, ring_rec, ring_pend; DevBuf<double> crL, crF, crW;
+    DevBuf<int> wrap_ptr, wrap_blk, wrap_row2, ring_rec, ring_tail; DevBuf<double> crL, crF, crW, crP, crT, crE;
     const int* wrap_ptr_p() const { return wrap_ptr.n ? wrap_ptr.p : nullptr; }
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
@@ -136,7 +136,7 @@ struct ssfm_ba_handle {
         col_pos.free(); trans_pos.free(); trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         pub_ticket.free(); gr_rec.free(); pt_grouped.free();
-        wrap_ptr.free(); wrap_blk.free(); wrap_row2.free(); ring_rec.free(); ring_pend.free(); crL.free(); crF.free(); crW.free();
+        wrap_ptr.free(); wrap_blk.free(); wrap_row2.free(); ring_rec.free(); ring_tail.free(); crL.free(); crF.free(); crW.free(); crP.free(); crT.free(); crE.free();
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
         host_pub = nullptr;
@@ -264,8 +264,9 @@ static int sub_upload(ssfm_ba_handle* h, int DC) {
     SSFM_HIP_CHECK(ctx, h->subC.alloc((size_t)B.nchain * Q * (Q + 1) / 2)); SSFM_HIP_CHECK(ctx, h->subTc.alloc((size_t)B.nchain * 2 * Q)); SSFM_HIP_CHECK(ctx, h->sub_flags.alloc((size_t)2 * B.nchain));
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->sub_flags.p, 0, (size_t)2 * B.nchain * sizeof(int), st)); h->sub_seq = 0;
     if (B.nring > 0) {
-        SSFM_HIP_CHECK(ctx, upload(h->ring_rec, B.ring_rec, st)); SSFM_HIP_CHECK(ctx, upload(h->ring_pend, B.ring_pend, st));
+        SSFM_HIP_CHECK(ctx, upload(h->ring_rec, B.ring_rec, st)); SSFM_HIP_CHECK(ctx, upload(h->ring_tail, B.ring_tail_ptr, st));
         SSFM_HIP_CHECK(ctx, h->crL.alloc((size_t)B.nsep * Q * Q)); SSFM_HIP_CHECK(ctx, h->crF.alloc((size_t)B.nsep * 2 * Q * Q)); SSFM_HIP_CHECK(ctx, h->crW.alloc((size_t)B.nsep * 2 * Q));
+        SSFM_HIP_CHECK(ctx, h->crP.alloc((size_t)B.nsep * 2 * Q * Q)); SSFM_HIP_CHECK(ctx, h->crT.alloc((size_t)B.nsep * 4 * Q)); SSFM_HIP_CHECK(ctx, h->crE.alloc((size_t)B.nsep * Q * Q));
     }
     return SSFM_OK;
 }
@@ -367,7 +368,14 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             int max_rows = 0; for (int sg : B.left_segs) max_rows = std::max(max_rows, (B.seg_hi[sg] - B.seg_lo[sg]) * DC);
             if (B.nsep > 0) {
                 h->span_begin(KID_SUB_SPIKE);
-                hipLaunchKernelGGL((k_sub_spike_fwd<DC>), dim3(B.nleft, (Q + SPIKE_NC - 1) / SPIKE_NC), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+                // columns per wave (band_sub.h 2): one while a step is bound by what a wave can issue (half-widths >= 10), more when the band is narrow and the launch is
+                // bound by the factor rows every column streams again
+                static const int spike_nc_env = std::getenv("SSFM_SPIKE_NC") ? std::atoi(std::getenv("SSFM_SPIKE_NC")) : 0;
+                const int spike_nc = spike_nc_env > 0 ? spike_nc_env : (b <= 8 ? 3 : 1);
+                if (spike_nc >= 4) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 4>), dim3(B.nleft, (Q + 3) / 4), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+                else if (spike_nc == 3) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 3>), dim3(B.nleft, (Q + 2) / 3), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+                else if (spike_nc == 2) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 2>), dim3(B.nleft, (Q + 1) / 2), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
+                else hipLaunchKernelGGL((k_sub_spike_fwd<DC, 1>), dim3(B.nleft, Q), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
                 h->span_end();
                 const int ntl = (Q + SUB_TS - 1) / SUB_TS;
                 const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
@@ -420,14 +428,19 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 else LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
                 }
                 if (B.nring > 0) {
-                    // rings (band_ring.h): the separator cycles by cyclic reduction, one launch per step down and one per step back up
-                    const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2);
+                    // rings (band_ring.h): the separator cycles by cyclic reduction -- one launch per parallel step down, ONE for the last few separators of every ring
+                    // (their eliminations, the roots, their back substitutions), one per parallel step back up
+                    const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2), lt = std::max(le, lb);
                     if (le > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_elim<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le));
                     if (lb > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_back<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                    if (lt > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_tail<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt));
                     const int nsteps = (int)B.ring_step_ptr.size() - 1;
+                    const int cr_threads = Q > 48 ? 1024 : 512;            // (rows of the tall factorisation: 3 Q + 2 <= 256 either way; fewer waves make cheaper barriers)
                     for (int sidx = 0; sidx < nsteps; sidx++)
-                        LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], 1024, le, h->ring_rec.p, h->ring_pend.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
-                               h->crL.p, h->crF.p, h->crW.p, Nc, b, failp);
+                        LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], cr_threads, le, h->ring_rec.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
+                               h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Nc, b, failp);
+                    LAUNCH(h, KID_RING_TAIL, (k_ring_cr_tail<DC, 2>), B.nring, cr_threads, lt, h->ring_rec.p, h->ring_tail.p, h->subZ.p, h->subD.p, h->subT.p,
+                           h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Y, Nc, b, failp);
                     for (int sidx = nsteps - 1; sidx >= 0; sidx--)
                         LAUNCH(h, KID_RING_BACK, (k_ring_cr_back<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], 256, lb, h->ring_rec.p, B.ring_step_ptr[sidx], h->crL.p, h->crF.p, h->crW.p, Y, Nc, b);
                 }

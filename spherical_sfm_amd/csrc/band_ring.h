@@ -12,14 +12,14 @@
 // Cyclic reduction: of the p separators still active (a cycle) every second one is eliminated at once -- each has two active neighbours u, w that are NOT eliminated
 // in the same step --, which couples u and w directly (fill) and leaves a cycle of ceil(p / 2); two nodes are eliminated one after the other, the last one is the
 // root.  Depth ceil(log2 m) + 2 instead of m / 2 + 2 for a chain taken from both ends, and every block is half the size of the folded chain's (2.5th power: 5.6x).
-// One node's elimination (one workgroup, k_ring_cr_elim), v with neighbours u_j:
-//     A   = D_v - sum over earlier eliminated neighbours x of F_{x,v} F_{x,v}^T          (the pending Schur updates of v, GATHERED: no atomics anywhere)
-//     t   = t_v - sum F_{x,v} w_x
-//     B_j = M[u_j][v]    = the original coupling E (from Z) and / or the fill -F_{x,u_j} F_{x,v}^T through an earlier eliminated x
+// One node's elimination (one workgroup, ring_elim_node), v with neighbours u_j:
+//     A   = D_v - PL[v] - PR[v]          PL / PR: the Schur updates earlier eliminations on v's left / right have left for it (each has ONE writer per step, steps are
+//     t   = t_v - tL[v] - tR[v]          launches: no atomics, a fixed order of every sum -- the replicated multi-rank solve relies on that)
+//     B_j = M[u_j][v]                    the original coupling E (from Z) and / or the fill an earlier elimination stored in ringE, either possibly transposed
 //     [A; B_0; B_1; t^T]  ->  tall right-looking Cholesky on the first Q columns:   L = chol(A),  F_j = B_j L^-T,  w = L^-1 t      (one pass: the B and t rows ride along as panel rows)
-// and on the way back (k_ring_cr_back):  x_v = L^-T (w - sum_j F_j^T x_{u_j}).
-// Every sum has a fixed order: the result does not depend on the schedule (the replicated multi-rank solve relies on that).
-// The products of two stored F blocks run on the matrix cores with the operands straight from global memory (v_mfma_f64_16x16x4, the layout of k_sub_sep_assemble_mfma).
+//     then, while F_0, F_1, w still sit in LDS, what the neighbours will need:  P{side}[u_j] (+)= F_j F_j^T,  t{side}[u_j] (+)= F_j w,  ringE[v] = -F_1 F_0^T
+//     (16x16 tiles of v_mfma_f64_16x16x4 with the operands read from LDS)
+// and on the way back (ring_back_node):  x_v = L^-T (w - sum_j F_j^T x_{u_j}).
 #pragma once
 #include "band_sub.h"
 #include "ring_schedule.h"
@@ -28,105 +28,65 @@ namespace ssfm {
 
 inline size_t ring_elim_lds_bytes(int Q, int NR) { return (size_t)(3 * Q + NR) * (size_t)(Q | 1) * sizeof(double); }
 
-// ---- elimination of one separator --------------------------------------------------------------------------------------------------------
-// one 16x16 tile of P R^T (P, R: [Q][Q] row-major in global memory), added to acc: lane (li, lk) loads P[r0 + li][k0 + 4 lk ..+3] and R[c0 + li][...] -- 32 contiguous
-// bytes per operand and trip -- and holds C[lk + 4 q][li] in acc[q] (the accumulator layout of v_mfma_f64_16x16x4, band_sub.h 3b)
-__device__ __forceinline__ v4d_t ring_tile_abt(const double* __restrict__ P, const double* __restrict__ R, int r0, int c0, int Q, int li, int lk, v4d_t acc) {
-    const double* pa = P + (size_t)min(r0 + li, Q - 1) * Q;
-    const double* pb = R + (size_t)min(c0 + li, Q - 1) * Q;
-    constexpr int DEPTH = 3;                                       // trips of 16 k in flight together
-    for (int k0 = 0; k0 < Q; k0 += 16 * DEPTH) {
-        double a[DEPTH][4], bb[DEPTH][4];
+// one 16x16 tile of P R^T with P, R = rows of the LDS matrix T (row stride LD, odd: the sixteen rows of an operand read fall into sixteen different banks); K = Q columns.
+// lane (li, lk) reads P[r0 + li][k0 + 4 lk .. + 3] and R[c0 + li][...] and holds C[lk + 4 q][li] in acc[q] (the layout of v_mfma_f64_16x16x4, band_sub.h 3b)
+__device__ __forceinline__ v4d_t ring_tile_lds(const double* __restrict__ P, const double* __restrict__ R, int r0, int c0, int Q, int LD, int li, int lk) {
+    const double* pa = P + (size_t)min(r0 + li, Q - 1) * LD;
+    const double* pb = R + (size_t)min(c0 + li, Q - 1) * LD;
+    v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < Q; k0 += 16) {
+        const int k = k0 + 4 * lk;
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const int k = k0 + 16 * d + 4 * lk;
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const bool in = k + u < Q; const int kk = in ? k + u : 0; const double av = pa[kk], bv = pb[kk]; a[d][u] = in ? av : 0.0; bb[d][u] = in ? bv : 0.0; }
+        for (int u = 0; u < 4; u++) {
+            const bool in = k + u < Q; const int kk = in ? k + u : 0;
+            const double av = pa[kk], bv = pb[kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? av : 0.0, in ? bv : 0.0, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][u], bb[d][u], acc, 0, 0, 0);
     }
     return acc;
 }
 
+// The elimination of one separator by the whole workgroup (blockDim.x threads, a multiple of 256; LDS: ring_elim_lds_bytes).  r = its record (ring_schedule.h).
 template <int DC, int NR>
-__global__ void __launch_bounds__(1024)
-k_ring_cr_elim(const int* __restrict__ rec, const int* __restrict__ pend, int rec0, const double* __restrict__ Z, const double* __restrict__ Dd,
-               const double* __restrict__ tt, double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, int N, int b, int* __restrict__ fail_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
+                                               double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT,
+                                               double* __restrict__ crE, const int N, const int b, int* __restrict__ fail_flag, double* __restrict__ T) {
     constexpr int NB = DC;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-    const int* r = rec + (size_t)(rec0 + blockIdx.x) * RING_REC;
-    const int v = r[0], nn = r[1], pl = r[2], ph = r[3];
-    double* T = lds;                                                // rows [0, Q): A; [Q + j Q, ..): B_j; [3 Q, 3 Q + NR): t^T
-    const size_t QQ = (size_t)Q * Q;
-    // ---- phase 0: D_v, the couplings that sit in Z, t_v
-    for (int e = tid; e < Q * Q; e += nt) {
-        const int i = e / Q, c = e - i * Q;
-        T[i * LD + c] = (c <= i) ? Dd[((size_t)v * Q + i) * Q + c] : 0.0;
+    const int v = r[0], nn = r[1], hasL = r[2], hasR = r[3];
+    const size_t QQ = (size_t)Q * Q;                              // T rows [0, Q): A; [Q + j Q, ..): B_j; [3 Q, 3 Q + NR): t^T
+    // ---- phase 0: everything this elimination reads from global memory, in one sweep of independent loads
+    {
+        const double* D = Dd + (size_t)v * QQ; const double* PL = crP + ((size_t)v * 2) * QQ; const double* PR = PL + QQ;
+        for (int e = tid; e < Q * Q; e += nt) {
+            const int i = e / Q, c = e - i * Q;
+            double val = 0.0;
+            if (c <= i) { val = D[e]; if (hasL) val -= PL[e]; if (hasR) val -= PR[e]; }
+            T[i * LD + c] = val;
+        }
+        for (int e = tid; e < NR * Q; e += nt) {
+            const int rr = e / Q, c = e - rr * Q;
+            double val = tt[(size_t)v * NR * Q + e];
+            if (hasL) val -= crT[((size_t)v * 2) * NR * Q + e];
+            if (hasR) val -= crT[((size_t)v * 2 + 1) * NR * Q + e];
+            T[(3 * Q + rr) * LD + c] = val;
+        }
         for (int j = 0; j < nn; j++) {
             const int* q = r + 8 + 16 * j;
-            double val = 0.0;
             for (int t = 0; t < q[2]; t++) {
-                const int* z = q + 4 + 6 * t;
-                if (z[0] == 0) val += z[2] ? Z[(size_t)i * n + (size_t)z[1] * DC + c] : Z[(size_t)c * n + (size_t)z[1] * DC + i];
-            }
-            T[(Q + j * Q + i) * LD + c] = val;
-        }
-    }
-    for (int e = tid; e < NR * Q; e += nt) { const int rr = e / Q, c = e - rr * Q; T[(3 * Q + rr) * LD + c] = tt[(size_t)v * NR * Q + e]; }
-    __syncthreads();
-    // ---- phase 1a: t -= F_{x,v} w_x over the pending updates, one wave per row, in list order
-    for (int i = wave; i < Q && ph > pl; i += nw) {
-        double acc[NR];
-#pragma unroll
-        for (int rr = 0; rr < NR; rr++) acc[rr] = 0.0;
-        for (int p = pl; p < ph; p++) {
-            const int x = pend[2 * p], sl = pend[2 * p + 1];
-            const double* F = crF + ((size_t)x * 2 + sl) * QQ + (size_t)i * Q;
-            const double* w = crW + (size_t)x * NR * Q;
-            double part[NR];
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) part[rr] = 0.0;
-            for (int k = lane; k < Q; k += 64) { const double f = F[k];
-#pragma unroll
-                for (int rr = 0; rr < NR; rr++) part[rr] += f * w[rr * Q + k]; }
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) acc[rr] += wave_sum(part[rr]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) T[(3 * Q + rr) * LD + i] -= acc[rr];
-        }
-    }
-    // ---- phase 1b: products of stored F blocks on the matrix cores; every output tile belongs to one wave, which sums its terms in list order
-    {
-        const int li = lane & 15, lk = lane >> 4, TQ = (Q + 15) / 16, ntl = TQ * (TQ + 1) / 2;
-        const int ntask = ntl + nn * TQ * TQ;
-        for (int task = wave; task < ntask; task += nw) {
-            v4d_t acc = {0.0, 0.0, 0.0, 0.0};
-            int I = 0, J = 0, rowbase = 0; bool lower = false, any = false;
-            if (task < ntl) {
-                while ((I + 1) * (I + 2) / 2 <= task) I++;
-                J = task - I * (I + 1) / 2; lower = true;
-                for (int p = pl; p < ph; p++) { const double* F = crF + ((size_t)pend[2 * p] * 2 + pend[2 * p + 1]) * QQ; acc = ring_tile_abt(F, F, 16 * I, 16 * J, Q, li, lk, acc); any = true; }
-            } else {
-                const int t2 = task - ntl, j = t2 / (TQ * TQ), u = t2 - j * TQ * TQ;
-                I = u / TQ; J = u - I * TQ; rowbase = Q + j * Q;
-                const int* q = r + 8 + 16 * j;
-                for (int t = 0; t < q[2]; t++) {
-                    const int* z = q + 4 + 6 * t;
-                    if (z[0] == 1) { acc = ring_tile_abt(crF + ((size_t)z[1] * 2 + z[2]) * QQ, crF + ((size_t)z[1] * 2 + z[3]) * QQ, 16 * I, 16 * J, Q, li, lk, acc); any = true; }
+                const int* z = q + 4 + 5 * t;
+                const bool first = t == 0;
+                // consecutive threads walk the contiguous index of the source; the LDS row stride is odd, so the transposed writes do not collide either
+                if (z[0] == 0) {
+                    const size_t base = (size_t)z[1] * DC;
+                    if (z[2]) { for (int e = tid; e < Q * Q; e += nt) { const int i = e / Q, c = e - i * Q; const double val = Z[(size_t)i * n + base + c]; double* d = T + (Q + j * Q + i) * LD + c; *d = first ? val : *d + val; } }
+                    else      { for (int e = tid; e < Q * Q; e += nt) { const int c = e / Q, i = e - c * Q; const double val = Z[(size_t)c * n + base + i]; double* d = T + (Q + j * Q + i) * LD + c; *d = first ? val : *d + val; } }
+                } else {
+                    const double* E = crE + (size_t)z[1] * QQ;
+                    if (z[2]) { for (int e = tid; e < Q * Q; e += nt) { const int c = e / Q, i = e - c * Q; const double val = E[e]; double* d = T + (Q + j * Q + i) * LD + c; *d = first ? val : *d + val; } }
+                    else      { for (int e = tid; e < Q * Q; e += nt) { const int i = e / Q, c = e - i * Q; const double val = E[e]; double* d = T + (Q + j * Q + i) * LD + c; *d = first ? val : *d + val; } }
                 }
-            }
-            if (any) {
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const int row = 16 * I + lk + 4 * qq, col = 16 * J + li;
-                    if (row < Q && col < Q && (!lower || col <= row)) T[(rowbase + row) * LD + col] -= acc[qq];
-                }
+                __syncthreads();                                    // (a second term adds to what the first one wrote, through another thread mapping)
             }
         }
     }
@@ -177,36 +137,70 @@ k_ring_cr_elim(const int* __restrict__ rec, const int* __restrict__ pend, int re
         }
     }
     __syncthreads();
-    // ---- phase 3: L (diagonal blocks hold G = L_blk^-1), F_j, w
+    // ---- phase 3: L (diagonal blocks hold G = L_blk^-1), F_j, w for the way back; the neighbours' Schur updates and the fill between them, from the F rows in LDS
     for (int e = tid; e < Q * Q; e += nt) {
         const int i = e / Q, c = e - i * Q;
         crL[(size_t)v * QQ + e] = (c <= i) ? T[i * LD + c] : 0.0;
         for (int j = 0; j < nn; j++) crF[((size_t)v * 2 + j) * QQ + e] = T[(Q + j * Q + i) * LD + c];
     }
     for (int e = tid; e < NR * Q; e += nt) { const int rr = e / Q, c = e - rr * Q; crW[(size_t)v * NR * Q + e] = T[(3 * Q + rr) * LD + c]; }
+    if (nn > 0) {
+        const int li = lane & 15, lk = lane >> 4, TQ = (Q + 15) / 16, ntl = TQ * (TQ + 1) / 2;
+        const int ntask = nn * ntl + (r[6] ? TQ * TQ : 0);
+        for (int task = wave; task < ntask; task += nw) {
+            if (task < nn * ntl) {                                 // P{side}[u_j] (+)= F_j F_j^T, lower tiles
+                const int j = task / ntl, t2 = task - j * ntl;
+                int I = 0; while ((I + 1) * (I + 2) / 2 <= t2) I++;
+                const int J = t2 - I * (I + 1) / 2;
+                const double* F = T + (size_t)(Q + j * Q) * LD;
+                const v4d_t acc = ring_tile_lds(F, F, 16 * I, 16 * J, Q, LD, li, lk);
+                const int* q = r + 8 + 16 * j;
+                double* P = crP + ((size_t)q[0] * 2 + q[3]) * QQ;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const int row = 16 * I + lk + 4 * qq, col = 16 * J + li;
+                    if (row < Q && col <= row) { double* d = P + (size_t)row * Q + col; *d = q[14] ? *d + acc[qq] : acc[qq]; }
+                }
+            } else {                                               // ringE[v] = -F_1 F_0^T  (rows: neighbour 1, columns: neighbour 0)
+                const int u = task - nn * ntl, I = u / TQ, J = u - I * TQ;
+                const v4d_t acc = ring_tile_lds(T + (size_t)(2 * Q) * LD, T + (size_t)Q * LD, 16 * I, 16 * J, Q, LD, li, lk);
+                double* E = crE + (size_t)v * QQ;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const int row = 16 * I + lk + 4 * qq, col = 16 * J + li;
+                    if (row < Q && col < Q) E[(size_t)row * Q + col] = -acc[qq];
+                }
+            }
+        }
+        for (int e = tid; e < nn * NR * Q; e += nt) {             // t{side}[u_j] (+)= F_j w
+            const int j = e / (NR * Q), e2 = e - j * NR * Q, rr = e2 / Q, i = e2 - rr * Q;
+            const double* Fr = T + (size_t)(Q + j * Q + i) * LD; const double* w = T + (size_t)(3 * Q + rr) * LD;
+            double a = 0.0;
+            for (int k = 0; k < Q; k++) a += Fr[k] * w[k];
+            const int* q = r + 8 + 16 * j;
+            double* d = crT + ((size_t)q[0] * 2 + q[3]) * NR * Q + e2;
+            *d = q[14] ? *d + a : a;
+        }
+    }
 }
 
-// ---- back substitution of one separator: x_v = L^-T (w - sum_j F_j^T x_{u_j}) -> Y rows of v (and of its copy slot) ---------------------------------
+// ---- back substitution of one separator by the whole workgroup: x_v = L^-T (w - sum_j F_j^T x_{u_j}) -> Y rows of v (and of its copy slot); LDS: ring_back_lds_bytes
 template <int DC, int NR>
-__global__ void __launch_bounds__(256)
-k_ring_cr_back(const int* __restrict__ rec, int rec0, const double* __restrict__ crL, const double* __restrict__ crF, const double* __restrict__ crW,
-               double* __restrict__ Y, int N, int b) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void ring_back_node(const int* __restrict__ r, const double* __restrict__ crL, const double* __restrict__ crF, const double* __restrict__ crW,
+                                               double* __restrict__ Y, const int N, const int b, double* __restrict__ lds) {
     constexpr int NB = DC;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x;
-    const int* r = rec + (size_t)(rec0 + blockIdx.x) * RING_REC;
     const int v = r[0], nn = r[1], copy = r[4], p0 = r[5];
     const size_t QQ = (size_t)Q * Q;
     double* sL = lds;                      // [Q][LD]
     double* sv = sL + (size_t)Q * LD;      // [NR][Q]
     double* sx = sv + NR * Q;              // [2][NR][Q]  neighbours' solutions
     double* so = sx + 2 * NR * Q;          // [NR][Q]     x_v
-    for (int e = tid; e < Q * Q; e += nt) { const int i = e / Q, c = e - i * Q; sL[i * LD + c] = crL[(size_t)v * QQ + e]; }
-    for (int e = tid; e < NR * Q; e += nt) sv[e] = crW[(size_t)v * NR * Q + e];
     for (int j = 0; j < nn; j++) {
         const int pj = r[8 + 16 * j + 1];
         for (int e = tid; e < NR * Q; e += nt) { const int rr = e / Q, i = e - rr * Q; sx[(j * NR + rr) * Q + i] = Y[(size_t)rr * n + (size_t)pj * DC + i]; }
     }
+    for (int e = tid; e < Q * Q; e += nt) { const int i = e / Q, c = e - i * Q; sL[i * LD + c] = crL[(size_t)v * QQ + e]; }
     __syncthreads();
     for (int e = tid; e < NR * Q; e += nt) {
         const int rr = e / Q, k = e - rr * Q;
@@ -214,9 +208,10 @@ k_ring_cr_back(const int* __restrict__ rec, int rec0, const double* __restrict__
         for (int j = 0; j < nn; j++) {
             const double* F = crF + ((size_t)v * 2 + j) * QQ;
             const double* xj = sx + (j * NR + rr) * Q;
+#pragma unroll 8
             for (int i = 0; i < Q; i++) acc += F[(size_t)i * Q + k] * xj[i];
         }
-        sv[e] -= acc;
+        sv[e] = crW[(size_t)v * NR * Q + e] - acc;
     }
     __syncthreads();
     for (int c0 = Q - NB; c0 >= 0; c0 -= NB) {
@@ -243,5 +238,42 @@ k_ring_cr_back(const int* __restrict__ rec, int rec0, const double* __restrict__
     }
 }
 inline size_t ring_back_lds_bytes(int Q, int NR) { return ((size_t)Q * (Q | 1) + (size_t)4 * NR * Q) * sizeof(double); }
+
+// one step of the reduction: the eliminations of the step, one workgroup each
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_ring_cr_elim(const int* __restrict__ rec, int rec0, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
+               double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT, double* __restrict__ crE,
+               int N, int b, int* __restrict__ fail_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ring_elim_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds);
+}
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_ring_cr_back(const int* __restrict__ rec, int rec0, const double* __restrict__ crL, const double* __restrict__ crF, const double* __restrict__ crW,
+               double* __restrict__ Y, int N, int b) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ring_back_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, crL, crF, crW, Y, N, b, lds);
+}
+// The last few separators of every ring (from RING_TAIL_P active ones on): their eliminations, the root and their back substitutions by ONE workgroup per ring in ONE
+// launch, one after the other -- at that point a step holds one or two eliminations per ring and a launch per step would cost more than the work.  tail_ptr: records of
+// ring g = [tail_ptr[g], tail_ptr[g + 1]) in elimination order.  Blocks written by an earlier elimination of the same workgroup are read back through global memory:
+// __threadfence + barrier between two nodes.
+template <int DC, int NR>
+__global__ void __launch_bounds__(1024)
+k_ring_cr_tail(const int* __restrict__ rec, const int* __restrict__ tail_ptr, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
+               double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT, double* __restrict__ crE,
+               double* __restrict__ Y, int N, int b, int* __restrict__ fail_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int q0 = tail_ptr[blockIdx.x], q1 = tail_ptr[blockIdx.x + 1];
+    for (int q = q0; q < q1; q++) {
+        ring_elim_node<DC, NR>(rec + (size_t)q * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds);
+        __threadfence(); __syncthreads();
+    }
+    for (int q = q1 - 1; q >= q0; q--) {
+        ring_back_node<DC, NR>(rec + (size_t)q * RING_REC, crL, crF, crW, Y, N, b, lds);
+        __threadfence(); __syncthreads();
+    }
+}
 
 }  // namespace ssfm

@@ -42,11 +42,11 @@ struct BandSub {
     std::vector<int> seg_twist;                     // per segment: 2t + half of the twisted component it belongs to, else -1
     std::vector<int> fz_lo, fz_hi, fz_wend, fz_merge, fz_await, fz_signal;
     // rings (round 5, band_ring.h): arcs are segments, their separators a cycle solved by cyclic reduction.  sep_copy: first band row of a separator's copy slot (the
-    // last separator of a ring is also "in front of" its first arc) or -1; ring_seps: (first separator id, cuts) per ring; the schedule: RING_REC ints per elimination,
-    // eliminations of step s = records [ring_step_ptr[s], ring_step_ptr[s + 1]), ring_pend = (separator, slot) pairs of the pending Schur updates
+    // last separator of a ring is also "in front of" its first arc) or -1; ring_seps: (first separator id, cuts) per ring; the schedule (ring_schedule.h): RING_REC ints
+    // per elimination, eliminations of parallel step s = records [ring_step_ptr[s], ring_step_ptr[s + 1]), the tail of ring g = [ring_tail_ptr[g], ring_tail_ptr[g + 1])
     int nring = 0;
     std::vector<int> sep_copy; std::vector<std::pair<int, int>> ring_seps;
-    std::vector<int> ring_rec, ring_step_ptr, ring_pend;
+    std::vector<int> ring_rec, ring_step_ptr, ring_tail_ptr;
 };
 
 // Cost model in microseconds, fitted to MI355X measurements (profiles/r01_notes.md): per block row of a segment the factorisation
@@ -119,7 +119,7 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
     S.nseg = (int)S.seg_lo.size(); S.nsep = (int)S.sep_lo.size(); S.nchain = (int)S.chain_ptr.size() - 1; S.nleft = (int)S.left_segs.size();
     S.ntwist = (int)S.tw_lo.size();
     if (!S.enabled) { S = BandSub(); return; }
-    if (S.nring > 0) ring_schedule(S.ring_seps, S.sep_lo, S.sep_copy, S.ring_rec, S.ring_step_ptr, S.ring_pend);
+    if (S.nring > 0) ring_schedule(S.ring_seps, S.sep_lo, S.sep_copy, S.ring_rec, S.ring_step_ptr, S.ring_tail_ptr);
     S.fz_lo = S.seg_lo; S.fz_hi = S.seg_hi; S.fz_wend = S.seg_wend; S.fz_merge.assign(S.nseg, -1); S.fz_await.assign(S.nseg, -1); S.fz_signal = S.seg_twist;
     for (int t = 0; t < S.ntwist; t++) { S.fz_lo.push_back(S.tw_lo[t]); S.fz_hi.push_back(S.tw_hi[t]); S.fz_wend.push_back(S.tw_hi[t]); S.fz_merge.push_back(S.tw_copy[t]); S.fz_await.push_back(2 * t); S.fz_signal.push_back(-1); }
 }
@@ -132,12 +132,15 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
 // wave carries SPIKE_NC columns through one stream of L.  Round 1 (half-width 19, flat 64-bit indices): one column per wave was L2-bandwidth bound and four
 // columns per wave won.  Round 2 (half-width 14 after the ordering change, scalar row bases): a step is bound by what one wave can issue, the columns of a
 // wave run one after the other inside a step, and there are CUs to spare -- 4 columns 210 us, 2 columns 169 us, 1 column 130 us per launch at the configs[4] size.
+// Round 5: narrow bands (the ring-native layout halves the half-width) turn the balance again -- the arithmetic of a step shrinks with the band, the factor rows every
+// column streams do not: 42 columns x 102 arcs at the configs[4] size read the whole band 42 times (311 MB from L2, ~72 us whatever the number of arcs).  NC is a template
+// parameter now and the launch picks it by half-width (ba_handle.h).
 constexpr int SPIKE_PD = 4, SPIKE_NC = 1;
-template <int DC>
+template <int DC, int NC = SPIKE_NC>
 __global__ void __launch_bounds__(64)
 k_sub_spike_fwd(const double* __restrict__ band, const double* __restrict__ Ginv, double* __restrict__ Z, const int* __restrict__ seg_lo,
                 const int* __restrict__ seg_hi, const int* __restrict__ seg_wend, const int* __restrict__ left_segs, int N, int b) {
-    constexpr int BB = DC * DC, NC = SPIKE_NC;
+    constexpr int BB = DC * DC;
     const int W = b + 1, n = N * DC, lane = threadIdx.x, Q = b * DC;
     const int seg = left_segs[blockIdx.x], q0 = blockIdx.y * NC;
     const int r0 = seg_lo[seg], r1 = seg_hi[seg], re = seg_wend[seg];

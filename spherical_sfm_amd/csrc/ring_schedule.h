@@ -8,39 +8,49 @@
 namespace ssfm {
 
 // record of one elimination (ints):
-//   [0] separator v   [1] neighbours nn (0..2)   [2] pend_lo   [3] pend_hi (pairs (x, slot) in ring_pend)   [4] first band row of v's copy slot or -1   [5] first band row of v
-//   neighbour j at 8 + 16 j:  [0] separator u_j   [1] first band row of u_j   [2] terms (1..2)   term t at + 4 + 6 t:  [0] kind  [1] a  [2] b  [3] c
-//     kind 0  original coupling held in Z at the rows of the separator whose first band row is a:  b = 0: B(i, c) = Z[c][a DC + i],  b = 1: B(i, c) = Z[i][a DC + c]
-//     kind 1  fill through the eliminated separator a:  B -= F[a][slot b] F[a][slot c]^T
+//   [0] separator v   [1] neighbours nn (0..2)   [2] hasL  [3] hasR: earlier eliminations left Schur updates of v in PL[v] / PR[v] (and tL / tR)
+//   [4] first band row of v's copy slot or -1   [5] first band row of v   [6] 1 = store the fill -F_1 F_0^T between the two neighbours in ringE[v]
+//   neighbour j at 8 + 16 j:  [0] separator u_j   [1] first band row of u_j   [2] terms (1..2)   [3] side of u_j that takes this elimination's update (0: PL / tL, 1: PR / tR)
+//                             [14] 0 = first update of that side (store), 1 = add to what is there      term t at + 4 + 5 t:  [0] kind  [1] a  [2] transposed
+//     kind 0  original coupling, held in Z at the rows of the separator whose first band row is a (E(i, c) = Z[c][a DC + i]):  B = E, or E^T when transposed
+//     kind 1  fill left by the elimination of separator a in ringE[a]:  B = ringE[a], or its transpose
+// Every separator has one record; the eliminations of a step are independent of each other.  The last steps of a ring (from RING_TAIL_P active separators on) go to
+// the ring's TAIL list instead of the step lists: one workgroup runs them one after the other in one launch (band_ring.h: k_ring_cr_tail).
 constexpr int RING_REC = 40;
+constexpr int RING_TAIL_P = 2;
 
-struct RingTermH { int kind, a, b, c; };
+struct RingTermH { int kind, a, tr; };
 
 // Schedule of all rings of a plan.  ring_seps: (first separator id, m) per ring; separators of a ring are consecutive ids in cyclic order, separator s0 + k lies behind arc k.
+// out: rec (all records: the steps' first, then the tails'), step_ptr (records of parallel step s: [step_ptr[s], step_ptr[s+1])), tail_ptr (records of ring g's tail:
+// [tail_ptr[g], tail_ptr[g+1]), in elimination order)
 inline void ring_schedule(const std::vector<std::pair<int, int>>& ring_seps, const std::vector<int>& sep_lo, const std::vector<int>& sep_copy,
-                          std::vector<int>& rec, std::vector<int>& step_ptr, std::vector<int>& pend_out) {
-    rec.clear(); pend_out.clear(); step_ptr.assign(1, 0);
-    struct Node { int v, nn, nbr[2]; std::vector<RingTermH> terms[2]; std::vector<std::pair<int, int>> pend; };
-    std::vector<std::vector<Node>> steps;
-    auto transposed = [](const RingTermH& t) { RingTermH r = t; if (t.kind == 0) r.b = 1 - t.b; else { r.b = t.c; r.c = t.b; } return r; };
-    for (const auto& rs : ring_seps) {
-        const int s0 = rs.first, m = rs.second;
+                          std::vector<int>& rec, std::vector<int>& step_ptr, std::vector<int>& tail_ptr) {
+    rec.clear(); step_ptr.assign(1, 0); tail_ptr.clear();
+    struct Node { int v, nn, nbr[2], side[2], accum[2], hasL, hasR, writeE; std::vector<RingTermH> terms[2]; };
+    std::vector<std::vector<Node>> steps, tails(ring_seps.size());
+    auto transposed = [](const RingTermH& t) { RingTermH r = t; r.tr = 1 - t.tr; return r; };
+    int nsep_total = 0; for (const auto& rs : ring_seps) nsep_total = std::max(nsep_total, rs.first + rs.second);
+    std::vector<char> wroteL(nsep_total, 0), wroteR(nsep_total, 0);
+    for (size_t g = 0; g < ring_seps.size(); g++) {
+        const int s0 = ring_seps[g].first, m = ring_seps[g].second;
         std::vector<int> act(m); for (int k = 0; k < m; k++) act[k] = s0 + k;
         // adj[i]: the terms of M[act[i+1]][act[i]] (rows = the later node of the pair in cyclic order)
         std::vector<std::vector<RingTermH>> adj(m);
-        for (int k = 0; k < m; k++) adj[k].push_back(RingTermH{0, sep_lo[act[(k + 1) % m]], 0, 0});
-        std::vector<std::vector<std::pair<int, int>>> pend(m);            // by separator id - s0
+        for (int k = 0; k < m; k++) adj[k].push_back(RingTermH{0, sep_lo[act[(k + 1) % m]], 0});
         size_t round = 0;
+        auto emit = [&](const Node& nd, int p) { if (p <= RING_TAIL_P) tails[g].push_back(nd); else { if (steps.size() <= round) steps.resize(round + 1); steps[round].push_back(nd); } };
+        auto target = [&](Node& nd, int j, int node, int side) { nd.side[j] = side; char& w = side ? wroteR[node] : wroteL[node]; nd.accum[j] = w; w = 1; };
         for (;;) {
-            if (steps.size() <= round) steps.emplace_back();
             const int p = (int)act.size();
-            if (p == 1) { Node nd; nd.v = act[0]; nd.nn = 0; nd.pend = pend[act[0] - s0]; steps[round].push_back(nd); break; }
+            Node nd; nd.nn = 0; nd.writeE = 0; nd.nbr[0] = nd.nbr[1] = 0; nd.side[0] = nd.side[1] = 0; nd.accum[0] = nd.accum[1] = 0;
+            if (p == 1) { nd.v = act[0]; nd.hasL = wroteL[nd.v]; nd.hasR = wroteR[nd.v]; emit(nd, p); break; }
             if (p == 2) {
-                Node nd; nd.v = act[0]; nd.nn = 1; nd.nbr[0] = act[1]; nd.pend = pend[act[0] - s0];
+                nd.v = act[0]; nd.nn = 1; nd.nbr[0] = act[1]; nd.hasL = wroteL[nd.v]; nd.hasR = wroteR[nd.v];
                 for (const auto& t : adj[0]) nd.terms[0].push_back(t);                     // M[c][a] as stored
                 for (const auto& t : adj[1]) nd.terms[0].push_back(transposed(t));         // M[a][c] transposed
-                pend[act[1] - s0].push_back({act[0], 0});
-                steps[round].push_back(nd);
+                target(nd, 0, act[1], 0);
+                emit(nd, p);
                 act.erase(act.begin()); adj.clear(); adj.resize(1);
                 round++; continue;
             }
@@ -49,33 +59,31 @@ inline void ring_schedule(const std::vector<std::pair<int, int>>& ring_seps, con
                 act2.push_back(act[i]);
                 if (i + 1 < p) {                                                            // eliminate act[i+1] between act[i] and act[i+2 mod p]
                     const int u = act[i], v = act[i + 1], w = act[(i + 2) % p];
-                    Node nd; nd.v = v; nd.nn = 2; nd.nbr[0] = u; nd.nbr[1] = w; nd.pend = pend[v - s0];
-                    for (const auto& t : adj[i]) nd.terms[0].push_back(transposed(t));     // M[u][v] = (M[v][u])^T
-                    for (const auto& t : adj[i + 1]) nd.terms[1].push_back(t);             // M[w][v]
-                    pend[u - s0].push_back({v, 0}); pend[w - s0].push_back({v, 1});
-                    steps[round].push_back(nd);
-                    adj2.push_back({RingTermH{1, v, 1, 0}});                                // M[w][u] -= F_{v,w} F_{v,u}^T
+                    Node e = nd; e.v = v; e.nn = 2; e.nbr[0] = u; e.nbr[1] = w; e.hasL = wroteL[v]; e.hasR = wroteR[v]; e.writeE = 1;
+                    for (const auto& t : adj[i]) e.terms[0].push_back(transposed(t));      // M[u][v] = (M[v][u])^T
+                    for (const auto& t : adj[i + 1]) e.terms[1].push_back(t);              // M[w][v]
+                    target(e, 0, u, 1); target(e, 1, w, 0);                                // v is u's right neighbour and w's left one
+                    emit(e, p);
+                    adj2.push_back({RingTermH{1, v, 0}});                                   // M[w][u] -= F_w F_u^T, kept in ringE[v] (rows w)
                 } else adj2.push_back(adj[i]);                                              // odd p: the pair (act[p-1], act[0]) keeps its coupling
             }
             act.swap(act2); adj.swap(adj2);
             round++;
         }
     }
-    for (const auto& st : steps) {
-        for (const Node& nd : st) {
-            std::vector<int> r(RING_REC, 0);
-            r[0] = nd.v; r[1] = nd.nn; r[2] = (int)pend_out.size() / 2;
-            for (const auto& pr : nd.pend) { pend_out.push_back(pr.first); pend_out.push_back(pr.second); }
-            r[3] = (int)pend_out.size() / 2; r[4] = sep_copy[nd.v]; r[5] = sep_lo[nd.v];
-            for (int j = 0; j < nd.nn; j++) {
-                int* q = r.data() + 8 + 16 * j;
-                q[0] = nd.nbr[j]; q[1] = sep_lo[nd.nbr[j]]; q[2] = (int)nd.terms[j].size();
-                for (size_t t = 0; t < nd.terms[j].size() && t < 2; t++) { int* z = q + 4 + 6 * (int)t; z[0] = nd.terms[j][t].kind; z[1] = nd.terms[j][t].a; z[2] = nd.terms[j][t].b; z[3] = nd.terms[j][t].c; }
-            }
-            rec.insert(rec.end(), r.begin(), r.end());
+    auto put = [&](const Node& nd) {
+        std::vector<int> r(RING_REC, 0);
+        r[0] = nd.v; r[1] = nd.nn; r[2] = nd.hasL; r[3] = nd.hasR; r[4] = sep_copy[nd.v]; r[5] = sep_lo[nd.v]; r[6] = nd.writeE;
+        for (int j = 0; j < nd.nn; j++) {
+            int* q = r.data() + 8 + 16 * j;
+            q[0] = nd.nbr[j]; q[1] = sep_lo[nd.nbr[j]]; q[2] = (int)nd.terms[j].size(); q[3] = nd.side[j]; q[14] = nd.accum[j];
+            for (size_t t = 0; t < nd.terms[j].size() && t < 2; t++) { int* z = q + 4 + 5 * (int)t; z[0] = nd.terms[j][t].kind; z[1] = nd.terms[j][t].a; z[2] = nd.terms[j][t].tr; }
         }
-        step_ptr.push_back((int)rec.size() / RING_REC);
-    }
+        rec.insert(rec.end(), r.begin(), r.end());
+    };
+    for (const auto& st : steps) { for (const Node& nd : st) put(nd); step_ptr.push_back((int)rec.size() / RING_REC); }
+    tail_ptr.push_back((int)rec.size() / RING_REC);
+    for (const auto& tl : tails) { for (const Node& nd : tl) put(nd); tail_ptr.push_back((int)rec.size() / RING_REC); }
 }
 
 }  // namespace ssfm

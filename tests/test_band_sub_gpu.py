@@ -47,19 +47,24 @@ def test_refinement_path_with_segments(gpu_ctx, monkeypatch):
     assert np.isfinite(cams).all() and np.isfinite(pts).all()
 
 
-def test_long_component_is_cut_by_default(gpu_ctx, oracle):
+def test_long_component_is_cut_by_default(gpu_ctx, oracle, monkeypatch):
     """1000 cameras, K = 6 -> stride 13, coprime with 1000 -> ONE ring of 1000 cameras: cut without being asked.
     Config 2 (four rings of 75) stays on one workgroup per ring."""
     from spherical_sfm_amd import ba
     info2, _, _, _ = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))
     assert info2["band_separators"] == 4 and info2["band_segments"] == 8          # twisted, not cut into chains
     p = synth.make_circle(1000, 40000, 6, spherical=False, focal_fixed=True, seed=3)
-    info, _, _, _ = ba.plan(p)
-    assert info["band_separators"] >= 3 and info["band_segments"] == info["band_separators"] + 1
-    cams, pts, f, s = ba.optimize(gpu_ctx, p)
-    assert s["band_separators"] == info["band_separators"] and s["pcg_iterations_total"] == 0
     ocams, opts, of, os_ = oracle.ba_solve(p)
-    assert s["iterations"] == os_["iterations"] and rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+    # round 5: by default the ring is laid out in its own circular order (half the band width, a CYCLE of separators solved by cyclic reduction, band_ring.h);
+    # SSFM_RING=0: the Cuthill-McKee fold cut into a chain of segments (rounds 1-4)
+    for ring in ("1", "0"):
+        monkeypatch.setenv("SSFM_RING", ring); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+        info, _, _, _ = ba.plan(p)
+        assert info["band_separators"] >= 3 and info["band_segments"] == info["band_separators"] + (0 if ring == "1" else 1)
+        assert info["band_half_width"] == (5 if ring == "1" else 10)
+        cams, pts, f, s = ba.optimize(gpu_ctx, p)
+        assert s["band_separators"] == info["band_separators"] and s["pcg_iterations_total"] == 0
+        assert s["iterations"] == os_["iterations"] and rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
 
 
 @pytest.mark.parametrize("spherical,focal_fixed,Nc,K", [(False, True, 300, 6), (True, False, 240, 6), (False, False, 60, 6), (False, True, 210, 8)])
@@ -112,11 +117,13 @@ def test_long_three_dof_component_merged_and_cut(gpu_ctx, oracle, monkeypatch):
     from spherical_sfm_amd import ba
     monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
     p = synth.make_circle(2000, 24000, 6, spherical=True, focal_fixed=True, seed=8)
-    cams, pts, f, s = ba.optimize(gpu_ctx, p)
-    assert s["camera_dof"] == 3 and s["band_separators"] >= 2 and s["band_segments"] == s["band_separators"] + 1
     ocams, opts, of, os_ = oracle.ba_solve(p)
-    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
-    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+    for ring in ("1", "0"):                                        # ring-native layout of the merged pairs (default) / the folded chain of rounds 1-4
+        monkeypatch.setenv("SSFM_RING", ring)
+        cams, pts, f, s = ba.optimize(gpu_ctx, p)
+        assert s["camera_dof"] == 3 and s["band_separators"] >= 2 and s["band_segments"] == s["band_separators"] + (0 if ring == "1" else 1)
+        assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+        assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
 
 
 @pytest.mark.parametrize("spherical", [False, True])
@@ -130,3 +137,34 @@ def test_shared_focal_free_above_1024_cameras(gpu_ctx, oracle, monkeypatch, sphe
     ocams, opts, of, os_ = oracle.ba_solve(p)
     assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
     assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+
+
+@pytest.mark.parametrize("cuts", [2, 3, 4, 5, 7, 8, 9, 13, 16, 33])
+def test_ring_layout_with_forced_cuts_matches_oracle(gpu_ctx, oracle, monkeypatch, cuts):
+    """Round 5, band_ring.h: every shape of the cyclic reduction -- two separators (both couplings of the pair add up), odd cycles (one pair keeps its coupling across a
+    step), all-tail (<= 4 separators: one launch), one and two parallel steps in front of the tail -- on ONE ring of 1000 six-dof cameras with the shared focal free
+    (the focal border rides along as the second right-hand side): same LM iterations as the oracle, cameras / points / focal <= 1e-5 (observed ~1e-10)."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.setenv("SSFM_RING_CUTS", str(cuts))
+    p = synth.make_circle(1000, 30000, 6, spherical=False, focal_fixed=False, seed=21)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert (s["band_segments"], s["band_separators"], s["band_half_width"]) == (cuts, cuts, 5) and s["pcg_iterations_total"] == 0
+    global _ring_oracle
+    try: ref = _ring_oracle
+    except NameError: ref = _ring_oracle = oracle.ba_solve(p)
+    ocams, opts, of, os_ = ref
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"]
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_two_rings_and_a_short_component(gpu_ctx, oracle, monkeypatch, spherical):
+    """Two rings of 2000 cameras (SURVEY 8d's stride rule at 4000 cameras, K = 8) next to nothing else, and the same with merged 3-dof pairs: ring layouts side by side."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_circle(4000, 60000, 8, spherical=spherical, focal_fixed=True, seed=4)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["band_half_width"] == (4 if spherical else 7) and s["band_segments"] == s["band_separators"] >= 8
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
