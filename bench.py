@@ -111,6 +111,63 @@ def kernel_rooflines(kern, M, nP, nnzb, Nc, dc, pairs, n_lm, world=1, focal_free
     return out
 
 
+def pass_rooflines(kern, M, nP, world, gram, copy_gbs):
+    """SURVEY 8d's B_alg = 72 B/obs + 240 B/pt split over the logical passes of one LM iteration and the kernels that run them -- the parts ADD UP to B_alg:
+         A    linearise + assemble     obs 16 + ids 8 per observation; X 24 read, V^-1 + g_p 72 written per point          = 24 M +  96 nP
+         C+D  back-substitute + cost   obs 24 twice per observation; V^-1 + g_p 72 read, dp 24 written, X_new 24 read,
+                                       24 committed per point                                                               = 48 M + 144 nP
+       durations: hipEvent averages of this run (NaN when a kernel did not run)"""
+    a_k = ["k_point_lin", "k_schur_gram"] if gram else ["k_point_lin", "k_cam_sums2", "k_schur_pairs2"]
+    c_k = [k for k in ("k_point_backsub", "k_gram_backsub") if kern.get(k, {}).get("launches", 0)]
+    def us_of(names):
+        t = 0.0
+        for k in names:
+            u = kern.get(k, {}).get("avg_us"); n = kern.get(k, {}).get("launches", 0)
+            if n and u == u: t += u
+        return t
+    out = {}
+    for name, ks, b in (("A_linearise_assemble", a_k, 24.0 * M + 96.0 * nP), ("CD_backsubstitute_candidate_cost", c_k, 48.0 * M + 144.0 * nP)):
+        us = us_of(ks); b = b / world
+        g = b / (us * 1e-6) / 1e9 if us > 0 else None
+        out[name] = {"kernels": ks, "algorithmic_bytes": b, "sum_of_avg_us": us, "achieved_GBs": g, "frac_hbm": (g / HBM_PEAK_GBS) if g else None,
+                     "frac_of_measured_copy": (g / copy_gbs) if (g and copy_gbs) else None}
+    out["sum_of_algorithmic_bytes"] = sum(v["algorithmic_bytes"] for v in out.values() if isinstance(v, dict))
+    out["B_alg"] = (72.0 * M + 240.0 * nP) / world
+    return out
+
+
+SHARDED_KERNELS = ("k_point_lin", "k_cam_sums2", "k_schur_pairs2", "k_schur_gram", "k_point_backsub", "k_gram_backsub")
+
+
+def scaling_model(world, n_lm_per_step):
+    """DESIGN.md 6's strong-scaling model, evaluated from the committed N = 1 bench line of the same workload (the newest profiles/r??*_bench.json): the point-major
+    kernels shard with 1 / N, the reduced solve and the small per-camera kernels are replicated, and every LM iteration pays two all-reduces (the reduced system and
+    the candidate-cost scalars, ~20 us each over xGMI -- an assumption until a multi-GPU box has been measured).  Printed next to the measured value so that the first
+    real curve can be read against it; it is NOT a measurement."""
+    import glob
+    import re
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_bench.json")) if re.search(r"r\d\d[a-z]?_bench\.json$", f))
+    if not cands:
+        return {"note": "no committed N = 1 bench line under profiles/"}
+    try:
+        base = json.loads(open(cands[-1]).read().strip().splitlines()[-1])
+        kern = base["kernels"]; it1 = base["steps"] and base["ms_per_step"] * 1e3 / max(1.0, base["config"]["lm_iterations_per_step"])
+    except Exception as e:
+        return {"note": f"could not read {cands[-1]}: {e}"}
+    nit = max(1.0, base["config"]["lm_iterations_per_step"])                   # the kernel table of a bench line is ONE profiled step
+    per_it = lambda k: kern[k]["avg_us"] * kern[k]["launches"] / nit if k in kern and kern[k].get("launches") else 0.0
+    lm_kernels = [k for k in kern if kern[k].get("launches", 0) >= 0.9 * nit]
+    sharded = sum(per_it(k) for k in lm_kernels if k in SHARDED_KERNELS)
+    replicated = sum(per_it(k) for k in lm_kernels if k not in SHARDED_KERNELS)
+    gaps = max(0.0, it1 - sharded - replicated)
+    coll = 0.0 if world == 1 else 2 * 20.0
+    itn = sharded / world + replicated + gaps + coll
+    return {"source": os.path.relpath(cands[-1], ROOT), "n1_iteration_us": it1, "sharded_kernels_us": sharded, "replicated_kernels_us": replicated, "dispatch_gaps_us": gaps,
+            "assumed_collectives_us": coll, "predicted_iteration_us": itn, "predicted_speedup_vs_n1": it1 / itn if itn > 0 else None,
+            "predicted_value_obs_per_s": base["value"] * it1 / itn if itn > 0 else None,
+            "note": "model (DESIGN.md 6), not a measurement: sharded / N + replicated + gaps + two assumed 20 us all-reduces per LM iteration"}
+
+
 def with_copy_fraction(per_kernel, copy_gbs, rocprof=None):
     """adds frac_of_measured_copy (achieved / the device copy bandwidth measured in the same run) next to frac_hbm (achieved / nominal 8 TB/s), and -- when the committed
     rocprofv3 summary of this command is there -- the same fractions from ITS average launch durations (the event brackets of this run include a few us of dispatch
@@ -190,6 +247,12 @@ def side_paths(ctx):
     run = lambda: ransac.estimate_indexed(ctx, feat_ptr, feat_rays, fr, fr, ptr, m0, m1, THR, min_num_inliers=20)
     run()                                                                               # warm-up: module load, pinned staging buffers
     t = time.perf_counter(); o = run(); dt = time.perf_counter() - t
+    k_ms = ransac.last_kernel_ms(ctx)                                                   # device time of the kernels of that call (hipEvent brackets per slab)
+    # SURVEY 8d prices this leg in FP64 flop/s of Sampson scoring: every iteration scores its four candidate models against all correspondences of the pair
+    # (include/RansacLib/ransac.h:295-303, src/spherical_estimator.cpp:67-78), 48 flop per score (3x3 matrix-vector product 15, E^T v's two components 10, v . Eu 5,
+    # two squared norms 7, square + quotient via reciprocal ~11); local optimisation, least squares and the minimal solver are NOT counted (algorithmic flop of the scoring only)
+    scores = float(o["iterations"].astype(np.float64).sum()) * 4.0 * NC
+    sampson_tflops = scores * 48.0 / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
     ns = 24; tc = time.perf_counter(); worst = 0.0; same_its = 0
     for k in range(ns):
         r = O.lomsac_pair(probs[k][0], probs[k][1], THR, min_num_inliers=20)
@@ -198,6 +261,13 @@ def side_paths(ctx):
     res["pairwise_lomsac"] = {"workload": f"{P} pairs x {NC} correspondences, 30% outliers, reference-trace LO-MSAC (std::mt19937 streams replayed on the device), ssfm_ransac_batch_indexed: "
                                           f"feature rays of {POOL} frames + match lists from host memory",
                               "value": P / dt, "unit": "pairs/s", "includes_pcie": True, "mean_iterations": float(o["iterations"].mean()),
+                              "kernel_ms": k_ms, "kernel_pairs_per_s": (P / (k_ms * 1e-3)) if k_ms > 0 else None,
+                              "roofline": {"bound": "fp64 vector", "achieved": sampson_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": (sampson_tflops / FP64_VECTOR_PEAK_TFLOPS) if sampson_tflops else None,
+                                           "algorithmic_flop": scores * 48.0, "scores": scores, "flop_per_score": 48,
+                                           "note": "algorithmic flop = Sampson scores of the RANSAC iterations only (iterations x 4 models x correspondences x 48), divided by the device time of "
+                                                   "ALL kernels of the call (sampling, minimal solver, scoring, local optimisation, final least squares, decomposition); rays sit in LDS, "
+                                                   "so the bound is the FP64 vector pipe, not HBM (SURVEY 8d)"},
                               "cpu_baseline": {"value": 1.0 / tc, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"the first {ns} pairs"},
                               "parity_vs_oracle": {"max_rotation_error_rad": worst, "pairs_with_identical_iteration_count": same_its, "pairs_checked": ns}}
     R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(300, 8)
@@ -452,11 +522,13 @@ def main():
                   "useful_achieved": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12) if dom_us == dom_us else None,
                   "useful_frac": (pairs / world * PAIR_USEFUL_FLOP / (dom_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if dom_us == dom_us else None}
         iter_ms = 1e3 * elapsed / max(1, n_lm)          # wall time of the timed loop per LM iteration (host round trips included)
-        traffic = None; valu = None; mops = None
+        traffic = None; valu = None; mops = None; pmc_meta = None
         tp = os.path.join(ROOT, PMC_PROFILE)
         if os.path.exists(tp):
             try:
                 pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom); mops = pm.get("_mfma_mops_f64", {}).get(dom)
+                # which run the quoted counters come from: the tag of the file and what its collector recorded about the tree it profiled (a stale file shows here)
+                pmc_meta = {"file": PMC_PROFILE, "tag": os.path.basename(PMC_PROFILE).split("_")[0], "recorded": pm.get("_meta", "no _meta in this file (collected before round 5)")}
             except Exception:
                 traffic = None
         out = {
@@ -485,11 +557,18 @@ def main():
                                             "gfx950 x2 FETCH_SIZE correction applied) -- NOT measured in this run",
                           "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us}),
             # the same kernel on the HBM line (SURVEY 8d's figure of merit): algorithmic bytes per launch / duration
+            "pmc_profile": pmc_meta,
+            "scaling_model": scaling_model(world, n_lm / max(1, args.steps)) if world > 1 else None,
             "hbm_copy_GBs": copy_gbs,       # measured in this run: float4 device copy of 512 MB (read + write bytes per second)
             "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                              "frac_of_measured_copy": vs_copy(achieved),
                              "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
             "roofline_compute": rc,
+            # the per-kernel byte counts below are each kernel's OWN minimum traffic (its inputs and outputs once); three of them read the observations again, so they
+            # do not add up to SURVEY 8d's B_alg -- roofline_passes does: its two passes split B_alg = 72 B/obs + 240 B/pt exactly
+            "roofline_per_kernel_note": "algorithmic_bytes_per_launch = per-kernel minimum (the kernel's own inputs and outputs once); the kernels of one LM iteration re-read the "
+                                        "observations, so these do NOT sum to B_alg; see roofline_passes for a split that does",
+            "roofline_passes": pass_rooflines(kern, M, args.points, world, gram, copy_gbs),
             "roofline_per_kernel": with_copy_fraction(kernel_rooflines(kern, M, args.points, nnzb, args.cameras, dc, pairs, n_lm_prof, world, args.focal_free), copy_gbs,
                                                       rocprof_avg_us() if (world == 1 and not spherical and not args.focal_free and args.cameras == 300 and args.points == 100000) else None),
             # the dominant kernel is bound by instruction issue, not by HBM: VALU wave-instructions per launch (PMC SQ_INSTS_VALU of the
@@ -542,7 +621,9 @@ def main():
             for k_ in (5, 6):
                 pf_ = prob.pt_fixed.copy(); pf_[k_] = 1
                 colds.append(e2e_call(dataclasses.replace(prob, pt_fixed=pf_)))
-            e2e = min(colds, key=lambda d: d["gpu_s"]); e2e["cold_samples_s"] = [c_["gpu_s"] for c_ in colds]
+            srt = sorted(colds, key=lambda d: d["gpu_s"])
+            e2e = dict(srt[len(srt) // 2]); e2e["cold_samples_s"] = [c_["gpu_s"] for c_ in colds]      # the MEDIAN sample is the quoted one (gpu_s and its parts)
+            e2e["first_s"] = colds[0]["gpu_s"]; e2e["median_s"] = srt[len(srt) // 2]["gpu_s"]; e2e["best_s"] = srt[0]["gpu_s"]
             e2e_call()                                              # back on the original structure (cold once more), then:
             warm = min((e2e_call() for _ in range(3)), key=lambda d: d["gpu_s"])   # same structure again (the drivers' pattern): plan cache hit
             e2e["warm"] = warm

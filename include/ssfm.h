@@ -267,6 +267,9 @@ int ssfm_ransac_batch_indexed_sharded(ssfm_ctx* ctx, int32_t num_frames, const i
                                       const int32_t* match_idx0, const int32_t* match_idx1,
                                       double squared_inlier_threshold, const ssfm_ransac_options* o, double* E, double* R, uint8_t* inlier_mask,
                                       int32_t* num_inliers, double* scores, uint32_t* stats);
+/* Measurement aid (the RANSAC leg is priced in FP64 flop/s of Sampson scoring, not GB/s): device time of the kernels of this context's last
+ * ssfm_ransac_batch* call, summed over its slabs (hipEvent brackets on the solver stream; uploads and read-backs are outside).  No reference counterpart. */
+int ssfm_ransac_last_kernel_ms(ssfm_ctx* ctx, double* ms);
 /* ---- the reference's estimator interface for ONE pair (rays resident on the device) ------------------------------------------------
  * One entry point per virtual of sphericalsfm::Estimator<Eigen::Matrix3d> / EssentialEstimator (include/sphericalsfm/estimator.h:7-29) as
  * SphericalEstimator implements them (include/sphericalsfm/spherical_estimator.h:8-35, src/spherical_estimator.cpp:67-164): what a host-side

@@ -262,6 +262,8 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
     for (int k = 0; k < ns; k++) { cap_rays = std::max(cap_rays, (size_t)(pair_ptr[slab[k + 1]] - pair_ptr[slab[k]])); cap_pairs = std::max(cap_pairs, slab[k + 1] - slab[k]); }
     hipStream_t st = ctx->stream;
     hipStream_t cs = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
+    hipEvent_t kt0[2] = {nullptr, nullptr}, kt1[2] = {nullptr, nullptr};      // around the kernels of a slab: ssfm_ransac_last_kernel_ms (bench.py: FP64 rate of the scoring)
+    ctx->ransac_kernel_ms = 0.0;
     // per-slab device buffers x 2 (upload of the next slab overlaps the kernels of this one); pinned staging x 2
     struct Slot { DevBuf<int> ptr, pid, nin, lists, idx, off; DevBuf<double> u, v, E, S, R; DevBuf<unsigned char> mask; DevBuf<unsigned> stats;
                   double* h_uv = nullptr; int* h_ptr = nullptr; int* h_idx = nullptr; double* h_res = nullptr; unsigned char* h_mask = nullptr; int* h_nin = nullptr; unsigned* h_stats = nullptr; } slot[2];
@@ -281,6 +283,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
         for (int b = 0; b < nslot; b++) {
             Slot& s = slot[b];
             SSFM_HIP_CHECK(ctx, hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming)); SSFM_HIP_CHECK(ctx, hipEventCreateWithFlags(&compute_done[b], hipEventDisableTiming));
+            SSFM_HIP_CHECK(ctx, hipEventCreate(&kt0[b])); SSFM_HIP_CHECK(ctx, hipEventCreate(&kt1[b]));
             SSFM_HIP_CHECK(ctx, s.ptr.alloc(cap_pairs + 1)); SSFM_HIP_CHECK(ctx, s.pid.alloc(cap_pairs)); SSFM_HIP_CHECK(ctx, s.nin.alloc(cap_pairs));
             SSFM_HIP_CHECK(ctx, s.u.alloc(3 * cap_rays)); SSFM_HIP_CHECK(ctx, s.v.alloc(3 * cap_rays)); SSFM_HIP_CHECK(ctx, s.E.alloc((size_t)9 * cap_pairs));
             SSFM_HIP_CHECK(ctx, s.S.alloc(cap_pairs)); SSFM_HIP_CHECK(ctx, s.R.alloc((size_t)9 * cap_pairs)); SSFM_HIP_CHECK(ctx, s.mask.alloc(cap_rays));
@@ -354,6 +357,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             Slot& s = slot[k % nslot];
             const int p0 = slab[k], np = slab[k + 1] - p0, r0 = pair_ptr[p0]; const size_t nr = (size_t)(pair_ptr[slab[k + 1]] - r0);
             SSFM_HIP_CHECK(ctx, hipEventSynchronize(compute_done[k % nslot]));
+            { float ms = 0.0f; if (hipEventElapsedTime(&ms, kt0[k % nslot], kt1[k % nslot]) == hipSuccess) ctx->ransac_kernel_ms += ms; else (void)hipGetLastError(); }
             for (int i = 0; i < np; i++) {
                 if (E_out) rm_to_cm(s.h_res + 9 * (size_t)i, E_out + 9 * (size_t)(p0 + i));
                 if (R_out) rm_to_cm(s.h_res + 9 * (size_t)cap_pairs + 9 * (size_t)i, R_out + 9 * (size_t)(p0 + i));
@@ -370,6 +374,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
             const int np = slab[k + 1] - slab[k]; const size_t nr = (size_t)(pair_ptr[slab[k + 1]] - pair_ptr[slab[k]]);
             int slab_max_n = 0; for (int p = slab[k]; p < slab[k + 1]; p++) slab_max_n = std::max(slab_max_n, pair_ptr[p + 1] - pair_ptr[p]);
             SSFM_HIP_CHECK(ctx, hipStreamWaitEvent(st, up_done[k % nslot], 0));
+            SSFM_HIP_CHECK(ctx, hipEventRecord(kt0[k % nslot], st));
             if (X && np > 0) hipLaunchKernelGGL(k_gather_rays, dim3(np), dim3(256), 0, st, s.ptr.p, s.off.p, s.idx.p, s.idx.p + cap_rays, frays.p, s.u.p, s.v.p);
             if (trace) {
                 const int r = lomsac_launch(ctx, st, np, slab_max_n, s.ptr.p, s.u.p, s.v.p, (int)nr, O, sq_thresh, dmt.p, glists ? s.lists.p : nullptr, s.E.p, s.S.p, s.R.p, s.mask.p, s.nin.p, s.stats.p);
@@ -387,6 +392,7 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
                                    s.lists.p, s.E.p, s.S.p, s.R.p, s.mask.p, s.nin.p);
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(s.stats.p, 0, (size_t)2 * np * sizeof(unsigned), st));
             }
+            SSFM_HIP_CHECK(ctx, hipEventRecord(kt1[k % nslot], st));
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.h_res, s.E.p, (size_t)9 * np * sizeof(double), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.h_res + 9 * (size_t)cap_pairs, s.R.p, (size_t)9 * np * sizeof(double), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(s.h_res + 18 * (size_t)cap_pairs, s.S.p, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -408,10 +414,17 @@ static int ransac_batch_impl(ssfm_ctx* ctx, int32_t num_pairs, const int32_t* pa
         if (s.h_uv) (void)hipHostFree(s.h_uv); if (s.h_ptr) (void)hipHostFree(s.h_ptr); if (s.h_res) (void)hipHostFree(s.h_res);
         if (s.h_mask) (void)hipHostFree(s.h_mask); if (s.h_nin) (void)hipHostFree(s.h_nin); if (s.h_stats) (void)hipHostFree(s.h_stats);
         if (up_done[b]) (void)hipEventDestroy(up_done[b]); if (compute_done[b]) (void)hipEventDestroy(compute_done[b]);
+        if (kt0[b]) (void)hipEventDestroy(kt0[b]); if (kt1[b]) (void)hipEventDestroy(kt1[b]);
     }
     dmt.free(); frays.free();
     if (cs) (void)hipStreamDestroy(cs);
     return rc;
+}
+
+extern "C" int ssfm_ransac_last_kernel_ms(ssfm_ctx* ctx, double* ms) {
+    if (!ctx || !ms) return SSFM_ERR_INVALID;
+    *ms = ctx->ransac_kernel_ms;
+    return SSFM_OK;
 }
 
 extern "C" int ssfm_ransac_batch_indexed(ssfm_ctx* ctx, int32_t num_frames, const int32_t* feat_ptr, const double* feat_rays, int32_t num_pairs,

@@ -26,6 +26,7 @@ struct ssfm_ctx {
     // coherent pinned block the LM loops publish their end-of-iteration scalars into (k_publish) + its sequence number; owned by the
     // context (one stream, solves run one after the other): a hipHostMalloc per handle cost 0.2 ms of a 3 ms solve
     double* host_pub = nullptr; unsigned long long pub_seq = 0;
+    double ransac_kernel_ms = 0.0;      // device time of the kernels of the last ssfm_ransac_batch* call (hipEvent brackets per slab), ssfm_ransac_last_kernel_ms
 };
 
 namespace ssfm {

@@ -68,6 +68,13 @@ def estimate_indexed(ctx, feat_ptr, feat_rays, pair_frame0, pair_frame1, match_p
     return dict(E=_unflat(E), R=_unflat(R), mask=mask[:int(mp[-1])], num_inliers=nin, scores=sc, iterations=st[0::2].copy(), lo_runs=st[1::2].copy())
 
 
+def last_kernel_ms(ctx):
+    """device time of the kernels of the context's last estimate_* call (ssfm_ransac_last_kernel_ms)"""
+    ms = C.c_double(0)
+    _lib.check(_lib.lib().ssfm_ransac_last_kernel_ms(ctx._p, C.byref(ms)), ctx._p)
+    return ms.value
+
+
 def solver_probe(ctx, u, v, samples, poly=False):
     """The minimal solver (action matrix, or the quartic variant with poly=True) on given 3-point samples ->
     list (per sample) of lists of E (3,3)."""
