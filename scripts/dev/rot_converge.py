@@ -17,7 +17,7 @@ for n in [int(a) for a in sys.argv[1:]] or [2000, 4000]:
     t = time.time(); Ro, co, so = O.optimize_rotations(R0.copy(), i0, i1, Rrel); to = time.time() - t
     O.pose_graph_test_options(0)
     ang = np.linalg.norm(Rotation.from_matrix(np.einsum('nij,nkj->nik', R, Ro)).as_rotvec(), axis=1)
-    print(f"n={n} gpu: it {s['iterations']} term {s['termination']} cost {c!r} {tg:.1f}s | oracle: it {so['iterations']} term {so['termination']} cost {co!r} {to:.1f}s | "
+    print(f"n={n} gpu: it {s['iterations']} (ok {s['num_successful_steps']}, rejected {s['num_unsuccessful_steps']}) term {s['termination']} cost {c!r} {tg:.1f}s | oracle: it {so['iterations']} term {so['termination']} cost {co!r} {to:.1f}s | "
           f"dcost/cost {abs(c - co) / co:.2e} max angle {ang.max():.2e} rad", flush=True)
     # cross starts: is each side's answer a minimum by the OTHER side's rules?  (a flat valley shows as: cost equal to rounding, rotations apart)
     t = time.time(); R2, c2, s2 = rotavg.optimize_rotations(ctx, Ro, i0, i1, Rrel, max_num_iterations=cap, **tol)

@@ -651,12 +651,20 @@ __device__ __forceinline__ void wave_lds_handover() {
 }
 // entry (r, i) of the unscaled 6-dof camera block that is zero by construction: d/dt = [a 0 -a x; 0 a -a y]
 template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i) { return DC == 6 && ((r == 0 && i == 1) || (r == 1 && i == 0)); }
-template <int DC, int NT, int TI = 0>
+// Round 5, FUSE (every point of the problem sits in a signature group): the kernel also does k_point_lin's work -- the lanes of a point fold their V = sum Jp^T Jp, g_p and
+// focal coupling over the K observation lanes (three xor exchanges), every lane damps and inverts the 3x3 block itself, lane 0 of the point stores the record PS and g_p
+// for the back substitution and the wave adds the five point-pass sums (cost, focal sums) and the gradient maximum to its scalar slot at the end.  k_point_lin does not
+// run then (15.5 us of a 173 us iteration at config 2, 180 of 1550 at the configs[4] size), PS is not read back and the observations are read one pass less.
+// spec (speculative launch behind k_publish, like k_point_lin's): [go, radius] as decided on the device.
+struct GramFuse { const double* scale_pt; double radius, min_diag, max_diag; double* PS_out; double* gp_out; double* scal; const double* spec; };
+template <int DC, int NT, int TI = 0, bool FUSE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // <= 256 registers (vector + accumulation): at one wave per SIMD config 2's 1800 tasks need two rounds
 k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
              const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
              const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int task0, double* __restrict__ S_val, double* __restrict__ rhs,
-             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg) {
+             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, GramFuse fz = GramFuse{}) {
+    double fz_radius = fz.radius;
+    if (FUSE && fz.spec) { if (fz.spec[0] == 0.0) return; fz_radius = fz.spec[1]; }
     constexpr int BB = DC * DC, off = (DC == 6) ? 0 : 3;                // NT = row tiles of 16 in use: the launch covers the tasks with 16 (NT - 1) < DC K <= 16 NT
     constexpr int NU = DC * (DC + 1) / 2, NS = NU + 3 * DC, NO = (NS + 7) / 8;          // camera-side sums: [Jc^T Jc (upper) | Jc^T r | -Jc^T Jp V^-1 g | Jc^T (J_f - Jp V^-1 w_f)]
     typedef double v4d_ __attribute__((ext_vector_type(4)));
@@ -704,12 +712,17 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
     const double sf = scale_f[0];
     // point record of a sub-chunk: X, the scaled V^-1 (6) with V^-1 g (3) and V^-1 w_f (3), this lane's observation
     double X[3], V[12]; double2 ob;
+    double spt[3] = {0.0, 0.0, 0.0};                                     // FUSE: Jacobi scales of the point (what k_point_lin read)
+    double pacc[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, pgmax = 0.0;             // FUSE: cost, FJJ, FJR, FWW, FWG of this lane; gradient maximum
 #define GRAM_LOAD(s0_)                                                                                                            \
     do {                                                                                                                          \
         const int q_ = min((s0_) + lp, cnt - 1);                                                                                  \
         _Pragma("unroll") for (int k = 0; k < 3; k++) X[k] = pts[3 * (size_t)(p0 + q_) + k];                                      \
+        if (FUSE) { _Pragma("unroll") for (int k = 0; k < 3; k++) spt[k] = fz.scale_pt[3 * (size_t)(p0 + q_) + k]; }              \
+        else {                                                                                                                    \
         _Pragma("unroll") for (int k = 0; k < 9; k++) V[k] = PS[12 * (size_t)(p0 + q_) + k];                                      \
         if (focal_free) { _Pragma("unroll") for (int k = 9; k < 12; k++) V[k] = PS[12 * (size_t)(p0 + q_) + k]; }                 \
+        }                                                                                                                         \
         ob = obs_xy[j00 + (size_t)q_ * K + kq];                                                                                   \
     } while (0)
     GRAM_LOAD(0);
@@ -718,6 +731,50 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
         wave_lds_handover();                                             // the tiles of the previous sub-chunk have read sY (first pass: sCam is written)
         {
             const bool valid = s0 + lp < cnt;
+            const double* crec = sCam + kq * GRAM_CAMREC;
+            ObsLin Lk; lin_obs<DC == 6>(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lk);
+            if (FUSE) {
+                // the point pass (k_point_lin): this lane's observation, folded over the K lanes of its point
+                const double wgt = (valid && lq < K) ? 1.0 : 0.0;
+                double pv[12];
+                {
+                    double j0[2], j1[2], j2[2], jf[2];
+#pragma unroll
+                    for (int a = 0; a < 2; a++) { j0[a] = Lk.Jp[a][0] * spt[0] * wgt; j1[a] = Lk.Jp[a][1] * spt[1] * wgt; j2[a] = Lk.Jp[a][2] * spt[2] * wgt; jf[a] = Lk.Jf[a] * sf * wgt; }
+                    pv[0] = j0[0] * j0[0] + j0[1] * j0[1]; pv[1] = j0[0] * j1[0] + j0[1] * j1[1]; pv[2] = j0[0] * j2[0] + j0[1] * j2[1];
+                    pv[3] = j1[0] * j1[0] + j1[1] * j1[1]; pv[4] = j1[0] * j2[0] + j1[1] * j2[1]; pv[5] = j2[0] * j2[0] + j2[1] * j2[1];
+                    pv[6] = j0[0] * Lk.r[0] + j0[1] * Lk.r[1]; pv[7] = j1[0] * Lk.r[0] + j1[1] * Lk.r[1]; pv[8] = j2[0] * Lk.r[0] + j2[1] * Lk.r[1];
+                    pv[9] = jf[0] * j0[0] + jf[1] * j0[1]; pv[10] = jf[0] * j1[0] + jf[1] * j1[1]; pv[11] = jf[0] * j2[0] + jf[1] * j2[1];
+                    pacc[0] += wgt * Lk.half_rho; pacc[1] += jf[0] * jf[0] + jf[1] * jf[1]; pacc[2] += jf[0] * Lk.r[0] + jf[1] * Lk.r[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 12; i++) { double t = pv[i]; t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64); pv[i] = t; }
+                double Vd[6] = {pv[0], pv[1], pv[2], pv[3], pv[4], pv[5]};
+                if (spt[0] > 0.0) {
+                    if (valid && lq == 0) pgmax = fmax(pgmax, fmax(fabs(pv[6] / spt[0]), fmax(fabs(pv[7] / spt[1]), fabs(pv[8] / spt[2]))));
+                    Vd[0] += fmin(fmax(Vd[0], fz.min_diag), fz.max_diag) / fz_radius;
+                    Vd[3] += fmin(fmax(Vd[3], fz.min_diag), fz.max_diag) / fz_radius;
+                    Vd[5] += fmin(fmax(Vd[5], fz.min_diag), fz.max_diag) / fz_radius;
+                } else { Vd[0] = Vd[3] = Vd[5] = 1.0; }                   // constant point: identity block, zero coupling
+                double Vi[6]; sym3_inverse(Vd, Vi);
+                const double u0 = pv[9] * Vi[0] + pv[10] * Vi[1] + pv[11] * Vi[2];
+                const double u1 = pv[9] * Vi[1] + pv[10] * Vi[3] + pv[11] * Vi[4];
+                const double u2 = pv[9] * Vi[2] + pv[10] * Vi[4] + pv[11] * Vi[5];
+                V[0] = Vi[0] * spt[0] * spt[0]; V[1] = Vi[1] * spt[0] * spt[1]; V[2] = Vi[2] * spt[0] * spt[2];
+                V[3] = Vi[3] * spt[1] * spt[1]; V[4] = Vi[4] * spt[1] * spt[2]; V[5] = Vi[5] * spt[2] * spt[2];
+                V[6] = spt[0] * (Vi[0] * pv[6] + Vi[1] * pv[7] + Vi[2] * pv[8]); V[7] = spt[1] * (Vi[1] * pv[6] + Vi[3] * pv[7] + Vi[4] * pv[8]);
+                V[8] = spt[2] * (Vi[2] * pv[6] + Vi[4] * pv[7] + Vi[5] * pv[8]);
+                V[9] = spt[0] * u0; V[10] = spt[1] * u1; V[11] = spt[2] * u2;
+                if (valid && lq == 0) {
+                    pacc[3] += u0 * pv[9] + u1 * pv[10] + u2 * pv[11];
+                    pacc[4] += u0 * pv[6] + u1 * pv[7] + u2 * pv[8];
+                    double* ps = fz.PS_out + 12 * (size_t)(p0 + s0 + lp);
+#pragma unroll
+                    for (int k = 0; k < 12; k++) ps[k] = V[k];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) fz.gp_out[3 * (size_t)(p0 + s0 + lp) + k] = pv[6 + k];
+                }
+            }
             // Cholesky factor of the scaled V^-1 (all zero for a fixed point or a lane past the end of the task: its columns of Y are zero)
             double L00 = 0, L10 = 0, L20 = 0, L11 = 0, L21 = 0, L22 = 0;
             if (valid && V[0] > 0.0) {
@@ -731,8 +788,6 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
                     if (d2 > 0.0) L22 = d2 * fast_rsqrt(d2);
                 }
             }
-            const double* crec = sCam + kq * GRAM_CAMREC;
-            ObsLin Lk; lin_obs<DC == 6>(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lk);
             double Jc[2][DC]; cam_block_raw<DC>(Lk, Jc);
             double T[2][3];
 #pragma unroll
@@ -891,6 +946,14 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
                 }
             }
         }
+    }
+    if (FUSE) {                                                          // the point pass's sums and gradient maximum, one wave = one scalar slot (k_point_lin's rule)
+        const double t = wave_transpose_sum(pacc);
+        pgmax = wave_max(pgmax);
+        const int slot = wave_tr_index();
+        double* sl = fz.scal + (size_t)(task & (SC_NSLOT - 1)) * SC_TOTAL;
+        if (slot < 5) unsafeAtomicAdd(&sl[slot], t);
+        if (lane == 0 && pgmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], pgmax);
     }
     if (dbg && lane == 0) { long long* d = dbg + 4 * (size_t)task; d[0] = t_0; d[1] = t_1; d[2] = t_2; d[3] = wall_clock64(); }   // SSFM_GRAM_STAMPS (timing study)
 }

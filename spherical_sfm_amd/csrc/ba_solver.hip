@@ -104,6 +104,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
     const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
     bool lin_done = false, spec_launched = false;
+    // Round 5: when every point sits in a signature group, k_schur_gram does the point pass itself (ba_kernels.h: FUSE) and k_point_lin does not run; the speculative
+    // launch behind k_publish is then the Gram kernel of the NEXT iteration, accumulating into the next zone.  SSFM_GRAM_FUSE=0 keeps the separate point pass.
+    static const bool gram_fuse_env = !(std::getenv("SSFM_GRAM_FUSE") && std::atoi(std::getenv("SSFM_GRAM_FUSE")) == 0);
+    const bool fuse_lin = gram_fuse_env && nP > 0 && !F.gr_rec.empty() && F.gram_points == (int64_t)nP && F.chunk_cam.empty() && F.cs_task_cam.empty();
+    struct ZonePtrs { double *scal, *S_val, *rhs, *Udiag, *Sfc, *gcraw; };
+    auto zone_ptrs = [&](int which) { ZonePtrs z; z.scal = h->zone.p + (size_t)which * h->zone_len; double* red = z.scal + h->scal.n + h->pcg.n;
+                                      z.S_val = red; z.rhs = z.S_val + h->zone_nnz; z.Udiag = z.rhs + (h->zone_n + 1); z.Sfc = z.Udiag + h->zone_n; z.gcraw = z.Sfc + h->zone_n; return z; };
     // EXPERIMENT, off (SSFM_PUBLISH_FUSED=1): the end-of-iteration hand-over in the last workgroup of k_point_backsub (arrival ticket) instead of a k_publish
     // launch.  Measured: k_point_backsub 22.8 -> 55.9 us at config 2 and 380 -> 1290 us at the configs[4] size -- every workgroup needs an agent-scope release
     // fence (an L2 write-back on this multi-XCD part) + a same-address atomic before it may leave, which costs far more than the 4.7 us launch it saves.
@@ -135,10 +142,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         // per-kernel profiling: the first launch after the host's hand-over would carry the queue's wake-up inside its event bracket (k_point_lin read 25.7 us
         // against 14.7 us under rocprofv3); an empty launch takes that, the bracket of the real kernel then starts behind it like every other one
         if (h->profile && nP > 0 && !lin_done) hipLaunchKernelGGL(k_profile_pad, dim3(1), dim3(64), 0, st);
-        if (nP > 0 && !lin_done)             // (lin_done: it ran speculatively behind the previous iteration, with this radius)
+        if (nP > 0 && !lin_done && !fuse_lin)             // (lin_done: it ran speculatively behind the previous iteration, with this radius)
             LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, h->scal.p, (const double*)nullptr);
-        lin_done = false;
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         if (!F.cs_task_cam.empty()) {
             const int ntasks = (int)F.cs_task_cam.size();
@@ -156,7 +162,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
-        if (!F.gr_rec.empty()) {                                   // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram)
+        // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram); one launch per tile class.  xc / xr / xp / xf = the state it linearises at,
+        // z = the zone it accumulates into, spec = device-side [go, radius] of a speculative launch (fused point pass only)
+        auto launch_gram = [&](const double* xc, const double* xr, const double* xp, const double* xf, const ZonePtrs& z, double rad, const double* spec) -> int {
             const int ng = (int)(F.gr_rec.size() / GRAM_REC);
             static bool gram_stamps_done = std::getenv("SSFM_GRAM_STAMPS") == nullptr;      // timing study: per-task phase stamps of the first launch
             long long* gram_dbg = nullptr;
@@ -168,30 +176,38 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             auto tile_class = [&](int K) { const int rows = DC * K; return rows <= 16 ? 0 : (rows <= 20 && gram_t4) ? 1 : rows <= 32 ? 2 : (rows <= 36 && gram_t4) ? 3 : 4; };
             int cls_end[5] = {0, 0, 0, 0, 0};
             for (int t = 0; t < ng; t++) { const int c0 = tile_class(F.gr_rec[(size_t)t * GRAM_REC + 2]); for (int c = c0; c < 5; c++) cls_end[c] = t + 1; }
-#define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_)                                                                                                               \
+            GramFuse fz; fz.scale_pt = h->scale_pt.p; fz.radius = rad; fz.min_diag = O.min_lm_diagonal; fz.max_diag = O.max_lm_diagonal; fz.PS_out = h->Vs.p; fz.gp_out = h->gp.p; fz.scal = z.scal; fz.spec = spec;
+#define SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, FUSE_)                                                                                                       \
             do {                                                                                                                                       \
                 const int t0 = (CLS_ == 0) ? 0 : cls_end[(CLS_ >= 1) ? CLS_ - 1 : 0], t1 = cls_end[CLS_];                                             \
                 if (t1 > t0) {                                                                                                                         \
                     const int rows_alloc = DC * F.gr_rec[(size_t)(t1 - 1) * GRAM_REC + 2];              /* the largest K of the class: its last task */ \
                     const size_t gram_lds = (size_t)gram_waves * ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);                          \
                     if (gram_lds > 48 * 1024)                                                                                                          \
-                        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_, TI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
-                    LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_, TI_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, cam_x, rot_x, pts_x, fx, oxy, t1, h->gr_rec.p,  \
-                           h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, h->S_val, h->rhs, h->Udiag, h->Sfc, h->gcraw, gram_dbg);  \
+                        SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_, TI_, FUSE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
+                    LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_, TI_, FUSE_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, xc, xr, xp, xf, oxy, t1, h->gr_rec.p,  \
+                           h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw, gram_dbg, fz);  \
                 }                                                                                                                                      \
             } while (0)
+#define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) do { if (fuse_lin) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, true); else SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false); } while (0)
             SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
             if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
 #undef SSFM_GRAM_LAUNCH
+#undef SSFM_GRAM_LAUNCH_
             if (gram_dbg) {                                        // print the phase times of this launch (100 MHz clock) and stop stamping
-                std::vector<long long> st((size_t)4 * ng); (void)hipStreamSynchronize(h->ctx->stream); (void)hipMemcpy(st.data(), gram_dbg, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
-                long long tmin = st[0], tmax = 0; double a = 0, b = 0, c = 0;
-                for (int t = 0; t < ng; t++) { tmin = std::min(tmin, st[4 * t]); tmax = std::max(tmax, st[4 * t + 3]); a += st[4 * t + 1] - st[4 * t]; b += st[4 * t + 2] - st[4 * t + 1]; c += st[4 * t + 3] - st[4 * t + 2]; }
+                std::vector<long long> st2((size_t)4 * ng); (void)hipStreamSynchronize(h->ctx->stream); (void)hipMemcpy(st2.data(), gram_dbg, st2.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                long long tmin = st2[0], tmax = 0; double a = 0, b = 0, c = 0;
+                for (int t = 0; t < ng; t++) { tmin = std::min(tmin, st2[4 * t]); tmax = std::max(tmax, st2[4 * t + 3]); a += st2[4 * t + 1] - st2[4 * t]; b += st2[4 * t + 2] - st2[4 * t + 1]; c += st2[4 * t + 3] - st2[4 * t + 2]; }
                 std::fprintf(stderr, "[gram] %d tasks, kernel span %.1f us; mean per task: start + first linearisation %.2f us, tiles + other sub-chunks %.2f us, emission %.2f us\n", ng, (tmax - tmin) * 0.01,
                              a / ng * 0.01, b / ng * 0.01, c / ng * 0.01);
                 (void)hipFree(gram_dbg); gram_dbg = nullptr; gram_stamps_done = true;
             }
+            return SSFM_OK;
+        };
+        if (!F.gr_rec.empty() && !(fuse_lin && lin_done)) {          // (fused + lin_done: the whole assembly of this iteration ran speculatively behind the previous one)
+            const int rc = launch_gram(cam_x, rot_x, pts_x, fx, zone_ptrs(iteration & 1), radius, nullptr); if (rc) return rc;
         }
+        lin_done = false;
         if (y_probe && !F.chunk_cam.empty()) {                     // experiment only (ba_kernels.h: k_pairs_y_probe)
             const int ntasks = (int)F.chunk_cam.size();
             hipLaunchKernelGGL(k_pairs_y_probe<DC>, dim3((ntasks + 3) / 4), dim3(256), 0, st, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, ntasks,
@@ -310,7 +326,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[4], st));
         // (otherwise) the next iteration's zone is cleared while the host wakes up and decides
         if (!clear_in_finalize) SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
-        if (spec_launched)                   // x = this iteration's candidate, scalars into the next zone (scal is its first block)
+        if (spec_launched && fuse_lin) { const int rc = launch_gram(cam_c, rot_c, pts_c, fc, zone_ptrs((iteration + 1) & 1), radius, (const double*)h->lmdev.p); if (rc) return rc; }
+        else if (spec_launched)              // x = this iteration's candidate, scalars into the next zone (scal is its first block)
             LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
                    h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, next_zone, (const double*)h->lmdev.p);
         { int rc = wait_iteration(); if (rc) return rc; }
