@@ -732,20 +732,22 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
         {
             const bool valid = s0 + lp < cnt;
             const double* crec = sCam + kq * GRAM_CAMREC;
-            ObsLin Lk; lin_obs<DC == 6>(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lk);
             if (FUSE) {
-                // the point pass (k_point_lin): this lane's observation, folded over the K lanes of its point
+                // the point pass (k_point_lin): this lane's observation through the point-side view of the linearisation FIRST (r, J_f, J_p: 11 values; the camera blocks
+                // are formed afterwards, so that they are not alive during the fold -- together with the 39 camera sums and the tile accumulators they spilled 49-80 registers),
+                // folded over the K lanes of its point
                 const double wgt = (valid && lq < K) ? 1.0 : 0.0;
                 double pv[12];
                 {
+                    ObsPoint Lp; lin_obs_point(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lp);
                     double j0[2], j1[2], j2[2], jf[2];
 #pragma unroll
-                    for (int a = 0; a < 2; a++) { j0[a] = Lk.Jp[a][0] * spt[0] * wgt; j1[a] = Lk.Jp[a][1] * spt[1] * wgt; j2[a] = Lk.Jp[a][2] * spt[2] * wgt; jf[a] = Lk.Jf[a] * sf * wgt; }
+                    for (int a = 0; a < 2; a++) { j0[a] = Lp.Jp[a][0] * spt[0] * wgt; j1[a] = Lp.Jp[a][1] * spt[1] * wgt; j2[a] = Lp.Jp[a][2] * spt[2] * wgt; jf[a] = Lp.Jf[a] * sf * wgt; }
                     pv[0] = j0[0] * j0[0] + j0[1] * j0[1]; pv[1] = j0[0] * j1[0] + j0[1] * j1[1]; pv[2] = j0[0] * j2[0] + j0[1] * j2[1];
                     pv[3] = j1[0] * j1[0] + j1[1] * j1[1]; pv[4] = j1[0] * j2[0] + j1[1] * j2[1]; pv[5] = j2[0] * j2[0] + j2[1] * j2[1];
-                    pv[6] = j0[0] * Lk.r[0] + j0[1] * Lk.r[1]; pv[7] = j1[0] * Lk.r[0] + j1[1] * Lk.r[1]; pv[8] = j2[0] * Lk.r[0] + j2[1] * Lk.r[1];
+                    pv[6] = j0[0] * Lp.r[0] + j0[1] * Lp.r[1]; pv[7] = j1[0] * Lp.r[0] + j1[1] * Lp.r[1]; pv[8] = j2[0] * Lp.r[0] + j2[1] * Lp.r[1];
                     pv[9] = jf[0] * j0[0] + jf[1] * j0[1]; pv[10] = jf[0] * j1[0] + jf[1] * j1[1]; pv[11] = jf[0] * j2[0] + jf[1] * j2[1];
-                    pacc[0] += wgt * Lk.half_rho; pacc[1] += jf[0] * jf[0] + jf[1] * jf[1]; pacc[2] += jf[0] * Lk.r[0] + jf[1] * Lk.r[1];
+                    pacc[0] += wgt * Lp.half_rho; pacc[1] += jf[0] * jf[0] + jf[1] * jf[1]; pacc[2] += jf[0] * Lp.r[0] + jf[1] * Lp.r[1];
                 }
 #pragma unroll
                 for (int i = 0; i < 12; i++) { double t = pv[i]; t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64); pv[i] = t; }
@@ -775,6 +777,7 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
                     for (int k = 0; k < 3; k++) fz.gp_out[3 * (size_t)(p0 + s0 + lp) + k] = pv[6 + k];
                 }
             }
+            ObsLin Lk; lin_obs<DC == 6>(f, crec, crec + 6, X, ob.x, ob.y, loss, la, Lk);
             // Cholesky factor of the scaled V^-1 (all zero for a fixed point or a lane past the end of the task: its columns of Y are zero)
             double L00 = 0, L10 = 0, L20 = 0, L11 = 0, L21 = 0, L22 = 0;
             if (valid && V[0] > 0.0) {

@@ -104,9 +104,12 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
     const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
     bool lin_done = false, spec_launched = false;
-    // Round 5: when every point sits in a signature group, k_schur_gram does the point pass itself (ba_kernels.h: FUSE) and k_point_lin does not run; the speculative
-    // launch behind k_publish is then the Gram kernel of the NEXT iteration, accumulating into the next zone.  SSFM_GRAM_FUSE=0 keeps the separate point pass.
-    static const bool gram_fuse_env = !(std::getenv("SSFM_GRAM_FUSE") && std::atoi(std::getenv("SSFM_GRAM_FUSE")) == 0);
+    // Round 5 EXPERIMENT, off (SSFM_GRAM_FUSE=1): when every point sits in a signature group, k_schur_gram does the point pass itself (ba_kernels.h: FUSE) and k_point_lin
+    // does not run; the speculative launch behind k_publish is then the Gram kernel of the NEXT iteration, accumulating into the next zone.  Correct (parity 3e-11, same
+    // iterations) and SLOWER: 97.6 us against 43.7 + 18.3 at config 2, 1357 against 409 + 179 at the configs[4] size -- the Gram kernel sits at its register limit
+    // (256 at two waves per SIMD: 39 camera sums, the tile accumulators, one observation's linearisation) and the point pass's fold spills 43-80 of them to scratch
+    // (profiles/r05_notes.md).  One launch less is not worth a kernel that leaves its registers.
+    static const bool gram_fuse_env = std::getenv("SSFM_GRAM_FUSE") && std::atoi(std::getenv("SSFM_GRAM_FUSE")) != 0;
     const bool fuse_lin = gram_fuse_env && nP > 0 && !F.gr_rec.empty() && F.gram_points == (int64_t)nP && F.chunk_cam.empty() && F.cs_task_cam.empty();
     struct ZonePtrs { double *scal, *S_val, *rhs, *Udiag, *Sfc, *gcraw; };
     auto zone_ptrs = [&](int which) { ZonePtrs z; z.scal = h->zone.p + (size_t)which * h->zone_len; double* red = z.scal + h->scal.n + h->pcg.n;

@@ -180,7 +180,7 @@ PAIR_CASES = [  # (correspondences, outlier fraction, noise, rotation, kwargs of
     (300, 0.30, 1 / 600, 18, dict(use_poly=True)),
     (300, 0.30, 1 / 600, 18, dict(use_poly=True, num_lo_steps=10, num_lsq_iterations=4)),
     (400, 0.80, 1 / 600, 10, dict(num_lo_steps=10, num_lsq_iterations=4, success_probability=0.99)),
-    (1000, 0.40, 1 / 600, 40, dict(num_lo_steps=10, num_lsq_iterations=4, min_sample_multiplicator=3, non_min_sample_multiplier=5, threshold_multiplier=2.0)),
+    (1000, 0.40, 1 / 600, 40, dict(num_lo_steps=10, num_lsq_iterations=4, min_sample_multiplicator=3, non_min_sample_multiplier=2, threshold_multiplier=2.0)),
     (250, 0.95, 1 / 600, 10, dict(num_lo_steps=10, num_lsq_iterations=4, max_iterations=300)),  # hardly any consensus: the iteration cap ends it
     (500, 0.30, 1 / 600, 12, dict(inward=True, num_lo_steps=10, num_lsq_iterations=4)),
 ]

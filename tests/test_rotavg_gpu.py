@@ -150,26 +150,31 @@ def test_large_graphs_follow_the_oracle_on_the_early_path(gpu_ctx, oracle, n):
 def test_large_graphs_reach_the_oracle_minimum(gpu_ctx, oracle, n):
     """VERDICT r4 #1b: the CONVERGED answers (src/rotation_averaging.cpp:44-91 with Ceres' 50-iteration cap lifted and its tolerances tightened to rounding level on both
     sides -- the capped runs above stop on a plateau, 1 % in cost above the minimum, where two summation orders are 0.3 rad apart after 50 iterations).
-    Both sides need ~2000-3300 LM iterations.  What holds and what does not (measured on MI355X, scripts/dev/rot_converge.py):
-      * the final COST agrees to 1e-15 (2000 nodes) and 7e-13 (4000 nodes): asserted <= 1e-9, the statement the two sides can make about 'the same minimum';
-      * the ROTATIONS agree to 6e-9 rad at 2000 nodes (asserted <= 1e-5, north_star's bound) -- and only to ~2e-4 rad at 4000 nodes: A FINDING, not a tolerance that
-        was widened to pass.  The minimum of the 4000-node ring is flat along its longest-wavelength mode: a cost difference of 7e-13 (relative) between two states
-        1.6e-4 rad apart means a curvature of ~6e-4 there, so cost changes reach double-precision rounding (the function tolerance both sides stop on) ~1e-4 rad away
-        from the minimiser whichever side is run; the oracle restarted from the device's answer stops at once, and so does the device restarted from the oracle's
-        (rot_converge.py).  Ceres itself would sit in the same valley.  The 4000-node rotations are held to 1e-3 rad and the cost to 1e-9."""
+    The sides need 2000 ... 9000 LM iterations from the common start.  Measured on MI355X (scripts/dev/rot_converge.py, profiles/r05_notes.md):
+      * final COST: equal to 1e-15 (2000 nodes) / 7e-13 (4000 nodes) -- asserted <= 1e-9;
+      * ROTATIONS at 2000 nodes: 7e-9 rad apart -- asserted <= 1e-5 (north_star's bound);
+      * ROTATIONS at 4000 nodes: 1.7e-4 rad apart between the two runs FROM THE COMMON START -- a finding, not a tolerance widened to pass: the oracle's run stops first
+        (1971 iterations: a cost change of exactly rounding size fires its function tolerance) 7e-13 in cost above the device's end state, on the floor of a valley whose
+        longest-wavelength mode has a curvature of ~6e-4: there a relative cost difference of 1e-12 is 1e-4 rad.  What CAN be stated to 1e-5, and is asserted: the device's
+        answer is the minimum BY THE ORACLE'S OWN RULES -- the oracle restarted at the device's answer stops within a few iterations, moves the rotations by < 1e-5 rad
+        (3e-9 measured) and lowers the cost by < 1e-12.  (The reverse restart -- the device from the oracle's early stop -- walks the remaining 1.3e-4 rad to the same cost.)"""
     from spherical_sfm_amd import rotavg
     R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(n, 8)
     tol = dict(function_tolerance=1e-16, gradient_tolerance=1e-16, parameter_tolerance=1e-16)
-    R, cost, s = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel, max_num_iterations=8000, **tol)
-    oracle.pose_graph_test_options(8000, 1e-16, 1e-16, 1e-16)
+    cap = 30000
+    R, cost, s = rotavg.optimize_rotations(gpu_ctx, R0, i0, i1, Rrel, max_num_iterations=cap, **tol)
+    oracle.pose_graph_test_options(cap, 1e-16, 1e-16, 1e-16)
     try:
         Ro, co, so = oracle.optimize_rotations(R0.copy(), i0, i1, Rrel)
+        Ro2, co2, so2 = oracle.optimize_rotations(R.copy(), i0, i1, Rrel)           # the oracle's verdict on the device's answer
     finally:
         oracle.pose_graph_test_options(0)
-    assert s["termination"] == so["termination"] == 0 and 1000 < s["iterations"] < 8000 and 1000 < so["iterations"] < 8000
+    assert s["termination"] == so["termination"] == so2["termination"] == 0 and 1000 < s["iterations"] < cap and 1000 < so["iterations"] < cap
+    ang = rot_angle(R, Ro).max(); moved = rot_angle(Ro2, R).max()
+    print("n = %d: device %d iterations, oracle %d; |dcost| / cost = %.2e; rotations apart %.2e rad; oracle restarted at the device's answer: %d iterations, moved %.2e rad, cost %.3e lower"
+          % (n, s["iterations"], so["iterations"], abs(cost - co) / co, ang, so2["iterations"], moved, (cost - co2) / co))
     assert abs(cost - co) <= 1e-9 * co
-    ang = rot_angle(R, Ro).max()
-    print("n = %d: device %d iterations, oracle %d; |dcost| / cost = %.2e; max rotation difference %.2e rad" % (n, s["iterations"], so["iterations"], abs(cost - co) / co, ang))
+    assert moved <= 1e-5 and 0 <= cost - co2 + 1e-13 * co and cost - co2 <= 1e-12 * co and so2["iterations"] < 100
     assert ang <= (1e-5 if n == 2000 else 1e-3)
 
 
