@@ -436,9 +436,19 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     if (lt > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_tail<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt));
                     const int nsteps = (int)B.ring_step_ptr.size() - 1;
                     const int cr_threads = Q > 48 ? 1024 : 512;            // (rows of the tall factorisation: 3 Q + 2 <= 256 either way; fewer waves make cheaper barriers)
+                    // SSFM_RING_STAMPS=1 (timing study): phase stamps of every elimination of the first solve, printed once: [loads | factorisation | stores + products]
+                    static int ring_stamp_state = std::getenv("SSFM_RING_STAMPS") ? 1 : 0; static long long* ring_stamps = nullptr;
+                    if (ring_stamp_state == 1) { (void)hipMalloc((void**)&ring_stamps, (size_t)4 * B.nsep * sizeof(long long)); (void)hipMemsetAsync(ring_stamps, 0, (size_t)4 * B.nsep * sizeof(long long), st); ring_stamp_state = 2; }
                     for (int sidx = 0; sidx < nsteps; sidx++)
                         LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], cr_threads, le, h->ring_rec.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
-                               h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Nc, b, failp);
+                               h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Nc, b, failp, ring_stamp_state == 2 ? ring_stamps : (long long*)nullptr);
+                    if (ring_stamp_state == 2) {
+                        std::vector<long long> hs((size_t)4 * B.nsep); (void)hipStreamSynchronize(st); (void)hipMemcpy(hs.data(), ring_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                        double a = 0, bb = 0, c = 0; int cnt = 0;
+                        for (int q = 0; q < B.nsep; q++) if (hs[4 * q + 3] > 0) { a += hs[4 * q + 1] - hs[4 * q]; bb += hs[4 * q + 2] - hs[4 * q + 1]; c += hs[4 * q + 3] - hs[4 * q + 2]; cnt++; }
+                        if (cnt) std::fprintf(stderr, "[ring stamps, 100 MHz ticks] Q = %d, %d eliminations (parallel steps): loads %.0f | factorisation %.0f | stores + neighbour products %.0f\n", Q, cnt, a / cnt, bb / cnt, c / cnt);
+                        (void)hipFree(ring_stamps); ring_stamps = nullptr; ring_stamp_state = 3;
+                    }
                     LAUNCH(h, KID_RING_TAIL, (k_ring_cr_tail<DC, 2>), B.nring, cr_threads, lt, h->ring_rec.p, h->ring_tail.p, h->subZ.p, h->subD.p, h->subT.p,
                            h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Y, Nc, b, failp);
                     for (int sidx = nsteps - 1; sidx >= 0; sidx--)

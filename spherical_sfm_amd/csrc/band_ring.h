@@ -50,8 +50,10 @@ __device__ __forceinline__ v4d_t ring_tile_lds(const double* __restrict__ P, con
 template <int DC, int NR>
 __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
                                                double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT,
-                                               double* __restrict__ crE, const int N, const int b, int* __restrict__ fail_flag, double* __restrict__ T) {
+                                               double* __restrict__ crE, const int N, const int b, int* __restrict__ fail_flag, double* __restrict__ T,
+                                               long long* __restrict__ stamps = nullptr) {      // stamps: SSFM_RING_STAMPS timing study (ba_handle.h), null otherwise
     constexpr int NB = DC;
+    const long long ts0 = stamps ? wall_clock64() : 0;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int v = r[0], nn = r[1], hasL = r[2], hasR = r[3];
     const size_t QQ = (size_t)Q * Q;                              // T rows [0, Q): A; [Q + j Q, ..): B_j; [3 Q, 3 Q + NR): t^T
@@ -90,7 +92,11 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
             }
         }
     }
-    // ---- phase 2: tall right-looking Cholesky, NB columns per pass; rows [Q, 3 Q + NR) are panel rows only
+    const long long ts1 = stamps ? wall_clock64() : 0;
+    // ---- phase 2: tall right-looking Cholesky, NB columns per pass; rows [Q, 3 Q + NR) are panel rows only.
+    // (Measured and dropped, profiles/r05_notes.md r05h: a look-ahead wave that factors the next diagonal block during the trailing update -- 33.9 against 34.2 us per
+    //  elimination at Q = 42; four rows per thread in the trailing update + all loads of phase 0 issued up front -- 36.7 us.  Phase stamps at Q = 42 / 78: loads 6.9 / 9.5 us,
+    //  this phase 12.6 / 41.9 us, stores + the neighbours' products 9.2 / 14.2 us.)
     const int tx = tid & 255, ty = tid >> 8, nty = nt >> 8;
     const int R_all = 3 * Q + NR;
     const bool row_ok = tx < Q || (tx < 3 * Q && (tx - Q) / Q < nn) || (tx >= 3 * Q && tx < R_all);
@@ -137,6 +143,7 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
         }
     }
     __syncthreads();
+    const long long ts2 = stamps ? wall_clock64() : 0;
     // ---- phase 3: L (diagonal blocks hold G = L_blk^-1), F_j, w for the way back; the neighbours' Schur updates and the fill between them, from the F rows in LDS
     for (int e = tid; e < Q * Q; e += nt) {
         const int i = e / Q, c = e - i * Q;
@@ -182,6 +189,7 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
             *d = q[14] ? *d + a : a;
         }
     }
+    if (stamps && tid == 0) { long long* d = stamps + 4 * (size_t)v; d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64(); }
 }
 
 // ---- back substitution of one separator by the whole workgroup: x_v = L^-T (w - sum_j F_j^T x_{u_j}) -> Y rows of v (and of its copy slot); LDS: ring_back_lds_bytes
@@ -244,9 +252,9 @@ template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
 k_ring_cr_elim(const int* __restrict__ rec, int rec0, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
                double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT, double* __restrict__ crE,
-               int N, int b, int* __restrict__ fail_flag) {
+               int N, int b, int* __restrict__ fail_flag, long long* __restrict__ stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    ring_elim_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds);
+    ring_elim_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds, stamps);
 }
 template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
