@@ -28,6 +28,7 @@
 #include <vector>
 #include "../../include/ssfm.h"
 #include "ring_comp.h"
+#include "knobs.h"
 
 namespace ssfm {
 
@@ -167,7 +168,7 @@ inline PlanPool& plan_pool() {
 template <class Fn>
 inline void parallel_chunks(int64_t n, int T, Fn f) {
     if (T <= 1 || n < 4 * (int64_t)T) { f(0, (int64_t)0, n); return; }
-    static const bool use_pool = !(std::getenv("SSFM_PLAN_POOL") && std::atoi(std::getenv("SSFM_PLAN_POOL")) == 0);
+    static const bool use_pool = SSFM_LAB_KNOB("SSFM_PLAN_POOL", 1) != 0;
     if (use_pool) { plan_pool().run(T, [&](int t) { f(t, n * t / T, n * (t + 1) / T); }); return; }
     std::vector<std::thread> th; th.reserve(T);
     for (int t = 0; t < T; t++) th.emplace_back([=]() { f(t, n * t / T, n * (t + 1) / T); });

@@ -16,6 +16,7 @@
 #include "band_sub.h"
 #include "band_ring.h"
 #include "ssfm_ctx.h"
+#include "knobs.h"
 
 namespace ssfm {
 
@@ -302,14 +303,14 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
     const int tr_waves_split = (std::max(blk_tasks, 1) + 63) / 64 + (rhs_tasks + 63) / 64, tr_waves_packed = (blk_tasks + rhs_tasks + 63) / 64;
     const int chol_ntw = std::min(std::max(tr_waves_split <= 7 ? tr_waves_split : tr_waves_packed, 1), 7);
     const int chol_threads = 64 * (2 + CHOL2_LOADERS + chol_ntw);
-    static const bool chol_remap = !(std::getenv("SSFM_CHOL_WAVE_MAP") && std::atoi(std::getenv("SSFM_CHOL_WAVE_MAP")) == 0);
+    static const bool chol_remap = SSFM_LAB_KNOB("SSFM_CHOL_WAVE_MAP", 1) != 0;
     const CholWaveMap chol_map = chol_remap ? chol_wave_map(chol_threads / 64, chol_ntw, tr_waves_split <= 7 ? (std::max(blk_tasks, 1) + 63) / 64 : chol_ntw)
                                             : chol_wave_map(0, 0, 0);
     const size_t lds_chol = (size_t)(2 * BB + 2 * DC + (size_t)b * BB) * sizeof(double);
     const size_t lds_sub2 = (size_t)(2 * (size_t)b * 2 * DC + 2 * DC) * sizeof(double);
     // matrix-core panel + trailing update (band_kernels2.h, MF): 6x6 blocks only; SSFM_BAND_MFMA=0 keeps the VALU version
-    static const int band_mfma_env = std::getenv("SSFM_BAND_MFMA") ? std::atoi(std::getenv("SSFM_BAND_MFMA")) : 0;      // bit 0: panel, bit 1: trailing update (experiment)
-    constexpr int MFP = (DC == 6) ? 1 : 0, MFT = (DC == 6) ? 2 : 0, MFB = (DC == 6) ? 3 : 0;
+    static const int band_mfma_env = SSFM_LAB_KNOB("SSFM_BAND_MFMA", 0);      // bit 0: panel, bit 1: trailing update (experiment)
+    constexpr int MFP = (DC == 6) ? 1 : 0, MFT = (DC == 6) ? 2 : 0, MFB = (DC == 6) ? 3 : 0; (void)MFP; (void)MFT; (void)MFB;
     const int mf = (DC == 6 && b * DC <= 127) ? (band_mfma_env & 3) : 0;
 #define SSFM_LAUNCH_CHOL2_V(V_, grid_, ...)                                                                                                 \
     do { if (lds_win > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_chol_v2<DC, 2, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win)); \
@@ -332,33 +333,45 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
     // early look-ahead (band_kernels2.h, MF bit 2; experiment, off): the look-ahead wave computes X_1 and the update of the next diagonal block before barrier A.  Measured
     // in the lab (scripts/lab/chol_lab3.hip, same run): 89.8 against 79.9 us for 4 x 75 rows at half-width 10, 106.2 / 98.3 at 12, 124.9 / 123.2 at 14 -- once the pivot test
     // left the factorisation's chain the step is bound by the trailing waves, and the longer stretch in front of barrier A only delays them.  SSFM_BAND_EARLY=1 selects it.
-    static const bool early_on = std::getenv("SSFM_BAND_EARLY") && std::atoi(std::getenv("SSFM_BAND_EARLY")) != 0;
+    static const bool early_on = SSFM_LAB_KNOB("SSFM_BAND_EARLY", 0) != 0;
     const bool early = early_on && mf == 0 && b * BB <= BB + chol_threads - 64;
+#ifdef SSFM_LAB
 #define SSFM_LAUNCH_CHOL2(grid_, ...)                                                                                                       \
     do { if (early) SSFM_LAUNCH_CHOL2_V(4, grid_, __VA_ARGS__); else if (mf == 3) SSFM_LAUNCH_CHOL2_V(MFB, grid_, __VA_ARGS__); else if (mf == 2) SSFM_LAUNCH_CHOL2_V(MFT, grid_, __VA_ARGS__);          \
          else if (mf == 1) SSFM_LAUNCH_CHOL2_V(MFP, grid_, __VA_ARGS__); else SSFM_LAUNCH_CHOL2_V(0, grid_, __VA_ARGS__); } while (0)
+#else       // the shipped library holds the VALU factorisation only: the matrix-core panel / trailing update and the early look-ahead were measured slower
+#define SSFM_LAUNCH_CHOL2(grid_, ...) do { (void)early; (void)mf; SSFM_LAUNCH_CHOL2_V(0, grid_, __VA_ARGS__); } while (0)
+#endif
         if (h->sub.enabled && (use_lds || wide2p) && back_v2) {
             // substructured: segments in parallel, spikes, separator chain, back substitution (band_sub.h)
             const BandSub& B = h->sub;
             const int Q = b * DC;
             // a second packed triangle when it fits (Q <= 96): the chain kernel then brings the next separator's D in while it factors this one (band_sub.h: pingpong)
-            static const bool chain_pp_on = !(std::getenv("SSFM_CHAIN_PINGPONG") && std::atoi(std::getenv("SSFM_CHAIN_PINGPONG")) == 0);
+            static const bool chain_pp_on = SSFM_LAB_KNOB("SSFM_CHAIN_PINGPONG", 1) != 0;
             const size_t lds_chain1 = ((size_t)Q * (Q + 1) / 2 + (size_t)Q * Q + (size_t)(2 * 2) * Q) * sizeof(double);
             const int chain_pp = (chain_pp_on && lds_chain1 + (size_t)Q * (Q + 1) / 2 * sizeof(double) <= 160 * 1024) ? 1 : 0;
             const size_t lds_chain = lds_chain1 + (chain_pp ? (size_t)Q * (Q + 1) / 2 * sizeof(double) : 0);
+#ifdef SSFM_LAB
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+#endif
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+#ifdef SSFM_LAB
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+#endif
+#ifdef SSFM_LAB
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, true, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+#endif
+#ifdef SSFM_LAB
             if (B.nsep > 0 && lds_chain > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sub_sep_chain_mfma<DC, 2, true, true, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain));
+#endif
             // the 16x16 diagonal blocks of the chain are factored and inverted on the matrix cores (band_sub.h: wave_ldl_inverse16_mfma); SSFM_CHAIN_DIAG_MFMA=0: lane per row (round 2)
-            static const bool chain_diag_mfma = !(std::getenv("SSFM_CHAIN_DIAG_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_DIAG_MFMA")) == 0);
-            static const bool chain_mfma = !(std::getenv("SSFM_CHAIN_MFMA") && std::atoi(std::getenv("SSFM_CHAIN_MFMA")) == 0);     // matrix-core separator chain (band_sub.h 4b)
+            static const bool chain_diag_mfma = SSFM_LAB_KNOB("SSFM_CHAIN_DIAG_MFMA", 1) != 0;
+            static const bool chain_mfma = SSFM_LAB_KNOB("SSFM_CHAIN_MFMA", 1) != 0;     // matrix-core separator chain (band_sub.h 4b)
             int* failp = reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL);
             // SSFM_CHOL_FUSE=1 (experiment, off): one launch for the segments AND the separators of twisted components, which then wait for their two halves
             // through flags in global memory.  Measured at config 2: 70.7 us for the fused launch against 2 x 35.2, 2.958 vs 2.919 ms per solve -- the fence + flag
             // hand-over costs what the launch boundary did (profiles/r02_notes.md)
-            static const bool chol_fuse = std::getenv("SSFM_CHOL_FUSE") && std::atoi(std::getenv("SSFM_CHOL_FUSE")) != 0;
+            static const bool chol_fuse = SSFM_LAB_KNOB("SSFM_CHOL_FUSE", 0) != 0;
             const bool fused = chol_fuse && !wide2p && B.ntwist > 0 && B.nseg + B.ntwist <= ctx->num_cus;      // waiting workgroups must all be resident (one per compute unit)
             if (fused) { h->sub_fz_seq++;
                 SSFM_LAUNCH_CHOL2(B.nseg + B.ntwist, h->band.p, h->Linv.p, Y, h->band_pairs.p, h->sub_fz_lo.p, h->sub_fz_hi.p, h->sub_fz_wend.p, h->sub_fz_merge.p, Nc, b, failp, chol_map,
@@ -370,7 +383,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 h->span_begin(KID_SUB_SPIKE);
                 // columns per wave (band_sub.h 2): one while a step is bound by what a wave can issue (half-widths >= 10), more when the band is narrow and the launch is
                 // bound by the factor rows every column streams again
-                static const int spike_nc_env = std::getenv("SSFM_SPIKE_NC") ? std::atoi(std::getenv("SSFM_SPIKE_NC")) : 0;
+                static const int spike_nc_env = SSFM_LAB_KNOB("SSFM_SPIKE_NC", 0);
                 const int spike_nc = spike_nc_env > 0 ? spike_nc_env : (b <= 8 ? 3 : 1);
                 if (spike_nc >= 4) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 4>), dim3(B.nleft, (Q + 3) / 4), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
                 else if (spike_nc == 3) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 3>), dim3(B.nleft, (Q + 2) / 3), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
@@ -378,46 +391,54 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 else hipLaunchKernelGGL((k_sub_spike_fwd<DC, 1>), dim3(B.nleft, Q), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
                 h->span_end();
                 const int ntl = (Q + SUB_TS - 1) / SUB_TS;
-                const int nz = std::max(1, std::min(64, (max_rows + 511) / 512));
+                const int nz = std::max(1, std::min(64, (max_rows + 511) / 512)); (void)ntl; (void)nz;
                 // separator blocks on the matrix cores, operands straight from global memory, no atomics and no clears (band_sub.h 3b); SSFM_ASM_MFMA=0: the VALU kernel of round 1
-                static const bool asm_mfma = !(std::getenv("SSFM_ASM_MFMA") && std::atoi(std::getenv("SSFM_ASM_MFMA")) == 0);
+                static const bool asm_mfma = SSFM_LAB_KNOB("SSFM_ASM_MFMA", 1) != 0;
                 if (asm_mfma) {
                     const int tq = (Q + 15) / 16;
                     h->span_begin(KID_SUB_ASM);
                     hipLaunchKernelGGL((k_sub_sep_assemble_mfma<DC, 2>), dim3(B.nsep * (tq * (tq + 1) / 2 + tq)), dim3(64 * ASM_NW), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
                     h->span_end();
-                } else {
+                }
+#ifdef SSFM_LAB
+                else {
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subD.p, 0, h->subD.n * sizeof(double), st));
                 SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->subT.p, 0, h->subT.n * sizeof(double), st));
                 h->span_begin(KID_SUB_ASM);
                 hipLaunchKernelGGL((k_sub_sep_assemble<DC, 2>), dim3(B.nsep, ntl * (ntl + 1) / 2, nz), dim3(256), 0, st, h->band.p, h->subZ.p, Y, h->sub_sep_lo.p, h->sub_sep_rseg.p, h->sub_seg_lo.p, h->sub_seg_hi.p, Nc, b, h->subD.p, h->subT.p);
                 h->span_end();
                 }
+#endif
                 if (B.nchain > 0) {
                 if (chain_mfma) {
                     // SSFM_CHAIN_STAMPS=1: s_memtime stamps of the phases of one separator, printed once (profiles/*_notes.md)
-                    static long long* d_stamps = nullptr; static int stamp_state = std::getenv("SSFM_CHAIN_STAMPS") ? 1 : 0;
+                    static long long* d_stamps = nullptr; static int stamp_state = SSFM_LAB_KNOB("SSFM_CHAIN_STAMPS", 0) ? 1 : 0;
                     if (stamp_state == 1) { (void)hipMalloc((void**)&d_stamps, 16 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(long long), st); stamp_state = 2; }
                     // chains of three or more separators are eliminated from both ends by two workgroups each (SSFM_CHAIN_TWIST=0: one workgroup, front to back)
-                    static const bool chain_twist = !(std::getenv("SSFM_CHAIN_TWIST") && std::atoi(std::getenv("SSFM_CHAIN_TWIST")) == 0);
+                    static const bool chain_twist = SSFM_LAB_KNOB("SSFM_CHAIN_TWIST", 1) != 0;
                     // The two workgroups of a chain wait for each other through flags in global memory: both must be RESIDENT.  A chain workgroup (1024 threads,
                     // > 100 KB of LDS) owns a compute unit, so the two-sided form is only used while all 2 x nchain workgroups fit the device at once;
                     // beyond that the one-sided kernel runs (nothing waits on anything in it).
                     const int tw = (chain_twist && 2 * B.nchain <= ctx->num_cus) ? 1 : 0;
                     h->sub_seq++;
-                    static const int chain_threads = std::getenv("SSFM_CHAIN_THREADS") ? std::atoi(std::getenv("SSFM_CHAIN_THREADS")) : 1024;    // 512: eight waves with 256 registers each (band_sub.h)
+                    static const int chain_threads = SSFM_LAB_KNOB("SSFM_CHAIN_THREADS", 1024); (void)chain_threads;    // 512: eight waves with 256 registers each (band_sub.h)
+#ifdef SSFM_LAB
                     if (chain_diag_mfma && chain_threads == 512)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, true, true, 512>), B.nchain * (tw ? 2 : 1), 512, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
                     else if (chain_diag_mfma && d_stamps)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, true, true, 1024, true>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
-                    else if (chain_diag_mfma)
+                    else
+#endif
+                    if (chain_diag_mfma)
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq, chain_pp);
+#ifdef SSFM_LAB
                     else
                     LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain_mfma<DC, 2, false, false>), B.nchain * (tw ? 2 : 1), 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp, d_stamps,
                            tw, B.nsep, h->subC.p, h->subTc.p, h->sub_flags.p, h->sub_seq);
+#endif
                     if (stamp_state == 2) {
                         long long hs[16]; (void)hipMemcpyAsync(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st);
                         std::fprintf(stderr, "[chain stamps, cycles] load E %lld | F solve %lld | t update + F store %lld | load D %lld | syrk %lld | chol J=0: diag %lld panel %lld trailing %lld | chol total %lld | stores %lld\n",
@@ -425,7 +446,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                         stamp_state = 3;
                     }
                 }
+#ifdef SSFM_LAB
                 else LAUNCH(h, KID_SUB_CHAIN, (k_sub_sep_chain<DC, 2>), B.nchain, 1024, lds_chain, h->subZ.p, h->subD.p, h->subT.p, h->sub_chain_ptr.p, h->sub_sep_lo.p, Nc, b, h->subF.p, h->subL.p, h->subW.p, Y, failp);
+#endif
                 }
                 if (B.nring > 0) {
                     // rings (band_ring.h): the separator cycles by cyclic reduction -- one launch per parallel step down, ONE for the last few separators of every ring
@@ -437,7 +460,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     const int nsteps = (int)B.ring_step_ptr.size() - 1;
                     const int cr_threads = Q > 48 ? 1024 : 512;            // (rows of the tall factorisation: 3 Q + 2 <= 256 either way; fewer waves make cheaper barriers)
                     // SSFM_RING_STAMPS=1 (timing study): phase stamps of every elimination of the first solve, printed once: [loads | factorisation | stores + products]
-                    static int ring_stamp_state = std::getenv("SSFM_RING_STAMPS") ? 1 : 0; static long long* ring_stamps = nullptr;
+                    static int ring_stamp_state = SSFM_LAB_KNOB("SSFM_RING_STAMPS", 0) ? 1 : 0; static long long* ring_stamps = nullptr;
                     if (ring_stamp_state == 1) { (void)hipMalloc((void**)&ring_stamps, (size_t)4 * B.nsep * sizeof(long long)); (void)hipMemsetAsync(ring_stamps, 0, (size_t)4 * B.nsep * sizeof(long long), st); ring_stamp_state = 2; }
                     for (int sidx = 0; sidx < nsteps; sidx++)
                         LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], cr_threads, le, h->ring_rec.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
@@ -458,7 +481,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             // EXPERIMENT, off (SSFM_BACK_FUSE=1): the separator of a twisted component back-substituted by the two segment waves themselves (k_band_back_v2's modes 1 / 2) instead
             // of by a launch of its own.  Measured at config 2 (scripts/lab/ab_backfuse.sh): one launch of 23.2-23.8 us against two of 12.1-12.6 (event brackets), 2.545-2.555 against
             // 2.530-2.546 ms per solve -- the second wave's redundant separator sweep and a second pipeline fill cost what the launch gap did
-            static const bool back_fuse = std::getenv("SSFM_BACK_FUSE") && std::atoi(std::getenv("SSFM_BACK_FUSE")) != 0;
+            static const bool back_fuse = SSFM_LAB_KNOB("SSFM_BACK_FUSE", 0) != 0;
             if (B.ntwist > 0) {
                 // twisted components: both segments left their Schur updates in the separator and in its copy; the factorisation kernel merges
                 // them while loading its window and solves the separator as a component of b rows; the reversed segment's back substitution

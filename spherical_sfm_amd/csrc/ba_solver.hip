@@ -21,6 +21,7 @@
 #include "ba_flatten.h"
 #include "ba_kernels.h"
 #include "band_kernels.h"
+#include "knobs.h"
 #include "ssfm_ctx.h"
 
 #include "ba_handle.h"
@@ -35,9 +36,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const int loss = O.loss_type; const double la = O.loss_scale;
     const int gp_pts = (nP + 255) / 256, gp_cam = (Nc + 63) / 64;
     // lane-per-point kernels of the LM loop run as single-wave workgroups: 4x more workgroups spread evenly over the CUs
-    static const int PTB = std::getenv("SSFM_PT_BLOCK") ? std::atoi(std::getenv("SSFM_PT_BLOCK")) : 256;
+    static const int PTB = SSFM_LAB_KNOB("SSFM_PT_BLOCK", 256);
     const int gp_pts_lm = (nP + PTB - 1) / PTB;
-    static const int PLB = std::getenv("SSFM_PL_BLOCK") ? std::atoi(std::getenv("SSFM_PL_BLOCK")) : 64;      // k_point_lin has no workgroup-level step: one wave per workgroup spreads best
+    static const int PLB = SSFM_LAB_KNOB("SSFM_PL_BLOCK", 64);      // k_point_lin has no workgroup-level step: one wave per workgroup spreads best
     const double2* oxy = reinterpret_cast<const double2*>(h->obs_xy.p);
     double* fx = h->focal3.p; double* fc = h->focal3.p + 1;
     double* cam_x = h->cam_x.p; double* cam_c = h->cam_c.p; double* pts_x = h->pts_x.p; double* pts_c = h->pts_c.p;
@@ -104,12 +105,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const char* e_spec = std::getenv("SSFM_LM_SPECULATE");
     const bool spec_on = poll && nP > 0 && !(e_spec && std::atoi(e_spec) == 0);
     bool lin_done = false, spec_launched = false;
+    const int gram_bs_env = std::getenv("SSFM_GRAM_BACKSUB") ? std::atoi(std::getenv("SSFM_GRAM_BACKSUB")) : -1;      // read once per solve (tests switch it between solves)
     // Round 5 EXPERIMENT, off (SSFM_GRAM_FUSE=1): when every point sits in a signature group, k_schur_gram does the point pass itself (ba_kernels.h: FUSE) and k_point_lin
     // does not run; the speculative launch behind k_publish is then the Gram kernel of the NEXT iteration, accumulating into the next zone.  Correct (parity 3e-11, same
     // iterations) and SLOWER: 97.6 us against 43.7 + 18.3 at config 2, 1357 against 409 + 179 at the configs[4] size -- the Gram kernel sits at its register limit
     // (256 at two waves per SIMD: 39 camera sums, the tile accumulators, one observation's linearisation) and the point pass's fold spills 43-80 of them to scratch
     // (profiles/r05_notes.md).  One launch less is not worth a kernel that leaves its registers.
-    static const bool gram_fuse_env = std::getenv("SSFM_GRAM_FUSE") && std::atoi(std::getenv("SSFM_GRAM_FUSE")) != 0;
+    static const bool gram_fuse_env = SSFM_LAB_KNOB("SSFM_GRAM_FUSE", 0) != 0;
     const bool fuse_lin = gram_fuse_env && nP > 0 && !F.gr_rec.empty() && F.gram_points == (int64_t)nP && F.chunk_cam.empty() && F.cs_task_cam.empty();
     struct ZonePtrs { double *scal, *S_val, *rhs, *Udiag, *Sfc, *gcraw; };
     auto zone_ptrs = [&](int which) { ZonePtrs z; z.scal = h->zone.p + (size_t)which * h->zone_len; double* red = z.scal + h->scal.n + h->pcg.n;
@@ -117,18 +119,18 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     // EXPERIMENT, off (SSFM_PUBLISH_FUSED=1): the end-of-iteration hand-over in the last workgroup of k_point_backsub (arrival ticket) instead of a k_publish
     // launch.  Measured: k_point_backsub 22.8 -> 55.9 us at config 2 and 380 -> 1290 us at the configs[4] size -- every workgroup needs an agent-scope release
     // fence (an L2 write-back on this multi-XCD part) + a same-address atomic before it may leave, which costs far more than the 4.7 us launch it saves.
-    static const bool fused_publish = std::getenv("SSFM_PUBLISH_FUSED") && std::atoi(std::getenv("SSFM_PUBLISH_FUSED")) != 0;
+    static const bool fused_publish = SSFM_LAB_KNOB("SSFM_PUBLISH_FUSED", 0) != 0;
     if (fused_publish && poll && !h->pub_ticket.p) {
         SSFM_HIP_CHECK(ctx, h->pub_ticket.alloc(1)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pub_ticket.p, 0, sizeof(int), st));
     }
-    static const bool zone_clear_fused = !(std::getenv("SSFM_ZONE_CLEAR_FUSED") && std::atoi(std::getenv("SSFM_ZONE_CLEAR_FUSED")) == 0);
+    static const bool zone_clear_fused = SSFM_LAB_KNOB("SSFM_ZONE_CLEAR_FUSED", 1) != 0;
     // per-phase device times (summary.t_kernel_*_ms) cost five event records and four queries per iteration, the queries on the
     // host's critical path between two iterations: only with profiling on (ssfm_ba_set_profiling) or options.verbose
     const bool phases = h->profile || O.verbose;
     if (phases) for (auto& e : h->phase_ev) if (!e) SSFM_HIP_CHECK(ctx, hipEventCreate(&e));
 
     // SSFM_PAIRS_Y_PROBE=1: the half-product variant of the pair pass runs next to the real kernel, on scratch data, for rocprofv3
-    const bool y_probe = std::getenv("SSFM_PAIRS_Y_PROBE") && std::atoi(std::getenv("SSFM_PAIRS_Y_PROBE")) != 0;
+    const bool y_probe = SSFM_LAB_KNOB("SSFM_PAIRS_Y_PROBE", 0) != 0;
     DevBuf<double> probe_Y, probe_S;
     if (y_probe) {
         SSFM_HIP_CHECK(ctx, probe_Y.alloc((size_t)F.M * DC * 3)); SSFM_HIP_CHECK(ctx, probe_S.alloc(h->zone_nnz));
@@ -157,11 +159,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         }
         if (!F.chunk_cam.empty()) {
             const int ntasks = (int)F.chunk_cam.size();
-            static const bool occ3 = std::getenv("SSFM_PAIRS_OCC3") && std::atoi(std::getenv("SSFM_PAIRS_OCC3")) != 0;      // experiment (ba_kernels.h)
+#ifdef SSFM_LAB
+            static const bool occ3 = SSFM_LAB_KNOB("SSFM_PAIRS_OCC3", 0) != 0;      // experiment (ba_kernels.h): three waves per SIMD, slower
             if (occ3 && DC == 6)
                 LAUNCH(h, KID_SCHUR_ROWS, (k_schur_pairs2<DC, 3>), (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                        h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
             else
+#endif
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
                    h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
         }
@@ -169,11 +173,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         // z = the zone it accumulates into, spec = device-side [go, radius] of a speculative launch (fused point pass only)
         auto launch_gram = [&](const double* xc, const double* xr, const double* xp, const double* xf, const ZonePtrs& z, double rad, const double* spec) -> int {
             const int ng = (int)(F.gr_rec.size() / GRAM_REC);
-            static bool gram_stamps_done = std::getenv("SSFM_GRAM_STAMPS") == nullptr;      // timing study: per-task phase stamps of the first launch
+            static bool gram_stamps_done = SSFM_LAB_KNOB("SSFM_GRAM_STAMPS", 0) == 0;      // timing study: per-task phase stamps of the first launch
             long long* gram_dbg = nullptr;
             if (!gram_stamps_done) (void)hipMalloc((void**)&gram_dbg, (size_t)4 * ng * sizeof(long long));
-            static const bool gram_t4 = !(std::getenv("SSFM_GRAM_T4") && std::atoi(std::getenv("SSFM_GRAM_T4")) == 0);
-            static const int gram_waves = std::getenv("SSFM_GRAM_WAVES") ? std::min(4, std::max(1, std::atoi(std::getenv("SSFM_GRAM_WAVES")))) : 1;   // waves (tasks) per workgroup: 1 measured best (2: +14 %, 4: +13 % at the configs[4] size)
+            static const bool gram_t4 = SSFM_LAB_KNOB("SSFM_GRAM_T4", 1) != 0;
+            static const int gram_waves = std::min(4, std::max(1, SSFM_LAB_KNOB("SSFM_GRAM_WAVES", 1)));   // waves (tasks) per workgroup: 1 measured best (2: +14 %, 4: +13 % at the configs[4] size)
             // one launch per tile class (the tasks are sorted by K, i.e. by rows = DC K): rows <= 16 -> 1 row tile of 16; 17..20 -> 1 tile + a tail of <= 4 rows through
             // the 4x4x4 instruction; <= 32 -> 2 tiles; 33..36 -> 2 tiles + tail; else 3 tiles
             auto tile_class = [&](int K) { const int rows = DC * K; return rows <= 16 ? 0 : (rows <= 20 && gram_t4) ? 1 : rows <= 32 ? 2 : (rows <= 36 && gram_t4) ? 3 : 4; };
@@ -192,7 +196,11 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                            h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw, gram_dbg, fz);  \
                 }                                                                                                                                      \
             } while (0)
+#ifdef SSFM_LAB
 #define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) do { if (fuse_lin) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, true); else SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false); } while (0)
+#else
+#define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false)
+#endif
             SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
             if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
 #undef SSFM_GRAM_LAUNCH
@@ -211,11 +219,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             const int rc = launch_gram(cam_x, rot_x, pts_x, fx, zone_ptrs(iteration & 1), radius, nullptr); if (rc) return rc;
         }
         lin_done = false;
+#ifdef SSFM_LAB
         if (y_probe && !F.chunk_cam.empty()) {                     // experiment only (ba_kernels.h: k_pairs_y_probe)
             const int ntasks = (int)F.chunk_cam.size();
             hipLaunchKernelGGL(k_pairs_y_probe<DC>, dim3((ntasks + 3) / 4), dim3(256), 0, st, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p, h->chunk_b0.p, h->chunk_b1.p, ntasks,
                                h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, probe_Y.p, probe_S.p);
         }
+#endif
         if (ctx->collective) {
             // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
             hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->red_scal, ctx->rank);
@@ -282,8 +292,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     // Its time follows the POINTS (8 lanes per point whatever K), k_point_backsub's the observations: measured (scripts/prof_gram_backsub.py) 27.3 / 28.1 us
                     // at K = 6 / 8 against 23.4 / 31.7 (100k points) and 271 / 278 against 284 / 379 (1.5 M points): on from 7 observations per point on average.
                     // SSFM_GRAM_BACKSUB=0 / 1 forces it off / on.
-                    const char* e_gbs = std::getenv("SSFM_GRAM_BACKSUB");                        // read per launch: tests switch it
-                    const int gram_bs = e_gbs ? std::atoi(e_gbs) : -1;
+                    const int gram_bs = gram_bs_env;
                     const bool grouped = !fused_publish && !F.gr_rec.empty() && (gram_bs < 0 ? F.gram_obs >= 7 * F.gram_points : gram_bs != 0);
                     const bool all_grouped = grouped && F.gram_points == F.nP;               // then the residual check's workgroup rides with k_gram_backsub
                     if (grouped) {
@@ -295,13 +304,16 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     }
                     // EXPERIMENT, off (SSFM_BACKSUB_LPP=2): two lanes per point -- half the dependent camera gathers per lane, twice the waves.  Measured at config 2
                     // (scripts/lab/ab_lpp.sh, hipEvent averages): 25.1-25.3 us against 23.0-23.5 with one lane per point; 2.557 against 2.538-2.552 ms per solve
-                    static const int bs_lpp = std::getenv("SSFM_BACKSUB_LPP") ? std::atoi(std::getenv("SSFM_BACKSUB_LPP")) : 1;
+#ifdef SSFM_LAB
+                    static const int bs_lpp = SSFM_LAB_KNOB("SSFM_BACKSUB_LPP", 1);
                     if (!all_grouped && bs_lpp == 2)
                         LAUNCH(h, KID_BACKSUB, (k_point_backsub<DC, 2>), (2 * nP + PTB - 1) / PTB + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
                                (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr));
-                    else if (!all_grouped)
+                    else
+#endif
+                    if (!all_grouped)
                         LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,

@@ -678,7 +678,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0, x_cost = 0, minimum_cost = std::numeric_limits<double>::max();
     int iteration = 0, num_invalid = 0; bool last_successful = true;
     S->num_successful_steps = 1; S->termination = SSFM_NO_CONVERGENCE; S->camera_dof = 3; S->num_residual_blocks = S->num_residual_blocks_global = E;
-    static const bool fused_finalize = !(std::getenv("SSFM_ROT_FUSED_FINALIZE") && std::atoi(std::getenv("SSFM_ROT_FUSED_FINALIZE")) == 0);
+    static const bool fused_finalize = SSFM_LAB_KNOB("SSFM_ROT_FUSED_FINALIZE", 1) != 0;
     while (true) {
         if (iteration >= O.max_num_iterations) { S->termination = SSFM_NO_CONVERGENCE; break; }
         if (radius <= O.min_trust_region_radius) { S->termination = SSFM_CONVERGENCE; break; }
