@@ -16,7 +16,9 @@ def main():
     mode, out, spherical, focal_fixed = sys.argv[1], sys.argv[2], sys.argv[3] == "1", sys.argv[4] == "1"
     import torch
     from spherical_sfm_amd import ba, synth
-    if len(sys.argv) > 5 and sys.argv[5] == "weak2":        # the shape bench.py --gpus 2 runs: 2 x config 2's cameras, 8 rings of 75
+    if len(sys.argv) > 5 and sys.argv[5] == "ring":           # one ring of 1000 cameras: the ring-native reduced solve (band_ring.h), replicated on every rank
+        prob = synth.make_circle(1000, 20000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
+    elif len(sys.argv) > 5 and sys.argv[5] == "weak2":        # the shape bench.py --gpus 2 runs: 2 x config 2's cameras, 8 rings of 75
         prob = synth.make_circle(600, 24000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)
     else:
         prob = synth.make_circle(60, 6000, 6, spherical=spherical, focal_fixed=focal_fixed, seed=21)

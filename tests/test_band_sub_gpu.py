@@ -168,3 +168,55 @@ def test_two_rings_and_a_short_component(gpu_ctx, oracle, monkeypatch, spherical
     ocams, opts, of, os_ = oracle.ba_solve(p)
     assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
     assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+
+
+def _concat_problems(a, b):
+    """two independent scenes as one problem: cameras and points of b renumbered behind a's (two connected components of the camera graph)"""
+    import dataclasses
+    na, pa = len(a.cameras), len(a.points)
+    return dataclasses.replace(a, cameras=np.concatenate([a.cameras, b.cameras]), points=np.concatenate([a.points, b.points]),
+                               obs_xy=np.concatenate([a.obs_xy, b.obs_xy]), obs_cam=np.concatenate([a.obs_cam, b.obs_cam + na]).astype(np.int32),
+                               obs_pt=np.concatenate([a.obs_pt, b.obs_pt + pa]).astype(np.int32), rot_fixed=np.concatenate([a.rot_fixed, b.rot_fixed]),
+                               trans_fixed=np.concatenate([a.trans_fixed, b.trans_fixed]), pt_fixed=np.concatenate([a.pt_fixed, b.pt_fixed]),
+                               gt_cameras=np.concatenate([a.gt_cameras, b.gt_cameras]), gt_points=np.concatenate([a.gt_points, b.gt_points]))
+
+
+def test_ring_next_to_short_components(gpu_ctx, oracle, monkeypatch):
+    """A long ring (1000 cameras, reach 5: ring layout) in one problem with config 2's four short rings (75 cameras each, folded half-width 10: twisted).  The band has ONE
+    half-width -- 10, the widest component's -- so the long ring is laid out with separators of 10 rows although 5 would do; a third scene whose fold is wider than the
+    cyclic-reduction kernel's blocks allow (K = 10: half-width 18 x 6 = 108 > 78) makes the planner withdraw the ring layout and cut the fold into a chain as before."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    long_ring = synth.make_circle(1000, 20000, 6, spherical=False, focal_fixed=True, seed=3)
+    short = synth.make_circle(300, 6000, 6, spherical=False, focal_fixed=True, seed=4)
+    p = _concat_problems(long_ring, short)
+    info = ba.plan(p)[0]
+    assert info["band_half_width"] == 10
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["band_segments"] - 8 == s["band_separators"] - 4 >= 4            # (8 twisted halves + 4 separators of the short rings; the rest: arcs = separators of the long ring)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+    wide = synth.make_circle(150, 6000, 10, spherical=False, focal_fixed=True, seed=5, check_in_frame=False, xy_range=0.2)
+    p2 = _concat_problems(long_ring, wide)
+    info2 = ba.plan(p2)[0]
+    assert info2["band_half_width"] * 6 > 78 and info2["band_segments"] != info2["band_separators"]     # no ring layout at that width
+    cams, pts, f, s = ba.optimize(gpu_ctx, p2)
+    ocams, opts, of, os_ = oracle.ba_solve(p2)
+    assert s["iterations"] == os_["iterations"] and rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5
+
+
+def test_odd_merged_ring_and_refinement_path(gpu_ctx, oracle, monkeypatch):
+    """Spherical BA on a ring of 2003 cameras: 1002 merged pairs, the last one with an empty slot that lies in the ring's LAST separator (the one with the copy slot in
+    front of the first arc); then the same with an impossible PCG tolerance, so that every LM iteration rebuilds the band and runs the ring solve again on the residual."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_circle(2003, 24000, 6, spherical=True, focal_fixed=False, seed=8)
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    assert s["camera_dof"] == 3 and s["band_segments"] == s["band_separators"] >= 4
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert rel_err(cams, ocams) <= 1e-5 and point_rel_err(pts, opts) <= 1e-5 and abs(f - of) <= 1e-5 * of
+    c2, p2, f2, s2 = ba.optimize(gpu_ctx, p, pcg_tolerance=1e-30, pcg_max_iterations=2)
+    assert s2["pcg_iterations_total"] >= s2["num_linearizations"] and np.isfinite(c2).all() and np.isfinite(p2).all()
+    assert rel_err(c2, ocams) <= 1e-5 and point_rel_err(p2, opts) <= 1e-5

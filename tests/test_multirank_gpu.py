@@ -115,6 +115,20 @@ def test_weak_scaling_shape_two_ranks(gpu_ctx, tmp_path):
     assert np.array_equal(res[0]["cams"], res[1]["cams"]) and np.array_equal(res[0]["pts"], res[1]["pts"])
 
 
+def test_ring_layout_two_ranks(gpu_ctx, tmp_path):
+    """Round 5: the ring-native reduced solve is replicated like the folded one -- every sum in it has a fixed order (gathered Schur updates with one writer per step,
+    band_ring.h), so two ranks that all-reduce their partial reduced systems leave with BIT-identical cameras and points, equal to the single-rank solve to 1e-8."""
+    prob = synth.make_circle(1000, 20000, 6, spherical=False, focal_fixed=False, seed=21)
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, prob)
+    assert s1["band_half_width"] == 5 and s1["band_segments"] == s1["band_separators"] >= 4
+    res = _run("host", 2, str(tmp_path / "ring"), False, False, task="ring")
+    for r in res:
+        assert int(r["iterations"]) == s1["iterations"] and int(r["termination"]) == s1["termination"]
+        assert np.abs(r["cams"] - c1).max() <= 1e-8 * np.abs(c1).max() and abs(float(r["focal"]) - f1) <= 1e-9 * f1
+        assert (np.linalg.norm(r["pts"] - p1, axis=1) / np.linalg.norm(p1, axis=1)).max() <= 1e-8
+    assert np.array_equal(res[0]["cams"], res[1]["cams"]) and np.array_equal(res[0]["pts"], res[1]["pts"])
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
