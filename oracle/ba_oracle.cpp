@@ -12,7 +12,7 @@
 //  * minimiser          : oracle/lm.hpp (Ceres 2.2.0 trust-region loop, restated);
 //  * linear solve       : Schur elimination of the point blocks, exact Cholesky of the reduced
 //                         camera(+focal) system (oracle/skyline.hpp).
-// PARITY UNPINNED (see ssfm_oracle.h).  This file doubles as bench.py's timed CPU baseline
+// PARITY UNPINNED for this file (the Ceres path cannot be run here; see ssfm_oracle.h).  This file doubles as bench.py's timed CPU baseline
 // ("cpu_baseline.kind = port"): a proxy for the Ceres path, not Ceres.
 #include <omp.h>
 #include <algorithm>

@@ -14,7 +14,7 @@
 //   FindInterpolatingPolynomial (full-pivoting LU of the Vandermonde-type system), MinimizePolynomial (mid point, both ends, real parts
 //   of all roots of the derivative), FindPolynomialRoots (closed forms up to degree 2, companion-matrix eigenvalues above)  (polynomial.cc)
 // The reference reaches this code in optimize_rotations_and_focal_length only: it is the one solve with bounds
-// (src/uncalibrated_pose_graph.cpp:181-182).  PARITY UNPINNED (ssfm_oracle.h).
+// (src/uncalibrated_pose_graph.cpp:181-182).  PARITY UNPINNED for this file (Ceres path; ssfm_oracle.h).
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -7,7 +7,7 @@
 // src/uncalibrated_pose_graph.cpp:187-191 (defaults: 50 iterations, 5 invalid steps),
 // src/spherical_estimator.cpp:146-154 (200 iterations, 10 invalid steps).
 //
-// PARITY UNPINNED: the reference holds no golden vectors for any of these solves
+// PARITY UNPINNED for this file: the reference holds no golden vectors for any of these solves and Ceres cannot be run here
 // and Ceres cannot be built here, so this loop is anchored on Ceres' published algorithm:
 //   * cost = 1/2 sum rho(|r|^2); robustified residual/Jacobian = sqrt(rho') * (r, J) because
 //     rho'' <= 0 for Cauchy / SoftLOne (Corrector degenerates to scaling);

@@ -5,6 +5,8 @@
 //   UniformSampling (std::mt19937 + std::uniform_int_distribution)  include/RansacLib/sampling.h:46-135
 //   NumRequiredIterations, RandomShuffleAndResize                    include/RansacLib/utils.h:48-140
 // The random streams are libstdc++'s, exactly as a build of the reference would draw them.
+// PINNED (round 5): lomsac_reference.hpp runs the reference's own include/RansacLib over the same estimators; tests/test_reference_pins_cpu.py requires the two to
+// agree bit for bit on statistics, inlier sets, scores and models (committed fixtures + live where oracle/_ref exists).
 // Solver concept (include/sphericalsfm/estimator.h:7-23): min_sample_size, non_minimal_sample_size, num_data,
 // MinimalSolver(sample, vector<Model>*), NonMinimalSolver(sample, Model*), EvaluateModelOnPoint(model, i), LeastSquares(sample, Model*).
 #pragma once

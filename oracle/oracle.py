@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure only) -- ctypes loader for oracle/libssfm_oracle.so.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED: see oracle/ssfm_oracle.h.
+PARITY PARTLY PINNED: see oracle/ssfm_oracle.h (what the reference itself can compute in this image pins the RANSAC / solver part; Ceres / Eigen paths are restated).
 """
 import ctypes as C
 import os

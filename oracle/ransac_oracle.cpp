@@ -17,7 +17,7 @@
 //  * UniformSampling (std::mt19937 + std::uniform_int_distribution, libstdc++)          include/RansacLib/sampling.h:46-135
 //  * NumRequiredIterations, RandomShuffleAndResize                                      include/RansacLib/utils.h:48-140
 //  * estimate_pairwise per-pair logic                examples/spherical_sfm_tools.cpp:309-431
-// PARITY UNPINNED (ssfm_oracle.h).  3x3 matrices cross the C API column-major.
+// PARITY PARTLY PINNED (ssfm_oracle.h): LO-MSAC control flow, SolveQuartic, the constraint matrices and both solver back ends against the reference itself; LeastSquares / Decompose / the QR basis restated.  3x3 matrices cross the C API column-major.
 #include <algorithm>
 #include <cmath>
 #include <complex>

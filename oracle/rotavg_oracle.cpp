@@ -9,7 +9,7 @@
 //  * optimize_rotations_and_focal_length  src/uncalibrated_pose_graph.cpp:147-203
 // Residuals are evaluated with dual numbers (width 6 or 7) like the reference's AutoDiffCostFunction;
 // the solve is the restated Ceres loop of oracle/lm.hpp (defaults: 50 iterations) with an exact
-// Cholesky of J^T J + D^2 in place of SPARSE_NORMAL_CHOLESKY.  PARITY UNPINNED (ssfm_oracle.h).
+// Cholesky of J^T J + D^2 in place of SPARSE_NORMAL_CHOLESKY.  PARITY UNPINNED for this file (Ceres path; ssfm_oracle.h).
 #include <algorithm>
 #include <cstring>
 #include <vector>

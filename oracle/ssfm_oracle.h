@@ -3,10 +3,13 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (spherical_sfm_amd/) never links, imports or calls it.
  *
- * PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for any function on
- * this path (finding F7) and its un-vendored dependencies (Ceres 2.2.0, Eigen 3.4)
- * are absent here, so the reference cannot be run.  The oracle is anchored on the reference's
- * call sites (cited per function) and on oracle-free known-answer tests (tests/test_oracle_*.py).
+ * PARITY PARTLY PINNED (round 5).  The reference holds no golden vectors / known-answer tests for any function on this path
+ * (finding F7) and its un-vendored dependencies (Ceres 2.2.0, Eigen 3.4) are absent here, so the reference as a whole cannot be run.
+ * What CAN run here does: include/RansacLib/{ransac,sampling,utils}.h are compiled as they stand and drive this oracle's estimators (oracle/_ref, lomsac_reference.hpp),
+ * src/spherical_solvers.cpp:14-98 (SolveQuartic*) is compiled as it stands, and the generated coefficient code of both minimal solvers is evaluated from the
+ * reference's own lines -- tests/golden/ref_*.npz, tests/test_reference_pins_cpu.py pin lomsac.hpp, the quartic, the constraint matrices and both solver back ends to them.
+ * Everything that runs through Ceres or Eigen in the reference (the trust-region loops, losses, Jets, QR / LU / eigen / SVD decompositions) remains a restatement anchored
+ * on the reference's call sites (cited per function) and on oracle-free known-answer tests (tests/test_oracle_*.py, tests/test_scipy_anchor_cpu.py).
  */
 #ifndef SSFM_ORACLE_H
 #define SSFM_ORACLE_H

@@ -8,7 +8,7 @@
 //  * MinimalSolver / NonMinimalSolver (DLT, SVD)    src/triangulation_estimator.cpp:56-86
 //  * LeastSquares (TriangulationError, point-only)  src/triangulation_estimator.cpp:18-44, 88-127
 //  * the LO-MSAC loop                               oracle/lomsac.hpp (include/RansacLib)
-// PARITY UNPINNED (ssfm_oracle.h).
+// PARITY PARTLY PINNED (ssfm_oracle.h): the per-point LO-MSAC control flow against the reference's own RansacLib template; the estimator (DLT by SVD, Ceres fit) restated.
 #include <omp.h>
 #include <array>
 #include <cstring>

@@ -197,17 +197,20 @@ def test_focal_pose_graph_reaches_the_oracle_minimum(gpu_ctx, oracle):
 
 def test_large_focal_pose_graph_on_the_ring_layout(gpu_ctx, oracle):
     """optimize_rotations_and_focal_length at 2000 nodes: the ring layout of the merged node pairs with the shared focal multiplier as the dense border (second
-    right-hand side of every solve), its box bounds and the projected line search: the first five iterations against the oracle (the capped run ends on a plateau)."""
+    right-hand side of every solve), its box bounds and the projected line search.  Compared over the first two iterations: from the third on the trust region
+    has grown so far that the damping no longer fixes the gauge (a common rotation of all nodes costs nothing) and rounding differences in the solve are
+    amplified ~1e4 per iteration on BOTH layouts alike (scripts/dev/focal_steps.py: 6e-12 rad after two iterations, 4e-8 after three, 4e-4 after four, with
+    SSFM_RING=0 and 1); the run to the minimum is compared at 500 nodes above."""
     from spherical_sfm_amd import rotavg
     R0, i0, i1, Rrel, Rgt = synth.make_rotation_graph(2000, 8, noise_deg=0.2, outlier_frac=0.02)
-    oracle.pose_graph_test_options(5)
+    oracle.pose_graph_test_options(2)
     try:
         Ro, fo, co, so = oracle.optimize_rotations_and_focal_length(R0.copy(), i0, i1, Rrel, 800.0, 400.0, 1600.0)
     finally:
         oracle.pose_graph_test_options(0)
-    R, f, cost, s = rotavg.optimize_rotations_and_focal_length(gpu_ctx, R0, i0, i1, Rrel, 800.0, 400.0, 1600.0, max_num_iterations=5)
-    assert s["iterations"] == so["iterations"] == 5 and s["num_successful_steps"] == so["num_successful_steps"]
-    assert abs(cost - co) <= 1e-9 * co and abs(f - fo) <= 1e-8 * fo and rot_angle(R, Ro).max() <= 1e-7
+    R, f, cost, s = rotavg.optimize_rotations_and_focal_length(gpu_ctx, R0, i0, i1, Rrel, 800.0, 400.0, 1600.0, max_num_iterations=2)
+    assert s["iterations"] == so["iterations"] == 2 and s["num_successful_steps"] == so["num_successful_steps"]
+    assert abs(cost - co) <= 1e-11 * co and abs(f - fo) <= 1e-9 * fo and rot_angle(R, Ro).max() <= 1e-9
 
 
 def test_node_major_and_scatter_assembly_agree(gpu_ctx, monkeypatch):
