@@ -263,6 +263,20 @@ inline int ring_choose_cuts(int rows, int b) {
     return m;
 }
 
+// Short rings (under BAND_CUT_MIN_ROWS block rows, folded half-width <= 20): ring or fold by a cost model in microseconds per factorisation + solve, constants measured on
+// MI355X (profiles/r05_notes.md r05l).  Fold, twisted: two launches of the windowed factorisation + two of the back substitution, ~2.1 us per PAIR of rows (half-width
+// 10 ... 14).  Ring: arcs of L rows cost 2.6 us per row (factorisation 1.2, spike 1.0, back substitution 0.4) + 16 (assembly, left apply); a cyclic-reduction step on
+// separators of Q unknowns 34 + 1.4 (Q - 30) (elimination + back substitution) and the closing launch 47 + 2.15 (Q - 30).  Config 2's four rings of 75 (reach 5): fold 85
+// against 147 measured (model 85 / 146); one ring of 300 with tracks of 3 ... 8 cameras (reach 7): fold 312 against 260 measured (model 321 / 253).
+constexpr int RING_MIN_ROWS = 64;
+inline double fold_model_us(int rows) { return 2.1 * 0.5 * rows + 6.0; }
+inline double ring_model_us(int rows, int reach, int Q) {
+    const int m = ring_choose_cuts(rows, reach), L = (rows - m * reach) / m;
+    int steps = 0; for (int p = m; p > 2; p = (p + 1) / 2) steps++;
+    const double dq = Q - 30.0;
+    return 2.6 * L + 16.0 + steps * (34.0 + 1.4 * dq) + 47.0 + 2.15 * dq;
+}
+
 // Elimination order + band layout of the reduced camera system: Cuthill-McKee per component, then per component one of
 //   ring (above) | twisted | plain,   with (3-dof blocks) pairs of consecutive cameras merged into 6x6 block rows.
 //   out: pos (elimination order, a permutation), band (half-width in blocks), comp_ptr / band_rows (block rows), band_row / band_row2
@@ -299,7 +313,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         // (b) a walk round the ring from neighbour to nearest unvisited neighbour (rings whose ids are strided, e.g. SURVEY 8d's circle).  Whatever order comes out is only
         // USED when the component really is a narrow periodic band in it (the reach below is measured, not assumed).
         // reach = the largest circular distance between two coupled cameras, in block rows.
-        if (!(crows[k] >= BAND_CUT_MIN_ROWS || bk > 20)) continue;
+        if (crows[k] < RING_MIN_ROWS) continue;
         const int R = crows[k];
         auto circular_reach = [&](const std::vector<int>& ord) {
             for (int i = 0; i < n; i++) where[ord[i]] = i;
@@ -336,7 +350,9 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         std::vector<int>& best = (ra <= rb) ? ids : unf;
         const int reach = std::min(ra, rb);
         if (std::getenv("SSFM_RING_DEBUG")) std::fprintf(stderr, "[ring] component %d: %d cameras, %d block rows, fold half-width %d, circular reach by id %d, unfolded %d\n", k, n, R, bk, ra, rb);
-        const bool ok = reach >= 1 && reach * band_block <= RING_QMAX && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
+        bool ok = reach >= 1 && reach * band_block <= RING_QMAX && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
+        // short components with a band that the square LDS window holds: only when the measured cost model says so (long ones and wide ones: always)
+        if (ok && R < BAND_CUT_MIN_ROWS && bk <= 20 && !(ring_model_us(R, reach, reach * band_block) < 0.9 * fold_model_us(R))) ok = false;
         if (ok) { is_ring[k] = 1; seq_cm[k] = seq[k]; cb_cm[k] = bk; seq[k] = best; cb[k] = reach; }
         for (int i = 0; i < n; i++) where[seq[k][i]] = i;
     }

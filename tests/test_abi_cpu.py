@@ -212,7 +212,7 @@ def test_ring_components_fold_to_twice_their_reach(monkeypatch):
     half-width r; folded into a plain band it cannot be narrower than 2 r, and the planner reaches that (the root's children go closest first)."""
     for nc, k, reach in ((300, 6, 5), (75, 6, 5), (60, 6, 5), (500, 6, 5), (4000, 8, 7)):
         p = synth.make_circle(nc, 2000 if nc < 1000 else 16000, k, spherical=False, focal_fixed=True)
-        if nc >= 1000: monkeypatch.setenv("SSFM_RING", "0")                           # long rings are no longer folded by default (next test)
+        if nc >= 500:  monkeypatch.setenv("SSFM_RING", "0")                           # longer rings are no longer folded by default (next test)
         info = ba.plan(p)[0]
         assert info["band_half_width"] == 2 * reach, (nc, k, info["band_half_width"])
     monkeypatch.delenv("SSFM_RING", raising=False)
@@ -249,9 +249,14 @@ def test_ring_layout_of_long_rings(monkeypatch):
     monkeypatch.setenv("SSFM_RING", "0")
     assert ba.plan(rag)[0]["band_half_width"] == 26
     monkeypatch.delenv("SSFM_RING")
-    # short rings stay folded and twisted (config 2: four rings of 75)
+    # short rings stay folded and twisted when the cost model says so (config 2: four rings of 75) ...
     info = ba.plan(synth.make_circle(300, 3000, 6, spherical=False))[0]
     assert info["band_half_width"] == 10 and (info["band_segments"], info["band_separators"]) == (8, 4)
+    # ... and go to the ring layout when it does not: one ring of 300 cameras with reach 7 (tracks of 3 ... 8 cameras), one of 500 with reach 5
+    info = ba.plan(synth.make_ragged_circle(300, 60000, 3, 8))[0]
+    assert info["band_half_width"] == 7 and (info["band_segments"], info["band_separators"]) == (8, 8)
+    info = ba.plan(synth.make_circle(500, 2000, 6, spherical=False, focal_fixed=True))[0]
+    assert info["band_half_width"] == 5 and (info["band_segments"], info["band_separators"]) == (16, 16)
 
 
 def test_planner_pool_survives_fork():
