@@ -168,9 +168,10 @@ def test_ragged_tracks_full_size_parity(gpu_ctx, oracle, max_len, spherical, foc
     from spherical_sfm_amd import ba
     p = synth.make_ragged_circle(300, 600000, 3, max_len, spherical=spherical, focal_fixed=focal_fixed)
     info = ba.plan(p)[0]
-    # one connected ring of reach max_len - 1.  Folded (Cuthill-McKee) its band is twice that; from half-width 21 on (too wide for the square LDS window) the ring is
-    # laid out in its own circular order instead (round 5, band_ring.h): half-width = reach, a cycle of separators.  3-dof cameras are merged in pairs: half the block rows.
-    ring = (not spherical) and 2 * (max_len - 1) > 20
+    # one connected ring of reach max_len - 1.  Folded (Cuthill-McKee) its band is twice that; the ring of 300 six-dof cameras is laid out in its own circular order
+    # instead (round 5, band_ring.h: too wide for the square LDS window when folded from half-width 21 on, cheaper by the planner's cost model below that): half-width =
+    # reach, a cycle of separators.  3-dof cameras are merged in pairs: half the block rows, and the 150 rows stay folded.
+    ring = not spherical
     assert info["band_half_width"] == ((max_len - 1) if ring else 2 * (max_len - 1) // (2 if spherical else 1)) or spherical
     assert (info["band_segments"] == info["band_separators"]) == ring
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
