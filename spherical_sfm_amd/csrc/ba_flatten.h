@@ -263,18 +263,22 @@ inline int ring_choose_cuts(int rows, int b) {
     return m;
 }
 
-// Short rings (under BAND_CUT_MIN_ROWS block rows, folded half-width <= 20): ring or fold by a cost model in microseconds per factorisation + solve, constants measured on
-// MI355X (profiles/r05_notes.md r05l).  Fold, twisted: two launches of the windowed factorisation + two of the back substitution, ~2.1 us per PAIR of rows (half-width
-// 10 ... 14).  Ring: arcs of L rows cost 2.6 us per row (factorisation 1.2, spike 1.0, back substitution 0.4) + 16 (assembly, left apply); a cyclic-reduction step on
-// separators of Q unknowns 34 + 1.4 (Q - 30) (elimination + back substitution) and the closing launch 47 + 2.15 (Q - 30).  Config 2's four rings of 75 (reach 5): fold 85
-// against 147 measured (model 85 / 146); one ring of 300 with tracks of 3 ... 8 cameras (reach 7): fold 312 against 260 measured (model 321 / 253).
+// Short rings (under BAND_CUT_MIN_ROWS block rows, folded half-width <= 20): ring or fold by a cost model in microseconds per factorisation + solve, fitted to per-kernel
+// times measured on MI355X (profiles/r05_notes.md r05n; 6x6 blocks).
+//   fold, twisted (two launches of the windowed factorisation + two of the back substitution): 37 + s(bk) per PAIR of rows, s = 1.27 at half-width 10 ... 2.82 at 20.
+//   ring: arcs of L rows 35.5 + 2.1 L (factorisation 0.95, spike 0.85, back substitution 0.3 per row; assembly, left apply); a cyclic-reduction step on separators of Q
+//   unknowns 34 + 1.2 (Q - 30) + 0.004 (Q - 30)^2 (elimination + back substitution), the closing launch 47 + 1.5 (Q - 30) + 0.0135 (Q - 30)^2.
+// Measured fold -> ring per LM iteration: one ring of 300 cameras with reach 5 / 7 / 8 / 9 / 10: 331 -> 307, 427 -> 361, 476 -> 397, 526 -> 423, 596 -> 459 (model
+// differences 9 / 56 / 77 / - / 117 against 24 / 66 / 79 / 103 / 137 measured: the ring's extra launches overlap when nothing synchronises between them, hence the
+// 5 us in favour of the ring below); rings of 75 ... 80 (config 2): 175 -> 232, 138 -> 191, 155 -> 212 (stay folded); one ring of 200 / 250 with reach 5:
+// 217 -> 224 / 253 -> 239; 150 merged rows with reach 7: 321 -> 347.
 constexpr int RING_MIN_ROWS = 64;
-inline double fold_model_us(int rows) { return 2.1 * 0.5 * rows + 6.0; }
+inline double fold_model_us(int rows, int bk) { return 37.0 + 0.5 * rows * std::max(0.9, 1.27 + 0.155 * (bk - 10)); }
 inline double ring_model_us(int rows, int reach, int Q) {
-    const int m = ring_choose_cuts(rows, reach), L = (rows - m * reach) / m;
+    const int m = ring_choose_cuts(rows, reach);
+    const double L = double(rows - m * reach) / m, dq = Q - 30.0;
     int steps = 0; for (int p = m; p > 2; p = (p + 1) / 2) steps++;
-    const double dq = Q - 30.0;
-    return 2.6 * L + 16.0 + steps * (34.0 + 1.4 * dq) + 47.0 + 2.15 * dq;
+    return 35.5 + 2.1 * L + steps * (34.0 + 1.2 * dq + 0.004 * dq * dq) + 47.0 + 1.5 * dq + 0.0135 * dq * dq;
 }
 
 // Elimination order + band layout of the reduced camera system: Cuthill-McKee per component, then per component one of
@@ -352,7 +356,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         if (std::getenv("SSFM_RING_DEBUG")) std::fprintf(stderr, "[ring] component %d: %d cameras, %d block rows, fold half-width %d, circular reach by id %d, unfolded %d\n", k, n, R, bk, ra, rb);
         bool ok = reach >= 1 && reach * band_block <= RING_QMAX && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
         // short components with a band that the square LDS window holds: only when the measured cost model says so (long ones and wide ones: always)
-        if (ok && R < BAND_CUT_MIN_ROWS && bk <= 20 && !(ring_model_us(R, reach, reach * band_block) < 0.9 * fold_model_us(R))) ok = false;
+        if (ok && R < BAND_CUT_MIN_ROWS && bk <= 20 && !(env_r && env_r[0] == '2') && !(ring_model_us(R, reach, reach * band_block) < fold_model_us(R, bk) + 5.0)) ok = false;   // SSFM_RING=2: whenever possible
         if (ok) { is_ring[k] = 1; seq_cm[k] = seq[k]; cb_cm[k] = bk; seq[k] = best; cb[k] = reach; }
         for (int i = 0; i < n; i++) where[seq[k][i]] = i;
     }

@@ -23,6 +23,7 @@ def point_rel_err(a, b):
 def test_forced_segments_match_oracle(gpu_ctx, oracle, monkeypatch, spherical, focal_fixed, P, Nc, K):
     from spherical_sfm_amd import ba
     monkeypatch.setenv("SSFM_BAND_SEGMENTS", str(P)); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1"); monkeypatch.setenv("SSFM_BAND_TWIST", "0")
+    monkeypatch.setenv("SSFM_RING", "0")                                   # the chain of the folded band is the subject here (rings: below)
     p = synth.make_circle(Nc, 40 * Nc, K, spherical=spherical, focal_fixed=focal_fixed, check_in_frame=False, seed=77 + P)
     cams, pts, f, s = ba.optimize(gpu_ctx, p)
     assert s["band_separators"] >= 1 and s["band_segments"] > s["band_separators"]
