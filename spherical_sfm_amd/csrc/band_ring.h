@@ -52,7 +52,6 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
                                                double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT,
                                                double* __restrict__ crE, const int N, const int b, int* __restrict__ fail_flag, double* __restrict__ T,
                                                long long* __restrict__ stamps = nullptr) {      // stamps: SSFM_RING_STAMPS timing study (ba_handle.h), null otherwise
-    constexpr int NB = DC;
     const long long ts0 = stamps ? wall_clock64() : 0;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int v = r[0], nn = r[1], hasL = r[2], hasR = r[3];
@@ -97,48 +96,69 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
     // (Measured and dropped, profiles/r05_notes.md r05h: a look-ahead wave that factors the next diagonal block during the trailing update -- 33.9 against 34.2 us per
     //  elimination at Q = 42; four rows per thread in the trailing update + all loads of phase 0 issued up front -- 36.7 us.  Phase stamps at Q = 42 / 78: loads 6.9 / 9.5 us,
     //  this phase 12.6 / 41.9 us, stores + the neighbours' products 9.2 / 14.2 us.)
-    const int tx = tid & 255, ty = tid >> 8, nty = nt >> 8;
-    const int R_all = 3 * Q + NR;
-    const bool row_ok = tx < Q || (tx < 3 * Q && (tx - Q) / Q < nn) || (tx >= 3 * Q && tx < R_all);
-    for (int c0 = 0; c0 < Q; c0 += NB) {
-        __syncthreads();
-        if (wave == 0) {
-            double row[NB], g[NB];
+    // Sixteen columns per pass on the matrix cores (r05p; before: DC columns per pass, lane per row, 12.6 / 41.9 us of the 34 / 74 us at Q = 42 / 78): wave 0 factors and
+    // inverts the 16x16 diagonal block (wave_ldl_inverse16_mfma, band_sub.h), the panel rows become A G^T and the trailing tiles lose P_I P_J^T, both as 16x16x4 tiles
+    // with the operands read from LDS.  Row tiles sit on the 16-grid of the tall matrix (the last pass: from row Q on); rows of an absent neighbour ride along unread.
+    constexpr int TB = 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int R_all = 3 * Q + NR, TQ = (Q + TB - 1) / TB, RT = (R_all + TB - 1) / TB;
+    const int dead0 = Q + nn * Q, dead1 = 3 * Q;                    // [dead0, dead1): B rows of neighbours that do not exist
+    auto tile16 = [&](const double* pa, const double* pb, int nk) { // sum_k pa[k] pb[k], k < nk <= 16: pa / pb = this lane's operand rows at the pass's first column
+        v4d_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < NB; c++) row[c] = (lane < NB) ? T[(c0 + max(lane, c)) * LD + c0 + min(lane, c)] : ((lane == c) ? 1.0 : 0.0);
-            if (!wave_chol_inverse<NB>(row, g) && lane == 0) *fail_flag = 1;
-            if (lane < NB) {
+        for (int u = 0; u < 4; u++) {
+            const int k = 4 * lk + u; const bool in = k < nk;
+            const double av = pa[in ? k : 0], bv = pb[in ? k : 0];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? av : 0.0, in ? bv : 0.0, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto factor_diag = [&](int c0, int nJ) {                        // wave 0: the diagonal block becomes G = L_blk^-1 (lower triangle, in place)
+        v4d_t Sd, Gd;
 #pragma unroll
-                for (int rr = 0; rr < NB; rr++) if (rr >= lane) T[(c0 + rr) * LD + c0 + lane] = g[rr];
-            }
+        for (int q = 0; q < 4; q++) { const int rr = lk + 4 * q; Sd[q] = (rr < nJ && li < nJ) ? T[(c0 + max(rr, li)) * LD + c0 + min(rr, li)] : ((rr == li) ? 1.0 : 0.0); }
+        if (!wave_ldl_inverse16_mfma(Sd, Gd) && lane == 0) *fail_flag = 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int rr = lk + 4 * q; if (rr >= li && rr < nJ) T[(c0 + rr) * LD + c0 + li] = Gd[q]; }
+    };
+    auto trailing_tile = [&](int c0, int nJ, int I, int Jc) {
+        const int r0 = TB * I;
+        if (r0 >= dead0 && r0 + TB <= dead1) return;
+        const v4d_t acc = tile16(T + (size_t)min(r0 + li, R_all - 1) * LD + c0, T + (size_t)min(TB * Jc + li, Q - 1) * LD + c0, nJ);
+        const int col = TB * Jc + li;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = r0 + lk + 4 * q;
+            if (row < R_all && col < Q && (col <= row || row >= Q)) T[(size_t)row * LD + col] -= acc[q];     // triangle rows: up to the diagonal (the upper part stays zero: G^T above)
+        }
+    };
+    __syncthreads();
+    if (wave == 0) factor_diag(0, min(TB, Q));
+    for (int J = 0; J < TQ; J++) {
+        const int c0 = TB * J, nJ = min(TB, Q - c0);
+        __syncthreads();                                            // G_J is there (wave 0: above, or during the previous pass's trailing update)
+        const int r_start = (J + 1 < TQ) ? c0 + TB : Q;            // first panel row
+        const int npt = (R_all - r_start + TB - 1) / TB;
+        for (int t = wave; t < npt; t += nw) {                      // panel: L(rows, block J) = A'(rows, block J) G^T, in place (a wave reads its whole tile before it stores)
+            const int r0 = r_start + TB * t;
+            if (r0 >= dead0 && r0 + TB <= dead1) continue;
+            const v4d_t acc = tile16(T + (size_t)min(r0 + li, R_all - 1) * LD + c0, T + (size_t)(c0 + min(li, nJ - 1)) * LD + c0, nJ);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int row = r0 + lk + 4 * q; if (row < R_all && li < nJ) T[(size_t)row * LD + c0 + li] = acc[q]; }
         }
         __syncthreads();
-        if (ty == 0 && row_ok && tx >= c0 + NB) {                  // panel: L(i, c0..) = A'(i, c0..) G^T
-            double* Pr = T + tx * LD + c0;
-            double ev[NB], pv[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) ev[k] = Pr[k];
-#pragma unroll
-            for (int k = 0; k < NB; k++) { double a = 0.0;
-#pragma unroll
-                for (int m = 0; m <= k; m++) a += ev[m] * T[(c0 + k) * LD + c0 + m];
-                pv[k] = a; }
-#pragma unroll
-            for (int k = 0; k < NB; k++) Pr[k] = pv[k];
-        }
-        __syncthreads();
-        if (row_ok && tx >= c0 + NB) {
-            const double* Pr = T + tx * LD + c0;
-            double pv[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) pv[k] = Pr[k];
-            const int cend = (tx < Q) ? tx : Q - 1;                // triangle rows: columns up to the diagonal; B and t rows: all columns
-            for (int cp = c0 + NB + ty; cp <= cend; cp += nty) {
-                const double* Lr = T + cp * LD + c0;
-                double val = T[tx * LD + cp];
-#pragma unroll
-                for (int k = 0; k < NB; k++) val -= pv[k] * Lr[k];
-                T[tx * LD + cp] = val;
+        if (J + 1 < TQ) {
+            // trailing update: tiles (I, Jc), Jc > J, I >= Jc down to the last row tile.  Look-ahead: wave 0 takes the next diagonal tile first and factors it at once --
+            // nothing else touches that tile in this pass, the others only read block column J -- so the 16 dependent steps of the next block leave the critical path
+            if (wave == 0) { trailing_tile(c0, nJ, J + 1, J + 1); factor_diag(c0 + TB, min(TB, Q - c0 - TB)); }
+            else {
+                const int ncol = TQ - 1 - J;
+                int ntask = -1; for (int jc = 0; jc < ncol; jc++) ntask += RT - (J + 1 + jc);          // without the diagonal tile (task 0 of column J + 1)
+                for (int task = wave - 1; task < ntask; task += nw - 1) {
+                    int Jc = J + 1, t2 = task + 1;
+                    while (t2 >= RT - Jc) { t2 -= RT - Jc; Jc++; }
+                    trailing_tile(c0, nJ, Jc + t2, Jc);
+                }
             }
         }
     }
@@ -196,7 +216,6 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
 template <int DC, int NR>
 __device__ __forceinline__ void ring_back_node(const int* __restrict__ r, const double* __restrict__ crL, const double* __restrict__ crF, const double* __restrict__ crW,
                                                double* __restrict__ Y, const int N, const int b, double* __restrict__ lds) {
-    constexpr int NB = DC;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x;
     const int v = r[0], nn = r[1], copy = r[4], p0 = r[5];
     const size_t QQ = (size_t)Q * Q;
@@ -222,19 +241,19 @@ __device__ __forceinline__ void ring_back_node(const int* __restrict__ r, const 
         sv[e] = crW[(size_t)v * NR * Q + e] - acc;
     }
     __syncthreads();
-    for (int c0 = Q - NB; c0 >= 0; c0 -= NB) {
-        if (tid < NB * NR) {
-            const int rr = tid / NB, k = tid - rr * NB;
+    for (int J = (Q + 15) / 16 - 1; J >= 0; J--) {                  // blocks of sixteen columns, the last one shorter (ring_elim_node)
+        const int c0 = 16 * J, nJ = min(16, Q - c0);
+        if (tid < nJ * NR) {
+            const int rr = tid / nJ, k = tid - rr * nJ;
             double acc = 0.0;
-            for (int m = k; m < NB; m++) acc += sL[(c0 + m) * LD + c0 + k] * sv[rr * Q + c0 + m];     // (G^T v_blk)_k
+            for (int m = k; m < nJ; m++) acc += sL[(c0 + m) * LD + c0 + k] * sv[rr * Q + c0 + m];     // (G^T v_blk)_k
             so[rr * Q + c0 + k] = acc;
         }
         __syncthreads();
         for (int e = tid; e < NR * c0; e += nt) {
             const int rr = e / c0, i = e - rr * c0;
             double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < NB; k++) acc += sL[(c0 + k) * LD + i] * so[rr * Q + c0 + k];
+            for (int k = 0; k < nJ; k++) acc += sL[(c0 + k) * LD + i] * so[rr * Q + c0 + k];
             sv[rr * Q + i] -= acc;
         }
         __syncthreads();
