@@ -34,10 +34,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy bandwidth of the box is MEASURED in every run (hbm_copy_GBs, ssfm_debug_copy_bandwidth)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r04m_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r04.sh + collect_final_r04.py) the traffic / VALU figures are read from
+PMC_PROFILE = os.path.join("profiles", "r05s_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r05.sh + collect_final_r05.py) the traffic / VALU figures are read from
 if not os.path.exists(os.path.join(ROOT, PMC_PROFILE)):
-    PMC_PROFILE = os.path.join("profiles", "r03j_pmc_traffic.json")
-ROCPROF_STATS = os.path.join("profiles", "r04m_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
+    PMC_PROFILE = os.path.join("profiles", "r04m_pmc_traffic.json")
+ROCPROF_STATS = os.path.join("profiles", "r05s_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
 
 
 def rocprof_avg_us():
@@ -288,7 +288,7 @@ def side_paths(ctx):
     nz = Xo.any(1)
     pmc_r = {}
     try:
-        pmc_r = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_retriangulate.json")))
+        pmc_r = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_retriangulate.json")))
     except Exception:
         pass
     res["retriangulate"] = {
@@ -298,7 +298,7 @@ def side_paths(ctx):
         "cpu_baseline": {"value": 1e3 * tc, "unit": "ms per call", "cores": 16, "kind": "port", "sample": "the same 100 000 points"},
         "parity_vs_oracle": {"identical_zero_sets": bool(np.array_equal(nz, Xg.any(1))), "identical_inlier_counts": bool(np.array_equal(ning, nino)),
                              "max_rel_point": float((np.linalg.norm(Xg - Xo, axis=1)[nz] / np.linalg.norm(Xo[nz], axis=1)).max())},
-        "valu_issue": pmc_r or {"note": "no committed PMC pass found (profiles/r04_pmc_retriangulate.json)"}}
+        "valu_issue": pmc_r or {"note": "no committed PMC pass found (profiles/r05_pmc_retriangulate.json)"}}
     # ---- irregular structure: 300 cameras, 600k observations, RAGGED tracks of 3..14 (and 3..8) consecutive frames, point ids in build_sfm's
     # order (examples/spherical_sfm_tools.cpp:862-955; synth.make_ragged_circle).  Reports what the same LM loop does when the synthetic circle's regularity is gone:
     # grouped fraction (planner: signature sort + cost model), obs/s, where the time goes, parity and the CPU port beside it.
