@@ -901,7 +901,11 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 loose_pairs = all_pairs - grouped_pairs;
                 // per point: 0.45 ns in the latency-bound regime of one round of tasks (config 2: 100k points, 45 us), 0.27 ns once a class fills the chip for several
                 // rounds (configs[4] size: 1.5 M points of 8 cameras, 391 us)
-                double est_gram = 0; for (double v : cls_pts) if (v > 0) est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v);
+                // round 5: the classes share ONE launch (k_schur_gram_any) unless SSFM_GRAM_ANY=0 -- the latency floor is paid once
+                static const bool any_launch = knob_env_int("SSFM_GRAM_ANY", 1) != 0;
+                double est_gram = 0, v_all = 0;
+                for (double v : cls_pts) if (v > 0) { est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v); v_all += v; }
+                if (any_launch) est_gram = std::max(24.0, (v_all > 3e5 ? 0.27e-3 : 0.45e-3) * v_all);
                 const double obs_all = (double)F.pt_start[F.nP];
                 const double est_loose = loose_pairs > 0 ? std::max(36.0, 22e-6 * loose_pairs) + std::max(20.0, 34.5e-6 * obs_all) : 0.0;
                 const double est_pairs_only = std::max(36.0, 22e-6 * all_pairs) + std::max(20.0, 34.5e-6 * obs_all);

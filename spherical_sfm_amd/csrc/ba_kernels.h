@@ -657,12 +657,13 @@ template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i
 // run then (15.5 us of a 173 us iteration at config 2, 180 of 1550 at the configs[4] size), PS is not read back and the observations are read one pass less.
 // spec (speculative launch behind k_publish, like k_point_lin's): [go, radius] as decided on the device.
 struct GramFuse { const double* scale_pt; double radius, min_diag, max_diag; double* PS_out; double* gp_out; double* scal; const double* spec; };
-template <int DC, int NT, int TI = 0, bool FUSE = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // <= 256 registers (vector + accumulation): at one wave per SIMD config 2's 1800 tasks need two rounds
-k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
-             const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
-             const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int task0, double* __restrict__ S_val, double* __restrict__ rhs,
-             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, GramFuse fz = GramFuse{}) {
+// one wave task of k_schur_gram / k_schur_gram_any (below): the task's tile shape (NT, TI) is a template parameter, the task index an argument
+template <int DC, int NT, int TI, bool FUSE>
+__device__ __forceinline__ void
+schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+                const double2* __restrict__ obs_xy, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
+                const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, const int task, double* __restrict__ S_val, double* __restrict__ rhs,
+                double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, const GramFuse& fz) {
     double fz_radius = fz.radius;
     if (FUSE && fz.spec) { if (fz.spec[0] == 0.0) return; fz_radius = fz.spec[1]; }
     constexpr int BB = DC * DC, off = (DC == 6) ? 0 : 3;                // NT = row tiles of 16 in use: the launch covers the tasks with 16 (NT - 1) < DC K <= 16 NT
@@ -670,8 +671,6 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
     typedef double v4d_ __attribute__((ext_vector_type(4)));
     const long long t_0 = dbg ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) double sY[];          // per wave: [rows_alloc][GRAM_LD] | camera records [GRAM_KMAX][GRAM_CAMREC] | scales | slots | diagonal slots
-    const int task = task0 + __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));   // [task0, ntasks): this launch's tile class
-    if (task >= ntasks) return;
     const int lane = threadIdx.x & 63;
     double* sYw = sY + (size_t)(threadIdx.x >> 6) * (rows_alloc * GRAM_LD + GRAM_TAIL);
     double* sCam = sYw + rows_alloc * GRAM_LD;
@@ -959,6 +958,41 @@ k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, con
         if (lane == 0 && pgmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], pgmax);
     }
     if (dbg && lane == 0) { long long* d = dbg + 4 * (size_t)task; d[0] = t_0; d[1] = t_1; d[2] = t_2; d[3] = wall_clock64(); }   // SSFM_GRAM_STAMPS (timing study)
+}
+
+// one launch per tile class: tasks [task0, ntasks) all have 16 (NT - 1) < DC K <= 16 NT (+ 4 with TI > 0)
+template <int DC, int NT, int TI = 0, bool FUSE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // <= 256 registers (vector + accumulation): at one wave per SIMD config 2's 1800 tasks need two rounds
+k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+             const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
+             const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int task0, double* __restrict__ S_val, double* __restrict__ rhs,
+             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, GramFuse fz = GramFuse{}) {
+    const int task = task0 + __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));   // [task0, ntasks): this launch's tile class
+    if (task >= ntasks) return;
+    schur_gram_task<DC, NT, TI, FUSE>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, dbg, fz);
+}
+// Round 5: ALL tile classes in one launch -- tracks of mixed length (a real sequence: 3 ... 8 cameras per point) gave one launch per class, each with the ~25 us latency
+// floor of a wave task, one after the other on the stream (4 x 25 us against 44 + 21 us through the pair lists: the planner refused the groups, profiles/r04_notes.md
+// r04d).  Here every wave picks the instantiation of its task's class (wave-uniform branch on K; registers and LDS = those of the largest class), so the classes run
+// side by side and the launch costs the longest task once.  A problem with ONE class (config 2, configs[4]) keeps the specialised kernel above.
+template <int DC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+k_schur_gram_any(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+                 const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
+                 const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int use_t4, double* __restrict__ S_val, double* __restrict__ rhs,
+                 double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw) {
+    // the tasks are sorted by K ascending: the longest ones (most tiles) first
+    const int task = ntasks - 1 - __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (task < 0) return;
+    const int rows = DC * __builtin_amdgcn_readfirstlane(gr_rec[(size_t)task * GRAM_REC + 2]);
+    const GramFuse fz{};
+#define SSFM_GRAM_ANY(NT_, TI_) schur_gram_task<DC, NT_, TI_, false>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, nullptr, fz)
+    if (rows <= 16) SSFM_GRAM_ANY(1, 0);
+    else if (rows <= 20 && use_t4) SSFM_GRAM_ANY(1, 2);
+    else if (rows <= 32) SSFM_GRAM_ANY(2, 0);
+    else if (DC == 6 && rows <= 36 && use_t4) SSFM_GRAM_ANY(2, 3);
+    else if (DC == 6) SSFM_GRAM_ANY(3, 0);
+#undef SSFM_GRAM_ANY
 }
 
 // EXPERIMENT (SSFM_PAIRS_Y_PROBE=1, not part of the solve): the pair pass if every observation carried a stored half product

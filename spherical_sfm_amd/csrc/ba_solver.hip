@@ -201,8 +201,23 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
 #else
 #define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false)
 #endif
-            SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
-            if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
+            int n_cls = 0; for (int c = 0; c < 5; c++) if (cls_end[c] > (c ? cls_end[c - 1] : 0)) n_cls++;
+            static const bool gram_any = knob_env_int("SSFM_GRAM_ANY", 1) != 0;      // 0: one launch per tile class, one after the other (rounds 3-4)
+            bool any_ok = gram_any && n_cls > 1 && gram_waves == 1 && !gram_dbg;
+#ifdef SSFM_LAB
+            any_ok = any_ok && !fuse_lin;
+#endif
+            if (any_ok) {
+                // tracks of mixed length: every tile class in ONE launch (ba_kernels.h: k_schur_gram_any), LDS for the largest class
+                const int rows_alloc = DC * F.gr_rec[(size_t)(ng - 1) * GRAM_REC + 2];
+                const size_t gram_lds = ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);
+                if (gram_lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram_any<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
+                LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram_any<DC>), ng, 64, gram_lds, xc, xr, xp, xf, oxy, ng, h->gr_rec.p, h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc,
+                       F.focal_free ? 1 : 0, gram_t4 ? 1 : 0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw);
+            } else {
+                SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
+                if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
+            }
 #undef SSFM_GRAM_LAUNCH
 #undef SSFM_GRAM_LAUNCH_
             if (gram_dbg) {                                        // print the phase times of this launch (100 MHz clock) and stop stamping
