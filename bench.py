@@ -303,8 +303,8 @@ def side_paths(ctx):
     # order (examples/spherical_sfm_tools.cpp:862-955; synth.make_ragged_circle).  Reports what the same LM loop does when the synthetic circle's regularity is gone:
     # grouped fraction (planner: signature sort + cost model), obs/s, where the time goes, parity and the CPU port beside it.
     res["ba_irregular"] = {}
-    for max_len in (14, 8):
-        prob = synth.make_ragged_circle(300, 600000, 3, max_len)
+    for ncam_i, nobs_i, max_len in ((300, 600000, 14), (300, 600000, 8), (1000, 3000000, 8)):
+        prob = synth.make_ragged_circle(ncam_i, nobs_i, 3, max_len)
         info, _, _, _ = ba.plan(prob)
         adj = ba.BundleAdjuster(ctx, prob)
         adj.reset(); adj.run()
@@ -317,8 +317,8 @@ def side_paths(ctx):
         adj.close()
         t = time.perf_counter(); oc, op, of, os_ = O.ba_solve(prob); tcpu = time.perf_counter() - t
         tot = sum(v["total_ms"] for v in kt.values()) or 1.0
-        res["ba_irregular"][f"tracks_3_to_{max_len}"] = {
-            "workload": f"300 cameras x {len(prob.points)} points x {len(prob.obs_cam)} observations, tracks of 3..{max_len} consecutive frames, general BA, focal fixed",
+        res["ba_irregular"][f"tracks_3_to_{max_len}" + ("" if ncam_i == 300 else f"_{ncam_i}_cameras")] = {
+            "workload": f"{ncam_i} cameras x {len(prob.points)} points x {len(prob.obs_cam)} observations, tracks of 3..{max_len} consecutive frames, general BA, focal fixed",
             "value": len(prob.obs_cam) * n / dt, "unit": "obs/s", "ms_per_lm_iteration": 1e3 * dt / n, "lm_iterations": sa["iterations"],
             "grouped_fraction_of_observations": info["num_observations_grouped"] / max(1, info["num_observations_used"]),
             "band_half_width": info["band_half_width"], "band_segments": info["band_segments"], "band_separators": info["band_separators"],
@@ -328,8 +328,9 @@ def side_paths(ctx):
                              "sample": "the same problem, one solve", "wall_s": tcpu},
             "parity_vs_oracle": {"max_rel_camera": float(np.abs(cg - oc).max() / np.abs(oc).max()),
                                  "max_rel_point": float((np.linalg.norm(pg - op, axis=1) / np.linalg.norm(op, axis=1)).max()), "iterations_cpu": os_["iterations"]},
-            "note": "one connected ring of 300 cameras: the reduced system's band is 2 x (longest track - 1) wide; beyond half-width 21 the LDS-resident factorisation does not "
-                    "fit and the global-memory kernel runs (DESIGN.md 4 / 7)"}
+            "note": "one connected ring of cameras laid out in its own circular order (round 5: half-width = longest track - 1, separators by cyclic reduction, DESIGN.md 4b); "
+                    "signature groups (k_schur_gram_any: all track lengths in one launch) when the planner's cost model expects them to beat the pair lists -- at 600k observations "
+                    "they do not (70 us against 43 + 20 us), at 3 M they do (160 against 162 + 62 us)"}
     # ---- the drivers' whole stage sequence at BASELINE configs[2] size (500 frames / 170 000 points / 1.02 M observations, shared focal free, -generalba):
     # Optimize -> Retriangulate -> Optimize -> unfix t -> Optimize -> Normalize -> Retriangulate -> Optimize -> Normalize (examples/run_spherical_sfm_uncalib.cpp:176-222)
     # through the C++ mirror (spherical_sfm_amd/demo_circle = shim/demo_circle.cpp, its own process and context), wall per stage as the driver sees it (flatten +

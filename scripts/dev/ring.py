@@ -50,6 +50,7 @@ for c in cases:
     elif c == "sph2000": run_ba(c, synth.make_circle(2000, 24000, 6, spherical=True, focal_fixed=True, seed=8), chk)
     elif c == "ragged14": run_ba(c, synth.make_ragged_circle(300, 600000, 3, 14), chk)
     elif c == "ragged8": run_ba(c, synth.make_ragged_circle(300, 600000, 3, 8), chk)
+    elif c.startswith("bigragged"): run_ba(c, synth.make_ragged_circle(1000, 3000000, 3, int(c[9:])), chk)
     elif c.startswith("ragged"): run_ba(c, synth.make_ragged_circle(300, 600000, 3, int(c[6:])), chk)
     elif c.startswith("sragged"): run_ba(c, synth.make_ragged_circle(300, 600000, 3, int(c[7:]), spherical=True), chk)
     elif c.startswith("circle"): run_ba(c, synth.make_circle(int(c[6:]), 100 * int(c[6:]), 6, spherical=False, focal_fixed=True, seed=3), chk)

@@ -902,10 +902,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 // per point: 0.45 ns in the latency-bound regime of one round of tasks (config 2: 100k points, 45 us), 0.27 ns once a class fills the chip for several
                 // rounds (configs[4] size: 1.5 M points of 8 cameras, 391 us)
                 // round 5: the classes share ONE launch (k_schur_gram_any) unless SSFM_GRAM_ANY=0 -- the latency floor is paid once
-                static const bool any_launch = knob_env_int("SSFM_GRAM_ANY", 1) != 0;
+                const bool any_launch = knob_env_int("SSFM_GRAM_ANY", 1) != 0;       // read per plan: tests switch it
                 double est_gram = 0, v_all = 0;
                 for (double v : cls_pts) if (v > 0) { est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v); v_all += v; }
-                if (any_launch) est_gram = std::max(24.0, (v_all > 3e5 ? 0.27e-3 : 0.45e-3) * v_all);
+                if (any_launch && v_all > 0) est_gram *= 0.75;     // measured: tracks 3 ... 8, 600k observations, 2336 tasks of ~47 points: 70 us in one launch against 4 x 23.6 (pair lists: 43 + 20)
                 const double obs_all = (double)F.pt_start[F.nP];
                 const double est_loose = loose_pairs > 0 ? std::max(36.0, 22e-6 * loose_pairs) + std::max(20.0, 34.5e-6 * obs_all) : 0.0;
                 const double est_pairs_only = std::max(36.0, 22e-6 * all_pairs) + std::max(20.0, 34.5e-6 * obs_all);

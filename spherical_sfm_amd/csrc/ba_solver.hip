@@ -202,7 +202,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
 #define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false)
 #endif
             int n_cls = 0; for (int c = 0; c < 5; c++) if (cls_end[c] > (c ? cls_end[c - 1] : 0)) n_cls++;
-            static const bool gram_any = knob_env_int("SSFM_GRAM_ANY", 1) != 0;      // 0: one launch per tile class, one after the other (rounds 3-4)
+            const bool gram_any = knob_env_int("SSFM_GRAM_ANY", 1) != 0;      // 0: one launch per tile class, one after the other (rounds 3-4)
             bool any_ok = gram_any && n_cls > 1 && gram_waves == 1 && !gram_dbg;
 #ifdef SSFM_LAB
             any_ok = any_ok && !fuse_lin;

@@ -167,3 +167,25 @@ def test_runs_of_every_tile_class_in_one_problem(gpu_ctx, oracle, monkeypatch, s
     adj = ba.BundleAdjuster(gpu_ctx, p); adj.set_profiling(True); st = adj.run(); kt = adj.kernel_times(); adj.close()
     assert kt["k_schur_gram"]["launches"] >= 2 * st["num_linearizations"]
     assert kt["k_schur_pairs2"]["launches"] > 0
+
+
+@pytest.mark.parametrize("max_len,spherical,focal_fixed", [(8, False, True), (8, True, False), (7, False, False), (5, True, True)])
+def test_mixed_track_lengths_in_one_launch(gpu_ctx, oracle, monkeypatch, max_len, spherical, focal_fixed):
+    """Round 5 (ba_kernels.h: k_schur_gram_any): tracks of 3 ... max_len cameras give signature groups of several tile classes; one launch serves them all (every wave
+    picks the instantiation of its task's class).  Against the oracle, against one launch per class (SSFM_GRAM_ANY=0, rounds 3-4) and against the pair lists."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_ragged_circle(120, 330000, 3, max_len, spherical=spherical, focal_fixed=focal_fixed)
+    info = ba.plan(p)[0]
+    assert info["num_observations_grouped"] >= 0.9 * info["num_observations_used"]                   # every track length from 3 on sits in groups
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    ocams, opts, of, os_ = oracle.ba_solve(p)
+    assert s["termination"] == os_["termination"] == 0 and s["iterations"] == os_["iterations"] and s["pcg_iterations_total"] == 0
+    assert abs(s["final_cost"] - os_["final_cost"]) <= 1e-9 * os_["final_cost"]
+    assert rel_err(cams, ocams) <= 1e-6 and abs(f - of) <= 1e-6 * of
+    assert (np.linalg.norm(pts - opts, axis=1) / np.linalg.norm(opts, axis=1)).max() <= 1e-5
+    for var, val in (("SSFM_GRAM_ANY", "0"), ("SSFM_GRAM", "0")):
+        monkeypatch.setenv(var, val)
+        c0, p0, f0, s0 = ba.optimize(gpu_ctx, p)
+        monkeypatch.delenv(var)
+        assert s0["iterations"] == s["iterations"] and rel_err(cams, c0) <= 1e-8 and rel_err(pts, p0) <= 1e-8 and abs(f - f0) <= 1e-10 * f0
