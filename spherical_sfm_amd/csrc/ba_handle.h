@@ -24,13 +24,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_RING_TAIL, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_RING_TAIL, KID_DET_DECODE, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back", "k_ring_cr_tail"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back", "k_ring_cr_tail", "k_det_decode"};
 
 // SSFM_PLAN_TIMING: time spent in hipMalloc (atomic: the observation arrays are allocated by the upload thread of ba_create_impl while the main thread plans)
 static bool g_alloc_timing = false; static std::atomic<long long> g_alloc_ns{0}; static std::atomic<int> g_alloc_n{0};
@@ -79,6 +79,8 @@ struct ssfm_ba_handle {
     // BA: scal, pcg and redbuf are views into one of two zones; an LM iteration works in one while the memset of the other (for the next
     // iteration) is already queued behind it, off the host's critical path
     DevBuf<double> zone; bool zone_views = false; size_t zone_len = 0, zone_nnz = 0, zone_n = 0;
+    // SSFM_DETERMINISTIC=1 (det_acc.h): the assembly adds fixed-point limbs with integer atomics instead of doubles; k_det_decode turns them into the zone's doubles
+    bool det = false; DevBuf<long long> det_limb, det_lacc; DevBuf<double> det_dfpart; size_t det_nacc = 0;
     void set_zone(int which) {
         scal.p = zone.p + (size_t)which * zone_len; pcg.p = scal.p + scal.n; redbuf.p = pcg.p + pcg.n;
         S_val = redbuf.p; rhs = S_val + zone_nnz; Udiag = rhs + (zone_n + 1); Sfc = Udiag + zone_n; gcraw = Sfc + zone_n; red_scal = gcraw + zone_n;
@@ -207,9 +209,10 @@ static bool publish_alloc(ssfm_ba_handle* h) {
     h->host_pub = ctx->host_pub;
     return true;
 }
-static void publish(ssfm_ba_handle* h, const LmGate* gate = nullptr, double* spec = nullptr) {
+static void publish(ssfm_ba_handle* h, const LmGate* gate = nullptr, double* spec = nullptr, unsigned det_kmask = 0) {
     LmGate g; std::memset(&g, 0, sizeof(g)); if (gate) g = *gate;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq, g, spec);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(SC_TOTAL * 64), 0, h->ctx->stream, h->scal.p, h->pcg.p, h->host_pub, ++h->ctx->pub_seq, g, spec,
+                       (h->det && det_kmask) ? h->det_lacc.p : (long long*)nullptr, det_kmask);
 }
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
@@ -620,7 +623,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         if (phi_parts > 0) LAUNCH(h, KID_BAND_COMBINE, k_arrow_phi<DC>, phi_parts, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->cam_pos.p, Nc, h->pqpart.p);
         LAUNCH(h, KID_PCG_MATVEC, k_arrow_update<DC>, (Nc + 3) / 4, 512, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
                h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p, h->tail.cam, h->tail.focal, h->scale_cam.p, h->scale_f.p,
-               h->tail.cam_c, h->tail.focal_c, h->tail.rot_c, h->scal.p, h->pqpart.p, phi_parts, h->col_pos.p, h->trans_pos.p);
+               h->tail.cam_c, h->tail.focal_c, h->tail.rot_c, h->scal.p, h->pqpart.p, phi_parts, h->col_pos.p, h->trans_pos.p, h->det ? h->det_lacc.p : (long long*)nullptr);
     } else if (F.sym_lower) {
         LAUNCH(h, KID_PCG_MATVEC, k_arrow_matvec<DC>, (Nc + 3) / 4, 256, 0, h->Yb.p, h->Yb.p + nb, h->Sfc, h->Sff.p, h->rhs + n, h->cam_pos.p, h->row_ptr.p, h->col_idx.p,
                h->trans_ptr.p, h->trans_blk.p, h->trans_row.p, h->S_val, Nc, h->px.p, h->pq.p);

@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ssfm_math.h"
+#include "det_acc.h"
 
 namespace ssfm {
 
@@ -45,6 +46,43 @@ enum {
 // mod SC_NSLOT); readers fold the replicas (k_finalize_S on the device, the host after the copy, k_scal_fold before a collective).
 constexpr int SC_NSLOT = 64;
 __device__ __forceinline__ double* scal_slot(double* scal) { return scal + (size_t)(blockIdx.x & (SC_NSLOT - 1)) * SC_TOTAL; }
+// SSFM_DETERMINISTIC (det_acc.h): the scalar block's sums go to long accumulators instead -- entry (replica, k) of the block at `base` has its LA_STRIDE words at
+// lacc[(replica SC_TOTAL + k) LA_STRIDE]; lacc == nullptr: the floating-point atomic
+struct DetScal { const double* base = nullptr; long long* lacc = nullptr; };
+__device__ __forceinline__ void sadd(const DetScal& ds, double* p, double v) {
+    if (!ds.lacc) { unsafeAtomicAdd(p, v); return; }
+    lacc_add(ds.lacc + (size_t)(p - ds.base) * LA_STRIDE, v);
+}
+// limbs -> doubles, and the limbs cleared for the next assembly.  Workgroups [0, gz): entries [0, n) of the zone at `zone` (two limbs each; a poisoned assembly decodes
+// to NaN); the last workgroup: the scalars k with bit k of kmask set, summed over the SC_NSLOT replicas of the long accumulators, into replica 0 of `scal`.
+static __global__ void __launch_bounds__(256)
+k_det_decode(double* __restrict__ zone, long long* __restrict__ limb, size_t n, int gz, double* __restrict__ scal, long long* __restrict__ lacc, unsigned kmask) {
+    if ((int)blockIdx.x < gz) {
+        const bool poisoned = limb[-1] != 0;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gz * blockDim.x) {
+            const long long hi = limb[2 * i], lo = limb[2 * i + 1];
+            zone[i] = poisoned ? __builtin_nan("") : zdecode(hi, lo);
+            if (hi != 0 || lo != 0) { limb[2 * i] = 0; limb[2 * i + 1] = 0; }
+        }
+        return;
+    }
+    // one wave per scalar in turn: lane = replica
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int k = w; k < SC_TOTAL; k += nw) {
+        if (!((kmask >> k) & 1u)) continue;
+        long long* a = lacc + ((size_t)lane * SC_TOTAL + k) * LA_STRIDE;
+        long long tot[LA_STRIDE];
+#pragma unroll
+        for (int j = 0; j < LA_STRIDE; j++) {
+            long long v = a[j];
+            if (v != 0) a[j] = 0;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);          // integer sums: exact, any order
+            tot[j] = v;
+        }
+        if (lane == 0) scal[k] = lacc_value(tot, tot[LA_NL]);
+    }
+}
 enum { PCG_RZ = 0, PCG_BN2 = 1, PCG_RR = 2, PCG_DONE = 3, PCG_ITERS = 4, PCG_BREAKDOWN = 5, PCG_TOTAL = 8 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -249,7 +287,7 @@ static __global__ void k_colnorm(const double* __restrict__ cam, const double* _
                           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                           const int* __restrict__ pt_start, int nP, int loss, double la,
                           double* __restrict__ diag_pt, double* __restrict__ diag_f,
-                          const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi) {
+                          const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi, double* __restrict__ df_part = nullptr) {
     __shared__ double red[8];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double df[1] = {0.0};
@@ -266,7 +304,7 @@ static __global__ void k_colnorm(const double* __restrict__ cam, const double* _
         for (int k = 0; k < 3; k++) { diag_pt[3 * p + k] = dp[k]; scale_pt[3 * p + k] = mask_pt[3 * p + k] * (jacobi ? 1.0 / (1.0 + sqrt(dp[k])) : 1.0); }
     }
     block_sum<1>(df, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(diag_f, df[0]);
+    if (threadIdx.x == 0) { if (df_part) df_part[blockIdx.x] = df[0]; else unsafeAtomicAdd(diag_f, df[0]); }     // df_part (deterministic mode): k_startup_tail adds the parts in order
 }
 static __global__ void __launch_bounds__(256)
 k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
@@ -304,7 +342,8 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
             const int* __restrict__ pt_start, int nP, const double* __restrict__ scale_pt, const double* __restrict__ scale_f,
             int loss, double la, double radius, double min_diag, double max_diag,
             double* __restrict__ Vs, double* __restrict__ gp, double* __restrict__ scal,
-            const double* __restrict__ spec) {
+            const double* __restrict__ spec, long long* __restrict__ lacc = nullptr) {
+    const DetScal ds{scal, lacc};
     // spec (speculative launch behind k_publish of the previous iteration): [go, radius] as decided on the device
     if (spec) { if (spec[0] == 0.0) return; radius = spec[1]; }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,7 +422,7 @@ k_point_lin(const double* __restrict__ cam, const double* __restrict__ rot, cons
     gmax = wave_max(gmax);
     const int slot = wave_tr_index();
     double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
-    if (slot < 5) unsafeAtomicAdd(&sl[slot], t);
+    if (slot < 5) sadd(ds, &sl[slot], t);
     if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&sl[SC_GMAX], gmax);
 }
 
@@ -413,7 +452,7 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
             const int* __restrict__ task_q1, int ntasks, const int* __restrict__ row_ptr, const int* __restrict__ diag_slot,
             const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ PS, int loss, double la,
             double* __restrict__ S_val, double* __restrict__ rhs, double* __restrict__ Udiag, double* __restrict__ Sfc,
-            double* __restrict__ gcraw, const unsigned char* __restrict__ pt_skip) {
+            double* __restrict__ gcraw, const unsigned char* __restrict__ pt_skip, DetZone dz = DetZone{}) {
     constexpr int BB = DC * DC;
     constexpr int NU = DC * (DC + 1) / 2;
     constexpr int NSM = NU + 4 * DC;           // [S_cc (upper) | Jc^T r | -W g' | focal coupling | diag U]   (<= 64 for DC <= 6)
@@ -484,11 +523,11 @@ k_cam_sums2(const double* __restrict__ cam, const double* __restrict__ rot, cons
         int a = 0, rem = slot; while (rem >= DC - a) { rem -= DC - a; a++; }
         const int b = a + rem;
         double* blk = S_val + ((size_t)row_ptr[c] + diag_slot[c]) * BB;
-        unsafeAtomicAdd(&blk[a * DC + b], mine); if (b != a) unsafeAtomicAdd(&blk[b * DC + a], mine);
-    } else if (slot < NU + DC) { const int a = slot - NU; unsafeAtomicAdd(&rhs[c * DC + a], mine); unsafeAtomicAdd(&gcraw[c * DC + a], mine); }
-    else if (slot < NU + 2 * DC) unsafeAtomicAdd(&rhs[c * DC + slot - NU - DC], mine);
-    else if (slot < NU + 3 * DC) unsafeAtomicAdd(&Sfc[c * DC + slot - NU - 2 * DC], mine);
-    else if (slot < NSM) unsafeAtomicAdd(&Udiag[c * DC + slot - NU - 3 * DC], mine);
+        zadd(dz, &blk[a * DC + b], mine); if (b != a) zadd(dz, &blk[b * DC + a], mine);
+    } else if (slot < NU + DC) { const int a = slot - NU; zadd(dz, &rhs[c * DC + a], mine); zadd(dz, &gcraw[c * DC + a], mine); }
+    else if (slot < NU + 2 * DC) zadd(dz, &rhs[c * DC + slot - NU - DC], mine);
+    else if (slot < NU + 3 * DC) zadd(dz, &Sfc[c * DC + slot - NU - 2 * DC], mine);
+    else if (slot < NSM) zadd(dz, &Udiag[c * DC + slot - NU - 3 * DC], mine);
 }
 
 // ---- Schur complement from the slot-sorted pair lists, second generation ------------------------------------------
@@ -506,7 +545,7 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
                const int* __restrict__ col_idx, const int* __restrict__ task_cam, const int* __restrict__ task_b0,
                const int* __restrict__ task_b1, int ntasks, const int* __restrict__ batch_slot, const int* __restrict__ pair_j,
                const int* __restrict__ pair_j2, const int* __restrict__ pair_p, const double* __restrict__ scale_cam,
-               const double* __restrict__ Vs, int loss, double la, double* __restrict__ S_val) {
+               const double* __restrict__ Vs, int loss, double la, double* __restrict__ S_val, DetZone dz = DetZone{}) {
     constexpr int BB = DC * DC;
     const int lane = threadIdx.x & 63;
     const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -544,7 +583,7 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
         if (tr_slot < BB) {                                // Jacobi scales of both cameras, once per folded block
             constexpr int off = (DC == 6) ? 0 : 3;
             const int a = tr_slot / DC, b = tr_slot - a * DC, c2f = col_idx[rb + cur];
-            unsafeAtomicAdd(&dst[tr_slot], v * scale_cam[6 * c + off + a] * scale_cam[6 * c2f + off + b]);
+            zadd(dz, &dst[tr_slot], v * scale_cam[6 * c + off + a] * scale_cam[6 * c2f + off + b]);
         }
     };
 #define SP2_COMPUTE(bt_, X_, V_, o_, o2_, wgt_)                                                                       \
@@ -663,7 +702,7 @@ __device__ __forceinline__ void
 schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
                 const double2* __restrict__ obs_xy, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
                 const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, const int task, double* __restrict__ S_val, double* __restrict__ rhs,
-                double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, const GramFuse& fz) {
+                double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, const GramFuse& fz, const DetZone& dz) {
     double fz_radius = fz.radius;
     if (FUSE && fz.spec) { if (fz.spec[0] == 0.0) return; fz_radius = fz.spec[1]; }
     constexpr int BB = DC * DC, off = (DC == 6) ? 0 : 3;                // NT = row tiles of 16 in use: the launch covers the tasks with 16 (NT - 1) < DC K <= 16 NT
@@ -892,10 +931,10 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                     const int b = a + rem;
                     const double w = v * sc[a] * sc[b];
                     sU[lq * BB + a * DC + b] = w;
-                    if (b != a) sU[lq * BB + b * DC + a] = w; else unsafeAtomicAdd(&Udiag[c * DC + a], w);
-                } else if (i < NU + DC) { const int a = i - NU; unsafeAtomicAdd(&rhs[c * DC + a], v * sc[a]); unsafeAtomicAdd(&gcraw[c * DC + a], v * sc[a]); }
-                else if (i < NU + 2 * DC) { const int a = i - NU - DC; unsafeAtomicAdd(&rhs[c * DC + a], v * sc[a]); }
-                else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; unsafeAtomicAdd(&Sfc[c * DC + a], v * sc[a]); }
+                    if (b != a) sU[lq * BB + b * DC + a] = w; else zadd(dz, &Udiag[c * DC + a], w);
+                } else if (i < NU + DC) { const int a = i - NU; zadd(dz, &rhs[c * DC + a], v * sc[a]); zadd(dz, &gcraw[c * DC + a], v * sc[a]); }
+                else if (i < NU + 2 * DC) { const int a = i - NU - DC; zadd(dz, &rhs[c * DC + a], v * sc[a]); }
+                else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; zadd(dz, &Sfc[c * DC + a], v * sc[a]); }
             }
         }
     }
@@ -916,12 +955,12 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                     if (b < a) {
                         const int sl = sSlot[a * (a - 1) / 2 + b];
                         double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
-                        unsafeAtomicAdd(&blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                        zadd(dz, &blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
                     } else {                                            // diagonal block of camera a: a diagonal tile holds both triangles, a tile below the diagonal only (da > db)
                         double* blk = S_val + (size_t)sDiag[a] * BB;
                         const double w = v + sU[a * BB + da * DC + db];
-                        unsafeAtomicAdd(&blk[da * DC + db], w);
-                        if (ti != tj) unsafeAtomicAdd(&blk[db * DC + da], w);
+                        zadd(dz, &blk[da * DC + db], w);
+                        if (ti != tj) zadd(dz, &blk[db * DC + da], w);
                     }
                 }
             }
@@ -939,12 +978,12 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                 if (b < a) {
                     const int sl = sSlot[a * (a - 1) / 2 + b];
                     double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
-                    unsafeAtomicAdd(&blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                    zadd(dz, &blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
                 } else {
                     double* blk = S_val + (size_t)sDiag[a] * BB;
                     const double w = v + sU[a * BB + da * DC + db];
-                    unsafeAtomicAdd(&blk[da * DC + db], w);
-                    if (C < 16 * NT) unsafeAtomicAdd(&blk[db * DC + da], w);
+                    zadd(dz, &blk[da * DC + db], w);
+                    if (C < 16 * NT) zadd(dz, &blk[db * DC + da], w);
                 }
             }
         }
@@ -966,10 +1005,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  
 k_schur_gram(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
              const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
              const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int task0, double* __restrict__ S_val, double* __restrict__ rhs,
-             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, GramFuse fz = GramFuse{}) {
+             double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, long long* __restrict__ dbg, GramFuse fz = GramFuse{}, DetZone dz = DetZone{}) {
     const int task = task0 + __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));   // [task0, ntasks): this launch's tile class
     if (task >= ntasks) return;
-    schur_gram_task<DC, NT, TI, FUSE>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, dbg, fz);
+    schur_gram_task<DC, NT, TI, FUSE>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, dbg, fz, dz);
 }
 // Round 5: ALL tile classes in one launch -- tracks of mixed length (a real sequence: 3 ... 8 cameras per point) gave one launch per class, each with the ~25 us latency
 // floor of a wave task, one after the other on the stream (4 x 25 us against 44 + 21 us through the pair lists: the planner refused the groups, profiles/r04_notes.md
@@ -980,13 +1019,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_schur_gram_any(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
                  const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam, const double* __restrict__ scale_f,
                  const double* __restrict__ PS, int loss, double la, int rows_alloc, int focal_free, int use_t4, double* __restrict__ S_val, double* __restrict__ rhs,
-                 double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw) {
+                 double* __restrict__ Udiag, double* __restrict__ Sfc, double* __restrict__ gcraw, DetZone dz = DetZone{}) {
     // the tasks are sorted by K ascending: the longest ones (most tiles) first
     const int task = ntasks - 1 - __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (task < 0) return;
     const int rows = DC * __builtin_amdgcn_readfirstlane(gr_rec[(size_t)task * GRAM_REC + 2]);
     const GramFuse fz{};
-#define SSFM_GRAM_ANY(NT_, TI_) schur_gram_task<DC, NT_, TI_, false>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, nullptr, fz)
+#define SSFM_GRAM_ANY(NT_, TI_) schur_gram_task<DC, NT_, TI_, false>(cam, rot, pts, focal, obs_xy, gr_rec, scale_cam, scale_f, PS, loss, la, rows_alloc, focal_free, task, S_val, rhs, Udiag, Sfc, gcraw, nullptr, fz, dz)
     if (rows <= 16) SSFM_GRAM_ANY(1, 0);
     else if (rows <= 20 && use_t4) SSFM_GRAM_ANY(1, 2);
     else if (rows <= 32) SSFM_GRAM_ANY(2, 0);
@@ -1550,7 +1589,9 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
                const double* __restrict__ S_val, int Nc, double* __restrict__ x, double* __restrict__ q,
                const double* __restrict__ cam, const double* __restrict__ focal, const double* __restrict__ scale_cam,
                const double* __restrict__ scale_f, double* __restrict__ cam_c, double* __restrict__ focal_c, double* __restrict__ rot_c,
-               double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts, const int* __restrict__ col_pos, const int* __restrict__ trans_pos) {
+               double* __restrict__ scal, const double* __restrict__ phi_part, int phi_parts, const int* __restrict__ col_pos, const int* __restrict__ trans_pos,
+               long long* __restrict__ lacc = nullptr) {
+    const DetScal ds{scal, lacc};
     __shared__ double red[2 * 8];
     __shared__ double part[4][64];
     __shared__ double part2[4][2];
@@ -1639,7 +1680,7 @@ k_arrow_update(const double* __restrict__ V, const double* __restrict__ U, const
             focal_c[0] = vf;
         }
         double* sl = scal_slot(scal);
-        unsafeAtomicAdd(&sl[SC_STEP2_CAM], a0); unsafeAtomicAdd(&sl[SC_XN2_CAM], a1);
+        sadd(ds, &sl[SC_STEP2_CAM], a0); sadd(ds, &sl[SC_XN2_CAM], a1);
     }
 }
 
@@ -1655,9 +1696,26 @@ __device__ __forceinline__ double coherent_load(const double* p) {          // s
 // The end-of-iteration hand-over (fold of the scalar replicas, solver flags, the device's accept decision, sequence number into pinned host memory) as a
 // function any workgroup of >= 64 threads can run: k_publish is one launch of it, k_point_backsub's last workgroup runs it in place of that launch.
 __device__ __forceinline__ void publish_body(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
-                                             const LmGate& gate, double* __restrict__ spec, double* folded /* LDS [SC_TOTAL] */) {
+                                             const LmGate& gate, double* __restrict__ spec, double* folded /* LDS [SC_TOTAL] */,
+                                             long long* __restrict__ lacc = nullptr, unsigned kmask = 0) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int k = w; k < SC_TOTAL; k += nw) {
+        if (lacc && ((kmask >> k) & 1u)) {
+            // deterministic mode (det_acc.h): this scalar's sums sit in the long accumulators of the 64 replicas -- integer wave sums, then the value; the limbs are
+            // cleared for the next iteration (what k_det_decode does in a launch of its own for the sums of the assembly)
+            long long* a = lacc + ((size_t)lane * SC_TOTAL + k) * LA_STRIDE;
+            long long tot[LA_STRIDE];
+#pragma unroll
+            for (int j = 0; j < LA_STRIDE; j++) {
+                long long v = __hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v != 0) a[j] = 0;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                tot[j] = v;
+            }
+            if (lane == 0) folded[k] = lacc_value(tot, tot[LA_NL]);
+            continue;
+        }
         const double v = coherent_load(scal + (size_t)(lane & (SC_NSLOT - 1)) * SC_TOTAL + k);
         const double r = (k == SC_GMAX) ? wave_max(v) : wave_sum(v);
         if (lane == 0) folded[k] = r;
@@ -1738,7 +1796,8 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
                 // fused hand-over (pub_host != nullptr): the workgroup that finishes LAST (a ticket) folds the scalars and publishes them, which
                 // takes the k_publish launch (4.7 us in a dependent stream) off the iteration
                 int* __restrict__ pub_ticket = nullptr, double* __restrict__ pub_host = nullptr, unsigned long long pub_seq = 0,
-                const LmGate pub_gate = LmGate(), double* __restrict__ pub_spec = nullptr) {
+                const LmGate pub_gate = LmGate(), double* __restrict__ pub_spec = nullptr, long long* __restrict__ lacc = nullptr) {
+    const DetScal ds{scal, lacc};
     __shared__ double red[4 * 4];
     const bool residual_block = res_r && blockIdx.x == gridDim.x - 1;
     if (residual_block) {
@@ -1826,7 +1885,7 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
     const double t = wave_transpose_sum(acc);
     const int slot = wave_tr_index();
     double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (SC_NSLOT - 1)) * SC_TOTAL;
-    if (slot < 4 && !residual_block) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
+    if (slot < 4 && !residual_block) sadd(ds, &sl[SC_MODEL + slot], t);
     if (pub_host) {
         __shared__ int s_last; __shared__ double folded[SC_TOTAL];
         __threadfence();                                    // this workgroup's sums / flags are in L2 before its ticket is
@@ -1857,7 +1916,8 @@ k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, c
                const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
                // residual check of the reduced solve by one extra workgroup behind the task workgroups when res_r is given (as in k_point_backsub)
                const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
-               const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg) {
+               const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg, long long* __restrict__ lacc = nullptr) {
+    const DetScal ds{scal, lacc};
     constexpr int off = (DC == 6) ? 0 : 3;
     extern __shared__ __attribute__((aligned(16))) double sB[];          // per wave: camera records [K][34] | candidate [t | R] [K][12] | scaled camera steps [K][6]
     if (res_r && blockIdx.x == gridDim.x - 1) { __shared__ double red[4 * 4]; residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red); return; }
@@ -1955,7 +2015,7 @@ k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, c
     const double t = wave_transpose_sum(acc);
     const int slot = wave_tr_index();
     double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + wave) & (SC_NSLOT - 1)) * SC_TOTAL;
-    if (slot < 4) unsafeAtomicAdd(&sl[SC_MODEL + slot], t);
+    if (slot < 4) sadd(ds, &sl[SC_MODEL + slot], t);
 }
 
 // ---- K4: robustified cost at a state (one lane per point) ----------------------------------------------
@@ -2000,9 +2060,9 @@ k_scal_fold(double* __restrict__ scal, double* __restrict__ packed, int rank) {
 // the next iteration's k_point_lin (queued before the host has seen the scalars); the host decides for itself and stays authoritative.
 static __global__ void __launch_bounds__(SC_TOTAL * 64)
 k_publish(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
-          const LmGate gate, double* __restrict__ spec) {
+          const LmGate gate, double* __restrict__ spec, long long* __restrict__ lacc = nullptr, unsigned kmask = 0) {
     __shared__ double folded[SC_TOTAL];
-    publish_body(scal, pcg, host_out, seq, gate, spec, folded);
+    publish_body(scal, pcg, host_out, seq, gate, spec, folded, lacc, kmask);
 }
 // after the all-reduce: sums back into replica 0, gradient max = max over the per-rank slots
 static __global__ void __launch_bounds__(64)
@@ -2030,7 +2090,10 @@ static __global__ void k_startup_tail(const double* __restrict__ pts, const doub
                                       const double* __restrict__ focal, const double* __restrict__ mask_f,
                                       const double* __restrict__ diag_cam, double* __restrict__ scale_cam,     // scale_cam == nullptr: already written
                                       const double* __restrict__ diag_f, double* __restrict__ scale_f, int jacobi, // scale_f == nullptr: scales kept from an earlier solve
-                                      double* __restrict__ out_pt, double* __restrict__ out_cam) {
+                                      double* __restrict__ out_pt, double* __restrict__ out_cam,
+                                      const double* __restrict__ df_part = nullptr, int n_df_part = 0,    // deterministic mode: k_colnorm's per-workgroup focal norms, added here in order,
+                                      const double* __restrict__ scal_base = nullptr, long long* __restrict__ lacc = nullptr) {   // and the two norms through long accumulators
+    const DetScal ds{scal_base, lacc};
     __shared__ double red[4];
     const bool is_pt = (int)blockIdx.x < gpt;
     const int i0 = (is_pt ? blockIdx.x : blockIdx.x - gpt) * blockDim.x + threadIdx.x, stride = (is_pt ? gpt : (int)gridDim.x - gpt) * blockDim.x;
@@ -2043,11 +2106,13 @@ static __global__ void k_startup_tail(const double* __restrict__ pts, const doub
         }
         if ((int)blockIdx.x == gpt && threadIdx.x == 0) {
             if (mask_f[0] > 0.0) acc[0] += focal[0] * focal[0];
-            if (scale_f) scale_f[0] = mask_f[0] * (jacobi ? 1.0 / (1.0 + sqrt(diag_f[0])) : 1.0);
+            double dfv = diag_f[0];
+            if (df_part) { dfv = 0.0; for (int i = 0; i < n_df_part; i++) dfv += df_part[i]; }
+            if (scale_f) scale_f[0] = mask_f[0] * (jacobi ? 1.0 / (1.0 + sqrt(dfv)) : 1.0);
         }
     }
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0 && acc[0] != 0.0) unsafeAtomicAdd(is_pt ? out_pt : out_cam, acc[0]);
+    if (threadIdx.x == 0 && acc[0] != 0.0) sadd(ds, is_pt ? out_pt : out_cam, acc[0]);
 }
 
 // the state [cameras | points | focal] from one set of buffers into another in ONE launch (three copy launches before): reset and the end of a solve

@@ -69,7 +69,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     LAUNCH(h, KID_CAM_ROT, k_cam_rot0, gp_cam, 64, 0, cam_x, rot_x, Nc, h->scal.p, (int)SC_TOTAL, h->diag_f.p, make_scale ? 1 : 0);
     if (make_scale) {
         if (nP > 0) hipLaunchKernelGGL(k_colnorm, dim3(gp_pts), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP,
-                                       loss, la, h->diag_pt.p, h->diag_f.p, h->mask_pt.p, h->scale_pt.p, O.jacobi_scaling);
+                                       loss, la, h->diag_pt.p, h->diag_f.p, h->mask_pt.p, h->scale_pt.p, O.jacobi_scaling, h->det ? h->det_dfpart.p : (double*)nullptr);
         hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
                            loss, la, h->diag_cam.p, h->mask_cam.p, ctx->collective ? (double*)nullptr : h->scale_cam.p, O.jacobi_scaling);
         if (ctx->collective) {   // camera / focal column norms are sums over every rank's observations
@@ -83,7 +83,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         const int gpt = nP > 0 ? std::min(256, (nP * 3 + 255) / 256) : 0, gcm = std::min(16, (Nc * 6 + 255) / 256);
         hipLaunchKernelGGL(k_startup_tail, dim3(gpt + gcm), dim3(256), 0, st, pts_x, h->mask_pt.p, nP * 3, gpt, cam_x, h->mask_cam.p, Nc * 6, fx, h->mask_f.p,
                            h->diag_cam.p, (make_scale && ctx->collective) ? h->scale_cam.p : (double*)nullptr, h->diag_f.p, make_scale ? h->scale_f.p : (double*)nullptr,
-                           O.jacobi_scaling, h->scal.p + SC_X0N2_PT, h->scal.p + SC_X0N2_CAM);
+                           O.jacobi_scaling, h->scal.p + SC_X0N2_PT, h->scal.p + SC_X0N2_CAM, (make_scale && h->det && nP > 0) ? h->det_dfpart.p : (const double*)nullptr, gp_pts,
+                           (const double*)h->scal.p, h->det ? h->det_lacc.p : (long long*)nullptr);
+        if (h->det) LAUNCH(h, KID_DET_DECODE, k_det_decode, 1, 256, 0, h->S_val, h->det_limb.p + 1, h->det_nacc, 0, h->scal.p, h->det_lacc.p, (1u << SC_X0N2_PT) | (1u << SC_X0N2_CAM));
     }
     { int rc = allreduce(h, h->scal.p + SC_X0N2_PT, 1, ncclSum); if (rc) return rc; }
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -116,6 +118,15 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     struct ZonePtrs { double *scal, *S_val, *rhs, *Udiag, *Sfc, *gcraw; };
     auto zone_ptrs = [&](int which) { ZonePtrs z; z.scal = h->zone.p + (size_t)which * h->zone_len; double* red = z.scal + h->scal.n + h->pcg.n;
                                       z.S_val = red; z.rhs = z.S_val + h->zone_nnz; z.Udiag = z.rhs + (h->zone_n + 1); z.Sfc = z.Udiag + h->zone_n; z.gcraw = z.Sfc + h->zone_n; return z; };
+    // SSFM_DETERMINISTIC=1 (det_acc.h): where the limbs of a zone's accumulators live; the scalar block's long accumulators; the decode launches
+    long long* const lacc = h->det ? h->det_lacc.p : (long long*)nullptr;
+    auto det_zone = [&](const ZonePtrs& z) { DetZone dz; if (h->det) { dz.base = z.S_val; dz.limb = h->det_limb.p + 1; } return dz; };
+    constexpr unsigned DET_K_ASSEMBLY = (1u << SC_COST) | (1u << SC_FJJ) | (1u << SC_FJR) | (1u << SC_FWW) | (1u << SC_FWG);
+    constexpr unsigned DET_K_TAIL = (1u << SC_MODEL) | (1u << SC_STEP2_PT) | (1u << SC_XN2_PT) | (1u << SC_CAND_COST) | (1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM);
+    auto det_decode = [&](const ZonePtrs& z, bool matrices, unsigned kmask) {
+        const int gz = matrices ? (int)std::min<size_t>(512, (h->det_nacc + 255) / 256) : 0;
+        LAUNCH(h, KID_DET_DECODE, k_det_decode, gz + 1, 256, 0, z.S_val, h->det_limb.p + 1, h->det_nacc, gz, z.scal, h->det_lacc.p, kmask);
+    };
     // EXPERIMENT, off (SSFM_PUBLISH_FUSED=1): the end-of-iteration hand-over in the last workgroup of k_point_backsub (arrival ticket) instead of a k_publish
     // launch.  Measured: k_point_backsub 22.8 -> 55.9 us at config 2 and 380 -> 1290 us at the configs[4] size -- every workgroup needs an agent-scope release
     // fence (an L2 write-back on this multi-XCD part) + a same-address atomic before it may leave, which costs far more than the 4.7 us launch it saves.
@@ -149,13 +160,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (h->profile && nP > 0 && !lin_done) hipLaunchKernelGGL(k_profile_pad, dim3(1), dim3(64), 0, st);
         if (nP > 0 && !lin_done && !fuse_lin)             // (lin_done: it ran speculatively behind the previous iteration, with this radius)
             LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
-                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, h->scal.p, (const double*)nullptr);
+                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, h->scal.p, (const double*)nullptr, lacc);
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[1], st));
         if (!F.cs_task_cam.empty()) {
             const int ntasks = (int)F.cs_task_cam.size();
             LAUNCH(h, KID_CAM_SUMS, k_cam_sums2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->cam_obs.p, h->cam_obs_pt.p, h->cs_task_cam.p,
                    h->cs_task_q0.p, h->cs_task_q1.p, ntasks, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, h->S_val, h->rhs,
-                   h->Udiag, h->Sfc, h->gcraw, (const unsigned char*)(F.gram_points > 0 ? h->pt_grouped.p : nullptr));
+                   h->Udiag, h->Sfc, h->gcraw, (const unsigned char*)(F.gram_points > 0 ? h->pt_grouped.p : nullptr), det_zone(zone_ptrs(iteration & 1)));
         }
         if (!F.chunk_cam.empty()) {
             const int ntasks = (int)F.chunk_cam.size();
@@ -167,7 +178,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             else
 #endif
             LAUNCH(h, KID_SCHUR_ROWS, k_schur_pairs2<DC>, (ntasks + 3) / 4, 256, 0, cam_x, rot_x, pts_x, fx, oxy, h->row_ptr.p, h->col_idx.p, h->chunk_cam.p,
-                   h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val);
+                   h->chunk_b0.p, h->chunk_b1.p, ntasks, h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->pair_p.p, h->scale_cam.p, h->Vs.p, loss, la, h->S_val,
+                   det_zone(zone_ptrs(iteration & 1)));
         }
         // signature groups: Gram products on the matrix cores (ba_kernels.h: k_schur_gram); one launch per tile class.  xc / xr / xp / xf = the state it linearises at,
         // z = the zone it accumulates into, spec = device-side [go, radius] of a speculative launch (fused point pass only)
@@ -193,7 +205,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     if (gram_lds > 48 * 1024)                                                                                                          \
                         SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram<DC, NT_, TI_, FUSE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds)); \
                     LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram<DC, NT_, TI_, FUSE_>), (t1 - t0 + gram_waves - 1) / gram_waves, 64 * gram_waves, gram_lds, xc, xr, xp, xf, oxy, t1, h->gr_rec.p,  \
-                           h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw, gram_dbg, fz);  \
+                           h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc, F.focal_free ? 1 : 0, t0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw, gram_dbg, fz, det_zone(z));  \
                 }                                                                                                                                      \
             } while (0)
 #ifdef SSFM_LAB
@@ -213,7 +225,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                 const size_t gram_lds = ((size_t)rows_alloc * GRAM_LD + GRAM_TAIL) * sizeof(double);
                 if (gram_lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_gram_any<DC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
                 LAUNCH(h, KID_SCHUR_GRAM, (k_schur_gram_any<DC>), ng, 64, gram_lds, xc, xr, xp, xf, oxy, ng, h->gr_rec.p, h->scale_cam.p, h->scale_f.p, h->Vs.p, loss, la, rows_alloc,
-                       F.focal_free ? 1 : 0, gram_t4 ? 1 : 0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw);
+                       F.focal_free ? 1 : 0, gram_t4 ? 1 : 0, z.S_val, z.rhs, z.Udiag, z.Sfc, z.gcraw, det_zone(z));
             } else {
                 SSFM_GRAM_LAUNCH(0, 1, 0); SSFM_GRAM_LAUNCH(1, 1, 2); SSFM_GRAM_LAUNCH(2, 2, 0);
                 if (DC == 6) { SSFM_GRAM_LAUNCH(3, 2, 3); SSFM_GRAM_LAUNCH(4, 3, 0); }
@@ -241,6 +253,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, probe_Y.p, probe_S.p);
         }
 #endif
+        if (h->det) det_decode(zone_ptrs(iteration & 1), true, DET_K_ASSEMBLY);     // limbs -> the zone's doubles (and cleared); the point pass's sums -> replica 0 of the scalar block
         if (ctx->collective) {
             // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
             hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->red_scal, ctx->rank);
@@ -315,7 +328,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                         const bool res_here = res && all_grouped;
                         LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub<DC>, (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
                                h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
-                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p);
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc);
                     }
                     // EXPERIMENT, off (SSFM_BACKSUB_LPP=2): two lanes per point -- half the dependent camera gathers per lane, twice the waves.  Measured at config 2
                     // (scripts/lab/ab_lpp.sh, hipEvent averages): 25.1-25.3 us against 23.0-23.5 with one lane per point; 2.557 against 2.538-2.552 ms per solve
@@ -332,10 +345,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                         LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
-                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr));
+                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr), (int*)nullptr, (double*)nullptr, 0ull, LmGate(), (double*)nullptr, lacc);
                 }
             }
             if (published) return SSFM_OK;
+            // deterministic mode: the tail's sums (model change, step and candidate norms, candidate cost) sit in the long accumulators; k_publish folds them itself,
+            // the copying hand-over needs them as doubles in replica 0 first
+            if (h->det && !poll) det_decode(zone_ptrs(iteration & 1), false, DET_K_TAIL);
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
             if (poll) {
@@ -344,8 +360,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     LmGate g; g.enabled = 1; g.last_successful = last_successful ? 1 : 0; g.radius = radius; g.x_norm = x_norm;
                     g.function_tolerance = O.function_tolerance; g.gradient_tolerance = O.gradient_tolerance; g.parameter_tolerance = O.parameter_tolerance;
                     g.min_relative_decrease = O.min_relative_decrease; g.max_radius = O.max_trust_region_radius; g.min_radius = O.min_trust_region_radius;
-                    publish(h, &g, h->lmdev.p); spec_launched = true;
-                } else publish(h);
+                    publish(h, &g, h->lmdev.p, DET_K_TAIL); spec_launched = true;
+                } else publish(h, nullptr, nullptr, DET_K_TAIL);
                 return SSFM_OK;
             }
             hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags
@@ -359,13 +375,14 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         if (spec_launched && fuse_lin) { const int rc = launch_gram(cam_c, rot_c, pts_c, fc, zone_ptrs((iteration + 1) & 1), radius, (const double*)h->lmdev.p); if (rc) return rc; }
         else if (spec_launched)              // x = this iteration's candidate, scalars into the next zone (scal is its first block)
             LAUNCH(h, KID_POINT_LIN, k_point_lin<3>, (nP + PLB - 1) / PLB, PLB, 0, cam_c, rot_c, pts_c, fc, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_pt.p,
-                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, next_zone, (const double*)h->lmdev.p);
+                   h->scale_f.p, loss, la, radius, O.min_lm_diagonal, O.max_lm_diagonal, h->Vs.p, h->gp.p, next_zone, (const double*)h->lmdev.p, lacc);
         { int rc = wait_iteration(); if (rc) return rc; }
         // what the device decided for the speculative k_point_lin (it ran iff dev_go)
         const bool dev_go = spec_launched && h->host_pub[SC_TOTAL + PCG_TOTAL + 2] == 1.0;
         const double dev_radius = spec_launched ? h->host_pub[SC_TOTAL + PCG_TOTAL + 3] : 0.0;
         auto undo_speculation = [&]() -> int {                       // the host goes another way: the next zone must be clean again
             if (dev_go) SSFM_HIP_CHECK(ctx, hipMemsetAsync(next_zone, 0, h->zone_len * sizeof(double), st));
+            if (dev_go && h->det) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_lacc.p, 0, (size_t)SC_NSLOT * SC_TOTAL * LA_STRIDE * sizeof(long long), st));   // the speculative point pass's sums
             return SSFM_OK;
         };
         SSFM_HIP_CHECK(ctx, hipGetLastError());                      // a launch that was refused (bad configuration) must not pass silently
@@ -540,7 +557,11 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     h->ctx = ctx; h->device = ctx->device;
     if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
     std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
-    const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr;      // default: the pair lists are counted and filled on the GPU
+    h->det = std::getenv("SSFM_DETERMINISTIC") && std::atoi(std::getenv("SSFM_DETERMINISTIC")) != 0;
+    if (h->det && ctx->collective) { delete h; return fail(ctx, SSFM_ERR_INVALID, "SSFM_DETERMINISTIC=1 is implemented for the single-GPU solve only (det_acc.h)"); }
+    // default: the pair lists are counted and filled on the GPU (through atomic cursors: the order inside a slot differs from handle to handle, so the deterministic mode
+    // takes the host's lists, whose order is a function of the problem alone)
+    const bool host_pairs = std::getenv("SSFM_HOST_PAIRS") != nullptr || h->det;
     g_alloc_timing = std::getenv("SSFM_PLAN_TIMING") != nullptr; g_alloc_ns = 0; g_alloc_n = 0;
     const double t_create0 = wall_s();
     // The per-observation arrays are final long before the plan is (the structure of S, the ordering, the task tables follow): a second host thread
@@ -612,6 +633,12 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     AL(zone, 2 * h->zone_len);
     h->scal.n = SC_NSLOT * SC_TOTAL; h->pcg.n = PCG_TOTAL + 1; h->redbuf.n = n_red; h->zone_views = true;
     h->set_zone(0);
+    if (h->det) {
+        h->det_nacc = h->zone_nnz + 4 * n + 1;                      // [S | rhs (+ focal row) | diag U | S_fc | Jc^T r]: contiguous in the zone from S_val on
+        AL(det_limb, 2 * h->det_nacc + 2); AL(det_lacc, (size_t)SC_NSLOT * SC_TOTAL * LA_STRIDE); AL(det_dfpart, (size_t)std::max(1, (nP + 255) / 256));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, (2 * h->det_nacc + 2) * sizeof(long long), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_lacc.p, 0, (size_t)SC_NSLOT * SC_TOTAL * LA_STRIDE * sizeof(long long), st));
+    }
     AL(Minv, (size_t)Nc * DC * DC); AL(Sff, 1);
     AL(px, n + 1); AL(pr, n + 1); AL(pz, n + 1); AL(pp, n + 1); AL(pq, n + 1); AL(pqpart, (size_t)Nc);
     // band: F.band_rows block rows of F.band_block x F.band_block blocks (>= cameras: twisted components carry a second copy of their
@@ -921,7 +948,8 @@ extern "C" int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_op
         structure_hash(p, key.h1, key.h2);
         if (timing) std::fprintf(stderr, "[solve] structure hash %.3f ms\n", 1e3 * (wall_s() - t0));
         if (pc && pc->h && pc->Nc == key.Nc && pc->Np == key.Np && pc->M == key.M && pc->nranks == key.nranks && pc->rank == key.rank &&
-            pc->focal_fixed == key.focal_fixed && pc->h1 == key.h1 && pc->h2 == key.h2) {
+            pc->focal_fixed == key.focal_fixed && pc->h1 == key.h1 && pc->h2 == key.h2 &&
+            pc->h->det == (std::getenv("SSFM_DETERMINISTIC") && std::atoi(std::getenv("SSFM_DETERMINISTIC")) != 0)) {     // (the accumulation mode is a property of the handle)
             h = pc->h; reused = true;
             if (o) h->opt = *o; else ssfm_ba_default_options(&h->opt);
             h->t_flatten_s = 0.0;

@@ -1,0 +1,76 @@
+"""SSFM_DETERMINISTIC=1 (csrc/det_acc.h): the BA assembly adds fixed-point limbs with integer atomics (exact, hence independent of the order in
+which thousands of waves arrive) instead of doubles -- repeated solves are bit-identical, whichever way the launches are scheduled, and agree with the default
+floating-point accumulation and with the oracle to the usual tolerances."""
+import numpy as np
+import pytest
+
+from spherical_sfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def problems():
+    yield "config 2 (signature groups: k_schur_gram)", synth.make_circle(300, 100000, 6, spherical=False, focal_fixed=True), 200
+    yield "3-dof cameras, shared focal free", synth.make_circle(120, 20000, 6, spherical=True, focal_fixed=False), 20
+    yield "ragged tracks 3..8 (pair lists + camera sums), ring layout", synth.make_ragged_circle(300, 200000, 3, 8), 20
+    yield "ragged tracks 3..11, focal free", synth.make_ragged_circle(120, 60000, 3, 11, focal_fixed=False), 20
+    yield "mixed track lengths in signature groups (k_schur_gram_any) + loose points", None, 20
+
+
+def test_repeated_solves_are_bit_identical(gpu_ctx, oracle, monkeypatch):
+    from spherical_sfm_amd import ba
+    for name, p, reps in problems():
+        if p is None:
+            monkeypatch.setenv("SSFM_GRAM_MODEL", "0")
+            p = synth.make_ragged_circle(120, 330000, 3, 8, focal_fixed=False)
+        monkeypatch.setenv("SSFM_DETERMINISTIC", "1")
+        c0, x0, f0, s0 = ba.optimize(gpu_ctx, p)
+        adj = ba.BundleAdjuster(gpu_ctx, p)                     # a resident handle: reset + run (bench.py's loop) ...
+        for r in range(reps):
+            adj.reset(); s = adj.run(); c, x, f = adj.download()
+            assert np.array_equal(c, c0) and np.array_equal(x, x0) and np.array_equal(np.asarray(f), np.asarray(f0), equal_nan=True), (name, r)
+            assert s["final_cost"] == s0["final_cost"] and s["iterations"] == s0["iterations"], (name, r)
+        adj.close()
+        monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+        for r in range(4):                                       # ... and fresh handles (plan, lists and buffers rebuilt)
+            c, x, f, s = ba.optimize(gpu_ctx, p)
+            assert np.array_equal(c, c0) and np.array_equal(x, x0) and s["final_cost"] == s0["final_cost"], (name, "fresh", r)
+        monkeypatch.delenv("SSFM_NO_PLAN_CACHE")
+        # exact sums do not depend on how the work is scheduled either: no speculative point pass, the copying hand-over
+        for var in ("SSFM_LM_SPECULATE", "SSFM_LM_POLL"):
+            monkeypatch.setenv(var, "0")
+            c, x, f, s = ba.optimize(gpu_ctx, p)
+            monkeypatch.delenv(var)
+            assert np.array_equal(c, c0) and np.array_equal(x, x0) and s["final_cost"] == s0["final_cost"] and s["iterations"] == s0["iterations"], (name, var)
+        # against the default accumulation and against the oracle
+        monkeypatch.setenv("SSFM_DETERMINISTIC", "0")
+        c1, x1, f1, s1 = ba.optimize(gpu_ctx, p)
+        assert s1["iterations"] == s0["iterations"] and rel_err(c0, c1) <= 1e-9 and rel_err(x0, x1) <= 1e-9 and abs(s0["final_cost"] - s1["final_cost"]) <= 1e-12 * s1["final_cost"], name
+        oc, ox, of, os_ = oracle.ba_solve(p)
+        assert s0["iterations"] == os_["iterations"] and s0["termination"] == os_["termination"] == 0, name
+        assert rel_err(c0, oc) <= 1e-6 and abs(s0["final_cost"] - os_["final_cost"]) <= 1e-9 * os_["final_cost"], name
+        monkeypatch.delenv("SSFM_GRAM_MODEL", raising=False)
+
+
+def test_rejected_steps_are_reproduced_too(gpu_ctx, oracle, monkeypatch):
+    """A rough start (tests/test_ba_gpu_extra.py: test_hard_start_with_rejected_steps) makes LM reject steps: the speculative point pass is withdrawn and its long
+    accumulators are cleared with the zone.  Bit-identical when repeated, with and without the speculation, the same accept / reject sequence as the default accumulation."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 300, 6, spherical=True, rot_noise_deg=12.0, point_noise=0.3)
+    kw = dict(initial_trust_region_radius=1e8)
+    monkeypatch.setenv("SSFM_DETERMINISTIC", "1")
+    runs = [ba.optimize(gpu_ctx, p, **kw) for _ in range(6)]
+    monkeypatch.setenv("SSFM_LM_SPECULATE", "0")
+    runs.append(ba.optimize(gpu_ctx, p, **kw))
+    monkeypatch.delenv("SSFM_LM_SPECULATE")
+    s0 = runs[0][3]
+    assert s0["num_unsuccessful_steps"] >= 1
+    for c, x, f, s in runs[1:]:
+        assert np.array_equal(c, runs[0][0]) and np.array_equal(x, runs[0][1]) and s["final_cost"] == s0["final_cost"] and s["num_unsuccessful_steps"] == s0["num_unsuccessful_steps"]
+    monkeypatch.setenv("SSFM_DETERMINISTIC", "0")
+    c1, x1, f1, s1 = ba.optimize(gpu_ctx, p, **kw)
+    assert abs(s1["num_unsuccessful_steps"] - s0["num_unsuccessful_steps"]) <= 2 and abs(s1["final_cost"] - s0["final_cost"]) <= 1e-4 * s0["final_cost"]
