@@ -1,7 +1,7 @@
 // spherical_sfm_amd -- environment knobs, in two classes.
 //
 // PRODUCT switches select a SUPPORTED alternative path (a plan shape, a fall-back, a hand-over mode) that the tests exercise and a maintainer may need:
-//   SSFM_RING, SSFM_RING_CUTS, SSFM_BAND_TWIST, SSFM_BAND_MERGE, SSFM_BAND_SEGMENTS, SSFM_BAND_PACKED, SSFM_GRAM, SSFM_GRAM_KMIN, SSFM_GRAM_PTS, SSFM_GRAM_MIN_RUN,
+//   SSFM_DETERMINISTIC (det_acc.h: order-independent accumulation), SSFM_GRAM_ANY, SSFM_RING, SSFM_RING_CUTS, SSFM_BAND_TWIST, SSFM_BAND_MERGE, SSFM_BAND_SEGMENTS, SSFM_BAND_PACKED, SSFM_GRAM, SSFM_GRAM_KMIN, SSFM_GRAM_PTS, SSFM_GRAM_MIN_RUN,
 //   SSFM_GRAM_SORT, SSFM_GRAM_MODEL, SSFM_GRAM_BACKSUB, SSFM_NO_PLAN_CACHE, SSFM_HOST_PAIRS, SSFM_LM_POLL, SSFM_LM_SPECULATE, SSFM_ROT_NODE_MAJOR, SSFM_RETRI_ENUMERATE,
 //   SSFM_RETRI_WAVES, SSFM_RETRI_WORDS, SSFM_RANSAC_SLAB_*, SSFM_RANSAC_STAGE_THREADS, SSFM_PLAN_THREADS, SSFM_PLAN_TIMING, SSFM_PLAN_OVERLAP, SSFM_TASK_BATCHES,
 //   SSFM_CS_TASK_OBS, SSFM_COMM_SINGLE_RANK.  They are read where they apply, most of them once per process.

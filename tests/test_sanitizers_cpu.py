@@ -51,3 +51,18 @@ def test_ring_schedule_against_a_dense_solve_under_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "RING_SCHEDULE_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
     assert "runtime error" not in run.stderr
+
+
+def test_fixed_point_splits_of_the_deterministic_accumulation(tmp_path):
+    """csrc/det_acc.h (SSFM_DETERMINISTIC=1): the device adds every addend as fixed-point limbs with integer atomics.  The splits are host-compilable: exact over the
+    whole exponent range (long accumulator: 2^-180 .. 2^100, matrix accumulators: to 2^-74 absolute below 2^40), coefficient bounds, limb sums independent of the
+    order of the addends, decoded sums accurate to a double's last place, non-finite and out-of-range values refused (the device poisons the sum: NaN).  UBSan on."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "det_acc_check")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=all", os.path.join(ROOT, "tests", "native", "det_acc_check.cpp"), "-o", exe],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "DET_ACC_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
+    assert "runtime error" not in run.stderr
