@@ -299,6 +299,29 @@ def side_paths(ctx):
         "parity_vs_oracle": {"identical_zero_sets": bool(np.array_equal(nz, Xg.any(1))), "identical_inlier_counts": bool(np.array_equal(ning, nino)),
                              "max_rel_point": float((np.linalg.norm(Xg - Xo, axis=1)[nz] / np.linalg.norm(Xo[nz], axis=1)).max())},
         "valu_issue": pmc_r or {"note": "no committed PMC pass found (profiles/r05_pmc_retriangulate.json)"}}
+    # ---- order-independent accumulation (csrc/det_acc.h): the metric's problem with SSFM_DETERMINISTIC=1 -- repeated solves bit for bit, and what it costs
+    try:
+        prob = synth.make_circle(300, 100000, 6, spherical=False, focal_fixed=True)
+        out = {}
+        for mode in ("0", "1"):
+            os.environ["SSFM_DETERMINISTIC"] = mode
+            adj = ba.BundleAdjuster(ctx, prob)
+            adj.run(); runs = []; best = 1e9
+            for _ in range(20):
+                adj.reset(); t = time.perf_counter(); sa = adj.run(); best = min(best, time.perf_counter() - t)
+                cg, pg, _f = adj.download(); runs.append((np.copy(cg), np.copy(pg), sa["final_cost"]))
+            adj.close()
+            out[mode] = {"ms_per_solve": 1e3 * best, "lm_iterations": sa["iterations"],
+                         "repeats_identical_to_the_first": sum(1 for q in runs[1:] if np.array_equal(q[0], runs[0][0]) and np.array_equal(q[1], runs[0][1]) and q[2] == runs[0][2]),
+                         "repeats": len(runs) - 1, "first": runs[0]}
+        d0, d1 = out["0"].pop("first"), out["1"].pop("first")
+        res["deterministic_accumulation"] = {
+            "workload": "the metric's problem (300 cameras x 100 000 points x 600 000 observations), resident handle, 20 solves per mode",
+            "default_fp64_atomics": out["0"], "SSFM_DETERMINISTIC=1": out["1"], "overhead": out["1"]["ms_per_solve"] / out["0"]["ms_per_solve"] - 1.0,
+            "max_rel_camera_between_modes": float(np.abs(d0[0] - d1[0]).max() / np.abs(d0[0]).max()),
+            "note": "fixed-point limbs + 64-bit integer atomics (exact, order-independent) for the reduced system, long accumulators for the scalar block; off by default"}
+    finally:
+        os.environ.pop("SSFM_DETERMINISTIC", None)
     # ---- irregular structure: 300 cameras, 600k observations, RAGGED tracks of 3..14 (and 3..8) consecutive frames, point ids in build_sfm's
     # order (examples/spherical_sfm_tools.cpp:862-955; synth.make_ragged_circle).  Reports what the same LM loop does when the synthetic circle's regularity is gone:
     # grouped fraction (planner: signature sort + cost model), obs/s, where the time goes, parity and the CPU port beside it.

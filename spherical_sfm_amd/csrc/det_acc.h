@@ -1,4 +1,4 @@
-// spherical_sfm_amd -- order-independent accumulation (round 5, SSFM_DETERMINISTIC=1; VERDICT r4 #7, DESIGN.md 7.4).
+// spherical_sfm_amd -- order-independent accumulation (round 5, SSFM_DETERMINISTIC=1; VERDICT r4 #7, DESIGN.md 4b).
 //
 // The BA assembly adds into the reduced camera system (block-CSR S, J^T r, diag U, the focal border) and into the scalar block with fp64 atomics from thousands of
 // waves: the ORDER of the additions differs from run to run, and floating-point addition is not associative -- repeated solves agree to ~1e-12, not bit for bit.
