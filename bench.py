@@ -34,10 +34,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy bandwidth of the box is MEASURED in every run (hbm_copy_GBs, ssfm_debug_copy_bandwidth)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r05s_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r05.sh + collect_final_r05.py) the traffic / VALU figures are read from
+PMC_PROFILE = os.path.join("profiles", "r05z_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r05.sh + collect_final_r05.py) the traffic / VALU figures are read from
 if not os.path.exists(os.path.join(ROOT, PMC_PROFILE)):
-    PMC_PROFILE = os.path.join("profiles", "r04m_pmc_traffic.json")
-ROCPROF_STATS = os.path.join("profiles", "r05s_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
+    PMC_PROFILE = os.path.join("profiles", "r05s_pmc_traffic.json")
+ROCPROF_STATS = os.path.join("profiles", "r05z_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
 
 
 def rocprof_avg_us():

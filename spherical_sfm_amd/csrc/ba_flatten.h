@@ -318,6 +318,11 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         // USED when the component really is a narrow periodic band in it (the reach below is measured, not assumed).
         // reach = the largest circular distance between two coupled cameras, in block rows.
         if (crows[k] < RING_MIN_ROWS) continue;
+        {   // a ring with a reach of <= 20 block rows couples a camera to <= 2 * 20 * W + W - 1 others: a denser component (an all-pairs pose graph) is none, and the walk
+            // below costs n deg^2 -- not worth 30 ms of planning to find that out
+            int64_t deg = 0; for (int i = 0; i < n; i++) deg += row_ptr[seq[k][i] + 1] - row_ptr[seq[k][i]];
+            if (deg > (int64_t)n * (2 * 20 * W + W)) continue;
+        }
         const int R = crows[k];
         auto circular_reach = [&](const std::vector<int>& ord) {
             for (int i = 0; i < n; i++) where[ord[i]] = i;
