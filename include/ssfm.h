@@ -154,7 +154,11 @@ int ssfm_ba_plan(const ssfm_ba_problem* p, int32_t nranks, int32_t rank, ssfm_ba
  * The context keeps the resident plan of the last problem STRUCTURE it solved (observation ids in order, fixed masks, which
  * points are zero, sizes): a call with the same structure only uploads parameters and pixels -- the drivers' Optimize ->
  * Retriangulate -> Optimize pattern.  summary.t_flatten_s is 0 on such a call.  SSFM_NO_PLAN_CACHE=1 in the environment
- * disables the cache; ssfm_ctx_destroy releases it. */
+ * disables the cache; ssfm_ctx_destroy releases it.
+ * Reproducibility: by default the assembly of the reduced camera system adds with fp64 atomics, so repeated solves agree to ~1e-11, not bit for bit (Ceres' own
+ * multi-threaded evaluation behind src/sfm.cpp:276 is in the same position).  SSFM_DETERMINISTIC=1 in the environment, read when a handle is created, switches a
+ * single-GPU handle to order-independent accumulation (fixed-point limbs + integer atomics, csrc/det_acc.h): bit-identical repeats at ~1.2x the iteration time;
+ * a context with a communicator refuses it (SSFM_ERR_INVALID). */
 int ssfm_ba_solve(ssfm_ctx* ctx, ssfm_ba_problem* p, const ssfm_ba_options* o, ssfm_ba_summary* s);
 
 /* Staged form: problem stays resident in HBM between runs (bench.py, multi-GPU sharding). */
