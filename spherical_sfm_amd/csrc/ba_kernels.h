@@ -1697,9 +1697,14 @@ __device__ __forceinline__ double coherent_load(const double* p) {          // s
 // function any workgroup of >= 64 threads can run: k_publish is one launch of it, k_point_backsub's last workgroup runs it in place of that launch.
 __device__ __forceinline__ void publish_body(const double* __restrict__ scal, const double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq,
                                              const LmGate& gate, double* __restrict__ spec, double* folded /* LDS [SC_TOTAL] */,
-                                             long long* __restrict__ lacc = nullptr, unsigned kmask = 0) {
+                                             long long* __restrict__ lacc = nullptr, unsigned kmask = 0,
+                                             // values the calling workgroup has just computed itself (LDS: no trip through global memory inside the kernel): the
+                                             // scalars k with bit k of ov_mask set, and the solver words [0, PCG_TOTAL)
+                                             const double* ov_scal = nullptr, unsigned ov_mask = 0, const double* ov_pcg = nullptr) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    auto pcg_word = [&](int i) { return (ov_pcg && i < PCG_TOTAL) ? ov_pcg[i] : coherent_load(pcg + i); };
     for (int k = w; k < SC_TOTAL; k += nw) {
+        if (ov_scal && ((ov_mask >> k) & 1u)) { if (lane == 0) folded[k] = ov_scal[k]; continue; }
         if (lacc && ((kmask >> k) & 1u)) {
             // deterministic mode (det_acc.h): this scalar's sums sit in the long accumulators of the 64 replicas -- integer wave sums, then the value; the limbs are
             // cleared for the next iteration (what k_det_decode does in a launch of its own for the sums of the assembly)
@@ -1723,14 +1728,14 @@ __device__ __forceinline__ void publish_body(const double* __restrict__ scal, co
     __syncthreads();
     if (w == 0) {
         if (lane < SC_TOTAL) host_out[lane] = folded[lane];
-        else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = coherent_load(pcg + lane - SC_TOTAL);
+        else if (lane < SC_TOTAL + PCG_TOTAL + 1) host_out[lane] = pcg_word(lane - SC_TOTAL);
         if (spec && lane == 0) {
             double go = 0.0, new_radius = gate.radius;
             if (gate.enabled) {
                 int fail_word; { const double fw = coherent_load(pcg + PCG_TOTAL); __builtin_memcpy(&fail_word, &fw, sizeof(int)); }
                 const double x_cost = folded[SC_COST], gmax = folded[SC_GMAX], model = -folded[SC_MODEL], cand = folded[SC_CAND_COST];
                 bool ok = isfinite(x_cost) && !(gate.last_successful && gmax <= gate.gradient_tolerance);
-                ok = ok && fail_word == 0 && coherent_load(pcg + PCG_DONE) != 0.0 && isfinite(model) && model > 0.0 && isfinite(cand);
+                ok = ok && fail_word == 0 && pcg_word(PCG_DONE) != 0.0 && isfinite(model) && model > 0.0 && isfinite(cand);
                 const double step_norm = sqrt(folded[SC_STEP2_PT] + folded[SC_STEP2_CAM]);
                 ok = ok && !(step_norm <= gate.parameter_tolerance * (gate.x_norm + gate.parameter_tolerance));
                 const double cost_change = x_cost - cand;

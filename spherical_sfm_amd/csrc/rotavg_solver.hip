@@ -272,21 +272,27 @@ __global__ void __launch_bounds__(1024)
 k_rot_step(int n_nodes, const double* __restrict__ V, const double* __restrict__ U, const double* __restrict__ Sfc, const double* __restrict__ Sff,
            const double* __restrict__ rho_ptr, const int* __restrict__ pos, const double* __restrict__ x, const double* __restrict__ fm,
            const double* __restrict__ sc_node, const double* __restrict__ sc_f, const double* __restrict__ rhs_raw, double f_lo, double f_hi,
-           double* __restrict__ y, double* __restrict__ xc, double* __restrict__ fmc, double* __restrict__ step, double* __restrict__ scal) {
+           double* __restrict__ y, double* __restrict__ xc, double* __restrict__ fmc, double* __restrict__ step, double* __restrict__ scal,
+           int with_f = 1, double* __restrict__ step_part = nullptr /* [gridDim.x][5] */) {
+    // Round 5: several workgroups (one of 1024 lanes spent 26 us at 4000 nodes: twelve dependent gathers per lane, twice).  Every workgroup forms the two dot
+    // products of the focal arrow itself -- all of them over all entries in the same order, hence the same phi everywhere; without a focal parameter the arrow is
+    // empty and the pass is skipped -- and then takes its slice of the entries; its five sums go to step_part, folded in workgroup order by k_rot_fold_publish.
     __shared__ double red[96];
     __shared__ double sphi;
     const int n = 3 * n_nodes;
-    double d2[2] = {0, 0};
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const int c = t / 3, a = t - 3 * c; const int pi = pos[c] * 3 + a;
-        d2[0] += Sfc[t] * V[pi]; d2[1] += Sfc[t] * U[pi];
-    }
-    block_sum<2>(d2, red);
-    if (threadIdx.x == 0) sphi = (rho_ptr[0] - d2[0]) / (Sff[0] - d2[1]);
+    if (with_f) {
+        double d2[2] = {0, 0};
+        for (int t = threadIdx.x; t < n; t += blockDim.x) {
+            const int c = t / 3, a = t - 3 * c; const int pi = pos[c] * 3 + a;
+            d2[0] += Sfc[t] * V[pi]; d2[1] += Sfc[t] * U[pi];
+        }
+        block_sum<2>(d2, red);
+        if (threadIdx.x == 0) sphi = (rho_ptr[0] - d2[0]) / (Sff[0] - d2[1]);
+    } else if (threadIdx.x == 0) sphi = rho_ptr[0] / Sff[0];       // (Sfc = 0: what the sums above give)
     __syncthreads();
     const double phi = sphi;
     double acc[3] = {0, 0, 0}; double gmax = 0.0, dmax = 0.0;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int c = t / 3, a = t - 3 * c; const int pi = pos[c] * 3 + a;
         const double yi = V[pi] - U[pi] * phi; y[t] = yi;
         const double s = sc_node[t]; double v = x[t];
@@ -294,7 +300,7 @@ k_rot_step(int n_nodes, const double* __restrict__ V, const double* __restrict__
         if (s > 0.0) { const double d = st * s; v += d; acc[0] += d * d; acc[1] += v * v; gmax = fmax(gmax, fabs(rhs_raw[t] / s)); acc[2] += rhs_raw[t] * st; dmax = fmax(dmax, fabs(st * s)); }
         xc[t] = v;
     }
-    if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         y[n] = phi;
         const double s = sc_f[0]; double v = fm[0]; const double st = -phi; step[n] = st;
         if (s > 0.0) {
@@ -314,8 +320,8 @@ k_rot_step(int n_nodes, const double* __restrict__ V, const double* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         double g = 0.0, d = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) { g = fmax(g, red[48 + w]); d = fmax(d, red[64 + w]); }
-        scal[SC_GMAX] = g;
-        scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; scal[SC_GDELTA] = acc[2]; scal[SC_DMAX] = d;
+        if (step_part) { double* q = step_part + 5 * (size_t)blockIdx.x; q[0] = acc[0]; q[1] = acc[1]; q[2] = acc[2]; q[3] = g; q[4] = d; }
+        else { scal[SC_GMAX] = g; scal[SC_STEP2_CAM] = acc[0]; scal[SC_XN2_CAM] = acc[1]; scal[SC_GDELTA] = acc[2]; scal[SC_DMAX] = d; }
     }
 }
 
@@ -328,7 +334,8 @@ k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, con
            const double* __restrict__ ejac, const double* __restrict__ step, const double* __restrict__ xc, const double* __restrict__ fmc,
            const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val, const double* __restrict__ Sfc,
            const double* __restrict__ Sff, const double* __restrict__ rhs, const double* __restrict__ y, double tol2, double* __restrict__ resid /* [3n + 1] */,
-           double* __restrict__ wg_part /* [gridDim.x * 5] */, int* __restrict__ ticket, double* __restrict__ scal, double* __restrict__ pcg) {
+           double* __restrict__ wg_part /* [gridDim.x * 5] */, int* __restrict__ ticket /* null: the partial sums are folded by k_rot_fold_publish */,
+           double* __restrict__ scal, double* __restrict__ pcg) {
     __shared__ int s_last;
     const int lane = threadIdx.x, wg = blockIdx.x;
     double p[5] = {0, 0, 0, 0, 0};
@@ -371,6 +378,9 @@ k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, con
 #pragma unroll
     for (int k = 0; k < 5; k++) p[k] = wave_sum(p[k]);
     if (lane == 0) { double* w = wg_part + 5 * (size_t)wg; for (int k = 0; k < 5; k++) w[k] = p[k]; }
+    // Round 5: an agent-scope release per workgroup (an L2 write-back on this multi-XCD part) + the arrival ticket made this launch 38 us at 4000 nodes / 16 000
+    // edges; the fold now rides in the hand-over kernel, which runs behind the kernel boundary anyway
+    if (!ticket) return;
     __threadfence();
     if (lane == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
@@ -393,6 +403,50 @@ k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, con
         pcg[PCG_RR] = rr; pcg[PCG_BN2] = bn2; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0; pcg[PCG_DONE] = (rr <= tol2 * bn2) ? 1.0 : 0.0;
         *ticket = 0;
     }
+}
+
+// The end of a pose-graph iteration (round 5): the partial sums of k_rot_eval (per workgroup: model change, candidate cost, |r|^2, |rhs|^2, S_fc . y) and of
+// k_rot_step (per workgroup: |delta|^2, |candidate|^2, g . delta, gradient max, |delta|_inf) folded in workgroup order -- the same arithmetic as the in-kernel
+// folds they replace: lane-strided sums, then a wave sum --, the residual test of the direct solve, and the hand-over to the host (publish_body), all by ONE
+// workgroup of SC_TOTAL * 64 lanes behind the kernel boundary.  host_out == nullptr: the copying hand-over follows, only the device words are written.
+__global__ void __launch_bounds__(SC_TOTAL * 64)
+k_rot_fold_publish(const double* __restrict__ wg_part, int n_wg, const double* __restrict__ step_part, int n_step, int n_nodes, const double* __restrict__ Sff,
+                   const double* __restrict__ rhs, const double* __restrict__ y, double tol2, double* __restrict__ resid, double* __restrict__ scal,
+                   double* __restrict__ pcg, double* __restrict__ host_out, unsigned long long seq, const LmGate gate, double* __restrict__ spec) {
+    __shared__ double folded[SC_TOTAL], ov_scal[SC_TOTAL], ov_pcg[PCG_TOTAL];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w == 0) {
+        double c[5] = {0, 0, 0, 0, 0};
+        for (int k = lane; k < n_wg; k += 64) { const double* q = wg_part + 5 * (size_t)k;
+#pragma unroll
+            for (int j = 0; j < 5; j++) c[j] += q[j]; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) c[j] = wave_sum(c[j]);
+        if (lane == 0) {
+            const int n = 3 * n_nodes;
+            const double bf = rhs[n], rf = bf - (Sff[0] * y[n] + c[4]);          // the focal row of the bordered system
+            resid[n] = rf;
+            const double rr = c[2] + rf * rf, bn2 = c[3] + bf * bf;
+            ov_scal[SC_MODEL] = c[0]; ov_scal[SC_CAND_COST] = c[1]; scal[SC_MODEL] = c[0]; scal[SC_CAND_COST] = c[1];
+            for (int i = 0; i < PCG_TOTAL; i++) ov_pcg[i] = pcg[i];
+            ov_pcg[PCG_RR] = rr; ov_pcg[PCG_BN2] = bn2; ov_pcg[PCG_ITERS] = 0.0; ov_pcg[PCG_BREAKDOWN] = 0.0; ov_pcg[PCG_DONE] = (rr <= tol2 * bn2) ? 1.0 : 0.0;
+            pcg[PCG_RR] = rr; pcg[PCG_BN2] = bn2; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0; pcg[PCG_DONE] = ov_pcg[PCG_DONE];
+        }
+    } else if (w == 1) {
+        double a[3] = {0, 0, 0}, g = 0.0, d = 0.0;
+        for (int k = lane; k < n_step; k += 64) { const double* q = step_part + 5 * (size_t)k; a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; g = fmax(g, q[3]); d = fmax(d, q[4]); }
+#pragma unroll
+        for (int j = 0; j < 3; j++) a[j] = wave_sum(a[j]);
+        g = wave_max(g); d = wave_max(d);
+        if (lane == 0) {
+            ov_scal[SC_GMAX] = g; ov_scal[SC_STEP2_CAM] = a[0]; ov_scal[SC_XN2_CAM] = a[1]; ov_scal[SC_GDELTA] = a[2]; ov_scal[SC_DMAX] = d;
+            scal[SC_GMAX] = g; scal[SC_STEP2_CAM] = a[0]; scal[SC_XN2_CAM] = a[1]; scal[SC_GDELTA] = a[2]; scal[SC_DMAX] = d;
+        }
+    }
+    __syncthreads();
+    if (!host_out) return;
+    constexpr unsigned mask = (1u << SC_MODEL) | (1u << SC_CAND_COST) | (1u << SC_GMAX) | (1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM) | (1u << SC_GDELTA) | (1u << SC_DMAX);
+    publish_body(scal, pcg, host_out, seq, gate, spec, folded, nullptr, 0, ov_scal, mask, ov_pcg);
 }
 
 // candidate = Plus(x, alpha (scale o step)) with the box projection on the focal multiplier (Ceres ParameterBlock::Plus; alpha = 1 except
@@ -537,13 +591,13 @@ extern "C" int ssfm_rotavg_cost(ssfm_ctx* ctx, int32_t n, const double* rotation
 // the buffers of one pose-graph solve; released on every exit path of rot_solve (after the stream has drained: the pool rule of ssfm_ctx.h)
 struct RotScratch {
     ssfm_ctx* ctx; ssfm_ba_handle H;
-    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out, m3, mf, ejac, node_part, wg_part; DevBuf<int> e0, e1, nadj_ptr, nadj_edge, nadj_slot, ticket; DevBuf<EdgeConst> ec;
+    DevBuf<double> x, xc, fm2, sc3, sc6, scf, step, ls_out, m3, mf, ejac, node_part, wg_part, step_part; DevBuf<int> e0, e1, nadj_ptr, nadj_edge, nadj_slot, ticket; DevBuf<EdgeConst> ec;
     DevBuf<unsigned char> nadj_side, nadj_first;
     explicit RotScratch(ssfm_ctx* c) : ctx(c) {}
     ~RotScratch() {
         (void)hipStreamSynchronize(ctx->stream);
         x.free(); xc.free(); fm2.free(); sc3.free(); sc6.free(); scf.free(); step.free(); ls_out.free(); m3.free(); mf.free(); e0.free(); e1.free(); ec.free();
-        ejac.free(); node_part.free(); wg_part.free(); nadj_ptr.free(); nadj_edge.free(); nadj_slot.free(); ticket.free(); nadj_side.free(); nadj_first.free();
+        ejac.free(); node_part.free(); wg_part.free(); step_part.free(); nadj_ptr.free(); nadj_edge.free(); nadj_slot.free(); ticket.free(); nadj_side.free(); nadj_first.free();
         H.free_all();
     }
 };
@@ -643,7 +697,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         std::vector<int> zero2(2, 0);
         SSFM_HIP_CHECK(ctx, upload(RS.nadj_ptr, nptr, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_edge, nedge, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_slot, nslot, st));
         SSFM_HIP_CHECK(ctx, upload(RS.nadj_side, nside, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_first, nfirst, st)); SSFM_HIP_CHECK(ctx, upload(RS.ticket, zero2, st));
-        ALV(RS.ejac, (size_t)24 * E); ALV(RS.node_part, (size_t)3 * ((E + 63) / 64)); ALV(RS.wg_part, (size_t)5 * ((E + 63) / 64 + gnode));
+        ALV(RS.ejac, (size_t)24 * E); ALV(RS.node_part, (size_t)3 * ((E + 63) / 64)); ALV(RS.wg_part, (size_t)5 * ((E + 63) / 64 + gnode)); ALV(RS.step_part, (size_t)5 * 32);
     }
 #undef ALV
     double* fmx = fm2.p; double* fmc = fm2.p + 1; double* xx = x.p; double* xcand = xc.p;
@@ -706,13 +760,17 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         { int rc = solve_reduced<3>(h, host_pcg, &pcg_iters, &pcg_ok, 0); h->external_tail = false; if (rc) return rc; }
         const double tol2 = O.pcg_tolerance * O.pcg_tolerance;
         const int nbr = (F.band_rows > 0 ? F.y_rows(3) : n) * 3;                   // stride of the right-hand-side columns in band order
+        const int gstep = std::max(1, std::min(32, (3 * n + 1023) / 1024));      // workgroups of k_rot_step
         auto tail_fused = [&]() -> int {                                          // focal arrow + step + candidate | model change + candidate cost + residual check | hand-over
-            hipLaunchKernelGGL(k_rot_step, dim3(1), dim3(1024), 0, st, n, h->Yb.p, h->Yb.p + nbr, h->Sfc, h->Sff.p, h->rhs + 3 * n, h->cam_pos.p, xx, fmx, sc3.p, scf.p, h->rhs, f_lo, f_hi,
-                               h->px.p, xcand, fmc, step.p, h->scal.p);
+            hipLaunchKernelGGL(k_rot_step, dim3(gstep), dim3(1024), 0, st, n, h->Yb.p, h->Yb.p + nbr, h->Sfc, h->Sff.p, h->rhs + 3 * n, h->cam_pos.p, xx, fmx, sc3.p, scf.p, h->rhs, f_lo, f_hi,
+                               h->px.p, xcand, fmc, step.p, h->scal.p, with_f ? 1 : 0, RS.step_part.p);
             hipLaunchKernelGGL(k_rot_eval, dim3(ge + gnode), dim3(64), 0, st, kind, E, ge, n, e0.p, e1.p, ec.p, G.scale, la, RS.ejac.p, step.p, xcand, fmc, h->row_ptr.p, h->col_idx.p, h->S_val,
-                               h->Sfc, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p, RS.wg_part.p, RS.ticket.p + 1, h->scal.p, h->pcg.p);
-            if (poll) publish(h);
-            else SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+                               h->Sfc, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p, RS.wg_part.p, (int*)nullptr, h->scal.p, h->pcg.p);
+            // the two folds + the residual test + the hand-over in one single-workgroup launch (host_out null: the copy below hands over)
+            LmGate g0; std::memset(&g0, 0, sizeof(g0));
+            hipLaunchKernelGGL(k_rot_fold_publish, dim3(1), dim3(SC_TOTAL * 64), 0, st, RS.wg_part.p, ge + gnode, RS.step_part.p, gstep, n, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p,
+                               h->scal.p, h->pcg.p, poll ? h->host_pub : (double*)nullptr, poll ? ++ctx->pub_seq : 0ull, g0, (double*)nullptr);
+            if (!poll) SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
             return SSFM_OK;
         };
         auto tail = [&]() -> int {
