@@ -387,7 +387,11 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                 // columns per wave (band_sub.h 2): one while a step is bound by what a wave can issue (half-widths >= 10), more when the band is narrow and the launch is
                 // bound by the factor rows every column streams again
                 static const int spike_nc_env = SSFM_LAB_KNOB("SSFM_SPIKE_NC", 0);
-                const int spike_nc = spike_nc_env > 0 ? spike_nc_env : (b <= 8 ? 3 : 1);
+                // r05ac: what decides is how many one-wave workgroups the launch has, not the half-width -- one column per wave until the chip is full (~3000 waves),
+                // then two, then three (us per launch at NC = 1 / 2 / 3: 4 arcs b = 13: 35 / 45 / 58; 8 arcs b = 7: 18.5 / 24.8 / 32.0; 32 arcs b = 5: 19 / 23 / 29;
+                // 128 arcs b = 7: 70 / 52.6 / 58.7)
+                const long long spike_waves = (long long)B.nleft * Q;
+                const int spike_nc = spike_nc_env > 0 ? spike_nc_env : (spike_waves <= 3000 ? 1 : spike_waves <= 6000 ? 2 : 3);
                 if (spike_nc >= 4) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 4>), dim3(B.nleft, (Q + 3) / 4), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
                 else if (spike_nc == 3) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 3>), dim3(B.nleft, (Q + 2) / 3), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);
                 else if (spike_nc == 2) hipLaunchKernelGGL((k_sub_spike_fwd<DC, 2>), dim3(B.nleft, (Q + 1) / 2), dim3(64), 0, st, h->band.p, h->Linv.p, h->subZ.p, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_seg_wend.p, h->sub_left.p, Nc, b);

@@ -285,7 +285,8 @@ k_ring_cr_back(const int* __restrict__ rec, int rec0, const double* __restrict__
 // The last few separators of every ring (from RING_TAIL_P active ones on): their eliminations, the root and their back substitutions by ONE workgroup per ring in ONE
 // launch, one after the other -- at that point a step holds one or two eliminations per ring and a launch per step would cost more than the work.  tail_ptr: records of
 // ring g = [tail_ptr[g], tail_ptr[g + 1]) in elimination order.  Blocks written by an earlier elimination of the same workgroup are read back through global memory:
-// __threadfence + barrier between two nodes.
+// a WORKGROUP-scope fence + barrier between two nodes (the waves of a workgroup share one L1, which writes through: an agent-scope __threadfence would
+// write the L2 back for other XCDs that do not take part, r05ab).
 template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
 k_ring_cr_tail(const int* __restrict__ rec, const int* __restrict__ tail_ptr, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
@@ -295,11 +296,11 @@ k_ring_cr_tail(const int* __restrict__ rec, const int* __restrict__ tail_ptr, co
     const int q0 = tail_ptr[blockIdx.x], q1 = tail_ptr[blockIdx.x + 1];
     for (int q = q0; q < q1; q++) {
         ring_elim_node<DC, NR>(rec + (size_t)q * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds);
-        __threadfence(); __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
     }
     for (int q = q1 - 1; q >= q0; q--) {
         ring_back_node<DC, NR>(rec + (size_t)q * RING_REC, crL, crF, crW, Y, N, b, lds);
-        __threadfence(); __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
     }
 }
 
