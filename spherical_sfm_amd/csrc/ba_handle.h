@@ -461,6 +461,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     // rings (band_ring.h): the separator cycles by cyclic reduction -- one launch per parallel step down, ONE for the last few separators of every ring
                     // (their eliminations, the roots, their back substitutions), one per parallel step back up
                     const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2), lt = std::max(le, lb);
+                    const int back_threads = Q < 40 ? 256 : std::min(1024, std::max(256, ((RING_BACK_P * 2 * Q + 255) / 256) * 256));     // RING_BACK_P threads per entry of F^T x
                     if (le > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_elim<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le));
                     if (lb > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_back<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
                     if (lt > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_tail<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt));
@@ -482,7 +483,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     LAUNCH(h, KID_RING_TAIL, (k_ring_cr_tail<DC, 2>), B.nring, cr_threads, lt, h->ring_rec.p, h->ring_tail.p, h->subZ.p, h->subD.p, h->subT.p,
                            h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Y, Nc, b, failp);
                     for (int sidx = nsteps - 1; sidx >= 0; sidx--)
-                        LAUNCH(h, KID_RING_BACK, (k_ring_cr_back<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], 256, lb, h->ring_rec.p, B.ring_step_ptr[sidx], h->crL.p, h->crF.p, h->crW.p, Y, Nc, b);
+                        LAUNCH(h, KID_RING_BACK, (k_ring_cr_back<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], back_threads, lb, h->ring_rec.p, B.ring_step_ptr[sidx], h->crL.p, h->crF.p, h->crW.p, Y, Nc, b);
                 }
             }
             // EXPERIMENT, off (SSFM_BACK_FUSE=1): the separator of a twisted component back-substituted by the two segment waves themselves (k_band_back_v2's modes 1 / 2) instead

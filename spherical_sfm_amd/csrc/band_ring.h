@@ -26,6 +26,7 @@
 
 namespace ssfm {
 
+constexpr int RING_BACK_P = 8;                    // threads that share one entry of F^T x in ring_back_node
 inline size_t ring_elim_lds_bytes(int Q, int NR) { return (size_t)(3 * Q + NR) * (size_t)(Q | 1) * sizeof(double); }
 
 // one 16x16 tile of P R^T with P, R = rows of the LDS matrix T (row stride LD, odd: the sixteen rows of an operand read fall into sixteen different banks); K = Q columns.
@@ -229,16 +230,32 @@ __device__ __forceinline__ void ring_back_node(const int* __restrict__ r, const 
     }
     for (int e = tid; e < Q * Q; e += nt) { const int i = e / Q, c = e - i * Q; sL[i * LD + c] = crL[(size_t)v * QQ + e]; }
     __syncthreads();
-    for (int e = tid; e < NR * Q; e += nt) {
-        const int rr = e / Q, k = e - rr * Q;
-        double acc = 0.0;
-        for (int j = 0; j < nn; j++) {
-            const double* F = crF + ((size_t)v * 2 + j) * QQ;
-            const double* xj = sx + (j * NR + rr) * Q;
+    // F_j^T x_{u_j}: every entry (rr, k) is a sum over the Q rows of F, read from global memory column-wise (coalesced over k).  One thread per entry walked Q dependent-free
+    // but sequential loads per neighbour (20 of the 26 us of a back substitution at Q = 78); now RING_BACK_P threads share an entry -- each a slice of the rows, the
+    // slices in LDS, added in slice order (r05ad)
+    {
+        const int items = NR * Q;
+        int P = 1; if (Q >= 40) while (2 * P <= RING_BACK_P && 2 * P * items <= nt) P *= 2;      // (small blocks: the extra barrier costs more than the shorter walk saves -- 4000-node pose graph, Q = 24: 19.0 -> 20.3 ms)
+        double* spart = so + NR * Q;           // [RING_BACK_P][NR * Q]
+        const int rows_per = (Q + P - 1) / P;
+        for (int t = tid; t < P * items; t += nt) {
+            const int part = t / items, e = t - part * items, rr = e / Q, k = e - rr * Q;
+            const int i0 = part * rows_per, i1 = min(Q, i0 + rows_per);
+            double acc = 0.0;
+            for (int j = 0; j < nn; j++) {
+                const double* F = crF + ((size_t)v * 2 + j) * QQ;
+                const double* xj = sx + (j * NR + rr) * Q;
 #pragma unroll 8
-            for (int i = 0; i < Q; i++) acc += F[(size_t)i * Q + k] * xj[i];
+                for (int i = i0; i < i1; i++) acc += F[(size_t)i * Q + k] * xj[i];
+            }
+            spart[part * items + e] = acc;
         }
-        sv[e] = crW[(size_t)v * NR * Q + e] - acc;
+        __syncthreads();
+        for (int e = tid; e < items; e += nt) {
+            double acc = 0.0;
+            for (int part = 0; part < P; part++) acc += spart[part * items + e];
+            sv[e] = crW[(size_t)v * NR * Q + e] - acc;
+        }
     }
     __syncthreads();
     for (int J = (Q + 15) / 16 - 1; J >= 0; J--) {                  // blocks of sixteen columns, the last one shorter (ring_elim_node)
@@ -264,7 +281,7 @@ __device__ __forceinline__ void ring_back_node(const int* __restrict__ r, const 
         if (copy >= 0) Y[(size_t)rr * n + (size_t)copy * DC + i] = so[e];
     }
 }
-inline size_t ring_back_lds_bytes(int Q, int NR) { return ((size_t)Q * (Q | 1) + (size_t)4 * NR * Q) * sizeof(double); }
+inline size_t ring_back_lds_bytes(int Q, int NR) { return ((size_t)Q * (Q | 1) + (size_t)(4 + RING_BACK_P) * NR * Q) * sizeof(double); }
 
 // one step of the reduction: the eliminations of the step, one workgroup each
 template <int DC, int NR>
