@@ -254,9 +254,9 @@ constexpr int RING_QMAX = 78;                     // (3 Q + 2) (Q | 1) doubles o
 inline int ring_choose_cuts(int rows, int b) {
     if (const char* e = std::getenv("SSFM_RING_CUTS")) { const int m = std::atoi(e); if (m >= 2) return std::min(m, std::max(2, rows / (2 * b + 1))); }
     // A power of two: the cyclic reduction halves the cycle per step down to 2 separators, which one workgroup per ring finishes (band_ring.h), so m = 2 * 2^k costs k
-    // parallel steps whatever lies between two powers.  The largest one that leaves arcs of at least max(2 b + 2, 16) rows: an arc costs its length in dependent
+    // parallel steps whatever lies between two powers.  The largest one that leaves arcs of at least max(2 b - 2, 16) rows: an arc costs its length in dependent
     // steps three times over (factorisation, spike, back substitution: ~2.3 us per row), a doubling of the cuts one more step down and one more step back up (~35 us).
-    const int min_arc = std::max(2 * b + 2, 16);
+    const int min_arc = std::max(2 * b - 2, 16);      // (r05ae: 300 rows at b = 13: 8 cuts = arcs of 24.5 rows 503 us per iteration, 4 cuts 513; b = 10: 4 / 8 / 16 cuts 408 / 390 / 422; b = 7: 8 / 16 cuts 332 / 346)
     int m = 2;
     while (2 * m <= 256 && (rows - 2 * m * b) / (2 * m) >= min_arc) m *= 2;
     m = std::max(2, std::min(m, rows / (2 * b + 1)));
