@@ -461,6 +461,9 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     // rings (band_ring.h): the separator cycles by cyclic reduction -- one launch per parallel step down, ONE for the last few separators of every ring
                     // (their eliminations, the roots, their back substitutions), one per parallel step back up
                     const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2), lt = std::max(le, lb);
+                    // workgroups per elimination (band_ring.h, phase 3): three while the step leaves compute units idle, fewer when it fills the chip by itself
+                    static const int roles_env = knob_env_int("SSFM_RING_ROLES", 0);
+                    auto elim_roles = [&](int nodes) { if (roles_env > 0) return roles_env; return (Q < 40) ? 1 : (3 * nodes <= ctx->num_cus ? 3 : (2 * nodes <= ctx->num_cus ? 2 : 1)); };
                     const int back_threads = Q < 40 ? 256 : std::min(1024, std::max(256, ((RING_BACK_P * 2 * Q + 255) / 256) * 256));     // RING_BACK_P threads per entry of F^T x
                     if (le > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_elim<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le));
                     if (lb > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_back<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
@@ -471,7 +474,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     static int ring_stamp_state = SSFM_LAB_KNOB("SSFM_RING_STAMPS", 0) ? 1 : 0; static long long* ring_stamps = nullptr;
                     if (ring_stamp_state == 1) { (void)hipMalloc((void**)&ring_stamps, (size_t)4 * B.nsep * sizeof(long long)); (void)hipMemsetAsync(ring_stamps, 0, (size_t)4 * B.nsep * sizeof(long long), st); ring_stamp_state = 2; }
                     for (int sidx = 0; sidx < nsteps; sidx++)
-                        LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], cr_threads, le, h->ring_rec.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
+                        LAUNCH(h, KID_RING_ELIM, (k_ring_cr_elim<DC, 2>), dim3(B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx], elim_roles(B.ring_step_ptr[sidx + 1] - B.ring_step_ptr[sidx])), cr_threads, le, h->ring_rec.p, B.ring_step_ptr[sidx], h->subZ.p, h->subD.p, h->subT.p,
                                h->crL.p, h->crF.p, h->crW.p, h->crP.p, h->crT.p, h->crE.p, Nc, b, failp, ring_stamp_state == 2 ? ring_stamps : (long long*)nullptr);
                     if (ring_stamp_state == 2) {
                         std::vector<long long> hs((size_t)4 * B.nsep); (void)hipStreamSynchronize(st); (void)hipMemcpy(hs.data(), ring_stamps, hs.size() * sizeof(long long), hipMemcpyDeviceToHost);

@@ -52,7 +52,8 @@ template <int DC, int NR>
 __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const double* __restrict__ Z, const double* __restrict__ Dd, const double* __restrict__ tt,
                                                double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT,
                                                double* __restrict__ crE, const int N, const int b, int* __restrict__ fail_flag, double* __restrict__ T,
-                                               long long* __restrict__ stamps = nullptr) {      // stamps: SSFM_RING_STAMPS timing study (ba_handle.h), null otherwise
+                                               long long* __restrict__ stamps = nullptr,        // stamps: SSFM_RING_STAMPS timing study (ba_handle.h), null otherwise
+                                               const int role = 0, const int nroles = 1) {      // r05ag: nroles workgroups per node (below, phase 3)
     const long long ts0 = stamps ? wall_clock64() : 0;
     const int Q = b * DC, LD = Q | 1, n = N * DC, tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int v = r[0], nn = r[1], hasL = r[2], hasR = r[3];
@@ -166,16 +167,21 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
     __syncthreads();
     const long long ts2 = stamps ? wall_clock64() : 0;
     // ---- phase 3: L (diagonal blocks hold G = L_blk^-1), F_j, w for the way back; the neighbours' Schur updates and the fill between them, from the F rows in LDS
+    // Several workgroups per node (k_ring_cr_elim: gridDim.y) all run phases 0-2 -- the same loads and the same arithmetic, hence the same F rows in every LDS -- and
+    // share this phase: workgroup 0 stores the factor, the others' tiles of the neighbours' products are dealt round robin.  Every output still has ONE writer.  (The
+    // products are half of an elimination's flops and sat on one compute unit while 250 idled: 13.9 of 55 us at Q = 78.)
+    if (role == 0) {
     for (int e = tid; e < Q * Q; e += nt) {
         const int i = e / Q, c = e - i * Q;
         crL[(size_t)v * QQ + e] = (c <= i) ? T[i * LD + c] : 0.0;
         for (int j = 0; j < nn; j++) crF[((size_t)v * 2 + j) * QQ + e] = T[(Q + j * Q + i) * LD + c];
     }
     for (int e = tid; e < NR * Q; e += nt) { const int rr = e / Q, c = e - rr * Q; crW[(size_t)v * NR * Q + e] = T[(3 * Q + rr) * LD + c]; }
+    }
     if (nn > 0) {
         const int li = lane & 15, lk = lane >> 4, TQ = (Q + 15) / 16, ntl = TQ * (TQ + 1) / 2;
         const int ntask = nn * ntl + (r[6] ? TQ * TQ : 0);
-        for (int task = wave; task < ntask; task += nw) {
+        for (int task = wave + role * nw; task < ntask; task += nroles * nw) {
             if (task < nn * ntl) {                                 // P{side}[u_j] (+)= F_j F_j^T, lower tiles
                 const int j = task / ntl, t2 = task - j * ntl;
                 int I = 0; while ((I + 1) * (I + 2) / 2 <= t2) I++;
@@ -200,6 +206,7 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
                 }
             }
         }
+        if (role == 0)
         for (int e = tid; e < nn * NR * Q; e += nt) {             // t{side}[u_j] (+)= F_j w
             const int j = e / (NR * Q), e2 = e - j * NR * Q, rr = e2 / Q, i = e2 - rr * Q;
             const double* Fr = T + (size_t)(Q + j * Q + i) * LD; const double* w = T + (size_t)(3 * Q + rr) * LD;
@@ -210,7 +217,7 @@ __device__ __forceinline__ void ring_elim_node(const int* __restrict__ r, const 
             *d = q[14] ? *d + a : a;
         }
     }
-    if (stamps && tid == 0) { long long* d = stamps + 4 * (size_t)v; d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64(); }
+    if (stamps && tid == 0 && role == 0) { long long* d = stamps + 4 * (size_t)v; d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64(); }
 }
 
 // ---- back substitution of one separator by the whole workgroup: x_v = L^-T (w - sum_j F_j^T x_{u_j}) -> Y rows of v (and of its copy slot); LDS: ring_back_lds_bytes
@@ -290,7 +297,7 @@ k_ring_cr_elim(const int* __restrict__ rec, int rec0, const double* __restrict__
                double* __restrict__ crL, double* __restrict__ crF, double* __restrict__ crW, double* __restrict__ crP, double* __restrict__ crT, double* __restrict__ crE,
                int N, int b, int* __restrict__ fail_flag, long long* __restrict__ stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    ring_elim_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds, stamps);
+    ring_elim_node<DC, NR>(rec + (size_t)(rec0 + blockIdx.x) * RING_REC, Z, Dd, tt, crL, crF, crW, crP, crT, crE, N, b, fail_flag, lds, stamps, (int)blockIdx.y, (int)gridDim.y);
 }
 template <int DC, int NR>
 __global__ void __launch_bounds__(1024)
