@@ -507,7 +507,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
             }
             if (B.nleft > 0) {
                 h->span_begin(KID_SUB_APPLY);
-                hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + 255) / 256), dim3(256), (size_t)2 * Q * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
+                hipLaunchKernelGGL((k_sub_apply_left<DC, 2>), dim3(B.nleft, (max_rows + APPLY_ROWS - 1) / APPLY_ROWS), dim3(APPLY_ROWS * APPLY_SLICES), (size_t)(2 * Q + APPLY_SLICES * APPLY_ROWS * 2) * sizeof(double), st, h->subZ.p, Y, h->sub_seg_lo.p, h->sub_seg_hi.p, h->sub_left.p, Nc, b);
                 h->span_end();
             }
             h->span_begin(KID_BAND_BACK);

@@ -1026,28 +1026,46 @@ k_sub_sep_chain_mfma(const double* __restrict__ Z, const double* __restrict__ Dd
 }
 
 // ---- 5. y(seg) -= Z x(separator in front) ------------------------------------------------------------------------------------------
+// r05ah: 64 rows per workgroup, four threads per row (a quarter of the Q columns each, partial sums through LDS in slice order): one thread per row walked Q loads
+// one after the other -- 11.4 us at Q = 78 for 150 rows per arc.  LDS: NR * Q doubles (x of the separator) + 4 * 64 * NR (partial sums).
+constexpr int APPLY_ROWS = 64, APPLY_SLICES = 4;
 template <int DC, int NR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(APPLY_ROWS * APPLY_SLICES)
 k_sub_apply_left(const double* __restrict__ Z, double* __restrict__ Y, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
                  const int* __restrict__ left_segs, int N, int b) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int Q = b * DC, n = N * DC, tid = threadIdx.x;
     const int seg = left_segs[blockIdx.x], r0 = seg_lo[seg], r1 = seg_hi[seg];
-    const int kk = r0 * DC + blockIdx.y * 256 + tid;
-    if (r0 * DC + (int)blockIdx.y * 256 >= r1 * DC) return;
-    for (int e = tid; e < NR * Q; e += 256) { const int r = e / Q, q = e - r * Q; lds[e] = Y[(size_t)r * n + (size_t)(r0 - b) * DC + q]; }
+    if (r0 * DC + (int)blockIdx.y * APPLY_ROWS >= r1 * DC) return;
+    const int row = tid & (APPLY_ROWS - 1), slice = tid / APPLY_ROWS;
+    const int kk = r0 * DC + blockIdx.y * APPLY_ROWS + row;
+    double* part = lds + NR * Q;                       // [APPLY_SLICES][APPLY_ROWS][NR]
+    for (int e = tid; e < NR * Q; e += APPLY_ROWS * APPLY_SLICES) { const int r = e / Q, q = e - r * Q; lds[e] = Y[(size_t)r * n + (size_t)(r0 - b) * DC + q]; }
     __syncthreads();
-    if (kk >= r1 * DC) return;
+    const int qper = (Q + APPLY_SLICES - 1) / APPLY_SLICES, q0 = slice * qper, q1 = min(Q, q0 + qper);
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0.0;
-    for (int q = 0; q < Q; q++) {
-        const double zv = Z[(size_t)q * n + kk];
+    if (kk < r1 * DC) {
+#pragma unroll 4
+        for (int q = q0; q < q1; q++) {
+            const double zv = Z[(size_t)q * n + kk];
 #pragma unroll
-        for (int r = 0; r < NR; r++) acc[r] += zv * lds[r * Q + q];
+            for (int r = 0; r < NR; r++) acc[r] += zv * lds[r * Q + q];
+        }
     }
 #pragma unroll
-    for (int r = 0; r < NR; r++) Y[(size_t)r * n + kk] -= acc[r];
+    for (int r = 0; r < NR; r++) part[(slice * APPLY_ROWS + row) * NR + r] = acc[r];
+    __syncthreads();
+    if (slice == 0 && kk < r1 * DC) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            double a = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < APPLY_SLICES; sl++) a += part[(sl * APPLY_ROWS + row) * NR + r];
+            Y[(size_t)r * n + kk] -= a;
+        }
+    }
 }
 
 }  // namespace ssfm
