@@ -332,16 +332,16 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     }
                     // EXPERIMENT, off (SSFM_BACKSUB_LPP=2): two lanes per point -- half the dependent camera gathers per lane, twice the waves.  Measured at config 2
                     // (scripts/lab/ab_lpp.sh, hipEvent averages): 25.1-25.3 us against 23.0-23.5 with one lane per point; 2.557 against 2.538-2.552 ms per solve
-#ifdef SSFM_LAB
-                    static const int bs_lpp = SSFM_LAB_KNOB("SSFM_BACKSUB_LPP", 1);
+                    // r05ai: on LONG tracks it pays -- 300 cameras, tracks of 3 ... 14 (8.5 observations per point, 70 000 points = one wave per SIMD): 40.1 -> 33.0 us;
+                    // tracks 3 ... 8 (5.5 per point): 26.7 -> 28.7.  Two lanes per point from 8.25 observations per point on.
+                    static const int bs_lpp_env = SSFM_LAB_KNOB("SSFM_BACKSUB_LPP", 0);
+                    const int bs_lpp = bs_lpp_env > 0 ? bs_lpp_env : ((int64_t)4 * F.M > (int64_t)33 * F.nP ? 2 : 1);
                     if (!all_grouped && bs_lpp == 2)
                         LAUNCH(h, KID_BACKSUB, (k_point_backsub<DC, 2>), (2 * nP + PTB - 1) / PTB + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
-                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr));
-                    else
-#endif
-                    if (!all_grouped)
+                               (const unsigned char*)(grouped ? h->pt_grouped.p : nullptr), (int*)nullptr, (double*)nullptr, 0ull, LmGate(), (double*)nullptr, lacc);
+                    else if (!all_grouped)
                         LAUNCH(h, KID_BACKSUB, k_point_backsub<DC>, gp_pts_lm + (res ? 1 : 0), PTB, 0, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP, h->scale_cam.p,
                                h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res ? h->pr.p : (double*)nullptr, h->pcg.p,
