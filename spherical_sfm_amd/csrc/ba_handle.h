@@ -462,7 +462,7 @@ static int band_direct(ssfm_ba_handle* h, double* Y) {
                     // (their eliminations, the roots, their back substitutions), one per parallel step back up
                     const size_t le = ring_elim_lds_bytes(Q, 2), lb = ring_back_lds_bytes(Q, 2), lt = std::max(le, lb);
                     // workgroups per elimination (band_ring.h, phase 3): three while the step leaves compute units idle, fewer when it fills the chip by itself
-                    static const int roles_env = knob_env_int("SSFM_RING_ROLES", 0);
+                    static const int roles_env = SSFM_LAB_KNOB("SSFM_RING_ROLES", 0);      // lab: force the number (2 / 3 / 4 / 6 at Q = 78: 49 / 47.3 / 45.9 / 45.5 us)
                     auto elim_roles = [&](int nodes) { if (roles_env > 0) return roles_env; return (Q < 40) ? 1 : (3 * nodes <= ctx->num_cus ? 3 : (2 * nodes <= ctx->num_cus ? 2 : 1)); };
                     const int back_threads = Q < 40 ? 256 : std::min(1024, std::max(256, ((RING_BACK_P * 2 * Q + 255) / 256) * 256));     // RING_BACK_P threads per entry of F^T x
                     if (le > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_cr_elim<DC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le));
