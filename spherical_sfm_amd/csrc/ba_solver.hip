@@ -351,7 +351,9 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             if (published) return SSFM_OK;
             // deterministic mode: the tail's sums (model change, step and candidate norms, candidate cost) sit in the long accumulators; k_publish folds them itself,
             // the copying hand-over needs them as doubles in replica 0 first
-            if (h->det && !poll) det_decode(zone_ptrs(iteration & 1), false, DET_K_TAIL);
+            // (with_cams: k_cam_update, one workgroup, has STORED the two camera norms in replica 0 -- they are not in the long accumulators)
+            const unsigned det_kt = with_cams ? (DET_K_TAIL & ~((1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM))) : DET_K_TAIL;
+            if (h->det && !poll) det_decode(zone_ptrs(iteration & 1), false, det_kt);
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
             if (poll) {
@@ -360,8 +362,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     LmGate g; g.enabled = 1; g.last_successful = last_successful ? 1 : 0; g.radius = radius; g.x_norm = x_norm;
                     g.function_tolerance = O.function_tolerance; g.gradient_tolerance = O.gradient_tolerance; g.parameter_tolerance = O.parameter_tolerance;
                     g.min_relative_decrease = O.min_relative_decrease; g.max_radius = O.max_trust_region_radius; g.min_radius = O.min_trust_region_radius;
-                    publish(h, &g, h->lmdev.p, DET_K_TAIL); spec_launched = true;
-                } else publish(h, nullptr, nullptr, DET_K_TAIL);
+                    publish(h, &g, h->lmdev.p, det_kt); spec_launched = true;
+                } else publish(h, nullptr, nullptr, det_kt);
                 return SSFM_OK;
             }
             hipError_t e = hipMemcpyAsync(host_sp, h->scal.p, (SC_NSLOT * SC_TOTAL + PCG_TOTAL + 1) * sizeof(double), hipMemcpyDeviceToHost, st);   // scalars + solver flags

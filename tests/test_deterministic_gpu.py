@@ -74,3 +74,18 @@ def test_rejected_steps_are_reproduced_too(gpu_ctx, oracle, monkeypatch):
     monkeypatch.setenv("SSFM_DETERMINISTIC", "0")
     c1, x1, f1, s1 = ba.optimize(gpu_ctx, p, **kw)
     assert abs(s1["num_unsuccessful_steps"] - s0["num_unsuccessful_steps"]) <= 2 and abs(s1["final_cost"] - s0["final_cost"]) <= 1e-4 * s0["final_cost"]
+
+
+def test_other_solver_paths_in_deterministic_mode(gpu_ctx, monkeypatch):
+    """The mode converts the ASSEMBLY; the solver paths whose tail is not the fused arrow kernel (PCG refinement sweeps behind the direct solve, the block-Jacobi PCG
+    of `preconditioner = 1`) keep their own sums -- k_cam_update stores the camera norms itself, and the hand-over must take those, not the (empty) long accumulators.
+    Same answer as the default accumulation on both."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(60, 900, 6, spherical=False, focal_fixed=False)
+    for kw in (dict(pcg_tolerance=1e-13, pcg_max_iterations=3), dict(preconditioner=1)):
+        monkeypatch.setenv("SSFM_DETERMINISTIC", "0")
+        c0, x0, f0, s0 = ba.optimize(gpu_ctx, p, **kw)
+        monkeypatch.setenv("SSFM_DETERMINISTIC", "1")
+        c1, x1, f1, s1 = ba.optimize(gpu_ctx, p, **kw)
+        assert s1["termination"] == s0["termination"] and s1["iterations"] == s0["iterations"], kw
+        assert rel_err(c1, c0) <= 1e-8 and rel_err(x1, x0) <= 1e-8 and abs(f1 - f0) <= 1e-9 * f0, kw
