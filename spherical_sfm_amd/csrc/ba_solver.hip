@@ -64,6 +64,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     };
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     h->set_zone(0);
+    if (h->det) {   // a solve starts on clean limbs whatever the previous one on this handle left (normally nothing: every decode clears what it read)
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, (2 * h->det_nacc + 2) * sizeof(long long), st));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_lacc.p, 0, (size_t)SC_NSLOT * SC_TOTAL * LA_STRIDE * sizeof(long long), st));
+    }
     // four launches: [rotation tables + clears] [point column norms + scales] [camera column norms + scales] [|x|^2 + focal scale]
     const bool make_scale = !h->scale_ready;
     LAUNCH(h, KID_CAM_ROT, k_cam_rot0, gp_cam, 64, 0, cam_x, rot_x, Nc, h->scal.p, (int)SC_TOTAL, h->diag_f.p, make_scale ? 1 : 0);
