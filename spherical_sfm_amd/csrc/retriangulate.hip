@@ -295,8 +295,14 @@ inline void tri_camera_record(const double* cam, double* T) {
     for (int k = 28; k < TC; k++) T[k] = 0.0;
 }
 
+// r05ao: tt_lsq's model-cost pass re-evaluated every row's residual and Jacobian at the point the sweep before it had just linearised at (the same bits: that is why it
+// could) -- a third of the per-row work of an LM iteration.  The sweep now leaves r and J of its first TT_NCACHE rows in LDS (8 doubles per row, lane-interleaved: no bank
+// conflicts) and the model-cost pass reads them back; rows beyond are still re-evaluated.  5 rows x 8 x 64 lanes x 8 B = 20 KB per wave: seven waves per CU, which the
+// 1563 waves of 100 000 points need (6.1 per CU) -- six rows (24.6 KB, six waves per CU) would push the last waves into a second round.
+constexpr int TT_NCACHE = 5;
 struct TtPoint {                    // one point's observations (cameras ascending)
     const double* ct; const double2* oxy; const int* ocam; int j0, n; double f;
+    double* cache = nullptr;        // LDS, this lane's first element (stride 64), or null: re-evaluate
 };
 // EvaluateModelOnPoint (src/triangulation_estimator.cpp:46-54): P X + t left to right, behind the camera -> DBL_MAX
 __device__ __forceinline__ double tt_err(const TtPoint& c, int i, const double* X) {
@@ -426,6 +432,12 @@ __device__ int tt_lsq(const TtPoint& c, const int* list, int cnt, double* X) {
         for (int q = 0; q < cnt; q++) {
             double r[2], J[2][3];
             tt_residual<true>(c, list[q], xx, r, J[0], J[1]);
+            if (c.cache && q < TT_NCACHE) {
+                double* w = c.cache + (size_t)q * 8 * 64;
+                w[0] = r[0]; w[64] = r[1];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { w[(2 + k) * 64] = J[0][k]; w[(5 + k) * 64] = J[1][k]; }
+            }
 #pragma unroll
             for (int a = 0; a < 2; a++) {
 #pragma unroll
@@ -515,7 +527,12 @@ __device__ int tt_lsq(const TtPoint& c, const int* list, int cnt, double* X) {
                 double acc = 0.0;
                 for (int q = 0; q < cnt; q++) {
                     double r[2], J[2][3];
-                    tt_residual<true>(c, list[q], x, r, J[0], J[1]);
+                    if (c.cache && q < TT_NCACHE) {                     // what the last sweep at x stored (x only changes through a sweep)
+                        const double* w = c.cache + (size_t)q * 8 * 64;
+                        r[0] = w[0]; r[1] = w[64];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { J[0][k] = w[(2 + k) * 64]; J[1][k] = w[(5 + k) * 64]; }
+                    } else tt_residual<true>(c, list[q], x, r, J[0], J[1]);
 #pragma unroll
                     for (int a = 0; a < 2; a++) { double m = 0.0;
 #pragma unroll
@@ -613,6 +630,7 @@ __device__ void tt_local_optimization(const TtPoint& c, const TtOpts& o, TtRng& 
     }
 }
 
+template <bool CACHE>
 __device__ __forceinline__ void
 retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                       const int* __restrict__ pt_start, int nP, const int* __restrict__ order /* lane -> point, or null */, TtOpts o,
@@ -624,7 +642,9 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
     const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_id >= nP) return;
     const int p = order ? order[lane_id] : lane_id;
+    __shared__ double s_cache[CACHE ? TT_NCACHE * 8 * 64 : 1];
     TtPoint c{ct, obs_xy, obs_cam, pt_start[p], pt_start[p + 1] - pt_start[p], focal[0]};
+    if (CACHE) c.cache = s_cache + threadIdx.x;
     double best[3] = {0, 0, 0};
     int nin = 0; unsigned it = 0; int lo_count = 0;
     int* listI = lists + 3 * (size_t)c.j0; int* base = listI + c.n; int* work = base + c.n;
@@ -709,9 +729,9 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
     int LW, int* __restrict__ lists, double* __restrict__ pts, int* __restrict__ num_inliers, unsigned* __restrict__ stats,                    \
     unsigned char* __restrict__ flags, int* __restrict__ overflow
 #define SSFM_RETRI_PASS ct, focal, obs_xy, obs_cam, pt_start, nP, order, o, pt_slot, samples, req_ptr, req_it, W, LW, lists, pts, num_inliers, stats, flags, overflow
-__global__ void __launch_bounds__(64) k_retriangulate_trace(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_retriangulate_trace_w2(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_retriangulate_trace_w3(SSFM_RETRI_ARGS) { retriangulate_trace_body(SSFM_RETRI_PASS); }
+__global__ void __launch_bounds__(64) k_retriangulate_trace(SSFM_RETRI_ARGS) { retriangulate_trace_body<true>(SSFM_RETRI_PASS); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_retriangulate_trace_w2(SSFM_RETRI_ARGS) { retriangulate_trace_body<true>(SSFM_RETRI_PASS); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_retriangulate_trace_w3(SSFM_RETRI_ARGS) { retriangulate_trace_body<false>(SSFM_RETRI_PASS); }      // (three waves per SIMD leave no LDS for the row cache)
 
 // the estimator's pieces, one lane per task (bit-for-bit parity tests; mirrors oracle_tri_probe)
 __global__ void k_tri_probe(const double* __restrict__ ct, const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
