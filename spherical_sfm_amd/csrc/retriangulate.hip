@@ -425,18 +425,25 @@ __device__ int tt_lsq(const TtPoint& c, const int* list, int cnt, double* X) {
     double x[3] = {X[0] + 0.0, X[1] + 0.0, X[2] + 0.0};
     double g[3], colsq[3], A[3][3], b[3], scale[3] = {1.0, 1.0, 1.0}, x_cost = 0.0;
     // one sweep over the rows at x: cost, gradient J^T r, squared column norms; with_normal: also Js^T Js and Js^T r of the scaled Jacobian
-    auto sweep = [&](const double* xx, bool with_normal) -> bool {
+    auto sweep = [&](const double* xx, bool with_normal, bool reuse = false) -> bool {      // reuse: the cache holds the rows at xx (the sweep just before was at xx)
         double cc = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; k++) { g[k] = 0.0; colsq[k] = 0.0; b[k] = 0.0; A[k][0] = 0.0; A[k][1] = 0.0; A[k][2] = 0.0; }
         for (int q = 0; q < cnt; q++) {
             double r[2], J[2][3];
-            tt_residual<true>(c, list[q], xx, r, J[0], J[1]);
-            if (c.cache && q < TT_NCACHE) {
-                double* w = c.cache + (size_t)q * 8 * 64;
-                w[0] = r[0]; w[64] = r[1];
+            if (reuse && c.cache && q < TT_NCACHE) {
+                const double* w = c.cache + (size_t)q * 8 * 64;
+                r[0] = w[0]; r[1] = w[64];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { w[(2 + k) * 64] = J[0][k]; w[(5 + k) * 64] = J[1][k]; }
+                for (int k = 0; k < 3; k++) { J[0][k] = w[(2 + k) * 64]; J[1][k] = w[(5 + k) * 64]; }
+            } else {
+                tt_residual<true>(c, list[q], xx, r, J[0], J[1]);
+                if (c.cache && q < TT_NCACHE) {
+                    double* w = c.cache + (size_t)q * 8 * 64;
+                    w[0] = r[0]; w[64] = r[1];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { w[(2 + k) * 64] = J[0][k]; w[(5 + k) * 64] = J[1][k]; }
+                }
             }
 #pragma unroll
             for (int a = 0; a < 2; a++) {
@@ -472,7 +479,7 @@ __device__ int tt_lsq(const TtPoint& c, const int* list, int cnt, double* X) {
         return m; };
     double gmax = gradient_max();
     double best[3] = {x[0], x[1], x[2]}, minimum_cost = x_cost;
-    (void)sweep(x, true);                                                                     // the same rows again, now with the scaled normal equations
+    (void)sweep(x, true, true);                                                               // the same rows again (from the cache), now with the scaled normal equations
     double radius = 1e4, decrease = 2.0, diag[3] = {0, 0, 0};
     bool reuse_diagonal = false, last_ok = true;
     int iteration = 0, invalid = 0;
