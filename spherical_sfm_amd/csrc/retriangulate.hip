@@ -303,7 +303,9 @@ constexpr int TT_NCACHE = 5;
 struct TtPoint {                    // one point's observations (cameras ascending)
     const double* ct; const double2* oxy; const int* ocam; int j0, n; double f;
     double* cache = nullptr;        // LDS, this lane's first element (stride 64), or null: re-evaluate
+    double* ecache = nullptr;       // LDS [TT_NERR][64]: the errors tt_score saw last (GetInliers at the same model reads them back), or null
 };
+constexpr int TT_NERR = 5;          // (20 KB + 2.5 KB per wave: still seven waves per CU)
 // EvaluateModelOnPoint (src/triangulation_estimator.cpp:46-54): P X + t left to right, behind the camera -> DBL_MAX
 __device__ __forceinline__ double tt_err(const TtPoint& c, int i, const double* X) {
     const double* T = c.ct + (size_t)TC * c.ocam[c.j0 + i];
@@ -317,13 +319,14 @@ __device__ __forceinline__ double tt_err(const TtPoint& c, int i, const double* 
 // ScoreModel (ransac.h:295-303): sum of std::min(error, threshold) in observation order (std::min(a, b) = b < a ? b : a keeps a NaN error)
 __device__ double tt_score(const TtPoint& c, const double* X, double thr) {
     double s = 0.0;
-    for (int i = 0; i < c.n; i++) { const double e = tt_err(c, i, X); s += (thr < e) ? thr : e; }
+    for (int i = 0; i < c.n; i++) { const double e = tt_err(c, i, X); if (c.ecache && i < TT_NERR) c.ecache[i * 64] = e; s += (thr < e) ? thr : e; }
     return s;
 }
 // GetInliers (ransac.h:311-336)
-__device__ int tt_inliers(const TtPoint& c, const double* X, double th, int* list) {
+// scored: tt_score's last call was at this very X (the caller knows): the errors of the first TT_NERR observations come from LDS, the same bits
+__device__ int tt_inliers(const TtPoint& c, const double* X, double th, int* list, bool scored = false) {
     int cnt = 0;
-    for (int i = 0; i < c.n; i++) if (tt_err(c, i, X) < th) list[cnt++] = i;
+    for (int i = 0; i < c.n; i++) { const double e = (scored && c.ecache && i < TT_NERR) ? c.ecache[i * 64] : tt_err(c, i, X); if (e < th) list[cnt++] = i; }
     return cnt;
 }
 // NonMinimalSolver (src/triangulation_estimator.cpp:65-86): rows (P.row(2) x - P.row(0), P.row(2) y - P.row(1)) per sampled observation, in
@@ -603,8 +606,8 @@ __device__ void tt_shuffle_resize(int* list, int m, int target, TtRng& g) {
 }
 struct TtOpts { double thr, mult; int lo_steps, lsq_it, min_sample_mult, non_min_mult; unsigned min_it, lo_start; };
 // LeastSquaresFit (ransac.h:409-420)
-__device__ void tt_lsq_fit(const TtPoint& c, const TtOpts& o, double th, TtRng& g, int* work, double* model) {
-    const int ni = tt_inliers(c, model, th, work);
+__device__ void tt_lsq_fit(const TtPoint& c, const TtOpts& o, double th, TtRng& g, int* work, double* model, bool scored = false) {
+    const int ni = tt_inliers(c, model, th, work, scored);
     if (ni < 2) return;
     const int sz = min(o.min_sample_mult * 2, ni);
     tt_shuffle_resize(work, ni, sz, g);
@@ -627,10 +630,10 @@ __device__ void tt_local_optimization(const TtPoint& c, const TtOpts& o, TtRng& 
         double m[3];
         tt_dlt<12>(c, work, min(nonmin, 6), nb, m);                                          // NonMinimalSolver always returns 1
         tt_update(tt_score(c, m, o.thr), m, score_best, best_min);
-        tt_lsq_fit(c, o, o.thr, g, work, m);
+        tt_lsq_fit(c, o, o.thr, g, work, m, true);                                          // (m was scored one line up)
         double th = o.mult * o.thr; const double upd = (o.mult - 1.0) * o.thr / (double)(o.lsq_it - 1);
         for (int i = 0; i < o.lsq_it; i++) {
-            tt_lsq_fit(c, o, th, g, work, m);
+            tt_lsq_fit(c, o, th, g, work, m, i > 0);                                         // (from the second pass on m is what the pass before scored)
             tt_update(tt_score(c, m, o.thr), m, score_best, best_min);
             th -= upd;
         }
@@ -649,9 +652,9 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
     const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_id >= nP) return;
     const int p = order ? order[lane_id] : lane_id;
-    __shared__ double s_cache[CACHE ? TT_NCACHE * 8 * 64 : 1];
+    __shared__ double s_cache[CACHE ? (TT_NCACHE * 8 + TT_NERR) * 64 : 1];
     TtPoint c{ct, obs_xy, obs_cam, pt_start[p], pt_start[p + 1] - pt_start[p], focal[0]};
-    if (CACHE) c.cache = s_cache + threadIdx.x;
+    if (CACHE) { c.cache = s_cache + threadIdx.x; c.ecache = s_cache + TT_NCACHE * 8 * 64 + threadIdx.x; }
     double best[3] = {0, 0, 0};
     int nin = 0; unsigned it = 0; int lo_count = 0;
     int* listI = lists + 3 * (size_t)c.j0; int* base = listI + c.n; int* work = base + c.n;
