@@ -574,7 +574,10 @@ def main():
                           # cross-check of the model's matrix-pipe part against a counter: SQ_INSTS_VALU_MFMA_MOPS_F64 (512 flop per MOP) of the committed PMC profile
                           "executed_mfma_flop_model": ex_flop - M / world * GRAM_OBS_VALU_FLOP, "executed_mfma_flop_pmc": (mops * 512.0) if mops else None,
                           "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
-                                            "gfx950 x2 FETCH_SIZE correction applied; HBM bytes per launch) -- NOT measured in this run"} if gram else
+                                            "gfx950 x2 FETCH_SIZE correction applied; HBM bytes per launch) -- NOT measured in this run",
+                          "traffic_breakdown": "fetched 22.1 MB = the algorithmic reads (observations 9.6 + point records 9.6 + points 2.4 MB: read once); written 12.3 MB of which the "
+                                               "algorithmic part is the 0.6 MB of S -- the rest is what WRITE_SIZE counts for 0.97 M fp64 atomic adds of the tasks' blocks (8 B and more per "
+                                               "atomic; profiles/r05z_pmc_per_kernel_avg.json), not re-reads"} if gram else
                          {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                           "traffic_source": f"committed profile {PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
