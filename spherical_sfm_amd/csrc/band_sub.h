@@ -134,7 +134,7 @@ inline void sub_build(const std::vector<int>& comp_ptr, const std::vector<char>&
 // wave run one after the other inside a step, and there are CUs to spare -- 4 columns 210 us, 2 columns 169 us, 1 column 130 us per launch at the configs[4] size.
 // Round 5: narrow bands (the ring-native layout halves the half-width) turn the balance again -- the arithmetic of a step shrinks with the band, the factor rows every
 // column streams do not: 42 columns x 102 arcs at the configs[4] size read the whole band 42 times (311 MB from L2, ~72 us whatever the number of arcs).  NC is a template
-// parameter now and the launch picks it by half-width (ba_handle.h).
+// parameter now; the launch picks it by the number of one-wave workgroups it would have (ba_handle.h, r05ac: one column per wave until the chip is full).
 constexpr int SPIKE_PD = 4, SPIKE_NC = 1;
 template <int DC, int NC = SPIKE_NC>
 __global__ void __launch_bounds__(64)
