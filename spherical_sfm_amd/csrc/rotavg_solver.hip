@@ -327,16 +327,14 @@ k_rot_step(int n_nodes, const double* __restrict__ V, const double* __restrict__
 
 // Everything that is left of an iteration in one launch (was k_pcg_matvec + k_ref_residual + k_rot_edges(mode 1) + k_rot_cost): workgroups [0, ge) take
 // 64 edges each -- model cost change from the Jacobian records of the assembly, cost at the candidate --, workgroups [ge, ge + gn) take 64 nodes each --
-// their rows of S y for the residual check |rhs - S y| <= tol |rhs| of the direct solve.  Per-workgroup partial sums, folded in workgroup order by the
-// last workgroup to finish: [model, candidate cost, |r|^2, |rhs|^2, S_fc . y].
+// their rows of S y for the residual check |rhs - S y| <= tol |rhs| of the direct solve.  Per-workgroup partial sums [model, candidate cost, |r|^2, |rhs|^2, S_fc . y],
+// folded in workgroup order by k_rot_fold_publish.
 __global__ void __launch_bounds__(64)
 k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, const int* __restrict__ e1, const EdgeConst* __restrict__ ec, double scale, double loss_a,
            const double* __restrict__ ejac, const double* __restrict__ step, const double* __restrict__ xc, const double* __restrict__ fmc,
            const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const double* __restrict__ S_val, const double* __restrict__ Sfc,
            const double* __restrict__ Sff, const double* __restrict__ rhs, const double* __restrict__ y, double tol2, double* __restrict__ resid /* [3n + 1] */,
-           double* __restrict__ wg_part /* [gridDim.x * 5] */, int* __restrict__ ticket /* null: the partial sums are folded by k_rot_fold_publish */,
-           double* __restrict__ scal, double* __restrict__ pcg) {
-    __shared__ int s_last;
+           double* __restrict__ wg_part /* [gridDim.x * 5]: folded by k_rot_fold_publish */) {
     const int lane = threadIdx.x, wg = blockIdx.x;
     double p[5] = {0, 0, 0, 0, 0};
     if (wg < ge) {
@@ -378,31 +376,8 @@ k_rot_eval(int kind, int E, int ge, int n_nodes, const int* __restrict__ e0, con
 #pragma unroll
     for (int k = 0; k < 5; k++) p[k] = wave_sum(p[k]);
     if (lane == 0) { double* w = wg_part + 5 * (size_t)wg; for (int k = 0; k < 5; k++) w[k] = p[k]; }
-    // Round 5: an agent-scope release per workgroup (an L2 write-back on this multi-XCD part) + the arrival ticket made this launch 38 us at 4000 nodes / 16 000
-    // edges; the fold now rides in the hand-over kernel, which runs behind the kernel boundary anyway
-    if (!ticket) return;
-    __threadfence();
-    if (lane == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    double c[5] = {0, 0, 0, 0, 0};
-    for (int k = lane; k < (int)gridDim.x; k += 64) {
-        const volatile double* w = wg_part + 5 * (size_t)k;
-#pragma unroll
-        for (int j = 0; j < 5; j++) c[j] += w[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) c[j] = wave_sum(c[j]);
-    if (lane == 0) {
-        const int n = 3 * n_nodes;
-        const double bf = rhs[n], rf = bf - (Sff[0] * y[n] + c[4]);          // the focal row of the bordered system
-        resid[n] = rf;
-        const double rr = c[2] + rf * rf, bn2 = c[3] + bf * bf;
-        scal[SC_MODEL] = c[0]; scal[SC_CAND_COST] = c[1];
-        pcg[PCG_RR] = rr; pcg[PCG_BN2] = bn2; pcg[PCG_ITERS] = 0.0; pcg[PCG_BREAKDOWN] = 0.0; pcg[PCG_DONE] = (rr <= tol2 * bn2) ? 1.0 : 0.0;
-        *ticket = 0;
-    }
+    // (Rounds 2-4 folded here: the last workgroup to arrive, found through a ticket behind an agent-scope release per workgroup -- an L2 write-back on this multi-XCD
+    // part: 38 us per launch at 4000 nodes / 16 000 edges.  The fold rides in the hand-over kernel now, which runs behind the kernel boundary anyway.)
 }
 
 // The end of a pose-graph iteration (round 5): the partial sums of k_rot_eval (per workgroup: model change, candidate cost, |r|^2, |rhs|^2, S_fc . y) and of
@@ -765,7 +740,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
             hipLaunchKernelGGL(k_rot_step, dim3(gstep), dim3(1024), 0, st, n, h->Yb.p, h->Yb.p + nbr, h->Sfc, h->Sff.p, h->rhs + 3 * n, h->cam_pos.p, xx, fmx, sc3.p, scf.p, h->rhs, f_lo, f_hi,
                                h->px.p, xcand, fmc, step.p, h->scal.p, with_f ? 1 : 0, RS.step_part.p);
             hipLaunchKernelGGL(k_rot_eval, dim3(ge + gnode), dim3(64), 0, st, kind, E, ge, n, e0.p, e1.p, ec.p, G.scale, la, RS.ejac.p, step.p, xcand, fmc, h->row_ptr.p, h->col_idx.p, h->S_val,
-                               h->Sfc, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p, RS.wg_part.p, (int*)nullptr, h->scal.p, h->pcg.p);
+                               h->Sfc, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p, RS.wg_part.p);
             // the two folds + the residual test + the hand-over in one single-workgroup launch (host_out null: the copy below hands over)
             LmGate g0; std::memset(&g0, 0, sizeof(g0));
             hipLaunchKernelGGL(k_rot_fold_publish, dim3(1), dim3(SC_TOTAL * 64), 0, st, RS.wg_part.p, ge + gnode, RS.step_part.p, gstep, n, h->Sff.p, h->rhs, h->px.p, tol2, h->pr.p,
