@@ -40,6 +40,18 @@ if not os.path.exists(os.path.join(ROOT, PMC_PROFILE)):
 ROCPROF_STATS = os.path.join("profiles", "r05z_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
 
 
+def kernel_source_digest():
+    """sha256[:16] over the BA kernel sources (the files a PMC profile of bench.py depends on); a committed PMC file carries the digest of the tree it
+    profiled in _meta.kernel_source_sha16 and bench.py prints pmc_stale = true when today's differs (the GPU box has no .git to ask)"""
+    import hashlib
+    d = os.path.join(ROOT, "spherical_sfm_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) and not f.startswith(("ransac", "lomsac", "retriangulate", "sampson", "rotavg", "line_search")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def rocprof_avg_us():
     """{kernel name without template arguments: average launch duration in us} from the committed rocprofv3 summary (None if it is not there)"""
     import csv
@@ -55,6 +67,126 @@ def rocprof_avg_us():
         a = acc.setdefault(name, [0, 0.0]); a[0] += c; a[1] += t
     return {k: v[1] / v[0] / 1e3 for k, v in acc.items() if v[0]}
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The record.  bench.py computes a large `detail` dictionary (per-kernel tables, side paths, notes); that goes to
+# bench_detail.json.  The LAST stdout line is compact_record(detail): numbers and short identifiers only, well under
+# 6 KB, strict JSON.  tests/test_bench_record_cpu.py builds it from a committed detail file and checks size and keys.
+RECORD_LIMIT = 6000
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _num(x, sig=6):
+    """a float rounded to `sig` significant digits (ints, None, bools and strings pass; NaN / inf become None: strict JSON has neither)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def _pick(d, keys, sig=6):
+    """{k: d[k]} for the scalar entries of `keys` present in d, rounded"""
+    if not isinstance(d, dict):
+        return None
+    return {k: _num(d[k], sig) for k in keys if k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_record(d):
+    """the one-line record of a run from the detail dictionary `d` (see main()): every value a number, bool, null or a short identifier"""
+    cfg = d.get("config", {})
+    rec = {k: _num(d.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    rec["config"] = {"workload": str(cfg.get("workload", ""))[:200], "camera_dof": cfg.get("camera_dof"), "lm_iterations_per_step": _num(cfg.get("lm_iterations_per_step")),
+                     "sharding": cfg.get("sharding"), "comm": str(cfg.get("comm", ""))[:40], "reduced_solver": str(cfg.get("reduced_solver_short", "band-cholesky"))[:40],
+                     "pcg_sweeps": cfg.get("pcg_sweeps")}
+    r = d.get("roofline") or {}
+    rec["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch", "executed_frac"))
+    pm = d.get("pmc_profile") or {}
+    rec["roofline"]["pmc_tag"] = pm.get("tag"); rec["roofline"]["pmc_stale"] = pm.get("stale")
+    if d.get("roofline_hbm"):
+        rec["roofline_hbm"] = _pick(d["roofline_hbm"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_measured_copy", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us"))
+    if d.get("roofline_lm_iteration"):
+        rec["roofline_lm_iteration"] = _pick(d["roofline_lm_iteration"], ("bound", "algorithmic_bytes", "avg_ms", "achieved", "peak", "unit", "frac", "frac_of_measured_copy"))
+    if d.get("cpu_baseline"):
+        rec["cpu_baseline"] = _pick(d["cpu_baseline"], ("value", "unit", "cores", "kind", "solve_s", "end_to_end_s", "host_cpus"))
+        rec["cpu_baseline"]["sample"] = str(d["cpu_baseline"].get("sample", ""))[:120]
+    if d.get("parity_vs_oracle"):
+        rec["parity_vs_oracle"] = _pick(d["parity_vs_oracle"], ("max_rel_camera", "max_rel_point", "iterations_gpu", "iterations_cpu"), 3)
+    rec["hbm_copy_GBs"] = _num(d.get("hbm_copy_GBs"), 4)
+    if d.get("kernels"):
+        n_it = max(1.0, float(cfg.get("lm_iterations_per_step") or 1.0))
+        n_lm_prof = d.get("lm_iterations_profiled_step") or n_it
+        rec["kernel_us_per_lm_iteration"] = _num(sum(v["launches"] * v["avg_us"] for v in d["kernels"].values()) / n_lm_prof, 4)
+        rec["kernel_avg_us"] = {k: _num(v["avg_us"], 4) for k, v in d["kernels"].items()}
+    if d.get("end_to_end_optimize"):
+        rec["end_to_end_optimize"] = _pick(d["end_to_end_optimize"], ("first_s", "median_s", "best_s", "cpu_s", "speedup", "speedup_warm"), 4)
+        w = d["end_to_end_optimize"].get("warm")
+        if isinstance(w, dict):
+            rec["end_to_end_optimize"]["warm_s"] = _num(w.get("gpu_s"), 4)
+    if d.get("scaling_model"):
+        rec["scaling_model"] = {k: _num(v, 4) for k, v in d["scaling_model"].items() if not isinstance(v, (dict, list, str))}
+    # side paths: at most ten scalars
+    side = {}
+    sp = d.get("side_paths") or {}
+    def g(path, sig=4):
+        o = sp
+        for k in path:
+            if not isinstance(o, dict) or k not in o:
+                return None
+            o = o[k]
+        return _num(o, sig) if not isinstance(o, (dict, list)) else None
+    for name, path in (("pairwise_lomsac_pairs_per_s", ("pairwise_lomsac", "value")), ("rotation_averaging_ms", ("rotation_averaging", "value")),
+                       ("retriangulate_ms", ("retriangulate", "value")), ("deterministic_overhead", ("deterministic_accumulation", "overhead")),
+                       ("default_repeats_identical", ("deterministic_accumulation", "default_repeats_identical")),
+                       ("irregular_3_to_14_obs_per_s", ("ba_irregular", "tracks_3_to_14", "value")), ("irregular_3_to_14_grouped", ("ba_irregular", "tracks_3_to_14", "grouped_fraction_of_observations")),
+                       ("irregular_3_to_8_obs_per_s", ("ba_irregular", "tracks_3_to_8", "value")),
+                       ("irregular_1000_cameras_obs_per_s", ("ba_irregular", "tracks_3_to_8_1000_cameras", "value")), ("pipeline_configs2_gpu_ms", ("pipeline_configs2", "gpu_ms_total"))):
+        v = g(path)
+        if v is not None:
+            side[name] = v
+    if side:
+        rec["side_paths"] = side
+    if d.get("scale_probe_configs4_size_one_gpu"):
+        rec["scale_probe_configs4_size_one_gpu"] = _pick(d["scale_probe_configs4_size_one_gpu"], ("value", "unit", "ms_per_solve", "lm_iterations"), 4)
+        li = (d.get("roofline_configs4") or {}).get("lm_iteration")
+        if li:
+            rec["scale_probe_configs4_size_one_gpu"]["frac_hbm_lm_iteration"] = _num(li.get("frac_hbm"), 4)
+    for k, keys in (("timing_without_collective", ("ms_per_lm_iteration", "ms_per_lm_iteration_with_collectives")),
+                    ("configs4_sharded", ("value", "unit", "ms_per_solve", "lm_iterations", "n_gpus")), ("pairwise_sharded", ("value", "unit", "seconds", "n_gpus"))):
+        if d.get(k):
+            rec[k] = _pick(d[k], keys, 4)
+    rec["detail"] = d.get("detail_path")
+    return rec
+
+
+def record_line(d):
+    """compact_record(d) as the single stdout line; raises if it is not a record the driver can keep (size, strict JSON, required keys)"""
+    rec = compact_record(d)
+    line = json.dumps(rec, allow_nan=False, separators=(", ", ": "))
+    missing = [k for k in REQUIRED_KEYS if rec.get(k) is None and k != "vs_baseline"]
+    if missing or "\n" in line or len(line) >= RECORD_LIMIT:
+        raise ValueError(f"bench record unusable: {len(line)} chars, missing {missing}")
+    return line
+
+
+def _jsonable(o):
+    """detail dictionary with NaN / inf replaced by None (strict JSON) and numpy scalars unwrapped"""
+    if isinstance(o, dict):
+        return {str(k): _jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    if isinstance(o, float):
+        return o if (o == o and o not in (float("inf"), float("-inf"))) else None
+    if hasattr(o, "item") and not isinstance(o, (str, bytes)):
+        try:
+            return _jsonable(o.item())
+        except Exception:
+            return str(o)
+    return o
 
 
 def pair_kernel_flops(pairs):
@@ -416,6 +548,7 @@ def main():
     ap.add_argument("--no-collective-probe", action="store_true", help="N > 1: skip the timing probe that re-runs the sharded solve with its reductions switched off")
     ap.add_argument("--no-pairwise", action="store_true", help="N > 1: skip BASELINE configs[3] (exhaustive pairwise RANSAC) sharded over the N ranks")
     ap.add_argument("--pairwise-pairs", type=int, default=1999000, help="N > 1: image pairs of the pairwise_sharded leg (default: the 2000-frame exhaustive circle)")
+    ap.add_argument("--detail", default=None, help="where the full detail dictionary goes (default: bench_detail.json next to bench.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -552,7 +685,9 @@ def main():
             try:
                 pm = json.load(open(tp)); traffic = pm.get(dom); valu = pm.get("_valu_wave_instructions", {}).get(dom); mops = pm.get("_mfma_mops_f64", {}).get(dom)
                 # which run the quoted counters come from: the tag of the file and what its collector recorded about the tree it profiled (a stale file shows here)
-                pmc_meta = {"file": PMC_PROFILE, "tag": os.path.basename(PMC_PROFILE).split("_")[0], "recorded": pm.get("_meta", "no _meta in this file (collected before round 5)")}
+                meta = pm.get("_meta") if isinstance(pm.get("_meta"), dict) else {}
+                pmc_meta = {"file": PMC_PROFILE, "tag": os.path.basename(PMC_PROFILE).split("_")[0], "recorded": meta,
+                            "kernel_source_sha16_now": kernel_source_digest(), "stale": meta.get("kernel_source_sha16") != kernel_source_digest()}
             except Exception:
                 traffic = None
         out = {
@@ -563,6 +698,7 @@ def main():
                                    f"{args.mode} BA, focal {'free' if args.focal_free else 'fixed'}, CauchyLoss(1.0), Ceres-default LM",
                        "reduced_solver": "exact block-banded Cholesky in Cuthill-McKee order (direct, like the reference's SPARSE_SCHUR); the PCG of the metric's name is a "
                                          f"refinement that did not run: {s.get('pcg_iterations_total', 0)} sweeps in the last step",
+                       "reduced_solver_short": "band-cholesky (direct)", "pcg_sweeps": int(s.get("pcg_iterations_total", 0)),
                        "camera_dof": dc, "lm_iterations_per_step": n_lm / args.steps, "sharding": f"points/{world}", "comm": ("none" if world == 1 else ("host-staged gloo (test configuration)" if host_comm else "rccl"))},
             # The dominant kernel against the roof that bounds it.  k_schur_gram is a matrix-core kernel: ALGORITHMIC flop per launch (what the Schur assembly asks for
             # whatever the implementation: per observation one linearisation 150 + the half product 102 + the camera-side sums 132 + the upper triangle of its
@@ -614,7 +750,7 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": per_iter_bytes / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else None,
                                       "frac_of_measured_copy": vs_copy(per_iter_bytes / (iter_ms * 1e-3) / 1e9) if iter_ms > 0 else None},
-            "kernels": kern,
+            "kernels": kern, "lm_iterations_profiled_step": n_lm_prof,
             "phases_ms_per_lm_iteration_profiled_step": {k: v / max(1, n_lm_prof) for k, v in phase.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -752,7 +888,16 @@ def main():
                             f"ssfm_ransac_batch_indexed_sharded: pairs round robin over the ranks, host buffers in, every result on every rank (one all-reduce per {PER} pairs)",
                 "n_gpus": world, "scaling": "strong", "value": TOTAL / tp, "unit": "pairs/s", "seconds": tp, "accepted_pairs": acc, "includes_pcie": True}
     if rank == 0:
-        print(json.dumps(out))
+        detail = _jsonable(out)
+        dpath = args.detail or os.path.join(ROOT, "bench_detail.json" if world == 1 else f"bench_detail_n{world}.json")
+        try:
+            with open(dpath, "w") as fh:
+                json.dump(detail, fh, allow_nan=False)
+            detail["detail_path"] = os.path.relpath(dpath, ROOT)
+        except OSError as e:
+            print(f"bench.py: could not write {dpath}: {e}", file=sys.stderr)
+        sys.stdout.flush()
+        print(record_line(detail), flush=True)
     adj.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -31,7 +31,9 @@ try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     commit = "unknown"
-traffic["_meta"] = {"tag": tag, "commit_at_collection": commit, "collected": datetime.date.today().isoformat(),
+sys.path.insert(0, ROOT)
+from bench import kernel_source_digest
+traffic["_meta"] = {"tag": tag, "kernel_source_sha16": kernel_source_digest(), "commit_at_collection": commit, "collected": datetime.date.today().isoformat(),
                     "command": "bench.py --no-cpu-baseline --no-scale-probe --no-side-paths --steps 1 --warmup 0 under rocprofv3 --kernel-trace --pmc <one counter group per pass>"}
 traffic["_mfma_mops_f64"] = {re.sub(r"<.*>", "", k): d["SQ_INSTS_VALU_MFMA_MOPS_F64"] for k, d in out.items() if d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) > 0}   # per launch; one MOP = 512 flop
 traffic["_valu_wave_instructions"] = {re.sub(r"<.*>", "", k): d["SQ_INSTS_VALU"] for k, d in out.items() if "SQ_INSTS_VALU" in d}   # per launch, all waves
