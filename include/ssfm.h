@@ -133,6 +133,19 @@ void ssfm_ba_default_options(ssfm_ba_options* o);
 int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32_t b, int32_t ncomp, const int32_t* comp_ptr, const double* band,
                           double* Y, int32_t* segs_seps_fail, double* Zdump, double* Ddump, double* Tdump);
 
+/* Test probe (round 6): the supernodal ring / chain solver of the reduced camera system alone (csrc/snode.h; it takes the place of the sparse Cholesky
+ * inside Ceres' SPARSE_SCHUR, reference src/sfm.cpp:205,273, whenever every component of the camera graph is a chain or a closed loop whose tracks span
+ * <= 30 / dc cameras).  S: block-CSR (row_ptr [Nc + 1], col_idx), every coupled pair of cameras stored once in either orientation plus the diagonal blocks,
+ * row-major dc x dc blocks; rhs2: [2][Nc * dc]; nr = 1 | 2 right-hand sides; Y: [2][Nc * dc] out (camera order).
+ * info: [4] = {1 if the plan applies (else nothing ran), workgroups, rows of the closing separator, non-positive-pivot flag}. */
+int ssfm_snode_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t Nc, const int32_t* row_ptr, const int32_t* col_idx, const double* S_val, const double* rhs2,
+                           int32_t nr, double* Y, int32_t* info);
+/* Host-only (no GPU): the plan of that solver for a block structure.  sizes: [8] = {applies, workgroups, rows reserved for the closing separator, cameras per supernode,
+ * capacity of a node's camera list, ints of half_rec, of step_rec, of node_cam}; the tables (layouts: csrc/snode.h) are copied out when the pointers are non-null;
+ * tab_len: capacity of tab in, its length out. */
+int ssfm_snode_plan_probe(int32_t dc, int32_t Nc, const int32_t* row_ptr, const int32_t* col_idx, int32_t num_cus, int32_t* sizes, int32_t* half_rec, int32_t* step_rec,
+                          int32_t* node_cam, int32_t* tab, int32_t* tab_len);
+
 /* Host-only planning (no GPU needed): what the flatten rules of src/sfm.cpp:240-263 keep, how the used points
  * are sharded over ranks (contiguous ranges balanced by observations), and the camera elimination order. */
 typedef struct {

@@ -79,7 +79,7 @@ DECLARED_SYMBOLS = [
     "ssfm_ba_default_options", "ssfm_ba_plan", "ssfm_ba_solve", "ssfm_ba_create", "ssfm_ba_reset", "ssfm_ba_run", "ssfm_ba_download",
     "ssfm_ba_destroy", "ssfm_ba_evaluate", "ssfm_ba_set_profiling", "ssfm_ba_kernel_times",
     "ssfm_rotavg_default_options", "ssfm_rotavg_solve", "ssfm_rotavg_cost", "ssfm_posegraph_focal_solve",
-    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_ransac_batch_indexed", "ssfm_ransac_batch_indexed_sharded", "ssfm_ransac_last_kernel_ms", "ssfm_band_solve_probe", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_debug_timing_skip_collectives", "ssfm_debug_copy_bandwidth", "ssfm_retriangulate", "ssfm_retriangulate_mode", "ssfm_retriangulate_ex", "ssfm_tri_probe", "ssfm_focal_search",
+    "ssfm_ransac_default_options", "ssfm_ransac_batch", "ssfm_ransac_batch_sharded", "ssfm_ransac_batch_indexed", "ssfm_ransac_batch_indexed_sharded", "ssfm_ransac_last_kernel_ms", "ssfm_band_solve_probe", "ssfm_snode_solve_probe", "ssfm_snode_plan_probe", "ssfm_spherical_solver_probe", "ssfm_spherical_solver_poly_probe", "ssfm_build_tracks", "ssfm_debug_timing_skip_collectives", "ssfm_debug_copy_bandwidth", "ssfm_retriangulate", "ssfm_retriangulate_mode", "ssfm_retriangulate_ex", "ssfm_tri_probe", "ssfm_focal_search",
     "ssfm_sampson_refine_probe", "ssfm_sampson_refine_probe_ex", "ssfm_decompose_probe", "ssfm_nonminimal_probe", "ssfm_so3_probe", "ssfm_mt19937_probe",
     "ssfm_minimal_solver_probe", "ssfm_sampson_probe",
     "ssfm_estimator_create", "ssfm_estimator_destroy", "ssfm_estimator_minimal_solver", "ssfm_estimator_non_minimal_solver",
@@ -135,6 +135,10 @@ def lib():
     L.ssfm_posegraph_focal_solve.restype = C.c_int
     L.ssfm_band_solve_probe.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32_p, c_double_p, c_double_p, c_i32_p, c_double_p, c_double_p, c_double_p]
     L.ssfm_band_solve_probe.restype = C.c_int
+    L.ssfm_snode_solve_probe.argtypes = [vp, C.c_int32, C.c_int32, c_i32_p, c_i32_p, c_double_p, c_double_p, C.c_int32, c_double_p, c_i32_p]
+    L.ssfm_snode_solve_probe.restype = C.c_int
+    L.ssfm_snode_plan_probe.argtypes = [C.c_int32, C.c_int32, c_i32_p, c_i32_p, C.c_int32, c_i32_p, c_i32_p, c_i32_p, c_i32_p, c_i32_p, c_i32_p]
+    L.ssfm_snode_plan_probe.restype = C.c_int
     L.ssfm_ransac_default_options.argtypes = [C.POINTER(RansacOptionsC)]; L.ssfm_ransac_default_options.restype = None
     L.ssfm_ransac_batch.argtypes = [vp, C.c_int32, c_i32_p, c_double_p, c_double_p, C.c_double, C.POINTER(RansacOptionsC), c_double_p, c_double_p,
                                     c_u8_p, c_i32_p, c_double_p, c_u32_p]

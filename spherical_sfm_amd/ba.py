@@ -126,6 +126,31 @@ def band_solve_probe(ctx, dc, comp_ptr, band, Y, dump=False):
     return (Yc, d, Z, D, T) if dump else (Yc, d)
 
 
+def snode_solve_probe(ctx, dc, row_ptr, col_idx, S_val, rhs2, nr=2):
+    """ssfm_snode_solve_probe: block-CSR S (blocks (nnz, dc, dc)), rhs2 (2, Nc*dc) -> (Y (2, Nc*dc), info dict); info['applies'] is False when the plan does not apply."""
+    rp = np.ascontiguousarray(row_ptr, np.int32); ci = np.ascontiguousarray(col_idx, np.int32); Nc = len(rp) - 1
+    Sv = np.ascontiguousarray(S_val, np.float64); R = np.ascontiguousarray(rhs2, np.float64)
+    Y = np.zeros((2, Nc * dc)); info = np.zeros(4, np.int32)
+    _lib.check(_lib.lib().ssfm_snode_solve_probe(ctx._p, dc, Nc, rp.ctypes.data_as(c_i32_p), ci.ctypes.data_as(c_i32_p), Sv.ctypes.data_as(c_double_p),
+                                                 R.ctypes.data_as(c_double_p), nr, Y.ctypes.data_as(c_double_p), info.ctypes.data_as(c_i32_p)), ctx._p)
+    return Y, dict(applies=bool(info[0]), workgroups=int(info[1]), t_rows=int(info[2]), failed=int(info[3]))
+
+
+def snode_plan_probe(dc, row_ptr, col_idx, num_cus=256):
+    """ssfm_snode_plan_probe (host only): None when the plan does not apply, else dict(nhalf, qtm, S, CAPT, half_rec (nhalf, 16), step_rec (steps, 8), node_cam (nodes, CAPT), tab)."""
+    rp = np.ascontiguousarray(row_ptr, np.int32); ci = np.ascontiguousarray(col_idx, np.int32); Nc = len(rp) - 1
+    sizes = np.zeros(8, np.int32); p32 = lambda a: a.ctypes.data_as(c_i32_p)
+    L = _lib.lib()
+    tl = np.zeros(1, np.int32)
+    assert L.ssfm_snode_plan_probe(dc, Nc, p32(rp), p32(ci), num_cus, p32(sizes), None, None, None, None, p32(tl)) == 0
+    if not sizes[0]:
+        return None
+    hr = np.zeros(sizes[5], np.int32); sr = np.zeros(max(sizes[6], 1), np.int32); nc = np.zeros(sizes[7], np.int32); tab = np.zeros(max(int(tl[0]), 1), np.int32); tl[0] = len(tab)
+    assert L.ssfm_snode_plan_probe(dc, Nc, p32(rp), p32(ci), num_cus, p32(sizes), p32(hr), p32(sr), p32(nc), p32(tab), p32(tl)) == 0
+    return dict(nhalf=int(sizes[1]), qtm=int(sizes[2]), S=int(sizes[3]), CAPT=int(sizes[4]), half_rec=hr.reshape(-1, 16), step_rec=sr[:sizes[6]].reshape(-1, 8),
+                node_cam=nc.reshape(-1, int(sizes[4])), tab=tab)
+
+
 RETRI_MODE_TRACE, RETRI_MODE_ENUMERATE = 0, 1
 
 

@@ -15,6 +15,7 @@
 #include "band_kernels2p.h"
 #include "band_sub.h"
 #include "band_ring.h"
+#include "snode.h"
 #include "ssfm_ctx.h"
 #include "knobs.h"
 
@@ -24,13 +25,13 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 
 enum KernelId { KID_CAM_ROT, KID_POINT_LIN, KID_SCHUR_ROWS, KID_FINALIZE, KID_PCG_INIT, KID_PCG_MATVEC, KID_PCG_VECOPS,
                 KID_CAM_UPDATE, KID_BACKSUB, KID_COST, KID_ALLREDUCE, KID_BAND_GATHER, KID_BAND_CHOL, KID_BAND_FWD, KID_BAND_BACK,
-                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_RING_TAIL, KID_DET_DECODE, KID_COUNT };
+                KID_BAND_COMBINE, KID_REF_VEC, KID_CAM_SUMS, KID_SUB_SPIKE, KID_SUB_ASM, KID_SUB_CHAIN, KID_SUB_APPLY, KID_SCHUR_GRAM, KID_GRAM_BACKSUB, KID_RING_ELIM, KID_RING_BACK, KID_RING_TAIL, KID_DET_DECODE, KID_SNODE, KID_COUNT };
 // names as rocprofv3 prints them (template arguments dropped)
 static const char* kKernelNames[KID_COUNT] = {"k_cam_rot", "k_point_lin", "k_schur_pairs2", "k_finalize_gather", "k_pcg_init",
                                               "k_arrow_update", "k_pcg_vecops", "k_cam_update", "k_point_backsub",
                                               "k_point_cost", "rccl_allreduce", "k_band_gather", "k_band_chol_v2", "k_band_fwd_lds",
                                               "k_band_back_v2", "k_arrow_phi", "k_ref_vecops", "k_cam_sums2", "k_sub_spike_fwd",
-                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back", "k_ring_cr_tail", "k_det_decode"};
+                                              "k_sub_sep_assemble", "k_sub_sep_chain", "k_sub_apply_left", "k_schur_gram", "k_gram_backsub", "k_ring_cr_elim", "k_ring_cr_back", "k_ring_cr_tail", "k_det_decode", "k_snode_solve"};
 
 // SSFM_PLAN_TIMING: time spent in hipMalloc (atomic: the observation arrays are allocated by the upload thread of ba_create_impl while the main thread plans)
 static bool g_alloc_timing = false; static std::atomic<long long> g_alloc_ns{0}; static std::atomic<int> g_alloc_n{0};
@@ -97,6 +98,8 @@ struct ssfm_ba_handle {
     // rings (round 5, band_ring.h): wrap table of the gather kernels, cyclic-reduction schedule, per-separator factor / coupling / right-hand-side blocks
     DevBuf<int> wrap_ptr, wrap_blk, wrap_row2, ring_rec, ring_tail; DevBuf<double> crL, crF, crW, crP, crT, crE;
     const int* wrap_ptr_p() const { return wrap_ptr.n ? wrap_ptr.p : nullptr; }
+    // supernodal ring / chain solver of the reduced system (snode.h): plan, tables, factor workspace, the halves' exchange buffers and flags
+    SnodePlan sn; DevBuf<int> sn_half, sn_step, sn_node, sn_tab, sn_flags; DevBuf<double> sn_work, sn_xchg; int sn_seq = 0;
     DevBuf<int> trans_ptr, trans_blk, trans_row, pair_j, pair_j2, pair_p, batch_slot, cam_batch_ptr, chunk_cam, chunk_b0, chunk_b1, cam_obs_pt, cs_task_cam, cs_task_q0, cs_task_q1;
     double *S_val = nullptr, *rhs = nullptr, *Udiag = nullptr, *Sfc = nullptr, *gcraw = nullptr, *red_scal = nullptr;
     double focal_host = 0, t_flatten_s = 0;
@@ -139,6 +142,7 @@ struct ssfm_ba_handle {
         col_pos.free(); trans_pos.free(); trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         pub_ticket.free(); gr_rec.free(); pt_grouped.free();
+        sn_half.free(); sn_step.free(); sn_node.free(); sn_tab.free(); sn_flags.free(); sn_work.free(); sn_xchg.free(); sn.enabled = false;
         wrap_ptr.free(); wrap_blk.free(); wrap_row2.free(); ring_rec.free(); ring_tail.free(); crL.free(); crF.free(); crW.free(); crP.free(); crT.free(); crE.free();
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();
         if (host_sp) { (void)hipHostFree(host_sp); host_sp = nullptr; }
@@ -283,6 +287,40 @@ static bool band_wide_packed(int DC, int b, bool use_lds) {
     if (use_lds || DC != 6 || b < 1 || !band_packed_enabled()) return false;
     const int tasks2p = (b * (b + 1) / 2) * 4 - 4 + b * DC;
     return chol2p_lds_bytes(b, 2) <= 160 * 1024 && tasks2p <= 3 * 12 * 64 && b * 36 <= 2 * 1024 && (b + 1) * 36 + 2 * DC <= 9 * 128 && b * DC <= 192;
+}
+
+
+// ---- supernodal solver (snode.h): tables and buffers of a plan; the one launch that factors, substitutes and scatters
+static int snode_upload(ssfm_ba_handle* h) {
+    ssfm_ctx* ctx = h->ctx; hipStream_t st = ctx->stream;
+    const SnodePlan& P = h->sn;
+    if (!P.enabled) return SSFM_OK;
+    SSFM_HIP_CHECK(ctx, upload(h->sn_half, P.half_rec, st)); SSFM_HIP_CHECK(ctx, upload(h->sn_step, P.step_rec.empty() ? std::vector<int>(SN_SREC, 0) : P.step_rec, st));
+    SSFM_HIP_CHECK(ctx, upload(h->sn_node, P.node_cam, st)); SSFM_HIP_CHECK(ctx, upload(h->sn_tab, P.tab.empty() ? std::vector<int>(1, -1) : P.tab, st));
+    SSFM_HIP_CHECK(ctx, h->sn_work.alloc(std::max<size_t>(P.work_doubles, 1))); SSFM_HIP_CHECK(ctx, h->sn_xchg.alloc(std::max<size_t>(P.xchg_doubles, 1)));
+    SSFM_HIP_CHECK(ctx, h->sn_flags.alloc((size_t)std::max(P.nflags, 1)));
+    SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->sn_flags.p, 0, (size_t)std::max(P.nflags, 1) * sizeof(int), st));
+    h->sn_seq = 0;
+    return SSFM_OK;
+}
+template <int DC, int NR, bool RING>
+static int snode_launch(ssfm_ba_handle* h, double* Y, size_t ystride) {
+    ssfm_ctx* ctx = h->ctx;
+    const SnodePlan& P = h->sn;
+    const size_t lds = P.lds_bytes();
+    if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_snode_solve<DC, NR, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->sn_seq++;
+    LAUNCH(h, KID_SNODE, (k_snode_solve<DC, NR, RING>), P.nhalf, SN_THREADS, lds, h->S_val, h->rhs, h->Sfc, h->sn_half.p, h->sn_step.p, h->sn_node.p, h->sn_tab.p, h->cam_pos.p,
+           h->sn_work.p, h->sn_xchg.p, h->sn_flags.p, h->sn_seq, P.qtm, Y, ystride, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+    return SSFM_OK;
+}
+// S y = [rhs | S_fc] by the supernodal solver; Y in the band-row layout of the right-hand sides (the second column only with a free focal length: it stays as
+// k_finalize_gather left it otherwise, zero)
+template <int DC>
+static int snode_direct(ssfm_ba_handle* h, double* Y, size_t ystride) {
+    const bool ring = h->sn.qtm > 0;
+    if (h->F.focal_free) return ring ? snode_launch<DC, 2, true>(h, Y, ystride) : snode_launch<DC, 2, false>(h, Y, ystride);
+    return ring ? snode_launch<DC, 1, true>(h, Y, ystride) : snode_launch<DC, 1, false>(h, Y, ystride);
 }
 
 // Factor the band in h->band (block-band Cholesky in Cuthill-McKee order) and solve for the two right-hand-side columns of Y
@@ -623,7 +661,7 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->rhs, h->Sfc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, Nb, h->Yb.p);
     }
     h->band_filled = false;
-    { const int rc = direct(h->Yb.p); if (rc) return rc; }
+    { const int rc = h->sn.enabled ? snode_direct<DC>(h, h->Yb.p, (size_t)nb) : direct(h->Yb.p); if (rc) return rc; }
     if (h->external_tail) { *iters_out = 0; *ok_out = true; return SSFM_OK; }
     // ---- focal arrow, then the residual check r = rhs - S x (PCG refinement with the factor as preconditioner while it is too large)
     if (F.sym_lower && h->tail.on) {
@@ -649,8 +687,8 @@ static int solve_reduced(ssfm_ba_handle* h, double* host_pcg, int* iters_out, bo
       if (fail_flag) { *iters_out = 0; *ok_out = false; return SSFM_OK; } }   // S not positive definite: invalid step
     while (host_pcg[PCG_DONE] == 0.0 && it < O.pcg_max_iterations) {
         hipLaunchKernelGGL(k_band_permute_rhs<DC>, dim3((n + 255) / 256), dim3(256), 0, st, h->pr.p, h->Sfc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, Nc, Nb, h->Yr.p);
-        bool refactor = false;
-        { const int rc = merged ? band_resolve<6>(h, h->Yr.p, &refactor) : band_resolve<DC>(h, h->Yr.p, &refactor); if (rc) return rc; }
+        bool refactor = h->sn.enabled;      // (the supernodal factor has no stand-alone substitution: the refinement path rebuilds the band and takes the band kernels)
+        if (!refactor) { const int rc = merged ? band_resolve<6>(h, h->Yr.p, &refactor) : band_resolve<DC>(h, h->Yr.p, &refactor); if (rc) return rc; }
         if (refactor) {
             // the substructured factor has no stand-alone substitution kernels: rebuild the band from S and solve again (rare path)
             gather();

@@ -525,6 +525,64 @@ extern "C" int ssfm_band_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t N, int32
     return rc;
 }
 
+
+// Test probe: the supernodal solver alone on a caller-supplied block-sparse symmetric positive definite matrix (block-CSR, every coupled pair of cameras stored
+// once in either orientation + the diagonal blocks, row-major dc x dc blocks) and two right-hand-side columns; Y [2][Nc * dc] out (camera order).
+// info: [0] 1 = the plan applies (else nothing ran) [1] workgroups [2] rows of T [3] factorisation failure flag
+extern "C" int ssfm_snode_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t Nc, const int32_t* row_ptr, const int32_t* col_idx, const double* S_val, const double* rhs2,
+                                      int32_t nr, double* Y, int32_t* info) {
+    if (!ctx || (dc != 3 && dc != 6) || Nc <= 0 || !row_ptr || !col_idx || !S_val || !rhs2 || !Y || !info || (nr != 1 && nr != 2)) return fail(ctx, SSFM_ERR_INVALID, "ssfm_snode_solve_probe: bad arguments");
+    SSFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ssfm_ba_handle hh; ssfm_ba_handle* h = &hh;
+    h->ctx = ctx; ssfm_ba_default_options(&h->opt);
+    std::memset(h->k_launches, 0, sizeof(h->k_launches)); std::memset(h->k_ms, 0, sizeof(h->k_ms));
+    std::vector<int> rp(row_ptr, row_ptr + Nc + 1), ci(col_idx, col_idx + row_ptr[Nc]);
+    snode_plan(Nc, dc, rp, ci, ctx->num_cus, h->sn);
+    info[0] = h->sn.enabled ? 1 : 0; info[1] = h->sn.nhalf; info[2] = h->sn.qtm; info[3] = 0;
+    if (!h->sn.enabled) return SSFM_OK;
+    const size_t n = (size_t)Nc * dc, nnz = (size_t)row_ptr[Nc] * dc * dc;
+    DevBuf<double> dS, dR; std::vector<int> ident(Nc); for (int c = 0; c < Nc; c++) ident[c] = c;
+    auto run = [&]() -> int {
+        SSFM_HIP_CHECK(ctx, dS.alloc(nnz)); SSFM_HIP_CHECK(ctx, dR.alloc(2 * n)); SSFM_HIP_CHECK(ctx, h->Yb.alloc(2 * n)); SSFM_HIP_CHECK(ctx, h->pcg.alloc(PCG_TOTAL + 1));
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->pcg.p, 0, (PCG_TOTAL + 1) * sizeof(double), st)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->Yb.p, 0, 2 * n * sizeof(double), st));
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(dS.p, S_val, nnz * sizeof(double), hipMemcpyHostToDevice, st)); SSFM_HIP_CHECK(ctx, hipMemcpyAsync(dR.p, rhs2, 2 * n * sizeof(double), hipMemcpyHostToDevice, st));
+        SSFM_HIP_CHECK(ctx, upload(h->cam_pos, ident, st));
+        { const int r = snode_upload(h); if (r) return r; }
+        h->S_val = dS.p; h->rhs = dR.p; h->Sfc = dR.p + n; h->F.focal_free = nr == 2;
+        for (int rep = 0; rep < 2; rep++) { const int r = (dc == 3) ? snode_direct<3>(h, h->Yb.p, n) : snode_direct<6>(h, h->Yb.p, n); if (r) return r; }      // twice: the flags' sequence numbers
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Y, h->Yb.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+        int flag = 0;
+        SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&flag, h->pcg.p + PCG_TOTAL, sizeof(int), hipMemcpyDeviceToHost, st));
+        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        info[3] = flag;
+        return SSFM_OK;
+    };
+    const int rc = run();
+    h->S_val = nullptr; h->rhs = nullptr; h->Sfc = nullptr;
+    dS.free(); dR.free(); h->free_all();
+    return rc;
+}
+
+
+// Host-only (no GPU): the supernodal plan of a block structure, for the CPU tests and for anyone who wants to see what the solver will do.
+// sizes: [8] = {applies, workgroups, rows reserved for T, cameras per supernode, node capacity, ints of half_rec, of step_rec, of node_cam}; the three tables and the block
+// tables are copied out when the pointers are non-null and the capacities (in ints) suffice; tab_len in/out.
+extern "C" int ssfm_snode_plan_probe(int32_t dc, int32_t Nc, const int32_t* row_ptr, const int32_t* col_idx, int32_t num_cus, int32_t* sizes, int32_t* half_rec, int32_t* step_rec,
+                                     int32_t* node_cam, int32_t* tab, int32_t* tab_len) {
+    if ((dc != 3 && dc != 6) || Nc <= 0 || !row_ptr || !col_idx || !sizes) return SSFM_ERR_INVALID;
+    std::vector<int> rp(row_ptr, row_ptr + Nc + 1), ci(col_idx, col_idx + row_ptr[Nc]);
+    SnodePlan P;
+    snode_plan(Nc, dc, rp, ci, num_cus, P);
+    sizes[0] = P.enabled ? 1 : 0; sizes[1] = P.nhalf; sizes[2] = P.qtm; sizes[3] = P.S; sizes[4] = P.CAPT; sizes[5] = (int)P.half_rec.size(); sizes[6] = (int)P.step_rec.size(); sizes[7] = (int)P.node_cam.size();
+    if (!P.enabled) return SSFM_OK;
+    if (half_rec) std::copy(P.half_rec.begin(), P.half_rec.end(), half_rec);
+    if (step_rec) std::copy(P.step_rec.begin(), P.step_rec.end(), step_rec);
+    if (node_cam) std::copy(P.node_cam.begin(), P.node_cam.end(), node_cam);
+    if (tab_len) { if (tab && *tab_len >= (int)P.tab.size()) std::copy(P.tab.begin(), P.tab.end(), tab); *tab_len = (int)P.tab.size(); }
+    return SSFM_OK;
+}
+
 // ssfm_ctx_destroy releases the recycled host arrays of the planner (ba_flatten.h: HostStash)
 void ssfm_host_stash_clear() { host_stash_clear(); }
 
@@ -657,6 +715,13 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     SSFM_HIP_CHECK(ctx, upload(h->band_pairs, F.band_pairs, st));
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
+    // rings / chains of cameras with a reach of <= 30 / DC cameras: the supernodal solver (snode.h) takes the direct solve; the band stays planned for the refinement path
+    if (h->opt.preconditioner == 0 && F.sym_lower) {
+        const double ts = wall_s();
+        snode_plan(Nc, DC, F.row_ptr, F.col_idx, ctx->num_cus, h->sn);
+        if (g_alloc_timing) std::fprintf(stderr, "[create] supernodal plan %.2f ms: %s, %d workgroups, T rows %d\n", 1e3 * (wall_s() - ts), h->sn.enabled ? "on" : "not applicable", h->sn.nhalf, h->sn.qtm);
+        const int rc = snode_upload(h); if (rc) return rc;
+    }
     SSFM_HIP_CHECK(ctx, upload(h->trans_ptr, F.trans_ptr, st)); SSFM_HIP_CHECK(ctx, upload(h->trans_blk, F.trans_blk, st));
     SSFM_HIP_CHECK(ctx, upload(h->trans_row, F.trans_row, st));
     {   // band row of every stored block's column camera (and of every transposed block's): k_arrow_update reads it instead of col_idx -> pos, one dependent gather less
