@@ -304,23 +304,23 @@ static int snode_upload(ssfm_ba_handle* h) {
     return SSFM_OK;
 }
 template <int DC, int NR, bool RING>
-static int snode_launch(ssfm_ba_handle* h, double* Y, size_t ystride) {
+static int snode_launch(ssfm_ba_handle* h, double* Y, size_t ystride, long long* stamps = nullptr) {
     ssfm_ctx* ctx = h->ctx;
     const SnodePlan& P = h->sn;
     const size_t lds = P.lds_bytes();
     if (lds > 48 * 1024) SSFM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_snode_solve<DC, NR, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->sn_seq++;
     LAUNCH(h, KID_SNODE, (k_snode_solve<DC, NR, RING>), P.nhalf, SN_THREADS, lds, h->S_val, h->rhs, h->Sfc, h->sn_half.p, h->sn_step.p, h->sn_node.p, h->sn_tab.p, h->cam_pos.p,
-           h->sn_work.p, h->sn_xchg.p, h->sn_flags.p, h->sn_seq, P.qtm, Y, ystride, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL));
+           h->sn_work.p, h->sn_xchg.p, h->sn_flags.p, h->sn_seq, P.qtm, Y, ystride, reinterpret_cast<int*>(h->pcg.p + PCG_TOTAL), stamps);
     return SSFM_OK;
 }
 // S y = [rhs | S_fc] by the supernodal solver; Y in the band-row layout of the right-hand sides (the second column only with a free focal length: it stays as
 // k_finalize_gather left it otherwise, zero)
 template <int DC>
-static int snode_direct(ssfm_ba_handle* h, double* Y, size_t ystride) {
+static int snode_direct(ssfm_ba_handle* h, double* Y, size_t ystride, long long* stamps = nullptr) {
     const bool ring = h->sn.qtm > 0;
-    if (h->F.focal_free) return ring ? snode_launch<DC, 2, true>(h, Y, ystride) : snode_launch<DC, 2, false>(h, Y, ystride);
-    return ring ? snode_launch<DC, 1, true>(h, Y, ystride) : snode_launch<DC, 1, false>(h, Y, ystride);
+    if (h->F.focal_free) return ring ? snode_launch<DC, 2, true>(h, Y, ystride, stamps) : snode_launch<DC, 2, false>(h, Y, ystride, stamps);
+    return ring ? snode_launch<DC, 1, true>(h, Y, ystride, stamps) : snode_launch<DC, 1, false>(h, Y, ystride, stamps);
 }
 
 // Factor the band in h->band (block-band Cholesky in Cuthill-McKee order) and solve for the two right-hand-side columns of Y

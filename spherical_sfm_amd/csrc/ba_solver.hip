@@ -550,7 +550,24 @@ extern "C" int ssfm_snode_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t Nc, con
         SSFM_HIP_CHECK(ctx, upload(h->cam_pos, ident, st));
         { const int r = snode_upload(h); if (r) return r; }
         h->S_val = dS.p; h->rhs = dR.p; h->Sfc = dR.p + n; h->F.focal_free = nr == 2;
-        for (int rep = 0; rep < 2; rep++) { const int r = (dc == 3) ? snode_direct<3>(h, h->Yb.p, n) : snode_direct<6>(h, h->Yb.p, n); if (r) return r; }      // twice: the flags' sequence numbers
+        // SSFM_SNODE_STAMPS=1 (timing study): phase stamps of every workgroup of the last launch on stderr, 100 MHz ticks
+        const bool want_stamps = std::getenv("SSFM_SNODE_STAMPS") != nullptr; DevBuf<long long> dst;
+        if (want_stamps) { SSFM_HIP_CHECK(ctx, dst.alloc((size_t)h->sn.nhalf * 64)); SSFM_HIP_CHECK(ctx, hipMemsetAsync(dst.p, 0, (size_t)h->sn.nhalf * 64 * sizeof(long long), st)); }
+        const int reps = want_stamps ? 6 : 2;
+        for (int rep = 0; rep < reps; rep++) { const int r = (dc == 3) ? snode_direct<3>(h, h->Yb.p, n, dst.p) : snode_direct<6>(h, h->Yb.p, n, dst.p); if (r) return r; }      // twice: the flags' sequence numbers
+        if (want_stamps) {
+            std::vector<long long> hs((size_t)h->sn.nhalf * 64); SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), dst.p, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, st)); SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            long long t00 = hs[0]; for (int b = 0; b < h->sn.nhalf; b++) t00 = std::min(t00, hs[(size_t)b * 64]);
+            for (int b = 0; b < h->sn.nhalf; b++) { const long long* q = &hs[(size_t)b * 64];
+                std::fprintf(stderr, "[snode] wg %d (%d steps): start +%lld | prologue %lld | elimination %lld | exchange %lld | M,T %lld | back %lld | total %lld ticks\n", b, h->sn.half_rec[(size_t)b * SN_HREC],
+                             q[0] - t00, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+                if (b < 2) { const long long* u0 = q + 40; const long long* u1 = q + 48;
+                    std::fprintf(stderr, "        stage M: panel (wave 0) %lld | barrier %lld | T rows + rhs (wave 1) %lld | outputs + barriers %lld | tiles + barrier %lld | the T stages %lld\n",
+                                 u0[1] - u0[0], u0[2] - u0[1], u1[3] - u1[2], u0[4] - u1[3], u0[5] - u0[4], q[4] - u0[5]); }
+                if (b < 2) for (int w = 0; w < 4; w++) { const long long* u = q + 8 + w * 8;
+                    std::fprintf(stderr, "        slot 2, wave %d: own work %lld | wait B0 + outputs + B1 %lld | tiles %lld | wait B2 %lld\n", w, u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]); } }
+            dst.free();
+        }
         SSFM_HIP_CHECK(ctx, hipMemcpyAsync(Y, h->Yb.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost, st));
         int flag = 0;
         SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&flag, h->pcg.p + PCG_TOTAL, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -716,7 +733,7 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     SSFM_HIP_CHECK(ctx, upload(h->comp_ptr, F.comp_ptr, st));
     { const int rc = sub_upload(h, DC); if (rc) return rc; }     // long components: segments + separators (band_sub.h)
     // rings / chains of cameras with a reach of <= 30 / DC cameras: the supernodal solver (snode.h) takes the direct solve; the band stays planned for the refinement path
-    if (h->opt.preconditioner == 0 && F.sym_lower) {
+    if (h->opt.preconditioner == 0 && F.sym_lower && snode_enabled()) {
         const double ts = wall_s();
         snode_plan(Nc, DC, F.row_ptr, F.col_idx, ctx->num_cus, h->sn);
         if (g_alloc_timing) std::fprintf(stderr, "[create] supernodal plan %.2f ms: %s, %d workgroups, T rows %d\n", 1e3 * (wall_s() - ts), h->sn.enabled ? "on" : "not applicable", h->sn.nhalf, h->sn.qtm);

@@ -31,11 +31,16 @@
 namespace ssfm {
 
 constexpr int SNQ = 30;            // scalar rows of a supernode (5 cameras x 6 or 10 cameras x 3)
+constexpr int SN_CS = 66;          // stride of one column of the panel in LDS: [column][lane], lanes 0..29 the pivot's rows, 32..61 the next supernode's
 constexpr int SN_LD = 31;          // leading dimension of the Q-column LDS / workspace matrices (odd: rows of consecutive lanes fall into different banks)
 constexpr int SN_QTMAX = 60;       // rows of T: s + (n mod s) cameras <= 2 s - 1
 constexpr int SN_MAXSTEPS = 16;    // pivots of one half
 constexpr int SN_THREADS = 256;
 constexpr int SN_HREC = 16, SN_SREC = 8;
+
+// Opt-in (SSFM_SNODE=1): measured at BASELINE config 2 the launch takes 112 us against 86 us for the four launches of the band kernels it replaces (phase
+// stamps in profiles/r06_notes.md), so the LM loop keeps the band kernels by default; the probes below run it regardless.
+inline bool snode_enabled() { const char* e = std::getenv("SSFM_SNODE"); return e && std::atoi(e) != 0; }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // Host plan
@@ -53,8 +58,8 @@ struct SnodePlan {
     std::vector<int> tab;               // block tables: entry = slot of S | 1 << 30 when the stored block is the transpose; -1 zero block; -2 identity (padding diagonal)
     size_t work_step() const { return (size_t)2 * SNQ * SN_LD + (size_t)qtm * SN_LD + 2 * SNQ; }
     size_t xchg_half() const { return (size_t)SNQ * SN_LD + 2 * SNQ + (size_t)qtm * SN_LD + (size_t)qtm * (qtm + 1) + 2 * qtm; }
-    size_t lds_bytes() const {
-        const size_t d = (size_t)4 * SNQ * SN_LD + (size_t)2 * qtm * SN_LD + (size_t)2 * SNQ * SN_LD + (size_t)qtm * SN_LD + (size_t)qtm * (qtm + 1)
+    size_t lds_bytes() const {      // k_snode_solve's carve-up: D, C (two each), E (two), the panel columns (two), LTP, T x T, right-hand sides, small vectors
+        const size_t d = (size_t)4 * SNQ * SN_LD + (size_t)2 * qtm * SN_LD + (size_t)2 * SNQ * SN_CS + (size_t)qtm * SN_LD + (size_t)qtm * (qtm + 1)
                        + (size_t)(SN_MAXSTEPS + 2) * 2 * SNQ + 6 * SNQ + (size_t)6 * qtm + 64;
         return d * sizeof(double);
     }
@@ -111,7 +116,6 @@ inline int snode_order(const std::vector<int>& comp, const std::vector<std::vect
 // row_ptr / col_idx: the stored blocks of S (each coupled pair of cameras once, in either orientation, plus the diagonal blocks)
 inline bool snode_plan(int Nc, int DC, const std::vector<int>& row_ptr, const std::vector<int>& col_idx, int num_cus, SnodePlan& P) {
     P = SnodePlan();
-    if (const char* e = std::getenv("SSFM_SNODE")) if (std::atoi(e) == 0) return false;
     if ((DC != 3 && DC != 6) || Nc < 1) return false;
     const int S = SNQ / DC, CAPT = 2 * S;
     P.DC = DC; P.S = S; P.CAPT = CAPT;
@@ -203,6 +207,7 @@ inline bool snode_plan(int Nc, int DC, const std::vector<int>& row_ptr, const st
             const int Pn = h.piv[k], Nn = (k + 1 < ns) ? h.piv[k + 1] : h.M;
             const bool orig = (k + 1 < ns) || h.owner;                     // the original blocks of M are the owner's
             int s8[SN_SREC] = {Pn, Nn, add_table(Nn, Pn, S, false), orig ? add_table(Nn, Nn, S, true) : -1, (h.T >= 0 && orig) ? add_table(h.T, Nn, S, false) : -1, orig ? 1 : 0, 0, 0};
+            if (s8[4] >= 0) return false;                                  // a supernode behind the first pivot that touches T: cannot happen with >= 3 supernodes per ring; the kernel relies on it
             for (int q = 0; q < SN_SREC; q++) P.step_rec.push_back(s8[q]);
         }
     }
@@ -241,6 +246,87 @@ __device__ __forceinline__ void sn_gather(double* dst, int ld, int nrows, int nc
         }
     }
 }
+// the same gather in batches of B entries per thread (tables first, then values, then the LDS stores: two memory round trips per batch)
+template <int DC, int B>
+__device__ __forceinline__ void sn_gather_b(double* dst, int ld, int nrows, int ncols, const double* __restrict__ S_val, const int* __restrict__ tabs, int tab, int ncb, int t, int nt) {
+    constexpr int BB = DC * DC;
+    const int total = nrows * ncols;
+    if (tab < 0) { for (int idx = t; idx < total; idx += nt) { const int i = idx / ncols, j = idx - i * ncols; dst[i * ld + j] = 0.0; } return; }
+    const int* __restrict__ tb = tabs + tab;
+    for (int base = 0; base < total; base += B * nt) {
+        int e[B], o[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int idx = min(base + u * nt + t, total - 1), i = idx / ncols, j = idx - i * ncols, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;
+            e[u] = tb[a * ncb + b];
+            o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
+        }
+        double val[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int idx = base + u * nt + t;
+            if (idx < total) { const int i = idx / ncols, j = idx - i * ncols; dst[i * ld + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]); }
+        }
+    }
+}
+// Up to four SNQ-column matrices in ONE pass (segment g: dst, leading dimension, rows, columns = SNQ, table (-1: zeros, -3: skipped), blocks per table row): every table entry a
+// thread needs is loaded first, then every value, then the LDS stores -- two memory round trips for the lot (a gather per matrix in batches of four paid two per batch:
+// the helpers' 4 us per slot were eight dependent round trips, the prologue 6.5 us).  PER * nt must cover the elements.
+struct SnSeg { double* dst; int ld, nrows, ncols, tab, ncb; };
+template <int DC, int PER>
+__device__ __forceinline__ void sn_gather_multi(const SnSeg (&sg)[4], const double* __restrict__ S_val, const int* __restrict__ tabs, int t, int nt) {
+    constexpr int BB = DC * DC;
+    const int n0 = sg[0].nrows * sg[0].ncols, n1 = n0 + sg[1].nrows * sg[1].ncols, n2 = n1 + sg[2].nrows * sg[2].ncols, n3 = n2 + sg[3].nrows * sg[3].ncols;
+    int e[PER], o[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int g = min(u * nt + t, max(n3 - 1, 0));
+        const int q = g >= n2 ? 3 : (g >= n1 ? 2 : (g >= n0 ? 1 : 0)), base = q == 3 ? n2 : (q == 2 ? n1 : (q == 1 ? n0 : 0));
+        const int idx = g - base, i = idx / SNQ, j = idx - i * SNQ, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;      // (every segment has SNQ columns)
+        e[u] = sg[q].tab >= 0 ? tabs[sg[q].tab + a * sg[q].ncb + b] : -1;
+        o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
+    }
+    double val[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int g = u * nt + t;
+        if (g < n3) {
+            const int q = g >= n2 ? 3 : (g >= n1 ? 2 : (g >= n0 ? 1 : 0)), base = q == 3 ? n2 : (q == 2 ? n1 : (q == 1 ? n0 : 0));
+            const int idx = g - base, i = idx / SNQ, j = idx - i * SNQ;
+            if (sg[q].tab != -3) sg[q].dst[i * sg[q].ld + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]);
+        }
+    }
+}
+// Two SNQ x SNQ matrices (leading dimension SN_LD) in ONE pass: every table entry a thread needs is loaded first, then every value, then the LDS stores -- two memory
+// round trips per slot instead of two per batch of four (the helpers' 4 us per slot were eight dependent round trips).  tab == -3: that matrix is skipped.
+template <int DC>
+__device__ __forceinline__ void sn_gather2(double* dstA, int tabA, double* dstB, int tabB, const double* __restrict__ S_val, const int* __restrict__ tabs, int t, int nt) {
+    constexpr int BB = DC * DC, S = SNQ / DC, NE = SNQ * SNQ, PER = 16;      // 2 * 900 entries over >= 128 threads: <= 15 each
+    int e[PER], o[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int g = min(u * nt + t, 2 * NE - 1), which = g >= NE ? 1 : 0, idx = g - which * NE;
+        const int i = idx / SNQ, j = idx - i * SNQ, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;
+        const int tab = which ? tabB : tabA;
+        e[u] = tab >= 0 ? tabs[tab + a * S + b] : -1;
+        o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
+    }
+    double val[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int g = u * nt + t;
+        if (g < 2 * NE) {
+            const int which = g >= NE ? 1 : 0, idx = g - which * NE, i = idx / SNQ, j = idx - i * SNQ;
+            if ((which ? tabB : tabA) != -3) (which ? dstB : dstA)[i * SN_LD + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]);
+        }
+    }
+}
 // right-hand-side rows of a node: dst[i * 2 + t] = (rhs | Sfc)[camera(i) * DC + component(i)], zero for padding cameras or when the node's data are not this half's
 template <int DC, int NR>
 __device__ __forceinline__ void sn_gather_rhs(double* dst, const int* __restrict__ cams, int nrows, bool load, const double* __restrict__ rhs, const double* __restrict__ Sfc, int t, int nt) {
@@ -251,54 +337,90 @@ __device__ __forceinline__ void sn_gather_rhs(double* dst, const int* __restrict
     }
 }
 
-// The tall panel.  Lane l < 30: row l of the pivot's diagonal block; lane 32 + l: row l of the coupling block (next supernode x pivot); rowT (TR): row `lane` of the
-// coupling block (T x pivot).  row[SNQ + t] / rowT[SNQ + t]: right-hand side t of that row.  Exit: row[j] = L(row, j) (the diagonal entry holds 1 / L_jj),
-// row[SNQ + t] = y (pivot rows) or the updated right-hand side (other rows).  Returns false when a pivot is not positive.
-template <int NR, bool TR>
-__device__ __forceinline__ bool sn_panel(double (&row)[SNQ + NR], double (&rowT)[SNQ + NR], const int lane_in) {
-    bool ok = true;
-    // Every column is its own scheduling region (sched_barrier): left alone, the compiler turns the fully unrolled right-looking loop into a LEFT-looking one to save
-    // registers -- column c then starts with a chain of c dependent multiply-adds on the pivot entry (ISA of the first build: 3.5k cycles of pure latency per panel) and
-    // every broadcast value is parked in a VGPR lane for later.  The lane index is made opaque per column so that the 60 (lane == c) / (lane > c) masks are compared on
-    // the spot (one instruction) instead of being hoisted, spilled to VGPR lanes and read back (two v_readlane + wait states each).
-    int lane = lane_in;
+// The tall panel of one supernode on ONE wave.  Lane l < 30 enters with row l of the pivot's diagonal block in row[], lane 32 + l with row l of the coupling block
+// (next supernode x pivot); the other four lanes with zeros.  Column c of the factor leaves through LDS: Lc[c * SN_CS + lane] = L(lane's row, c) (the diagonal entry
+// is L_cc itself), which is at once the panel's only output and its own broadcast channel: the pivot entry and the two rows that become pivots next take column c
+// through v_readlane (they sit on the dependent chain), every other row reads L(c2, c) back from LDS with a wave-uniform address -- a broadcast that costs the
+// vector pipe nothing -- and applies it one column LATER, when the read has long returned.  Right-hand sides and the rows of T are not here: the second wave
+// takes them from Lc one step behind (sn_trows).  Returns false when a pivot was not positive (or not a number).
+__device__ __forceinline__ bool sn_panel(double (&row)[SNQ], double* __restrict__ Lc, const int lane) {
+    double dacc = 1.0, lp = 0.0, llast = 0.0;
+    double2 sb[2][SNQ / 2];                                                  // column c's entries c2 = 2 q, 2 q + 1 as read back from LDS (128-bit broadcasts)
 #pragma unroll
     for (int c = 0; c < SNQ; c++) {
-        asm volatile("" : "+v"(lane));
         const double d = lane_bcast(row[c], c);
-        ok = ok && (d > 0.0);
-        const double rs = fast_rsqrt(d);
+        dacc = fmin(dacc, d);
+        const double rs = fast_rsqrt3(d);
         const double l = row[c] * rs;
-        double lT = 0.0;
-        if (TR) { lT = rowT[c] * rs; rowT[c] = lT; }
-        row[c] = (lane == c) ? rs : l;
+        Lc[c * SN_CS + lane] = l;
+        if (c + 1 < SNQ) row[c + 1] = fma(-l, lane_bcast(l, c + 1), row[c + 1]);
+        if (c + 2 < SNQ) row[c + 2] = fma(-l, lane_bcast(l, c + 2), row[c + 2]);
+        const double2* __restrict__ col2 = reinterpret_cast<const double2*>(Lc + c * SN_CS);
 #pragma unroll
-        for (int c2 = c + 1; c2 < SNQ; c2++) {
-            const double s = lane_bcast(l, c2);
-            row[c2] = fma(-l, s, row[c2]);
-            if (TR) rowT[c2] = fma(-lT, s, rowT[c2]);
-        }
+        for (int q = (c + 3) / 2; q < SNQ / 2; q++) sb[c & 1][q] = col2[q];                         // wave-uniform address: broadcast
+        if (c >= 1) {
 #pragma unroll
-        for (int t = 0; t < NR; t++) {
-            const double yc = lane_bcast(row[SNQ + t], c) * rs;
-            const double lm = (lane > c) ? l : 0.0;
-            row[SNQ + t] = (lane == c) ? yc : fma(-lm, yc, row[SNQ + t]);
-            if (TR) rowT[SNQ + t] = fma(-lT, yc, rowT[SNQ + t]);
+            for (int c2 = c + 2; c2 < SNQ; c2++) { const double2 v = sb[(c - 1) & 1][c2 / 2]; row[c2] = fma(-lp, (c2 & 1) ? v.y : v.x, row[c2]); }   // the previous column's share of the rows behind the look-ahead
         }
-        __builtin_amdgcn_sched_barrier(0);
+        lp = l;
+        if (c == SNQ - 1) llast = lane_bcast(l, SNQ - 1);
+        __builtin_amdgcn_sched_barrier(0);                                                          // (a column is a scheduling region: see the note in DESIGN.md 4c on what the scheduler does otherwise)
     }
-    return ok;
+    return dacc > 0.0 && llast == llast;
 }
 
-// One 16x16 tile on the matrix cores:  C(i, j) -= sum_k X(i, k) Y(j, k),  k < SNQ; rows of X below nx, rows of Y below ny.
-__device__ __forceinline__ void sn_tile(double* C, int ldc, const double* X, int ldx, int nx, const double* Y, int ldy, int ny, int ti, int tj, int lane) {
+// The rows of T and every right-hand side of one elimination step, on the second wave, from the finished panel in LDS (one step behind the first wave):
+//   rowT[j]  in: row `lane` of the coupling block (T x pivot)            out: L(T row, j)
+//   gr[t]    in: right-hand side t of the panel row this lane stands for (lanes 0..29 the pivot's, 32..61 the next supernode's)
+//            out: lanes 0..29 UNSCALED y (the caller multiplies by 1 / L_cc), lanes 32..61 the next supernode's updated right-hand side
+//   gT[t]    in / out: right-hand side t of T's row `lane`
+// L(c2, c) for the T rows comes from LDS at wave-uniform addresses (broadcasts); only y_c crosses lanes (one v_readlane pair per column and right-hand side).
+template <int NR, bool TR>
+__device__ __forceinline__ void sn_trows(double (&rowT)[SNQ], double (&gT)[NR], double (&gr)[NR], const double* __restrict__ Lc, const int lane_in) {
+    int lane = lane_in;
+    double2 sb[2][SNQ / 2];
+    double lTp = 0.0;
+    // software-pipelined by one column, like the panel: region c issues the 128-bit broadcast reads of column c and applies column c - 1 (whose reads returned long ago);
+    // with read and use in one region the compiler waits for every read on the spot (ISA of the first build: 45 cycles per entry)
+#pragma unroll
+    for (int c = 0; c < SNQ; c++) {
+        asm volatile("" : "+v"(lane));                                                              // the (lane > c) masks are compared on the spot, not hoisted and spilled
+        const double2* __restrict__ col2 = reinterpret_cast<const double2*>(Lc + c * SN_CS);
+        if (TR) {
+#pragma unroll
+            for (int q = (c + 1) / 2; q < SNQ / 2; q++) sb[c & 1][q] = col2[q];
+        }
+        const double lcc = Lc[c * SN_CS + c];
+        const double lown = Lc[c * SN_CS + lane_in];
+        if (TR && c >= 1) {
+#pragma unroll
+            for (int c2 = c; c2 < SNQ; c2++) { const double2 v = sb[(c - 1) & 1][c2 / 2]; rowT[c2] = fma(-lTp, (c2 & 1) ? v.y : v.x, rowT[c2]); }
+        }
+        const double rs = fast_rcp(lcc);
+        const double lm = (lane > c) ? lown : 0.0;
+        double lT = 0.0;
+        if (TR) { lT = rowT[c] * rs; rowT[c] = lT; }
+#pragma unroll
+        for (int t = 0; t < NR; t++) {
+            const double yc = lane_bcast(gr[t], c) * rs;
+            gr[t] = fma(-lm, yc, gr[t]);
+            if (TR) gT[t] = fma(-lT, yc, gT[t]);
+        }
+        lTp = lT;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One 16x16 tile on the matrix cores:  C(i, j) (-)= sum_k X(i, k) Y(j, k),  k < SNQ; X(i, k) = X[i * xi + k * xk], rows below nx; Y likewise.  ZERO: C = -sum (no read of C).
+template <bool ZERO>
+__device__ __forceinline__ void sn_tile(double* C, int ldc, const double* X, int xi, int xk, int nx, const double* Y, int yi, int yk, int ny, int ti, int tj, int lane) {
     const int li = lane & 15, lk = lane >> 4;
     const int i = 16 * ti + li, j = 16 * tj + li;
     const bool vi = i < nx, vj = j < ny;
-    const double* Xi = X + (size_t)(vi ? i : 0) * ldx; const double* Yj = Y + (size_t)(vj ? j : 0) * ldy;
+    const double* Xi = X + (size_t)(vi ? i : 0) * xi; const double* Yj = Y + (size_t)(vj ? j : 0) * yi;
     double a[8], b[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) { const int k = min(4 * ks + lk, SNQ - 1); a[ks] = Xi[k]; b[ks] = Yj[k]; }
+    for (int ks = 0; ks < 8; ks++) { const int k = min(4 * ks + lk, SNQ - 1); a[ks] = Xi[k * xk]; b[ks] = Yj[k * yk]; }
     sn_v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
@@ -306,31 +428,34 @@ __device__ __forceinline__ void sn_tile(double* C, int ldc, const double* X, int
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((vi && vk) ? a[ks] : 0.0, (vj && vk) ? b[ks] : 0.0, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int r = 16 * ti + lk + 4 * q, c = 16 * tj + li; if (r < nx && c < ny) C[(size_t)r * ldc + c] -= acc[q]; }
+    for (int q = 0; q < 4; q++) { const int r = 16 * ti + lk + 4 * q, c = 16 * tj + li; if (r < nx && c < ny) { if (ZERO) C[(size_t)r * ldc + c] = -acc[q]; else C[(size_t)r * ldc + c] -= acc[q]; } }
 }
-// lower triangle (tiles) of C -= X X^T, rows below n; tiles dealt to `nw` waves, this one is w
-__device__ __forceinline__ void sn_syrk(double* C, int ldc, const double* X, int ldx, int n, int w, int nw, int lane) {
+// lower triangle (tiles) of C -= X X^T, rows below n; the tiles t0, t0 + 1, ... are dealt to `nw` waves, this one is w; returns the next free tile number
+__device__ __forceinline__ int sn_syrk(double* C, int ldc, const double* X, int xi, int xk, int n, int w, int nw, int t0, int lane) {
     const int nt = (n + 15) >> 4;
-    int t = 0;
-    for (int ti = 0; ti < nt; ti++) for (int tj = 0; tj <= ti; tj++, t++) if (t % nw == w) sn_tile(C, ldc, X, ldx, n, X, ldx, n, ti, tj, lane);
+    int t = t0;
+    for (int ti = 0; ti < nt; ti++) for (int tj = 0; tj <= ti; tj++, t++) if (t % nw == w) sn_tile<false>(C, ldc, X, xi, xk, n, X, xi, xk, n, ti, tj, lane);
+    return t;
 }
-// all of C -= X Y^T (X: nx rows, Y: ny rows)
-__device__ __forceinline__ void sn_gemm(double* C, int ldc, const double* X, int ldx, int nx, const double* Y, int ldy, int ny, int w, int nw, int t0, int lane) {
+// all of C = - X Y^T (X: nx rows, Y: ny rows)
+__device__ __forceinline__ int sn_gemm_neg(double* C, int ldc, const double* X, int xi, int xk, int nx, const double* Y, int yi, int yk, int ny, int w, int nw, int t0, int lane) {
     const int ntx = (nx + 15) >> 4, nty = (ny + 15) >> 4;
     int t = t0;
-    for (int ti = 0; ti < ntx; ti++) for (int tj = 0; tj < nty; tj++, t++) if (t % nw == w) sn_tile(C, ldc, X, ldx, nx, Y, ldy, ny, ti, tj, lane);
+    for (int ti = 0; ti < ntx; ti++) for (int tj = 0; tj < nty; tj++, t++) if (t % nw == w) sn_tile<true>(C, ldc, X, xi, xk, nx, Y, yi, yk, ny, ti, tj, lane);
+    return t;
 }
 
-// Back substitution of one supernode on ONE wave:  x = Ldd^-T ( y - A^T xa - B^T xb ),  Ldd: SNQ x SNQ lower with 1 / L_jj on the diagonal (leading dimension ldd),
-// A: na x SNQ (lda) with xa[na][2], B: nb x SNQ (ldb) with xb[nb][2] (either may be empty).  Lanes 0..31 take A's sum, lanes 32..63 B's.  Exit: x[t] on lanes j < SNQ.
+// Back substitution of one supernode on ONE wave:  x = Ldd^-T ( y - A^T xa - B^T xb ).  Ldd(r, j) = Ldd[r * lr + j * lj] lower with L_jj on the diagonal; y [ny][2] already
+// scaled (L^-1 g); A(r, j) = A[r * ar + j * aj], na rows, with xa[na][2]; B likewise (either may be empty).  Lanes 0..31 take A's sum, lanes 32..63 B's.  Exit: x[t] on lanes j < SNQ.
 template <int NR>
-__device__ __forceinline__ void sn_back(const double* Ldd, int ldd, const double* y /* [ny][2] */, int ny, const double* A, int lda, int na, const double* xa,
-                                        const double* B, int ldb, int nb, const double* xb, double (&x)[NR], const int lane) {
+__device__ __forceinline__ void sn_back(const double* Ldd, int lr, int lj, const double* y, int ny, const double* A, int ar, int aj, int na, const double* xa,
+                                        const double* B, int br, int bj, int nb, const double* xb, double (&x)[NR], const int lane) {
     const int half = lane >> 5, jj = min(lane & 31, SNQ - 1);
     double col[SNQ];
 #pragma unroll
-    for (int r = 0; r < SNQ; r++) col[r] = Ldd[(size_t)r * ldd + jj];
-    const double* Mt = half ? B : A; const int ldm = half ? ldb : lda, nm = half ? nb : na; const double* xv = half ? xb : xa;
+    for (int r = 0; r < SNQ; r++) col[r] = Ldd[(size_t)r * lr + (size_t)jj * lj];
+    const double rsl = fast_rcp(Ldd[(size_t)jj * lr + (size_t)jj * lj]);
+    const double* Mt = half ? B : A; const int mr = half ? br : ar, mj = half ? bj : aj, nm = half ? nb : na; const double* xv = half ? xb : xa;
     double acc[NR];
 #pragma unroll
     for (int t = 0; t < NR; t++) acc[t] = 0.0;
@@ -340,7 +465,7 @@ __device__ __forceinline__ void sn_back(const double* Ldd, int ldd, const double
 #pragma unroll
         for (int u = 0; u < 6; u++) {
             const int r = min(r0 + u, max(nm - 1, 0));
-            m[u] = nm > 0 ? Mt[(size_t)r * ldm + jj] : 0.0;
+            m[u] = nm > 0 ? Mt[(size_t)r * mr + (size_t)jj * mj] : 0.0;
 #pragma unroll
             for (int t = 0; t < NR; t++) v[u][t] = nm > 0 ? xv[r * 2 + t] : 0.0;
         }
@@ -355,7 +480,7 @@ __device__ __forceinline__ void sn_back(const double* Ldd, int ldd, const double
     for (int t = 0; t < NR; t++) { const double other = __shfl_xor(acc[t], 32, 64); const double yv = y[min(jj, ny - 1) * 2 + t]; w[t] = ((lane & 31) < ny ? yv : 0.0) - (acc[t] + other); }
     double rsv[SNQ];
 #pragma unroll
-    for (int r = 0; r < SNQ; r++) rsv[r] = lane_bcast(col[r], r);
+    for (int r = 0; r < SNQ; r++) rsv[r] = lane_bcast(rsl, r);
 #pragma unroll
     for (int r = SNQ - 1; r >= 0; r--) {
 #pragma unroll
@@ -368,11 +493,69 @@ __device__ __forceinline__ void sn_back(const double* Ldd, int ldd, const double
     for (int t = 0; t < NR; t++) x[t] = w[t];
 }
 
+
+// Back substitution of the pivots, spread over the four waves (a wave takes every fourth step): the factor blocks come back from global memory (L2), and one step is far
+// shorter than that round trip -- so a wave loads the blocks of its NEXT step right after finishing one and has three steps of the other waves to wait for them
+// (lds_barrier does not wait for vector memory).  Lane j < 32: column j of Ldd and of Lsd (and of L(T, .) rows 30.. when T has more than 30); lane 32 + j: column j of
+// L(T, .) rows 0..29.
+struct SnBackRegs { double col[SNQ], m[SNQ], m2[SNQ], diag, y[2]; };
+__device__ __forceinline__ void sn_back_load(SnBackRegs& R, const double* __restrict__ wp, int qtm, int QT, int lane) {
+    constexpr int Q = SNQ, LD = SN_LD;
+    const int half = lane >> 5, jj = min(lane & 31, Q - 1);
+    const double* Ldd = wp; const double* Lsd = wp + Q * LD; const double* LTP = wp + 2 * Q * LD; const double* yv = LTP + (size_t)qtm * LD;
+    const double* M = half ? LTP : Lsd; const int nm = half ? min(QT, Q) : Q;
+#pragma unroll
+    for (int r = 0; r < Q; r++) { R.col[r] = Ldd[r * LD + jj]; R.m[r] = M[min(r, max(nm - 1, 0)) * LD + jj]; }
+    if (QT > Q) {
+#pragma unroll
+        for (int r = 0; r < Q; r++) R.m2[r] = LTP[min(Q + r, QT - 1) * LD + jj];
+    }
+    R.diag = Ldd[jj * LD + jj]; R.y[0] = yv[jj * 2]; R.y[1] = yv[jj * 2 + 1];
+}
+template <int NR>
+__device__ __forceinline__ void sn_back_step(const SnBackRegs& R, int QT, const double* __restrict__ xN, const double* __restrict__ xT, double (&x)[NR], int lane) {
+    constexpr int Q = SNQ;
+    const int half = lane >> 5;
+    const double* xv = half ? xT : xN; const int nm = half ? min(QT, Q) : Q;
+    double acc[NR];
+#pragma unroll
+    for (int t = 0; t < NR; t++) acc[t] = 0.0;
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+#pragma unroll
+        for (int t = 0; t < NR; t++) { const double v = xv[r * 2 + t]; acc[t] = fma(r < nm ? R.m[r] : 0.0, v, acc[t]); }
+    }
+    if (QT > Q) {
+#pragma unroll
+        for (int r = 0; r < Q; r++) {
+#pragma unroll
+            for (int t = 0; t < NR; t++) { const double v = xT[min(Q + r, QT - 1) * 2 + t]; acc[t] = fma((!half && Q + r < QT) ? R.m2[r] : 0.0, v, acc[t]); }
+        }
+    }
+    const double rsl = fast_rcp(R.diag);
+    double w[NR];
+#pragma unroll
+    for (int t = 0; t < NR; t++) { const double other = __shfl_xor(acc[t], 32, 64); w[t] = R.y[t] - (acc[t] + other); }
+    double rsv[SNQ];
+#pragma unroll
+    for (int r = 0; r < Q; r++) rsv[r] = lane_bcast(rsl, r);
+#pragma unroll
+    for (int r = Q - 1; r >= 0; r--) {
+#pragma unroll
+        for (int t = 0; t < NR; t++) {
+            const double xr = lane_bcast(w[t], r) * rsv[r];
+            w[t] = (lane == r) ? xr : ((lane < r) ? fma(-R.col[r], xr, w[t]) : w[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NR; t++) x[t] = w[t];
+}
+
 // solution rows of a node -> Y (the layout k_arrow_update reads: Y[t * ystride + pos[camera] * DC + component])
 template <int DC, int NR>
-__device__ __forceinline__ void sn_store_y(double* __restrict__ Y, size_t ystride, const int* __restrict__ cams, const int* __restrict__ pos, int nrows, const double (&x)[NR], int lane) {
+__device__ __forceinline__ void sn_store_y(double* __restrict__ Y, size_t ystride, const int* __restrict__ cams, const int* __restrict__ pos, int row0, int nrows, const double (&x)[NR], int lane) {
     if (lane < nrows) {
-        const int a = lane / DC, u = lane - a * DC, cam = cams[a];
+        const int i = row0 + lane, a = i / DC, u = i - a * DC, cam = cams[a];
         if (cam >= 0) {
 #pragma unroll
             for (int t = 0; t < NR; t++) Y[(size_t)t * ystride + (size_t)pos[cam] * DC + u] = x[t];
@@ -380,28 +563,40 @@ __device__ __forceinline__ void sn_store_y(double* __restrict__ Y, size_t ystrid
     }
 }
 
+// One workgroup per half (four waves), one loop over STAGES so that the panel and the T-row code exist once (the first build had four copies of each: 170 KB of
+// code, and the copy behind the exchange spilled 570 registers to scratch):
+//   stages 0 .. ns-1   pivot k: wave 0 factors its panel from D / C in LDS into Lc[k & 1] WHILE wave 1 does the rows of T and every right-hand side of pivot k - 1
+//                      from Lc[(k - 1) & 1] and waves 2, 3 bring the next supernode's original blocks from S into LDS and send the previous steps' factor blocks to
+//                      global memory (the back substitution reads them again); then all four, behind a barrier: D(next) -= Lsd Lsd^T (pivot k),
+//                      E(T, P_k) = - L(T, P_k-1) Lsd_k-1^T and T x T -= L(T, P_k-1) L(T, P_k-1)^T (pivot k - 1) on the matrix cores
+//   stage ns           drains wave 1 (pivot ns - 1); then the exchange with the partner half
+//   stage ns+1         M:   panel, barrier, T rows + right-hand side of the SAME stage, T x T -= L(T, M) L(T, M)^T
+//   stage ns+2 (rings) T_1 = the first 30 rows of T, T_2 (<= 30 more) rides as the coupling block; T_2 x T_2 -= L_21 L_21^T
+//   stage ns+3 (T_2)   the rest of T
 template <int DC, int NR, bool RING>
 __global__ void __launch_bounds__(SN_THREADS)
 k_snode_solve(const double* __restrict__ S_val, const double* __restrict__ rhs, const double* __restrict__ Sfc,
               const int* __restrict__ half_rec, const int* __restrict__ step_rec, const int* __restrict__ node_cam, const int* __restrict__ tabs,
               const int* __restrict__ pos, double* __restrict__ work, double* __restrict__ xchg, int* __restrict__ flags, int seq, int qtm,
-              double* __restrict__ Y, size_t ystride, int* __restrict__ fail_flag) {
-    constexpr int S = SNQ / DC, CAPT = 2 * S, Q = SNQ, LD = SN_LD;
+              double* __restrict__ Y, size_t ystride, int* __restrict__ fail_flag, long long* __restrict__ stamps = nullptr) {
+    constexpr int S = SNQ / DC, CAPT = 2 * S, Q = SNQ, LD = SN_LD, CS = SN_CS;
+#define SN_STAMP(i_) do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 64 + (i_)] = (long long)wall_clock64(); } while (0)
+#define SN_WSTAMP(i_) do { if (stamps && lane == 0 && st == 2) stamps[(size_t)blockIdx.x * 64 + 8 + wave * 8 + (i_)] = (long long)wall_clock64(); } while (0)
+#define SN_TSTAMP(i_) do { if (stamps && lane == 0 && wave <= 1 && st == ns + 1) stamps[(size_t)blockIdx.x * 64 + 40 + wave * 8 + (i_)] = (long long)wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int LDT = qtm + 1;
     double* Dbuf = lds;                                   // [2][Q][LD]   diagonal block of the pivot (cur) / of the next supernode (next: original, then updated)
     double* Cbuf = Dbuf + 2 * Q * LD;                     // [2][Q][LD]   coupling (next x pivot)
-    double* Ebuf = Cbuf + 2 * Q * LD;                     // [2][qtm][LD] coupling (T x pivot)
-    double* Ldd = Ebuf + 2 * qtm * LD;                    // [Q][LD]      panel outputs of the step
-    double* Lsd = Ldd + Q * LD;                           // [Q][LD]
-    double* LTP = Lsd + Q * LD;                           // [qtm][LD]
+    double* Ebuf = Cbuf + 2 * Q * LD;                     // [2][qtm][LD] coupling (T x pivot of stage k) in Ebuf[k & 1]
+    double* Lcb = Ebuf + 2 * qtm * LD;                    // [2][Q][CS]   the panel's columns
+    double* LTP = Lcb + 2 * Q * CS;                       // [qtm][LD]    L(T, pivot) of the stage wave 1 finished last
     double* ATT = LTP + qtm * LD;                         // [qtm][LDT]   T x T, accumulated over the half
     double* gAll = ATT + qtm * LDT;                       // [MAXSTEPS + 2][Q][2]  right-hand sides of the pivots and of M (updated in place as the elimination passes)
-    double* yP = gAll + (SN_MAXSTEPS + 2) * 2 * Q;        // [Q][2]       y of the step
+    double* yP = gAll + (SN_MAXSTEPS + 2) * 2 * Q;        // [Q][2]       y of the stage wave 1 finished last
     double* xN = yP + 2 * Q;                              // [Q][2]       solution of the supernode behind (back substitution)
     double* yM = xN + 2 * Q;                              // [Q][2]
-    double* gT = yM + 2 * Q;                              // [qtm][2]     right-hand side of T
-    double* yT = gT + 2 * qtm;                            // [qtm][2]
+    double* gTb = yM + 2 * Q;                             // [qtm][2]     right-hand side of T
+    double* yT = gTb + 2 * qtm;                           // [qtm][2]
     double* xT = yT + 2 * qtm;                            // [qtm][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int* hr = half_rec + (size_t)blockIdx.x * SN_HREC;
@@ -410,241 +605,268 @@ k_snode_solve(const double* __restrict__ S_val, const double* __restrict__ rhs, 
     double* wk = work + (size_t)hr[6];
     const size_t wstep = (size_t)2 * Q * LD + (size_t)qtm * LD + 2 * Q;
     const int* tcams = node_cam + (size_t)max(tnode, 0) * CAPT;
+    const int sl = lane - 32;
+    const bool dl = lane < Q;
+    const int QT2 = RING ? max(QT - Q, 0) : 0;
+    const bool hasT = RING && QT > 0;
+    SN_STAMP(0);
     // ---- prologue: the first pivot (or M when the half has none), every right-hand side, T's own block
-    sn_gather<DC>(Dbuf, LD, Q, Q, S_val, tabs, hr[9], S, tid, SN_THREADS);
-    if (RING) sn_gather<DC>(Ebuf, LD, QT, Q, S_val, tabs, hr[10], S, tid, SN_THREADS);
-    if (RING) sn_gather<DC>(ATT, LDT, QT, QT, S_val, tabs, hr[11], CAPT, tid, SN_THREADS);
-    if (ns > 0) sn_gather<DC>(Cbuf, LD, Q, Q, S_val, tabs, sr0[2], S, tid, SN_THREADS);
+    {
+        // one matrix per wave, all four at once: two memory round trips for the lot when a matrix fits one batch of 16 per lane (the 30 x 30 ones do)
+        if (wave == 0) sn_gather_b<DC, 16>(Dbuf, LD, Q, Q, S_val, tabs, hr[9], S, lane, 64);
+        else if (wave == 1) { if (ns > 0) sn_gather_b<DC, 16>(Cbuf, LD, Q, Q, S_val, tabs, sr0[2], S, lane, 64); }
+        else if (wave == 2) { if (RING) sn_gather_b<DC, 16>(Ebuf, LD, QT, Q, S_val, tabs, hr[10], S, lane, 64); }
+        else if (RING) sn_gather_b<DC, 16>(ATT, LDT, QT, QT, S_val, tabs, hr[11], CAPT, lane, 64);
+    }
     sn_gather_rhs<DC, 2>(gAll, node_cam + (size_t)hr[13] * CAPT, Q, ns > 0 || owner, rhs, Sfc, tid, SN_THREADS);
     for (int k = 0; k < ns; k++) sn_gather_rhs<DC, 2>(gAll + (size_t)(k + 1) * 2 * Q, node_cam + (size_t)sr0[k * SN_SREC + 1] * CAPT, Q, sr0[k * SN_SREC + 5] != 0, rhs, Sfc, tid, SN_THREADS);
-    if (RING) sn_gather_rhs<DC, 2>(gT, tcams, QT, owner != 0, rhs, Sfc, tid, SN_THREADS);
+    if (RING) sn_gather_rhs<DC, 2>(gTb, tcams, QT, owner != 0, rhs, Sfc, tid, SN_THREADS);
+    for (int e = tid; e < 2 * qtm; e += SN_THREADS) { xT[e] = 0.0; yT[e] = 0.0; }      // (read under a mask by halves without a T: must be numbers)
+    for (int e = tid; e < 2 * Q; e += SN_THREADS) { xN[e] = 0.0; yM[e] = 0.0; yP[e] = 0.0; }
     __syncthreads();
+    SN_STAMP(1);
     int cur = 0;
     bool ok = true;
-    double row[Q + NR], rowT[Q + NR];
-    if (wave == 0) {
+    double row[Q], gT[NR], gr[NR];                                         // row: the panel's row on wave 0, T's row on wave 1 (one array: a wave is one or the other)
 #pragma unroll
-        for (int t = 0; t < NR; t++) rowT[Q + t] = (RING && lane < QT) ? gT[lane * 2 + t] : 0.0;
-    }
-    // ---- elimination of the half's pivots
-    for (int k = 0; k < ns; k++) {
-        const int* sr = sr0 + (size_t)k * SN_SREC;
+    for (int t = 0; t < NR; t++) { gT[t] = (wave == 1 && hasT && lane < QT) ? gTb[lane * 2 + t] : 0.0; gr[t] = 0.0; }
+    double* LcT2 = Dbuf;                                                   // the panel of T_2: D's two buffers and part of C's (Q x CS doubles), free by then
+    const int nstages = ns + 2 + (hasT ? 1 : 0) + (QT2 > 0 ? 1 : 0);
+    for (int st = (ns > 0 ? 0 : 1); st < nstages; st++) {
+        const int kind = st < ns ? 0 : st - ns + 1;                        // 0 pivot, 1 drain, 2 M, 3 T_1, 4 T_2
         const int nxt = cur ^ 1;
         double* Dc = Dbuf + cur * Q * LD; double* Dn = Dbuf + nxt * Q * LD;
         double* Cc = Cbuf + cur * Q * LD; double* Cn = Cbuf + nxt * Q * LD;
-        double* Ec = Ebuf + cur * qtm * LD; double* En = Ebuf + nxt * qtm * LD;
-        double* gP = gAll + (size_t)k * 2 * Q; double* gN = gAll + (size_t)(k + 1) * 2 * Q;
-        if (wave == 0) {
-            const int sl = lane - 32;
-            const bool dl = lane < Q, sub = sl >= 0 && sl < Q;
-            const double* src = dl ? Dc + lane * LD : Cc + (sub ? sl : 0) * LD;
+        double* Lk = kind == 4 ? LcT2 : Lcb + (st & 1) * Q * CS;           // this stage's panel columns
+        double* Lp = kind <= 1 ? Lcb + ((st + 1) & 1) * Q * CS : Lk;       // the panel wave 1 works on: the previous pivot's while the pivots run, this stage's own behind the exchange
+        double* EM = Ebuf + (ns & 1) * qtm * LD;                           // E(T, M), then L(T, M) in place
+        double* gM = gAll + (size_t)ns * 2 * Q;
+        // ---- the exchange with the partner half sits in front of M: both end up with the same sums
+        if (kind == 2) {
+            SN_STAMP(2);
+            if (ns > 0) {                                                    // what is still in LDS goes to global memory
+                double* wp = wk + (size_t)(ns - 1) * wstep;
+                if (RING) for (int e = tid; e < QT * LD; e += SN_THREADS) wp[2 * Q * LD + e] = LTP[e];
+                for (int e = tid; e < 2 * Q; e += SN_THREADS) wp[2 * Q * LD + (size_t)qtm * LD + e] = yP[e];
+            }
+            if (hasT && wave == 1 && lane < QT) {                           // T's right-hand side leaves wave 1's registers
+#pragma unroll
+                for (int t = 0; t < NR; t++) gTb[lane * 2 + t] = gT[t];
+                if (NR == 1) gTb[lane * 2 + 1] = 0.0;
+            }
+            __syncthreads();
+            if (partner >= 0) {
+                double* mine = xchg + (size_t)hr[7]; const double* other = xchg + (size_t)hr[14];
+                const int nD = Q * LD, nE = qtm * LD, nTT = qtm * LDT;
+                for (int e = tid; e < nD; e += SN_THREADS) mine[e] = Dc[e];
+                for (int e = tid; e < 2 * Q; e += SN_THREADS) mine[nD + e] = gM[e];
+                if (RING) {
+                    for (int e = tid; e < nE; e += SN_THREADS) mine[nD + 2 * Q + e] = EM[e];
+                    for (int e = tid; e < nTT; e += SN_THREADS) mine[nD + 2 * Q + nE + e] = ATT[e];
+                    for (int e = tid; e < 2 * qtm; e += SN_THREADS) mine[nD + 2 * Q + nE + nTT + e] = gTb[e];
+                }
+                __threadfence(); __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(flags + hr[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    while (__hip_atomic_load(flags + hr[15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+                }
+                __syncthreads(); __threadfence();
+                for (int e = tid; e < nD; e += SN_THREADS) Dc[e] += other[e];
+                for (int e = tid; e < 2 * Q; e += SN_THREADS) gM[e] += other[nD + e];
+                if (RING) {
+                    for (int e = tid; e < nE; e += SN_THREADS) EM[e] += other[nD + 2 * Q + e];
+                    for (int e = tid; e < nTT; e += SN_THREADS) ATT[e] += other[nD + 2 * Q + nE + e];
+                    for (int e = tid; e < 2 * qtm; e += SN_THREADS) gTb[e] += other[nD + 2 * Q + nE + nTT + e];
+                }
+                __syncthreads();
+            }
+            if (wave == 1 && hasT && lane < QT) {
+#pragma unroll
+                for (int t = 0; t < NR; t++) gT[t] = gTb[lane * 2 + t];
+            }
+            SN_STAMP(3);
+        }
+        if (kind == 4) {                                                     // T_2's diagonal block, identity-padded to 30 rows, into C's place (LcT2 takes D's and the front of C's second half only later)
+            double* P2 = Cbuf + Q * LD;
+            for (int e = tid; e < Q * Q; e += SN_THREADS) { const int i = e / Q, j = e - i * Q; P2[i * LD + j] = (i < QT2 && j < QT2) ? ATT[(size_t)(Q + i) * LDT + Q + j] : (i == j ? 1.0 : 0.0); }
+            __syncthreads();
+        }
+        SN_WSTAMP(0); SN_TSTAMP(0);
+        // ---- wave 0: the panel of this stage
+        if (wave == 0 && kind != 1) {
+            const double* pD = kind == 0 || kind == 2 ? Dc : (kind == 3 ? ATT : Cbuf + Q * LD); const int ldD = kind == 3 ? LDT : LD;
+            const double* pC = kind == 0 ? Cc : ATT + (size_t)Q * LDT; const int ldC = kind == 0 ? LD : LDT, nsub = kind == 0 ? Q : (kind == 3 ? QT2 : 0);
+            const bool sub = sl >= 0 && sl < nsub;
+            const double* src = dl ? pD + (size_t)lane * ldD : pC + (size_t)(sub ? sl : 0) * ldC;
 #pragma unroll
             for (int j = 0; j < Q; j++) { const double v = src[j]; row[j] = (dl || sub) ? v : 0.0; }
+            ok = sn_panel(row, Lk, lane) && ok;
+        }
+        SN_TSTAMP(1);
+        if (kind >= 2) __syncthreads();                                      // behind the exchange wave 1 works on THIS stage's panel
+        SN_TSTAMP(2);
+        // ---- wave 1: rows of T and right-hand sides (of the previous pivot while the pivots run)
+        const bool w1 = wave == 1 && (kind >= 2 || st >= 1);
+        const bool tr = hasT && kind <= 2;
+        if (w1) {
+            const double* pE = kind <= 1 ? Ebuf + ((st - 1) & 1) * qtm * LD : EM;
+            if (tr) {
+                const double* srcT = pE + (size_t)(lane < QT ? lane : 0) * LD;
 #pragma unroll
-            for (int t = 0; t < NR; t++) { const double v = dl ? gP[lane * 2 + t] : gN[(sub ? sl : 0) * 2 + t]; row[Q + t] = (dl || sub) ? v : 0.0; }
-            if (RING) {
-                const double* srcT = Ec + (lane < QT ? lane : 0) * LD;
-#pragma unroll
-                for (int j = 0; j < Q; j++) { const double v = srcT[j]; rowT[j] = lane < QT ? v : 0.0; }
+                for (int j = 0; j < Q; j++) { const double v = srcT[j]; row[j] = lane < QT ? v : 0.0; }
             }
-            ok = sn_panel<NR, RING>(row, rowT, lane) && ok;
-            lds_barrier();                                                   // B0: the helpers are done with the previous step's outputs
-            double* dst = dl ? Ldd + lane * LD : Lsd + (sub ? sl : 0) * LD;
-            if (dl || sub) {
+            // right-hand sides: lanes 0..29 the stage's pivot rows, lanes 32.. the rows that ride below them
+            const double* gP = kind <= 1 ? gAll + (size_t)(st - 1) * 2 * Q : (kind == 2 ? gM : (kind == 3 ? gTb : gTb + 2 * Q));
+            const double* gN = kind <= 1 ? gAll + (size_t)st * 2 * Q : gTb + 2 * Q;
+            const int nd = kind == 4 ? QT2 : Q, nsubg = kind <= 1 ? Q : (kind == 3 ? QT2 : 0);
+            const bool dg = lane < nd, sg = sl >= 0 && sl < nsubg;
+            const double* gsrc = dg ? gP + lane * 2 : gN + (sg ? sl : 0) * 2;
 #pragma unroll
-                for (int j = 0; j < Q; j++) dst[j] = row[j];
+            for (int t = 0; t < NR; t++) { const double v = gsrc[t]; gr[t] = (dg || sg) ? v : 0.0; }
+            if (RING && tr) sn_trows<NR, RING>(row, gT, gr, Lp, lane); else sn_trows<NR, false>(row, gT, gr, Lp, lane);      // (a run-time flag inside the column loop cost 45 %)
+        }
+        SN_TSTAMP(3);
+        // ---- waves 2, 3 while the pivots run: the next supernode's original blocks; the previous stages' factor blocks to global memory
+        if (wave >= 2 && kind <= 1) {
+            const int ht = tid - 128, hn = SN_THREADS - 128;
+            // order matters: vector memory returns in order, so the table loads go first, the stores to global memory fill the time of the two round trips
+            constexpr int PER = 16, NE = Q * Q, BB = DC * DC;
+            int ge[PER], go[PER]; double gv[PER];
+            const int* sr = sr0 + (size_t)min(st, max(ns - 1, 0)) * SN_SREC;
+            const int tabA = kind == 0 ? sr[3] : -3, tabB = (kind == 0 && st + 1 < ns) ? sr[SN_SREC + 2] : -3;      // D(N_st), C(N_st+1, N_st)
+            if (kind == 0) {
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int g = min(u * hn + ht, 2 * NE - 1), which = g >= NE ? 1 : 0, idx = g - which * NE;
+                    const int i = idx / Q, j = idx - i * Q, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;
+                    const int tab = which ? tabB : tabA;
+                    ge[u] = tab >= 0 ? tabs[tab + a * S + b] : -1;
+                    go[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < NR; t++) { if (dl) yP[lane * 2 + t] = row[Q + t]; else if (sub) gN[sl * 2 + t] = row[Q + t]; }
-            if (RING && lane < QT) {
-#pragma unroll
-                for (int j = 0; j < Q; j++) LTP[lane * LD + j] = rowT[j];
-            }
-            lds_barrier();                                                   // B1: the panel is in LDS
-        } else {
-            const int ht = tid - 64, hn = SN_THREADS - 64, hw = wave - 1;
-            if (k > 0) {
-                if (RING) sn_syrk(ATT, LDT, LTP, LD, QT, hw, 3, lane);       // T x T takes the previous step's share
-                double* wp = wk + (size_t)(k - 1) * wstep;                   // the previous step's factor blocks and y -> global memory (read again by the back substitution)
-                for (int e = ht; e < Q * LD; e += hn) { wp[e] = Ldd[e]; wp[Q * LD + e] = Lsd[e]; }
+            if (st >= 2) {                                                   // L(T, P_st-2) and y_st-2
+                double* wp = wk + (size_t)(st - 2) * wstep;
                 if (RING) for (int e = ht; e < QT * LD; e += hn) wp[2 * Q * LD + e] = LTP[e];
                 for (int e = ht; e < 2 * Q; e += hn) wp[2 * Q * LD + (size_t)qtm * LD + e] = yP[e];
             }
-            sn_gather<DC>(Dn, LD, Q, Q, S_val, tabs, sr[3], S, ht, hn);      // the next supernode's original blocks
-            if (RING) sn_gather<DC>(En, LD, QT, Q, S_val, tabs, sr[4], S, ht, hn);
-            if (k + 1 < ns) sn_gather<DC>(Cn, LD, Q, Q, S_val, tabs, sr[SN_SREC + 2], S, ht, hn);
-            lds_barrier();                                                   // B0
-            lds_barrier();                                                   // B1
-        }
-        // ---- Schur updates on the matrix cores: D(N) -= Lsd Lsd^T (lower tiles), E(T, N) -= LTP Lsd^T
-        sn_syrk(Dn, LD, Lsd, LD, Q, wave, 4, lane);
-        if (RING) sn_gemm(En, LD, LTP, LD, QT, Lsd, LD, Q, wave, 4, 3, lane);
-        lds_barrier();                                                       // B2
-        cur = nxt;
-    }
-    // ---- the last step's outputs: T x T share, factor blocks to global memory
-    if (ns > 0) {
-        if (RING) sn_syrk(ATT, LDT, LTP, LD, QT, wave, 4, lane);
-        double* wp = wk + (size_t)(ns - 1) * wstep;
-        for (int e = tid; e < Q * LD; e += SN_THREADS) { wp[e] = Ldd[e]; wp[Q * LD + e] = Lsd[e]; }
-        if (RING) for (int e = tid; e < QT * LD; e += SN_THREADS) wp[2 * Q * LD + e] = LTP[e];
-        for (int e = tid; e < 2 * Q; e += SN_THREADS) wp[2 * Q * LD + (size_t)qtm * LD + e] = yP[e];
-    }
-    if (RING && wave == 0 && lane < QT) {
+            if (kind == 0) {
 #pragma unroll
-        for (int t = 0; t < NR; t++) gT[lane * 2 + t] = rowT[Q + t];
-        if (NR == 1) gT[lane * 2 + 1] = 0.0;
-    }
-    __syncthreads();
-    double* DM = Dbuf + cur * Q * LD;                     // M's diagonal block, E(T, M), M's right-hand side: this half's share
-    double* EM = Ebuf + cur * qtm * LD;
-    double* gM = gAll + (size_t)ns * 2 * Q;
-    // ---- exchange with the partner half: both end up with the same sums
-    if (partner >= 0) {
-        double* mine = xchg + (size_t)hr[7]; const double* other = xchg + (size_t)hr[14];
-        const int nD = Q * LD, nE = qtm * LD, nTT = qtm * LDT;
-        for (int e = tid; e < nD; e += SN_THREADS) mine[e] = DM[e];
-        for (int e = tid; e < 2 * Q; e += SN_THREADS) mine[nD + e] = gM[e];
-        if (RING) {
-            for (int e = tid; e < nE; e += SN_THREADS) mine[nD + 2 * Q + e] = EM[e];
-            for (int e = tid; e < nTT; e += SN_THREADS) mine[nD + 2 * Q + nE + e] = ATT[e];
-            for (int e = tid; e < 2 * qtm; e += SN_THREADS) mine[nD + 2 * Q + nE + nTT + e] = gT[e];
-        }
-        __threadfence(); __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(flags + hr[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(flags + hr[15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
-        }
-        __syncthreads(); __threadfence();
-        for (int e = tid; e < nD; e += SN_THREADS) DM[e] += other[e];
-        for (int e = tid; e < 2 * Q; e += SN_THREADS) gM[e] += other[nD + e];
-        if (RING) {
-            for (int e = tid; e < nE; e += SN_THREADS) EM[e] += other[nD + 2 * Q + e];
-            for (int e = tid; e < nTT; e += SN_THREADS) ATT[e] += other[nD + 2 * Q + nE + e];
-            for (int e = tid; e < 2 * qtm; e += SN_THREADS) gT[e] += other[nD + 2 * Q + nE + nTT + e];
-        }
-        __syncthreads();
-    }
-    // ---- M, then T (both halves of a ring do this redundantly, on identical data)
-    const int QT2 = RING ? max(QT - Q, 0) : 0;
-    const bool hasT = RING && QT > 0;
-    if (wave == 0) {
-        const bool dl = lane < Q;
-#pragma unroll
-        for (int j = 0; j < Q; j++) { const double v = DM[(dl ? lane : 0) * LD + j]; row[j] = dl ? v : 0.0; }
-#pragma unroll
-        for (int t = 0; t < NR; t++) { const double v = gM[(dl ? lane : 0) * 2 + t]; row[Q + t] = dl ? v : 0.0; }
-        if (RING) {
-#pragma unroll
-            for (int j = 0; j < Q; j++) { const double v = EM[(lane < QT ? lane : 0) * LD + j]; rowT[j] = lane < QT ? v : 0.0; }
-#pragma unroll
-            for (int t = 0; t < NR; t++) rowT[Q + t] = lane < QT ? gT[lane * 2 + t] : 0.0;
-        }
-        ok = sn_panel<NR, RING>(row, rowT, lane) && ok;
-        if (dl) {
-#pragma unroll
-            for (int j = 0; j < Q; j++) DM[lane * LD + j] = row[j];
-#pragma unroll
-            for (int t = 0; t < NR; t++) yM[lane * 2 + t] = row[Q + t];
-        }
-        if (RING && lane < QT) {
-#pragma unroll
-            for (int j = 0; j < Q; j++) EM[lane * LD + j] = rowT[j];
-#pragma unroll
-            for (int t = 0; t < NR; t++) gT[lane * 2 + t] = rowT[Q + t];
-        }
-    }
-    if (hasT) {
-        __syncthreads();
-        sn_syrk(ATT, LDT, EM, LD, QT, wave, 4, lane);                        // T x T -= L(T, M) L(T, M)^T
-        __syncthreads();
-        if (wave == 0) {                                                     // T_1 = the first 30 rows of T, T_2 (<= 30 rows) rides as the coupling block
-            const int sl = lane - 32;
-            const bool dl = lane < Q, sub = sl >= 0 && sl < QT2;
-            const int r = dl ? lane : (sub ? Q + sl : 0);
-#pragma unroll
-            for (int j = 0; j < Q; j++) { const double v = ATT[(size_t)r * LDT + j]; row[j] = (dl || sub) ? v : 0.0; }
-#pragma unroll
-            for (int t = 0; t < NR; t++) { const double v = gT[r * 2 + t]; row[Q + t] = (dl || sub) ? v : 0.0; }
-            double none[Q + NR];
-            ok = sn_panel<NR, false>(row, none, lane) && ok;
-            if (dl || sub) {
-#pragma unroll
-                for (int j = 0; j < Q; j++) ATT[(size_t)r * LDT + j] = row[j];
-#pragma unroll
-                for (int t = 0; t < NR; t++) { if (dl) yT[r * 2 + t] = row[Q + t]; else gT[r * 2 + t] = row[Q + t]; }
+                for (int u = 0; u < PER; u++) { const int slot = ge[u] >= 0 ? (ge[u] & 0x3fffffff) : 0; gv[u] = S_val[(size_t)slot * BB + ((ge[u] & 0x40000000) ? ((go[u] >> 8) & 255) : (go[u] & 255))]; }
             }
-        }
-        if (QT2 > 0) {
-            __syncthreads();
-            sn_syrk(ATT + (size_t)Q * LDT + Q, LDT, ATT + (size_t)Q * LDT, LDT, QT2, wave, 4, lane);      // T_2 x T_2 -= L_21 L_21^T
-            __syncthreads();
-            if (wave == 0) {
-                const bool dl = lane < Q, real = lane < QT2;
+            if (st >= 1) {                                                   // the previous panel, row-major: Ldd | Lsd
+                double* wp = wk + (size_t)(st - 1) * wstep;
+                for (int e = ht; e < Q * Q; e += hn) { const int r = e / Q, j = e - r * Q; wp[r * LD + j] = Lp[j * CS + r]; wp[Q * LD + r * LD + j] = Lp[j * CS + 32 + r]; }
+            }
+            if (kind == 0) {
 #pragma unroll
-                for (int j = 0; j < Q; j++) { const double v = ATT[(size_t)(Q + (real ? lane : 0)) * LDT + Q + min(j, max(QT2 - 1, 0))]; row[j] = (real && j < QT2) ? v : ((dl && j == lane) ? 1.0 : 0.0); }
-#pragma unroll
-                for (int t = 0; t < NR; t++) { const double v = gT[(Q + (real ? lane : 0)) * 2 + t]; row[Q + t] = real ? v : 0.0; }
-                double none[Q + NR];
-                ok = sn_panel<NR, false>(row, none, lane) && ok;
-                if (dl) {                                                    // L_22 (identity padded) to a buffer of its own: Ldd is free now
-#pragma unroll
-                    for (int j = 0; j < Q; j++) Ldd[lane * LD + j] = row[j];
-#pragma unroll
-                    for (int t = 0; t < NR; t++) if (real) yT[(Q + lane) * 2 + t] = row[Q + t];
+                for (int u = 0; u < PER; u++) {
+                    const int g = u * hn + ht;
+                    if (g < 2 * NE) {
+                        const int which = g >= NE ? 1 : 0, idx = g - which * NE, i = idx / Q, j = idx - i * Q;
+                        if ((which ? tabB : tabA) != -3) (which ? Cn : Dn)[i * LD + j] = ge[u] == -1 ? 0.0 : (ge[u] == -2 ? ((go[u] >> 16) ? 1.0 : 0.0) : gv[u]);
+                    }
                 }
             }
         }
+        SN_WSTAMP(1);
+        lds_barrier();                                                       // B0: LTP / yP / the right-hand sides may be overwritten
+        if (w1) {
+            double* pLT = kind <= 1 ? LTP : EM;
+            if (tr && lane < QT) {
+#pragma unroll
+                for (int j = 0; j < Q; j++) pLT[lane * LD + j] = row[j];
+            }
+            double* py = kind <= 1 ? yP : (kind == 2 ? yM : (kind == 3 ? yT : yT + 2 * Q));
+            double* pgN = kind <= 1 ? gAll + (size_t)st * 2 * Q : gTb + 2 * Q;
+            const int nd = kind == 4 ? QT2 : Q, nsubg = kind <= 1 ? Q : (kind == 3 ? QT2 : 0);
+            if (lane < nd) {
+                const double rsl = fast_rcp(Lp[lane * CS + lane]);
+#pragma unroll
+                for (int t = 0; t < NR; t++) py[lane * 2 + t] = gr[t] * rsl;
+            } else if (sl >= 0 && sl < nsubg) {
+#pragma unroll
+                for (int t = 0; t < NR; t++) pgN[sl * 2 + t] = gr[t];
+            }
+            if (kind == 2 && hasT && lane < QT) {                           // T's right-hand side behind M: the T stages read it from LDS
+#pragma unroll
+                for (int t = 0; t < NR; t++) gTb[lane * 2 + t] = gT[t];
+            }
+        }
+        lds_barrier();                                                       // B1
+        SN_WSTAMP(2); SN_TSTAMP(4);
+        // ---- Schur updates on the matrix cores
+        int t0 = 0;
+        if (kind == 0) t0 = sn_syrk(Dn, LD, Lk + 32, 1, CS, Q, wave, 4, t0, lane);                                    // D(N_k) -= Lsd_k Lsd_k^T
+        if (hasT && kind <= 1 && st >= 1) {
+            t0 = sn_gemm_neg(Ebuf + (st & 1) * qtm * LD, LD, LTP, LD, 1, QT, Lp + 32, 1, CS, Q, wave, 4, t0, lane);   // E(T, P_st) = - L(T, P_st-1) Lsd_st-1^T
+            t0 = sn_syrk(ATT, LDT, LTP, LD, 1, QT, wave, 4, t0, lane);                                                 // T x T -= L(T, P_st-1) L(T, P_st-1)^T
+        }
+        if (hasT && kind == 2) t0 = sn_syrk(ATT, LDT, EM, LD, 1, QT, wave, 4, t0, lane);                               // T x T -= L(T, M) L(T, M)^T
+        if (kind == 3 && QT2 > 0) t0 = sn_syrk(ATT + (size_t)Q * LDT + Q, LDT, Lk + 32, 1, CS, QT2, wave, 4, t0, lane);   // T_2 x T_2 -= L_21 L_21^T
+        SN_WSTAMP(3);
+        lds_barrier();                                                       // B2
+        SN_WSTAMP(4); SN_TSTAMP(5);
+        if (kind == 0) cur = nxt;
     }
     if (wave == 0 && lane == 0 && !ok) *fail_flag = 1;
     __syncthreads();
-    // ---- back substitution: T_2, T_1, M, then this half's pivots from the last to the first; one wave
+    SN_STAMP(4);
+    double* LcM = Lcb + ((ns + 1) & 1) * Q * CS; double* LcT1 = Lcb + (ns & 1) * Q * CS;
+    double* EM = Ebuf + (ns & 1) * qtm * LD;
+    // ---- back substitution: T_2, T_1, M on wave 0 (from LDS); then this half's pivots from the last to the first, a wave per step in turn (sn_back_load / sn_back_step)
+    const int bpos = (wave + 3) & 3;                        // wave 1 takes the first pivot step, 2 the second, 3 the third, 0 the fourth, ...
+    SnBackRegs BR;
+    if (wave != 0 && bpos < ns) sn_back_load(BR, wk + (size_t)(ns - 1 - bpos) * wstep, qtm, QT, lane);
     if (wave == 0) {
         double x[NR];
         const int* mcams = node_cam + (size_t)hr[12] * CAPT;
         if (hasT) {
             if (QT2 > 0) {
-                sn_back<NR>(Ldd, LD, yT + 2 * Q, QT2, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, x, lane);
+                sn_back<NR>(LcT2, 1, CS, yT + 2 * Q, QT2, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, nullptr, x, lane);
                 if (lane < QT2) {
 #pragma unroll
                     for (int t = 0; t < NR; t++) xT[(Q + lane) * 2 + t] = x[t];
                 }
-                if (owner && lane < QT2) {
-                    const int i = Q + lane, a = i / DC, u = i - a * DC, cam = tcams[a];
-                    if (cam >= 0) {
-#pragma unroll
-                        for (int t = 0; t < NR; t++) Y[(size_t)t * ystride + (size_t)pos[cam] * DC + u] = x[t];
-                    }
-                }
+                if (owner) sn_store_y<DC, NR>(Y, ystride, tcams, pos, Q, QT2, x, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            sn_back<NR>(ATT, LDT, yT, Q, ATT + (size_t)Q * LDT, LDT, QT2, xT + 2 * Q, nullptr, 0, 0, nullptr, x, lane);
+            sn_back<NR>(LcT1, 1, CS, yT, Q, LcT1 + 32, 1, CS, QT2, xT + 2 * Q, nullptr, 0, 0, 0, nullptr, x, lane);
             if (lane < Q) {
 #pragma unroll
                 for (int t = 0; t < NR; t++) xT[lane * 2 + t] = x[t];
             }
-            if (owner) sn_store_y<DC, NR>(Y, ystride, tcams, pos, Q, x, lane);
+            if (owner) sn_store_y<DC, NR>(Y, ystride, tcams, pos, 0, Q, x, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        sn_back<NR>(DM, LD, yM, Q, nullptr, 0, 0, nullptr, EM, LD, QT, xT, x, lane);
+        sn_back<NR>(LcM, 1, CS, yM, Q, nullptr, 0, 0, 0, nullptr, EM, LD, 1, QT, xT, x, lane);
         if (lane < Q) {
 #pragma unroll
             for (int t = 0; t < NR; t++) xN[lane * 2 + t] = x[t];
         }
-        if (owner) sn_store_y<DC, NR>(Y, ystride, mcams, pos, Q, x, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int k = ns - 1; k >= 0; k--) {
-            const double* wp = wk + (size_t)k * wstep;
-            sn_back<NR>(wp, LD, wp + 2 * Q * LD + (size_t)qtm * LD, Q, wp + Q * LD, LD, Q, xN, wp + 2 * Q * LD, LD, QT, xT, x, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (owner) sn_store_y<DC, NR>(Y, ystride, mcams, pos, 0, Q, x, lane);
+        if (bpos < ns) sn_back_load(BR, wk + (size_t)(ns - 1 - bpos) * wstep, qtm, QT, lane);
+    }
+    lds_barrier();                                                           // x_M and x_T are in LDS
+    {
+        int done = 0;
+        for (int i = bpos; i < ns; i += 4) {
+            while (done < i) { lds_barrier(); done++; }                      // the other waves' steps
+            double x[NR];
+            sn_back_step<NR>(BR, QT, xN, xT, x, lane);
             if (lane < Q) {
 #pragma unroll
                 for (int t = 0; t < NR; t++) xN[lane * 2 + t] = x[t];
             }
-            sn_store_y<DC, NR>(Y, ystride, node_cam + (size_t)sr0[k * SN_SREC] * CAPT, pos, Q, x, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sn_store_y<DC, NR>(Y, ystride, node_cam + (size_t)sr0[(ns - 1 - i) * SN_SREC] * CAPT, pos, 0, Q, x, lane);
+            sn_back_load(BR, wk + (size_t)max(ns - 1 - (i + 4), 0) * wstep, qtm, QT, lane);      // this wave's next step (a harmless reload of step 0 when there is none)
+            lds_barrier(); done++;
         }
+        while (done < ns) { lds_barrier(); done++; }
     }
+    SN_STAMP(5);
+#undef SN_STAMP
+#undef SN_WSTAMP
+#undef SN_TSTAMP
 }
 
 }  // namespace ssfm

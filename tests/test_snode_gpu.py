@@ -106,3 +106,21 @@ def test_snode_failure_flag(gpu_ctx):
     d = [k for k in range(len(ci)) if ci[k] == 40 and rp[40] <= k < rp[41]][0]
     blk[d] -= np.eye(6) * 1e4
     assert ba.snode_solve_probe(gpu_ctx, 6, rp, ci, blk, rhs2)[1]["failed"] == 1
+
+
+@pytest.mark.parametrize("cams,spherical,focal_fixed", [(60, False, True), (60, True, False), (300, False, False), (300, False, True), (120, True, True)])
+def test_lm_loop_with_the_supernodal_solver_matches_the_oracle(gpu_ctx, oracle, monkeypatch, cams, spherical, focal_fixed):
+    """SSFM_SNODE=1: the LM loop's direct solve through k_snode_solve (opt-in, csrc/snode.h) -- same iteration count and the same answer as the oracle's
+    sparse Cholesky, one and two right-hand sides (free focal), 6- and 3-dof cameras, one ring (stride 1) and four interleaved rings (BASELINE config 2's ids)."""
+    from spherical_sfm_amd import ba, synth
+    monkeypatch.setenv("SSFM_SNODE", "1")
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = synth.make_circle(cams, cams * 40, 6, spherical=spherical, focal_fixed=focal_fixed)
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
+    oc, op, of, os_ = oracle.ba_solve(p)
+    assert s1["termination"] == os_["termination"] == 0 and s1["iterations"] == os_["iterations"]
+    assert np.abs(c1 - oc).max() <= 1e-5 * np.abs(oc).max() and abs(f1 - of) <= 1e-5 * of
+    assert (np.linalg.norm(p1 - op, axis=1) / np.linalg.norm(op, axis=1)).max() <= 1e-5
+    monkeypatch.setenv("SSFM_SNODE", "0")
+    c0, p0, f0, s0 = ba.optimize(gpu_ctx, p)                   # the band kernels on the same problem: two direct solvers, one answer
+    assert s0["iterations"] == s1["iterations"] and np.abs(c0 - c1).max() <= 1e-9 * np.abs(c0).max()
