@@ -112,6 +112,7 @@ struct BAFlat {
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
     int64_t gram_points = 0, gram_obs = 0;
     bool gram_sorted = false;               // the local points were re-ordered by camera-list signature (ba_flatten: signature sort)
+    bool gram_any = true;                   // SSFM_GRAM_ANY as read when the plan was made: every tile class in one k_schur_gram_any launch (the cost model below assumes what the launch then does)
 };
 constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3, GRAM_SUB_PTS = 8;      // GRAM_SUB_PTS = GRAM_SUB of ba_kernels.h (points per sub-chunk)
 
@@ -250,7 +251,10 @@ constexpr int BAND_CUT_MIN_ROWS = 512;            // below: twisted (two workgro
 // transposed: ring_wrap_table).  The separators form a CYCLE of m dense blocks of r DC unknowns -- half the size of the folded ones --, solved by cyclic reduction
 // (band_ring.h).  A component is laid out like this when it is long (or too wide for the LDS window when folded), periodic in camera-id order with a reach well
 // under the folded half-width, and its separator blocks fit the cyclic-reduction kernel (r DC <= RING_QMAX).  SSFM_RING=0 turns it off; SSFM_RING_CUTS=m forces m.
-constexpr int RING_QMAX = 78;                     // (3 Q + 2) (Q | 1) doubles of LDS in k_ring_cr_elim
+constexpr int RING_QMAX = 78;                     // (3 Q + 2) (Q | 1) doubles of LDS in k_ring_cr_elim: 149 KB at Q = 78, i.e. a 160 KB compute unit
+// LDS a workgroup may ask for on the device the plans are made for (ctx.hip sets it from hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KB on gfx950, the only target):
+// a ring whose cyclic-reduction blocks would not fit stays on the fold instead of failing in hipFuncSetAttribute at solve time
+inline bool ring_blocks_fit(int Q) { return (size_t)(3 * Q + 2) * (size_t)(Q | 1) * sizeof(double) <= plan_lds_limit(); }
 inline int ring_choose_cuts(int rows, int b) {
     if (const char* e = std::getenv("SSFM_RING_CUTS")) { const int m = std::atoi(e); if (m >= 2) return std::min(m, std::max(2, rows / (2 * b + 1))); }
     // A power of two: the cyclic reduction halves the cycle per step down to 2 separators, which one workgroup per ring finishes (band_ring.h), so m = 2 * 2^k costs k
@@ -359,7 +363,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         std::vector<int>& best = (ra <= rb) ? ids : unf;
         const int reach = std::min(ra, rb);
         if (std::getenv("SSFM_RING_DEBUG")) std::fprintf(stderr, "[ring] component %d: %d cameras, %d block rows, fold half-width %d, circular reach by id %d, unfolded %d\n", k, n, R, bk, ra, rb);
-        bool ok = reach >= 1 && reach * band_block <= RING_QMAX && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
+        bool ok = reach >= 1 && reach * band_block <= RING_QMAX && ring_blocks_fit(reach * band_block) && 5 * reach <= 3 * bk && R >= 2 * (2 * reach + 1) && reach <= 20;
         // short components with a band that the square LDS window holds: only when the measured cost model says so (long ones and wide ones: always)
         if (ok && R < BAND_CUT_MIN_ROWS && bk <= 20 && !(env_r && env_r[0] == '2') && !(ring_model_us(R, reach, reach * band_block) < fold_model_us(R, bk) + 5.0)) ok = false;   // SSFM_RING=2: whenever possible
         if (ok) { is_ring[k] = 1; seq_cm[k] = seq[k]; cb_cm[k] = bk; seq[k] = best; cb[k] = reach; }
@@ -370,7 +374,7 @@ inline void band_plan(int Nc, int dc, const std::vector<int>& row_ptr, const std
         band = merge ? 1 : 0;                                              // (6-dof: a graph without couplings keeps half-width 0, as before)
         for (int k = 0; k < ncomp; k++) band = std::max(band, cb[k]);
         int demote = -1;
-        for (int k = 0; k < ncomp; k++) if (is_ring[k] && (band * band_block > RING_QMAX || crows[k] < 2 * (2 * band + 1))) { demote = k; break; }
+        for (int k = 0; k < ncomp; k++) if (is_ring[k] && (band * band_block > RING_QMAX || !ring_blocks_fit(band * band_block) || crows[k] < 2 * (2 * band + 1))) { demote = k; break; }
         if (demote < 0) break;
         is_ring[demote] = 0; seq[demote].swap(seq_cm[demote]); cb[demote] = cb_cm[demote];
     }
@@ -854,6 +858,7 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
         const bool gram_on = !(std::getenv("SSFM_GRAM") && std::atoi(std::getenv("SSFM_GRAM")) == 0);                               // read per plan: tests switch it
         const int kmin = std::getenv("SSFM_GRAM_KMIN") ? std::max(2, std::atoi(std::getenv("SSFM_GRAM_KMIN"))) : GRAM_KMIN;
         const int min_run = std::getenv("SSFM_GRAM_MIN_RUN") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_MIN_RUN"))) : GRAM_MIN_RUN;       // shortest run that becomes a wave task
+        F.gram_any = knob_env_int("SSFM_GRAM_ANY", 1) != 0;                 // read once per plan: tests switch it between solves; the launch uses this value too
         const int gram_pts_env = std::getenv("SSFM_GRAM_PTS") ? std::max(8, std::atoi(std::getenv("SSFM_GRAM_PTS"))) : 0;           // points per wave task (0: by size)
         F.pt_grouped.resize((size_t)F.nP);
         if (F.nP > 0) std::memset(F.pt_grouped.data(), 0, (size_t)F.nP);
@@ -907,10 +912,10 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
                 // per point: 0.45 ns in the latency-bound regime of one round of tasks (config 2: 100k points, 45 us), 0.27 ns once a class fills the chip for several
                 // rounds (configs[4] size: 1.5 M points of 8 cameras, 391 us)
                 // round 5: the classes share ONE launch (k_schur_gram_any) unless SSFM_GRAM_ANY=0 -- the latency floor is paid once
-                const bool any_launch = knob_env_int("SSFM_GRAM_ANY", 1) != 0;       // read per plan: tests switch it
-                double est_gram = 0, v_all = 0;
-                for (double v : cls_pts) if (v > 0) { est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v); v_all += v; }
-                if (any_launch && v_all > 0) est_gram *= 0.75;     // measured: tracks 3 ... 8, 600k observations, 2336 tasks of ~47 points: 70 us in one launch against 4 x 23.6 (pair lists: 43 + 20)
+                const bool any_launch = F.gram_any;
+                double est_gram = 0; int n_cls = 0;
+                for (double v : cls_pts) if (v > 0) { est_gram += std::max(24.0, (v > 3e5 ? 0.27e-3 : 0.45e-3) * v); n_cls++; }
+                if (any_launch && n_cls > 1) est_gram *= 0.75;      // (only when several classes really share the launch: single-class problems run the specialised kernel)     // measured: tracks 3 ... 8, 600k observations, 2336 tasks of ~47 points: 70 us in one launch against 4 x 23.6 (pair lists: 43 + 20)
                 const double obs_all = (double)F.pt_start[F.nP];
                 const double est_loose = loose_pairs > 0 ? std::max(36.0, 22e-6 * loose_pairs) + std::max(20.0, 34.5e-6 * obs_all) : 0.0;
                 const double est_pairs_only = std::max(36.0, 22e-6 * all_pairs) + std::max(20.0, 34.5e-6 * obs_all);

@@ -218,7 +218,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
 #define SSFM_GRAM_LAUNCH(CLS_, NT_, TI_) SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, false)
 #endif
             int n_cls = 0; for (int c = 0; c < 5; c++) if (cls_end[c] > (c ? cls_end[c - 1] : 0)) n_cls++;
-            const bool gram_any = knob_env_int("SSFM_GRAM_ANY", 1) != 0;      // 0: one launch per tile class, one after the other (rounds 3-4)
+            const bool gram_any = F.gram_any;                                 // SSFM_GRAM_ANY as the PLAN read it (one value for the cost model and the launch; 0: one launch per tile class)
             bool any_ok = gram_any && n_cls > 1 && gram_waves == 1 && !gram_dbg;
 #ifdef SSFM_LAB
             any_ok = any_ok && !fuse_lin;
@@ -257,7 +257,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, probe_Y.p, probe_S.p);
         }
 #endif
-        if (h->det) det_decode(zone_ptrs(iteration & 1), true, DET_K_ASSEMBLY);     // limbs -> the zone's doubles (and cleared); the point pass's sums -> replica 0 of the scalar block
+        if (h->det) {
+            det_decode(zone_ptrs(iteration & 1), true, DET_K_ASSEMBLY);      // limbs -> the zone's doubles (and cleared); the point pass's sums -> replica 0 of the scalar block
+            SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, sizeof(long long), st));      // the poison word: read by every decode workgroup, cleared behind the launch
+        }
         if (ctx->collective) {
             // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
             hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->red_scal, ctx->rank);
@@ -559,8 +562,8 @@ extern "C" int ssfm_snode_solve_probe(ssfm_ctx* ctx, int32_t dc, int32_t Nc, con
             std::vector<long long> hs((size_t)h->sn.nhalf * 64); SSFM_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), dst.p, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, st)); SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             long long t00 = hs[0]; for (int b = 0; b < h->sn.nhalf; b++) t00 = std::min(t00, hs[(size_t)b * 64]);
             for (int b = 0; b < h->sn.nhalf; b++) { const long long* q = &hs[(size_t)b * 64];
-                std::fprintf(stderr, "[snode] wg %d (%d steps): start +%lld | prologue %lld | elimination %lld | exchange %lld | M,T %lld | back %lld | total %lld ticks\n", b, h->sn.half_rec[(size_t)b * SN_HREC],
-                             q[0] - t00, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+                std::fprintf(stderr, "[snode] wg %d (%d steps): start +%lld | prologue %lld | elimination %lld | exchange %lld | M,T %lld | back %lld (T, M %lld) | total %lld ticks\n", b, h->sn.half_rec[(size_t)b * SN_HREC],
+                             q[0] - t00, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[4], q[5] - q[0]);
                 if (b < 2) { const long long* u0 = q + 40; const long long* u1 = q + 48;
                     std::fprintf(stderr, "        stage M: panel (wave 0) %lld | barrier %lld | T rows + rhs (wave 1) %lld | outputs + barriers %lld | tiles + barrier %lld | the T stages %lld\n",
                                  u0[1] - u0[0], u0[2] - u0[1], u1[3] - u1[2], u0[4] - u1[3], u0[5] - u0[4], q[4] - u0[5]); }

@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "ssfm_ctx.h"
+#include "knobs.h"
 
 namespace ssfm { std::string g_last_error; }
 using namespace ssfm;
@@ -28,6 +29,7 @@ extern "C" int ssfm_ctx_create(int32_t device, void* stream, ssfm_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds >= 64 * 1024) ssfm::plan_lds_limit() = (size_t)lds; }      // what the planners may ask for (ba_flatten.h)
     *out = c;
     return SSFM_OK;
 }

@@ -5,9 +5,12 @@
 // Here every addend is converted to FIXED POINT first and added with 64-bit INTEGER atomics, which are exact and therefore commute:
 //
 //   * matrix / vector accumulators (zadd): two limbs per entry, value = hi 2^-22 + lo 2^-74.  |addend| < 2^40; up to 2^11 addends per entry without overflow of
-//     the low limb (|lo| <= 2^51 each), far more in the high one.  The split of an addend is exact down to 2^-74 = 5e-23 ABSOLUTE -- the Jacobi-scaled system has
-//     entries of order 1, so a sum carries ~20 bits more than a double accumulator would.  An addend that is not finite or not below 2^42 bumps a poison word and
-//     the decoded entry becomes NaN (what the floating-point sum would have propagated: the factorisation then fails and the LM loop rejects the step).
+//     the low limb (|lo| <= 2^51 each); the high limb holds |addend| 2^22 < 2^62 per addend, so the SUM of an entry (not only each addend) has to stay below 2^41
+//     (a 64-bit integer of units 2^-22) -- orders of magnitude above anything the Jacobi-scaled system holds, and checked by tests/native/det_acc_check.cpp.  The split of an addend is exact down to 2^-74 = 5e-23 ABSOLUTE -- the Jacobi-scaled system has
+//     entries of order 1, so a sum carries ~20 bits more than a double accumulator would.  An addend that is not finite or not below 2^40 bumps a poison word and
+//     every entry of THAT assembly decodes to NaN (what the floating-point sum would have propagated: the factorisation then fails and the LM loop rejects the step);
+//     the word is cleared behind the decode launch (ba_solver.hip), so one poisoned assembly does not condemn the rest of the solve.  Without Jacobi scaling and
+//     with a focal length of thousands of pixels an addend can exceed 2^40 where the fp64 path would still succeed: the mode is meant for the default scaling.
 //   * scalars (lacc_add): costs and norms span hundreds of binary orders of magnitude over a solve, so they get a LONG accumulator: seven limbs of 40 bits,
 //     limb j in units of 2^(-180 + 40 j); an addend touches the <= 3 limbs its 53 bits overlap.  Exact for 2^-180 <= |v| < 2^100, 2^23 addends per limb.
 //

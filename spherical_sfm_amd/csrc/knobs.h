@@ -10,9 +10,12 @@
 // their defaults in and does not contain the rejected kernels; `make lab` builds libssfm_hip_lab.so with -DSSFM_LAB, where every one of them is live again
 // (Python: SSFM_LIB_PATH=spherical_sfm_amd/libssfm_hip_lab.so).  SSFM_LAB_KNOB(name, default) is the value, read once per call site.
 #pragma once
+#include <cstddef>
 #include <cstdlib>
 
 namespace ssfm {
+// LDS bytes a workgroup may ask for on the device the plans are made for: 160 KB on gfx950 (the only target); ssfm_ctx_create overwrites it with the device's attribute
+inline size_t& plan_lds_limit() { static size_t v = 160 * 1024; return v; }
 inline int knob_env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
 }  // namespace ssfm
 

@@ -847,6 +847,7 @@ k_snode_solve(const double* __restrict__ S_val, const double* __restrict__ rhs, 
         if (bpos < ns) sn_back_load(BR, wk + (size_t)(ns - 1 - bpos) * wstep, qtm, QT, lane);
     }
     lds_barrier();                                                           // x_M and x_T are in LDS
+    SN_STAMP(6);
     {
         int done = 0;
         for (int i = bpos; i < ns; i += 4) {
