@@ -34,10 +34,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy bandwidth of the box is MEASURED in every run (hbm_copy_GBs, ssfm_debug_copy_bandwidth)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 x 2.4 GHz)
-PMC_PROFILE = os.path.join("profiles", "r05z_pmc_traffic.json")   # committed rocprofv3 --pmc summary (scripts/gpu_final_r05.sh + collect_final_r05.py) the traffic / VALU figures are read from
-if not os.path.exists(os.path.join(ROOT, PMC_PROFILE)):
-    PMC_PROFILE = os.path.join("profiles", "r05s_pmc_traffic.json")
-ROCPROF_STATS = os.path.join("profiles", "r05z_rocprofv3_kernel_stats.csv")   # committed rocprofv3 --kernel-trace --stats summary of the same command: launch durations without the event brackets' hand-over
+
+
+def _pick_profiles():
+    """the committed rocprofv3 summaries this run quotes (scripts/gpu_final.sh + collect_final.py + pmc_summary.py): the PMC file whose recorded kernel-source digest
+    equals today's, else the newest by tag (bench.py then prints pmc_stale = true); the kernel-stats file and the Retriangulate counters of the same tag"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    pick = None
+    for c in cands:
+        try:
+            if (json.load(open(c)).get("_meta") or {}).get("kernel_source_sha16") == kernel_source_digest():
+                pick = c
+        except Exception:
+            pass
+    if pick is None and cands:
+        pick = cands[-1]
+    if pick is None:
+        return os.path.join("profiles", "none_pmc_traffic.json"), os.path.join("profiles", "none_rocprofv3_kernel_stats.csv"), None
+    tag = os.path.basename(pick).split("_")[0]
+    retri = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_retriangulate.json")))
+    return os.path.relpath(pick, ROOT), os.path.join("profiles", f"{tag}_rocprofv3_kernel_stats.csv"), (os.path.relpath(retri[-1], ROOT) if retri else None)
 
 
 def kernel_source_digest():
@@ -50,6 +67,9 @@ def kernel_source_digest():
         if f.endswith((".h", ".hip")) and not f.startswith(("ransac", "lomsac", "retriangulate", "sampson", "rotavg", "line_search")):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+PMC_PROFILE, ROCPROF_STATS, PMC_RETRI = _pick_profiles()
 
 
 def rocprof_avg_us():
@@ -420,7 +440,7 @@ def side_paths(ctx):
     nz = Xo.any(1)
     pmc_r = {}
     try:
-        pmc_r = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_retriangulate.json")))
+        pmc_r = json.load(open(os.path.join(ROOT, PMC_RETRI)))
     except Exception:
         pass
     res["retriangulate"] = {

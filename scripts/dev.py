@@ -14,9 +14,11 @@ parity / debugging
   sub [dc b rows P]   the band solver probe against numpy, stage by stage
   ransac, trace, trace_mismatch, lsq_replay   pairwise LO-MSAC: batch vs oracle, where a reference-trace run leaves the oracle's
   retri, tri_bits Retriangulate vs the oracle; which bits of DLT / score / least squares differ
-other scripts of round 4 (scripts/): soak_band_solver.py (randomised soak of the substructured solver against numpy), sweep_segments_r04.sh (SSFM_BAND_SEGMENTS sweep at the
-configs[4] size and on the large pose graphs), prof_rot_rocprof.sh (rocprofv3 kernel stats of optimize_rotations), gpu_final_r04.sh + collect_final_r04.py (the final measurement pass),
-lab/ldl16_lab.hip (16x16 factor-and-invert: lane per row vs matrix cores), lab/syrk_lab.hip (the chain's rank-Q update alone), lab/ab_*.sh (same-run A/B of an environment switch)
+other scripts (scripts/): gpu_final.sh + collect_final.py + pmc_summary.py (the final measurement pass: rocprofv3 stats, PMC passes, bench lines -> profiles/), gpu_retry.sh (retry a
+gpurun call while the pod's slots are busy), bench_pairwise.py (configs[3] pairwise RANSAC), prof_gram_*.py / prof_irregular.py / prof_retri.py / prof_rot.py (single-workload
+profiling drivers named in DESIGN.md and the profiles/ notes), soak_*.py (randomised soaks: band solver vs numpy, repeated BA solves, Gram fuzz, Retriangulate trace),
+build_gram_ld_variants.sh (library variants for SSFM_LIB_PATH), r06/ab.sh (same-run A/B of environment settings at config 2), r06/snode_stamps.py (phase stamps of k_snode_solve),
+r06/reflow_md.py (Markdown reflow to 160 columns), lab/ (kernel labs and A/B scripts of rounds 2-5: chol_lab, ldl16_lab, syrk_lab, point_lab, ab_*.sh)
 """
 import os
 import runpy

@@ -13,6 +13,9 @@ struct RelativeRotation {
 
 double optimize_rotations(std::vector<Mat3>& rotations, const std::vector<RelativeRotation>& relative_rotations);
 
+#ifdef SSFM_WITH_EIGEN
+#include <Eigen/Core>       // (named here, not only through sfm.h: ADVICE r5)
+#endif
 #ifdef SSFM_WITH_EIGEN      // the reference's own signature (rotation_averaging.h:9-16); not compiled in this image (no Eigen), see sfm.h
 inline Mat3 mat3_from_eigen(const Eigen::Matrix3d& M) { Mat3 m; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) m[i + 3 * j] = M(i, j); return m; }
 inline Eigen::Matrix3d mat3_to_eigen(const Mat3& m) { Eigen::Matrix3d M; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) M(i, j) = m[i + 3 * j]; return M; }

@@ -18,7 +18,7 @@
 #include <vector>
 #include "../../../include/ssfm.h"
 // SSFM_WITH_EIGEN (SURVEY 8b "Build constraint"; reference include/sphericalsfm/sfm.h:4-13, sfm_types.h:3-29): a maintainer who HAS Eigen defines it and the
-// PODs below convert to and from the Eigen types of the reference's signatures implicitly -- sfm.AddPoint(Eigen::Vector3d(...)), Eigen::Vector3d X = sfm.GetPoint(j),
+// PODs below convert to and from the Eigen types of the reference's signatures implicitly -- sfm.AddPoint(Eigen::Vector3d(...)), Eigen::Vector3d X(sfm.GetPoint(j)) / sfm.GetPoint(j).eigen() (POD -> Eigen is explicit),
 // Pose(Eigen::Vector3d t, Eigen::Vector3d r), pose.P() -- so a caller written against the reference's headers compiles against these.  Eigen is not in this
 // image: this block is written from Eigen's documented interface and has NOT been compiled here (INTEGRATION.md says so too).
 #ifdef SSFM_WITH_EIGEN
@@ -32,8 +32,9 @@ struct Vec3 {
     Vec3() : v{0, 0, 0} {}
     Vec3(double x, double y, double z) : v{x, y, z} {}
 #ifdef SSFM_WITH_EIGEN
-    Vec3(const Eigen::Vector3d& e) : v{e(0), e(1), e(2)} {}
-    operator Eigen::Vector3d() const { return Eigen::Vector3d(v[0], v[1], v[2]); }
+    Vec3(const Eigen::Vector3d& e) : v{e(0), e(1), e(2)} {}                                 // Eigen -> POD implicit (arguments of AddPoint, SetPoint, Pose(...))
+    explicit operator Eigen::Vector3d() const { return Eigen::Vector3d(v[0], v[1], v[2]); }   // POD -> Eigen explicit: one implicit direction only, so that mixed expressions are not ambiguous
+    Eigen::Vector3d eigen() const { return Eigen::Vector3d(v[0], v[1], v[2]); }
 #endif
     double& operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
@@ -49,7 +50,8 @@ struct Observation {
     Observation(double _x, double _y) : x(_x), y(_y) {}
 #ifdef SSFM_WITH_EIGEN                    // typedef Eigen::Vector2d Observation, sfm_types.h:12
     Observation(const Eigen::Vector2d& e) : x(e(0)), y(e(1)) {}
-    operator Eigen::Vector2d() const { return Eigen::Vector2d(x, y); }
+    explicit operator Eigen::Vector2d() const { return Eigen::Vector2d(x, y); }
+    Eigen::Vector2d eigen() const { return Eigen::Vector2d(x, y); }
     double operator()(int i) const { return i == 0 ? x : y; }
 #endif
 };

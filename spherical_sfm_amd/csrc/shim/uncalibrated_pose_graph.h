@@ -9,6 +9,9 @@ double get_cost(std::vector<Mat3>& rotations, const std::vector<RelativeRotation
 double optimize_rotations_and_focal_length(std::vector<Mat3>& rotations, const std::vector<RelativeRotation>& relative_rotations, double& focal_length,
                                            const double min_focal, const double max_focal, const double focal_guess, bool inward);
 
+#ifdef SSFM_WITH_EIGEN
+#include <Eigen/Core>       // (named here, not only through sfm.h: ADVICE r5)
+#endif
 #ifdef SSFM_WITH_EIGEN      // the reference's own signatures (uncalibrated_pose_graph.h:8-19); not compiled in this image (no Eigen), see sfm.h
 inline double get_cost(std::vector<Eigen::Matrix3d>& rotations, const std::vector<RelativeRotationEigen>& relative_rotations) {
     std::vector<Mat3> R; R.reserve(rotations.size());

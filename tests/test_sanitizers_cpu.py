@@ -38,6 +38,21 @@ def test_mirror_containers_under_sanitizers(tmp_path):
     assert "runtime error" not in run.stderr
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/include/sphericalsfm/sparse.hpp"), reason="the reference tree is only in the build container")
+def test_mirror_containers_against_the_references_own_sparse_hpp(tmp_path):
+    """VERDICT r5 #7b: the same harness with the REFERENCE's SparseVector / SparseMatrix (include/sphericalsfm/sparse.hpp: std-only, compiled as it stands from
+    /root/reference, nothing copied) as the yardstick for the point table and the observation table, on the operations src/sfm.cpp uses.  ASan + UBSan."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_maps_vs_reference")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-DSSFM_REF_SPARSE", "-I/root/reference/include",
+                         os.path.join(ROOT, "tests", "native", "shim_maps_sanitize.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "SHIM_VS_REFERENCE_SPARSE_OK" in run.stdout and "SHIM_MAPS_OK" in run.stdout, (run.stdout + run.stderr)[-3000:]
+    assert "runtime error" not in run.stderr
+
+
 def test_ring_schedule_against_a_dense_solve_under_sanitizers(tmp_path):
     """Cyclic-reduction schedule of the ring-native reduced solve (csrc/ring_schedule.h; kernels: band_ring.h): the records are replayed with dense loops exactly as the
     kernels read them -- gathered pending updates, couplings from Z or as products of stored F blocks, back substitution in reverse step order -- on random SPD cyclic
