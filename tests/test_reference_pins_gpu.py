@@ -64,7 +64,7 @@ _KW = dict(use_poly="use_poly_solver", max_iterations="max_num_iterations", min_
 def test_lomsac_trace_equals_the_reference_ransaclib_runs(gpu_ctx):
     g = np.load(os.path.join(GOLD, "ref_ransaclib.npz")); m = _fixture_module()
     ptr = g["pair_ptr"]
-    plain, lo = [], []
+    plain, lo, parting = [], [], []
     for k in range(len(g["pair_seed"])):
         kw = dict(m.PAIR_CASES[g["pair_case"][k]][4])
         dev = {_KW.get(a, a): (int(b) if isinstance(b, (bool, np.bool_)) else b) for a, b in kw.items()}
@@ -77,10 +77,15 @@ def test_lomsac_trace_equals_the_reference_ransaclib_runs(gpu_ctx):
         #  its answer is set by the Levenberg-Marquardt damping alone -- there the trace, the inlier flags and the score are the statement)
         close = (not same) or g["pair_num_inliers"][k] == 0 or len(u) <= 5 or _sign_dist(out["E"][0], g["pair_E"][k]) <= 1e-8
         (lo if dev["num_lo_steps"] > 0 else plain).append(same and close)
+        if dev["num_lo_steps"] > 0 and not (same and close):
+            parting.append(k)
         if dev["num_lo_steps"] == 0:
             assert same and close, (k, kw, out["iterations"][0], g["pair_iterations"][k], out["num_inliers"][0], g["pair_num_inliers"][k])
     print("estimate_pairwise-style options: %d / %d identical; with in-loop local optimisation: %d / %d" % (sum(plain), len(plain), sum(lo), len(lo)))
-    assert all(plain) and np.mean(lo) >= 0.85
+    # round 6 (VERDICT r5 #7a): the runs with in-loop local optimisation that leave the reference's are LISTED, not bounded by a rate: of the 36 such runs one does --
+    # run 4 (500 correspondences, 100 iterations: 337 against 338 inliers after an ill-conditioned non-minimal solve picked the other of two near-equal candidates).
+    # A second parting run is a regression; run 4 starting to agree is welcome (scripts/r06/list_parting.py prints the list).
+    assert all(plain) and set(parting) <= {4}, parting
 
 
 def test_retriangulate_trace_equals_the_reference_ransaclib_runs(gpu_ctx):
