@@ -112,8 +112,17 @@ struct BAFlat {
     raw_vector<unsigned char> pt_grouped;   // [nP] 1 = handled by a signature group
     int64_t gram_points = 0, gram_obs = 0;
     bool gram_sorted = false;               // the local points were re-ordered by camera-list signature (ba_flatten: signature sort)
+    // Round 6 -- atomics-free emission of k_schur_gram when EVERY point sits in a signature group (the circle workloads): task t writes its K (K + 1) / 2 blocks and its
+    // cameras' vectors with plain stores into its own stretch of a partial buffer (gpart_off[t]; layout: gram_part_* below) and k_finalize_gather folds, per row of S,
+    // the partial blocks of every slot in a FIXED order (fold_slot_*).  No atomics, no clears, the same bits every run.
+    std::vector<int> gpart_off;             // [tasks + 1] offset of every task's stretch in doubles
+    std::vector<int> fold_slot_ptr, fold_slot_src;      // fold_slot_src: [Nc][GRAM_FOLD_STRIDE] one table per camera row (sources, first source of every extended slot, the sources' offsets); fold_slot_ptr: unused
     bool gram_any = true;                   // SSFM_GRAM_ANY as read when the plan was made: every tile class in one k_schur_gram_any launch (the cost model below assumes what the launch then does)
 };
+// a task's partial stretch: [K (K + 1) / 2 blocks of DC x DC, block (a, b), b <= a, at a (a + 1) / 2 + b, off-diagonal ones in the orientation S stores][K x (diag U | rhs 1 | rhs 2 | Jc^T r | S_fc) of DC each]
+inline int gram_part_blocks(int K) { return K * (K + 1) / 2; }
+inline int gram_part_len(int K, int DC) { return gram_part_blocks(K) * DC * DC + K * 5 * DC; }
+constexpr int GRAM_FOLD_PTRS = 31, GRAM_FOLD_HEAD = 32, GRAM_FOLD_SRCS = 128, GRAM_FOLD_STRIDE = GRAM_FOLD_HEAD + GRAM_FOLD_SRCS;      // the fold table of one camera row: <= 29 blocks + the vectors, <= 128 sources
 constexpr int GRAM_KMAX = 8, GRAM_NPAIR = 28, GRAM_REC = 48, GRAM_MIN_RUN = 32, GRAM_KMIN = 3, GRAM_SUB_PTS = 8;      // GRAM_SUB_PTS = GRAM_SUB of ba_kernels.h (points per sub-chunk)
 
 // fork-join over [0, n) in T contiguous chunks; f(thread index, begin, end).  The planner's loops over cameras / points are independent
@@ -978,6 +987,56 @@ inline void ba_flatten(const ssfm_ba_problem& P, int nranks, int rank, BAFlat& F
     }
     if (timing) std::fprintf(stderr, "[plan] signature groups: %lld of %d points in %zu tasks\n", (long long)F.gram_points, F.nP, F.gr_rec.size() / GRAM_REC);
     lap("signature groups");
+    // ---- fold lists of the atomics-free Gram emission: only when the signature groups hold every point (otherwise the pair kernels add into the same accumulators).
+    // One list per "extended slot": the slots of row c keep their order and the row gets one more entry behind them for the camera's vectors -- extended id of slot s
+    // of row c = s + c, of the vectors of camera c = row_ptr[c + 1] + c -- so that everything k_finalize_gather's workgroup c folds is ONE contiguous stretch of sources.
+    F.gpart_off.clear(); F.fold_slot_ptr.clear(); F.fold_slot_src.clear();
+    if (F.nP > 0 && F.gram_points == (int64_t)F.nP && F.cs_task_cam.empty()) {
+        const int ng = (int)(F.gr_rec.size() / GRAM_REC), DC = F.DC, BB = DC * DC;
+        const size_t nnzb = F.col_idx.size(), next = nnzb + Nc;
+        std::vector<int> row_of(nnzb); for (int c = 0; c < Nc; c++) for (int e = F.row_ptr[c]; e < F.row_ptr[c + 1]; e++) row_of[e] = c;
+        auto ext_slot = [&](int sl) { return sl + row_of[sl]; };
+        auto ext_cam = [&](int c) { return F.row_ptr[c + 1] + c; };
+        F.gpart_off.assign(ng + 1, 0);
+        std::vector<int> cnt(next + 1, 0);
+        int64_t tot = 0;
+        for (int t = 0; t < ng; t++) {
+            const int* rec = &F.gr_rec[(size_t)t * GRAM_REC]; const int K = rec[2];
+            F.gpart_off[t] = (int)tot; tot += gram_part_len(K, DC);
+            for (int a = 0; a < K; a++) { cnt[ext_slot(rec[40 + a]) + 1]++; cnt[ext_cam(rec[4 + a]) + 1]++; for (int b2 = 0; b2 < a; b2++) cnt[ext_slot(rec[12 + a * (a - 1) / 2 + b2] & 0x3fffffff) + 1]++; }
+        }
+        F.gpart_off[ng] = (int)tot;
+        bool fits = tot < ((int64_t)1 << 30);
+        for (size_t e = 0; e < next; e++) cnt[e + 1] += cnt[e];
+        for (int c = 0; c < Nc && fits; c++) {
+            const int x0 = F.row_ptr[c] + c, nx = F.row_ptr[c + 1] - F.row_ptr[c] + 1;
+            if (nx + 1 > GRAM_FOLD_PTRS || cnt[x0 + nx] - cnt[x0] > GRAM_FOLD_SRCS) fits = false;      // a row with more blocks / more sources than the fixed table holds
+        }
+        if (fits) {
+            // one fixed-stride table per camera row, so that k_finalize_gather's workgroup c needs ONE round of index loads (no row_ptr -> list pointer -> list chain):
+            // [0] sources  [1 .. 1 + GRAM_FOLD_PTRS) first source of every extended slot of the row, relative to the row's first  [GRAM_FOLD_HEAD ..) the sources' offsets
+            F.fold_slot_ptr.clear();
+            F.fold_slot_src.assign((size_t)Nc * GRAM_FOLD_STRIDE, 0);
+            std::vector<int> flat(cnt[next], 0), cur(cnt.begin(), cnt.end() - 1);
+            for (int t = 0; t < ng; t++) {                                    // tasks in order: the fold adds in task order
+                const int* rec = &F.gr_rec[(size_t)t * GRAM_REC]; const int K = rec[2], base = F.gpart_off[t], vb = base + gram_part_blocks(K) * BB;
+                for (int a = 0; a < K; a++) {
+                    flat[cur[ext_slot(rec[40 + a])]++] = base + (a * (a + 1) / 2 + a) * BB;
+                    flat[cur[ext_cam(rec[4 + a])]++] = vb + a * 5 * DC;
+                    for (int b2 = 0; b2 < a; b2++) flat[cur[ext_slot(rec[12 + a * (a - 1) / 2 + b2] & 0x3fffffff)]++] = base + (a * (a + 1) / 2 + b2) * BB;
+                }
+            }
+            for (int c = 0; c < Nc; c++) {
+                int* row = &F.fold_slot_src[(size_t)c * GRAM_FOLD_STRIDE];
+                const int x0 = F.row_ptr[c] + c, nx = F.row_ptr[c + 1] - F.row_ptr[c] + 1, q0 = cnt[x0];
+                row[0] = cnt[x0 + nx] - q0;
+                for (int j = 0; j <= nx; j++) row[1 + j] = cnt[x0 + j] - q0;
+                for (int j = nx + 1; j < GRAM_FOLD_PTRS; j++) row[1 + j] = row[1 + nx];
+                for (int q = 0; q < row[0]; q++) row[GRAM_FOLD_HEAD + q] = flat[q0 + q];
+            }
+        } else F.gpart_off.clear();
+    }
+    lap("fold lists");
     // ---- Schur pair lists, grouped by (row camera, slot), padded to 64-entry batches
     if (host_pairs) {
         std::vector<int> slot_cnt; pair_counts_host(F, NT, slot_cnt);

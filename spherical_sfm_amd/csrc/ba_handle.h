@@ -110,6 +110,8 @@ struct ssfm_ba_handle {
     // set by the LM loop for the next solve_reduced call: the candidate cameras are produced by the arrow kernel (k_arrow_update)
     struct { bool on = false, residual_later = false; const double *cam = nullptr, *focal = nullptr; double *cam_c = nullptr, *focal_c = nullptr, *rot_c = nullptr; } tail;
     DevBuf<int> gr_rec; DevBuf<unsigned char> pt_grouped;     // signature groups of k_schur_gram (ba_flatten.h)
+    // atomics-free Gram emission (round 6): the tasks' partial blocks / vectors and the fold lists of k_finalize_gather; gram_fold = the path is in use
+    DevBuf<double> gram_part; DevBuf<int> gpart_off, fold_slot_ptr, fold_slot_src; bool gram_fold = false;
     DevBuf<int> pub_ticket;              // arrival counter of the fused hand-over in k_point_backsub (zero between launches)
     int pcg_prev_iters = 16;
     bool external_tail = false;          // the caller runs its own focal arrow / residual check after the direct solve (rotavg_solver.hip: k_rot_step, k_rot_eval)
@@ -142,6 +144,7 @@ struct ssfm_ba_handle {
         col_pos.free(); trans_pos.free(); trans_ptr.free(); trans_blk.free(); trans_row.free(); pair_j.free(); pair_j2.free(); pair_p.free(); batch_slot.free(); cam_batch_ptr.free(); chunk_cam.free(); chunk_b0.free(); chunk_b1.free(); cam_obs_pt.free(); cs_task_cam.free(); cs_task_q0.free(); cs_task_q1.free();
         if (zone_views) { scal.p = nullptr; pcg.p = nullptr; redbuf.p = nullptr; zone_views = false; }
         pub_ticket.free(); gr_rec.free(); pt_grouped.free();
+        gram_part.free(); gpart_off.free(); fold_slot_ptr.free(); fold_slot_src.free(); gram_fold = false;
         sn_half.free(); sn_step.free(); sn_node.free(); sn_tab.free(); sn_flags.free(); sn_work.free(); sn_xchg.free(); sn.enabled = false;
         wrap_ptr.free(); wrap_blk.free(); wrap_row2.free(); ring_rec.free(); ring_tail.free(); crL.free(); crF.free(); crW.free(); crP.free(); crT.free(); crE.free();
         zone.free(); redbuf.free(); Minv.free(); Sff.free(); px.free(); pr.free(); pz.free(); pp.free(); pq.free(); pqpart.free(); scal.free(); pcg.free();

@@ -73,9 +73,12 @@ k_det_decode(double* __restrict__ zone, long long* __restrict__ limb, size_t n, 
         long long* a = lacc + ((size_t)lane * SC_TOTAL + k) * LA_STRIDE;
         long long tot[LA_STRIDE];
 #pragma unroll
+        for (int j = 0; j < LA_STRIDE; j++) tot[j] = a[j];                        // (all limbs in flight before the first clear: see publish_body)
+#pragma unroll
+        for (int j = 0; j < LA_STRIDE; j++) if (tot[j] != 0) a[j] = 0;
+#pragma unroll
         for (int j = 0; j < LA_STRIDE; j++) {
-            long long v = a[j];
-            if (v != 0) a[j] = 0;
+            long long v = tot[j];
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);          // integer sums: exact, any order
             tot[j] = v;
@@ -915,6 +918,9 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
     // to LDS (sU[k][DC x DC], over sY: the tiles are done) and rides with the Gram diagonal of its camera: one atomic per entry of a diagonal block, not two
     wave_lds_handover();
     double* sU = sYw;
+    // atomics-free emission (round 6, det_acc.h: DetZone::part): this task's stretch of the partial buffer -- blocks, then the cameras' vectors
+    double* const PB = dz.part ? dz.part + dz.part_off[task] : nullptr;
+    double* const PV = PB ? PB + (K * (K + 1) / 2) * BB : nullptr;
     {
         double out[NO];
         OctTR<NS, 4>::run(sm, out);
@@ -931,10 +937,10 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                     const int b = a + rem;
                     const double w = v * sc[a] * sc[b];
                     sU[lq * BB + a * DC + b] = w;
-                    if (b != a) sU[lq * BB + b * DC + a] = w; else zadd(dz, &Udiag[c * DC + a], w);
-                } else if (i < NU + DC) { const int a = i - NU; zadd(dz, &rhs[c * DC + a], v * sc[a]); zadd(dz, &gcraw[c * DC + a], v * sc[a]); }
-                else if (i < NU + 2 * DC) { const int a = i - NU - DC; zadd(dz, &rhs[c * DC + a], v * sc[a]); }
-                else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; zadd(dz, &Sfc[c * DC + a], v * sc[a]); }
+                    if (b != a) sU[lq * BB + b * DC + a] = w; else if (PV) PV[lq * 5 * DC + a] = w; else zadd(dz, &Udiag[c * DC + a], w);
+                } else if (i < NU + DC) { const int a = i - NU; if (PV) { PV[lq * 5 * DC + DC + a] = v * sc[a]; PV[lq * 5 * DC + 3 * DC + a] = v * sc[a]; } else { zadd(dz, &rhs[c * DC + a], v * sc[a]); zadd(dz, &gcraw[c * DC + a], v * sc[a]); } }
+                else if (i < NU + 2 * DC) { const int a = i - NU - DC; if (PV) PV[lq * 5 * DC + 2 * DC + a] = v * sc[a]; else zadd(dz, &rhs[c * DC + a], v * sc[a]); }
+                else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; if (PV) PV[lq * 5 * DC + 4 * DC + a] = v * sc[a]; else zadd(dz, &Sfc[c * DC + a], v * sc[a]); }
             }
         }
     }
@@ -954,13 +960,13 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                     const double v = -acc[tix][reg] * sScale[R] * sScale[C];
                     if (b < a) {
                         const int sl = sSlot[a * (a - 1) / 2 + b];
-                        double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
-                        zadd(dz, &blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                        const int e = (sl & (1 << 30)) ? (db * DC + da) : (da * DC + db);
+                        if (PB) PB[(a * (a + 1) / 2 + b) * BB + e] = v;
+                        else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[e], v);
                     } else {                                            // diagonal block of camera a: a diagonal tile holds both triangles, a tile below the diagonal only (da > db)
-                        double* blk = S_val + (size_t)sDiag[a] * BB;
                         const double w = v + sU[a * BB + da * DC + db];
-                        zadd(dz, &blk[da * DC + db], w);
-                        if (ti != tj) zadd(dz, &blk[db * DC + da], w);
+                        if (PB) { double* blk = PB + (a * (a + 1) / 2 + a) * BB; blk[da * DC + db] = w; if (ti != tj) blk[db * DC + da] = w; }
+                        else { double* blk = S_val + (size_t)sDiag[a] * BB; zadd(dz, &blk[da * DC + db], w); if (ti != tj) zadd(dz, &blk[db * DC + da], w); }
                     }
                 }
             }
@@ -977,13 +983,13 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                 const double v = -tacc[u] * sScale[R] * sScale[C];
                 if (b < a) {
                     const int sl = sSlot[a * (a - 1) / 2 + b];
-                    double* blk = S_val + (size_t)(sl & 0x3fffffff) * BB;
-                    zadd(dz, &blk[(sl & (1 << 30)) ? (db * DC + da) : (da * DC + db)], v);
+                    const int e = (sl & (1 << 30)) ? (db * DC + da) : (da * DC + db);
+                    if (PB) PB[(a * (a + 1) / 2 + b) * BB + e] = v;
+                    else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[e], v);
                 } else {
-                    double* blk = S_val + (size_t)sDiag[a] * BB;
                     const double w = v + sU[a * BB + da * DC + db];
-                    zadd(dz, &blk[da * DC + db], w);
-                    if (C < 16 * NT) zadd(dz, &blk[db * DC + da], w);
+                    if (PB) { double* blk = PB + (a * (a + 1) / 2 + a) * BB; blk[da * DC + db] = w; if (C < 16 * NT) blk[db * DC + da] = w; }
+                    else { double* blk = S_val + (size_t)sDiag[a] * BB; zadd(dz, &blk[da * DC + db], w); if (C < 16 * NT) zadd(dz, &blk[db * DC + da], w); }
                 }
             }
         }
@@ -1710,10 +1716,14 @@ __device__ __forceinline__ void publish_body(const double* __restrict__ scal, co
             // cleared for the next iteration (what k_det_decode does in a launch of its own for the sums of the assembly)
             long long* a = lacc + ((size_t)lane * SC_TOTAL + k) * LA_STRIDE;
             long long tot[LA_STRIDE];
+            // round 6: the eight limbs first, then the clears, then the sums -- load / clear / butterfly per limb in turn was eight dependent round trips per scalar
+#pragma unroll
+            for (int j = 0; j < LA_STRIDE; j++) tot[j] = __hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < LA_STRIDE; j++) if (tot[j] != 0) a[j] = 0;
 #pragma unroll
             for (int j = 0; j < LA_STRIDE; j++) {
-                long long v = __hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v != 0) a[j] = 0;
+                long long v = tot[j];
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
                 tot[j] = v;

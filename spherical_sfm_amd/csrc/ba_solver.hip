@@ -65,7 +65,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     // ---- iteration 0: rotation tables, Jacobi scaling from the initial Jacobian, |x|
     h->set_zone(0);
     if (h->det) {   // a solve starts on clean limbs whatever the previous one on this handle left (normally nothing: every decode clears what it read)
-        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, (2 * h->det_nacc + 2) * sizeof(long long), st));
+        if (!h->gram_fold) SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, (2 * h->det_nacc + 2) * sizeof(long long), st));      // (atomics-free emission: no limbs in use)
         SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_lacc.p, 0, (size_t)SC_NSLOT * SC_TOTAL * LA_STRIDE * sizeof(long long), st));
     }
     // four launches: [rotation tables + clears] [point column norms + scales] [camera column norms + scales] [|x|^2 + focal scale]
@@ -124,7 +124,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                       z.S_val = red; z.rhs = z.S_val + h->zone_nnz; z.Udiag = z.rhs + (h->zone_n + 1); z.Sfc = z.Udiag + h->zone_n; z.gcraw = z.Sfc + h->zone_n; return z; };
     // SSFM_DETERMINISTIC=1 (det_acc.h): where the limbs of a zone's accumulators live; the scalar block's long accumulators; the decode launches
     long long* const lacc = h->det ? h->det_lacc.p : (long long*)nullptr;
-    auto det_zone = [&](const ZonePtrs& z) { DetZone dz; if (h->det) { dz.base = z.S_val; dz.limb = h->det_limb.p + 1; } return dz; };
+    auto det_zone = [&](const ZonePtrs& z) { DetZone dz; if (h->det) { dz.base = z.S_val; dz.limb = h->det_limb.p + 1; } if (h->gram_fold) { dz.part = h->gram_part.p; dz.part_off = h->gpart_off.p; } return dz; };
     constexpr unsigned DET_K_ASSEMBLY = (1u << SC_COST) | (1u << SC_FJJ) | (1u << SC_FJR) | (1u << SC_FWW) | (1u << SC_FWG);
     constexpr unsigned DET_K_TAIL = (1u << SC_MODEL) | (1u << SC_STEP2_PT) | (1u << SC_XN2_PT) | (1u << SC_CAND_COST) | (1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM);
     auto det_decode = [&](const ZonePtrs& z, bool matrices, unsigned kmask) {
@@ -257,10 +257,12 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                                h->batch_slot.p, h->pair_j.p, h->pair_j2.p, h->scale_cam.p, probe_Y.p, probe_S.p);
         }
 #endif
-        if (h->det) {
+        if (h->det && !h->gram_fold) {
             det_decode(zone_ptrs(iteration & 1), true, DET_K_ASSEMBLY);      // limbs -> the zone's doubles (and cleared); the point pass's sums -> replica 0 of the scalar block
             SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->det_limb.p, 0, sizeof(long long), st));      // the poison word: read by every decode workgroup, cleared behind the launch
         }
+        // (atomics-free emission, gram_fold: nothing went through the limbs; the focal sums are folded from the long accumulators by k_finalize_gather, the cost by k_publish:
+        //  no decode launch at all)
         if (ctx->collective) {
             // ONE sum all-reduce per assembly: [S | rhs | diag U | S_fc | Jc^T r | scalar sums | one gradient-max slot per rank]
             hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, h->red_scal, ctx->rank);
@@ -272,13 +274,16 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         const bool clear_in_finalize = O.preconditioner == 0 && zone_clear_fused && (h->zone_len % 2 == 0) && ((reinterpret_cast<uintptr_t>(next_zone) & 15) == 0);
         double2* clear_next = clear_in_finalize ? reinterpret_cast<double2*>(next_zone) : (double2*)nullptr;
         const size_t clear_len2 = clear_in_finalize ? h->zone_len / 2 : 0;
+        const double* fold_part = h->gram_fold ? h->gram_part.p : (const double*)nullptr;      // atomics-free Gram emission: k_finalize_gather folds the tasks' partial blocks first
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             if (F.band_block != DC)      // 3-dof cameras merged in pairs into 6x6 block rows of the band
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr);
             else
                 LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
-                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p);
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr);
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
@@ -359,7 +364,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             // deterministic mode: the tail's sums (model change, step and candidate norms, candidate cost) sit in the long accumulators; k_publish folds them itself,
             // the copying hand-over needs them as doubles in replica 0 first
             // (with_cams: k_cam_update, one workgroup, has STORED the two camera norms in replica 0 -- they are not in the long accumulators)
-            const unsigned det_kt = with_cams ? (DET_K_TAIL & ~((1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM))) : DET_K_TAIL;
+            const unsigned det_kt = (with_cams ? (DET_K_TAIL & ~((1u << SC_STEP2_CAM) | (1u << SC_XN2_CAM))) : DET_K_TAIL) | (h->gram_fold ? (1u << SC_COST) : 0u);   // (gram_fold: the cost was not decoded behind the assembly)
             if (h->det && !poll) det_decode(zone_ptrs(iteration & 1), false, det_kt);
             if (ctx->collective) hipLaunchKernelGGL(k_scal_fold, dim3(1), dim3(SC_TOTAL * 64), 0, st, h->scal.p, (double*)nullptr, 0);
             int rc = allreduce(h, h->scal.p + SC_MODEL, 4, ncclSum); if (rc) return rc;   // MODEL, STEP2_PT, XN2_PT, CAND_COST
@@ -699,6 +704,13 @@ static int ba_create_impl(ssfm_ctx* ctx, const ssfm_ba_problem* p, const ssfm_ba
     }
     UP(cs_task_cam, F.cs_task_cam); UP(cs_task_q0, F.cs_task_q0); UP(cs_task_q1, F.cs_task_q1); UP(row_ptr, F.row_ptr); UP(col_idx, F.col_idx); UP(diag_slot, F.diag_slot);
     if (!F.gr_rec.empty()) UP(gr_rec, F.gr_rec);
+    // atomics-free Gram emission + fold (round 6): single rank, direct solver, every point grouped; on with SSFM_DETERMINISTIC=1 (h->det), see ba_flatten.h
+    h->gram_fold = h->det && !ctx->collective && h->opt.preconditioner == 0 && !F.gpart_off.empty() && F.max_row_blocks <= 27 && F.max_row_blocks + 2 <= GRAM_FOLD_PTRS && !(std::getenv("SSFM_GRAM_FOLD") && std::atoi(std::getenv("SSFM_GRAM_FOLD")) == 0);
+    if (h->gram_fold) {
+        UP(gpart_off, F.gpart_off); UP(fold_slot_src, F.fold_slot_src);
+        SSFM_HIP_CHECK(ctx, h->gram_part.alloc((size_t)F.gpart_off.back() + 64));      // (+ slack: the fold reads a fixed number of doubles per source)
+        SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->gram_part.p, 0, ((size_t)F.gpart_off.back() + 64) * sizeof(double), st));      // entries a task never writes (S_fc with a fixed focal) stay zero
+    }
     UP(pt_grouped, F.pt_grouped);
 #undef UP
 #define AL(buf, count) SSFM_HIP_CHECK(ctx, h->buf.alloc(count))

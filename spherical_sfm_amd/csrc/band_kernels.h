@@ -128,15 +128,74 @@ __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __rest
 template <int DC, bool MERGE>
 __global__ void __launch_bounds__(256)
 k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ diag_slot,
-                  const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* __restrict__ Udiag,
-                  const double* __restrict__ gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,
-                  const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* __restrict__ S_val, double* __restrict__ rhs,
-                  const double* __restrict__ Sfc, double* __restrict__ Sff,
+                  const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* Udiag,      // (Udiag, gcraw, Sfc, rhs, S_val: no __restrict__ --
+                  const double* gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,            //  the fold below writes them through *_w)
+                  const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* S_val, double* rhs,
+                  const double* Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal,
                   double2* __restrict__ clear = nullptr, size_t clear_len2 = 0, const int* __restrict__ col_pos = nullptr,
-                  const int* __restrict__ wrap_ptr = nullptr, const int* __restrict__ wrap_blk = nullptr, const int* __restrict__ wrap_row2 = nullptr) {
+                  const int* __restrict__ wrap_ptr = nullptr, const int* __restrict__ wrap_blk = nullptr, const int* __restrict__ wrap_row2 = nullptr,
+                  // round 6, atomics-free Gram emission (ba_flatten.h: fold lists): this camera's row of S and its vectors are the sums, in list order, of the
+                  // partial blocks / vector stretches k_schur_gram's tasks stored; nullptr: S_val ... hold the accumulated values already
+                  const double* __restrict__ part = nullptr, const int* __restrict__ fold_slot_ptr = nullptr, const int* __restrict__ fold_slot_src = nullptr,
+                  double* __restrict__ Udiag_w = nullptr,
+                  double* __restrict__ gcraw_w = nullptr, double* __restrict__ Sfc_w = nullptr,
+                  // deterministic mode without a decode launch: the four focal sums come straight from the long accumulators (det_acc.h), which are cleared here
+                  long long* __restrict__ lacc = nullptr) {
     constexpr int BB = DC * DC; constexpr int off = (DC == 6) ? 0 : 3;
     const int c = blockIdx.x, tid = threadIdx.x;
+    // deterministic mode: the limbs of the four focal sums (wave 1 of workgroup 0 folds them at the end) are requested NOW -- 32 independent loads that fly under
+    // everything else; loaded where they are used they were 5 us on the launch's critical path
+    constexpr int LA_KS[4] = {SC_FJJ, SC_FWW, SC_FJR, SC_FWG};
+    long long lv[4][LA_STRIDE];
+    // (with a fixed focal length the sums are not used -- S_ff = 1, rho = 0 -- and nothing was added to their limbs: Jf is scaled by zero)
+    const bool la_wave = lacc && c == 0 && tid >= 64 && tid < 128 && scale_f[0] > 0.0;
+    if (la_wave) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < LA_STRIDE; j++) lv[k][j] = lacc[((size_t)(tid - 64) * SC_TOTAL + LA_KS[k]) * LA_STRIDE + j];
+    }
+    if (part) {
+        // Everything this row needs -- the partial blocks of its slots, then the vector stretches of its camera -- is one list of sources in a fixed-stride table per
+        // camera (ba_flatten.h: GRAM_FOLD_*): ONE round of index loads, ONE round of independent value loads into LDS, then every entry of S / of the four vectors is
+        // summed over its own sub-range in list order from LDS.  (A thread walking its entry's list through memory: 19 us per launch, a dependent round trip per source;
+        // CSR lists found through row_ptr: 23 us, four dependent round trips -- these small launches pay ~2.5 us for each.)
+        constexpr int SL = (BB > 5 * DC) ? BB : 5 * DC;                                            // doubles per source in LDS: a block, or a vector stretch (diag U | rhs 1 | rhs 2 | Jc^T r | S_fc)
+        __shared__ double fold_buf[GRAM_FOLD_SRCS * SL];
+        __shared__ int fold_tab[GRAM_FOLD_STRIDE];
+        const int* __restrict__ tab = fold_slot_src + (size_t)c * GRAM_FOLD_STRIDE;
+        if (tid < GRAM_FOLD_STRIDE) fold_tab[tid] = tab[tid];
+        const int nnb0 = row_ptr[c + 1] - row_ptr[c], rb0 = row_ptr[c];
+        __syncthreads();
+        const int nq = fold_tab[0];
+        // (all of a thread's loads in flight before the first LDS store: the plain loop waited for every load in turn -- eleven dependent round trips, 15 us)
+        constexpr int FOLD_LD = (GRAM_FOLD_SRCS * SL + 255) / 256;                                 // <= 18 values per thread
+        {
+            double fv[FOLD_LD];
+#pragma unroll
+            for (int u = 0; u < FOLD_LD; u++) { const int idx = min(tid + u * 256, max(nq * SL - 1, 0)); fv[u] = part[(size_t)fold_tab[GRAM_FOLD_HEAD + idx / SL] + idx % SL]; }      // (reads past a 3-dof block's 9 entries stay inside the buffer's slack)
+#pragma unroll
+            for (int u = 0; u < FOLD_LD; u++) { const int idx = tid + u * 256; if (idx < nq * SL) fold_buf[idx] = fv[u]; }
+        }
+        __syncthreads();
+        const int nent = nnb0 * BB + 4 * DC;                                                       // entries this workgroup produces: blocks, then diag U | rhs | Jc^T r | S_fc
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                                                              // <= 4 x 256 entries: rows of <= 27 blocks (the host checks)
+            const int idx = tid + u * 256;
+            if (idx < nent) {
+                const bool vec = idx >= nnb0 * BB;
+                const int j = vec ? nnb0 : idx / BB, e = vec ? idx - nnb0 * BB : idx % BB;
+                const int a = fold_tab[1 + j], b = fold_tab[2 + j];
+                double t = 0.0;
+                if (!vec) { for (int q = a; q < b; q++) t += fold_buf[q * SL + e]; S_val[(size_t)rb0 * BB + idx] = t; }
+                else { const int v = e / DC, ca = e - v * DC;
+                       for (int q = a; q < b; q++) { const double* pv = fold_buf + q * SL; t += (v == 0) ? pv[ca] : (v == 1) ? (pv[DC + ca] + pv[2 * DC + ca]) : (v == 2) ? pv[3 * DC + ca] : pv[4 * DC + ca]; }
+                       (v == 0 ? Udiag_w : v == 1 ? rhs : v == 2 ? gcraw_w : Sfc_w)[c * DC + ca] = t; }
+            }
+        }
+        __syncthreads();
+    }
     // the accumulation zone of the NEXT iteration (nothing has read it since the iteration before this one ended) is cleared here, a slice
     // per workgroup: the separate memset was a launch of its own on the critical path behind k_publish (4.7 us per iteration)
     if (clear) {
@@ -163,7 +222,34 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
     if (c == 0 && tid >= 64 && tid < 128) {                        // wave 1 of workgroup 0: focal row from the replicas of the focal sums
         const int l = tid - 64;
         const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;
-        const double fjj = wave_sum(sl[SC_FJJ]), fww = wave_sum(sl[SC_FWW]), fjr = wave_sum(sl[SC_FJR]), fwg = wave_sum(sl[SC_FWG]);
+        double fjj, fww, fjr, fwg;
+        if (la_wave) {
+            // (the limbs were loaded at the top of the kernel; load / clear / load / ... in turn made every limb a dependent round trip)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int j = 0; j < LA_STRIDE; j++) if (lv[k][j] != 0) lacc[((size_t)l * SC_TOTAL + LA_KS[k]) * LA_STRIDE + j] = 0;
+            // integer sums over the 64 replicas through LDS: lane t < 32 adds column t = (sum k, limb j) of the 64 rows (192 64-bit butterflies took 3 us)
+            __shared__ long long la_buf[64 * 33];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int j = 0; j < LA_STRIDE; j++) la_buf[l * 33 + k * LA_STRIDE + j] = lv[k][j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            long long colsum = 0;
+            if (l < 32) for (int r = 0; r < 64; r++) colsum += la_buf[r * 33 + l];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (l < 32) la_buf[l] = colsum;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double fs[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { long long tot[LA_STRIDE];
+#pragma unroll
+                                          for (int j = 0; j < LA_STRIDE; j++) tot[j] = la_buf[k * LA_STRIDE + j];
+                                          fs[k] = lacc_value(tot, tot[LA_NL]); }
+            fjj = fs[0]; fww = fs[1]; fjr = fs[2]; fwg = fs[3];
+        } else if (lacc) { fjj = fww = 1.0; fjr = fwg = 0.0; } else {      // (lacc without la_wave: the focal length is fixed, the values are not used)
+ fjj = wave_sum(sl[SC_FJJ]); fww = wave_sum(sl[SC_FWW]); fjr = wave_sum(sl[SC_FJR]); fwg = wave_sum(sl[SC_FWG]); }
         if (l == 0) {
             const double sf = scale_f[0];
             if (sf > 0.0) {

@@ -16,6 +16,12 @@
 //
 // k_det_decode turns the limbs back into the doubles every consumer reads (and clears them for the next assembly): one extra launch per assembly and one per
 // hand-over.  Everything downstream (factorisation, substitutions, candidate) was deterministic already.
+//
+// Round 6 -- no limbs at all when EVERY point sits in a signature group (the circle workloads; DetZone::part below): k_schur_gram stores each task's blocks and
+// vectors with plain stores into its own stretch of a partial buffer and k_finalize_gather folds, per row of S, the partial blocks of every slot in task order from
+// a fixed-stride table (ba_flatten.h: GRAM_FOLD_*).  The scalar block keeps the long accumulators; k_finalize_gather and k_publish fold them themselves, so the mode
+// has no extra launch.  At BASELINE config 2: k_schur_gram 41.0 -> 34.4 us, k_finalize_gather 5.3 -> 11.5, k_publish 4.7 -> 8.7: +3 % per solve against +19 % with
+// the limbs (SSFM_GRAM_FOLD=0 keeps them; ragged tracks, which also add through the pair kernels, always do).
 #pragma once
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
@@ -32,7 +38,9 @@ constexpr int ZA_H = 22, ZA_L = 74;                 // matrix accumulators: hi i
 constexpr int LA_W = 40, LA_E0 = -180, LA_NL = 7, LA_STRIDE = 8;      // long accumulator: LA_NL limbs + one poison word
 
 // where the limbs of a double accumulator live: entry p of the zone [base, ...) has its two limbs at limb[2 (p - base)], the poison word at limb[-1]
-struct DetZone { const double* base = nullptr; long long* limb = nullptr; };
+// round 6: part != nullptr -> k_schur_gram writes task t's blocks and vectors with plain stores at part + part_off[t] (ba_flatten.h: gram_part_len) and
+// k_finalize_gather folds them in a fixed order: no atomics at all for these accumulators (limb is then unused)
+struct DetZone { const double* base = nullptr; long long* limb = nullptr; double* part = nullptr; const int* part_off = nullptr; };
 
 // ---- the arithmetic, host-compilable (tests/native/det_acc_check.cpp) ------------------------------------------------------------------
 // false: v cannot be represented (not finite, or too large) -> the caller bumps the poison word

@@ -221,32 +221,8 @@ inline bool snode_plan(int Nc, int DC, const std::vector<int>& row_ptr, const st
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 typedef double sn_v4d __attribute__((ext_vector_type(4)));
 
-// dst[i * ld + j] (i < nrows, j < ncols) <- the matrix a block table describes (tab < 0: zeros); nt cooperating threads, this one is t
-template <int DC>
-__device__ __forceinline__ void sn_gather(double* dst, int ld, int nrows, int ncols, const double* __restrict__ S_val, const int* __restrict__ tabs, int tab, int ncb, int t, int nt) {
-    constexpr int BB = DC * DC;
-    const int total = nrows * ncols;
-    if (tab < 0) { for (int idx = t; idx < total; idx += nt) { const int i = idx / ncols, j = idx - i * ncols; dst[i * ld + j] = 0.0; } return; }
-    const int* __restrict__ tb = tabs + tab;
-    for (int base = 0; base < total; base += 4 * nt) {
-        int e[4], o[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = min(base + u * nt + t, total - 1), i = idx / ncols, j = idx - i * ncols, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;
-            e[u] = tb[a * ncb + b];
-            o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
-        }
-        double val[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = base + u * nt + t;
-            if (idx < total) { const int i = idx / ncols, j = idx - i * ncols; dst[i * ld + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]); }
-        }
-    }
-}
-// the same gather in batches of B entries per thread (tables first, then values, then the LDS stores: two memory round trips per batch)
+// dst[i * ld + j] (i < nrows, j < ncols) <- the matrix a block table describes (tab < 0: zeros); nt cooperating threads, this one is t; batches of B entries per
+// thread: the table entries first, then the values, then the LDS stores -- two memory round trips per batch
 template <int DC, int B>
 __device__ __forceinline__ void sn_gather_b(double* dst, int ld, int nrows, int ncols, const double* __restrict__ S_val, const int* __restrict__ tabs, int tab, int ncb, int t, int nt) {
     constexpr int BB = DC * DC;
@@ -268,62 +244,6 @@ __device__ __forceinline__ void sn_gather_b(double* dst, int ld, int nrows, int 
         for (int u = 0; u < B; u++) {
             const int idx = base + u * nt + t;
             if (idx < total) { const int i = idx / ncols, j = idx - i * ncols; dst[i * ld + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]); }
-        }
-    }
-}
-// Up to four SNQ-column matrices in ONE pass (segment g: dst, leading dimension, rows, columns = SNQ, table (-1: zeros, -3: skipped), blocks per table row): every table entry a
-// thread needs is loaded first, then every value, then the LDS stores -- two memory round trips for the lot (a gather per matrix in batches of four paid two per batch:
-// the helpers' 4 us per slot were eight dependent round trips, the prologue 6.5 us).  PER * nt must cover the elements.
-struct SnSeg { double* dst; int ld, nrows, ncols, tab, ncb; };
-template <int DC, int PER>
-__device__ __forceinline__ void sn_gather_multi(const SnSeg (&sg)[4], const double* __restrict__ S_val, const int* __restrict__ tabs, int t, int nt) {
-    constexpr int BB = DC * DC;
-    const int n0 = sg[0].nrows * sg[0].ncols, n1 = n0 + sg[1].nrows * sg[1].ncols, n2 = n1 + sg[2].nrows * sg[2].ncols, n3 = n2 + sg[3].nrows * sg[3].ncols;
-    int e[PER], o[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int g = min(u * nt + t, max(n3 - 1, 0));
-        const int q = g >= n2 ? 3 : (g >= n1 ? 2 : (g >= n0 ? 1 : 0)), base = q == 3 ? n2 : (q == 2 ? n1 : (q == 1 ? n0 : 0));
-        const int idx = g - base, i = idx / SNQ, j = idx - i * SNQ, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;      // (every segment has SNQ columns)
-        e[u] = sg[q].tab >= 0 ? tabs[sg[q].tab + a * sg[q].ncb + b] : -1;
-        o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
-    }
-    double val[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int g = u * nt + t;
-        if (g < n3) {
-            const int q = g >= n2 ? 3 : (g >= n1 ? 2 : (g >= n0 ? 1 : 0)), base = q == 3 ? n2 : (q == 2 ? n1 : (q == 1 ? n0 : 0));
-            const int idx = g - base, i = idx / SNQ, j = idx - i * SNQ;
-            if (sg[q].tab != -3) sg[q].dst[i * sg[q].ld + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]);
-        }
-    }
-}
-// Two SNQ x SNQ matrices (leading dimension SN_LD) in ONE pass: every table entry a thread needs is loaded first, then every value, then the LDS stores -- two memory
-// round trips per slot instead of two per batch of four (the helpers' 4 us per slot were eight dependent round trips).  tab == -3: that matrix is skipped.
-template <int DC>
-__device__ __forceinline__ void sn_gather2(double* dstA, int tabA, double* dstB, int tabB, const double* __restrict__ S_val, const int* __restrict__ tabs, int t, int nt) {
-    constexpr int BB = DC * DC, S = SNQ / DC, NE = SNQ * SNQ, PER = 16;      // 2 * 900 entries over >= 128 threads: <= 15 each
-    int e[PER], o[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int g = min(u * nt + t, 2 * NE - 1), which = g >= NE ? 1 : 0, idx = g - which * NE;
-        const int i = idx / SNQ, j = idx - i * SNQ, a = i / DC, uu = i - a * DC, b = j / DC, v = j - b * DC;
-        const int tab = which ? tabB : tabA;
-        e[u] = tab >= 0 ? tabs[tab + a * S + b] : -1;
-        o[u] = (uu * DC + v) | ((v * DC + uu) << 8) | ((uu == v ? 1 : 0) << 16);
-    }
-    double val[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) { const int slot = e[u] >= 0 ? (e[u] & 0x3fffffff) : 0; val[u] = S_val[(size_t)slot * BB + ((e[u] & 0x40000000) ? ((o[u] >> 8) & 255) : (o[u] & 255))]; }
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int g = u * nt + t;
-        if (g < 2 * NE) {
-            const int which = g >= NE ? 1 : 0, idx = g - which * NE, i = idx / SNQ, j = idx - i * SNQ;
-            if ((which ? tabB : tabA) != -3) (which ? dstB : dstA)[i * SN_LD + j] = e[u] == -1 ? 0.0 : (e[u] == -2 ? ((o[u] >> 16) ? 1.0 : 0.0) : val[u]);
         }
     }
 }

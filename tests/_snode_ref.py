@@ -55,7 +55,7 @@ def solve(plan, blocks, rhs2, dc):
         fac = []
         for k in range(ns):
             Cm = gather(plan, blocks, dc, sr[k][2], Q, Q, S)
-            L = np.linalg.cholesky((D + D.T) / 2 if False else np.tril(D) + np.tril(D, -1).T)
+            L = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)                   # the kernel reads the lower triangle only
             Lsd = np.linalg.solve(L, Cm.T).T
             LTP = np.linalg.solve(L, E.T).T
             y = np.linalg.solve(L, g[k])

@@ -89,3 +89,21 @@ def test_other_solver_paths_in_deterministic_mode(gpu_ctx, monkeypatch):
         c1, x1, f1, s1 = ba.optimize(gpu_ctx, p, **kw)
         assert s1["termination"] == s0["termination"] and s1["iterations"] == s0["iterations"], kw
         assert rel_err(c1, c0) <= 1e-8 and rel_err(x1, x0) <= 1e-8 and abs(f1 - f0) <= 1e-9 * f0, kw
+
+
+@pytest.mark.parametrize("cams,pts,K,spherical,focal_fixed", [(300, 30000, 6, False, True), (240, 24000, 8, False, False), (120, 12000, 3, True, False), (90, 9000, 5, False, True)])
+def test_atomics_free_emission_equals_the_limb_accumulation(gpu_ctx, monkeypatch, cams, pts, K, spherical, focal_fixed):
+    """Round 6: when every point sits in a signature group the deterministic mode stores per-task partial blocks with plain stores and k_finalize_gather folds them in task
+    order (no limbs, no decode launches; csrc/ba_flatten.h fold lists) -- SSFM_GRAM_FOLD=0 keeps the fixed-point limbs of round 5.  Both are bit-reproducible and agree with
+    each other to rounding: tracks of 3 / 5 / 6 / 8 cameras (one tile, tile + 4x4x4 tail, two tiles + tail, three tiles), 6- and 3-dof cameras, fixed and free focal."""
+    from spherical_sfm_amd import ba
+    p = synth.make_circle(cams, pts, K, spherical=spherical, focal_fixed=focal_fixed)
+    monkeypatch.setenv("SSFM_DETERMINISTIC", "1"); monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    runs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SSFM_GRAM_FOLD", fold)
+        a = ba.optimize(gpu_ctx, p); b = ba.optimize(gpu_ctx, p)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3]["final_cost"] == b[3]["final_cost"], fold
+        runs[fold] = a
+    assert runs["1"][3]["iterations"] == runs["0"][3]["iterations"]
+    assert rel_err(runs["1"][0], runs["0"][0]) <= 1e-9 and rel_err(runs["1"][1], runs["0"][1]) <= 1e-9 and abs(runs["1"][2] - runs["0"][2]) <= 1e-9 * abs(runs["0"][2])
