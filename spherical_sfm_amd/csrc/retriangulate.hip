@@ -605,6 +605,11 @@ __device__ void tt_shuffle_resize(int* list, int m, int target, TtRng& g) {
     }
 }
 struct TtOpts { double thr, mult; int lo_steps, lsq_it, min_sample_mult, non_min_mult; unsigned min_it, lo_start; };
+// Round 6 -- one local optimisation per launch.  A wave runs as many local-optimisation rounds as its busiest lane needs, and a round is ~100 RANSAC iterations of
+// work: at 100k points x 6 observations 89 % of the points need two and 11 % three, so nearly every wave of 64 ran a third round with ~7 lanes active (PMC: 37.8 of 64
+// lanes).  Now a lane whose point asks for another local optimisation after it has had this launch's one SAVES its loop state (below) and its point goes onto the list
+// of the next launch, which starts with dense waves of parked points.  The per-point sequence of operations -- and with it every bit of the result -- is unchanged.
+struct TtState { double best[3], best_score, best_min[3], best_min_score; unsigned it, max_it; int nin, lo_count, need, pos, ovf, pad; };
 // LeastSquaresFit (ransac.h:409-420)
 __device__ void tt_lsq_fit(const TtPoint& c, const TtOpts& o, double th, TtRng& g, int* work, double* model, bool scored = false) {
     const int ni = tt_inliers(c, model, th, work, scored);
@@ -648,7 +653,7 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
                       const int* __restrict__ req_ptr, const unsigned* __restrict__ req_it /* NumRequiredIterations per (slot, inlier count) */,
                       const unsigned* __restrict__ W, int LW, int* __restrict__ lists /* [3 * total observations] */,
                       double* __restrict__ pts, int* __restrict__ num_inliers, unsigned* __restrict__ stats, unsigned char* __restrict__ flags,
-                      int* __restrict__ overflow) {
+                      int* __restrict__ overflow, TtState* __restrict__ state, int resume, int lo_budget, int* __restrict__ next_list, int* __restrict__ next_count) {
     const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_id >= nP) return;
     const int p = order ? order[lane_id] : lane_id;
@@ -658,6 +663,7 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
     double best[3] = {0, 0, 0};
     int nin = 0; unsigned it = 0; int lo_count = 0;
     int* listI = lists + 3 * (size_t)c.j0; int* base = listI + c.n; int* work = base + c.n;
+    bool suspended = false;
     if (c.n >= 3) {                                                           // src/sfm.cpp:173
         TtRng g{W, LW, 0, false};
         const int slot = pt_slot[p];
@@ -665,6 +671,14 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
         const unsigned* req = req_it + req_ptr[slot];
         double best_score = TRI_DMAX, best_min[3] = {0, 0, 0}, best_min_score = TRI_DMAX;
         unsigned max_it = TRI_MAX_IT;                                         // max(max_num_iterations_, min_num_iterations_)
+        int need0 = 0;                                                        // a resumed lane comes back parked: it asked for a local optimisation when it was suspended
+        if (resume) {
+            const TtState& S = state[p];
+            best[0] = S.best[0]; best[1] = S.best[1]; best[2] = S.best[2]; best_score = S.best_score;
+            best_min[0] = S.best_min[0]; best_min[1] = S.best_min[1]; best_min[2] = S.best_min[2]; best_min_score = S.best_min_score;
+            it = S.it; max_it = S.max_it; nin = S.nin; lo_count = S.lo_count; need0 = S.need; g.pos = S.pos; g.overflow = S.ovf != 0;
+        }
+        int budget = lo_budget;
         // EstimateModel's loop (ransac.h:154-229) as a per-lane state machine.  A lane's sequence of operations is the reference's; what changes is WHEN
         // the wave executes them: a local optimisation is ~100x an iteration, and lanes call it at different iterations (whenever their point finds a
         // new best minimal model after iteration 50) -- run where the loop calls it, the wave executed up to 64 of them one after the other with one lane
@@ -672,10 +686,10 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
         // ones run it together, then all resume.  Rounds = the largest number of local optimisations of any lane of the wave (2-4).
         //   phase 0: top of iteration `it` (loop test, the lo_starting_iterations_ call of ransac.h:162-176)   phase 1: sample, solve, score, update
         int phase = 0; bool done = false;
-        it = 0;
+        if (!resume) it = 0;
         while (true) {
-            int need = 0;                                                     // 1: LocalOptimization(best_model) at lo_start; 2: LocalOptimization(best_minimal_model)
-            while (!done) {
+            int need = need0; need0 = 0;                                      // 1: LocalOptimization(best_model) at lo_start; 2: LocalOptimization(best_minimal_model)
+            while (!done && need == 0) {
                 if (phase == 0) {
                     if (!(it < max_it)) { done = true; break; }
                     if (it == o.lo_start && best_min_score < TRI_DMAX) { need = 1; break; }
@@ -697,8 +711,17 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
                 }
                 ++it; phase = 0;
             }
-            if (__ballot(need != 0) == 0ull) break;                           // every lane of the wave has finished its loop
+            if (need != 0 && budget <= 0) {                                   // this launch's local optimisation is spent: the point goes to the next launch, parked
+                TtState& S = state[p];
+                S.best[0] = best[0]; S.best[1] = best[1]; S.best[2] = best[2]; S.best_score = best_score;
+                S.best_min[0] = best_min[0]; S.best_min[1] = best_min[1]; S.best_min[2] = best_min[2]; S.best_min_score = best_min_score;
+                S.it = it; S.max_it = max_it; S.nin = nin; S.lo_count = lo_count; S.need = need; S.pos = g.pos; S.ovf = g.overflow ? 1 : 0;
+                next_list[atomicAdd(next_count, 1)] = p;
+                suspended = true; done = true; need = 0;
+            }
+            if (__ballot(need != 0) == 0ull) break;                           // every lane of the wave has finished its loop (or left for the next launch)
             if (need != 0) {                                                  // the parked lanes, together
+                --budget;
                 double model[3], msc;
                 if (need == 1) { model[0] = best[0]; model[1] = best[1]; model[2] = best[2]; msc = best_score; }
                 else { model[0] = best_min[0]; model[1] = best_min[1]; model[2] = best_min[2]; msc = best_min_score; }
@@ -711,6 +734,7 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
                 if (need == 2) { ++it; phase = 0; }
             }
         }
+        if (suspended) { if (g.overflow) atomicExch(overflow, 1); return; }
         if (it <= o.lo_start && best_score < TRI_DMAX) {                      // ransac.h:232-243 (never reached with min_num_iterations_ 100 > 50)
             ++lo_count;
             tt_local_optimization(c, o, g, base, work, best, &best_score);
@@ -737,8 +761,8 @@ retriangulate_trace_body(const double* __restrict__ ct, const double* __restrict
     const int* __restrict__ pt_start, int nP, const int* __restrict__ order, TtOpts o, const int* __restrict__ pt_slot,                          \
     const unsigned short* __restrict__ samples, const int* __restrict__ req_ptr, const unsigned* __restrict__ req_it, const unsigned* __restrict__ W, \
     int LW, int* __restrict__ lists, double* __restrict__ pts, int* __restrict__ num_inliers, unsigned* __restrict__ stats,                    \
-    unsigned char* __restrict__ flags, int* __restrict__ overflow
-#define SSFM_RETRI_PASS ct, focal, obs_xy, obs_cam, pt_start, nP, order, o, pt_slot, samples, req_ptr, req_it, W, LW, lists, pts, num_inliers, stats, flags, overflow
+    unsigned char* __restrict__ flags, int* __restrict__ overflow, TtState* __restrict__ state, int resume, int lo_budget, int* __restrict__ next_list, int* __restrict__ next_count
+#define SSFM_RETRI_PASS ct, focal, obs_xy, obs_cam, pt_start, nP, order, o, pt_slot, samples, req_ptr, req_it, W, LW, lists, pts, num_inliers, stats, flags, overflow, state, resume, lo_budget, next_list, next_count
 __global__ void __launch_bounds__(64) k_retriangulate_trace(SSFM_RETRI_ARGS) { retriangulate_trace_body<true>(SSFM_RETRI_PASS); }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_retriangulate_trace_w2(SSFM_RETRI_ARGS) { retriangulate_trace_body<true>(SSFM_RETRI_PASS); }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_retriangulate_trace_w3(SSFM_RETRI_ARGS) { retriangulate_trace_body<false>(SSFM_RETRI_PASS); }      // (three waves per SIMD leave no LDS for the row cache)
@@ -893,10 +917,10 @@ static unsigned tri_num_required_iterations(double ratio, double pmiss, int ssiz
 }
 
 struct TriDevice {                  // the uploaded problem of one call
-    DevBuf<double> dct, df, dxy, dpts, dX, dout; DevBuf<int> dcamidx, dps, dnin, dslot, dreqptr, dlists, dovf, dtpt, dtptr, dtl, dorder; DevBuf<unsigned> dreq, dW, dstats;
+    DevBuf<double> dct, df, dxy, dpts, dX, dout; DevBuf<int> dcamidx, dps, dnin, dslot, dreqptr, dlists, dovf, dtpt, dtptr, dtl, dorder, dnext0, dnext1, dcount; DevBuf<unsigned> dreq, dW, dstats; DevBuf<TtState> dstate;
     DevBuf<unsigned short> dsamples; DevBuf<unsigned char> dflags;
     void free_all() { dct.free(); df.free(); dxy.free(); dpts.free(); dX.free(); dout.free(); dcamidx.free(); dps.free(); dnin.free(); dslot.free(); dreqptr.free(); dlists.free();
-                      dovf.free(); dtpt.free(); dtptr.free(); dtl.free(); dorder.free(); dreq.free(); dW.free(); dstats.free(); dsamples.free(); dflags.free(); }
+                      dovf.free(); dtpt.free(); dtptr.free(); dtl.free(); dorder.free(); dnext0.free(); dnext1.free(); dcount.free(); dstate.free(); dreq.free(); dW.free(); dstats.free(); dsamples.free(); dflags.free(); }
 };
 static int tri_upload_problem(ssfm_ctx* ctx, hipStream_t st, const ssfm_ba_problem* p, TriDevice& D, std::vector<int>& pt_start, std::vector<int64_t>* obs_index, int* total_out) {
     const int Nc = p->num_cameras;
@@ -952,7 +976,8 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
         SSFM_HIP_CHECK(ctx, upload(D.dslot, pt_slot, st)); SSFM_HIP_CHECK(ctx, upload(D.dsamples, samples, st)); SSFM_HIP_CHECK(ctx, upload(D.dreqptr, req_ptr, st));
         SSFM_HIP_CHECK(ctx, upload(D.dreq, req, st)); SSFM_HIP_CHECK(ctx, upload(D.dorder, order, st));
         SSFM_HIP_CHECK(ctx, D.dlists.alloc((size_t)3 * std::max(total, 1))); SSFM_HIP_CHECK(ctx, D.dpts.alloc((size_t)std::max(Np, 1) * 3)); SSFM_HIP_CHECK(ctx, D.dnin.alloc(std::max(Np, 1)));
-        SSFM_HIP_CHECK(ctx, D.dovf.alloc(1));
+        SSFM_HIP_CHECK(ctx, D.dovf.alloc(1)); SSFM_HIP_CHECK(ctx, D.dcount.alloc(1));
+        SSFM_HIP_CHECK(ctx, D.dstate.alloc((size_t)std::max(Np, 1))); SSFM_HIP_CHECK(ctx, D.dnext0.alloc((size_t)std::max(Np, 1))); SSFM_HIP_CHECK(ctx, D.dnext1.alloc((size_t)std::max(Np, 1)));
         if (stats_out) SSFM_HIP_CHECK(ctx, D.dstats.alloc((size_t)2 * std::max(Np, 1)));
         if (inlier_flags_out) SSFM_HIP_CHECK(ctx, D.dflags.alloc(std::max(total, 1)));
         // raw words of the local optimisation's std::mt19937(0); a lane that needs more makes the launch repeat with a longer table
@@ -969,12 +994,27 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
             // two, but still fits one round at three (3072) -- and at sizes of many rounds three has the higher throughput (122 against 88 waves per ms).
             const char* ew = getenv("SSFM_RETRI_WAVES");
             const int waves = ew ? atoi(ew) : (((Np + 63) / 64 <= 8 * ctx->num_cus) ? 2 : 3);
-#define SSFM_RETRI_LAUNCH(K) hipLaunchKernelGGL(K, dim3((Np + 63) / 64), dim3(64), 0, st, D.dct.p, D.df.p, reinterpret_cast<const double2*>(D.dxy.p), D.dcamidx.p, D.dps.p, Np, \
-                                           D.dorder.p, o, D.dslot.p, D.dsamples.p, D.dreqptr.p, D.dreq.p, D.dW.p, (int)LW, D.dlists.p, D.dpts.p, D.dnin.p,                \
-                                           stats_out ? D.dstats.p : nullptr, inlier_flags_out ? D.dflags.p : nullptr, D.dovf.p)
-            if (Np > 0) { if (waves == 2) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w2); else if (waves == 3) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w3); else SSFM_RETRI_LAUNCH(k_retriangulate_trace); }
+            // round 6: one local optimisation per launch (TtState); the first launch takes every point in `order`, launch r + 1 the points launch r parked, as dense waves
+            // (SSFM_RETRI_ROUNDS=0: everything in one launch, rounds 3-5)
+            const bool rounds_on = !(getenv("SSFM_RETRI_ROUNDS") && atoi(getenv("SSFM_RETRI_ROUNDS")) == 0);      // (read per call: tests switch it)
+            const int budget = rounds_on ? 1 : (1 << 30);
+#define SSFM_RETRI_LAUNCH(K, N_, LIST_, RESUME_, NEXT_) hipLaunchKernelGGL(K, dim3(((N_) + 63) / 64), dim3(64), 0, st, D.dct.p, D.df.p, reinterpret_cast<const double2*>(D.dxy.p), D.dcamidx.p, D.dps.p, (N_), \
+                                           (LIST_), o, D.dslot.p, D.dsamples.p, D.dreqptr.p, D.dreq.p, D.dW.p, (int)LW, D.dlists.p, D.dpts.p, D.dnin.p,                   \
+                                           stats_out ? D.dstats.p : nullptr, inlier_flags_out ? D.dflags.p : nullptr, D.dovf.p, D.dstate.p, (RESUME_), budget, (NEXT_), D.dcount.p)
+            int n_act = Np; const int* list = D.dorder.p; int resume = 0, round = 0;
+            while (n_act > 0) {
+                int* next = (round & 1) ? D.dnext1.p : D.dnext0.p;
+                SSFM_HIP_CHECK(ctx, hipMemsetAsync(D.dcount.p, 0, sizeof(int), st));
+                if (waves == 2) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w2, n_act, list, resume, next); else if (waves == 3) SSFM_RETRI_LAUNCH(k_retriangulate_trace_w3, n_act, list, resume, next);
+                else SSFM_RETRI_LAUNCH(k_retriangulate_trace, n_act, list, resume, next);
+                SSFM_HIP_CHECK(ctx, hipGetLastError());
+                int cnt = 0;
+                SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&cnt, D.dcount.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                n_act = cnt; list = next; resume = 1; round++;
+                if (round > 100000) return fail(ctx, SSFM_ERR_INVALID, "ssfm_retriangulate: the local-optimisation rounds do not end");
+            }
 #undef SSFM_RETRI_LAUNCH
-            SSFM_HIP_CHECK(ctx, hipGetLastError());
             int ovf = 0;
             SSFM_HIP_CHECK(ctx, hipMemcpyAsync(&ovf, D.dovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
             SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
