@@ -4,18 +4,22 @@
 // structures the reference's drivers produce for a closed camera loop (examples/spherical_sfm_tools.cpp:887-950: a track couples the cameras it spans, so
 // the reduced matrix of a loop is a PERIODIC block band of half-width r = longest track - 1).
 //
-// Why a new kernel.  The windowed block-band factorisation (band_kernels2.h) is a chain of one dependent step per CAMERA -- 1.27 us each at
-// BASELINE config 2, 42 + 15 + 5 + 16 us per LM iteration in four launches, 45 % of the iteration on <= 12 of 256 compute units.  The arithmetic is nothing
-// (6.5 Mflop); what costs is the number of dependent steps and what one step has to wait for (two barriers, an LDS round trip of the panel, the 6x6
-// factor-and-invert on one wave).  Here a step eliminates a SUPERNODE of s = 30 / DC cameras (30 scalar columns) and the whole tall panel
-//      [ diagonal block (30 rows) ; coupling to the next supernode (30 rows) ; coupling to the ring's closing separator T (<= 60 rows) ]
-// is factored by ONE wave with one lane per row, right-looking, the pivot row broadcast by v_readlane: no LDS, no barrier inside the 30 columns, and the
-// right-hand sides ride along as two more columns (the forward substitution costs two instructions per column).  The Schur updates of the next supernode
-// and of T run on the matrix cores (v_mfma_f64_16x16x4) from LDS copies of the panel.  A ring in its own circular order with reach r <= s is block
-// tridiagonal in supernodes plus one separator T that closes it; it is eliminated from both sides of T towards a middle supernode M by two workgroups
-// (halves A and B, 7 steps each at config 2 instead of 33 + 10), which exchange their contributions to [M, T] ONCE through global memory, both solve the
-// 60...90-row remainder redundantly (a + b == b + a: identical bits) and back-substitute their own half.  One launch does the factorisation, both substitutions
-// and the scatter of the solution into the layout k_arrow_update reads.  No atomics anywhere: the result does not depend on scheduling.
+// The idea.  The windowed block-band factorisation (band_kernels2.h) is a chain of one dependent step per CAMERA -- 1.27 us each at BASELINE config 2,
+// 42 + 15 + 5 + 16 us per LM iteration in four launches, 45 % of the iteration on <= 12 of 256 compute units.  The arithmetic is nothing (6.5 Mflop); what costs is the
+// number of dependent steps and what one step waits for.  Here a step eliminates a SUPERNODE of s = 30 / DC cameras (30 scalar columns): the tall panel
+//      [ diagonal block (30 rows) ; coupling to the next supernode (30 rows) ]
+// is factored by ONE wave with one lane per row, right-looking (sn_panel: the pivot entry and the two rows that become pivots next take the column through
+// v_readlane, every other row reads L(c2, c) back from LDS at a wave-uniform address one column later).  A ring in its own circular order with reach r <= s is block
+// tridiagonal in supernodes plus one separator T that closes it; it is eliminated from both sides of T towards a middle supernode M by two workgroups (halves A and B,
+// 7 steps each at config 2 instead of 33 + 10), which exchange their contributions to [M, T] ONCE through global memory, both solve the 60...90-row remainder
+// redundantly (a + b == b + a: identical bits) and back-substitute their own half.  A second wave takes the rows of T and every right-hand side from the finished
+// panel one stage behind (sn_trows), two more gather the next supernode's blocks from S and send factor blocks to global memory, the Schur updates run on the matrix
+// cores (v_mfma_f64_16x16x4), the back substitution is spread over the four waves.  One launch does the factorisation, both substitutions and the scatter of the
+// solution into the layout k_arrow_update reads.  No atomics anywhere: the result does not depend on scheduling.
+//
+// MEASURED SLOWER than what it replaces (112 us against 86 us at config 2; phase stamps and the five builds in profiles/r06_notes.md): a panel is ~2300 instructions
+// on one wave -- 3.8 us per five cameras, the same issue-bound regime as the windowed kernel -- and the stage around it (barriers, tiles, the slower helper waves,
+// the exchange) eats the rest.  Hence opt-in (snode_enabled below).
 //
 // Applicability (snode_plan below): every connected component of the camera graph is a chain or a ring with reach <= s cameras in some linear / circular
 // order (camera ids, or a greedy walk), rings have >= 4 s cameras, halves <= SN_MAXSTEPS steps, and all workgroups are resident at once.  Everything else
