@@ -51,6 +51,40 @@ static long check(const ssfm::BAFlat& F, int Nc) {
         for (int q = 0; q < F.nP; q++) if (!F.pt_grouped.empty() && (bool)F.pt_grouped[q] != (bool)seen[q]) { std::printf("flag without group\n"); std::abort(); }
         for (size_t e = 0; e < F.pair_j.size(); e++) if (F.pair_p[e] >= 0 && F.pt_grouped[F.pair_p[e]]) { std::printf("grouped point in the pair lists\n"); std::abort(); }
     }
+    // round 6, fold tables of the atomics-free Gram emission (one fixed-stride table per camera row): every partial block / vector stretch of every task appears
+    // exactly once, in the table of the row that owns its destination, under the right extended slot, in task order
+    if (!F.gpart_off.empty()) {
+        const int ng = (int)(F.gr_rec.size() / ssfm::GRAM_REC), DC = F.DC, BB = DC * DC;
+        if ((int)F.gpart_off.size() != ng + 1 || F.gram_points != (int64_t)F.nP || F.fold_slot_src.size() != (size_t)Nc * ssfm::GRAM_FOLD_STRIDE) { std::printf("fold: sizes\n"); std::abort(); }
+        std::vector<int> owner((size_t)F.gpart_off[ng], -1);            // partial offset -> extended slot it must be folded into
+        for (int t = 0; t < ng; t++) {
+            const int* r = &F.gr_rec[(size_t)t * ssfm::GRAM_REC]; const int K = r[2], base = F.gpart_off[t];
+            if (F.gpart_off[t + 1] - base != ssfm::gram_part_len(K, DC)) { std::printf("fold: stretch length\n"); std::abort(); }
+            auto row_of = [&](int sl) { int c = 0; while (F.row_ptr[c + 1] <= sl) c++; return c; };
+            for (int a = 0; a < K; a++) {
+                owner[base + (a * (a + 1) / 2 + a) * BB] = r[40 + a] + row_of(r[40 + a]);
+                owner[base + ssfm::gram_part_blocks(K) * BB + a * 5 * DC] = F.row_ptr[r[4 + a] + 1] + r[4 + a];
+                for (int b = 0; b < a; b++) { const int sl = r[12 + a * (a - 1) / 2 + b] & 0x3fffffff; owner[base + (a * (a + 1) / 2 + b) * BB] = sl + row_of(sl); }
+            }
+        }
+        size_t listed = 0;
+        for (int c = 0; c < Nc; c++) {
+            const int* tab = &F.fold_slot_src[(size_t)c * ssfm::GRAM_FOLD_STRIDE];
+            const int nq = tab[0], nx = F.row_ptr[c + 1] - F.row_ptr[c] + 1, x0 = F.row_ptr[c] + c;
+            if (nq < 0 || nq > ssfm::GRAM_FOLD_SRCS || nx + 1 > ssfm::GRAM_FOLD_PTRS || tab[1] != 0 || tab[1 + nx] != nq) { std::printf("fold: table head\n"); std::abort(); }
+            for (int j = 0; j < nx; j++) {
+                if (tab[1 + j] > tab[2 + j]) { std::printf("fold: pointers\n"); std::abort(); }
+                int last = -1;
+                for (int q = tab[1 + j]; q < tab[2 + j]; q++) {
+                    const int src = tab[ssfm::GRAM_FOLD_HEAD + q];
+                    if (src < 0 || src >= F.gpart_off[ng] || owner[src] != x0 + j || src <= last) { std::printf("fold: source %d of row %d\n", src, c); std::abort(); }
+                    last = src; owner[src] = -2; listed++;
+                }
+            }
+        }
+        for (int v : owner) if (v >= 0) { std::printf("fold: a partial block is not listed\n"); std::abort(); }
+        sum += (long)listed;
+    }
     return sum;
 }
 
@@ -132,6 +166,28 @@ int main() {
         if (groups == 0) { std::printf("no signature group found\n"); std::abort(); }
     }
     unsetenv("SSFM_GRAM_KMIN"); unsetenv("SSFM_GRAM_PTS");
+    // round 6: fully grouped problems (a strided circle: every point of an anchor camera sees the same K cameras) must come with the fold tables of the atomics-free
+    // emission (check() verifies them entry by entry); K = 3 / 6 / 8, 6- and 3-dof, one and two ranks
+    {
+        long folds = 0;
+        for (int trial = 0; trial < 4; trial++) {
+            const int Nc = trial == 3 ? 96 : 120, K = trial == 0 ? 3 : (trial == 1 ? 6 : 8), per = 90, Np = Nc * per, stride = trial == 2 ? 3 : 1;
+            std::vector<double> cams((size_t)Nc * 6, 0.1), pts((size_t)Np * 3), xy; std::vector<int32_t> oc, op;
+            std::vector<uint8_t> rf(Nc, 0), tf(Nc, trial == 3), pf(Np, 0);
+            for (auto& v : pts) v = (rng() % 100) / 10.0 + 0.5;
+            for (int j = 0; j < Np; j++) {
+                std::vector<int> cs; for (int q = 0; q < K; q++) cs.push_back((j / per + stride * q) % Nc);
+                std::sort(cs.begin(), cs.end());
+                for (int c : cs) { oc.push_back(c); op.push_back(j); xy.push_back(1.0); xy.push_back(2.0); }
+            }
+            double focal = 800.0;
+            ssfm_ba_problem P;
+            P.num_cameras = Nc; P.num_points = Np; P.num_observations = (int64_t)oc.size(); P.cameras = cams.data(); P.points = pts.data(); P.focal = &focal;
+            P.obs_xy = xy.data(); P.obs_cam = oc.data(); P.obs_pt = op.data(); P.rot_fixed = rf.data(); P.trans_fixed = tf.data(); P.pt_fixed = pf.data(); P.focal_fixed = trial & 1;
+            for (int nr = 1; nr <= 2; nr++) for (int r = 0; r < nr; r++) { ssfm::BAFlat F; ssfm::ba_flatten(P, nr, r, F); acc += check(F, Nc); folds += F.gpart_off.empty() ? 0 : 1; }
+        }
+        if (folds < 8) { std::printf("fully grouped problems without fold tables (%ld of 12)\n", folds); std::abort(); }
+    }
     // tracks: random match sets incl. merges
     for (int trial = 0; trial < 20; trial++) {
         const int nk = 2 + rng() % 6; std::vector<int32_t> fp(nk + 1, 0); for (int k = 0; k < nk; k++) fp[k + 1] = fp[k] + 5 + rng() % 20;
