@@ -277,13 +277,17 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         const double* fold_part = h->gram_fold ? h->gram_part.p : (const double*)nullptr;      // atomics-free Gram emission: k_finalize_gather folds the tasks' partial blocks first
         if (O.preconditioner == 0) {                               // finalize + band gather + rhs permutation in one launch
             if (F.band_block != DC)      // 3-dof cameras merged in pairs into 6x6 block rows of the band
-                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                { if (h->gram_fold) LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
                        radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
-                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr);
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr); else LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr); }
             else
-                LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                { if (h->gram_fold) LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false, true>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
                        radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
-                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr);
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr); else LAUNCH(h, KID_FINALIZE, (k_finalize_gather<DC, false>), Nc, 256, 0, h->row_ptr.p, h->col_idx.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,
+                       radius, O.min_lm_diagonal, O.max_lm_diagonal, Nc, h->cam_pos.p, h->cam_pos2.p, h->pair_dummy.p, F.y_rows(DC), F.band, h->S_val, h->rhs, h->Sfc, h->Sff.p, h->band.p, h->Yb.p, h->scal.p, clear_next, clear_len2, h->col_pos.p, h->wrap_ptr_p(), h->wrap_blk.p, h->wrap_row2.p,
+                       fold_part, (const int*)nullptr, h->fold_slot_src.p, h->Udiag, h->gcraw, h->Sfc, h->gram_fold ? lacc : (long long*)nullptr); }
             h->band_filled = true;
         } else {
             LAUNCH(h, KID_FINALIZE, k_finalize_S<DC>, gp_cam, 64, 0, h->row_ptr.p, h->diag_slot.p, h->scale_cam.p, h->scale_f.p, h->Udiag, h->gcraw,

@@ -125,13 +125,17 @@ __global__ void k_band_gather(const int* __restrict__ row_ptr, const int* __rest
 // camera, which owns its diagonal block, its band row and its slice of the right-hand sides): LM diagonal on the diagonal block
 // (in S_val too: the residual check multiplies by S), gradient max-norm, band row, permuted [rhs | S_fc]; workgroup 0 also folds the
 // focal sums and writes the focal row.  The block-Jacobi inverse of k_finalize_S is only needed by preconditioner 1 and is not built here.
-template <int DC, bool MERGE>
+// (the default kernel keeps __restrict__ on the arrays the fold variant writes through *_w)
+template <bool R, class T> struct RestrictIf { typedef T* type; };
+template <class T> struct RestrictIf<true, T> { typedef T* __restrict__ type; };
+// FOLD (round 6): the variant that first folds the partial blocks of the atomics-free Gram emission (its 37 KB of LDS and its registers stay out of the default kernel)
+template <int DC, bool MERGE, bool FOLD = false>
 __global__ void __launch_bounds__(256)
 k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ diag_slot,
-                  const double* __restrict__ scale_cam, const double* __restrict__ scale_f, const double* Udiag,      // (Udiag, gcraw, Sfc, rhs, S_val: no __restrict__ --
-                  const double* gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,            //  the fold below writes them through *_w)
-                  const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, double* S_val, double* rhs,
-                  const double* Sfc, double* __restrict__ Sff,
+                  const double* __restrict__ scale_cam, const double* __restrict__ scale_f, typename RestrictIf<!FOLD, const double>::type Udiag,      // (Udiag, gcraw, Sfc, rhs, S_val: no __restrict__ in the variant --
+                  typename RestrictIf<!FOLD, const double>::type gcraw, double radius, double min_diag, double max_diag, int Nc, const int* __restrict__ pos,            //  the fold below writes them through *_w)
+                  const int* __restrict__ pos2, const unsigned char* __restrict__ pair_dummy, int Nb, int b, typename RestrictIf<!FOLD, double>::type S_val, typename RestrictIf<!FOLD, double>::type rhs,
+                  typename RestrictIf<!FOLD, const double>::type Sfc, double* __restrict__ Sff,
                   double* __restrict__ band, double* __restrict__ Y, double* __restrict__ scal,
                   double2* __restrict__ clear = nullptr, size_t clear_len2 = 0, const int* __restrict__ col_pos = nullptr,
                   const int* __restrict__ wrap_ptr = nullptr, const int* __restrict__ wrap_blk = nullptr, const int* __restrict__ wrap_row2 = nullptr,
@@ -149,14 +153,14 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
     constexpr int LA_KS[4] = {SC_FJJ, SC_FWW, SC_FJR, SC_FWG};
     long long lv[4][LA_STRIDE];
     // (with a fixed focal length the sums are not used -- S_ff = 1, rho = 0 -- and nothing was added to their limbs: Jf is scaled by zero)
-    const bool la_wave = lacc && c == 0 && tid >= 64 && tid < 128 && scale_f[0] > 0.0;
+    const bool la_wave = FOLD && lacc && c == 0 && tid >= 64 && tid < 128 && scale_f[0] > 0.0;
     if (la_wave) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int j = 0; j < LA_STRIDE; j++) lv[k][j] = lacc[((size_t)(tid - 64) * SC_TOTAL + LA_KS[k]) * LA_STRIDE + j];
     }
-    if (part) {
+    if constexpr (FOLD) {
         // Everything this row needs -- the partial blocks of its slots, then the vector stretches of its camera -- is one list of sources in a fixed-stride table per
         // camera (ba_flatten.h: GRAM_FOLD_*): ONE round of index loads, ONE round of independent value loads into LDS, then every entry of S / of the four vectors is
         // summed over its own sub-range in list order from LDS.  (A thread walking its entry's list through memory: 19 us per launch, a dependent round trip per source;
@@ -223,7 +227,7 @@ k_finalize_gather(const int* __restrict__ row_ptr, const int* __restrict__ col_i
         const int l = tid - 64;
         const double* sl = scal + (size_t)(l & (SC_NSLOT - 1)) * SC_TOTAL;
         double fjj, fww, fjr, fwg;
-        if (la_wave) {
+        if (FOLD && la_wave) {
             // (the limbs were loaded at the top of the kernel; load / clear / load / ... in turn made every limb a dependent round trip)
 #pragma unroll
             for (int k = 0; k < 4; k++)
