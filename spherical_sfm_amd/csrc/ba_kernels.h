@@ -693,6 +693,29 @@ __device__ __forceinline__ void wave_lds_handover() {
 }
 // entry (r, i) of the unscaled 6-dof camera block that is zero by construction: d/dt = [a 0 -a x; 0 a -a y]
 template <int DC> __device__ __forceinline__ constexpr bool jc_zero(int r, int i) { return DC == 6 && ((r == 0 && i == 1) || (r == 1 && i == 0)); }
+// The cameras of a task (gr_rec[4 ..]) as a LANE VECTOR -- lane i < GRAM_KMAX holds camera i, read with one ds_bpermute -- and the gathers of the per-camera tables
+// with every load of a table in flight before its first LDS store (round 6).  Rounds 3-5 kept the ids in scalar registers behind a select chain; the compiler turned
+// that chain into a scratch array, and the head of every task was, per 64 table entries, scratch load -> wait -> global load -> wait -> LDS store: five to seven
+// dependent round trips before the first observation could be linearised.
+__device__ __forceinline__ int gram_cam_of(int camv, int k) { return __shfl(camv, k, 64); }
+// table entries e < K PER: camera k = e / PER, entry i = e - PER k = (i < NA) ? A[6 c + i] : B[27 c + i - NA], to dst[k STRIDE + i]
+template <int PER, int STRIDE, int NA>
+__device__ __forceinline__ void gram_gather(const double* __restrict__ A, const double* __restrict__ B, int camv, int K, int lane, double* __restrict__ dst) {
+    constexpr int NIT = (GRAM_KMAX * PER + 63) / 64;
+    double v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int e = lane + 64 * it, k = e / PER, i = e - PER * k;
+        const int c = gram_cam_of(camv, min(k, K - 1));                 // (past the table: a valid address, the value is dropped)
+        const double* src = (i < NA) ? A + 6 * (size_t)c + i : B + 27 * (size_t)c + (i - NA);
+        v[it] = *src;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int e = lane + 64 * it, k = e / PER, i = e - PER * k;
+        if (e < K * PER) dst[k * STRIDE + i] = v[it];
+    }
+}
 // Round 5, FUSE (every point of the problem sits in a signature group): the kernel also does k_point_lin's work -- the lanes of a point fold their V = sum Jp^T Jp, g_p and
 // focal coupling over the K observation lanes (three xor exchanges), every lane damps and inverts the 3x3 block itself, lane 0 of the point stores the record PS and g_p
 // for the back substitution and the wave adds the five point-pass sums (cost, focal sums) and the gradient maximum to its scalar slot at the end.  k_point_lin does not
@@ -723,17 +746,9 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
     const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
     const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
     const double f = focal[0];
-    // the eight camera ids ride in scalar registers (one s_load with the head of the record): the loads of the camera records below depend on the record
-    // alone, not on a second round trip for an id per lane
-    int cams[GRAM_KMAX];
-#pragma unroll
-    for (int k = 0; k < GRAM_KMAX; k++) cams[k] = __builtin_amdgcn_readfirstlane(rec[4 + k]);
-    auto cam_of = [&](int k) { int c = cams[0];
-#pragma unroll
-                               for (int q = 1; q < GRAM_KMAX; q++) c = (k == q) ? cams[q] : c;
-                               return c; };
-    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = cam_of(k); sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
-    if (lane < DC * K) { const int k = lane / DC; sScale[lane] = scale_cam[6 * cam_of(k) + off + lane - DC * k]; }
+    const int camv = rec[4 + (lane & (GRAM_KMAX - 1))];                 // the task's cameras as a lane vector (gram_cam_of)
+    gram_gather<33, GRAM_CAMREC, 6>(cam, rot, camv, K, lane, sCam);
+    { const int k = min(lane / DC, K - 1), c = gram_cam_of(camv, k); const double sc = scale_cam[6 * c + off + lane - DC * (lane / DC)]; if (lane < DC * K) sScale[lane] = sc; }
     if (lane < GRAM_NPAIR + GRAM_KMAX) sSlot[lane] = rec[12 + lane];
     v4d_ acc[NT * (NT + 1) / 2];
 #pragma unroll
@@ -924,8 +939,9 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
     {
         double out[NO];
         OctTR<NS, 4>::run(sm, out);
+        const int cam_k = gram_cam_of(camv, kq);                         // (every lane takes part in the exchange)
         if (lq < K) {
-            const int c = cam_of(lq);
+            const int c = cam_k;
             const double* sc = sScale + DC * lq;
             const int i0 = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
 #pragma unroll
@@ -1948,16 +1964,10 @@ k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, c
     const int* rec = gr_rec + (size_t)task * GRAM_REC;
     const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
     const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
-    int cams[GRAM_KMAX];
-#pragma unroll
-    for (int k = 0; k < GRAM_KMAX; k++) cams[k] = __builtin_amdgcn_readfirstlane(rec[4 + k]);
-    auto cam_of = [&](int k) { int c = cams[0];
-#pragma unroll
-                               for (int q = 1; q < GRAM_KMAX; q++) c = (k == q) ? cams[q] : c;
-                               return c; };
-    for (int e = lane; e < K * 33; e += 64) { const int k = e / 33, i = e - 33 * k, c = cam_of(k); sCam[k * GRAM_CAMREC + i] = (i < 6) ? cam[6 * c + i] : rot[27 * c + i - 6]; }
-    for (int e = lane; e < K * GBS_CAMC; e += 64) { const int k = e / GBS_CAMC, i = e - GBS_CAMC * k, c = cam_of(k); sCamC[e] = (i < 3) ? cam_c[6 * c + i] : rot_c[27 * c + i - 3]; }
-    if (lane < DC * K) { const int k = lane / DC, a = lane - DC * k, c = cam_of(k); sStep[6 * k + a] = scale_cam[6 * c + off + a] * y[c * DC + a]; }
+    const int camv = rec[4 + (lane & (GRAM_KMAX - 1))];                 // the task's cameras as a lane vector (gram_cam_of)
+    gram_gather<33, GRAM_CAMREC, 6>(cam, rot, camv, K, lane, sCam);
+    gram_gather<GBS_CAMC, GBS_CAMC, 3>(cam_c, rot_c, camv, K, lane, sCamC);
+    { const int k = min(lane / DC, K - 1), a = lane - DC * (lane / DC), c = gram_cam_of(camv, k); const double st = scale_cam[6 * c + off + a] * y[c * DC + a]; if (lane < DC * K) sStep[6 * k + a] = st; }
     const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC], fcand = focal_c[0];
     const int lp = lane & (GRAM_SUB - 1), lq = lane >> 3;
     const int kq = min(lq, K - 1);
@@ -2027,6 +2037,136 @@ k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, c
     }
 #undef GBS_LOAD
     static_assert(SC_STEP2_PT == SC_MODEL + 1 && SC_XN2_PT == SC_MODEL + 2 && SC_CAND_COST == SC_MODEL + 3, "the four sums are consecutive scalars");
+    const double t = wave_transpose_sum(acc);
+    const int slot = wave_tr_index();
+    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + wave) & (SC_NSLOT - 1)) * SC_TOTAL;
+    if (slot < 4) sadd(ds, &sl[SC_MODEL + slot], t);
+}
+
+// ---- round 6: the same pass with the point records staged through LDS and the 8 observation lanes of a point ADJACENT -------------------------------------
+// k_gram_backsub above keeps two copies of a sub-chunk's point records in registers (the one in use and the one in flight: 2 x 17 doubles per lane, every value
+// requested by the eight lanes of its point -- sixteen load instructions per sub-chunk) and folds B^T a over lanes 8 / 16 / 32 apart with ds_bpermute (three dependent
+// LDS round trips).  Here lane = 8 point + observation: a sub-chunk's observations are ONE coalesced 1 KB load; its 8 point records come in through three loads shared
+// by the wave, wait one iteration in registers, go to a wave-private LDS slice (two buffers, GBS2_PT doubles per point: the eight points' 16-byte reads fall into
+// disjoint banks) and are read where they are used; the fold over the 8 lanes of a point is three DPP exchanges (quad_perm, quad_perm, row_half_mirror) without LDS.
+// The point's step comes from the record PS alone: with w = sum over its observations of Jp^T m (m = the camera / focal part of the model residual) the step in the
+// caller's coordinates is  u = PS[6..8] - PS[0..5] w   (PS[0..5] = S V^-1 S, PS[6..8] = S V^-1 g, S = the Jacobi scales: k_point_lin) -- no g_p, no scales, no
+// reciprocal; a fixed point has an all-zero record.  Sums in another order than k_gram_backsub's (tests: oracle tolerance).
+constexpr int GBS2_PT = 18, GBS2_STAGE = 2 * GRAM_SUB * GBS2_PT, GBS2_TAIL = GBS_TAIL + GBS2_STAGE;
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double fold8_dpp(double v) {                 // sum over the 8 lanes of an aligned group, in every lane of the group
+    v += dpp_f64<0xB1>(v);                                               // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v);                                               // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0x141>(v);                                              // row_half_mirror: lane i <- lane 7 - i of the same 8 (the other quad's sum)
+    return v;
+}
+template <int DC, int WPE = 4>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+k_gram_backsub2(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+                const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam,
+                const double* __restrict__ scale_f, const double* __restrict__ PS,
+                const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
+                const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
+                const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
+                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg, long long* __restrict__ lacc = nullptr) {
+    const DetScal ds{scal, lacc};
+    constexpr int off = (DC == 6) ? 0 : 3;
+    extern __shared__ __attribute__((aligned(16))) double sB[];          // per wave: k_gram_backsub's records | point records [2][8][GBS2_PT]: X at 0, PS at 4
+    if (res_r && blockIdx.x == gridDim.x - 1) { __shared__ double red[4 * 4]; residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red); return; }
+    const int nwg = res_r ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, nwg) * (blockDim.x >> 6) + wave);
+    if (task >= ntasks) return;
+    double* sCam = sB + (size_t)wave * GBS2_TAIL;
+    double* sCamC = sCam + GRAM_KMAX * GRAM_CAMREC;
+    double* sStep = sCamC + GRAM_KMAX * GBS_CAMC;
+    double* sPt = sStep + GRAM_KMAX * 6;
+    const int* rec = gr_rec + (size_t)task * GRAM_REC;
+    const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
+    const int camv = rec[4 + (lane & (GRAM_KMAX - 1))];                 // the task's cameras as a lane vector (gram_cam_of)
+    gram_gather<33, GRAM_CAMREC, 6>(cam, rot, camv, K, lane, sCam);
+    gram_gather<GBS_CAMC, GBS_CAMC, 3>(cam_c, rot_c, camv, K, lane, sCamC);
+    { const int k = min(lane / DC, K - 1), a = lane - DC * (lane / DC), c = gram_cam_of(camv, k); const double st = scale_cam[6 * c + off + a] * y[c * DC + a]; if (lane < DC * K) sStep[6 * k + a] = st; }
+    const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC], fcand = focal_c[0];
+    const int lq = lane & (GRAM_SUB - 1), lp = lane >> 3;               // observation (= camera of the group), point of the sub-chunk
+    const int kq = min(lq, K - 1);
+    double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
+    // the wave's three record loads of a sub-chunk: A lanes [0, 24) X; B entries [0, 64) of the 8 x 12 doubles of PS, C entries [64, 96)
+    const int a_i = lane / 3, a_k = lane - 3 * a_i, b_i = lane / 12, b_k = lane - 12 * b_i, c_i = (64 + lane) / 12, c_k = 64 + lane - 12 * c_i;
+    const int a_dst = a_i * GBS2_PT + a_k, b_dst = b_i * GBS2_PT + 4 + b_k, c_dst = c_i * GBS2_PT + 4 + c_k;
+    double ra = 0.0, rb = 0.0, rc = 0.0; double2 ob;
+#define GBS2_LOAD(s0_)                                                                                                            \
+    do {                                                                                                                          \
+        if (lane < 24) ra = pts[3 * (size_t)(p0 + min((s0_) + a_i, cnt - 1)) + a_k];                                              \
+        rb = PS[12 * (size_t)(p0 + min((s0_) + b_i, cnt - 1)) + b_k];                                                             \
+        if (lane < 32) rc = PS[12 * (size_t)(p0 + min((s0_) + c_i, cnt - 1)) + c_k];                                              \
+    } while (0)
+#define GBS2_STAGE_STORE(buf_)                                                                                                    \
+    do {                                                                                                                          \
+        double* d_ = sPt + (buf_) * GRAM_SUB * GBS2_PT;                                                                           \
+        if (lane < 24) d_[a_dst] = ra;                                                                                            \
+        d_[b_dst] = rb;                                                                                                           \
+        if (lane < 32) d_[c_dst] = rc;                                                                                            \
+    } while (0)
+    GBS2_LOAD(0);
+    ob = obs_xy[j00 + (size_t)min(lp, cnt - 1) * K + kq];
+    GBS2_STAGE_STORE(0);
+    if (GRAM_SUB < cnt) GBS2_LOAD(GRAM_SUB);
+    wave_lds_handover();
+    int buf = 0;
+    for (int s0 = 0; s0 < cnt; s0 += GRAM_SUB, buf ^= 1) {
+        const bool valid = s0 + lp < cnt, act = valid && lq < K;
+        const double2 on = ob;
+        const size_t pn = (size_t)(p0 + min(s0 + lp, cnt - 1));
+        // the next sub-chunk's records (loaded one iteration ago) go to the other buffer -- its readers finished before the previous hand-over --, the one after that is requested
+        if (s0 + GRAM_SUB < cnt) {
+            GBS2_STAGE_STORE(buf ^ 1);
+            ob = obs_xy[j00 + (size_t)min(s0 + GRAM_SUB + lp, cnt - 1) * K + kq];
+            if (s0 + 2 * GRAM_SUB < cnt) GBS2_LOAD(s0 + 2 * GRAM_SUB);
+        }
+        const double* pr = sPt + (buf * GRAM_SUB + lp) * GBS2_PT;
+        const double Xn[3] = {pr[0], pr[1], pr[2]};
+        double m0 = 0.0, m1 = 0.0, r0 = 0.0, r1 = 0.0, J0[3] = {0, 0, 0}, J1[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+        if (act) {
+            const double* crec = sCam + kq * GRAM_CAMREC;
+            ObsLin L; lin_obs<DC == 6>(f, crec, crec + 6, Xn, on.x, on.y, loss, la, L);
+            double Jc[2][DC]; cam_block_raw<DC>(L, Jc);
+            m0 = L.Jf[0] * sf * yf; m1 = L.Jf[1] * sf * yf; r0 = L.r[0]; r1 = L.r[1];
+#pragma unroll
+            for (int a = 0; a < DC; a++) {
+                const double ya = sStep[6 * kq + a];
+                if (!jc_zero<DC>(0, a)) m0 += Jc[0][a] * ya;
+                if (!jc_zero<DC>(1, a)) m1 += Jc[1][a] * ya;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { J0[k] = L.Jp[0][k]; J1[k] = L.Jp[1][k]; w[k] = J0[k] * m0 + J1[k] * m1; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] = fold8_dpp(w[i]);
+        const double P[9] = {pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12]};
+        const double u[3] = {P[6] - (P[0] * w[0] + P[1] * w[1] + P[2] * w[2]), P[7] - (P[1] * w[0] + P[3] * w[1] + P[4] * w[2]), P[8] - (P[2] * w[0] + P[4] * w[1] + P[5] * w[2])};
+        const double Xc[3] = {Xn[0] - u[0], Xn[1] - u[1], Xn[2] - u[2]};
+        if (act) {
+            const double M0 = m0 + J0[0] * u[0] + J0[1] * u[1] + J0[2] * u[2], M1 = m1 + J1[0] * u[0] + J1[1] * u[1] + J1[2] * u[2];
+            acc[0] += -(M0 * r0 + M1 * r1) + 0.5 * (M0 * M0 + M1 * M1);
+            const double* cc = sCamC + kq * GBS_CAMC;
+            acc[3] += obs_cost(fcand, cc, cc + 3, Xc, on.x, on.y, loss, la);
+        }
+        if (valid && lq == 0) {                                          // the point's candidate and step norms, once per point (a fixed point: zero record, zero step, not counted)
+#pragma unroll
+            for (int k = 0; k < 3; k++) pts_c[3 * pn + k] = Xc[k];
+            if (P[0] > 0.0) { acc[1] += u[0] * u[0] + u[1] * u[1] + u[2] * u[2]; acc[2] += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]; }
+        }
+        wave_lds_handover();                                             // this sub-chunk's records are read, the next one's are written
+    }
+#undef GBS2_LOAD
+#undef GBS2_STAGE_STORE
     const double t = wave_transpose_sum(acc);
     const int slot = wave_tr_index();
     double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + wave) & (SC_NSLOT - 1)) * SC_TOTAL;

@@ -342,6 +342,17 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     if (grouped) {
                         const int ng = (int)(F.gr_rec.size() / GRAM_REC);
                         const bool res_here = res && all_grouped;
+                        // round 6: k_gram_backsub2 (point records through LDS, DPP folds); SSFM_GBS_V=1: the kernel of rounds 3-5
+                        static const int gbs_v = knob_env_int("SSFM_GBS_V", 2);
+#define GBS2_LAUNCH(WPE_) LAUNCH(h, KID_GRAM_BACKSUB, (k_gram_backsub2<DC, WPE_>), (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, \
+                               h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p, \
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc)
+                        static const int gbs_wpe = knob_env_int("SSFM_GBS_WPE", 4);
+                        if (gbs_v == 2 && gbs_wpe == 3) GBS2_LAUNCH(3);
+                        else if (gbs_v == 2 && gbs_wpe == 5) GBS2_LAUNCH(5);
+                        else if (gbs_v == 2) GBS2_LAUNCH(4);
+#undef GBS2_LAUNCH
+                        else
                         LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub<DC>, (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
                                h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc);
