@@ -8,6 +8,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "big"
 ctx = ba.Context(0)
 if which == "big":
     prob = synth.make_circle(4000, 1500000, 8, spherical=False, focal_fixed=True)
+elif which == "config2":
+    prob = synth.make_circle(300, 100000, 6, spherical=False, focal_fixed=True)
 else:
     prob = synth.make_circle(600, 100000, 6, spherical=False, focal_fixed=True)
 _, _, _, s = ba.optimize(ctx, prob)

@@ -721,7 +721,7 @@ __device__ __forceinline__ void gram_gather(const double* __restrict__ A, const 
 // for the back substitution and the wave adds the five point-pass sums (cost, focal sums) and the gradient maximum to its scalar slot at the end.  k_point_lin does not
 // run then (15.5 us of a 173 us iteration at config 2, 180 of 1550 at the configs[4] size), PS is not read back and the observations are read one pass less.
 // spec (speculative launch behind k_publish, like k_point_lin's): [go, radius] as decided on the device.
-struct GramFuse { const double* scale_pt; double radius, min_diag, max_diag; double* PS_out; double* gp_out; double* scal; const double* spec; };
+struct GramFuse { const double* scale_pt; double radius, min_diag, max_diag; double* PS_out; double* gp_out; double* scal; const double* spec; int emit_skip = 0; };
 // one wave task of k_schur_gram / k_schur_gram_any (below): the task's tile shape (NT, TI) is a template parameter, the task index an argument
 template <int DC, int NT, int TI, bool FUSE>
 __device__ __forceinline__ void
@@ -929,17 +929,51 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
     }
 #undef GRAM_LOAD
     if (dbg) t_2 = wall_clock64();
-    // camera-side sums: fold over the 8 point lanes of every camera; the lane that holds value i adds it where k_cam_sums2 would -- except Jc^T Jc, which goes
-    // to LDS (sU[k][DC x DC], over sY: the tiles are done) and rides with the Gram diagonal of its camera: one atomic per entry of a diagonal block, not two
+    if (fz.emit_skip && (task % fz.emit_skip) != 0) { if (dbg && lane == 0) { long long* d = dbg + 4 * (size_t)task; d[0] = t_0; d[1] = t_1; d[2] = t_2; d[3] = wall_clock64(); } return; }   // EXPERIMENT (lab)
+    // ---- emission (round 6: by BLOCKS, through LDS).  Rounds 3-5 went from the accumulators straight to the atomics: every (tile, register) entry worked out its camera
+    // pair, slot and transposition with integer divisions behind divergent guards -- ~130 instructions per entry, ~2000 per task, 7-8 us of a 39 us task with nothing else
+    // on its SIMD (SSFM_GRAM_STAMPS: a single emitting task took 8.3 us).  Now the scaled, negated tiles go to LDS as the lower triangle of G (bands of 16 rows: band t
+    // has 16 (t + 1) + 1 columns; a store is lane coordinates + a constant), Jc^T Jc of every camera is added to its diagonal block there, and the K (K + 1) / 2 blocks
+    // leave in block order: entry e of block (a, b) is G[6 a + e / DC][6 b + e % DC] -- consecutive lanes, consecutive addresses of S.
     wave_lds_handover();
-    double* sU = sYw;
+    double* sG = sYw;                                                    // over sY and the camera records (both done): gram_g_off(DC K) <= rows_alloc GRAM_LD + GRAM_KMAX GRAM_CAMREC
+    auto g_off = [](int R) { const int t = R >> 4; return 128 * t * t + 144 * t + (R & 15) * (16 * t + 17); };
+    {
+        double cs[NT], rs[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { cs[t] = sScale[min(16 * t + li, DC * GRAM_KMAX - 1)];
+#pragma unroll
+                                       for (int reg = 0; reg < 4; reg++) rs[t][reg] = sScale[min(16 * t + lk + 4 * reg, DC * GRAM_KMAX - 1)]; }
+        int tix = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)                        // (rows / columns >= DC K: whatever the scales' padding gives -- no block reads them)
+                    if (16 * ti + lk + 4 * reg < rows_alloc) sG[(128 * ti * ti + 144 * ti) + (lk + 4 * reg) * (16 * ti + 17) + 16 * tj + li] = -acc[tix][reg] * rs[ti][reg] * cs[tj];
+                tix++;
+            }
+        if constexpr (TI > 0) {
+            const int R = 16 * NT + (lane >> 4);
+            const double rsc = sScale[min(R, DC * GRAM_KMAX - 1)];
+#pragma unroll
+            for (int u = 0; u < TI; u++) {
+                const int C = 16 * u + ((lane >> 2) & 3) * 4 + (lane & 3);
+                sG[(128 * NT * NT + 144 * NT) + (lane >> 4) * (16 * NT + 17) + C] = -tacc[u] * rsc * sScale[min(C, DC * GRAM_KMAX - 1)];
+            }
+        }
+    }
     // atomics-free emission (round 6, det_acc.h: DetZone::part): this task's stretch of the partial buffer -- blocks, then the cameras' vectors
     double* const PB = dz.part ? dz.part + dz.part_off[task] : nullptr;
     double* const PV = PB ? PB + (K * (K + 1) / 2) * BB : nullptr;
+    const int cam_k = gram_cam_of(camv, kq);                             // (every lane takes part in the exchange)
+    wave_lds_handover();
+    // camera-side sums: fold over the 8 point lanes of every camera; the lane that holds value i adds it where k_cam_sums2 would -- except Jc^T Jc, which joins the
+    // diagonal block of its camera in G (lower triangle: one owner lane per entry)
     {
         double out[NO];
         OctTR<NS, 4>::run(sm, out);
-        const int cam_k = gram_cam_of(camv, kq);                         // (every lane takes part in the exchange)
         if (lq < K) {
             const int c = cam_k;
             const double* sc = sScale + DC * lq;
@@ -950,10 +984,10 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
                 const double v = out[j];
                 if (i < NU) {
                     int a = 0, rem = i; while (rem >= DC - a) { rem -= DC - a; a++; }
-                    const int b = a + rem;
+                    const int b = a + rem;                                // b >= a: the entry (row DC lq + b, column DC lq + a) of the lower triangle
                     const double w = v * sc[a] * sc[b];
-                    sU[lq * BB + a * DC + b] = w;
-                    if (b != a) sU[lq * BB + b * DC + a] = w; else if (PV) PV[lq * 5 * DC + a] = w; else zadd(dz, &Udiag[c * DC + a], w);
+                    sG[g_off(DC * lq + b) + DC * lq + a] += w;
+                    if (b == a) { if (PV) PV[lq * 5 * DC + a] = w; else zadd(dz, &Udiag[c * DC + a], w); }
                 } else if (i < NU + DC) { const int a = i - NU; if (PV) { PV[lq * 5 * DC + DC + a] = v * sc[a]; PV[lq * 5 * DC + 3 * DC + a] = v * sc[a]; } else { zadd(dz, &rhs[c * DC + a], v * sc[a]); zadd(dz, &gcraw[c * DC + a], v * sc[a]); } }
                 else if (i < NU + 2 * DC) { const int a = i - NU - DC; if (PV) PV[lq * 5 * DC + 2 * DC + a] = v * sc[a]; else zadd(dz, &rhs[c * DC + a], v * sc[a]); }
                 else if (i < NS && focal_free) { const int a = i - NU - 2 * DC; if (PV) PV[lq * 5 * DC + 4 * DC + a] = v * sc[a]; else zadd(dz, &Sfc[c * DC + a], v * sc[a]); }
@@ -961,53 +995,39 @@ schur_gram_task(const double* __restrict__ cam, const double* __restrict__ rot, 
         }
     }
     wave_lds_handover();
-    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg.  Everything the emission needs sits in LDS: no load
-    // between the last tile and the atomics (the first version fetched slot, cameras and scales per entry behind divergent branches: ~30 us per task)
-    int tix = 0;
-#pragma unroll
-    for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-        for (int tj = 0; tj <= ti; tj++) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int R = 16 * ti + lk + 4 * reg, C = 16 * tj + li;
-                const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
-                if (a < K && b <= a) {
-                    const double v = -acc[tix][reg] * sScale[R] * sScale[C];
-                    if (b < a) {
-                        const int sl = sSlot[a * (a - 1) / 2 + b];
-                        const int e = (sl & (1 << 30)) ? (db * DC + da) : (da * DC + db);
-                        if (PB) PB[(a * (a + 1) / 2 + b) * BB + e] = v;
-                        else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[e], v);
-                    } else {                                            // diagonal block of camera a: a diagonal tile holds both triangles, a tile below the diagonal only (da > db)
-                        const double w = v + sU[a * BB + da * DC + db];
-                        if (PB) { double* blk = PB + (a * (a + 1) / 2 + a) * BB; blk[da * DC + db] = w; if (ti != tj) blk[db * DC + da] = w; }
-                        else { double* blk = S_val + (size_t)sDiag[a] * BB; zadd(dz, &blk[da * DC + db], w); if (ti != tj) zadd(dz, &blk[db * DC + da], w); }
-                    }
+    if constexpr (2 * BB > 64) {
+        // one block per instruction on lanes [0, BB): the block's cameras, slot and orientation are wave-uniform (scalar loop counters, one broadcast LDS read),
+        // the lane's entry (da, db) never changes -- an iteration is a dozen vector instructions and one atomic over BB consecutive doubles of S
+        const int e = min(lane, BB - 1), da = e / DC, db = e - da * DC, eT = db * DC + da;
+        const bool on = lane < BB;
+        for (int a = 0; a < K; a++) {
+            const int Ra = DC * a + da;
+            for (int b = 0; b <= a; b++) {
+                const int C = DC * b + db;
+                const double v = sG[(b < a) ? g_off(Ra) + C : g_off(max(Ra, C)) + min(Ra, C)];
+                const int sl = (b < a) ? sSlot[a * (a - 1) / 2 + b] : sDiag[a];
+                const int eo = (b < a && (sl & (1 << 30))) ? eT : e;      // the block as S stores it
+                if (on) {
+                    if (PB) PB[(a * (a + 1) / 2 + b) * BB + eo] = v;       // (fold lists, ba_flatten.h: block (a, b) of the task at (a (a + 1) / 2 + b) BB)
+                    else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[eo], v);
                 }
             }
-            tix++;
         }
-    if constexpr (TI > 0) {
-        // rows 16 NT .. + 3 against every column: off-diagonal blocks to their slots, a camera's own block to its diagonal block -- with the mirrored entry where
-        // the column lies in the 16-row tiles, whose rows never met these columns
-#pragma unroll
-        for (int u = 0; u < TI; u++) {
-            const int g = 4 * u + ((lane >> 2) & 3), R = 16 * NT + (lane >> 4), C = 4 * g + (lane & 3);
-            const int a = R / DC, da = R - a * DC, b = C / DC, db = C - b * DC;
-            if (a < K && b <= a && C < DC * K) {
-                const double v = -tacc[u] * sScale[R] * sScale[C];
-                if (b < a) {
-                    const int sl = sSlot[a * (a - 1) / 2 + b];
-                    const int e = (sl & (1 << 30)) ? (db * DC + da) : (da * DC + db);
-                    if (PB) PB[(a * (a + 1) / 2 + b) * BB + e] = v;
-                    else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[e], v);
-                } else {
-                    const double w = v + sU[a * BB + da * DC + db];
-                    if (PB) { double* blk = PB + (a * (a + 1) / 2 + a) * BB; blk[da * DC + db] = w; if (C < 16 * NT) blk[db * DC + da] = w; }
-                    else { double* blk = S_val + (size_t)sDiag[a] * BB; zadd(dz, &blk[da * DC + db], w); if (C < 16 * NT) zadd(dz, &blk[db * DC + da], w); }
-                }
-            }
+    } else {
+        const int nent = (K * (K + 1) / 2) * BB;
+        for (int idx = lane; idx < nent; idx += 64) {
+            const int blk = idx / BB, e = idx - blk * BB, da = e / DC, db = e - da * DC;
+            const int a = (int)((__fsqrt_rn((float)(8 * blk + 1)) - 1.0f) * 0.5f);        // blk = a (a + 1) / 2 + b, b <= a (8 blk + 1 = (2 a + 1)^2 + 8 b: exact in float)
+            const int b = blk - a * (a + 1) / 2;
+            const int R = DC * a + da, C = DC * b + db;
+            const double v = sG[g_off(max(R, C)) + min(R, C)];           // (max / min: the upper triangle of a diagonal block)
+            if (b < a) {
+                const int sl = sSlot[a * (a - 1) / 2 + b];
+                const int eo = (sl & (1 << 30)) ? (db * DC + da) : e;      // the block as S stores it
+                if (PB) PB[blk * BB + eo] = v;
+                else zadd(dz, &(S_val + (size_t)(sl & 0x3fffffff) * BB)[eo], v);
+            } else if (PB) PB[idx] = v;
+            else zadd(dz, &(S_val + (size_t)sDiag[a] * BB)[e], v);
         }
     }
     if (FUSE) {                                                          // the point pass's sums and gradient maximum, one wave = one scalar slot (k_point_lin's rule)

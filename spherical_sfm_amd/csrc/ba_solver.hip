@@ -199,7 +199,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
             auto tile_class = [&](int K) { const int rows = DC * K; return rows <= 16 ? 0 : (rows <= 20 && gram_t4) ? 1 : rows <= 32 ? 2 : (rows <= 36 && gram_t4) ? 3 : 4; };
             int cls_end[5] = {0, 0, 0, 0, 0};
             for (int t = 0; t < ng; t++) { const int c0 = tile_class(F.gr_rec[(size_t)t * GRAM_REC + 2]); for (int c = c0; c < 5; c++) cls_end[c] = t + 1; }
-            GramFuse fz; fz.scale_pt = h->scale_pt.p; fz.radius = rad; fz.min_diag = O.min_lm_diagonal; fz.max_diag = O.max_lm_diagonal; fz.PS_out = h->Vs.p; fz.gp_out = h->gp.p; fz.scal = z.scal; fz.spec = spec;
+            GramFuse fz; fz.scale_pt = h->scale_pt.p; fz.radius = rad; fz.min_diag = O.min_lm_diagonal; fz.max_diag = O.max_lm_diagonal; fz.PS_out = h->Vs.p; fz.gp_out = h->gp.p; fz.scal = z.scal; fz.emit_skip = SSFM_LAB_KNOB("SSFM_GRAM_EMIT_SKIP", 0); fz.spec = spec;
 #define SSFM_GRAM_LAUNCH_(CLS_, NT_, TI_, FUSE_)                                                                                                       \
             do {                                                                                                                                       \
                 const int t0 = (CLS_ == 0) ? 0 : cls_end[(CLS_ >= 1) ? CLS_ - 1 : 0], t1 = cls_end[CLS_];                                             \
@@ -242,6 +242,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                 for (int t = 0; t < ng; t++) { tmin = std::min(tmin, st2[4 * t]); tmax = std::max(tmax, st2[4 * t + 3]); a += st2[4 * t + 1] - st2[4 * t]; b += st2[4 * t + 2] - st2[4 * t + 1]; c += st2[4 * t + 3] - st2[4 * t + 2]; }
                 std::fprintf(stderr, "[gram] %d tasks, kernel span %.1f us; mean per task: start + first linearisation %.2f us, tiles + other sub-chunks %.2f us, emission %.2f us\n", ng, (tmax - tmin) * 0.01,
                              a / ng * 0.01, b / ng * 0.01, c / ng * 0.01);
+                { double s_mean = 0, s_max = 0, e_mean = 0, a_max = 0, b_max = 0, c_max = 0;
+                  for (int t = 0; t < ng; t++) { const double so = (st2[4 * t] - tmin) * 0.01; s_mean += so; s_max = std::max(s_max, so); e_mean += (st2[4 * t + 3] - tmin) * 0.01;
+                                                 a_max = std::max(a_max, (st2[4 * t + 1] - st2[4 * t]) * 0.01); b_max = std::max(b_max, (st2[4 * t + 2] - st2[4 * t + 1]) * 0.01); c_max = std::max(c_max, (st2[4 * t + 3] - st2[4 * t + 2]) * 0.01); }
+                  std::fprintf(stderr, "[gram] task start after the first: mean %.2f max %.2f us; task end mean %.2f us; longest phases %.2f | %.2f | %.2f us\n", s_mean / ng, s_max, e_mean / ng, a_max, b_max, c_max); }
                 (void)hipFree(gram_dbg); gram_dbg = nullptr; gram_stamps_done = true;
             }
             return SSFM_OK;
