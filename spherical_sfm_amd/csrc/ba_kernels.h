@@ -646,6 +646,9 @@ k_schur_pairs2(const double* __restrict__ cam, const double* __restrict__ rot, c
 // the Schur corrections of the K diagonal blocks are the blocks of ONE Gram matrix  G = sum_points Y Y^T  -- every observation is linearised ONCE (the
 // pair kernel re-linearises it K - 1 times, k_cam_sums2 once more) and the products run as v_mfma_f64_16x16x4_f64 tiles.  FP64 MFMA has the VALU's flop
 // rate on gfx950; what it buys is issue slots: one instruction per 1024 multiply-adds with its operands from LDS, against ~470 VALU instructions per 64 pairs.
+// (Round 6, measured: a wave does NOT overlap its fp64 matrix products with its own fp64 vector work -- the hand-interleaved, double-buffered loop of
+// profiles/r06_notes.md r06k ran the 14 sub-chunks of a config-2 task in 24.3 us against 22.6 one after the other: both use the same fp64 units, so a sub-chunk costs
+// its ~2000 vector cycles PLUS its ~1450 matrix cycles whatever the order.)
 // One wave per task, sub-chunks of 8 points: lane (point = lane & 7, k = lane >> 3) linearises observation k of its point (camera records staged in LDS
 // once per task) and lays Y out in LDS as sY[row = DC k + d][3 point + c] (24 columns, leading dimension 28: the fragment loads touch every bank twice,
 // the hardware minimum for 64 x 8 bytes); then the wave runs the tiles of the lower triangle over the 6 k-steps, accumulating across sub-chunks.
@@ -2093,14 +2096,16 @@ k_gram_backsub2(const double* __restrict__ cam, const double* __restrict__ rot, 
                 const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
                 const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
                 const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
-                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg, long long* __restrict__ lacc = nullptr) {
+                const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg, long long* __restrict__ lacc = nullptr,
+                const int split = 1) {        // split: waves per task, each with a contiguous share of the task's sub-chunks (small problems: more waves per SIMD)
     const DetScal ds{scal, lacc};
     constexpr int off = (DC == 6) ? 0 : 3;
     extern __shared__ __attribute__((aligned(16))) double sB[];          // per wave: k_gram_backsub's records | point records [2][8][GBS2_PT]: X at 0, PS at 4
     if (res_r && blockIdx.x == gridDim.x - 1) { __shared__ double red[4 * 4]; residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red); return; }
     const int nwg = res_r ? (int)gridDim.x - 1 : (int)gridDim.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, nwg) * (blockDim.x >> 6) + wave);
+    const int gtask = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, nwg) * (blockDim.x >> 6) + wave);
+    const int task = gtask / split, part = gtask - task * split;
     if (task >= ntasks) return;
     double* sCam = sB + (size_t)wave * GBS2_TAIL;
     double* sCamC = sCam + GRAM_KMAX * GRAM_CAMREC;
@@ -2109,6 +2114,9 @@ k_gram_backsub2(const double* __restrict__ cam, const double* __restrict__ rot, 
     const int* rec = gr_rec + (size_t)task * GRAM_REC;
     const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
     const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
+    const int sub_per = ((cnt + GRAM_SUB - 1) / GRAM_SUB + split - 1) / split;
+    const int s_begin = part * sub_per * GRAM_SUB, s_end = min(cnt, s_begin + sub_per * GRAM_SUB);
+    if (s_begin >= cnt) return;
     const int camv = rec[4 + (lane & (GRAM_KMAX - 1))];                 // the task's cameras as a lane vector (gram_cam_of)
     gram_gather<33, GRAM_CAMREC, 6>(cam, rot, camv, K, lane, sCam);
     gram_gather<GBS_CAMC, GBS_CAMC, 3>(cam_c, rot_c, camv, K, lane, sCamC);
@@ -2134,21 +2142,21 @@ k_gram_backsub2(const double* __restrict__ cam, const double* __restrict__ rot, 
         d_[b_dst] = rb;                                                                                                           \
         if (lane < 32) d_[c_dst] = rc;                                                                                            \
     } while (0)
-    GBS2_LOAD(0);
-    ob = obs_xy[j00 + (size_t)min(lp, cnt - 1) * K + kq];
+    GBS2_LOAD(s_begin);
+    ob = obs_xy[j00 + (size_t)min(s_begin + lp, cnt - 1) * K + kq];
     GBS2_STAGE_STORE(0);
-    if (GRAM_SUB < cnt) GBS2_LOAD(GRAM_SUB);
+    if (s_begin + GRAM_SUB < s_end) GBS2_LOAD(s_begin + GRAM_SUB);
     wave_lds_handover();
     int buf = 0;
-    for (int s0 = 0; s0 < cnt; s0 += GRAM_SUB, buf ^= 1) {
+    for (int s0 = s_begin; s0 < s_end; s0 += GRAM_SUB, buf ^= 1) {
         const bool valid = s0 + lp < cnt, act = valid && lq < K;
         const double2 on = ob;
         const size_t pn = (size_t)(p0 + min(s0 + lp, cnt - 1));
         // the next sub-chunk's records (loaded one iteration ago) go to the other buffer -- its readers finished before the previous hand-over --, the one after that is requested
-        if (s0 + GRAM_SUB < cnt) {
+        if (s0 + GRAM_SUB < s_end) {
             GBS2_STAGE_STORE(buf ^ 1);
             ob = obs_xy[j00 + (size_t)min(s0 + GRAM_SUB + lp, cnt - 1) * K + kq];
-            if (s0 + 2 * GRAM_SUB < cnt) GBS2_LOAD(s0 + 2 * GRAM_SUB);
+            if (s0 + 2 * GRAM_SUB < s_end) GBS2_LOAD(s0 + 2 * GRAM_SUB);
         }
         const double* pr = sPt + (buf * GRAM_SUB + lp) * GBS2_PT;
         const double Xn[3] = {pr[0], pr[1], pr[2]};

@@ -337,20 +337,25 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                 } else {
                     // the points of signature groups take k_gram_backsub (lane = observation, camera records in LDS); k_point_backsub keeps the others and
                     // the residual check's extra workgroup
-                    // Its time follows the POINTS (8 lanes per point whatever K), k_point_backsub's the observations: measured (scripts/prof_gram_backsub.py) 27.3 / 28.1 us
-                    // at K = 6 / 8 against 23.4 / 31.7 (100k points) and 271 / 278 against 284 / 379 (1.5 M points): on from 7 observations per point on average.
+                    // Its time follows the POINTS (8 lanes per point whatever K), k_point_backsub's the observations: measured (rounds 3-5, k_gram_backsub) 27.3 / 28.1 us
+                    // at K = 6 / 8 against 23.4 / 31.7 (100k points) and 271 / 278 against 284 / 379 (1.5 M points).  Round 6, k_gram_backsub2: 195 us at 1.5 M points (K = 8),
+                    // 21.1 against 23.0 us at config 2 (K = 6, four waves per task): on from 6 observations per point on average.
                     // SSFM_GRAM_BACKSUB=0 / 1 forces it off / on.
                     const int gram_bs = gram_bs_env;
-                    const bool grouped = !fused_publish && !F.gr_rec.empty() && (gram_bs < 0 ? F.gram_obs >= 7 * F.gram_points : gram_bs != 0);
+                    const bool grouped = !fused_publish && !F.gr_rec.empty() && (gram_bs < 0 ? F.gram_obs >= 6 * F.gram_points : gram_bs != 0);
                     const bool all_grouped = grouped && F.gram_points == F.nP;               // then the residual check's workgroup rides with k_gram_backsub
                     if (grouped) {
                         const int ng = (int)(F.gr_rec.size() / GRAM_REC);
                         const bool res_here = res && all_grouped;
                         // round 6: k_gram_backsub2 (point records through LDS, DPP folds); SSFM_GBS_V=1: the kernel of rounds 3-5
                         static const int gbs_v = knob_env_int("SSFM_GBS_V", 2);
-#define GBS2_LAUNCH(WPE_) LAUNCH(h, KID_GRAM_BACKSUB, (k_gram_backsub2<DC, WPE_>), (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, \
+                        // waves per task: a small problem (config 2: 900 tasks on 1024 SIMDs) runs with several waves per SIMD, each with a share of its task's sub-chunks
+                        // (config 2, hipEvent: 1 wave per task 26.3 us, 2: 24, 4: 21.1, 6 / 8: 24; k_point_backsub 23.0)
+                        static const int gbs_split_env = knob_env_int("SSFM_GBS_SPLIT", 0);
+                        const int gbs_split = gbs_split_env > 0 ? std::min(8, gbs_split_env) : std::max(1, std::min(4, (4 * 4 * ctx->num_cus / 2) / std::max(1, ng)));
+#define GBS2_LAUNCH(WPE_) LAUNCH(h, KID_GRAM_BACKSUB, (k_gram_backsub2<DC, WPE_>), (ng * gbs_split + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, \
                                h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p, \
-                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc)
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc, gbs_split)
                         static const int gbs_wpe = knob_env_int("SSFM_GBS_WPE", 4);
                         if (gbs_v == 2 && gbs_wpe == 3) GBS2_LAUNCH(3);
                         else if (gbs_v == 2 && gbs_wpe == 5) GBS2_LAUNCH(5);

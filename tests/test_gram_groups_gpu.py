@@ -91,7 +91,9 @@ def test_which_kernels_run(gpu_ctx, monkeypatch):
     full = synth.make_circle(60, 60 * 70, 6, spherical=False, focal_fixed=True)
     k = kernels(full)
     assert "k_schur_gram" in k and "k_schur_pairs2" not in k and "k_cam_sums2" not in k
-    assert "k_point_backsub" in k and "k_gram_backsub" not in k          # 6 observations per point: the lane-per-point back substitution
+    assert "k_gram_backsub" in k and "k_point_backsub" not in k          # 6 observations per point (round 6, k_gram_backsub2): the grouped back substitution
+    k = kernels(synth.make_circle(60, 60 * 70, 5, spherical=False, focal_fixed=True))
+    assert "k_point_backsub" in k and "k_gram_backsub" not in k          # 5 per point: the lane-per-point back substitution
     full8 = synth.make_circle(80, 80 * 70, 8, spherical=False, focal_fixed=True, check_in_frame=False, xy_range=0.25)
     k = kernels(full8)
     assert "k_gram_backsub" in k and "k_point_backsub" not in k          # 8 per point, every point grouped: the residual check rides with k_gram_backsub
