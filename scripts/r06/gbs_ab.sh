@@ -1,4 +1,4 @@
-# usage (GPU box): bash scripts/r06/gbs_ab.sh "ENV=.." ...  -- k_gram_backsub variants at the configs[4] size (scripts/dev/scale.py, hipEvent averages); SSFM_GBS_V=1: the kernel of rounds 3-5
+# usage (GPU box): bash scripts/r06/gbs_ab.sh "ENV=.." ...  -- k_gram_backsub2 under environments (e.g. SSFM_GBS_SPLIT=n) at the configs[4] size (scripts/dev/scale.py, hipEvent averages)
 cd $GRAFT_REPO_ROOT
 for e in "$@"; do
   echo "== [$e]"

@@ -1954,120 +1954,16 @@ k_point_backsub(const double* __restrict__ cam, const double* __restrict__ rot, 
     }
 }
 
-// ---- back substitution + candidate + both costs for the points of SIGNATURE GROUPS (round 3) -------------------------------------------------
+// ---- back substitution + candidate + both costs for the points of SIGNATURE GROUPS (round 3; the kernel of rounds 3-5, k_gram_backsub, is in the history:
+// lane = (point, observation) with the point's 8 lanes 8 apart, two register copies of a sub-chunk's point records, folds by ds_bpermute -- 258 us at the configs[4] size) ----
 // What k_point_backsub does with a lane per point and one dependent camera-table gather per observation, in k_schur_gram's layout: wave task = a run of
 // points with the same K <= 8 cameras, sub-chunks of 8 points, lane = (point, observation).  The K camera records (current and candidate) and the cameras'
-// steps sit in LDS, every lane linearises ONE observation, the per-point sums (|a|^2, a.r, B^T B, B^T a: 11 doubles) are folded over the 8 observation
-// lanes of the point with three xor-shuffles, every lane of the point then knows the point's step and evaluates ITS observation at the candidate.
-// No dependent index load anywhere (the observations of a group are consecutive, K per point); the next sub-chunk's records are in flight during the arithmetic.
+// steps sit in LDS, every lane linearises ONE observation, what the point's step needs is folded over the 8 observation lanes of the point, every lane of the
+// point then knows the step and evaluates ITS observation at the candidate.  No dependent index load anywhere (the observations of a group are consecutive,
+// K per point); the next sub-chunk's records are in flight during the arithmetic.
 constexpr int GBS_CAMC = 12, GBS_TAIL = GRAM_KMAX * (GRAM_CAMREC + GBS_CAMC + 6), GBS_WAVES = 4;
-template <int DC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs + 64 B of scratch: 277 -> 254 us at the configs[4] size; 4 waves (128) spill: 532
-k_gram_backsub(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
-               const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam,
-               const double* __restrict__ scale_pt, const double* __restrict__ scale_f, const double* __restrict__ PS, const double* __restrict__ gp,
-               const double* __restrict__ y, int Nc, int loss, double la, const double* __restrict__ cam_c, const double* __restrict__ rot_c,
-               const double* __restrict__ focal_c, double* __restrict__ pts_c, double* __restrict__ scal,
-               // residual check of the reduced solve by one extra workgroup behind the task workgroups when res_r is given (as in k_point_backsub)
-               const double* __restrict__ res_b, const double* __restrict__ res_q, const double* __restrict__ res_Sfc,
-               const double* __restrict__ res_Sff, double res_tol2, double* __restrict__ res_r, double* __restrict__ res_pcg, long long* __restrict__ lacc = nullptr) {
-    const DetScal ds{scal, lacc};
-    constexpr int off = (DC == 6) ? 0 : 3;
-    extern __shared__ __attribute__((aligned(16))) double sB[];          // per wave: camera records [K][34] | candidate [t | R] [K][12] | scaled camera steps [K][6]
-    if (res_r && blockIdx.x == gridDim.x - 1) { __shared__ double red[4 * 4]; residual_check_body(Nc * DC, y, res_b, res_q, res_Sfc, res_Sff, res_tol2, res_r, res_pcg, red); return; }
-    const int nwg = res_r ? (int)gridDim.x - 1 : (int)gridDim.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // (one WORKGROUP per task with its four waves taking the sub-chunks in turn -- four times the waves -- was slower: 25.9 -> 33.4 us at config 2, 277 -> 353 us
-    // at the configs[4] size)
-    const int task = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, nwg) * (blockDim.x >> 6) + wave);
-    if (task >= ntasks) return;
-    double* sCam = sB + (size_t)wave * GBS_TAIL;
-    double* sCamC = sCam + GRAM_KMAX * GRAM_CAMREC;
-    double* sStep = sCamC + GRAM_KMAX * GBS_CAMC;
-    const int* rec = gr_rec + (size_t)task * GRAM_REC;
-    const int p0 = __builtin_amdgcn_readfirstlane(rec[0]), cnt = __builtin_amdgcn_readfirstlane(rec[1]), K = __builtin_amdgcn_readfirstlane(rec[2]);
-    const int j00 = __builtin_amdgcn_readfirstlane(rec[3]);
-    const int camv = rec[4 + (lane & (GRAM_KMAX - 1))];                 // the task's cameras as a lane vector (gram_cam_of)
-    gram_gather<33, GRAM_CAMREC, 6>(cam, rot, camv, K, lane, sCam);
-    gram_gather<GBS_CAMC, GBS_CAMC, 3>(cam_c, rot_c, camv, K, lane, sCamC);
-    { const int k = min(lane / DC, K - 1), a = lane - DC * (lane / DC), c = gram_cam_of(camv, k); const double st = scale_cam[6 * c + off + a] * y[c * DC + a]; if (lane < DC * K) sStep[6 * k + a] = st; }
-    const double f = focal[0], sf = scale_f[0], yf = y[Nc * DC], fcand = focal_c[0];
-    const int lp = lane & (GRAM_SUB - 1), lq = lane >> 3;
-    const int kq = min(lq, K - 1);
-    double acc[4] = {0, 0, 0, 0};   // model, step2, xn2, candidate cost
-    double X[3], sp[3], g3[3], Vi[6]; double2 ob;
-#define GBS_LOAD(s0_)                                                                                                             \
-    do {                                                                                                                          \
-        const size_t p_ = (size_t)(p0 + min((s0_) + lp, cnt - 1));                                                                \
-        _Pragma("unroll") for (int k = 0; k < 3; k++) { X[k] = pts[3 * p_ + k]; sp[k] = scale_pt[3 * p_ + k]; g3[k] = gp[3 * p_ + k]; } \
-        _Pragma("unroll") for (int k = 0; k < 6; k++) Vi[k] = PS[12 * p_ + k];                                                     \
-        ob = obs_xy[j00 + (size_t)min((s0_) + lp, cnt - 1) * K + kq];                                                             \
-    } while (0)
-    constexpr int s_step = GRAM_SUB;
-    GBS_LOAD(0);
-    wave_lds_handover();
-    for (int s0 = 0; s0 < cnt; s0 += s_step) {
-        const bool valid = s0 + lp < cnt, act = valid && lq < K;
-        const double Xn[3] = {X[0], X[1], X[2]}, spn[3] = {sp[0], sp[1], sp[2]}, gn[3] = {g3[0], g3[1], g3[2]}, Vn[6] = {Vi[0], Vi[1], Vi[2], Vi[3], Vi[4], Vi[5]};
-        const double2 on = ob;
-        const size_t pn = (size_t)(p0 + min(s0 + lp, cnt - 1));
-        if (s0 + s_step < cnt) GBS_LOAD(s0 + s_step);
-        // this observation: a = camera / focal part of J s, B = Jp diag(s_p).  With M = a + B z (z = the point's step) the model cost change is
-        // -sum M.(r - M/2): only B^T a has to be known per POINT before z is (three values folded over the 8 observation lanes); M itself is per lane
-        double m0 = 0.0, m1 = 0.0, r0 = 0.0, r1 = 0.0, B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, Ba[3] = {0, 0, 0};
-        if (act) {
-            const double* crec = sCam + kq * GRAM_CAMREC;
-            ObsLin L; lin_obs<DC == 6>(f, crec, crec + 6, Xn, on.x, on.y, loss, la, L);
-            double Jc[2][DC]; cam_block_raw<DC>(L, Jc);
-            m0 = L.Jf[0] * sf * yf; m1 = L.Jf[1] * sf * yf; r0 = L.r[0]; r1 = L.r[1];
-#pragma unroll
-            for (int a = 0; a < DC; a++) {
-                const double ya = sStep[6 * kq + a];
-                if (!jc_zero<DC>(0, a)) m0 += Jc[0][a] * ya;
-                if (!jc_zero<DC>(1, a)) m1 += Jc[1][a] * ya;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) { B0[k] = L.Jp[0][k] * spn[k]; B1[k] = L.Jp[1][k] * spn[k]; Ba[k] = B0[k] * m0 + B1[k] * m1; }
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { double v = Ba[i]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); Ba[i] = v; }
-        const double b[3] = {gn[0] - Ba[0], gn[1] - Ba[1], gn[2] - Ba[2]};
-        double yp[3] = {0.0, 0.0, 0.0};
-        if (spn[0] > 0.0) {
-            const double is[3] = {fast_rcp(spn[0]), fast_rcp(spn[1]), fast_rcp(spn[2])};
-            const double bs[3] = {b[0] * is[0], b[1] * is[1], b[2] * is[2]};
-            yp[0] = (Vn[0] * bs[0] + Vn[1] * bs[1] + Vn[2] * bs[2]) * is[0];
-            yp[1] = (Vn[1] * bs[0] + Vn[3] * bs[1] + Vn[4] * bs[2]) * is[1];
-            yp[2] = (Vn[2] * bs[0] + Vn[4] * bs[1] + Vn[5] * bs[2]) * is[2];
-        }
-        double Xc[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) Xc[k] = Xn[k] - yp[k] * spn[k];
-        if (act) {
-            const double M0 = m0 + B0[0] * yp[0] + B0[1] * yp[1] + B0[2] * yp[2], M1 = m1 + B1[0] * yp[0] + B1[1] * yp[1] + B1[2] * yp[2];
-            acc[0] += -(M0 * r0 + M1 * r1) + 0.5 * (M0 * M0 + M1 * M1);
-            const double* cc = sCamC + kq * GBS_CAMC;
-            acc[3] += obs_cost(fcand, cc, cc + 3, Xc, on.x, on.y, loss, la);
-        }
-        if (valid && lq == 0) {                                          // the point's candidate and step norms, once per point
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double d = -yp[k] * spn[k];
-                pts_c[3 * pn + k] = Xc[k];
-                if (spn[k] > 0.0) { acc[1] += d * d; acc[2] += Xc[k] * Xc[k]; }
-            }
-        }
-    }
-#undef GBS_LOAD
-    static_assert(SC_STEP2_PT == SC_MODEL + 1 && SC_XN2_PT == SC_MODEL + 2 && SC_CAND_COST == SC_MODEL + 3, "the four sums are consecutive scalars");
-    const double t = wave_transpose_sum(acc);
-    const int slot = wave_tr_index();
-    double* sl = scal + (size_t)((blockIdx.x * (blockDim.x >> 6) + wave) & (SC_NSLOT - 1)) * SC_TOTAL;
-    if (slot < 4) sadd(ds, &sl[SC_MODEL + slot], t);
-}
-
-// ---- round 6: the same pass with the point records staged through LDS and the 8 observation lanes of a point ADJACENT -------------------------------------
-// k_gram_backsub above keeps two copies of a sub-chunk's point records in registers (the one in use and the one in flight: 2 x 17 doubles per lane, every value
+// ---- round 6: the point records staged through LDS and the 8 observation lanes of a point ADJACENT -------------------------------------
+// k_gram_backsub kept two copies of a sub-chunk's point records in registers (the one in use and the one in flight: 2 x 17 doubles per lane, every value
 // requested by the eight lanes of its point -- sixteen load instructions per sub-chunk) and folds B^T a over lanes 8 / 16 / 32 apart with ds_bpermute (three dependent
 // LDS round trips).  Here lane = 8 point + observation: a sub-chunk's observations are ONE coalesced 1 KB load; its 8 point records come in through three loads shared
 // by the wave, wait one iteration in registers, go to a wave-private LDS slice (two buffers, GBS2_PT doubles per point: the eight points' 16-byte reads fall into
@@ -2088,8 +1984,8 @@ __device__ __forceinline__ double fold8_dpp(double v) {                 // sum o
     v += dpp_f64<0x141>(v);                                              // row_half_mirror: lane i <- lane 7 - i of the same 8 (the other quad's sum)
     return v;
 }
-template <int DC, int WPE = 4>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <int DC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs; 3 waves per SIMD: 213 us, 5 (96 VGPRs, spills): 474 against 195
 k_gram_backsub2(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
                 const double2* __restrict__ obs_xy, int ntasks, const int* __restrict__ gr_rec, const double* __restrict__ scale_cam,
                 const double* __restrict__ scale_f, const double* __restrict__ PS,

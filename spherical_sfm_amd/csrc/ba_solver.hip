@@ -347,24 +347,13 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                     if (grouped) {
                         const int ng = (int)(F.gr_rec.size() / GRAM_REC);
                         const bool res_here = res && all_grouped;
-                        // round 6: k_gram_backsub2 (point records through LDS, DPP folds); SSFM_GBS_V=1: the kernel of rounds 3-5
-                        static const int gbs_v = knob_env_int("SSFM_GBS_V", 2);
                         // waves per task: a small problem (config 2: 900 tasks on 1024 SIMDs) runs with several waves per SIMD, each with a share of its task's sub-chunks
                         // (config 2, hipEvent: 1 wave per task 26.3 us, 2: 24, 4: 21.1, 6 / 8: 24; k_point_backsub 23.0)
                         static const int gbs_split_env = knob_env_int("SSFM_GBS_SPLIT", 0);
                         const int gbs_split = gbs_split_env > 0 ? std::min(8, gbs_split_env) : std::max(1, std::min(4, (4 * 4 * ctx->num_cus / 2) / std::max(1, ng)));
-#define GBS2_LAUNCH(WPE_) LAUNCH(h, KID_GRAM_BACKSUB, (k_gram_backsub2<DC, WPE_>), (ng * gbs_split + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p, \
-                               h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p, \
-                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc, gbs_split)
-                        static const int gbs_wpe = knob_env_int("SSFM_GBS_WPE", 4);
-                        if (gbs_v == 2 && gbs_wpe == 3) GBS2_LAUNCH(3);
-                        else if (gbs_v == 2 && gbs_wpe == 5) GBS2_LAUNCH(5);
-                        else if (gbs_v == 2) GBS2_LAUNCH(4);
-#undef GBS2_LAUNCH
-                        else
-                        LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub<DC>, (ng + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
-                               h->scale_cam.p, h->scale_pt.p, h->scale_f.p, h->Vs.p, h->gp.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
-                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc);
+                        LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub2<DC>, (ng * gbs_split + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
+                               h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
+                               h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc, gbs_split);
                     }
                     // EXPERIMENT, off (SSFM_BACKSUB_LPP=2): two lanes per point -- half the dependent camera gathers per lane, twice the waves.  Measured at config 2
                     // (scripts/lab/ab_lpp.sh, hipEvent averages): 25.1-25.3 us against 23.0-23.5 with one lane per point; 2.557 against 2.538-2.552 ms per solve
