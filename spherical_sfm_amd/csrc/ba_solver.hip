@@ -349,7 +349,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                         const bool res_here = res && all_grouped;
                         // waves per task: a small problem (config 2: 900 tasks on 1024 SIMDs) runs with several waves per SIMD, each with a share of its task's sub-chunks
                         // (config 2, hipEvent: 1 wave per task 26.3 us, 2: 24, 4: 21.1, 6 / 8: 24; k_point_backsub 23.0)
-                        static const int gbs_split_env = knob_env_int("SSFM_GBS_SPLIT", 0);
+                        const int gbs_split_env = std::getenv("SSFM_GBS_SPLIT") ? std::atoi(std::getenv("SSFM_GBS_SPLIT")) : 0;      // (read per launch: tests switch it)
                         const int gbs_split = gbs_split_env > 0 ? std::min(8, gbs_split_env) : std::max(1, std::min(4, (4 * 4 * ctx->num_cus / 2) / std::max(1, ng)));
                         LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub2<DC>, (ng * gbs_split + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
                                h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,

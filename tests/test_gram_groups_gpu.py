@@ -129,6 +129,22 @@ def test_task_length_does_not_change_the_answer(gpu_ctx, monkeypatch, pts_per_ta
     assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and rel_err(pts, p1) <= 1e-8 and abs(f - f1) <= 1e-10 * f
 
 
+@pytest.mark.parametrize("split", [1, 2, 3, 5, 8])
+def test_waves_per_task_of_the_grouped_back_substitution(gpu_ctx, monkeypatch, split):
+    """k_gram_backsub2 with several waves per task (SSFM_GBS_SPLIT): shares that end inside a sub-chunk, empty shares (more waves than sub-chunks), every share count
+    against the lane-per-point kernel."""
+    from spherical_sfm_amd import ba
+    monkeypatch.setenv("SSFM_NO_PLAN_CACHE", "1")
+    p = mixed_problem(17, 7, False, False, per_cam=45)
+    monkeypatch.setenv("SSFM_GRAM_BACKSUB", "0")
+    cams, pts, f, s = ba.optimize(gpu_ctx, p)
+    monkeypatch.setenv("SSFM_GRAM_BACKSUB", "1")
+    monkeypatch.setenv("SSFM_GRAM_PTS", "40")                           # five sub-chunks per task
+    monkeypatch.setenv("SSFM_GBS_SPLIT", str(split))
+    c1, p1, f1, s1 = ba.optimize(gpu_ctx, p)
+    assert s1["iterations"] == s["iterations"] and rel_err(cams, c1) <= 1e-8 and rel_err(pts, p1) <= 1e-8 and abs(f - f1) <= 1e-10 * f
+
+
 def multi_k_problem(seed, spherical, focal_fixed, block=48):
     """An 8-observation circle whose points keep only their first k cameras, k drawn per block of `block` consecutive points from 3..8: runs of every length class
     (one, two and three 16-row tiles) in ONE problem, plus blocks shorter than a run (16 points: pair lists)."""
