@@ -18,7 +18,9 @@ other scripts (scripts/): gpu_final.sh + collect_final.py + pmc_summary.py (the 
 gpurun call while the pod's slots are busy), bench_pairwise.py (configs[3] pairwise RANSAC), prof_gram_*.py / prof_irregular.py / prof_retri.py / prof_rot.py (single-workload
 profiling drivers named in DESIGN.md and the profiles/ notes), soak_*.py (randomised soaks: band solver vs numpy, repeated BA solves, Gram fuzz, Retriangulate trace),
 build_gram_ld_variants.sh (library variants for SSFM_LIB_PATH), r06/ab.sh (same-run A/B of environment settings at config 2), r06/snode_stamps.py (phase stamps of k_snode_solve),
-r06/reflow_md.py (Markdown reflow to 160 columns), lab/ (kernel labs and A/B scripts of rounds 2-5: chol_lab, ldl16_lab, syrk_lab, point_lab, ab_*.sh)
+r06/reflow_md.py (Markdown reflow to 160 columns), r06/ab_mode.sh + ragged_ab.sh + gbs_ab.sh (the same for bench.py flags / the ragged problems / the configs[4] size),
+r06/build.sh (library + lab build from anywhere), r06/k8_probe.py (the Gram kernels on 109k points x 8), kernel_resources.py (registers / scratch / spills of every kernel in the
+built library, from the code objects' metadata: no GPU; tests/test_kernel_resources_cpu.py), lab/ (kernel labs and A/B scripts of rounds 2-5: chol_lab, ldl16_lab, syrk_lab, point_lab, ab_*.sh)
 """
 import os
 import runpy
