@@ -350,7 +350,8 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
                         // waves per task: a small problem (config 2: 900 tasks on 1024 SIMDs) runs with several waves per SIMD, each with a share of its task's sub-chunks
                         // (config 2, hipEvent: 1 wave per task 26.3 us, 2: 24, 4: 21.1, 6 / 8: 24; k_point_backsub 23.0)
                         const int gbs_split_env = std::getenv("SSFM_GBS_SPLIT") ? std::atoi(std::getenv("SSFM_GBS_SPLIT")) : 0;      // (read per launch: tests switch it)
-                        const int gbs_split = gbs_split_env > 0 ? std::min(8, gbs_split_env) : std::max(1, std::min(4, (4 * 4 * ctx->num_cus / 2) / std::max(1, ng)));
+                        const int gbs_wave_target = 14 * ctx->num_cus;      // ~3.5 waves per SIMD in flight (config 2: 900 tasks x 4; 1200 tasks x 1 took 31 us, x 3: see profiles/r06_notes.md r06i)
+                        const int gbs_split = gbs_split_env > 0 ? std::min(8, gbs_split_env) : std::max(1, std::min(4, (gbs_wave_target + ng - 1) / std::max(1, ng)));
                         LAUNCH(h, KID_GRAM_BACKSUB, k_gram_backsub2<DC>, (ng * gbs_split + GBS_WAVES - 1) / GBS_WAVES + (res_here ? 1 : 0), 64 * GBS_WAVES, GBS_WAVES * GBS2_TAIL * sizeof(double), cam_x, rot_x, pts_x, fx, oxy, ng, h->gr_rec.p,
                                h->scale_cam.p, h->scale_f.p, h->Vs.p, h->px.p, Nc, loss, la, cam_c, rot_c, fc, pts_c, h->scal.p,
                                h->rhs, h->pq.p, h->Sfc, h->Sff.p, O.pcg_tolerance * O.pcg_tolerance, res_here ? h->pr.p : (double*)nullptr, h->pcg.p, lacc, gbs_split);
