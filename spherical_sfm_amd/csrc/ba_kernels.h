@@ -286,13 +286,12 @@ static __global__ void k_cam_rot0(const double* __restrict__ cam, double* __rest
 // ---- one-time: squared column norms of the unscaled robustified Jacobian (Jacobi scaling, iteration 0)
 // (each kernel also writes the Jacobi scale of the columns it owns: mask * 1/(1 + sqrt(norm^2)), problem_impl.cc / trust_region_minimizer.cc of Ceres 2.2)
 // points + focal: one lane per point;  cameras: one workgroup per camera over its observation list (no atomics)
-static __global__ void k_colnorm(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+static __device__ __forceinline__ void colnorm_pt_body(const int bx, double* __restrict__ red, const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
                           const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam,
                           const int* __restrict__ pt_start, int nP, int loss, double la,
                           double* __restrict__ diag_pt, double* __restrict__ diag_f,
-                          const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi, double* __restrict__ df_part = nullptr) {
-    __shared__ double red[8];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+                          const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi, double* __restrict__ df_part) {
+    const int p = bx * blockDim.x + threadIdx.x;
     double df[1] = {0.0};
     if (p < nP) {
         const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
@@ -307,15 +306,13 @@ static __global__ void k_colnorm(const double* __restrict__ cam, const double* _
         for (int k = 0; k < 3; k++) { diag_pt[3 * p + k] = dp[k]; scale_pt[3 * p + k] = mask_pt[3 * p + k] * (jacobi ? 1.0 / (1.0 + sqrt(dp[k])) : 1.0); }
     }
     block_sum<1>(df, red);
-    if (threadIdx.x == 0) { if (df_part) df_part[blockIdx.x] = df[0]; else unsafeAtomicAdd(diag_f, df[0]); }     // df_part (deterministic mode): k_startup_tail adds the parts in order
+    if (threadIdx.x == 0) { if (df_part) df_part[bx] = df[0]; else unsafeAtomicAdd(diag_f, df[0]); }     // df_part (deterministic mode): k_startup_tail adds the parts in order
 }
-static __global__ void __launch_bounds__(256)
-k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+static __device__ __forceinline__ void colnorm_cam_body(const int bx, double* __restrict__ red, const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
               const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
               const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam,
               const double* __restrict__ mask_cam, double* __restrict__ scale_cam, int jacobi) {   // scale_cam == nullptr: the norms still need a sum over ranks
-    __shared__ double red[6 * 4];
-    const int c = blockIdx.x;
+    const int c = bx;
     double d[6] = {0, 0, 0, 0, 0, 0};
     const double f = focal[0];
     for (int q = cam_start[c] + threadIdx.x; q < cam_start[c + 1]; q += blockDim.x) {
@@ -330,6 +327,26 @@ k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, co
         diag_cam[c * 6 + k] = d[k];
         if (scale_cam) scale_cam[c * 6 + k] = mask_cam[c * 6 + k] * (jacobi ? 1.0 / (1.0 + sqrt(d[k])) : 1.0);
     }
+}
+static __global__ void __launch_bounds__(256)
+k_colnorm_cam(const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts,
+              const double* __restrict__ focal, const double2* __restrict__ obs_xy, const int* __restrict__ obs_pt,
+              const int* __restrict__ cam_start, const int* __restrict__ cam_obs, int loss, double la, double* __restrict__ diag_cam,
+              const double* __restrict__ mask_cam, double* __restrict__ scale_cam, int jacobi) {
+    __shared__ double red[6 * 4];
+    colnorm_cam_body((int)blockIdx.x, red, cam, rot, pts, focal, obs_xy, obs_pt, cam_start, cam_obs, loss, la, diag_cam, mask_cam, scale_cam, jacobi);
+}
+// both column-norm passes of a solve's start in ONE launch (round 6): workgroups [0, gp) take the points, the rest one camera each -- the two passes are independent and
+// each was a launch of its own in the dependent stream (12 + 17 us per solve)
+static __global__ void __launch_bounds__(256)
+k_colnorm_both(int gp, const double* __restrict__ cam, const double* __restrict__ rot, const double* __restrict__ pts, const double* __restrict__ focal,
+               const double2* __restrict__ obs_xy, const int* __restrict__ obs_cam, const int* __restrict__ pt_start, int nP, int loss, double la,
+               double* __restrict__ diag_pt, double* __restrict__ diag_f, const double* __restrict__ mask_pt, double* __restrict__ scale_pt, int jacobi, double* __restrict__ df_part,
+               const int* __restrict__ obs_pt, const int* __restrict__ cam_start, const int* __restrict__ cam_obs, double* __restrict__ diag_cam,
+               const double* __restrict__ mask_cam, double* __restrict__ scale_cam) {
+    __shared__ double red[6 * 4];
+    if ((int)blockIdx.x < gp) colnorm_pt_body((int)blockIdx.x, red, cam, rot, pts, focal, obs_xy, obs_cam, pt_start, nP, loss, la, diag_pt, diag_f, mask_pt, scale_pt, jacobi, df_part);
+    else colnorm_cam_body((int)blockIdx.x - gp, red, cam, rot, pts, focal, obs_xy, obs_pt, cam_start, cam_obs, loss, la, diag_cam, mask_cam, scale_cam, jacobi);
 }
 static __global__ void k_make_scale(const double* __restrict__ diag, const double* __restrict__ mask, double* __restrict__ scale, int n, int jacobi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

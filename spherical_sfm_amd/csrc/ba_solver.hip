@@ -72,9 +72,10 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     const bool make_scale = !h->scale_ready;
     LAUNCH(h, KID_CAM_ROT, k_cam_rot0, gp_cam, 64, 0, cam_x, rot_x, Nc, h->scal.p, (int)SC_TOTAL, h->diag_f.p, make_scale ? 1 : 0);
     if (make_scale) {
-        if (nP > 0) hipLaunchKernelGGL(k_colnorm, dim3(gp_pts), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP,
-                                       loss, la, h->diag_pt.p, h->diag_f.p, h->mask_pt.p, h->scale_pt.p, O.jacobi_scaling, h->det ? h->det_dfpart.p : (double*)nullptr);
-        hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
+        if (nP > 0) hipLaunchKernelGGL(k_colnorm_both, dim3(gp_pts + Nc), dim3(256), 0, st, gp_pts, cam_x, rot_x, pts_x, fx, oxy, h->obs_cam.p, h->pt_start.p, nP,
+                                       loss, la, h->diag_pt.p, h->diag_f.p, h->mask_pt.p, h->scale_pt.p, O.jacobi_scaling, h->det ? h->det_dfpart.p : (double*)nullptr,
+                                       h->obs_pt.p, h->cam_start.p, h->cam_obs.p, h->diag_cam.p, h->mask_cam.p, ctx->collective ? (double*)nullptr : h->scale_cam.p);
+        else hipLaunchKernelGGL(k_colnorm_cam, dim3(Nc), dim3(256), 0, st, cam_x, rot_x, pts_x, fx, oxy, h->obs_pt.p, h->cam_start.p, h->cam_obs.p,
                            loss, la, h->diag_cam.p, h->mask_cam.p, ctx->collective ? (double*)nullptr : h->scale_cam.p, O.jacobi_scaling);
         if (ctx->collective) {   // camera / focal column norms are sums over every rank's observations
             int rc = allreduce(h, h->diag_cam.p, (size_t)Nc * 6, ncclSum); if (rc) return rc;
