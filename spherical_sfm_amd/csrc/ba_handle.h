@@ -122,6 +122,7 @@ struct ssfm_ba_handle {
     std::vector<Span> spans;
     int64_t k_launches[KID_COUNT]; double k_ms[KID_COUNT];
     hipEvent_t phase_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t x0_ev = nullptr;          // behind the copy of |x_0|^2 at a solve's start: the host reads it when the first tail is enqueued, not before the first kernels
 
     hipEvent_t get_event() {
         if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
@@ -153,6 +154,7 @@ struct ssfm_ba_handle {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         for (auto& e : phase_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (x0_ev) { (void)hipEventDestroy(x0_ev); x0_ev = nullptr; }
     }
 };
 

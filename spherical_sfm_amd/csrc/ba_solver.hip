@@ -94,8 +94,17 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
     }
     { int rc = allreduce(h, h->scal.p + SC_X0N2_PT, 1, ncclSum); if (rc) return rc; }
     SSFM_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, h->scal.p, SC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, st));
-    SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    double x_norm = std::sqrt(host_scal[SC_X0N2_PT] + host_scal[SC_X0N2_CAM]);
+    // |x_0| is first needed when iteration 0's tail is enqueued (the device-side gate takes it as an argument): the host waits for the copy THERE, behind the kernels of
+    // iteration 0's assembly and solve -- a stream synchronisation here left the GPU idle for the host's wake-up and first launches (~20 us per solve)
+    if (!h->x0_ev) SSFM_HIP_CHECK(ctx, hipEventCreateWithFlags(&h->x0_ev, hipEventDisableTiming));
+    SSFM_HIP_CHECK(ctx, hipEventRecord(h->x0_ev, st));
+    double x_norm = 0.0; bool x0_pending = true;
+    auto need_x0 = [&]() -> int {
+        if (!x0_pending) return SSFM_OK;
+        SSFM_HIP_CHECK(ctx, hipEventSynchronize(h->x0_ev));
+        x_norm = std::sqrt(host_scal[SC_X0N2_PT] + host_scal[SC_X0N2_CAM]); x0_pending = false;
+        return SSFM_OK;
+    };
 
     SSFM_HIP_CHECK(ctx, hipMemsetAsync(h->zone.p + h->zone_len, 0, h->zone_len * sizeof(double), st));   // zone of iteration 1
     double radius = O.initial_trust_region_radius, decrease_factor = 2.0;
@@ -311,6 +320,7 @@ static int lm_loop(ssfm_ba_handle* h, ssfm_ba_summary* S) {
         { int rc = solve_reduced<DC>(h, host_pcg1, &pcg_iters, &pcg_ok, 0); h->tail.on = false; h->tail.residual_later = false; if (rc) return rc; }
         if (phases) SSFM_HIP_CHECK(ctx, hipEventRecord(h->phase_ev[3], st));
         auto enqueue_tail = [&](bool with_cams) -> int {
+            { const int rc0 = need_x0(); if (rc0) return rc0; }
             // candidate cameras + their rotation tables; then per point: back-substitution, candidate, model cost change, candidate cost
             if (with_cams) {
                 LAUNCH(h, KID_CAM_UPDATE, k_cam_update<DC>, 1, 1024, 0, cam_x, fx, h->scale_cam.p, h->scale_f.p, h->px.p, Nc, cam_c, fc, rot_c, h->scal.p, Nc <= 1024 ? 1 : 0);
