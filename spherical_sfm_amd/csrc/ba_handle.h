@@ -189,6 +189,34 @@ static hipError_t upload(DevBuf<T>& b, const std::vector<T, A>& v, hipStream_t s
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
+// Small host arrays through the context's pinned staging buffer (round 6): a pageable hipMemcpyAsync stages and waits inside the call -- the ~25 arrays of a pose-graph
+// solve's set-up were 25 copies of 2-5 us with the host's 4-20 us between them (rocprofv3 trace: 210 us); from pinned memory the calls return at once and the copies
+// run back to back.  reserve() before the first up(): the buffer is grow-only and must not move while copies are in flight; an array that does not fit takes upload().
+struct StagedUploads {
+    ssfm_ctx* ctx; hipStream_t st; size_t off = 0;
+    StagedUploads(ssfm_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+    hipError_t reserve(size_t bytes) {
+        const size_t want = (bytes + 7) / 8 + 64;
+        if (ctx->dl_stage_n >= want) return hipSuccess;
+        if (ctx->dl_stage) (void)hipHostFree(ctx->dl_stage);
+        ctx->dl_stage = nullptr; ctx->dl_stage_n = 0;
+        const size_t n = want + want / 2;
+        hipError_t e = hipHostMalloc((void**)&ctx->dl_stage, n * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) ctx->dl_stage_n = n; else { ctx->dl_stage = nullptr; (void)hipGetLastError(); }
+        return hipSuccess;                                             // (no pinned memory: every up() falls back to upload())
+    }
+    template <typename T, typename A>
+    hipError_t up(DevBuf<T>& b, const std::vector<T, A>& v) {
+        const size_t bytes = v.size() * sizeof(T), need = (bytes + 63) / 64 * 64;
+        if (!ctx->dl_stage || off + need > ctx->dl_stage_n * sizeof(double)) return upload(b, v, st);
+        hipError_t e = b.alloc(v.size()); if (e != hipSuccess) return e;
+        if (v.empty()) return hipSuccess;
+        char* dst = reinterpret_cast<char*>(ctx->dl_stage) + off; off += need;
+        std::memcpy(dst, v.data(), bytes);
+        return hipMemcpyAsync(b.p, dst, bytes, hipMemcpyHostToDevice, st);
+    }
+};
+
 static int allreduce(ssfm_ba_handle* h, double* buf, size_t n, ncclRedOp_t op) {
     if (!h->ctx->collective) return SSFM_OK;
     // TIMING EXPERIMENT ONLY (bench.py --gpus N, `timing_without_collective`; switched on by ssfm_debug_timing_skip_collectives, which warns on stderr -- no

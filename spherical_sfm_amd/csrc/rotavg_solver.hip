@@ -620,7 +620,9 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     DevBuf<int>&e0 = RS.e0, &e1 = RS.e1; DevBuf<EdgeConst>& ec = RS.ec;
     const double fm0 = with_f ? std::fmin(std::fmax(1.0, f_lo), f_hi) : 1.0;      // IterationZero projects the start point of a bounded problem
     std::vector<double> fmv = {fm0, fm0};
-#define UPV(buf, vec) SSFM_HIP_CHECK(ctx, upload(buf, vec, st))
+    StagedUploads su(ctx, st);
+    SSFM_HIP_CHECK(ctx, su.reserve((size_t)n * 160 + (size_t)E * (sizeof(EdgeConst) + 64) + nnzb * 16 + (size_t)F.band_pairs.size() * 4 + 65536));
+#define UPV(buf, vec) SSFM_HIP_CHECK(ctx, su.up(buf, vec))
     UPV(x, G.x0); UPV(fm2, fmv); UPV(e0, G.e0); UPV(e1, G.e1); UPV(ec, G.ec);
     UPV(h->row_ptr, F.row_ptr); UPV(h->col_idx, F.col_idx); UPV(h->diag_slot, F.diag_slot); UPV(h->cam_pos, F.band_row); UPV(h->cam_pos2, F.band_row2); UPV(h->pair_dummy, F.pair_dummy);   // the device only needs band rows
     UPV(h->band_pairs, F.band_pairs); UPV(h->comp_ptr, F.comp_ptr);
@@ -670,8 +672,8 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         }
         if (nedge.empty()) { nedge.push_back(0); nslot.push_back(0); nside.push_back(0); nfirst.push_back(0); }
         std::vector<int> zero2(2, 0);
-        SSFM_HIP_CHECK(ctx, upload(RS.nadj_ptr, nptr, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_edge, nedge, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_slot, nslot, st));
-        SSFM_HIP_CHECK(ctx, upload(RS.nadj_side, nside, st)); SSFM_HIP_CHECK(ctx, upload(RS.nadj_first, nfirst, st)); SSFM_HIP_CHECK(ctx, upload(RS.ticket, zero2, st));
+        SSFM_HIP_CHECK(ctx, su.up(RS.nadj_ptr, nptr)); SSFM_HIP_CHECK(ctx, su.up(RS.nadj_edge, nedge)); SSFM_HIP_CHECK(ctx, su.up(RS.nadj_slot, nslot));
+        SSFM_HIP_CHECK(ctx, su.up(RS.nadj_side, nside)); SSFM_HIP_CHECK(ctx, su.up(RS.nadj_first, nfirst)); SSFM_HIP_CHECK(ctx, su.up(RS.ticket, zero2));
         ALV(RS.ejac, (size_t)24 * E); ALV(RS.node_part, (size_t)3 * ((E + 63) / 64)); ALV(RS.wg_part, (size_t)5 * ((E + 63) / 64 + gnode)); ALV(RS.step_part, (size_t)5 * 32);
     }
 #undef ALV
@@ -695,7 +697,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
     // ---- Jacobi scaling from the initial Jacobian: s = mask / (1 + |J_col|)
     {
         DevBuf<double>&m3 = RS.m3, &mf = RS.mf; std::vector<double> mfv = {with_f ? 1.0 : 0.0};
-        SSFM_HIP_CHECK(ctx, upload(m3, G.mask, st)); SSFM_HIP_CHECK(ctx, upload(mf, mfv, st));
+        SSFM_HIP_CHECK(ctx, su.up(m3, G.mask)); SSFM_HIP_CHECK(ctx, su.up(mf, mfv));
         int rc = assemble(m3.p, mf.p); if (rc) return rc;
         hipLaunchKernelGGL(k_make_scale, dim3((3 * n + 255) / 256), dim3(256), 0, st, h->Udiag, m3.p, sc3.p, 3 * n, O.jacobi_scaling);
         hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->scal.p + SC_FJJ, mf.p, scf.p, 1, O.jacobi_scaling);
