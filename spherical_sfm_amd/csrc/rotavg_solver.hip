@@ -702,7 +702,7 @@ static int rot_solve(ssfm_ctx* ctx, int kind, int32_t n, double* rotations, int3
         hipLaunchKernelGGL(k_make_scale, dim3((3 * n + 255) / 256), dim3(256), 0, st, h->Udiag, m3.p, sc3.p, 3 * n, O.jacobi_scaling);
         hipLaunchKernelGGL(k_make_scale, dim3(1), dim3(64), 0, st, h->scal.p + SC_FJJ, mf.p, scf.p, 1, O.jacobi_scaling);
         hipLaunchKernelGGL(k_scale3to6, dim3((6 * n + 255) / 256), dim3(256), 0, st, sc3.p, n, sc6.p);
-        SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (timing) SSFM_HIP_CHECK(ctx, hipStreamSynchronize(st));       // (only for the lap below: nothing of the set-up is read on the host, and the first iteration's launches follow at once)
     }
     lap("allocations, uploads, Jacobi scaling");
     double x_norm = 0; { double s2 = with_f ? fm0 * fm0 : 0.0; for (size_t i = 0; i < nn; i++) if (G.mask[i] > 0) s2 += G.x0[i] * G.x0[i]; x_norm = std::sqrt(s2); }
