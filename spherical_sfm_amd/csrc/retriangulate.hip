@@ -970,9 +970,15 @@ static int retriangulate_trace(ssfm_ctx* ctx, ssfm_ba_problem* p, int32_t* num_i
         }
         if (req.empty()) req.push_back(0);
         // points of equal track length run the same sampler sequence: adjacent lanes get points of the same length (stable, so neighbours stay neighbours)
+        // (a stable counting sort by track length: std::stable_sort took 2-3 ms of a 17 ms call at 100 000 points)
         std::vector<int> order(std::max(Np, 1), 0);
-        for (int j = 0; j < Np; j++) order[j] = j;
-        std::stable_sort(order.begin(), order.begin() + Np, [&](int a, int b) { return (pt_start[a + 1] - pt_start[a]) < (pt_start[b + 1] - pt_start[b]); });
+        {
+            int nmax = 0; for (int j = 0; j < Np; j++) nmax = std::max(nmax, pt_start[j + 1] - pt_start[j]);
+            std::vector<int> first((size_t)nmax + 2, 0);
+            for (int j = 0; j < Np; j++) first[(size_t)(pt_start[j + 1] - pt_start[j]) + 1]++;
+            for (int k = 0; k <= nmax; k++) first[k + 1] += first[k];
+            for (int j = 0; j < Np; j++) order[first[pt_start[j + 1] - pt_start[j]]++] = j;
+        }
         SSFM_HIP_CHECK(ctx, upload(D.dslot, pt_slot, st)); SSFM_HIP_CHECK(ctx, upload(D.dsamples, samples, st)); SSFM_HIP_CHECK(ctx, upload(D.dreqptr, req_ptr, st));
         SSFM_HIP_CHECK(ctx, upload(D.dreq, req, st)); SSFM_HIP_CHECK(ctx, upload(D.dorder, order, st));
         SSFM_HIP_CHECK(ctx, D.dlists.alloc((size_t)3 * std::max(total, 1))); SSFM_HIP_CHECK(ctx, D.dpts.alloc((size_t)std::max(Np, 1) * 3)); SSFM_HIP_CHECK(ctx, D.dnin.alloc(std::max(Np, 1)));
